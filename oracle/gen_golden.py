@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE itself (read-only import
+from /root/reference) in the build container.  Test infrastructure; never runs
+on the GPU box (the reference does not travel) -- only the vectors do.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/
+
+The reference has no tests / golden vectors of its own; these
+captured outputs are what pins the oracle (tests/test_oracle_golden.py) and, through
+the oracle and directly, the HIP path (tests/test_*_gpu.py).
+
+Stub modules: torch_scatter (FastMDCT4 only), torchvision.models (dead Vgg19),
+torchaudio.functional (dB branches only) are absent from this image and unused on
+the hot path; empty stand-ins let `models.*` import.  `bottleneck_transformer_pytorch`
+is absent too: the G7 fixture (keys/shapes only, parity unpinned) uses the oracle's
+restatement as the stand-in.
+"""
+import argparse
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+
+def import_reference():
+    for name in ["torch_scatter", "torchvision", "torchvision.models", "torchaudio", "torchaudio.functional"]:
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["torch_scatter"].scatter = None
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    sys.modules["torchaudio"].functional = sys.modules["torchaudio.functional"]
+    from oracle import nets as onets
+    bot = types.ModuleType("bottleneck_transformer_pytorch")
+
+    def BottleStack(*, dim, fmap_size, dim_out, num_layers, proj_factor, downsample, heads, dim_head, activation,
+                    rel_pos_emb):
+        assert not downsample and not rel_pos_emb
+        return onets.BotStackRef(dim, fmap_size, dim_out, num_layers, proj_factor, heads, dim_head)
+    bot.BottleStack = BottleStack
+    sys.modules["bottleneck_transformer_pytorch"] = bot
+    sys.path.insert(0, REF)
+    import models.mdct as rmdct
+    import models.networks as rnet
+    import models.pix2pixHD_model as rmodel
+    import util.util as rutil
+    return rmdct, rnet, rmodel, rutil
+
+
+def ref_options(extra):
+    """TrainOptions().parse() of the reference, in a scratch cwd (it writes opt.txt)."""
+    from options.train_options import TrainOptions
+    argv = sys.argv
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    try:
+        os.chdir(tmp)
+        sys.argv = ["train.py", "--gpu_ids", "-1", "--name", "golden"] + extra
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            opt = TrainOptions().parse()
+    finally:
+        sys.argv = argv
+        os.chdir(cwd)
+    return opt
+
+
+SPECTRAL = ["--arcsinh_transform", "--abs_spectro", "--arcsinh_gain", "1000", "--norm_range", "-1", "1",
+            "--src_range", "-5", "5", "--lr_sampling_rate", "12000"]
+
+
+def quiet(fn, *a, **k):
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=OUT)
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    rmdct, rnet, rmodel, rutil = import_reference()
+    from oracle import nets as onets
+    g = torch.Generator().manual_seed(1234)
+
+    def save(name, **arrs):
+        np.savez_compressed(os.path.join(args.out, name + ".npz"), **arrs)
+        print("wrote", name, {k: (v.shape, str(v.dtype)) for k, v in arrs.items() if hasattr(v, "shape")})
+
+    # ---- G1 window ----------------------------------------------------
+    save("g1_kbdwin", w512=rutil.kbdwin(512).numpy(), w1024=rutil.kbdwin(1024).numpy())
+
+    # ---- G2/G3 transform ----------------------------------------------
+    win = rutil.kbdwin(512)
+    mdct = rmdct.MDCT4(n_fft=512, hop_length=256, win_length=512, window=win, device="cpu")
+    imdct = rmdct.IMDCT4(n_fft=512, hop_length=256, win_length=512, window=win, device="cpu")
+    x = torch.randn(2, 7936, generator=g)
+    x[1] *= 0.05
+    X, frames = mdct(x, True)
+    y, yframes = imdct(X.clone(), True)
+    Xr = torch.randn(2, 32, 256, generator=g, dtype=torch.float64)
+    yr, _ = imdct(Xr.clone())
+    save("g2_mdct4", x=x.numpy(), X=X.numpy(), frames=frames.numpy())
+    save("g3_imdct4", X=X.numpy(), y=y.numpy(), yframes=yframes.numpy(), Xr=Xr.numpy(), yr=yr.numpy())
+
+    # ---- G4 codec -----------------------------------------------------
+    xa = 0.05 * torch.randn(2, 7936, generator=g)
+    for tag, extra in (("abs", ["--abs_norm"]), ("minmax", [])):
+        opt = ref_options(SPECTRAL + extra)
+        pre = rmodel.Audio2MDCT(opt)
+        torch.manual_seed(0)
+        s, pha, norm = pre.to_spectro(xa)
+        audio = pre.to_audio(s, norm, pha)
+        save("g4_codec_" + tag, x=xa.numpy(), log_spectro=s.numpy(), max=norm["max"].numpy(),
+             min=norm["min"].numpy(), mean=norm["mean"].numpy(), std=norm["std"].numpy(), audio=audio.numpy())
+
+    # ---- G5 generators ------------------------------------------------
+    gin = torch.rand(1, 2, 32, 256, generator=g) * 2 - 1
+    variants = {
+        "global": dict(netG="global", ngf=8, n_downsample_global=4, n_blocks_global=2, n_blocks_local=1),
+        "local": dict(netG="local", ngf=4, n_downsample_global=3, n_blocks_global=2, n_blocks_local=1),
+        "global_resconv_interp": dict(netG="global", ngf=4, n_downsample_global=3, n_blocks_global=1,
+                                      n_blocks_local=1, upsample_type="interpolate", downsample_type="resconv"),
+    }
+    for tag, v in variants.items():
+        net = quiet(rnet.define_G, 2, 1, v["ngf"], v["netG"], v["n_downsample_global"], v["n_blocks_global"], 1,
+                    v["n_blocks_local"], "instance", gpu_ids=[], upsample_type=v.get("upsample_type", "transconv"),
+                    downsample_type=v.get("downsample_type", "conv"), input_size=(32, 256), n_attn_g=0)
+        onets.fill_deterministic(net)
+        with torch.no_grad():
+            out = net(gin)
+        save("g5_netG_" + tag, x=gin.numpy(), y=out.numpy(),
+             keys=np.array(list(net.state_dict().keys())),
+             shapes=np.array([str(tuple(p.shape)) for p in net.state_dict().values()]))
+
+    # ---- G6 discriminator + losses + one optimisation step ---------------
+    rnet.GlobalGenerator.set_freeze = lambda self, *a, **k: None  # reference bug, harness patch
+    opt = ref_options(SPECTRAL + ["--abs_norm", "--netG", "global", "--ngf", "4", "--n_blocks_global", "2",
+                                  "--n_blocks_attn_g", "0", "--num_D", "2", "--ndf", "8", "--batchSize", "2",
+                                  "--bins", "32", "--segment_length", "7936"])
+    model = quiet(lambda: rmodel.Pix2PixHDModel())
+    quiet(model.initialize, opt)
+    onets.fill_deterministic(model.netG)
+    onets.fill_deterministic(model.netD)
+    hr = 0.05 * torch.randn(2, 7936, generator=g)
+    spec = torch.fft.rfft(hr)
+    spec[:, spec.shape[-1] // 4:] = 0           # ideal low-pass to 6 kHz (12k -> 48k)
+    lr = torch.fft.irfft(spec, n=hr.shape[-1])
+    torch.manual_seed(0)
+    losses, sr = model._forward(lr, hr, infer=True)
+    ld = dict(zip(model.loss_names, [torch.mean(v) for v in losses]))
+    loss_D = (ld["D_fake"] + ld["D_real"]) * 0.5            # train.py:175-178
+    loss_G = ld["G_GAN"] + ld["G_GAN_Feat"]
+    model.optimizer_G.zero_grad(); loss_G.backward()
+    gG = {k: p.grad.clone() for k, p in model.netG.named_parameters()}
+    gD_from_G = {k: p.grad.clone() for k, p in model.netD.named_parameters()}
+    model.optimizer_G.step()
+    model.optimizer_D.zero_grad(); loss_D.backward()
+    gD = {k: p.grad.clone() for k, p in model.netD.named_parameters()}
+    model.optimizer_D.step()
+    torch.manual_seed(0)
+    losses2, _ = model._forward(lr, hr, infer=False)
+    ld2 = dict(zip(model.loss_names, [float(torch.mean(v)) for v in losses2]))
+    arrs = dict(lr=lr.numpy(), hr=hr.numpy(), sr_spectro=sr.detach().numpy(),
+                loss_names=np.array(model.loss_names),
+                losses=np.array([float(ld[k]) for k in model.loss_names]),
+                losses_after=np.array([ld2[k] for k in model.loss_names]))
+    for k, v in gG.items():
+        arrs["gG/" + k] = v.numpy()
+    for k, v in gD.items():
+        arrs["gD/" + k] = v.numpy()
+    for k, v in model.netG.state_dict().items():
+        arrs["pG_after/" + k] = v.numpy()
+    for k, v in model.netD.state_dict().items():
+        arrs["pD_after/" + k] = v.numpy()
+    arrs["keysD"] = np.array(list(model.netD.state_dict().keys()))
+    # inference through the facade (pix2pixHD_model.py:618-638), after the step
+    torch.manual_seed(0)
+    sr_s, sr_audio, _, _, lr_s = model.inference(lr)
+    arrs["inf_sr_spectro"] = sr_s.numpy()
+    arrs["inf_sr_audio"] = sr_audio.numpy()
+    arrs["inf_lr_spectro"] = lr_s.numpy()
+    save("g6_step_global", **arrs)
+
+    # D features alone (deterministic weights, fresh net)
+    netD = quiet(rnet.define_D, 3, 8, 3, "instance", False, 2, True, gpu_ids=[])
+    onets.fill_deterministic(netD)
+    din = torch.rand(2, 3, 32, 256, generator=g) * 2 - 1
+    with torch.no_grad():
+        feats = netD(din)
+    arrs = {"x": din.numpy()}
+    for i, sc in enumerate(feats):
+        for j, f in enumerate(sc):
+            arrs["f%d_%d" % (i, j)] = f.numpy()
+    save("g6_netD", **arrs)
+
+    # ---- G7 local + BoT keys/shapes (UNPINNED numerics) ---------------
+    net = quiet(rnet.define_G, 2, 1, 8, "local", 3, 2, 1, 1, "instance", gpu_ids=[], input_size=(64, 256),
+                n_attn_g=2, heads_g=2, dim_head_g=16, proj_factor_g=4)
+    save("g7_local_bot_keys", keys=np.array(list(net.state_dict().keys())),
+         shapes=np.array([str(tuple(p.shape)) for p in net.state_dict().values()]))
+
+    # ---- G8 segment stitching (generate_audio.py:40-53 restated verbatim-in-behaviour) ----
+    seg = torch.randn(3, 1, 1, 7936, generator=g, dtype=torch.float64)
+    from torch.nn.functional import fold
+    ov = 512
+    stride = 7936 - ov
+    out_len = (3 - 1) * stride + 7936
+    a = seg.clone()
+    a[..., :ov] *= 0.5
+    a[..., -ov:] *= 0.5
+    a = a.squeeze().transpose(-1, -2)
+    a = fold(a, kernel_size=(1, 7936), stride=(1, stride), output_size=(1, out_len)).squeeze(0)
+    a = a[..., ov:-ov]
+    save("g8_stitch", seg=seg.numpy(), overlap=np.array(ov), stitched=a.numpy(),
+         concat=seg.reshape(1, -1).numpy())
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,93 @@
+"""Oracle (test infrastructure): the model facade and the G/D optimisation step.
+
+* ``HotPathRef.forward_losses`` <- models/pix2pixHD_model.py:394-451, 616 (forward + _forward)
+* ``HotPathRef.train_step``     <- train.py:160-202 (fp32 branch)
+* ``HotPathRef.inference``      <- models/pix2pixHD_model.py:618-638
+
+Torch CPU, float32 nets (float64 optional) and float64 transform, like the
+reference.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg may import this module.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import nets, transform
+
+
+class CodecCfg:
+    """The spectral flags every BASELINE config carries (train.sh:9-10)."""
+
+    def __init__(self, n_fft=512, hop=256, win=512, arcsinh_gain=1000.0, norm_range=(-1.0, 1.0),
+                 src_range=(-5.0, 5.0), abs_norm=True, hr_rate=48000, lr_rate=12000, fit_residual=False):
+        self.n_fft, self.hop, self.win = n_fft, hop, win
+        self.codec = dict(arcsinh_transform=True, raw_mdct=False, arcsinh_gain=arcsinh_gain, abs_norm=abs_norm,
+                          src_range=src_range, norm_range=norm_range)
+        self.norm_range = norm_range
+        self.up_ratio = hr_rate / lr_rate
+        self.fit_residual = fit_residual
+        self.window = transform.kbd_window(win)
+
+
+class HotPathRef:
+    def __init__(self, netG, netD, cfg: CodecCfg, n_layers_D=3, num_D=2, lambda_feat=10.0, lr=2e-4, beta1=0.5,
+                 dtype=torch.float32):
+        self.netG, self.netD, self.cfg = netG.to(dtype), (netD.to(dtype) if netD is not None else None), cfg
+        self.n_layers_D, self.num_D, self.lambda_feat, self.dtype = n_layers_D, num_D, lambda_feat, dtype
+        if netD is not None:
+            self.opt_G = torch.optim.Adam(self.netG.parameters(), lr=lr, betas=(beta1, 0.999))
+            self.opt_D = torch.optim.Adam(self.netD.parameters(), lr=lr, betas=(beta1, 0.999))
+
+    # -- codec ---------------------------------------------------------
+    def spectro(self, audio):
+        c = self.cfg
+        s, norm = transform.to_spectro(np.asarray(audio), c.window, c.n_fft, c.hop, **c.codec)
+        return torch.from_numpy(s).to(self.dtype), norm
+
+    def two_channel(self, s):
+        return torch.cat((s, s.abs() * 2 + self.cfg.norm_range[0]), dim=1)  # pix2pixHD_model.py:400-402
+
+    # -- forward + losses ----------------------------------------------
+    def forward_losses(self, lr_audio, hr_audio):
+        lr_s, _ = self.spectro(lr_audio)
+        hr_s, _ = self.spectro(hr_audio)
+        sr_s = self.netG(self.two_channel(lr_s))
+        if self.cfg.fit_residual:
+            sr_s = sr_s + lr_s
+        sr_in, hr_in = self.two_channel(sr_s), self.two_channel(hr_s)
+        pred_fake_pool = self.netD(torch.cat((lr_s, sr_in.detach()), dim=1))
+        loss_D_fake = nets.lsgan_loss(pred_fake_pool, False)
+        pred_real = self.netD(torch.cat((lr_s, hr_in), dim=1))
+        loss_D_real = nets.lsgan_loss(pred_real, True)
+        pred_fake = self.netD(torch.cat((lr_s, sr_in), dim=1))
+        loss_G_GAN = nets.lsgan_loss(pred_fake, True)
+        loss_G_feat = nets.feature_matching_loss(pred_fake, pred_real, self.n_layers_D, self.num_D, self.lambda_feat)
+        losses = {"G_GAN": loss_G_GAN, "G_GAN_Feat": loss_G_feat, "D_real": loss_D_real, "D_fake": loss_D_fake}
+        return losses, sr_s
+
+    def train_step(self, lr_audio, hr_audio):
+        """One train.py:160-202 iteration (fp32 branch).  Returns the loss dict (floats)."""
+        losses, _ = self.forward_losses(lr_audio, hr_audio)
+        loss_D = (losses["D_fake"] + losses["D_real"]) * 0.5
+        loss_G = losses["G_GAN"] + losses["G_GAN_Feat"]
+        self.opt_G.zero_grad()
+        loss_G.backward()
+        self.opt_G.step()
+        self.opt_D.zero_grad()
+        loss_D.backward()
+        self.opt_D.step()
+        return {k: float(v) for k, v in losses.items()}
+
+    # -- inference -----------------------------------------------------
+    @torch.no_grad()
+    def inference(self, lr_audio):
+        c = self.cfg
+        lr_s, norm = self.spectro(lr_audio)
+        sr_s = self.netG(self.two_channel(lr_s))
+        if c.fit_residual:  # pix2pixHD_model.py:631-635
+            lr_part = int(sr_s.size(-1) / c.up_ratio)
+            sr_s[..., :lr_part] *= 1e-3
+            sr_s = sr_s + lr_s
+        audio = transform.to_audio(sr_s.numpy(), norm, c.window, c.n_fft, c.hop, **c.codec)
+        return sr_s, audio, norm, lr_s

@@ -1,0 +1,191 @@
+"""The CPU oracle against outputs captured from the reference itself
+(tests/golden/*.npz, written by oracle/gen_golden.py).  Runs without a GPU."""
+import numpy as np
+import torch
+
+from oracle import nets, step, transform
+
+
+def test_kbd_window(golden):
+    g = golden("g1_kbdwin")
+    for n in (512, 1024):
+        w = transform.kbd_window(n)
+        assert w.dtype == np.float32 and w.shape == (n,)
+        np.testing.assert_array_equal(w, g["w%d" % n])          # same float32 op chain as util.py:179-186
+        np.testing.assert_allclose(transform.kbd_window_f64(n), g["w%d" % n], atol=3e-7, rtol=0)
+    w = transform.kbd_window(512).astype(np.float64)
+    np.testing.assert_allclose(w[:256] ** 2 + w[256:] ** 2, 1.0, atol=5e-7)  # Princen-Bradley
+
+
+def test_mdct4_matches_reference_fft_path(golden):
+    g = golden("g2_mdct4")
+    w = golden("g1_kbdwin")["w512"]
+    X, frames = transform.mdct4(g["x"], w, 512, 256)
+    np.testing.assert_array_equal(frames, g["frames"])           # fp32 window multiply: bit-exact
+    scale = np.abs(g["X"]).max()
+    assert np.abs(X - g["X"]).max() <= 1e-11 * scale
+    Xf = transform.mdct4_folded(g["x"], w, 512, 256)               # TDAC fold + DCT-IV == direct form
+    assert np.abs(Xf - g["X"]).max() <= 1e-11 * scale
+
+
+def test_imdct4_matches_reference(golden):
+    g = golden("g3_imdct4")
+    w = golden("g1_kbdwin")["w512"]
+    for key_in, key_out in (("X", "y"), ("Xr", "yr")):
+        y, frames = transform.imdct4(g[key_in], w, 512, 256)
+        assert y.shape == g[key_out].shape and y.dtype == np.float64
+        assert np.abs(y - g[key_out]).max() <= 1e-12 * max(1.0, np.abs(g[key_out]).max())
+    _, frames = transform.imdct4(g["X"], w, 512, 256)
+    assert np.abs(frames - g["yframes"]).max() <= 1e-10 * np.abs(g["yframes"]).max()
+    # unfolded DCT-IV form of the inverse
+    v = g["Xr"] @ transform.dct4_matrix(256)
+    yy = transform.tdac_unfold(v)
+    direct = g["Xr"] @ transform.mdct_matrix(512).T
+    assert np.abs(yy - direct).max() <= 1e-10 * np.abs(direct).max()
+
+
+def test_tdac_round_trip():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((3, 32512)).astype(np.float32)
+    w = transform.kbd_window(512)
+    X, _ = transform.mdct4(x, w, 512, 256)
+    assert X.shape == (3, 128, 256)
+    y, _ = transform.imdct4(X, w, 512, 256)
+    assert y.shape == (3, 1, 1, 32512)
+    assert np.abs(y[:, 0, 0] - x).max() < 2e-6
+
+
+def test_imdct4_shape_errors():
+    w = transform.kbd_window(512)
+    for bad in (np.zeros((2, 256)), np.zeros((1, 4, 255))):
+        try:
+            transform.imdct4(bad, w, 512, 256)
+        except AssertionError:
+            continue
+        raise AssertionError("expected AssertionError like mdct.py:458-461")
+
+
+def _codec(abs_norm):
+    return dict(arcsinh_transform=True, raw_mdct=False, arcsinh_gain=1000.0, abs_norm=abs_norm,
+                src_range=(-5.0, 5.0), norm_range=(-1.0, 1.0))
+
+
+def test_codec_matches_reference(golden):
+    w = golden("g1_kbdwin")["w512"]
+    for tag, abs_norm in (("abs", True), ("minmax", False)):
+        g = golden("g4_codec_" + tag)
+        s, norm = transform.to_spectro(g["x"], w, 512, 256, **_codec(abs_norm))
+        assert s.dtype == np.float32 and s.shape == g["log_spectro"].shape
+        np.testing.assert_allclose(s, g["log_spectro"], atol=2e-7, rtol=0)
+        np.testing.assert_allclose(norm["max"], g["max"], rtol=1e-6)
+        np.testing.assert_allclose(norm["min"], g["min"], rtol=1e-6)
+        np.testing.assert_allclose(norm["mean"], g["mean"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(norm["std"], g["std"], rtol=1e-5)
+        audio = transform.to_audio(g["log_spectro"], {"min": g["min"], "max": g["max"]}, w, 512, 256, **_codec(abs_norm))
+        assert np.abs(audio - g["audio"]).max() <= 1e-12
+        assert np.abs(audio[:, 0, 0] - g["x"]).max() < 1e-6      # codec round trip
+
+
+def check_adam_first_step(got, want, lr, key):
+    """After the FIRST Adam step every parameter moved by lr * g/(|g| + eps) ~= +-lr, so a gradient whose
+    sign is rounding noise (|g| ~ 1e-9) legitimately lands 2*lr away; allow < 1 % such elements."""
+    d = np.abs(got - want)
+    assert d.max() <= 2 * lr + 2e-6, key
+    assert (d > 2e-6).mean() <= 0.01, key
+
+
+def dead_bias(key):
+    """Conv biases that feed an InstanceNorm(affine=False): the norm removes them, their true gradient is
+    exactly 0 and what any implementation computes is rounding noise (which Adam then normalises to +-lr)."""
+    if not key.endswith(".bias"):
+        return False
+    if key.startswith("scale"):
+        return any("layer%d" % j in key for j in (1, 2, 3))
+    return "model.31" not in key            # every G conv except the 7x7 head is followed by IN
+
+
+def test_generators_match_reference(golden):
+    cfgs = {
+        "global": dict(netG="global", ngf=8, n_down_global=4, n_blocks_global=2),
+        "local": dict(netG="local", ngf=4, n_down_global=3, n_blocks_global=2, n_blocks_local=1),
+        "global_resconv_interp": dict(netG="global", ngf=4, n_down_global=3, n_blocks_global=1,
+                                      up="interpolate", down="resconv"),
+    }
+    for tag, c in cfgs.items():
+        g = golden("g5_netG_" + tag)
+        net = nets.build_generator(c.pop("netG"), 2, 1, input_size=(32, 256), **c)
+        assert list(net.state_dict().keys()) == list(g["keys"])
+        assert [str(tuple(p.shape)) for p in net.state_dict().values()] == list(g["shapes"])
+        nets.fill_deterministic(net)
+        with torch.no_grad():
+            y = net(torch.from_numpy(g["x"]))
+        np.testing.assert_allclose(y.numpy(), g["y"], atol=2e-5, rtol=1e-4)
+
+
+def test_discriminator_matches_reference(golden):
+    g = golden("g6_netD")
+    net = nets.fill_deterministic(nets.MultiscaleDRef(3, ndf=8, n_layers=3, num_D=2))
+    with torch.no_grad():
+        feats = net(torch.from_numpy(g["x"]))
+    for i, sc in enumerate(feats):
+        for j, f in enumerate(sc):
+            np.testing.assert_allclose(f.numpy(), g["f%d_%d" % (i, j)], atol=2e-5, rtol=1e-4)
+
+
+def test_bot_keys_and_shapes(golden):
+    g = golden("g7_local_bot_keys")        # parity UNPINNED: keys / shapes only
+    net = nets.build_generator("local", 2, 1, 8, 3, 2, 1, input_size=(64, 256), n_attn_g=2, heads_g=2,
+                               dim_head_g=16, proj_factor_g=4)
+    assert list(net.state_dict().keys()) == list(g["keys"])
+    assert [str(tuple(p.shape)) for p in net.state_dict().values()] == list(g["shapes"])
+    y = net(torch.zeros(1, 2, 64, 256))
+    assert y.shape == (1, 1, 64, 256)
+
+
+def test_step_matches_reference(golden):
+    g = golden("g6_step_global")
+    netG = nets.fill_deterministic(nets.build_generator("global", 2, 1, 4, 4, 2, input_size=(32, 256)))
+    netD = nets.fill_deterministic(nets.MultiscaleDRef(3, ndf=8, n_layers=3, num_D=2))
+    assert list(netD.state_dict().keys()) == list(g["keysD"])
+    ref = step.HotPathRef(netG, netD, step.CodecCfg(), num_D=2)
+    losses, sr = ref.forward_losses(g["lr"], g["hr"])
+    # This tiny InstanceNorm net amplifies a 1e-7 input perturbation ~1000x (measured), and the oracle's
+    # float64 contraction differs from the reference's FFT by 6e-11 before the float32 cast -> rare 1-ulp flips.
+    np.testing.assert_allclose(sr.detach().numpy(), g["sr_spectro"], atol=2e-4, rtol=1e-4)
+    want = dict(zip(g["loss_names"], g["losses"]))
+    for k, v in losses.items():
+        np.testing.assert_allclose(float(v), want[k], rtol=2e-5)
+    # same step again through train_step, then compare grads / updated params / next losses
+    netG = nets.fill_deterministic(nets.build_generator("global", 2, 1, 4, 4, 2, input_size=(32, 256)))
+    netD = nets.fill_deterministic(nets.MultiscaleDRef(3, ndf=8, n_layers=3, num_D=2))
+    ref = step.HotPathRef(netG, netD, step.CodecCfg(), num_D=2)
+    ref.train_step(g["lr"], g["hr"])
+    for k, p in netD.named_parameters():
+        if dead_bias(k):
+            continue
+        gr = g["gD/" + k]
+        assert np.abs(p.grad.numpy() - gr).max() <= 1e-2 * np.abs(gr).max() + 1e-9, k  # conditioning-limited (see above)
+    for net, pre in ((netG, "pG_after/"), (netD, "pD_after/")):
+        for k, p in net.state_dict().items():
+            if not dead_bias(k):
+                check_adam_first_step(p.numpy(), g[pre + k], 2e-4, k)
+    losses2, _ = ref.forward_losses(g["lr"], g["hr"])
+    want2 = dict(zip(g["loss_names"], g["losses_after"]))
+    for k, v in losses2.items():
+        np.testing.assert_allclose(float(v), want2[k], rtol=5e-3)   # conditioning-limited
+    sr_s, audio, _, lr_s = ref.inference(g["lr"])
+    np.testing.assert_allclose(lr_s.numpy(), g["inf_lr_spectro"], atol=2e-7)
+    # after the step a handful of weights differ by 2*lr (sign-of-noise, see check_adam_first_step) and this
+    # ill-conditioned toy net turns that into O(1e-2) output changes: shape check only.
+    assert np.corrcoef(sr_s.numpy().ravel(), g["inf_sr_spectro"].ravel())[0, 1] > 0.98
+    # the decoder on the REFERENCE's own sr_spectro is tight (sinh amplifies the net's conditioning noise)
+    norm = {"min": np.float32([[[[-5.0]]]]), "max": np.float32([[[[5.0]]]])}
+    audio_ref_in = transform.to_audio(g["inf_sr_spectro"], norm, ref.cfg.window, 512, 256, **ref.cfg.codec)
+    assert np.abs(audio_ref_in - g["inf_sr_audio"]).max() <= 1e-12 * max(1.0, np.abs(g["inf_sr_audio"]).max())
+
+
+def test_stitch(golden):
+    g = golden("g8_stitch")
+    out = transform.stitch_segments(g["seg"], 7936, int(g["overlap"]))
+    np.testing.assert_allclose(out, g["stitched"], atol=1e-14)
+    np.testing.assert_array_equal(transform.stitch_segments(g["seg"], 7936, 0), g["concat"])
