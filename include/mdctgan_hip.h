@@ -1,0 +1,166 @@
+/* libmdctgan_hip.so -- C ABI of the MI355X (gfx950) mdctGAN hot path.
+ *
+ * The reference (neoncloud/mdctGAN) is pure Python/PyTorch and has no FFI layer of its own: the
+ * seam is the module API of models/mdct.py, models/pix2pixHD_model.py and models/networks.py.
+ * Each entry point below replaces the chain of ATen ops one of those methods dispatches; the
+ * reference site it replaces is cited on every declaration (paths relative to the reference
+ * repository).  The Python package mdctgan_amd binds these with ctypes and re-exposes the reference's own
+ * class / function names (see INTEGRATION.md for the binding a maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless it says "host"; no torch types anywhere;
+ *   - activations are float32 NHWC ([B, H, W, C], C fastest); spectrograms [B, F, 256] are the
+ *     C == 1 case of both NHWC and the reference's NCHW;
+ *   - convolution weights are float32 "OHWI": [Cout, KH, KW, Cin] for nn.Conv2d and
+ *     [Cin_T, KH, KW, Cout_T] for nn.ConvTranspose2d.  A reference-shaped state_dict tensor
+ *     ([Cout, Cin, KH, KW] / [Cin_T, Cout_T, KH, KW]) is the SAME memory viewed through
+ *     .permute(0, 3, 1, 2), so checkpoints load unchanged;
+ *   - `stream` is a hipStream_t (0 = the null stream); all work is enqueued asynchronously;
+ *   - return value: 0 on success, a positive hipError_t, or MG_ERR_* (negative) for a rejected
+ *     argument.  Nothing is ever computed on the host.
+ */
+#ifndef MDCTGAN_HIP_H
+#define MDCTGAN_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MG_OK 0
+#define MG_ERR_ARG (-1)
+#define MG_ERR_UNSUPPORTED (-2)
+
+/* codec selector: raw MDCT coefficients, arcsinh + range-norm, range-norm only (--raw_mdct) */
+#define MG_CODEC_RAW 0
+#define MG_CODEC_ARCSINH 1
+#define MG_CODEC_RANGE 2
+
+/* activation selector for fused epilogues */
+#define MG_ACT_NONE 0
+#define MG_ACT_RELU 1
+#define MG_ACT_LRELU02 2
+#define MG_ACT_TANH 3
+
+int mg_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1  MDCT4.forward (models/mdct.py:392-425) fused with Audio2MDCT.normalize
+ *     (models/pix2pixHD_model.py:83-125) and the 2-channel input build (:400-402).
+ *
+ *   audio [B, T] -> spec [B, F, n_fft/2], F = mg_mdct4_num_frames(T, n_fft); n_fft == 512 (hop 256).
+ *   codec RAW: spec = X.  ARCSINH: L = asinh(gain*X)/ln10.  RANGE: L = X.  Then
+ *   spec = (L - min)/(max - min)*(nr1 - nr0) + nr0, with (min, max) = (src_min, src_max)
+ *   (--abs_norm) or, when per_sample != 0, the per-clip min/max of L (written to min_out/max_out [B]).
+ *   in2 (nullable): NHWC pair [B, F, 256, 2] = (spec, 2*|spec| + nr0) -- the generator input.
+ *   frames_out (nullable): windowed frames [B, F, n_fft] (return_frames=True).
+ *   stats (nullable): double[2] = sum(L), sum(L^2) over the batch (for the returned mean / std).
+ *   scratch_u32: >= 2*B uint32, required when per_sample != 0.
+ *   window [n_fft], dct4 [n_fft/2][n_fft/2] (cos(pi/M (n+1/2)(k+1/2))) are device tables.
+ */
+int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* window, const float* dct4,
+                     int codec, float gain, float nr0, float nr1, float src_min, float src_max, int per_sample,
+                     float* spec, float* in2, float* frames_out, float* min_out, float* max_out,
+                     double* stats, unsigned* scratch_u32, void* stream);
+int mg_mdct4_num_frames(int T, int n_fft);
+
+/* K2  Audio2MDCT.denormalize (models/pix2pixHD_model.py:127-137) fused with IMDCT4.forward
+ *     (models/mdct.py:457-489: inverse DCT, window, fold() overlap-add, 4/N scale, centre crop).
+ *   spec [B, F, 256] -> audio [B, out_len], out_len <= (F-1)*256; float32, or float64 when out_f64.
+ *   min_b / max_b (nullable, [B]): per-clip range; otherwise (src_min, src_max).
+ *   frames_out (nullable): windowed synthesis frames [B, F, n_fft].
+ */
+int mg_imdct4_forward(const float* spec, int B, int F, int n_fft, const float* window, const float* dct4,
+                      int codec, float gain, float nr0, float nr1, float src_min, float src_max,
+                      const float* min_b, const float* max_b, void* audio, int out_len, int out_f64,
+                      float* frames_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3/K4/K6  Implicit-GEMM convolution on the f32 MFMA pipe (exact float32).
+ *   Replaces nn.Conv2d / nn.ConvTranspose2d / nn.ReflectionPad2d forward and backward at
+ *   models/networks.py:207-210, 308-309, 329, 349-352, 387-392, 406-411, 440, 456, 649-670.
+ *
+ *   The geometry always describes the *convolution* (for ConvTranspose2d: the convolution whose
+ *   data-gradient it is): x [B, H, W, Ci] --(KHxKW, stride, pad, zero|reflect)--> y [B, OH, OW, Co].
+ */
+typedef struct {
+    int B, H, W, Ci;
+    int OH, OW, Co;
+    int KH, KW, stride, pad;
+    int reflect; /* 0: zero padding, 1: reflection padding (ReflectionPad2d(pad) folded into the gather) */
+} mg_conv_geom;
+
+/* y = act(conv(x, w) + bias)            (bias nullable) */
+int mg_conv_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
+                void* stream);
+/* dx = conv^T(dy, w) (+ bias, act)      data gradient of the convolution == ConvTranspose2d forward */
+int mg_conv_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
+                  void* stream);
+/* dw [Co, KH, KW, Ci] = sum over pixels; dbias [Co] (nullable) = column sums of dy.
+ * accumulate != 0 adds into dw / dbias instead of overwriting.  workspace: mg_conv_wgrad_workspace() bytes. */
+int mg_conv_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias, int accumulate,
+                  void* workspace, size_t workspace_bytes, void* stream);
+size_t mg_conv_wgrad_workspace(const mg_conv_geom* g);
+/* column sums: out[c] (+)= sum_m a[m, c]  -- bias gradients of ConvTranspose2d layers */
+int mg_colsum(const float* a, long long M, int C, float* out, int accumulate, void* workspace,
+              size_t workspace_bytes, void* stream);
+size_t mg_colsum_workspace(long long M, int C);
+
+/* ------------------------------------------------------------------------------------------
+ * K5  InstanceNorm2d(affine=False, eps) with fused activation / residual (networks.py:26, 306,
+ *     462, 650-666).  x, y: [B, HW, C].  mean / rstd: [B, C] (saved for backward).
+ *     y = act((x - mean) * rstd) (+ residual).
+ */
+int mg_instnorm_fwd(const float* x, int B, int HW, int C, float eps, int act, const float* residual, float* y,
+                    float* mean, float* rstd, void* workspace, size_t workspace_bytes, void* stream);
+/* dx from dy (gradient wrt y, excluding the residual branch), the saved x, mean, rstd. */
+int mg_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, int B, int HW, int C,
+                    int act, float* dx, void* workspace, size_t workspace_bytes, void* stream);
+size_t mg_instnorm_workspace(int B, int HW, int C);
+
+/* K7  elementwise activation backward for conv epilogues: dx = dy * act'(y)  (in place allowed) */
+int mg_act_bwd(const float* dy, const float* y, float* dx, long long n, int act, void* stream);
+/* out = a + b (residual joins outside a norm), in place allowed */
+int mg_add(const float* a, const float* b, float* out, long long n, void* stream);
+
+/* K8  AvgPool2d(3, stride 2, padding 1, count_include_pad=False) (networks.py:249-250, 525-526) */
+int mg_avgpool3s2_fwd(const float* x, int B, int H, int W, int C, float* y, void* stream);
+int mg_avgpool3s2_bwd(const float* dy, int B, int H, int W, int C, float* dx, void* stream);
+/* K9  nearest x2 upsample (networks.py:396) */
+int mg_upsample2x_fwd(const float* x, int B, int H, int W, int C, float* y, void* stream);
+int mg_upsample2x_bwd(const float* dy, int B, int H, int W, int C, float* dx, void* stream);
+
+/* discriminator input assembly (pix2pixHD_model.py:420-424, 439-440):
+ *   out [B, HW, 3] = (lr, s, 2|s| + nr0);  backward: ds = g1 + 2*sign(s)*g2 */
+int mg_dinput_fwd(const float* lr, const float* s, long long n, float nr0, float* out, void* stream);
+int mg_dinput_bwd(const float* dout, const float* s, long long n, float* ds, void* stream);
+/* generator input pair [n, 2] = (s, 2|s| + nr0) from a spectrogram (pix2pixHD_model.py:400-402) */
+int mg_pair_fwd(const float* s, long long n, float nr0, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K11  losses (networks.py:127-137 GANLoss/LSGAN, pix2pixHD_model.py:443-451 feature matching).
+ *   fwd: loss[0] (+)= scale * mean((pred - target)^2)   |   scale * mean(|a - b|)
+ *        (two-stage fixed-order reduction in double: deterministic; workspace >= mg_loss_workspace()).
+ *   bwd: grad = d loss / d pred (resp. a) * grad_out[0]  (grad_out: device scalar, nullable == 1).
+ */
+size_t mg_loss_workspace(void);
+int mg_mse_const_fwd(const float* pred, long long n, float target, float scale, float* loss, int accumulate,
+                     void* workspace, void* stream);
+int mg_mse_const_bwd(const float* pred, long long n, float target, float scale, const float* grad_out, float* grad,
+                     void* stream);
+int mg_l1_fwd(const float* a, const float* b, long long n, float scale, float* loss, int accumulate, void* workspace,
+              void* stream);
+int mg_l1_bwd(const float* a, const float* b, long long n, float scale, const float* grad_out, float* grad_a,
+              void* stream);
+
+/* K12  fused Adam over one flat float32 buffer (torch.optim.Adam semantics, no weight decay / amsgrad):
+ *      pix2pixHD_model.py:350-351, 363-364; train.py:186-202.  step is 1-based.
+ *      grad_scale multiplies g first (1/world_size for DDP, 1/loss_scale for AMP). */
+int mg_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                 float eps, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDCTGAN_HIP_H */

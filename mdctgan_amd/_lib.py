@@ -1,0 +1,131 @@
+"""ctypes binding of libmdctgan_hip.so (the C ABI declared in include/mdctgan_hip.h).
+
+There is deliberately NO fallback: if the library is missing, or a tensor is not resident in
+HBM, the call raises.  PyTorch is used only for device memory, streams and autograd plumbing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmdctgan_hip.so")
+
+MG_CODEC_RAW, MG_CODEC_ARCSINH, MG_CODEC_RANGE = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_TANH = 0, 1, 2, 3
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [(n, C.c_int) for n in
+                ("B", "H", "W", "Ci", "OH", "OW", "Co", "KH", "KW", "stride", "pad", "reflect")]
+
+
+_p, _i, _f, _ll, _sz = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
+_G = C.POINTER(ConvGeom)
+
+# name -> (restype, argtypes); must list every symbol include/mdctgan_hip.h declares
+SIGNATURES = {
+    "mg_abi_version": (_i, []),
+    "mg_mdct4_forward": (_i, [_p, _i, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "mg_mdct4_num_frames": (_i, [_i, _i]),
+    "mg_imdct4_forward": (_i, [_p, _i, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _p, _p, _p, _i, _i, _p, _p]),
+    "mg_conv_fwd": (_i, [_G, _p, _p, _p, _p, _i, _p]),
+    "mg_conv_dgrad": (_i, [_G, _p, _p, _p, _p, _i, _p]),
+    "mg_conv_wgrad": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p]),
+    "mg_conv_wgrad_workspace": (_sz, [_G]),
+    "mg_colsum": (_i, [_p, _ll, _i, _p, _i, _p, _sz, _p]),
+    "mg_colsum_workspace": (_sz, [_ll, _i]),
+    "mg_instnorm_fwd": (_i, [_p, _i, _i, _i, _f, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    "mg_instnorm_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _sz, _p]),
+    "mg_instnorm_workspace": (_sz, [_i, _i, _i]),
+    "mg_act_bwd": (_i, [_p, _p, _p, _ll, _i, _p]),
+    "mg_add": (_i, [_p, _p, _p, _ll, _p]),
+    "mg_avgpool3s2_fwd": (_i, [_p, _i, _i, _i, _i, _p, _p]),
+    "mg_avgpool3s2_bwd": (_i, [_p, _i, _i, _i, _i, _p, _p]),
+    "mg_upsample2x_fwd": (_i, [_p, _i, _i, _i, _i, _p, _p]),
+    "mg_upsample2x_bwd": (_i, [_p, _i, _i, _i, _i, _p, _p]),
+    "mg_dinput_fwd": (_i, [_p, _p, _ll, _f, _p, _p]),
+    "mg_dinput_bwd": (_i, [_p, _p, _ll, _p, _p]),
+    "mg_pair_fwd": (_i, [_p, _ll, _f, _p, _p]),
+    "mg_loss_workspace": (_sz, []),
+    "mg_mse_const_fwd": (_i, [_p, _ll, _f, _f, _p, _i, _p, _p]),
+    "mg_mse_const_bwd": (_i, [_p, _ll, _f, _f, _p, _p, _p]),
+    "mg_l1_fwd": (_i, [_p, _p, _ll, _f, _p, _i, _p, _p]),
+    "mg_l1_bwd": (_i, [_p, _p, _ll, _f, _p, _p, _p]),
+    "mg_adam_step": (_i, [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _f, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises HipLibraryError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            "libmdctgan_hip.so not found at %s -- run `python -m mdctgan_amd.build` "
+            "(there is no CPU / eager fallback for the hot path)" % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise HipLibraryError("cannot load %s: %s" % (LIB_PATH, e)) from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError("libmdctgan_hip.so lacks symbol %s (stale build?)" % name) from e
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc == 0:
+        return
+    if rc == -1:
+        raise ValueError("%s: argument rejected by the HIP library (MG_ERR_ARG)" % what)
+    if rc == -2:
+        raise NotImplementedError("%s: configuration not supported by the HIP kernels (MG_ERR_UNSUPPORTED)" % what)
+    raise HipLibraryError("%s: HIP error %d" % (what, rc))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses host tensors: the hot path has no CPU leg."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipLibraryError("the MI355X hot path needs device tensors (got a %s tensor); "
+                              "there is no CPU fallback" % t.device)
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def f32c(t, name="tensor"):
+    """float32 + contiguous, converting when needed (plumbing only)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+_workspaces = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Persistent per-device scratch (grown on demand; all launches share one stream order)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes * 1.25), 1 << 22), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws

@@ -1,0 +1,774 @@
+// K3 / K4 / K6: implicit-GEMM convolution (forward, data-gradient == transposed convolution,
+// weight-gradient) on the gfx950 f32 MFMA pipe (v_mfma_f32_32x32x2_f32, exact float32).
+//
+// Replaces nn.Conv2d / nn.ConvTranspose2d / nn.ReflectionPad2d forward + backward of the reference
+// (models/networks.py:207-210, 308-309, 329, 349-352, 387-392, 406-411, 440, 456, 649-670).
+//
+// Layout: activations NHWC, weights OHWI ([Co][KH][KW][Ci]).  Every pass is one GEMM
+//      FWD    Y[m=(b,oy,ox)][n=co]     = sum_{k=(ky,kx,ci)} Xgather[m][k]  * W[n][k]
+//      DGRAD  dX[m=(b,iy,ix)][n=ci]    = sum_{k=(ky,kx,co)} dYgather[m][k] * W[k.co][k.tap][n]
+//      WGRAD  dW[co][n=(ky,kx,ci)]     = sum_{k=(b,oy,ox)}  dY[k][co]      * Xgather[k][n]
+// The gathers fold zero padding, ReflectionPad2d (forward: index reflection; backward: the up-to-4
+// padded positions that alias an interior pixel are summed in the loader), the stride (DGRAD runs
+// one launch slice per output-parity class so no MFMA work is spent on structural zeros) and the
+// transposed-convolution geometry into address generation: no padded / dilated tensor ever exists.
+//
+// Tile: BM x BN x 16, 256 threads = 2x2 waves, each wave (BM/2)x(BN/2) as 32x32 MFMA blocks.
+// LDS tiles are k-major ([16][rows + 4]): the MFMA fragment read is one conflict-free ds_read_b32 per
+// operand per MFMA (lanes 0-31 consecutive rows), k-contiguous global float4s are scattered with
+// 2-way (free) ds_write_b32, row-contiguous ones land as ds_write_b128.  Register-staged double
+// buffering, one barrier per k-chunk; with 64-cycle MFMAs the loader hides completely.
+#include "common.h"
+#include "mdctgan_hip.h"
+
+namespace {
+
+constexpr int BK = 16;
+
+struct Geom {
+    int B, H, W, Ci, OH, OW, Co, KH, KW, s, p, reflect;
+};
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == MG_ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == MG_ACT_LRELU02) return v > 0.0f ? v : 0.2f * v;
+    if (act == MG_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void add4(float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+
+// k-contiguous float4 (4 consecutive k of one row) -> k-major LDS tile
+template <int LD>
+__device__ __forceinline__ void st_kcontig(float* S, int row, int q, const float4 v) {
+    S[(4 * q + 0) * LD + row] = v.x;
+    S[(4 * q + 1) * LD + row] = v.y;
+    S[(4 * q + 2) * LD + row] = v.z;
+    S[(4 * q + 3) * LD + row] = v.w;
+}
+// row-contiguous float4 (4 consecutive rows at one k)
+template <int LD>
+__device__ __forceinline__ void st_rowcontig(float* S, int k, int row, const float4 v) {
+    *reinterpret_cast<float4*>(S + k * LD + row) = v;
+}
+
+template <int MB, int NB, int LDA, int LDB>
+__device__ __forceinline__ void mma_chunk(const float* Ap, const float* Bp, f32x16 (&acc)[MB][NB], int wm0, int wn0,
+                                          int lane) {
+    const int r = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int kp = 0; kp < BK / 2; ++kp) {
+        float a[MB], b[NB];
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) a[mi] = Ap[(2 * kp + kh) * LDA + wm0 + 32 * mi + r];
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni) b[ni] = Bp[(2 * kp + kh) * LDB + wn0 + 32 * ni + r];
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = mfma32x32x2(a[mi], b[ni], acc[mi][ni]);
+    }
+}
+
+// ================================================================================================
+// FWD
+// ================================================================================================
+template <int BM, int BN, bool VEC>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(Geom g, const float* __restrict__ x,
+                                                       const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y,
+                                                       int act) {
+    constexpr int MB = BM / 64, NB = BN / 64, LDA = BM + 4, LDB = BN + 4;
+    constexpr int NVA = BM * 4 / 256, NVB = BN * 4 / 256;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
+    auto As = [&](int buf) -> float* { return smem + buf * (BK * LDA); };
+    auto Bs = [&](int buf) -> float* { return smem + 2 * BK * LDA + buf * (BK * LDB); };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = g.B * g.OH * g.OW, N = g.Co, K = g.KH * g.KW * g.Ci;
+    const int cpt = g.Ci / BK;   // chunks per tap (VEC)
+    const int nchunks = VEC ? g.KH * g.KW * cpt : (K + BK - 1) / BK;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int m0 = (t % tiles_m) * BM, n0 = (t / tiles_m) * BN;
+    const int q = tid & 3, r0 = tid >> 2;
+
+    int iy0[NVA], ix0[NVA], pb[NVA];
+    bool va_ok[NVA];
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) {
+        const int m = m0 + r0 + 64 * i;
+        va_ok[i] = m < M;
+        const int mm = va_ok[i] ? m : 0;
+        const int b = mm / (g.OH * g.OW), rem = mm - b * (g.OH * g.OW);
+        const int oy = rem / g.OW, ox = rem - oy * g.OW;
+        iy0[i] = oy * g.s - g.p;
+        ix0[i] = ox * g.s - g.p;
+        pb[i] = b * g.H * g.W;
+    }
+
+    auto src_pixel = [&](int i, int ky, int kx) -> int {   // -1: zero padding
+        int iy = iy0[i] + ky, ix = ix0[i] + kx;
+        if (g.reflect) {
+            iy = reflect_idx(iy, g.H);
+            ix = reflect_idx(ix, g.W);
+        } else if (iy < 0 || iy >= g.H || ix < 0 || ix >= g.W) {
+            return -1;
+        }
+        return pb[i] + iy * g.W + ix;
+    };
+
+    auto load_a = [&](int c, float4 (&va)[NVA]) {
+        if (VEC) {
+            const int tap = c / cpt, ci0 = (c - tap * cpt) * BK;
+            const int ky = tap / g.KW, kx = tap - ky * g.KW;
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) {
+                va[i] = zero4();
+                if (!va_ok[i]) continue;
+                const int px = src_pixel(i, ky, kx);
+                if (px >= 0) va[i] = ld4(x + (size_t)px * g.Ci + ci0 + 4 * q);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) {
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = c * BK + 4 * q + j;
+                    e[j] = 0.0f;
+                    if (va_ok[i] && k < K) {
+                        const int tap = k / g.Ci, ci = k - tap * g.Ci;
+                        const int ky = tap / g.KW, kx = tap - ky * g.KW;
+                        const int px = src_pixel(i, ky, kx);
+                        if (px >= 0) e[j] = x[(size_t)px * g.Ci + ci];
+                    }
+                }
+                va[i] = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+    };
+    auto load_b = [&](int c, float4 (&vb)[NVB]) {
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            const int n = n0 + r0 + 64 * i;
+            vb[i] = zero4();
+            if (n >= N) continue;
+            if (VEC) {
+                vb[i] = ld4(w + (size_t)n * K + c * BK + 4 * q);
+            } else {
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = c * BK + 4 * q + j;
+                    e[j] = (k < K) ? w[(size_t)n * K + k] : 0.0f;
+                }
+                vb[i] = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = f32x16{0};
+    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+
+    float4 va[NVA], vb[NVB];
+    load_a(0, va);
+    load_b(0, vb);
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) st_kcontig<LDA>(As(0), r0 + 64 * i, q, va[i]);
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) st_kcontig<LDB>(Bs(0), r0 + 64 * i, q, vb[i]);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int cur = c & 1;
+        if (c + 1 < nchunks) {
+            load_a(c + 1, va);
+            load_b(c + 1, vb);
+        }
+        mma_chunk<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane);
+        if (c + 1 < nchunks) {
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) st_kcontig<LDA>(As(cur ^ 1), r0 + 64 * i, q, va[i]);
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) st_kcontig<LDB>(Bs(cur ^ 1), r0 + 64 * i, q, vb[i]);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni) {
+            const int col = n0 + wn0 + 32 * ni + (lane & 31);
+            const float bv = (bias && col < N) ? bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm0 + 32 * mi + mfma32_row(r, lane);
+                if (row < M && col < N) y[(size_t)row * N + col] = apply_act(acc[mi][ni][r] + bv, act);
+            }
+        }
+}
+
+// ================================================================================================
+// DGRAD (== transposed convolution forward).  blockIdx.z = output-parity class (stride^2 of them).
+// ================================================================================================
+template <int BM, int BN, bool VECA, bool VECB>
+__global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __restrict__ dy,
+                                                         const float* __restrict__ w,
+                                                         const float* __restrict__ bias,
+                                                         float* __restrict__ dx, int act) {
+    constexpr int MB = BM / 64, NB = BN / 64, LDA = BM + 4, LDB = BN + 4;
+    constexpr int NVA = BM * 4 / 256, NVB = BN * 4 / 256;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
+    auto As = [&](int buf) -> float* { return smem + buf * (BK * LDA); };
+    auto Bs = [&](int buf) -> float* { return smem + 2 * BK * LDA + buf * (BK * LDB); };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = g.s;
+    const int py = blockIdx.z / s, px = blockIdx.z - py * s;
+    const int Hc = (g.H - py + s - 1) / s, Wc = (g.W - px + s - 1) / s;   // pixels of this class
+    const int M = g.B * Hc * Wc, N = g.Ci;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    if ((int)blockIdx.x >= tiles_m * tiles_n) return;
+    // taps that reach this class: ky = ky0 + s*i
+    const int ky0 = (py + g.p) % s, kx0 = (px + g.p) % s;
+    const int nky = (g.KH - ky0 + s - 1) / s, nkx = (g.KW - kx0 + s - 1) / s;
+    const int oyb = (py + g.p) / s, oxb = (px + g.p) / s;                 // oy = yy + oyb - tyi
+    const int ntap = nky * nkx;
+    const int Kc = ntap * g.Co;
+    const int cpt = g.Co / BK;
+    const int nchunks = VECA ? ntap * cpt : (Kc + BK - 1) / BK;
+    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int m0 = (t % tiles_m) * BM, n0 = (t / tiles_m) * BN;
+    const int q = tid & 3, r0 = tid >> 2;
+
+    int yy[NVA], xx[NVA], bb[NVA];
+    bool va_ok[NVA];
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) {
+        const int m = m0 + r0 + 64 * i;
+        va_ok[i] = m < M;
+        const int mm = va_ok[i] ? m : 0;
+        bb[i] = mm / (Hc * Wc);
+        const int rem = mm - bb[i] * (Hc * Wc);
+        yy[i] = rem / Wc;
+        xx[i] = rem - yy[i] * Wc;
+    }
+
+    // gather of dY for row i and tap index (tyi, txi): float4 at channel offset co (VEC) or scalar
+    auto gather4 = [&](int i, int tyi, int txi, int co) -> float4 {
+        float4 v = zero4();
+        if (!g.reflect) {
+            const int oy = yy[i] + oyb - tyi, ox = xx[i] + oxb - txi;
+            if (oy >= 0 && oy < g.OH && ox >= 0 && ox < g.OW)
+                v = ld4(dy + ((size_t)(bb[i] * g.OH + oy) * g.OW + ox) * g.Co + co);
+        } else {   // stride 1: iy = yy, ky = tyi.  Padded rows aliasing iy: iy+p, p-iy, 2(H-1)-iy+p.
+            const int iy = yy[i], ix = xx[i], p = g.p;
+            int cy[3] = {iy + p, (iy >= 1 && iy <= p) ? p - iy : -1000000,
+                         (iy >= g.H - 1 - p && iy <= g.H - 2) ? 2 * (g.H - 1) - iy + p : -1000000};
+            int cx[3] = {ix + p, (ix >= 1 && ix <= p) ? p - ix : -1000000,
+                         (ix >= g.W - 1 - p && ix <= g.W - 2) ? 2 * (g.W - 1) - ix + p : -1000000};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int oy = cy[a] - tyi;
+                if (oy < 0 || oy >= g.OH) continue;
+#pragma unroll
+                for (int c2 = 0; c2 < 3; ++c2) {
+                    const int ox = cx[c2] - txi;
+                    if (ox < 0 || ox >= g.OW) continue;
+                    add4(v, ld4(dy + ((size_t)(bb[i] * g.OH + oy) * g.OW + ox) * g.Co + co));
+                }
+            }
+        }
+        return v;
+    };
+    auto gather1 = [&](int i, int tyi, int txi, int co) -> float {
+        float v = 0.0f;
+        if (!g.reflect) {
+            const int oy = yy[i] + oyb - tyi, ox = xx[i] + oxb - txi;
+            if (oy >= 0 && oy < g.OH && ox >= 0 && ox < g.OW)
+                v = dy[((size_t)(bb[i] * g.OH + oy) * g.OW + ox) * g.Co + co];
+        } else {
+            const int iy = yy[i], ix = xx[i], p = g.p;
+            int cy[3] = {iy + p, (iy >= 1 && iy <= p) ? p - iy : -1000000,
+                         (iy >= g.H - 1 - p && iy <= g.H - 2) ? 2 * (g.H - 1) - iy + p : -1000000};
+            int cx[3] = {ix + p, (ix >= 1 && ix <= p) ? p - ix : -1000000,
+                         (ix >= g.W - 1 - p && ix <= g.W - 2) ? 2 * (g.W - 1) - ix + p : -1000000};
+            for (int a = 0; a < 3; ++a) {
+                const int oy = cy[a] - tyi;
+                if (oy < 0 || oy >= g.OH) continue;
+                for (int c2 = 0; c2 < 3; ++c2) {
+                    const int ox = cx[c2] - txi;
+                    if (ox < 0 || ox >= g.OW) continue;
+                    v += dy[((size_t)(bb[i] * g.OH + oy) * g.OW + ox) * g.Co + co];
+                }
+            }
+        }
+        return v;
+    };
+
+    auto load_a = [&](int c, float4 (&va)[NVA]) {
+        if (VECA) {
+            const int tap = c / cpt, co0 = (c - tap * cpt) * BK;
+            const int tyi = tap / nkx, txi = tap - tyi * nkx;
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) va[i] = va_ok[i] ? gather4(i, tyi, txi, co0 + 4 * q) : zero4();
+        } else {
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) {
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = c * BK + 4 * q + j;
+                    e[j] = 0.0f;
+                    if (va_ok[i] && k < Kc) {
+                        const int tap = k / g.Co, co = k - tap * g.Co;
+                        const int tyi = tap / nkx, txi = tap - tyi * nkx;
+                        e[j] = gather1(i, tyi, txi, co);
+                    }
+                }
+                va[i] = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+    };
+    // B[k=(tap,co)][n=ci] = W[co][ky][kx][ci]: contiguous along n
+    const int bk_l = tid / (BN / 4), bn_q = tid % (BN / 4);       // NVB passes step k by 256/(BN/4)
+    auto load_b = [&](int c, float4 (&vb)[NVB]) {
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            const int kl = bk_l + i * (1024 / BN);
+            int tap, co;
+            if (VECA) {
+                tap = c / cpt;
+                co = (c - tap * cpt) * BK + kl;
+            } else {
+                const int k = c * BK + kl;
+                tap = k / g.Co;
+                co = k - tap * g.Co;
+                if (k >= Kc) { vb[i] = zero4(); continue; }
+            }
+            const int tyi = tap / nkx, txi = tap - tyi * nkx;
+            const int ky = ky0 + s * tyi, kx = kx0 + s * txi;
+            const float* wp = w + ((size_t)(co * g.KH + ky) * g.KW + kx) * g.Ci;
+            const int n = n0 + 4 * bn_q;
+            if (VECB) {
+                vb[i] = (n < N) ? ld4(wp + n) : zero4();
+            } else {
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = (n + j < N) ? wp[n + j] : 0.0f;
+                vb[i] = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = f32x16{0};
+    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+
+    float4 va[NVA], vb[NVB];
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) st_kcontig<LDA>(As(buf), r0 + 64 * i, q, va[i]);
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) st_rowcontig<LDB>(Bs(buf), bk_l + i * (1024 / BN), 4 * bn_q, vb[i]);
+    };
+    if (nchunks > 0) {
+        load_a(0, va);
+        load_b(0, vb);
+        stash(0);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int cur = c & 1;
+        if (c + 1 < nchunks) {
+            load_a(c + 1, va);
+            load_b(c + 1, vb);
+        }
+        mma_chunk<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane);
+        if (c + 1 < nchunks) stash(cur ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm0 + 32 * mi + mfma32_row(r, lane);
+            if (m >= M) continue;
+            const int b = m / (Hc * Wc), rem = m - b * (Hc * Wc);
+            const int y2 = rem / Wc, x2 = rem - y2 * Wc;
+            const size_t o = ((size_t)(b * g.H + y2 * s + py) * g.W + x2 * s + px) * g.Ci;
+#pragma unroll
+            for (int ni = 0; ni < NB; ++ni) {
+                const int col = n0 + wn0 + 32 * ni + (lane & 31);
+                if (col < N) {
+                    const float bv = bias ? bias[col] : 0.0f;
+                    dx[o + col] = apply_act(acc[mi][ni][r] + bv, act);
+                }
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// WGRAD.  rows = co, cols = n = (ky,kx,ci), reduction over pixels m; blockIdx.z = split of m.
+// ================================================================================================
+template <int BM, int BN, bool VECA, bool VECB>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __restrict__ x,
+                                                         const float* __restrict__ dy, float* __restrict__ out,
+                                                         int chunks_per_split, int accumulate) {
+    constexpr int MB = BM / 64, NB = BN / 64, LDA = BM + 4, LDB = BN + 4;
+    constexpr int NVA = BM * 4 / 256, NVB = BN * 4 / 256;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
+    auto As = [&](int buf) -> float* { return smem + buf * (BK * LDA); };
+    auto Bs = [&](int buf) -> float* { return smem + 2 * BK * LDA + buf * (BK * LDB); };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Mtot = g.B * g.OH * g.OW;          // reduction length
+    const int R = g.Co, N = g.KH * g.KW * g.Ci;  // output rows / cols
+    const int tiles_m = (R + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int r_0 = (t % tiles_m) * BM, n0 = (t / tiles_m) * BN;
+    const int total_chunks = (Mtot + BK - 1) / BK;
+    const int c_begin = blockIdx.z * chunks_per_split;
+    const int c_end = min(total_chunks, c_begin + chunks_per_split);
+
+    const int ak_l = tid / (BM / 4), a_q = tid % (BM / 4);
+    const int bk_l = tid / (BN / 4), b_q = tid % (BN / 4);
+
+    // this thread's B columns (fixed through the loop)
+    int b_tap[4], b_ci[4];
+    {
+        const int n = n0 + 4 * b_q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nn = n + (VECB ? 0 : j);
+            b_tap[j] = (nn < N) ? nn / g.Ci : -1;
+            b_ci[j] = (nn < N) ? nn - b_tap[j] * g.Ci : 0;
+        }
+    }
+
+    auto load_a = [&](int c, float4 (&va)[NVA]) {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+            const int m = c * BK + ak_l + i * (1024 / BM);
+            const int co = r_0 + 4 * a_q;
+            va[i] = zero4();
+            if (m >= Mtot) continue;
+            if (VECA) {
+                if (co < R) va[i] = ld4(dy + (size_t)m * g.Co + co);
+            } else {
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = (co + j < R) ? dy[(size_t)m * g.Co + co + j] : 0.0f;
+                va[i] = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+    };
+    auto src_pixel = [&](int b, int oy, int ox, int tap) -> int {
+        const int ky = tap / g.KW, kx = tap - ky * g.KW;
+        int iy = oy * g.s - g.p + ky, ix = ox * g.s - g.p + kx;
+        if (g.reflect) {
+            iy = reflect_idx(iy, g.H);
+            ix = reflect_idx(ix, g.W);
+        } else if (iy < 0 || iy >= g.H || ix < 0 || ix >= g.W) {
+            return -1;
+        }
+        return (b * g.H + iy) * g.W + ix;
+    };
+    auto load_b = [&](int c, float4 (&vb)[NVB]) {
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            const int m = c * BK + bk_l + i * (1024 / BN);
+            vb[i] = zero4();
+            if (m >= Mtot) continue;
+            const int b = m / (g.OH * g.OW), rem = m - b * (g.OH * g.OW);
+            const int oy = rem / g.OW, ox = rem - oy * g.OW;
+            if (VECB) {
+                if (b_tap[0] < 0) continue;
+                const int px = src_pixel(b, oy, ox, b_tap[0]);
+                if (px >= 0) vb[i] = ld4(x + (size_t)px * g.Ci + b_ci[0]);
+            } else {
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    e[j] = 0.0f;
+                    if (b_tap[j] < 0) continue;
+                    const int px = src_pixel(b, oy, ox, b_tap[j]);
+                    if (px >= 0) e[j] = x[(size_t)px * g.Ci + b_ci[j]];
+                }
+                vb[i] = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = f32x16{0};
+    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+
+    float4 va[NVA], vb[NVB];
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) st_rowcontig<LDA>(As(buf), ak_l + i * (1024 / BM), 4 * a_q, va[i]);
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) st_rowcontig<LDB>(Bs(buf), bk_l + i * (1024 / BN), 4 * b_q, vb[i]);
+    };
+    if (c_begin < c_end) {
+        load_a(c_begin, va);
+        load_b(c_begin, vb);
+        stash(0);
+    }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const int cur = (c - c_begin) & 1;
+        if (c + 1 < c_end) {
+            load_a(c + 1, va);
+            load_b(c + 1, vb);
+        }
+        mma_chunk<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane);
+        if (c + 1 < c_end) stash(cur ^ 1);
+        __syncthreads();
+    }
+
+    float* o = out + (size_t)blockIdx.z * R * N;
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni) {
+            const int col = n0 + wn0 + 32 * ni + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = r_0 + wm0 + 32 * mi + mfma32_row(r, lane);
+                if (row < R && col < N) {
+                    const size_t idx = (size_t)row * N + col;
+                    o[idx] = accumulate ? o[idx] + acc[mi][ni][r] : acc[mi][ni][r];
+                }
+            }
+        }
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int S, size_t n, float* __restrict__ out,
+                                     int accumulate) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.0f;
+        for (int z = 0; z < S; ++z) s += part[(size_t)z * n + i];
+        out[i] = accumulate ? out[i] + s : s;
+    }
+}
+
+// column sums of a [M, C] matrix: stage 1 -> partial [S][C], stage 2 = splitk_reduce_kernel
+__global__ void colsum_partial_kernel(const float* __restrict__ a, long long M, int C, long long rows_per_split,
+                                      float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const long long m_begin = (long long)blockIdx.y * rows_per_split;
+    const long long m_end = min(M, m_begin + rows_per_split);
+    float s = 0.0f;
+    if (c < C)
+        for (long long m = m_begin + rg; m < m_end; m += 4) s += a[m * C + c];
+    red[rg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rg == 0 && c < C)
+        part[(size_t)blockIdx.y * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
+                                           red[3][threadIdx.x];
+}
+
+Geom to_geom(const mg_conv_geom* g) {
+    return Geom{g->B, g->H, g->W, g->Ci, g->OH, g->OW, g->Co, g->KH, g->KW, g->stride, g->pad, g->reflect};
+}
+
+bool geom_ok(const mg_conv_geom* g) {
+    if (!g || g->B <= 0 || g->H <= 0 || g->W <= 0 || g->Ci <= 0 || g->Co <= 0 || g->KH <= 0 || g->KW <= 0) return false;
+    if (g->stride < 1 || g->stride > 2 || g->pad < 0) return false;
+    if (g->OH != (g->H + 2 * g->pad - g->KH) / g->stride + 1) return false;
+    if (g->OW != (g->W + 2 * g->pad - g->KW) / g->stride + 1) return false;
+    if (g->reflect && (g->pad >= g->H || g->pad >= g->W)) return false;
+    return true;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+struct ColsumPlan { int splits; long long rows_per_split; };
+ColsumPlan colsum_plan(long long M, int C) {
+    const int cb = (C + 63) / 64;
+    long long splits = (1024 + cb - 1) / cb;
+    if (splits > (M + 63) / 64) splits = (M + 63) / 64;
+    if (splits < 1) splits = 1;
+    long long rps = (M + splits - 1) / splits;
+    splits = (M + rps - 1) / rps;
+    return {(int)splits, rps};
+}
+
+struct WgradPlan { bool big; int tiles; int splits; int cps; };
+WgradPlan wgrad_plan(const mg_conv_geom* g) {
+    const int R = g->Co, N = g->KH * g->KW * g->Ci;
+    const long long Mtot = (long long)g->B * g->OH * g->OW;
+    const int chunks = (int)((Mtot + BK - 1) / BK);
+    const int t128 = ((R + 127) / 128) * ((N + 127) / 128);
+    const bool big = t128 >= 96 && R >= 128;
+    const int tiles = big ? t128 : ((R + 63) / 64) * ((N + 63) / 64);
+    int splits = (768 + tiles - 1) / tiles;
+    const int max_splits = chunks / 8 > 0 ? chunks / 8 : 1;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int cps = (chunks + splits - 1) / splits;
+    splits = (chunks + cps - 1) / cps;
+    return {big, tiles, splits, cps};
+}
+
+}  // namespace
+
+extern "C" {
+
+int mg_abi_version(void) { return 1; }
+
+int mg_conv_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
+                void* stream) {
+    if (!geom_ok(g) || !x || !w || !y) return MG_ERR_ARG;
+    const Geom gg = to_geom(g);
+    hipStream_t st = (hipStream_t)stream;
+    const long long M = (long long)g->B * g->OH * g->OW;
+    const int N = g->Co;
+    const bool vec = (g->Ci % BK == 0) && aligned16(x) && aligned16(w);
+    const long long t128 = ((M + 127) / 128) * ((N + 127) / 128);
+    const bool big = t128 >= 192 && N >= 128;
+    if (big) {
+        dim3 grid((unsigned)t128);
+        if (vec) hipLaunchKernelGGL((conv_fwd_kernel<128, 128, true>), grid, dim3(256), 0, st, gg, x, w, bias, y, act);
+        else hipLaunchKernelGGL((conv_fwd_kernel<128, 128, false>), grid, dim3(256), 0, st, gg, x, w, bias, y, act);
+    } else if (N > 32 || M < 64 * 512) {
+        dim3 grid((unsigned)(((M + 63) / 64) * ((N + 63) / 64)));
+        if (vec) hipLaunchKernelGGL((conv_fwd_kernel<64, 64, true>), grid, dim3(256), 0, st, gg, x, w, bias, y, act);
+        else hipLaunchKernelGGL((conv_fwd_kernel<64, 64, false>), grid, dim3(256), 0, st, gg, x, w, bias, y, act);
+    } else {   // few output channels, many pixels
+        dim3 grid((unsigned)(((M + 127) / 128) * ((N + 63) / 64)));
+        if (vec) hipLaunchKernelGGL((conv_fwd_kernel<128, 64, true>), grid, dim3(256), 0, st, gg, x, w, bias, y, act);
+        else hipLaunchKernelGGL((conv_fwd_kernel<128, 64, false>), grid, dim3(256), 0, st, gg, x, w, bias, y, act);
+    }
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+int mg_conv_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
+                  void* stream) {
+    if (!geom_ok(g) || !dy || !w || !dx) return MG_ERR_ARG;
+    if (g->reflect && g->stride != 1) return MG_ERR_UNSUPPORTED;
+    const Geom gg = to_geom(g);
+    hipStream_t st = (hipStream_t)stream;
+    const int s = g->stride;
+    // every input pixel must be produced by exactly one class launch; classes cover all of [0,H)x[0,W)
+    const long long Mc = (long long)g->B * ((g->H + s - 1) / s) * ((g->W + s - 1) / s);   // largest class
+    const int N = g->Ci;
+    const bool veca = (g->Co % BK == 0) && aligned16(dy);
+    const bool vecb = (g->Ci % 4 == 0) && aligned16(w);
+    const long long t128 = ((Mc + 127) / 128) * ((N + 127) / 128);
+    const bool big = t128 * s * s >= 192 && N >= 128;
+#define MG_LAUNCH_DGRAD(BM_, BN_)                                                                                  \
+    do {                                                                                                           \
+        dim3 grid((unsigned)(((Mc + BM_ - 1) / BM_) * ((N + BN_ - 1) / BN_)), 1, s * s);                           \
+        if (veca && vecb)                                                                                          \
+            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, true>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act);  \
+        else if (veca)                                                                                             \
+            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, false>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act); \
+        else if (vecb)                                                                                             \
+            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, false, true>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act); \
+        else                                                                                                       \
+            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, false, false>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act);\
+    } while (0)
+    if (big) MG_LAUNCH_DGRAD(128, 128);
+    else if (N > 32 || Mc < 64 * 512) MG_LAUNCH_DGRAD(64, 64);
+    else MG_LAUNCH_DGRAD(128, 64);
+#undef MG_LAUNCH_DGRAD
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+size_t mg_colsum_workspace(long long M, int C) {
+    const ColsumPlan p = colsum_plan(M, C);
+    return (size_t)p.splits * C * sizeof(float);
+}
+
+int mg_colsum(const float* a, long long M, int C, float* out, int accumulate, void* workspace,
+              size_t workspace_bytes, void* stream) {
+    if (!a || !out || M <= 0 || C <= 0 || !workspace) return MG_ERR_ARG;
+    if (workspace_bytes < mg_colsum_workspace(M, C)) return MG_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const ColsumPlan p = colsum_plan(M, C);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, p.splits), dim3(256), 0, st, a, M, C,
+                       p.rows_per_split, (float*)workspace);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)workspace,
+                       p.splits, (size_t)C, out, accumulate);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+size_t mg_conv_wgrad_workspace(const mg_conv_geom* g) {
+    if (!geom_ok(g)) return 0;
+    const WgradPlan p = wgrad_plan(g);
+    const size_t wg = p.splits > 1 ? (size_t)p.splits * g->Co * g->KH * g->KW * g->Ci * sizeof(float) : 0;
+    const size_t cs = mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co);
+    return (wg > cs ? wg : cs) + 256;
+}
+
+int mg_conv_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias, int accumulate,
+                  void* workspace, size_t workspace_bytes, void* stream) {
+    if (!geom_ok(g) || !x || !dy || !dw) return MG_ERR_ARG;
+    if (workspace_bytes < mg_conv_wgrad_workspace(g) || !workspace) return MG_ERR_ARG;
+    const Geom gg = to_geom(g);
+    hipStream_t st = (hipStream_t)stream;
+    const WgradPlan p = wgrad_plan(g);
+    const bool veca = (g->Co % 4 == 0) && aligned16(dy);
+    const bool vecb = (g->Ci % 4 == 0) && aligned16(x);
+    const size_t n_out = (size_t)g->Co * g->KH * g->KW * g->Ci;
+    float* target = p.splits > 1 ? (float*)workspace : dw;
+    const int acc_direct = (p.splits > 1) ? 0 : accumulate;
+#define MG_LAUNCH_WGRAD(BM_, BN_)                                                                                   \
+    do {                                                                                                            \
+        dim3 grid((unsigned)p.tiles, 1, p.splits);                                                                  \
+        if (veca && vecb)                                                                                           \
+            hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, true, true>), grid, dim3(256), 0, st, gg, x, dy, target, p.cps, acc_direct);  \
+        else if (veca)                                                                                              \
+            hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, true, false>), grid, dim3(256), 0, st, gg, x, dy, target, p.cps, acc_direct); \
+        else if (vecb)                                                                                              \
+            hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, false, true>), grid, dim3(256), 0, st, gg, x, dy, target, p.cps, acc_direct); \
+        else                                                                                                        \
+            hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, false, false>), grid, dim3(256), 0, st, gg, x, dy, target, p.cps, acc_direct);\
+    } while (0)
+    if (p.big) MG_LAUNCH_WGRAD(128, 128);
+    else MG_LAUNCH_WGRAD(64, 64);
+#undef MG_LAUNCH_WGRAD
+    MG_CHECK_LAUNCH();
+    if (p.splits > 1) {
+        const unsigned blocks = (unsigned)((n_out + 255) / 256 > 2048 ? 2048 : (n_out + 255) / 256);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, p.splits,
+                           n_out, dw, accumulate);
+        MG_CHECK_LAUNCH();
+    }
+    if (dbias) {
+        const int rc = mg_colsum(dy, (long long)g->B * g->OH * g->OW, g->Co, dbias, accumulate, workspace,
+                                 workspace_bytes, stream);
+        if (rc != MG_OK) return rc;
+    }
+    return MG_OK;
+}
+
+}  // extern "C"

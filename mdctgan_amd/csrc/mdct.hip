@@ -1,0 +1,332 @@
+// K1 / K2: framed KBD-windowed MDCT / IMDCT (TDAC fold + 256-point DCT-IV as an f32 MFMA
+// contraction) with the arcsinh / range-norm codec and the overlap-add fused in.
+//
+// Replaces the ATen chains of the reference:
+//   K1  models/mdct.py:392-425 (MDCT4.forward)  + models/pix2pixHD_model.py:83-125 (normalize)
+//       + :400-402 (the |x|*2+nr0 second channel)
+//   K2  models/pix2pixHD_model.py:127-137 (denormalize) + models/mdct.py:457-489 (IMDCT4.forward)
+//
+// Geometry: n_fft = win = 2*M, hop = M (M = 256 on the hot path).  One workgroup = 32 frames of
+// one clip = one 32x256x256 GEMM tile; 4 waves, each owning 64 output columns (2 MFMA
+// 32x32 blocks).  A (frames x k) is staged in LDS row-major with a 257-float row pitch (odd ->
+// conflict-free ds_read_b32 for the MFMA A fragment and conflict-free scalar writes);
+// B = the DCT-IV cosine table streams from L2 straight into VGPRs (no inter-wave reuse).
+#include "common.h"
+
+namespace {
+
+constexpr int M = 256;          // bins per frame = hop
+constexpr int FT = 32;          // frames per workgroup
+constexpr int LDA = M + 1;      // LDS row pitch (floats)
+
+enum Codec { CODEC_RAW = 0, CODEC_ARCSINH = 1, CODEC_RANGE = 2 };
+
+struct CodecParams {
+    int mode;            // Codec
+    float gain;          // arcsinh gain
+    float nr0, nr1;      // norm_range
+    float mn, mx;        // src_range when per_sample == 0
+    const float* mn_b;   // per-sample min / max when per_sample == 1 (IMDCT side)
+    const float* mx_b;
+    int per_sample;
+};
+
+constexpr float LN10F = 2.3025851249694824f;   // float32(log(10)), as torch.log(torch.tensor(10.0))
+
+__device__ __forceinline__ float decode(float v, const CodecParams& c, float mn, float mx) {
+    if (c.mode == CODEC_RAW) return v;
+    float l = (v - c.nr0) / (c.nr1 - c.nr0) * (mx - mn) + mn;
+    if (c.mode == CODEC_ARCSINH) return sinhf(l * LN10F) / c.gain;
+    return l;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1.  grid = (ceil(F / 32), B), block = 256.
+//   audio [B, T] -> spec [B, F, 256] (optionally NHWC pair in2 [B, F, 256, 2] = (v, 2|v| + nr0),
+//   optionally windowed frames [B, F, 512], optionally pre-normalisation L plus per-clip min/max
+//   and global sum / sum-of-squares for the returned statistics).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mdct4_kernel(
+    const float* __restrict__ audio, int T, int F, const float* __restrict__ window,
+    const float* __restrict__ dct4, CodecParams cp, float* __restrict__ spec, float* __restrict__ in2,
+    float* __restrict__ frames_out, int defer_norm, unsigned* __restrict__ minmax_ord,
+    double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                    // [(FT + 1) * M] raw padded samples
+    float* us = xs + (FT + 1) * M;       // [FT][LDA] folded, windowed frames (A operand)
+    float* ws = us + FT * LDA;           // [2 * M] window
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, f0 = blockIdx.x * FT;
+    const float* x = audio + (size_t)b * T;
+
+    // stage samples: padded position p = f0*M + i maps to audio index p - M (centre padding)
+    for (int i = tid; i < (FT + 1) * M; i += 256) {
+        const int t = f0 * M + i - M;
+        xs[i] = (t >= 0 && t < T) ? x[t] : 0.0f;
+    }
+    for (int i = tid; i < 2 * M; i += 256) ws[i] = window[i];
+    __syncthreads();
+
+    // windowed frame z_f[n] = fl32(x[f*M + n] * w[n]) (mdct.py:410, float32 like the reference), then the
+    // TDAC fold  u = [-c_r - d, a - b_r]  with quarters a, b, c, d of z.
+    constexpr int Q = M / 2;
+    for (int i = tid; i < FT * M; i += 256) {
+        const int j = i / M, n = i % M;
+        const float* xf = xs + j * M;
+        float u;
+        if (n < Q) {
+            const int n1 = 3 * Q - 1 - n, n2 = 3 * Q + n;
+            u = -__fmul_rn(xf[n1], ws[n1]) - __fmul_rn(xf[n2], ws[n2]);
+        } else {
+            const int m = n - Q, n1 = m, n2 = 2 * Q - 1 - m;
+            u = __fmul_rn(xf[n1], ws[n1]) - __fmul_rn(xf[n2], ws[n2]);
+        }
+        us[j * LDA + n] = (f0 + j < F) ? u : 0.0f;
+    }
+    if (frames_out) {
+        for (int i = tid; i < FT * 2 * M; i += 256) {
+            const int j = i / (2 * M), n = i % (2 * M);
+            if (f0 + j < F) frames_out[((size_t)b * F + f0 + j) * (2 * M) + n] = xs[j * M + n] * ws[n];
+        }
+    }
+    __syncthreads();
+
+    // 32 x 64 (per wave) x 256 contraction on the f32 MFMA pipe
+    f32x16 acc0 = {0}, acc1 = {0};
+    const int arow = lane & 31, khalf = lane >> 5;
+    const float* ap = us + arow * LDA + khalf;
+    const float* bp = dct4 + (size_t)khalf * M + wave * 64 + (lane & 31);
+#pragma unroll 8
+    for (int kp = 0; kp < M / 2; ++kp) {
+        const float a = ap[2 * kp];
+        const float b0 = bp[(size_t)(2 * kp) * M];
+        const float b1 = bp[(size_t)(2 * kp) * M + 32];
+        acc0 = mfma32x32x2(a, b0, acc0);
+        acc1 = mfma32x32x2(a, b1, acc1);
+    }
+
+    // epilogue: codec + stores
+    float mn = cp.mn, mx = cp.mx;
+    double s1 = 0.0, s2 = 0.0;
+    float vmin = INFINITY, vmax = -INFINITY;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = f0 + mfma32_row(r, lane);
+            const int col = wave * 64 + nb * 32 + (lane & 31);
+            const float xv = nb ? acc1[r] : acc0[r];
+            if (f >= F) continue;
+            float l = xv;
+            if (cp.mode == CODEC_ARCSINH) l = asinhf(cp.gain * xv) / LN10F;
+            if (stats && cp.mode != CODEC_RAW) { s1 += (double)l; s2 += (double)l * (double)l; }
+            float v;
+            if (cp.mode == CODEC_RAW) v = xv;
+            else if (defer_norm) { v = l; vmin = fminf(vmin, l); vmax = fmaxf(vmax, l); }
+            else v = (l - mn) / (mx - mn) * (cp.nr1 - cp.nr0) + cp.nr0;
+            const size_t o = ((size_t)b * F + f) * M + col;
+            spec[o] = v;
+            if (in2 && !defer_norm) {
+                float2 pr = make_float2(v, fabsf(v) * 2.0f + cp.nr0);
+                *reinterpret_cast<float2*>(in2 + 2 * o) = pr;
+            }
+        }
+    }
+    if (defer_norm && minmax_ord) {
+        vmin = wave_min(vmin); vmax = wave_max(vmax);
+        if (lane == 0) {
+            atomicMin(minmax_ord + 2 * b, f2ord(vmin));
+            atomicMax(minmax_ord + 2 * b + 1, f2ord(vmax));
+        }
+    }
+    if (stats && cp.mode != CODEC_RAW) {
+        s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+        if (lane == 0) { atomicAdd(stats, s1); atomicAdd(stats + 1, s2); }
+    }
+}
+
+// second pass of the per-sample min/max normalisation (no --abs_norm): in place over spec [B, n]
+__global__ void range_norm_kernel(float* __restrict__ spec, float* __restrict__ in2, int n,
+                                  const unsigned* __restrict__ minmax_ord, float nr0, float nr1,
+                                  float* __restrict__ mn_out, float* __restrict__ mx_out) {
+    const int b = blockIdx.y;
+    const float mn = ord2f(minmax_ord[2 * b]), mx = ord2f(minmax_ord[2 * b + 1]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { mn_out[b] = mn; mx_out[b] = mx; }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const size_t o = (size_t)b * n + i;
+        const float v = (spec[o] - mn) / (mx - mn) * (nr1 - nr0) + nr0;
+        spec[o] = v;
+        if (in2) *reinterpret_cast<float2*>(in2 + 2 * o) = make_float2(v, fabsf(v) * 2.0f + nr0);
+    }
+}
+
+__global__ void fill_u32_pairs(unsigned* p, int n_pairs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pairs) { p[2 * i] = 0xffffffffu; p[2 * i + 1] = 0u; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2.  grid = (ceil(F / 32), B), block = 256.
+//   spec [B, F, 256] (normalised) -> audio [B, (F-1)*256]   (mdct.py:484-486 centre crop)
+//   Workgroup (f0) decodes frames f0 .. f0+31 on the MFMA pipe and frame f0-1 (the halo whose second
+//   half overlaps hop-block f0) as a VALU dot product riding in the MFMA shadow, then emits hop-blocks
+//   h = f0 .. f0+31:  out[(h-1)*M + n] = 4/N * ( w[n] * y_h[n] + w[n+M] * y_{h-1}[n+M] ).
+// ---------------------------------------------------------------------------------------------
+template <typename OutT>
+__global__ __launch_bounds__(256) void imdct4_kernel(
+    const float* __restrict__ spec, int F, const float* __restrict__ window, const float* __restrict__ dct4,
+    CodecParams cp, OutT* __restrict__ audio, int out_len, float* __restrict__ frames_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* as = smem;                     // [(FT + 1)][LDA]: rows 0..31 = frames f0.., row 32 = halo frame f0-1
+    float* ws = as + (FT + 1) * LDA;      // [2 * M]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, f0 = blockIdx.x * FT;
+    float mn = cp.mn, mx = cp.mx;
+    if (cp.per_sample) { mn = cp.mn_b[b]; mx = cp.mx_b[b]; }
+
+    for (int i = tid; i < (FT + 1) * M; i += 256) {
+        const int j = i / M, k = i % M;
+        const int f = (j == FT) ? f0 - 1 : f0 + j;
+        float v = 0.0f;
+        if (f >= 0 && f < F) v = decode(spec[((size_t)b * F + f) * M + k], cp, mn, mx);
+        as[j * LDA + k] = v;
+    }
+    for (int i = tid; i < 2 * M; i += 256) ws[i] = window[i];
+    __syncthreads();
+
+    f32x16 acc0 = {0}, acc1 = {0};
+    float h0 = 0.0f, h1 = 0.0f;
+    const int arow = lane & 31, khalf = lane >> 5;
+    const float* ap = as + arow * LDA + khalf;
+    const float* hp = as + FT * LDA + khalf;
+    const float* bp = dct4 + (size_t)khalf * M + wave * 64 + (lane & 31);
+#pragma unroll 8
+    for (int kp = 0; kp < M / 2; ++kp) {
+        const float a = ap[2 * kp];
+        const float xh = hp[2 * kp];
+        const float b0 = bp[(size_t)(2 * kp) * M];
+        const float b1 = bp[(size_t)(2 * kp) * M + 32];
+        acc0 = mfma32x32x2(a, b0, acc0);
+        acc1 = mfma32x32x2(a, b1, acc1);
+        h0 = fmaf(xh, b0, h0);
+        h1 = fmaf(xh, b1, h1);
+    }
+    h0 += __shfl_xor(h0, 32, 64);
+    h1 += __shfl_xor(h1, 32, 64);
+    __syncthreads();                       // everyone is done reading `as` as the A operand
+
+    // v = DCT-IV(X) back into LDS (same buffer): rows 0..31 frames, row 32 halo
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = mfma32_row(r, lane);
+            as[j * LDA + wave * 64 + nb * 32 + (lane & 31)] = nb ? acc1[r] : acc0[r];
+        }
+    }
+    if (lane < 32) {
+        as[FT * LDA + wave * 64 + lane] = h0;
+        as[FT * LDA + wave * 64 + 32 + lane] = h1;
+    }
+    __syncthreads();
+
+    // unfold y = [v2, -v2_r, -v1_r, -v1], window, overlap-add, scale, centre crop
+    constexpr int Q = M / 2;
+    const float scale = 4.0f / (2 * M);
+    for (int i = tid; i < FT * M; i += 256) {
+        const int j = i / M, n = i % M;
+        const int h = f0 + j;
+        if (h < 1 || h > F - 1) continue;
+        const float* vc = as + j * LDA;                               // frame h
+        const float* vp = as + ((j == 0) ? FT : j - 1) * LDA;         // frame h-1
+        const float yc = (n < Q) ? vc[Q + n] : -vc[3 * Q - 1 - n];     // y_h[n]
+        const float yp = (n < Q) ? -vp[Q - 1 - n] : -vp[n - Q];        // y_{h-1}[n + M]
+        const int t = (h - 1) * M + n;
+        if (t < out_len) audio[(size_t)b * out_len + t] = (OutT)(scale * (ws[n] * yc + ws[n + M] * yp));
+    }
+    if (frames_out) {   // windowed synthesis frames [B, F, 2M] (return_frames=True), mdct.py:473-475
+        for (int i = tid; i < FT * 2 * M; i += 256) {
+            const int j = i / (2 * M), n = i % (2 * M);
+            if (f0 + j >= F) continue;
+            const float* v = as + j * LDA;
+            float y;
+            if (n < Q) y = v[Q + n];
+            else if (n < 2 * Q) y = -v[3 * Q - 1 - n];
+            else if (n < 3 * Q) y = -v[3 * Q - 1 - n];
+            else y = -v[n - 3 * Q];
+            frames_out[((size_t)b * F + f0 + j) * (2 * M) + n] = y * ws[n];
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+size_t mg_mdct4_lds_bytes() { return ((FT + 1) * M + FT * LDA + 2 * M) * sizeof(float); }
+
+// See include/mdctgan_hip.h for the contract.
+int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* window, const float* dct4,
+                     int codec, float gain, float nr0, float nr1, float src_min, float src_max, int per_sample,
+                     float* spec, float* in2, float* frames_out, float* min_out, float* max_out,
+                     double* stats, unsigned* scratch_u32, void* stream) {
+    if (!audio || !window || !dct4 || !spec || B <= 0 || T <= 0) return MG_ERR_ARG;
+    if (n_fft != 2 * M) return MG_ERR_UNSUPPORTED;
+    if (per_sample && (!scratch_u32 || !min_out || !max_out || codec == CODEC_RAW)) return MG_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int pad_tail = (T % M) ? (M - T % M) : 0;
+    const int F = (T + 2 * M + pad_tail - 2 * M) / M + 1;
+    CodecParams cp{codec, gain, nr0, nr1, src_min, src_max, nullptr, nullptr, per_sample};
+    const size_t lds = mg_mdct4_lds_bytes();
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)mdct4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    if (stats) hipMemsetAsync(stats, 0, 2 * sizeof(double), st);
+    if (per_sample) hipLaunchKernelGGL(fill_u32_pairs, dim3((B + 255) / 256), dim3(256), 0, st, scratch_u32, B);
+    dim3 grid((F + FT - 1) / FT, B);
+    hipLaunchKernelGGL(mdct4_kernel, grid, dim3(256), lds, st, audio, T, F, window, dct4, cp, spec, in2,
+                       frames_out, per_sample, scratch_u32, stats);
+    MG_CHECK_LAUNCH();
+    if (per_sample) {
+        hipLaunchKernelGGL(range_norm_kernel, dim3(64, B), dim3(256), 0, st, spec, in2, F * M, scratch_u32, nr0,
+                           nr1, min_out, max_out);
+        MG_CHECK_LAUNCH();
+    }
+    return MG_OK;
+}
+
+int mg_mdct4_num_frames(int T, int n_fft) {
+    const int m = n_fft / 2;
+    const int pad_tail = (T % m) ? (m - T % m) : 0;
+    return (T + pad_tail) / m + 1;
+}
+
+int mg_imdct4_forward(const float* spec, int B, int F, int n_fft, const float* window, const float* dct4,
+                      int codec, float gain, float nr0, float nr1, float src_min, float src_max,
+                      const float* min_b, const float* max_b, void* audio, int out_len, int out_f64,
+                      float* frames_out, void* stream) {
+    if (!spec || !window || !dct4 || !audio || B <= 0 || F <= 0) return MG_ERR_ARG;
+    if (n_fft != 2 * M) return MG_ERR_UNSUPPORTED;
+    if (out_len <= 0 || out_len > (F - 1) * M) return MG_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    CodecParams cp{codec, gain, nr0, nr1, src_min, src_max, min_b, max_b, (min_b && max_b) ? 1 : 0};
+    const size_t lds = ((FT + 1) * LDA + 2 * M) * sizeof(float);
+    dim3 grid((F + FT - 1) / FT, B);
+    if (out_f64)
+        hipLaunchKernelGGL(imdct4_kernel<double>, grid, dim3(256), lds, st, spec, F, window, dct4, cp,
+                           (double*)audio, out_len, frames_out);
+    else
+        hipLaunchKernelGGL(imdct4_kernel<float>, grid, dim3(256), lds, st, spec, F, window, dct4, cp,
+                           (float*)audio, out_len, frames_out);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,509 @@
+// K5 / K7 / K8 / K9 / K11 / K12: InstanceNorm (+activation, +residual) forward/backward, activation
+// backward, pooling / upsampling, discriminator-input assembly, LSGAN / L1 losses, fused Adam.
+// All HBM-bound: float4 (16 B / lane) coalesced NHWC streams, double-precision statistics.
+//
+// Replaces (reference): nn.InstanceNorm2d(affine=False) networks.py:26; ReLU / LeakyReLU(0.2) :306,
+// :650-666; the residual add :462; nn.AvgPool2d(3,2,1,count_include_pad=False) :249-250, :525-526;
+// interpolate(nearest, x2) :396; cat(lr, s, 2|s|+nr0) pix2pixHD_model.py:420-424; MSELoss / L1Loss
+// networks.py:127-137, pix2pixHD_model.py:443-451; torch.optim.Adam pix2pixHD_model.py:350-364.
+#include "common.h"
+#include "mdctgan_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+    if (act == MG_ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == MG_ACT_LRELU02) return v > 0.0f ? v : 0.2f * v;
+    if (act == MG_ACT_TANH) return tanhf(v);
+    return v;
+}
+// derivative given the PRE-activation value
+__device__ __forceinline__ float act_grad_pre(float pre, int act) {
+    if (act == MG_ACT_RELU) return pre > 0.0f ? 1.0f : 0.0f;
+    if (act == MG_ACT_LRELU02) return pre > 0.0f ? 1.0f : 0.2f;
+    return 1.0f;
+}
+// derivative given the POST-activation value
+__device__ __forceinline__ float act_grad_post(float y, int act) {
+    if (act == MG_ACT_RELU) return y > 0.0f ? 1.0f : 0.0f;
+    if (act == MG_ACT_LRELU02) return y > 0.0f ? 1.0f : 0.2f;
+    if (act == MG_ACT_TANH) return 1.0f - y * y;
+    return 1.0f;
+}
+
+struct NormPlan { int cblocks, splits, rows_per_split; };
+NormPlan norm_plan(int B, int HW, int C) {
+    const int cb = (C + 63) / 64;
+    int splits = (2048 + B * cb - 1) / (B * cb);
+    if (splits > (HW + 31) / 32) splits = (HW + 31) / 32;
+    if (splits < 1) splits = 1;
+    int rps = (HW + splits - 1) / splits;
+    splits = (HW + rps - 1) / rps;
+    return {cb, splits, rps};
+}
+
+// partial per-(b, c) sums over a slice of pixels.  MODE 0: (sum x, sum x^2).
+// MODE 1 (backward): g = dy * act'(xhat); (sum g, sum g * xhat).
+template <int MODE>
+__global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, int HW, int C,
+                                                           int rows_per_split, int act, double* __restrict__ part) {
+    __shared__ double red[2][4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, b = blockIdx.y, sp = blockIdx.z;
+    const int p0 = sp * rows_per_split, p1 = min(HW, p0 + rows_per_split);
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        const size_t base = (size_t)b * HW * C + c;
+        float mu = 0.f, rs = 0.f;
+        if (MODE == 1) { mu = mean[b * C + c]; rs = rstd[b * C + c]; }
+        for (int p = p0 + rg; p < p1; p += 4) {
+            const float v = x[base + (size_t)p * C];
+            if (MODE == 0) {
+                s1 += (double)v;
+                s2 += (double)v * (double)v;
+            } else {
+                const float xh = (v - mu) * rs;
+                const float gq = dy[base + (size_t)p * C] * act_grad_pre(xh, act);
+                s1 += (double)gq;
+                s2 += (double)gq * (double)xh;
+            }
+        }
+    }
+    red[0][rg][cl] = s1;
+    red[1][rg][cl] = s2;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        const size_t o = (((size_t)b * gridDim.z + sp) * C + c) * 2;
+        part[o] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+        part[o + 1] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    }
+}
+
+// MODE 0: mean, rstd = 1/sqrt(var_biased + eps).  MODE 1: (sum g)/HW, (sum g*xhat)/HW.
+template <int MODE>
+__global__ void norm_finalize_kernel(const double* __restrict__ part, int B, int S, int C, int HW, float eps,
+                                     float* __restrict__ o1, float* __restrict__ o2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C;
+    double s1 = 0.0, s2 = 0.0;
+    for (int s = 0; s < S; ++s) {
+        const size_t o = (((size_t)b * S + s) * C + c) * 2;
+        s1 += part[o];
+        s2 += part[o + 1];
+    }
+    if (MODE == 0) {
+        const double mu = s1 / HW;
+        double var = s2 / HW - mu * mu;
+        if (var < 0.0) var = 0.0;
+        o1[i] = (float)mu;
+        o2[i] = (float)(1.0 / sqrt(var + (double)eps));
+    } else {
+        o1[i] = (float)(s1 / HW);
+        o2[i] = (float)(s2 / HW);
+    }
+}
+
+template <bool VEC>
+__global__ void norm_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                      const float* __restrict__ rstd, const float* __restrict__ residual, int HW,
+                                      int C, int act, float* __restrict__ y, size_t total) {
+    constexpr int V = VEC ? 4 : 1;
+    const size_t per_b = (size_t)HW * C;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < total;
+         i += (size_t)gridDim.x * blockDim.x * V) {
+        const int b = (int)(i / per_b);
+        const int c = (int)(i % C);
+        if (VEC) {
+            const float4 v = *reinterpret_cast<const float4*>(x + i);
+            const float4 mu = *reinterpret_cast<const float4*>(mean + b * C + c);
+            const float4 rs = *reinterpret_cast<const float4*>(rstd + b * C + c);
+            float4 o;
+            o.x = act_fwd((v.x - mu.x) * rs.x, act);
+            o.y = act_fwd((v.y - mu.y) * rs.y, act);
+            o.z = act_fwd((v.z - mu.z) * rs.z, act);
+            o.w = act_fwd((v.w - mu.w) * rs.w, act);
+            if (residual) {
+                const float4 r = *reinterpret_cast<const float4*>(residual + i);
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            *reinterpret_cast<float4*>(y + i) = o;
+        } else {
+            float o = act_fwd((x[i] - mean[b * C + c]) * rstd[b * C + c], act);
+            if (residual) o += residual[i];
+            y[i] = o;
+        }
+    }
+}
+
+template <bool VEC>
+__global__ void norm_apply_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                      const float* __restrict__ m1, const float* __restrict__ m2, int HW, int C,
+                                      int act, float* __restrict__ dx, size_t total) {
+    constexpr int V = VEC ? 4 : 1;
+    const size_t per_b = (size_t)HW * C;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < total;
+         i += (size_t)gridDim.x * blockDim.x * V) {
+        const int b = (int)(i / per_b);
+        const int c = (int)(i % C);
+        float xv[4], gv[4], o[4];
+        if (VEC) {
+            *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + i);
+            *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(dy + i);
+        } else {
+            xv[0] = x[i];
+            gv[0] = dy[i];
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int sc = b * C + c + j;
+            const float rs = rstd[sc];
+            const float xh = (xv[j] - mean[sc]) * rs;
+            const float gq = gv[j] * act_grad_pre(xh, act);
+            o[j] = rs * (gq - m1[sc] - xh * m2[sc]);
+        }
+        if (VEC) *reinterpret_cast<float4*>(dx + i) = *reinterpret_cast<float4*>(o);
+        else dx[i] = o[0];
+    }
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
+                               size_t n, int act) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dx[i] = dy[i] * act_grad_post(y[i], act);
+}
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        o[i] = a[i] + b[i];
+}
+
+// AvgPool2d(3, stride=2, padding=1, count_include_pad=False)
+__global__ void avgpool_fwd_kernel(const float* __restrict__ x, int B, int H, int W, int C, int OH, int OW,
+                                   float* __restrict__ y) {
+    const size_t total = (size_t)B * OH * OW * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int ox = (int)(r % OW); r /= OW;
+        const int oy = (int)(r % OH);
+        const int b = (int)(r / OH);
+        const int y0 = max(0, 2 * oy - 1), y1 = min(H - 1, 2 * oy + 1);
+        const int x0 = max(0, 2 * ox - 1), x1 = min(W - 1, 2 * ox + 1);
+        float s = 0.0f;
+        for (int yy = y0; yy <= y1; ++yy)
+            for (int xx = x0; xx <= x1; ++xx) s += x[((size_t)(b * H + yy) * W + xx) * C + c];
+        y[i] = s / (float)((y1 - y0 + 1) * (x1 - x0 + 1));
+    }
+}
+__global__ void avgpool_bwd_kernel(const float* __restrict__ dy, int B, int H, int W, int C, int OH, int OW,
+                                   float* __restrict__ dx) {
+    const size_t total = (size_t)B * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int ix = (int)(r % W); r /= W;
+        const int iy = (int)(r % H);
+        const int b = (int)(r / H);
+        float s = 0.0f;
+        for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
+            if (oy >= OH) continue;
+            const int ny = min(H - 1, 2 * oy + 1) - max(0, 2 * oy - 1) + 1;
+            for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
+                if (ox >= OW) continue;
+                const int nx = min(W - 1, 2 * ox + 1) - max(0, 2 * ox - 1) + 1;
+                s += dy[((size_t)(b * OH + oy) * OW + ox) * C + c] / (float)(ny * nx);
+            }
+        }
+        dx[i] = s;
+    }
+}
+
+__global__ void upsample_fwd_kernel(const float* __restrict__ x, int B, int H, int W, int C, float* __restrict__ y) {
+    const size_t total = (size_t)B * 2 * H * 2 * W * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int ox = (int)(r % (2 * W)); r /= (2 * W);
+        const int oy = (int)(r % (2 * H));
+        const int b = (int)(r / (2 * H));
+        y[i] = x[((size_t)(b * H + oy / 2) * W + ox / 2) * C + c];
+    }
+}
+__global__ void upsample_bwd_kernel(const float* __restrict__ dy, int B, int H, int W, int C, float* __restrict__ dx) {
+    const size_t total = (size_t)B * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int ix = (int)(r % W); r /= W;
+        const int iy = (int)(r % H);
+        const int b = (int)(r / H);
+        const size_t o = ((size_t)(b * 2 * H + 2 * iy) * 2 * W + 2 * ix) * C + c;
+        dx[i] = dy[o] + dy[o + C] + dy[o + (size_t)2 * W * C] + dy[o + (size_t)2 * W * C + C];
+    }
+}
+
+__global__ void dinput_fwd_kernel(const float* __restrict__ lr, const float* __restrict__ s, size_t n, float nr0,
+                                  float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = s[i];
+        out[3 * i] = lr[i];
+        out[3 * i + 1] = v;
+        out[3 * i + 2] = fabsf(v) * 2.0f + nr0;
+    }
+}
+__global__ void dinput_bwd_kernel(const float* __restrict__ g, const float* __restrict__ s, size_t n,
+                                  float* __restrict__ ds) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = s[i];
+        const float sg = (v > 0.0f) ? 1.0f : (v < 0.0f ? -1.0f : 0.0f);
+        ds[i] = g[3 * i + 1] + 2.0f * sg * g[3 * i + 2];
+    }
+}
+__global__ void pair_fwd_kernel(const float* __restrict__ s, size_t n, float nr0, float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = s[i];
+        *reinterpret_cast<float2*>(out + 2 * i) = make_float2(v, fabsf(v) * 2.0f + nr0);
+    }
+}
+
+// ---- losses: stage 1 block partials (double), stage 2 fixed-order sum -> deterministic ----
+template <int KIND>   // 0: (p - t)^2   1: |a - b|
+__global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           float target, size_t n, double* __restrict__ part) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float d = a[i] - (KIND == 0 ? target : b[i]);
+        s += (KIND == 0) ? (double)d * (double)d : (double)fabsf(d);
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void loss_final_kernel(const double* __restrict__ part, int nb, double inv_n, float scale,
+                                  float* __restrict__ loss, int accumulate) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nb; ++i) s += part[i];
+        const float v = (float)(s * inv_n) * scale;
+        loss[0] = accumulate ? loss[0] + v : v;
+    }
+}
+template <int KIND>
+__global__ void loss_grad_kernel(const float* __restrict__ a, const float* __restrict__ b, float target, size_t n,
+                                 float coef, const float* __restrict__ go, float* __restrict__ grad) {
+    const float gsc = coef * (go ? go[0] : 1.0f);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float d = a[i] - (KIND == 0 ? target : b[i]);
+        if (KIND == 0) grad[i] = 2.0f * d * gsc;
+        else grad[i] = (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * gsc;
+    }
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, size_t n, float step_size, float b1, float b2, float eps,
+                            float bc2_sqrt, float gscale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);           // lerp, as torch's exp_avg.lerp_(grad, 1-beta1)
+        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;           // mul_(beta2).addcmul_(g, g, 1-beta2)
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+
+inline unsigned grid_for(size_t n, int per_thread = 1) {
+    size_t b = (n + 256 * (size_t)per_thread - 1) / (256 * (size_t)per_thread);
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+size_t mg_instnorm_workspace(int B, int HW, int C) {
+    const NormPlan p = norm_plan(B, HW, C);
+    return ((size_t)B * p.splits * C * 2) * sizeof(double) + (size_t)2 * B * C * sizeof(float) + 256;
+}
+
+int mg_instnorm_fwd(const float* x, int B, int HW, int C, float eps, int act, const float* residual, float* y,
+                    float* mean, float* rstd, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !y || !mean || !rstd || !workspace || B <= 0 || HW <= 0 || C <= 0) return MG_ERR_ARG;
+    if (workspace_bytes < mg_instnorm_workspace(B, HW, C)) return MG_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const NormPlan p = norm_plan(B, HW, C);
+    double* part = (double*)workspace;
+    hipLaunchKernelGGL(norm_partial_kernel<0>, dim3(p.cblocks, B, p.splits), dim3(256), 0, st, x, nullptr, nullptr,
+                       nullptr, HW, C, p.rows_per_split, act, part);
+    hipLaunchKernelGGL(norm_finalize_kernel<0>, dim3((B * C + 255) / 256), dim3(256), 0, st, part, B, p.splits, C, HW,
+                       eps, mean, rstd);
+    const size_t total = (size_t)B * HW * C;
+    const bool vec = (C % 4 == 0) && al16(x) && al16(y) && (!residual || al16(residual));
+    if (vec)
+        hipLaunchKernelGGL(norm_apply_fwd_kernel<true>, dim3(grid_for(total, 4)), dim3(256), 0, st, x, mean, rstd,
+                           residual, HW, C, act, y, total);
+    else
+        hipLaunchKernelGGL(norm_apply_fwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, x, mean, rstd,
+                           residual, HW, C, act, y, total);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+int mg_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, int B, int HW, int C,
+                    int act, float* dx, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dy || !x || !mean || !rstd || !dx || !workspace || B <= 0 || HW <= 0 || C <= 0) return MG_ERR_ARG;
+    if (workspace_bytes < mg_instnorm_workspace(B, HW, C)) return MG_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const NormPlan p = norm_plan(B, HW, C);
+    double* part = (double*)workspace;
+    float* m1 = (float*)((char*)workspace + (size_t)B * p.splits * C * 2 * sizeof(double));
+    float* m2 = m1 + (size_t)B * C;
+    hipLaunchKernelGGL(norm_partial_kernel<1>, dim3(p.cblocks, B, p.splits), dim3(256), 0, st, x, dy, mean, rstd, HW,
+                       C, p.rows_per_split, act, part);
+    hipLaunchKernelGGL(norm_finalize_kernel<1>, dim3((B * C + 255) / 256), dim3(256), 0, st, part, B, p.splits, C, HW,
+                       0.0f, m1, m2);
+    const size_t total = (size_t)B * HW * C;
+    const bool vec = (C % 4 == 0) && al16(x) && al16(dy) && al16(dx);
+    if (vec)
+        hipLaunchKernelGGL(norm_apply_bwd_kernel<true>, dim3(grid_for(total, 4)), dim3(256), 0, st, dy, x, mean, rstd,
+                           m1, m2, HW, C, act, dx, total);
+    else
+        hipLaunchKernelGGL(norm_apply_bwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, dy, x, mean, rstd,
+                           m1, m2, HW, C, act, dx, total);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+int mg_act_bwd(const float* dy, const float* y, float* dx, long long n, int act, void* stream) {
+    if (!dy || !y || !dx || n <= 0) return MG_ERR_ARG;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx,
+                       (size_t)n, act);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+int mg_add(const float* a, const float* b, float* out, long long n, void* stream) {
+    if (!a || !b || !out || n <= 0) return MG_ERR_ARG;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, a, b, out, (size_t)n);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+int mg_avgpool3s2_fwd(const float* x, int B, int H, int W, int C, float* y, void* stream) {
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return MG_ERR_ARG;
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for((size_t)B * OH * OW * C)), dim3(256), 0, (hipStream_t)stream,
+                       x, B, H, W, C, OH, OW, y);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+int mg_avgpool3s2_bwd(const float* dy, int B, int H, int W, int C, float* dx, void* stream) {
+    if (!dy || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0) return MG_ERR_ARG;
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((size_t)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy,
+                       B, H, W, C, OH, OW, dx);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+int mg_upsample2x_fwd(const float* x, int B, int H, int W, int C, float* y, void* stream) {
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return MG_ERR_ARG;
+    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(grid_for((size_t)B * 4 * H * W * C)), dim3(256), 0,
+                       (hipStream_t)stream, x, B, H, W, C, y);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+int mg_upsample2x_bwd(const float* dy, int B, int H, int W, int C, float* dx, void* stream) {
+    if (!dy || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0) return MG_ERR_ARG;
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for((size_t)B * H * W * C)), dim3(256), 0, (hipStream_t)stream,
+                       dy, B, H, W, C, dx);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+int mg_dinput_fwd(const float* lr, const float* s, long long n, float nr0, float* out, void* stream) {
+    if (!lr || !s || !out || n <= 0) return MG_ERR_ARG;
+    hipLaunchKernelGGL(dinput_fwd_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, lr, s,
+                       (size_t)n, nr0, out);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+int mg_dinput_bwd(const float* dout, const float* s, long long n, float* ds, void* stream) {
+    if (!dout || !s || !ds || n <= 0) return MG_ERR_ARG;
+    hipLaunchKernelGGL(dinput_bwd_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, dout, s,
+                       (size_t)n, ds);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+int mg_pair_fwd(const float* s, long long n, float nr0, float* out, void* stream) {
+    if (!s || !out || n <= 0) return MG_ERR_ARG;
+    hipLaunchKernelGGL(pair_fwd_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, s, (size_t)n,
+                       nr0, out);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+size_t mg_loss_workspace(void) { return 1024 * sizeof(double); }
+
+int mg_mse_const_fwd(const float* pred, long long n, float target, float scale, float* loss, int accumulate,
+                     void* workspace, void* stream) {
+    if (!pred || !loss || !workspace || n <= 0) return MG_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    size_t nb = ((size_t)n + 1023) / 1024;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(loss_partial_kernel<0>, dim3((unsigned)nb), dim3(256), 0, st, pred, nullptr, target, (size_t)n,
+                       (double*)workspace);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, (int)nb, 1.0 / (double)n,
+                       scale, loss, accumulate);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+int mg_mse_const_bwd(const float* pred, long long n, float target, float scale, const float* grad_out, float* grad,
+                     void* stream) {
+    if (!pred || !grad || n <= 0) return MG_ERR_ARG;
+    hipLaunchKernelGGL(loss_grad_kernel<0>, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, pred, nullptr,
+                       target, (size_t)n, scale / (float)n, grad_out, grad);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+int mg_l1_fwd(const float* a, const float* b, long long n, float scale, float* loss, int accumulate, void* workspace,
+              void* stream) {
+    if (!a || !b || !loss || !workspace || n <= 0) return MG_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    size_t nb = ((size_t)n + 1023) / 1024;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(loss_partial_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, a, b, 0.0f, (size_t)n,
+                       (double*)workspace);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, (int)nb, 1.0 / (double)n,
+                       scale, loss, accumulate);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+int mg_l1_bwd(const float* a, const float* b, long long n, float scale, const float* grad_out, float* grad_a,
+              void* stream) {
+    if (!a || !b || !grad_a || n <= 0) return MG_ERR_ARG;
+    hipLaunchKernelGGL(loss_grad_kernel<1>, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, a, b, 0.0f,
+                       (size_t)n, scale / (float)n, grad_out, grad_a);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+int mg_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                 float eps, int step, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || step < 1) return MG_ERR_ARG;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for((size_t)n, 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                       (size_t)n, (float)((double)lr / bc1), beta1, beta2, eps, (float)sqrt(bc2), grad_scale);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,165 @@
+"""MDCT4 / IMDCT4 with the reference's call signatures (models/mdct.py:359-489), executed by the
+gfx950 kernels K1 / K2 in csrc/mdct.hip through the C ABI (include/mdctgan_hip.h).
+
+Differences from the reference, all deliberate and documented in DESIGN.md:
+
+* arithmetic is float32 end to end (the DCT-IV runs on the f32 MFMA pipe); the reference promotes to
+  complex128 after its float32 window multiply.  Tolerances: tests/test_mdct_gpu.py.
+* the returned spectrogram / waveform dtype is float32 unless ``dtype=torch.float64`` is requested
+  (then the float32 result is widened, for code that relies on the reference's float64 outputs).
+* frame padding follows the signal length T (the reference uses ``len(signal)`` == batch size for
+  2-D input, SURVEY A2'); identical for every legal segment length (T % hop == 0).
+* supported geometry: win_length == n_fft == 2 * hop_length, n_fft == 512 (the hot path).  Anything
+  else raises NotImplementedError -- there is no eager fallback.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib
+
+
+def kbdwin(N: int, beta: float = 12.0, device="cpu") -> torch.Tensor:
+    """Kaiser-Bessel-derived window (reference: util/util.py:179-186).  Host-side table: built with the
+    same float32 op chain on the CPU so it is bit-identical to the reference's, then moved."""
+    assert N % 2 == 0, "N must be even"
+    w = torch.kaiser_window(window_length=N // 2 + 1, beta=beta * torch.pi, periodic=False, dtype=torch.float32)
+    half = torch.sqrt(torch.cumsum(w, dim=0) / w.sum())[:-1]
+    return torch.cat((half, half.flip(dims=(0,))), dim=0).to(device)
+
+
+_dct4_cache = {}
+
+
+def dct4_table(m: int, device) -> torch.Tensor:
+    """D4[n, k] = cos(pi/M (n + 1/2)(k + 1/2)) evaluated in float64 on the host, rounded once to float32."""
+    key = (m, str(device))
+    t = _dct4_cache.get(key)
+    if t is None:
+        n = torch.arange(m, dtype=torch.float64) + 0.5
+        t = torch.cos((math.pi / m) * torch.outer(n, n)).to(torch.float32).to(device).contiguous()
+        _dct4_cache[key] = t
+    return t
+
+
+def _make_window(window, win_length, device):
+    if window is None:
+        window = torch.ones
+    if callable(window):
+        win_length = int(win_length)
+        w = window(win_length)
+    else:
+        w = window
+        win_length = len(window)
+    return w.to(device=device, dtype=torch.float32).contiguous(), win_length
+
+
+def _check_geometry(n_fft, hop_length, win_length):
+    assert win_length <= n_fft, "Window lenth %d should be no more than fft length %d" % (win_length, n_fft)
+    assert hop_length <= win_length, "You hopped more than one frame"
+    if not (n_fft == 512 and win_length == n_fft and hop_length * 2 == n_fft):
+        raise NotImplementedError(
+            "HIP MDCT kernels cover n_fft == win_length == 2*hop_length == 512 (got n_fft=%d win=%d hop=%d)"
+            % (n_fft, win_length, hop_length))
+
+
+def mdct4_codec(audio, window, dct4, n_fft, *, codec=_lib.MG_CODEC_RAW, gain=1.0, norm_range=(0.0, 1.0),
+                src_range=(0.0, 1.0), per_sample=False, want_pair=False, want_frames=False, want_stats=False):
+    """K1 launcher.  audio [B, T] (device, float32) -> dict(spec [B,F,M], pair [B,F,M,2]|None, frames|None,
+    min/max [B]|None, stats double[2]|None)."""
+    lib = _lib.load()
+    audio = _lib.f32c(audio)
+    B, T = audio.shape
+    M = n_fft // 2
+    F = lib.mg_mdct4_num_frames(T, n_fft)
+    dev = audio.device
+    spec = torch.empty(B, F, M, dtype=torch.float32, device=dev)
+    pair = torch.empty(B, F, M, 2, dtype=torch.float32, device=dev) if want_pair else None
+    frames = torch.empty(B, F, n_fft, dtype=torch.float32, device=dev) if want_frames else None
+    stats = torch.empty(2, dtype=torch.float64, device=dev) if want_stats else None
+    mn = mx = scratch = None
+    if per_sample:
+        mn = torch.empty(B, dtype=torch.float32, device=dev)
+        mx = torch.empty(B, dtype=torch.float32, device=dev)
+        scratch = torch.empty(2 * B, dtype=torch.int32, device=dev)
+    rc = lib.mg_mdct4_forward(_lib.ptr(audio), B, T, n_fft, _lib.ptr(window), _lib.ptr(dct4), codec, gain,
+                              norm_range[0], norm_range[1], src_range[0], src_range[1], int(per_sample),
+                              _lib.ptr(spec), _lib.ptr(pair), _lib.ptr(frames), _lib.ptr(mn), _lib.ptr(mx),
+                              _lib.ptr(stats), _lib.ptr(scratch), _lib.stream())
+    _lib.check(rc, "mg_mdct4_forward")
+    return {"spec": spec, "pair": pair, "frames": frames, "min": mn, "max": mx, "stats": stats}
+
+
+def imdct4_codec(spec, window, dct4, n_fft, *, codec=_lib.MG_CODEC_RAW, gain=1.0, norm_range=(0.0, 1.0),
+                 src_range=(0.0, 1.0), min_b=None, max_b=None, out_length=None, out_dtype=torch.float32,
+                 want_frames=False):
+    """K2 launcher.  spec [B, F, M] (device) -> (audio [B, T_out], frames|None)."""
+    lib = _lib.load()
+    spec = _lib.f32c(spec)
+    B, F, M = spec.shape
+    t_out = (F - 1) * M
+    if out_length is not None:
+        t_out = min(t_out, int(out_length))
+    audio = torch.empty(B, t_out, dtype=out_dtype, device=spec.device)
+    frames = torch.empty(B, F, n_fft, dtype=torch.float32, device=spec.device) if want_frames else None
+    if min_b is not None:
+        min_b, max_b = _lib.f32c(min_b.reshape(-1)), _lib.f32c(max_b.reshape(-1))
+        assert min_b.numel() == B and max_b.numel() == B
+    rc = lib.mg_imdct4_forward(_lib.ptr(spec), B, F, n_fft, _lib.ptr(window), _lib.ptr(dct4), codec, gain,
+                               norm_range[0], norm_range[1], src_range[0], src_range[1], _lib.ptr(min_b),
+                               _lib.ptr(max_b), _lib.ptr(audio), t_out, int(out_dtype == torch.float64),
+                               _lib.ptr(frames), _lib.stream())
+    _lib.check(rc, "mg_imdct4_forward")
+    return audio, frames
+
+
+class MDCT4(torch.nn.Module):
+    """models/mdct.py:359-425.  forward(signal, return_frames=False) -> (spec [..., F, n_fft/2], frames)."""
+
+    def __init__(self, n_fft=2048, hop_length=None, win_length=None, window=None, center=True,
+                 pad_mode="constant", device="cuda", dtype=torch.float32) -> None:
+        super().__init__()
+        self.n_fft, self.pad_mode, self.device, self.hop_length, self.center = n_fft, pad_mode, device, hop_length, center
+        self.window, self.win_length = _make_window(window, win_length, device)
+        _check_geometry(self.n_fft, self.hop_length, self.win_length)
+        if not center or pad_mode != "constant":
+            raise NotImplementedError("HIP MDCT4 implements center=True with zero ('constant') padding")
+        self.out_dtype = dtype
+
+    def forward(self, signal, return_frames: bool = False):
+        lead = signal.shape[:-1]
+        x = signal.reshape(-1, signal.shape[-1])
+        if self.window.device != x.device:
+            self.window = self.window.to(x.device)
+        r = mdct4_codec(x, self.window, dct4_table(self.n_fft // 2, x.device), self.n_fft, want_frames=return_frames)
+        spec = r["spec"].reshape(*lead, *r["spec"].shape[1:]).to(self.out_dtype)
+        frames = r["frames"].reshape(*lead, *r["frames"].shape[1:]) if return_frames else torch.empty(1)
+        return spec, frames
+
+
+class IMDCT4(torch.nn.Module):
+    """models/mdct.py:428-489.  forward(spec [B, F, n_fft/2], return_frames=False) -> (audio [B,1,1,T], frames)."""
+
+    def __init__(self, n_fft=2048, hop_length=None, win_length=None, window=None, center=True,
+                 pad_mode="constant", out_length=None, device="cuda", dtype=torch.float32) -> None:
+        super().__init__()
+        self.n_fft, self.pad_mode, self.device, self.hop_length = n_fft, pad_mode, device, hop_length
+        self.center, self.out_length = center, out_length
+        self.window, self.win_length = _make_window(window, win_length, device)
+        _check_geometry(self.n_fft, self.hop_length, self.win_length)
+        if not center:
+            raise NotImplementedError("HIP IMDCT4 implements center=True")
+        self.out_dtype = dtype
+
+    def forward(self, signal, return_frames: bool = False):
+        assert signal.dim() == 3, "Only tensors shaped in BHW are supported, got tensor of shape %s" % (
+            str(signal.size()))
+        assert signal.size()[-1] == self.n_fft // 2, \
+            "The last dim of input tensor should match the n_fft. Expected %d ,got %d" % (self.n_fft, signal.size()[-1])
+        if self.window.device != signal.device:
+            self.window = self.window.to(signal.device)
+        audio, frames = imdct4_codec(signal, self.window, dct4_table(self.n_fft // 2, signal.device), self.n_fft,
+                                     out_length=self.out_length, out_dtype=self.out_dtype, want_frames=return_frames)
+        return audio[:, None, None, :], (frames if return_frames else torch.zeros(1))

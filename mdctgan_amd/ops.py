@@ -1,0 +1,184 @@
+"""Thin launchers over the C ABI (one Python function per entry point of include/mdctgan_hip.h).
+Tensors are float32, contiguous, NHWC, resident in HBM.  No arithmetic happens here."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LRELU02, ACT_NONE, ACT_RELU, ACT_TANH, ConvGeom  # noqa: F401
+
+
+def conv_geom(B, H, W, Ci, Co, KH, KW, stride, pad, reflect) -> ConvGeom:
+    OH = (H + 2 * pad - KH) // stride + 1
+    OW = (W + 2 * pad - KW) // stride + 1
+    return ConvGeom(B, H, W, Ci, OH, OW, Co, KH, KW, stride, pad, int(bool(reflect)))
+
+
+def _ws(nbytes, dev):
+    return _lib.workspace(nbytes, dev)
+
+
+def conv_fwd(g: ConvGeom, x, w, bias=None, act=ACT_NONE):
+    lib = _lib.load()
+    y = torch.empty(g.B, g.OH, g.OW, g.Co, dtype=torch.float32, device=x.device)
+    _lib.check(lib.mg_conv_fwd(g, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), act, _lib.stream()),
+               "mg_conv_fwd")
+    return y
+
+
+def conv_dgrad(g: ConvGeom, dy, w, bias=None, act=ACT_NONE):
+    lib = _lib.load()
+    dx = torch.empty(g.B, g.H, g.W, g.Ci, dtype=torch.float32, device=dy.device)
+    _lib.check(lib.mg_conv_dgrad(g, _lib.ptr(dy), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(dx), act, _lib.stream()),
+               "mg_conv_dgrad")
+    return dx
+
+
+def conv_wgrad(g: ConvGeom, x, dy, dw, dbias=None, accumulate=False):
+    """dw: float32 buffer of Co*KH*KW*Ci elements in OHWI order (written / accumulated in place)."""
+    lib = _lib.load()
+    nbytes = lib.mg_conv_wgrad_workspace(g)
+    ws = _ws(nbytes, x.device)
+    _lib.check(lib.mg_conv_wgrad(g, _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(dbias), int(accumulate),
+                                 _lib.ptr(ws), ws.numel(), _lib.stream()), "mg_conv_wgrad")
+
+
+def colsum(a2d, out, accumulate=False):
+    lib = _lib.load()
+    M, Cc = a2d.shape
+    ws = _ws(lib.mg_colsum_workspace(M, Cc), a2d.device)
+    _lib.check(lib.mg_colsum(_lib.ptr(a2d), M, Cc, _lib.ptr(out), int(accumulate), _lib.ptr(ws), ws.numel(),
+                             _lib.stream()), "mg_colsum")
+
+
+def instnorm_fwd(x, act=ACT_NONE, residual=None, eps=1e-5):
+    """x [B, H, W, C] -> (y, mean [B,C], rstd [B,C])."""
+    lib = _lib.load()
+    B, H, W, Cc = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+    ws = _ws(lib.mg_instnorm_workspace(B, H * W, Cc), x.device)
+    _lib.check(lib.mg_instnorm_fwd(_lib.ptr(x), B, H * W, Cc, eps, act, _lib.ptr(residual), _lib.ptr(y),
+                                   _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(ws), ws.numel(), _lib.stream()),
+               "mg_instnorm_fwd")
+    return y, mean, rstd
+
+
+def instnorm_bwd(dy, x, mean, rstd, act=ACT_NONE):
+    lib = _lib.load()
+    B, H, W, Cc = x.shape
+    dx = torch.empty_like(x)
+    ws = _ws(lib.mg_instnorm_workspace(B, H * W, Cc), x.device)
+    _lib.check(lib.mg_instnorm_bwd(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), B, H * W, Cc, act,
+                                   _lib.ptr(dx), _lib.ptr(ws), ws.numel(), _lib.stream()), "mg_instnorm_bwd")
+    return dx
+
+
+def act_bwd(dy, y, act, out=None):
+    lib = _lib.load()
+    out = torch.empty_like(dy) if out is None else out
+    _lib.check(lib.mg_act_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(out), dy.numel(), act, _lib.stream()), "mg_act_bwd")
+    return out
+
+
+def add(a, b, out=None):
+    lib = _lib.load()
+    out = torch.empty_like(a) if out is None else out
+    _lib.check(lib.mg_add(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), a.numel(), _lib.stream()), "mg_add")
+    return out
+
+
+def avgpool_fwd(x):
+    lib = _lib.load()
+    B, H, W, Cc = x.shape
+    y = torch.empty(B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc, dtype=torch.float32, device=x.device)
+    _lib.check(lib.mg_avgpool3s2_fwd(_lib.ptr(x), B, H, W, Cc, _lib.ptr(y), _lib.stream()), "mg_avgpool3s2_fwd")
+    return y
+
+
+def avgpool_bwd(dy, in_shape):
+    lib = _lib.load()
+    B, H, W, Cc = in_shape
+    dx = torch.empty(B, H, W, Cc, dtype=torch.float32, device=dy.device)
+    _lib.check(lib.mg_avgpool3s2_bwd(_lib.ptr(dy), B, H, W, Cc, _lib.ptr(dx), _lib.stream()), "mg_avgpool3s2_bwd")
+    return dx
+
+
+def upsample_fwd(x):
+    lib = _lib.load()
+    B, H, W, Cc = x.shape
+    y = torch.empty(B, 2 * H, 2 * W, Cc, dtype=torch.float32, device=x.device)
+    _lib.check(lib.mg_upsample2x_fwd(_lib.ptr(x), B, H, W, Cc, _lib.ptr(y), _lib.stream()), "mg_upsample2x_fwd")
+    return y
+
+
+def upsample_bwd(dy):
+    lib = _lib.load()
+    B, H2, W2, Cc = dy.shape
+    dx = torch.empty(B, H2 // 2, W2 // 2, Cc, dtype=torch.float32, device=dy.device)
+    _lib.check(lib.mg_upsample2x_bwd(_lib.ptr(dy), B, H2 // 2, W2 // 2, Cc, _lib.ptr(dx), _lib.stream()),
+               "mg_upsample2x_bwd")
+    return dx
+
+
+def dinput_fwd(lr, s, nr0):
+    """lr, s: [B, H, W] or [B, H, W, 1] -> [B, H, W, 3] = (lr, s, 2|s| + nr0)."""
+    lib = _lib.load()
+    B, H, W = s.shape[:3]
+    out = torch.empty(B, H, W, 3, dtype=torch.float32, device=s.device)
+    _lib.check(lib.mg_dinput_fwd(_lib.ptr(lr), _lib.ptr(s), s.numel(), nr0, _lib.ptr(out), _lib.stream()),
+               "mg_dinput_fwd")
+    return out
+
+
+def dinput_bwd(dout, s):
+    lib = _lib.load()
+    ds = torch.empty_like(s)
+    _lib.check(lib.mg_dinput_bwd(_lib.ptr(dout), _lib.ptr(s), s.numel(), _lib.ptr(ds), _lib.stream()),
+               "mg_dinput_bwd")
+    return ds
+
+
+def pair_fwd(s, nr0):
+    lib = _lib.load()
+    B, H, W = s.shape[:3]
+    out = torch.empty(B, H, W, 2, dtype=torch.float32, device=s.device)
+    _lib.check(lib.mg_pair_fwd(_lib.ptr(s), s.numel(), nr0, _lib.ptr(out), _lib.stream()), "mg_pair_fwd")
+    return out
+
+
+def mse_const_fwd(pred, target, scale, loss, accumulate):
+    lib = _lib.load()
+    ws = _ws(lib.mg_loss_workspace(), pred.device)
+    _lib.check(lib.mg_mse_const_fwd(_lib.ptr(pred), pred.numel(), target, scale, _lib.ptr(loss), int(accumulate),
+                                    _lib.ptr(ws), _lib.stream()), "mg_mse_const_fwd")
+
+
+def mse_const_bwd(pred, target, scale, grad_out):
+    lib = _lib.load()
+    g = torch.empty_like(pred)
+    _lib.check(lib.mg_mse_const_bwd(_lib.ptr(pred), pred.numel(), target, scale, _lib.ptr(grad_out), _lib.ptr(g),
+                                    _lib.stream()), "mg_mse_const_bwd")
+    return g
+
+
+def l1_fwd(a, b, scale, loss, accumulate):
+    lib = _lib.load()
+    ws = _ws(lib.mg_loss_workspace(), a.device)
+    _lib.check(lib.mg_l1_fwd(_lib.ptr(a), _lib.ptr(b), a.numel(), scale, _lib.ptr(loss), int(accumulate),
+                             _lib.ptr(ws), _lib.stream()), "mg_l1_fwd")
+
+
+def l1_bwd(a, b, scale, grad_out):
+    lib = _lib.load()
+    g = torch.empty_like(a)
+    _lib.check(lib.mg_l1_bwd(_lib.ptr(a), _lib.ptr(b), a.numel(), scale, _lib.ptr(grad_out), _lib.ptr(g),
+                             _lib.stream()), "mg_l1_bwd")
+    return g
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    lib = _lib.load()
+    _lib.check(lib.mg_adam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), p.numel(), lr, beta1, beta2, eps,
+                                step, grad_scale, _lib.stream()), "mg_adam_step")

@@ -1,0 +1,67 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/mdctgan_hip.h declares;
+the ctypes binding table covers exactly that set.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from mdctgan_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(REPO, "include", "mdctgan_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_table_agree():
+    syms = header_symbols()
+    assert len(syms) >= 25
+    assert sorted(_lib.SIGNATURES) == syms
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        from mdctgan_amd import build
+        build.build_hip(verbose=False)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for s in header_symbols():
+        assert hasattr(lib, s), s
+    assert _lib.load().mg_abi_version() == 1
+    assert _lib.load().mg_mdct4_num_frames(32512, 512) == 128
+    assert _lib.load().mg_mdct4_num_frames(7936, 512) == 32
+
+
+def test_host_tensors_are_refused():
+    import torch
+    with pytest.raises(_lib.HipLibraryError):
+        _lib.ptr(torch.zeros(4))
+    from mdctgan_amd.mdct import MDCT4, kbdwin
+    m = MDCT4(512, 256, 512, kbdwin, device="cpu")
+    with pytest.raises(_lib.HipLibraryError):
+        m(torch.zeros(2, 7936))
+
+
+def test_unsupported_geometry_raises():
+    from mdctgan_amd.mdct import IMDCT4, MDCT4, kbdwin
+    with pytest.raises(NotImplementedError):
+        MDCT4(2048, 512, 2048, kbdwin, device="cpu")
+    with pytest.raises(AssertionError):
+        MDCT4(512, 256, 1024, kbdwin, device="cpu")        # window longer than n_fft (mdct.py:383)
+    im = IMDCT4(512, 256, 512, kbdwin, device="cpu")
+    import torch
+    with pytest.raises(AssertionError):
+        im(torch.zeros(2, 256))                              # mdct.py:458
+    with pytest.raises(AssertionError):
+        im(torch.zeros(1, 4, 255))                           # mdct.py:460
+
+
+def test_kbdwin_is_the_reference_window(golden):
+    import numpy as np
+    from mdctgan_amd.mdct import kbdwin
+    g = golden("g1_kbdwin")
+    np.testing.assert_array_equal(kbdwin(512).numpy(), g["w512"])
+    np.testing.assert_array_equal(kbdwin(1024).numpy(), g["w1024"])

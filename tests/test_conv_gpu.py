@@ -1,0 +1,122 @@
+"""K3/K4/K6 implicit-GEMM convolution kernels (csrc/conv_igemm.hip) through the C ABI against a plain
+PyTorch float64 CPU evaluation of the same nn.Conv2d / nn.ConvTranspose2d / nn.ReflectionPad2d op.
+Tolerance: float32 accumulation over K terms -> 3e-5 * max|ref| (exact-f32 MFMA, K <= ~10^4)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+# (name, B, Ci, H, W, Co, k, stride, pad, reflect)
+CONV_CASES = [
+    ("res3x3_reflect", 2, 32, 8, 16, 32, 3, 1, 1, True),
+    ("res3x3_reflect_tiny", 3, 16, 2, 16, 16, 3, 1, 1, True),
+    ("stem7x7_reflect_ci2", 2, 2, 32, 64, 16, 7, 1, 3, True),
+    ("head7x7_reflect_co1", 2, 16, 32, 64, 1, 7, 1, 3, True),
+    ("down3x3_s2", 2, 16, 32, 64, 32, 3, 2, 1, False),
+    ("down3x3_s2_odd", 1, 16, 17, 33, 32, 3, 2, 1, False),
+    ("d4x4_s2_ci3", 2, 3, 32, 64, 16, 4, 2, 2, False),
+    ("d4x4_s2", 2, 16, 17, 33, 32, 4, 2, 2, False),
+    ("d4x4_s1", 2, 32, 5, 9, 64, 4, 1, 2, False),
+    ("d4x4_s1_co1", 2, 64, 6, 10, 1, 4, 1, 2, False),
+    ("conv5x5_p2", 1, 16, 12, 20, 24, 5, 1, 2, False),
+    ("conv5x5_p1", 1, 16, 12, 20, 24, 5, 1, 1, False),
+    ("conv3x3_p2", 1, 24, 12, 20, 16, 3, 1, 2, False),
+    ("conv1x1", 2, 64, 4, 8, 48, 1, 1, 0, False),
+    ("wide_128tile", 2, 64, 16, 32, 256, 3, 1, 1, True),
+    ("bottleneck_like", 8, 128, 8, 16, 128, 3, 1, 1, True),
+]
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def ref_conv(x, w, b, stride, pad, reflect):
+    if reflect and pad > 0:
+        x = F.pad(x, (pad, pad, pad, pad), mode="reflect")
+        pad = 0
+    return F.conv2d(x, w, b, stride=stride, padding=pad)
+
+
+def rel_err(got, want):
+    return (got.double().cpu() - want).abs().max().item() / max(want.abs().max().item(), 1e-30)
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(case):
+    from mdctgan_amd import ops
+    name, B, Ci, H, W, Co, k, s, p, reflect = case
+    gen = torch.Generator().manual_seed(hash(name) % 1000)
+    x = torch.randn(B, Ci, H, W, generator=gen, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Co, Ci, k, k, generator=gen, dtype=torch.float64) / np.sqrt(Ci * k * k)).requires_grad_()
+    b = torch.randn(Co, generator=gen, dtype=torch.float64, requires_grad=True)
+    y = ref_conv(x, w, b, s, p, reflect)
+    gy = torch.randn(y.shape, generator=gen, dtype=torch.float64)
+    y.backward(gy)
+
+    g = ops.conv_geom(B, H, W, Ci, Co, k, k, s, p, reflect)
+    assert (g.OH, g.OW) == tuple(y.shape[2:])
+    xd, wd, bd = nhwc(x.detach()).float().to(DEV), nhwc(w.detach()).float().to(DEV), b.detach().float().to(DEV)
+    gyd = nhwc(gy).float().to(DEV)
+    yd = ops.conv_fwd(g, xd, wd, bd)
+    assert rel_err(yd, nhwc(y.detach())) < 3e-5
+    dxd = ops.conv_dgrad(g, gyd, wd)
+    assert rel_err(dxd, nhwc(x.grad)) < 3e-5
+    dw = torch.full((Co, k, k, Ci), 7.0, dtype=torch.float32, device=DEV)
+    db = torch.full((Co,), 7.0, dtype=torch.float32, device=DEV)
+    ops.conv_wgrad(g, xd, gyd, dw, db)
+    assert rel_err(dw, nhwc(w.grad)) < 3e-5
+    assert rel_err(db, b.grad) < 3e-5
+    ops.conv_wgrad(g, xd, gyd, dw, db, accumulate=True)
+    assert rel_err(dw, 2 * nhwc(w.grad)) < 3e-5
+    assert rel_err(db, 2 * b.grad) < 3e-5
+
+
+def test_conv_fwd_fused_activations():
+    from mdctgan_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 16, 9, 13, generator=gen, dtype=torch.float64)
+    w = torch.randn(8, 16, 3, 3, generator=gen, dtype=torch.float64) / 12
+    b = torch.randn(8, generator=gen, dtype=torch.float64)
+    y = F.conv2d(x, w, b, padding=1)
+    g = ops.conv_geom(2, 9, 13, 16, 8, 3, 3, 1, 1, False)
+    xd, wd, bd = nhwc(x).float().to(DEV), nhwc(w).float().to(DEV), b.float().to(DEV)
+    for act, fn in ((ops.ACT_LRELU02, lambda t: F.leaky_relu(t, 0.2)), (ops.ACT_TANH, torch.tanh),
+                    (ops.ACT_RELU, torch.relu)):
+        assert rel_err(ops.conv_fwd(g, xd, wd, bd, act), nhwc(fn(y))) < 3e-5
+
+
+CONVT_CASES = [("up3x3", 2, 32, 8, 16, 16), ("up3x3_odd", 1, 16, 5, 7, 32), ("up_big", 2, 128, 16, 32, 64)]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES, ids=[c[0] for c in CONVT_CASES])
+def test_conv_transpose(case):
+    """nn.ConvTranspose2d(k3, s2, p1, output_padding=1) == the data-gradient kernel of the stride-2 conv."""
+    from mdctgan_amd import ops
+    name, B, Cin, h, w_, Cout = case
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(B, Cin, h, w_, generator=gen, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Cin, Cout, 3, 3, generator=gen, dtype=torch.float64) / np.sqrt(Cin * 9)).requires_grad_()
+    b = torch.randn(Cout, generator=gen, dtype=torch.float64, requires_grad=True)
+    y = F.conv_transpose2d(x, w, b, stride=2, padding=1, output_padding=1)
+    gy = torch.randn(y.shape, generator=gen, dtype=torch.float64)
+    y.backward(gy)
+    # equivalent convolution: high-res [B, 2h, 2w, Cout] --3x3 s2 p1--> low-res [B, h, w, Cin]
+    g = ops.conv_geom(B, 2 * h, 2 * w_, Cout, Cin, 3, 3, 2, 1, False)
+    assert (g.OH, g.OW) == (h, w_)
+    xd, gyd = nhwc(x.detach()).float().to(DEV), nhwc(gy).float().to(DEV)
+    wd = nhwc(w.detach()).float().to(DEV)          # [Cin_T, kh, kw, Cout_T] == OHWI of the equivalent conv
+    bd = b.detach().float().to(DEV)
+    yd = ops.conv_dgrad(g, xd, wd, bd)
+    assert rel_err(yd, nhwc(y.detach())) < 3e-5
+    dxd = ops.conv_fwd(g, gyd, wd)                 # input gradient of the transposed conv == forward conv
+    assert rel_err(dxd, nhwc(x.grad)) < 3e-5
+    dw = torch.empty(Cin, 3, 3, Cout, dtype=torch.float32, device=DEV)
+    ops.conv_wgrad(g, gyd, xd, dw)                 # roles swapped: "x" = high-res grad, "dy" = low-res input
+    assert rel_err(dw, nhwc(w.grad)) < 3e-5
+    db = torch.empty(Cout, dtype=torch.float32, device=DEV)
+    ops.colsum(gyd.reshape(-1, Cout), db)
+    assert rel_err(db, b.grad) < 3e-5

@@ -1,0 +1,110 @@
+"""K5/K7/K8/K9/K11/K12 kernels (csrc/norm_act.hip) against plain PyTorch float64 CPU references."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def rel_err(got, want):
+    return (got.double().cpu() - want).abs().max().item() / max(want.abs().max().item(), 1e-30)
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 8, 16), (3, 5, 7, 9), (2, 64, 32, 64), (8, 256, 8, 16), (2, 1, 19, 35)])
+@pytest.mark.parametrize("act", ["none", "relu", "lrelu"])
+def test_instnorm_fwd_bwd(shape, act):
+    from mdctgan_amd import ops
+    code = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU02}[act]
+    fn = {"none": lambda t: t, "relu": torch.relu, "lrelu": lambda t: F.leaky_relu(t, 0.2)}[act]
+    gen = torch.Generator().manual_seed(1)
+    x = (torch.randn(*shape, generator=gen, dtype=torch.float64) * 3 + 1.5).requires_grad_()
+    res = torch.randn(*shape, generator=gen, dtype=torch.float64)
+    y = fn(F.instance_norm(x, eps=1e-5)) + res
+    gy = torch.randn(*shape, generator=gen, dtype=torch.float64)
+    y.backward(gy)
+    xd, rd, gyd = nhwc(x.detach()).float().to(DEV), nhwc(res).float().to(DEV), nhwc(gy).float().to(DEV)
+    yd, mean, rstd = ops.instnorm_fwd(xd, code, rd)
+    assert rel_err(yd, nhwc(y.detach())) < 1e-5
+    dxd = ops.instnorm_bwd(gyd, xd, mean, rstd, code)
+    assert rel_err(dxd, nhwc(x.grad)) < 2e-5
+    y2, _, _ = ops.instnorm_fwd(xd, code, None)
+    assert rel_err(y2, nhwc((y - res).detach())) < 1e-5
+
+
+def test_act_bwd_add_pool_upsample():
+    from mdctgan_amd import ops
+    gen = torch.Generator().manual_seed(2)
+    for shape in [(2, 3, 32, 64), (1, 8, 17, 33), (2, 4, 5, 6)]:
+        x = torch.randn(*shape, generator=gen, dtype=torch.float64, requires_grad=True)
+        y = F.avg_pool2d(x, 3, stride=2, padding=1, count_include_pad=False)
+        gy = torch.randn(y.shape, generator=gen, dtype=torch.float64)
+        y.backward(gy)
+        xd = nhwc(x.detach()).float().to(DEV)
+        yd = ops.avgpool_fwd(xd)
+        assert yd.shape == nhwc(y).shape and rel_err(yd, nhwc(y.detach())) < 1e-6
+        dxd = ops.avgpool_bwd(nhwc(gy).float().to(DEV), xd.shape)
+        assert rel_err(dxd, nhwc(x.grad)) < 1e-6
+        x.grad = None
+        u = F.interpolate(x, scale_factor=2.0, mode="nearest")
+        gu = torch.randn(u.shape, generator=gen, dtype=torch.float64)
+        u.backward(gu)
+        assert rel_err(ops.upsample_fwd(xd), nhwc(u.detach())) == 0
+        assert rel_err(ops.upsample_bwd(nhwc(gu).float().to(DEV)), nhwc(x.grad)) < 1e-6
+    a = torch.randn(1000, generator=gen).to(DEV)
+    b = torch.randn(1000, generator=gen).to(DEV)
+    assert torch.equal(ops.add(a, b), a + b)
+    for act, f in ((ops.ACT_TANH, torch.tanh), (ops.ACT_LRELU02, lambda t: F.leaky_relu(t, 0.2))):
+        pre = torch.randn(1000, generator=gen, dtype=torch.float64, requires_grad=True)
+        yy = f(pre)
+        gg = torch.randn(1000, generator=gen, dtype=torch.float64)
+        yy.backward(gg)
+        got = ops.act_bwd(gg.float().to(DEV), yy.detach().float().to(DEV), act)
+        assert rel_err(got, pre.grad) < 1e-5
+
+
+def test_dinput_pair_losses_adam():
+    from mdctgan_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    lr = torch.randn(2, 8, 16, generator=gen, dtype=torch.float64)
+    s = torch.randn(2, 8, 16, generator=gen, dtype=torch.float64, requires_grad=True)
+    out = torch.stack((lr, s, s.abs() * 2 - 1), dim=-1)
+    go = torch.randn(out.shape, generator=gen, dtype=torch.float64)
+    out.backward(go)
+    od = ops.dinput_fwd(lr.float().to(DEV), s.detach().float().to(DEV), -1.0)
+    assert rel_err(od, out.detach()) < 1e-6
+    assert rel_err(ops.dinput_bwd(go.float().to(DEV), s.detach().float().to(DEV)), s.grad) < 1e-6
+    pr = ops.pair_fwd(s.detach().float().to(DEV), -1.0)
+    assert rel_err(pr, out.detach()[..., 1:]) < 1e-6
+    # losses
+    for n in (37, 5320, 300000):
+        a = torch.randn(n, generator=gen, dtype=torch.float64, requires_grad=True)
+        b = torch.randn(n, generator=gen, dtype=torch.float64)
+        la = 0.7 * F.mse_loss(a, torch.ones_like(a)) + 1.3 * F.l1_loss(a, b)
+        la.backward()
+        ad, bd = a.detach().float().to(DEV), b.float().to(DEV)
+        loss = torch.zeros(1, device=DEV)
+        ops.mse_const_fwd(ad, 1.0, 0.7, loss, False)
+        ops.l1_fwd(ad, bd, 1.3, loss, True)
+        assert abs(loss.item() - la.item()) < 1e-5 * abs(la.item())
+        go1 = torch.full((1,), 2.0, device=DEV)
+        gsum = ops.mse_const_bwd(ad, 1.0, 0.7, go1) + ops.l1_bwd(ad, bd, 1.3, go1)
+        assert rel_err(gsum, 2.0 * a.grad) < 1e-5
+    # Adam == torch.optim.Adam (betas 0.5/0.999, lr 2e-4), three steps
+    p0 = torch.randn(4097, generator=gen)
+    pt = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([pt], lr=2e-4, betas=(0.5, 0.999))
+    pd = p0.clone().to(DEV)
+    m = torch.zeros_like(pd)
+    v = torch.zeros_like(pd)
+    for step in range(1, 4):
+        g = torch.randn(4097, generator=gen) * 10 ** float(torch.randint(-6, 1, (1,), generator=gen))
+        pt.grad = g.clone()
+        opt.step()
+        ops.adam_step(pd, g.to(DEV), m, v, 2e-4, 0.5, 0.999, 1e-8, step)
+        assert (pd.cpu() - pt.detach()).abs().max().item() < 2e-9 + 1e-6 * 2e-4

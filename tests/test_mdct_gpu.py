@@ -1,0 +1,121 @@
+"""K1 / K2 (csrc/mdct.hip) through the C ABI against the CPU oracle and the golden vectors captured
+from the reference.  Stated tolerances (float32 MFMA contraction vs the reference's complex128 FFT):
+  MDCT coefficients   <= 2e-6 * max|X|          (3e-5 abs at |X|max ~ 56)
+  normalised spectro  <= 5e-4 abs in [-1, 1]    (arcsinh gain 1000 amplifies near-zero bins)
+  IMDCT waveform      <= 2e-6 * max|y| (+1e-7)
+  round trip          <= 3e-6 at sigma = 1
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import transform
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from mdctgan_amd.mdct import IMDCT4, MDCT4, kbdwin
+    w = kbdwin(512)
+    return MDCT4(512, 256, 512, w, device=DEV), IMDCT4(512, 256, 512, w, device=DEV), w.numpy()
+
+
+def test_mdct4_golden(mods, golden):
+    mdct, _, w = mods
+    g = golden("g2_mdct4")
+    X, frames = mdct(torch.from_numpy(g["x"]).to(DEV), True)
+    assert X.shape == (2, 32, 256) and frames.shape == (2, 32, 512)
+    np.testing.assert_array_equal(frames.cpu().numpy(), g["frames"])
+    Xc = X.cpu().numpy().astype(np.float64)
+    for b in range(2):
+        assert np.abs(Xc[b] - g["X"][b]).max() <= 2e-6 * np.abs(g["X"][b]).max()
+    X2, fr2 = mdct(torch.from_numpy(g["x"]).to(DEV))
+    assert fr2.numel() == 1 and torch.equal(X2, X)
+
+
+def test_mdct4_ragged_and_1d(mods):
+    mdct, _, w = mods
+    rng = np.random.default_rng(3)
+    for T in (7936 + 100, 300, 256, 1):
+        x = rng.standard_normal((3, T)).astype(np.float32)
+        want, _ = transform.mdct4(x, w, 512, 256)
+        got, _ = mdct(torch.from_numpy(x).to(DEV))
+        assert got.shape == want.shape
+        assert np.abs(got.cpu().numpy() - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
+    x1 = rng.standard_normal(7936).astype(np.float32)
+    got, _ = mdct(torch.from_numpy(x1).to(DEV))
+    want, _ = transform.mdct4(x1[None], w, 512, 256)
+    assert got.shape == (32, 256)
+    assert np.abs(got.cpu().numpy() - want[0]).max() <= 2e-6 * np.abs(want).max()
+
+
+def test_imdct4_golden(mods, golden):
+    _, imdct, _ = mods
+    g = golden("g3_imdct4")
+    for kin, kout in (("X", "y"), ("Xr", "yr")):
+        y, fr = imdct(torch.from_numpy(g[kin]).to(DEV).float())
+        assert y.shape == g[kout].shape and fr.numel() == 1
+        err = np.abs(y.cpu().numpy() - g[kout]).max()
+        assert err <= 2e-6 * np.abs(g[kout]).max() + 1e-7, err
+    y, fr = imdct(torch.from_numpy(g["X"]).to(DEV).float(), True)
+    assert np.abs(fr.cpu().numpy() - g["yframes"]).max() <= 2e-6 * np.abs(g["yframes"]).max()
+
+
+def test_round_trip_full_size(mods):
+    mdct, imdct, _ = mods
+    torch.manual_seed(0)
+    x = torch.randn(64, 32512, device=DEV)
+    X, _ = mdct(x)
+    assert X.shape == (64, 128, 256)
+    y, _ = imdct(X)
+    assert y.shape == (64, 1, 1, 32512)
+    assert (y[:, 0, 0] - x).abs().max().item() < 3e-6
+    # linearity at full size
+    x2 = torch.randn(64, 32512, device=DEV)
+    X2, _ = mdct(x2)
+    X12, _ = mdct(x + 2 * x2)
+    assert (X12 - (X + 2 * X2)).abs().max().item() < 2e-4
+    # float64 output option widens the float32 result
+    from mdctgan_amd.mdct import IMDCT4
+    im64 = IMDCT4(512, 256, 512, imdct.window, device=DEV, dtype=torch.float64)
+    y64, _ = im64(X)
+    assert y64.dtype == torch.float64 and torch.equal(y64.float(), y)
+
+
+def _codec_kw(abs_norm):
+    return dict(arcsinh_transform=True, raw_mdct=False, arcsinh_gain=1000.0, abs_norm=abs_norm,
+                src_range=(-5.0, 5.0), norm_range=(-1.0, 1.0))
+
+
+def test_codec_kernels_golden(mods, golden):
+    from mdctgan_amd import _lib
+    from mdctgan_amd.mdct import dct4_table, imdct4_codec, mdct4_codec
+    w = mods[0].window
+    d4 = dct4_table(256, DEV)
+    for tag, per_sample in (("abs", False), ("minmax", True)):
+        g = golden("g4_codec_" + tag)
+        r = mdct4_codec(torch.from_numpy(g["x"]).to(DEV), w, d4, 512, codec=_lib.MG_CODEC_ARCSINH, gain=1000.0,
+                        norm_range=(-1.0, 1.0), src_range=(-5.0, 5.0), per_sample=per_sample, want_pair=True,
+                        want_stats=True)
+        s = r["spec"].cpu().numpy()
+        assert np.abs(s - g["log_spectro"][:, 0]).max() <= 5e-4
+        pair = r["pair"].cpu().numpy()
+        np.testing.assert_array_equal(pair[..., 0], s)
+        np.testing.assert_allclose(pair[..., 1], np.abs(s) * 2 - 1, atol=1e-7)
+        n = s.size
+        st = r["stats"].cpu().numpy()
+        mean, var = st[0] / n, (st[1] - st[0] ** 2 / n) / (n - 1)
+        np.testing.assert_allclose(mean, g["mean"], atol=2e-5)
+        np.testing.assert_allclose(np.sqrt(var), g["std"], rtol=1e-4)
+        if per_sample:
+            np.testing.assert_allclose(r["min"].cpu().numpy(), g["min"].reshape(-1), atol=2e-4)
+            np.testing.assert_allclose(r["max"].cpu().numpy(), g["max"].reshape(-1), atol=2e-4)
+        mn = torch.from_numpy(g["min"].reshape(-1)).to(DEV) if per_sample else None
+        mx = torch.from_numpy(g["max"].reshape(-1)).to(DEV) if per_sample else None
+        audio, _ = imdct4_codec(torch.from_numpy(g["log_spectro"][:, 0]).to(DEV), w, d4, 512,
+                                codec=_lib.MG_CODEC_ARCSINH, gain=1000.0, norm_range=(-1.0, 1.0),
+                                src_range=(-5.0, 5.0), min_b=mn, max_b=mx)
+        ref = g["audio"][:, 0, 0]
+        assert np.abs(audio.cpu().numpy() - ref).max() <= 2e-6 * np.abs(ref).max() + 1e-7
