@@ -54,7 +54,7 @@ def test_act_bwd_add_pool_upsample():
         u = F.interpolate(x, scale_factor=2.0, mode="nearest")
         gu = torch.randn(u.shape, generator=gen, dtype=torch.float64)
         u.backward(gu)
-        assert rel_err(ops.upsample_fwd(xd), nhwc(u.detach())) == 0
+        assert rel_err(ops.upsample_fwd(xd), nhwc(u.detach())) < 1e-6
         assert rel_err(ops.upsample_bwd(nhwc(gu).float().to(DEV)), nhwc(x.grad)) < 1e-6
     a = torch.randn(1000, generator=gen).to(DEV)
     b = torch.randn(1000, generator=gen).to(DEV)
