@@ -1,0 +1,313 @@
+"""Autograd plumbing over the HIP launchers (ops.py).  Every tensor that crosses these functions is a
+logical NCHW tensor in torch.channels_last memory format -- i.e. NHWC in HBM, which is the layout the
+kernels consume -- so chaining them never copies.  Convolution weights ([Co, Ci, KH, KW] /
+[Cin_T, Cout_T, KH, KW]) are channels_last as well, which is exactly the OHWI layout of the C ABI.
+
+Weight / bias gradients are accumulated by the kernels straight into ``param.grad`` (no AccumulateGrad
+add pass, no per-step zero fill): the Function returns None for those inputs.  ``GradSlot`` tracks whether
+a parameter's gradient buffer already holds this step's first contribution.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from ._lib import ACT_LRELU02, ACT_NONE, ACT_RELU, ACT_TANH  # noqa: F401
+
+CL = torch.channels_last
+
+
+def to_cl(x: torch.Tensor) -> torch.Tensor:
+    """float32 channels_last (NHWC memory) without copying when it already is."""
+    if x.dtype != torch.float32:
+        x = x.float()
+    return x.contiguous(memory_format=CL)
+
+
+def nhwc_view(x):
+    return x.permute(0, 2, 3, 1)
+
+
+def nchw_view(y):
+    return y.permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused gradient accumulation
+# ------------------------------------------------------------------------------------------------
+def grad_buffer(p: torch.nn.Parameter):
+    """(buffer, accumulate?) for a parameter: allocates p.grad with p's own strides on first use; a buffer that
+    was handed out fresh (after zero_grad) is overwritten by the first kernel and accumulated into afterwards."""
+    fresh = getattr(p, "_mg_fresh", True)
+    if p.grad is None:
+        p.grad = torch.empty_like(p)          # preserve_format: same (channels_last) strides as the parameter
+        fresh = True
+    p._mg_fresh = False
+    return p.grad, (not fresh)
+
+
+def mark_fresh(params):
+    """zero_grad without a memset: the next wgrad kernel overwrites instead of accumulating."""
+    for p in params:
+        p._mg_fresh = True
+
+
+_grad_hooks = []
+
+
+def register_grad_ready_hook(fn):
+    """fn(param) is called right after a kernel finished writing param.grad (used by the DDP reducer)."""
+    _grad_hooks.append(fn)
+    return fn
+
+
+def remove_grad_ready_hook(fn):
+    if fn in _grad_hooks:
+        _grad_hooks.remove(fn)
+
+
+def _notify(p):
+    for fn in _grad_hooks:
+        fn(p)
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution
+# ------------------------------------------------------------------------------------------------
+class _ConvFn(torch.autograd.Function):
+    """y = act(conv(x, w) + b); transposed=True runs the data-gradient kernel forward (ConvTranspose2d)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cfg):
+        x = to_cl(x)
+        stride, pad, reflect, act, transposed, weight_grad = cfg
+        B, _, H, W = x.shape
+        w = weight.detach()
+        assert w.is_contiguous(memory_format=CL), "conv weights must be channels_last (OHWI) tensors"
+        KH, KW = w.shape[2], w.shape[3]
+        b = bias.detach() if bias is not None else None
+        if not transposed:
+            Co, Ci = w.shape[0], w.shape[1]
+            assert Ci == x.shape[1]
+            g = ops.conv_geom(B, H, W, Ci, Co, KH, KW, stride, pad, reflect)
+            y = ops.conv_fwd(g, nhwc_view(x), w, b, act)
+        else:
+            # nn.ConvTranspose2d(k, stride, pad, output_padding = stride - 1): the data gradient of the conv
+            # high-res [B, sH, sW, Cout_T] -> low-res [B, H, W, Cin_T]
+            cin_t, cout_t = w.shape[0], w.shape[1]
+            assert cin_t == x.shape[1]
+            g = ops.conv_geom(B, stride * H, stride * W, cout_t, cin_t, KH, KW, stride, pad, False)
+            assert (g.OH, g.OW) == (H, W), "unsupported ConvTranspose2d geometry"
+            y = ops.conv_dgrad(g, nhwc_view(x), w, b, act)
+        y = nchw_view(y)
+        ctx.g, ctx.cfg = g, cfg
+        ctx.weight, ctx.bias = weight, bias
+        ctx.save_for_backward(x, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y = ctx.saved_tensors
+        stride, pad, reflect, act, transposed, weight_grad = ctx.cfg
+        g, weight, bias = ctx.g, ctx.weight, ctx.bias
+        gy = to_cl(gy)
+        if act != ACT_NONE:
+            gy = nchw_view(ops.act_bwd(nhwc_view(gy), nhwc_view(y), act))
+        w = weight.detach()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if not transposed:
+                dx = nchw_view(ops.conv_dgrad(g, nhwc_view(gy), w))
+            else:
+                dx = nchw_view(ops.conv_fwd(g, nhwc_view(gy), w))
+        if weight_grad and weight.requires_grad:
+            wbuf, wacc = grad_buffer(weight)
+            bbuf = bacc = None
+            if bias is not None and bias.requires_grad:
+                bbuf, bacc = grad_buffer(bias)
+            if not transposed:
+                if bbuf is not None and bacc != wacc:      # keep one accumulate flag per launch
+                    ops.colsum(nhwc_view(gy).reshape(-1, g.Co), bbuf, bacc)
+                    bbuf = None
+                ops.conv_wgrad(g, nhwc_view(x), nhwc_view(gy), wbuf, bbuf, wacc)
+            else:
+                ops.conv_wgrad(g, nhwc_view(gy), nhwc_view(x), wbuf, None, wacc)
+                if bbuf is not None:
+                    ops.colsum(nhwc_view(gy).reshape(-1, g.Ci), bbuf, bacc)
+            _notify(weight)
+            if bias is not None and bias.requires_grad:
+                _notify(bias)
+        return dx, None, None, None
+
+
+def conv2d(x, weight, bias, stride=1, padding=0, reflect=False, act=ACT_NONE, weight_grad=True):
+    return _ConvFn.apply(x, weight, bias, (stride, padding, bool(reflect), act, False, weight_grad))
+
+
+def conv_transpose2d(x, weight, bias, stride=2, padding=1, act=ACT_NONE, weight_grad=True):
+    return _ConvFn.apply(x, weight, bias, (stride, padding, False, act, True, weight_grad))
+
+
+# ------------------------------------------------------------------------------------------------
+# instance norm (+ activation, + residual)
+# ------------------------------------------------------------------------------------------------
+class _InstNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, act, eps):
+        x = to_cl(x)
+        res = to_cl(residual) if residual is not None else None
+        y, mean, rstd = ops.instnorm_fwd(nhwc_view(x), act, nhwc_view(res) if res is not None else None, eps)
+        ctx.act = act
+        ctx.save_for_backward(x, mean, rstd)
+        return nchw_view(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, mean, rstd = ctx.saved_tensors
+        gy = to_cl(gy)
+        dx = nchw_view(ops.instnorm_bwd(nhwc_view(gy), nhwc_view(x), mean, rstd, ctx.act)) \
+            if ctx.needs_input_grad[0] else None
+        dres = gy if ctx.needs_input_grad[1] else None
+        return dx, dres, None, None
+
+
+def instance_norm_act(x, act=ACT_NONE, residual=None, eps=1e-5):
+    """act(InstanceNorm2d(affine=False)(x)) + residual."""
+    return _InstNormFn.apply(x, residual, act, eps)
+
+
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = to_cl(a), to_cl(b)
+        return nchw_view(ops.add(nhwc_view(a), nhwc_view(b)))
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return _AddFn.apply(a, b)
+
+
+class _AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = to_cl(x)
+        ctx.in_shape = nhwc_view(x).shape
+        return nchw_view(ops.avgpool_fwd(nhwc_view(x)))
+
+    @staticmethod
+    def backward(ctx, gy):
+        return nchw_view(ops.avgpool_bwd(nhwc_view(to_cl(gy)), tuple(ctx.in_shape)))
+
+
+def avg_pool_3s2(x):
+    """nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False)."""
+    return _AvgPoolFn.apply(x)
+
+
+class _UpsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return nchw_view(ops.upsample_fwd(nhwc_view(to_cl(x))))
+
+    @staticmethod
+    def backward(ctx, gy):
+        return nchw_view(ops.upsample_bwd(nhwc_view(to_cl(gy))))
+
+
+def upsample_nearest2x(x):
+    return _UpsampleFn.apply(x)
+
+
+class _ActFn(torch.autograd.Function):
+    """Stand-alone activation (only used when a pattern could not be fused): computed by the add-free path
+    y = act(x) through the conv epilogue helpers is not available, so use instnorm-free kernels."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        raise NotImplementedError("stand-alone activations are always fused into the producing kernel")
+
+
+# ------------------------------------------------------------------------------------------------
+# discriminator input / generator input assembly
+# ------------------------------------------------------------------------------------------------
+class _DInputFn(torch.autograd.Function):
+    """cat(lr, s, 2|s| + nr0) along channels (pix2pixHD_model.py:420-424, 439-440)."""
+
+    @staticmethod
+    def forward(ctx, lr, s, nr0):
+        lr, s = to_cl(lr), to_cl(s)
+        assert lr.shape[1] == 1 and s.shape[1] == 1
+        ctx.save_for_backward(s)
+        return nchw_view(ops.dinput_fwd(nhwc_view(lr), nhwc_view(s), nr0))
+
+    @staticmethod
+    def backward(ctx, g):
+        (s,) = ctx.saved_tensors
+        ds = nchw_view(ops.dinput_bwd(nhwc_view(to_cl(g)), nhwc_view(s))) if ctx.needs_input_grad[1] else None
+        return None, ds, None
+
+
+def d_input(lr_spectro, s_spectro, nr0):
+    return _DInputFn.apply(lr_spectro, s_spectro, nr0)
+
+
+def g_input(spectro, nr0):
+    """cat(s, 2|s| + nr0) (pix2pixHD_model.py:400-402); no gradient path (the generator input is data)."""
+    s = to_cl(spectro.detach())
+    return nchw_view(ops.pair_fwd(nhwc_view(s), nr0))
+
+
+# ------------------------------------------------------------------------------------------------
+# losses
+# ------------------------------------------------------------------------------------------------
+class _MseConstFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, scale):
+        pred = pred.contiguous(memory_format=CL) if pred.dim() == 4 else pred.contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        ops.mse_const_fwd(pred, target, scale, loss, False)
+        ctx.target, ctx.scale = target, scale
+        ctx.save_for_backward(pred)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, go):
+        (pred,) = ctx.saved_tensors
+        go = go.reshape(1).float().contiguous()
+        return ops.mse_const_bwd(pred, ctx.target, ctx.scale, go), None, None
+
+
+def mse_const_loss(pred, target: float, scale: float = 1.0):
+    """scale * mean((pred - target)^2)  == nn.MSELoss()(pred, full_like(pred, target)) * scale."""
+    return _MseConstFn.apply(pred, float(target), float(scale))
+
+
+class _L1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, scale):
+        fmt = CL if a.dim() == 4 else torch.contiguous_format
+        a, b = a.contiguous(memory_format=fmt), b.contiguous(memory_format=fmt)
+        loss = torch.empty(1, dtype=torch.float32, device=a.device)
+        ops.l1_fwd(a, b, scale, loss, False)
+        ctx.scale = scale
+        ctx.save_for_backward(a, b)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, go):
+        a, b = ctx.saved_tensors
+        go = go.reshape(1).float().contiguous()
+        ga = ops.l1_bwd(a, b, ctx.scale, go) if ctx.needs_input_grad[0] else None
+        gb = None
+        if ctx.needs_input_grad[1]:
+            gb = ops.l1_bwd(b, a, ctx.scale, go)
+        return ga, gb, None
+
+
+def l1_loss(a, b, scale: float = 1.0):
+    """scale * mean(|a - b|) == nn.L1Loss()(a, b) * scale."""
+    return _L1Fn.apply(a, b, float(scale))

@@ -1,0 +1,475 @@
+"""Generator / discriminator stacks and losses with the reference's public surface
+(models/networks.py: define_G :33-56, define_D :59-68, GANLoss :97-137, LocalEnhancer :173-298,
+GlobalGenerator :301-372, InterpolateUpsample :375-400, ConvResBlock :403-417, ResnetBlock :421-463,
+MultiscaleDiscriminator :507-550, NLayerDiscriminator :641-692) -- same constructor arguments, same
+module tree (hence identical state_dict keys / shapes, so reference checkpoints load unchanged), but every
+forward / backward runs the gfx950 kernels behind include/mdctgan_hip.h.
+
+The nn.Sequential containers hold the same layer objects as the reference (ReflectionPad2d, Conv2d,
+InstanceNorm2d, ReLU, ...) purely as *structure*: ``FusedSequence`` pattern-matches them into fused launches
+    [ReflectionPad2d] -> Conv2d/ConvTranspose2d -> [InstanceNorm2d] -> [ReLU | LeakyReLU(0.2) | Tanh]
+(padding folded into the implicit-GEMM gather, activation into the conv or norm epilogue, the ResnetBlock
+skip connection into the second norm).  Tensors are logical NCHW in channels_last memory (NHWC in HBM).
+There is no eager fallback: an unsupported layer pattern raises NotImplementedError.
+"""
+from __future__ import annotations
+
+import functools
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import functional as Fh
+from .functional import ACT_LRELU02, ACT_NONE, ACT_RELU, ACT_TANH, CL
+
+
+###############################################################################
+# layers (parameters live in channels_last == OHWI memory)
+###############################################################################
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d whose weight is stored OHWI and whose forward/backward are the implicit-GEMM HIP kernels."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        assert self.kernel_size[0] >= 1 and self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1]
+        assert self.dilation == (1, 1) and self.groups == 1 and self.padding_mode == "zeros"
+        self.weight.data = self.weight.data.contiguous(memory_format=CL)
+
+    def forward(self, x, reflect_pad: int = 0, act: int = ACT_NONE, weight_grad: bool = True):
+        pad = reflect_pad if reflect_pad else self.padding[0]
+        if reflect_pad:
+            assert self.padding[0] == 0
+        return Fh.conv2d(x, self.weight, self.bias, self.stride[0], pad, bool(reflect_pad), act, weight_grad)
+
+
+class ConvTranspose2d(nn.ConvTranspose2d):
+    """nn.ConvTranspose2d (weight [Cin, Cout, KH, KW] stored [Cin, KH, KW, Cout]) on the data-gradient kernel."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        s, p, k, op = self.stride[0], self.padding[0], self.kernel_size[0], self.output_padding[0]
+        if not (self.stride[0] == self.stride[1] and s in (1, 2) and op == s - 1 and k - 2 * p == 1):
+            raise NotImplementedError("HIP ConvTranspose2d covers k - 2p == 1, output_padding == stride - 1")
+        self.weight.data = self.weight.data.contiguous(memory_format=CL)
+
+    def forward(self, x, act: int = ACT_NONE, weight_grad: bool = True):
+        return Fh.conv_transpose2d(x, self.weight, self.bias, self.stride[0], self.padding[0], act, weight_grad)
+
+
+def weights_init(m):
+    """networks.py:13-19.  Values are drawn for the logical NCHW order (like the reference) and copied into the
+    channels_last storage."""
+    classname = m.__class__.__name__
+    if classname.find("Conv2d") != -1:
+        w = m.weight.data
+        m.weight.data.copy_(torch.empty(w.shape, device=w.device, dtype=w.dtype).normal_(0.0, 0.02))
+    elif classname.find("BatchNorm2d") != -1:
+        m.weight.data.normal_(1.0, 0.02)
+        m.bias.data.fill_(0)
+
+
+def get_norm_layer(norm_type="instance"):
+    if norm_type == "instance":
+        return functools.partial(nn.InstanceNorm2d, affine=False)
+    if norm_type == "batch":
+        raise NotImplementedError("only --norm instance is implemented on the HIP path")
+    raise NotImplementedError("normalization layer [%s] is not found" % norm_type)
+
+
+###############################################################################
+# fused execution of a reference-shaped layer list
+###############################################################################
+def _act_code(m):
+    if isinstance(m, nn.ReLU):
+        return ACT_RELU
+    if isinstance(m, nn.LeakyReLU):
+        if abs(m.negative_slope - 0.2) > 1e-12:
+            raise NotImplementedError("LeakyReLU slope %r" % m.negative_slope)
+        return ACT_LRELU02
+    if isinstance(m, nn.Tanh):
+        return ACT_TANH
+    return None
+
+
+class FusedSequence:
+    """Compiles a list of reference-shaped modules into fused HIP launches (see module docstring)."""
+
+    def __init__(self, modules):
+        self.steps = []
+        mods = list(modules)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            reflect = 0
+            if isinstance(m, nn.ReflectionPad2d):
+                reflect = int(m.padding[0])
+                i += 1
+                m = mods[i]
+                if not isinstance(m, Conv2d):
+                    raise NotImplementedError("ReflectionPad2d must precede a Conv2d")
+            i += 1
+            norm = False
+            act = ACT_NONE
+            is_producer = isinstance(m, (Conv2d, ConvTranspose2d, ConvResBlock, InterpolateUpsample))
+            if is_producer:
+                if i < len(mods) and isinstance(mods[i], nn.InstanceNorm2d):
+                    n = mods[i]
+                    if n.affine or n.track_running_stats:
+                        raise NotImplementedError("InstanceNorm2d(affine / running stats)")
+                    norm, eps = True, n.eps
+                    i += 1
+                else:
+                    eps = 1e-5
+                if i < len(mods) and _act_code(mods[i]) is not None:
+                    act = _act_code(mods[i])
+                    i += 1
+                self.steps.append(("producer", m, reflect, norm, act, eps))
+            elif isinstance(m, (ResnetBlock, FusedModule)):
+                self.steps.append(("module", m))
+            elif isinstance(m, nn.Sequential):
+                self.steps.append(("seq", FusedSequence(m)))
+            else:
+                raise NotImplementedError("no HIP lowering for layer %s in this position" % m.__class__.__name__)
+
+    def __call__(self, x, weight_grad=True):
+        for st in self.steps:
+            if st[0] == "producer":
+                _, m, reflect, norm, act, eps = st
+                conv_act = ACT_NONE if norm else act
+                if isinstance(m, Conv2d):
+                    x = m(x, reflect, conv_act, weight_grad)
+                elif isinstance(m, ConvTranspose2d):
+                    x = m(x, conv_act, weight_grad)
+                else:
+                    x = m(x, weight_grad=weight_grad)
+                    if not norm and act != ACT_NONE:
+                        raise NotImplementedError("activation directly after %s" % m.__class__.__name__)
+                if norm:
+                    x = Fh.instance_norm_act(x, act, None, eps)
+            elif st[0] == "module":
+                x = st[1](x, weight_grad=weight_grad)
+            else:
+                x = st[1](x, weight_grad)
+        return x
+
+
+class FusedModule(nn.Module):
+    """Base for containers whose forward is a FusedSequence over ``self.model``-style children."""
+
+    def _plan(self, name, modules):
+        cache = self.__dict__.setdefault("_plans", {})
+        if name not in cache:
+            cache[name] = FusedSequence(modules)
+        return cache[name]
+
+
+###############################################################################
+# Generator
+###############################################################################
+class ResnetBlock(nn.Module):
+    """networks.py:421-463: x + [pad, conv3x3, IN, ReLU, pad, conv3x3, IN](x); the add rides in the 2nd norm."""
+
+    def __init__(self, dim, padding_type, norm_layer, activation=nn.ReLU(True), use_dropout=False):
+        super().__init__()
+        if padding_type != "reflect" or use_dropout:
+            raise NotImplementedError("HIP ResnetBlock: reflect padding, no dropout")
+        self.conv_block = nn.Sequential(
+            nn.ReflectionPad2d(1), Conv2d(dim, dim, kernel_size=3, padding=0), norm_layer(dim), activation,
+            nn.ReflectionPad2d(1), Conv2d(dim, dim, kernel_size=3, padding=0), norm_layer(dim))
+
+    def forward(self, x, weight_grad=True):
+        cb = self.conv_block
+        h = cb[1](x, 1, ACT_NONE, weight_grad)
+        h = Fh.instance_norm_act(h, ACT_RELU, None, cb[2].eps)
+        h = cb[5](h, 1, ACT_NONE, weight_grad)
+        return Fh.instance_norm_act(h, ACT_NONE, x, cb[6].eps)
+
+
+class ConvResBlock(nn.Module):
+    """networks.py:403-417 (--downsample_type resconv)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding):
+        super().__init__()
+        self.conv1 = Conv2d(in_channels, in_channels, kernel_size, stride, padding)
+        self.conv2 = Conv2d(in_channels, out_channels, 5, padding=2)
+        self.conv_res = Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
+
+    def forward(self, x, weight_grad=True):
+        x = self.conv1(x, weight_grad=weight_grad)
+        return Fh.add(self.conv2(x, weight_grad=weight_grad), self.conv_res(x, weight_grad=weight_grad))
+
+
+class InterpolateUpsample(nn.Module):
+    """networks.py:375-400 (--upsample_type interpolate)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        self.in_channels, self.out_channels = kwargs["in_channels"], kwargs["out_channels"]
+        self.conv1 = Conv2d(self.in_channels, self.out_channels, 5, padding=1)
+        self.conv2 = Conv2d(self.out_channels, self.out_channels, 3, padding=2)
+        self.conv_res = Conv2d(self.in_channels, self.out_channels, 3, padding=1)
+
+    def forward(self, x, weight_grad=True):
+        assert x.shape[1] == self.in_channels
+        x = Fh.upsample_nearest2x(x)
+        res = self.conv_res(x, weight_grad=weight_grad)
+        return Fh.add(self.conv2(self.conv1(x, weight_grad=weight_grad), weight_grad=weight_grad), res)
+
+
+def _down_up_layers(downsample_type, upsample_type):
+    if downsample_type == "conv":
+        down = Conv2d
+    elif downsample_type == "resconv":
+        down = ConvResBlock
+    else:
+        raise NotImplementedError("downsample layer [{:s}] is not found".format(downsample_type))
+    if upsample_type == "transconv":
+        up = ConvTranspose2d
+    elif upsample_type == "interpolate":
+        up = InterpolateUpsample
+    else:
+        raise NotImplementedError("upsample layer [{:s}] is not found".format(upsample_type))
+    return down, up
+
+
+class GlobalGenerator(FusedModule):
+    """networks.py:301-372."""
+
+    def __init__(self, input_nc, output_nc, ngf=64, n_downsampling=3, n_blocks=9, norm_layer=None,
+                 padding_type="reflect", upsample_type="transconv", downsample_type="conv", n_attn_g=0,
+                 input_size=(128, 256), proj_factor_g=4, heads_g=4, dim_head_g=128):
+        assert n_blocks >= 0
+        super().__init__()
+        norm_layer = norm_layer or get_norm_layer("instance")
+        activation = nn.ReLU(True)
+        down, up = _down_up_layers(downsample_type, upsample_type)
+        model = [nn.ReflectionPad2d(3), Conv2d(input_nc, ngf, kernel_size=7, padding=0), norm_layer(ngf), activation]
+        for i in range(n_downsampling):
+            mult = 2 ** i
+            model += [down(ngf * mult, ngf * mult * 2, kernel_size=3, stride=2, padding=1),
+                      norm_layer(ngf * mult * 2), activation]
+        mult = 2 ** n_downsampling
+        bottle_neck = [ResnetBlock(ngf * mult, padding_type=padding_type, activation=activation,
+                                   norm_layer=norm_layer) for _ in range(n_blocks)]
+        if n_attn_g > 0:
+            raise NotImplementedError(
+                "bottleneck-transformer attention (n_blocks_attn_g > 0, kernel K10) is not built yet on the HIP path")
+        model += bottle_neck
+        for i in range(n_downsampling):
+            mult = 2 ** (n_downsampling - i)
+            model += [up(in_channels=ngf * mult, out_channels=int(ngf * mult / 2), kernel_size=3, stride=2,
+                         padding=1, output_padding=1), norm_layer(int(ngf * mult / 2)), activation]
+        model += [nn.ReflectionPad2d(3), Conv2d(ngf, output_nc, kernel_size=7, padding=0), nn.Tanh()]
+        self.model = nn.Sequential(*model)
+        self.freeze = False
+
+    def forward(self, input, weight_grad=True):
+        return self._plan("model", self.model)(input, weight_grad)
+
+    def set_freeze(self, freeze=True, *_unused):
+        """networks.py:359-372.  Extra positional flags are accepted and ignored: the reference calls this with the
+        four LocalEnhancer flags (pix2pixHD_model.py:241-242), which is a TypeError there."""
+        freeze = bool(freeze)
+        if self.freeze == freeze:
+            return
+        self.freeze = freeze
+        for _, layer in self.model.named_children():
+            if "ResnetBlock" in layer.__class__.__name__ or "BottleStack" in layer.__class__.__name__:
+                break
+            for param in layer.parameters():
+                param.requires_grad = not freeze
+
+
+class LocalEnhancer(FusedModule):
+    """networks.py:173-298 (n_local_enhancers == 1, n_attn_l == 0: every BASELINE / train.sh configuration)."""
+
+    def __init__(self, input_nc, output_nc, ngf=32, n_downsample_global=3, n_blocks_global=9, n_local_enhancers=1,
+                 n_blocks_local=3, norm_layer=None, padding_type="reflect", downsample_type="conv",
+                 upsample_type="transconv", n_attn_g=0, n_attn_l=0, input_size=(128, 256), proj_factor_g=4,
+                 heads_g=4, dim_head_g=128, proj_factor_l=4, heads_l=4, dim_head_l=128):
+        super().__init__()
+        if n_local_enhancers != 1 or n_attn_l > 0:
+            raise NotImplementedError("HIP LocalEnhancer: n_local_enhancers == 1 and n_blocks_attn_l == 0")
+        norm_layer = norm_layer or get_norm_layer("instance")
+        self.n_local_enhancers = n_local_enhancers
+        ngf_global = ngf * (2 ** n_local_enhancers)
+        model_global = GlobalGenerator(input_nc, output_nc, ngf_global, n_downsample_global, n_blocks_global,
+                                       norm_layer, downsample_type=downsample_type, upsample_type=upsample_type,
+                                       input_size=tuple(map(lambda x: x // 2, input_size)), n_attn_g=n_attn_g,
+                                       proj_factor_g=proj_factor_g, heads_g=heads_g, dim_head_g=dim_head_g).model
+        model_global = [model_global[i] for i in range(len(model_global) - 3)]
+        self.model = nn.Sequential(*model_global)
+        down, up = _down_up_layers(downsample_type, upsample_type)
+        ngf_global = ngf * (2 ** (n_local_enhancers - 1))
+        model_downsample = [nn.ReflectionPad2d(3), Conv2d(input_nc, ngf_global, kernel_size=7, padding=0),
+                            norm_layer(ngf_global), nn.ReLU(True),
+                            down(ngf_global, ngf_global * 2, kernel_size=3, stride=2, padding=1),
+                            norm_layer(ngf_global * 2), nn.ReLU(True)]
+        model_upsample = [ResnetBlock(ngf_global * 2, padding_type=padding_type, norm_layer=norm_layer)
+                          for _ in range(n_blocks_local)]
+        model_upsample += [up(in_channels=ngf_global * 2, out_channels=ngf_global, kernel_size=3, stride=2,
+                              padding=1, output_padding=1), norm_layer(ngf_global), nn.ReLU(True)]
+        model_upsample += [nn.ReflectionPad2d(3), Conv2d(ngf, output_nc, kernel_size=7, padding=0), nn.Tanh()]
+        self.model1_1 = nn.Sequential(*model_downsample)
+        self.model1_2 = nn.Sequential(*model_upsample)
+        self.downsample = nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False)
+        self.freeze = False
+
+    def forward(self, input, weight_grad=True):
+        coarse = self._plan("model", self.model)(Fh.avg_pool_3s2(input), weight_grad)
+        fine = self._plan("model1_1", self.model1_1)(input, weight_grad)
+        return self._plan("model1_2", self.model1_2)(Fh.add(fine, coarse), weight_grad)
+
+    def set_freeze(self, freeze_global_d=True, freeze_global_u=False, freeze_local_d=True, freeze_local_u=False):
+        """networks.py:269-298."""
+        for _, layer in self.model.named_children():
+            name = layer.__class__.__name__
+            if "Conv2d" in name and "ConvTranspose2d" not in name or "ConvResBlock" in name:
+                for param in layer.parameters():
+                    param.requires_grad = not freeze_global_d
+            elif any(k in name for k in ("InterpolateUpsample", "ConvTranspose2d", "ResnetBlock", "BottleStack")):
+                for param in layer.parameters():
+                    param.requires_grad = not freeze_global_u
+        for param in self.model1_1.parameters():
+            param.requires_grad = not freeze_local_d
+        for param in self.model1_2.parameters():
+            param.requires_grad = not freeze_local_u
+
+
+def define_G(input_nc, output_nc, ngf, netG, n_downsample_global=3, n_blocks_global=9, n_local_enhancers=1,
+             n_blocks_local=3, norm="instance", gpu_ids=[], upsample_type="transconv", downsample_type="conv",
+             input_size=(128, 256), n_attn_g=0, n_attn_l=0, proj_factor_g=4, heads_g=4, dim_head_g=128,
+             proj_factor_l=4, heads_l=4, dim_head_l=128):
+    """networks.py:33-56."""
+    norm_layer = get_norm_layer(norm_type=norm)
+    if netG == "global":
+        net = GlobalGenerator(input_nc, output_nc, ngf, n_downsample_global, n_blocks_global, norm_layer,
+                              downsample_type=downsample_type, upsample_type=upsample_type, input_size=input_size,
+                              n_attn_g=n_attn_g, proj_factor_g=proj_factor_g, heads_g=heads_g, dim_head_g=dim_head_g)
+    elif netG == "local":
+        net = LocalEnhancer(input_nc, output_nc, ngf, n_downsample_global, n_blocks_global, n_local_enhancers,
+                            n_blocks_local, norm_layer, downsample_type=downsample_type,
+                            upsample_type=upsample_type, input_size=input_size, n_attn_g=n_attn_g,
+                            proj_factor_g=proj_factor_g, heads_g=heads_g, dim_head_g=dim_head_g, n_attn_l=n_attn_l,
+                            proj_factor_l=proj_factor_l, heads_l=heads_l, dim_head_l=dim_head_l)
+    else:
+        raise NotImplementedError("generator not implemented!")
+    if len(gpu_ids) > 0:
+        assert torch.cuda.is_available()
+        net.cuda(gpu_ids[0])
+    net.apply(weights_init)
+    return net
+
+
+###############################################################################
+# Discriminator
+###############################################################################
+class NLayerDiscriminator(nn.Module):
+    """networks.py:641-692 (PatchGAN; kw 4, padw 2)."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=None, use_sigmoid=False, getIntermFeat=False):
+        super().__init__()
+        if use_sigmoid:
+            raise NotImplementedError("--no_lsgan (sigmoid + BCE) is outside the hot path")
+        norm_layer = norm_layer or get_norm_layer("instance")
+        self.getIntermFeat, self.n_layers = getIntermFeat, n_layers
+        kw, padw = 4, int(np.ceil((4 - 1.0) / 2))
+        sequence = [[Conv2d(input_nc, ndf, kernel_size=kw, stride=2, padding=padw), nn.LeakyReLU(0.2, True)]]
+        nf = ndf
+        for _ in range(1, n_layers):
+            nf_prev, nf = nf, min(nf * 2, 512)
+            sequence += [[Conv2d(nf_prev, nf, kernel_size=kw, stride=2, padding=padw), norm_layer(nf),
+                          nn.LeakyReLU(0.2, True)]]
+        nf_prev, nf = nf, min(nf * 2, 512)
+        sequence += [[Conv2d(nf_prev, nf, kernel_size=kw, stride=1, padding=padw), norm_layer(nf),
+                      nn.LeakyReLU(0.2, True)]]
+        sequence += [[Conv2d(nf, 1, kernel_size=kw, stride=1, padding=padw)]]
+        if getIntermFeat:
+            for n in range(len(sequence)):
+                setattr(self, "model" + str(n), nn.Sequential(*sequence[n]))
+        else:
+            self.model = nn.Sequential(*[m for s in sequence for m in s])
+
+    def forward(self, input, weight_grad=True):
+        if self.getIntermFeat:
+            res = [input]
+            for n in range(self.n_layers + 2):
+                res.append(FusedSequence(getattr(self, "model" + str(n)))(res[-1], weight_grad))
+            return res[1:]
+        return FusedSequence(self.model)(input, weight_grad)
+
+
+class MultiscaleDiscriminator(FusedModule):
+    """networks.py:507-550."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=None, use_sigmoid=False, num_D=3,
+                 getIntermFeat=False):
+        super().__init__()
+        self.num_D, self.n_layers, self.getIntermFeat = num_D, n_layers, getIntermFeat
+        for i in range(num_D):
+            netD = NLayerDiscriminator(input_nc, ndf, n_layers, norm_layer, use_sigmoid, getIntermFeat)
+            if getIntermFeat:
+                for j in range(n_layers + 2):
+                    setattr(self, "scale" + str(i) + "_layer" + str(j), getattr(netD, "model" + str(j)))
+            else:
+                setattr(self, "layer" + str(i), netD.model)
+        self.downsample = nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False)
+
+    def singleD_forward(self, names, input, weight_grad=True):
+        if self.getIntermFeat:
+            result = [input]
+            for n in names:
+                result.append(self._plan(n, getattr(self, n))(result[-1], weight_grad))
+            return result[1:]
+        return [self._plan(names, getattr(self, names))(input, weight_grad)]
+
+    def forward(self, input, weight_grad=True):
+        """weight_grad=False marks a pass whose discriminator weight gradients are discarded by the caller
+        (the generator-loss pass: train.py:182-194 zeroes them before the D step)."""
+        num_D = self.num_D
+        result = []
+        x = input
+        for i in range(num_D):
+            if self.getIntermFeat:
+                names = ["scale" + str(num_D - 1 - i) + "_layer" + str(j) for j in range(self.n_layers + 2)]
+            else:
+                names = "layer" + str(num_D - 1 - i)
+            result.append(self.singleD_forward(names, x, weight_grad))
+            if i != (num_D - 1):
+                x = Fh.avg_pool_3s2(x)
+        return result
+
+
+def define_D(input_nc, ndf, n_layers_D, norm="instance", use_sigmoid=False, num_D=1, getIntermFeat=False,
+             gpu_ids=[]):
+    """networks.py:59-68."""
+    norm_layer = get_norm_layer(norm_type=norm)
+    netD = MultiscaleDiscriminator(input_nc, ndf, n_layers_D, norm_layer, use_sigmoid, num_D, getIntermFeat)
+    if len(gpu_ids) > 0:
+        assert torch.cuda.is_available()
+        netD.cuda(gpu_ids[0])
+    netD.apply(weights_init)
+    return netD
+
+
+###############################################################################
+# Losses
+###############################################################################
+class GANLoss(nn.Module):
+    """networks.py:97-137 with use_lsgan=True: sum over scales of mean((pred[-1] - label)^2)."""
+
+    def __init__(self, use_lsgan=True, target_real_label=1.0, target_fake_label=0.0, device="cuda"):
+        super().__init__()
+        if not use_lsgan:
+            raise NotImplementedError("--no_lsgan (BCE) is outside the hot path")
+        self.real_label, self.fake_label, self.device = target_real_label, target_fake_label, device
+
+    def __call__(self, input, target_is_real):
+        label = self.real_label if target_is_real else self.fake_label
+        if isinstance(input[0], list):
+            loss = 0
+            for input_i in input:
+                loss = loss + Fh.mse_const_loss(input_i[-1], label)
+            return loss
+        return Fh.mse_const_loss(input[-1], label)

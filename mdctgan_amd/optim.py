@@ -1,0 +1,106 @@
+"""FusedAdam: torch.optim.Adam semantics (reference: pix2pixHD_model.py:350-351, 363-364 -- Adam(lr, betas=
+(beta1, 0.999)), eps 1e-8, no weight decay) as ONE multi-hundred-MB elementwise HIP launch (K12) over a flat
+float32 arena that holds every parameter, its gradient and both moments contiguously.
+
+* parameters are re-pointed at slices of the arena (keeping their channels_last strides), gradients likewise, so
+  the wgrad kernels write straight into the arena and a data-parallel reducer can all-reduce arena slices;
+* zero_grad() does not touch memory: it flags every gradient "fresh" so the next wgrad kernel overwrites;
+* param_groups[0]['lr'] is honoured every step (Pix2PixHDModel.update_learning_rate edits it).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import functional as Fh
+from . import ops
+
+
+def _arena_view(flat, off, p):
+    n = p.numel()
+    if p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) and not p.is_contiguous():
+        a, b, c, d = p.shape
+        return flat[off:off + n].view(a, c, d, b).permute(0, 3, 1, 2)
+    return flat[off:off + n].view(p.shape)
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-8):
+        params = [p for p in params]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._params = [p for g in self.param_groups for p in g["params"]]
+        self._step = 0
+        self._built = False
+        self.grad_scale = 1.0          # 1/world_size under data parallelism (gradients arrive summed)
+        self.pre_step_hook = None      # reducer.finish() under data parallelism
+
+    # -- arena ---------------------------------------------------------------------------------
+    def _build(self):
+        ps = self._params
+        if not ps:
+            self._built = True
+            return
+        dev = ps[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FusedAdam drives the HIP Adam kernel: parameters must live in HBM")
+        offs, total = [], 0
+        for p in ps:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4                  # keep every slice 16-byte aligned
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.offsets, self.total = offs, total
+        with torch.no_grad():
+            for p, off in zip(ps, offs):
+                view = _arena_view(self.flat_p, off, p)
+                view.copy_(p.data)
+                p.data = view
+                gview = _arena_view(self.flat_g, off, p)
+                if p.grad is not None:
+                    gview.copy_(p.grad)
+                    fresh = False
+                else:
+                    fresh = True
+                p.grad = gview
+                p._mg_fresh = fresh
+        self._built = True
+
+    def arena_slices(self):
+        """[(param, offset, padded_numel)] in arena order (used by the data-parallel reducer)."""
+        if not self._built:
+            self._build()
+        return [(p, o, (p.numel() + 3) // 4 * 4) for p, o in zip(self._params, self.offsets)]
+
+    # -- torch.optim API -----------------------------------------------------------------------
+    def zero_grad(self, set_to_none: bool = False):
+        if not self._built:
+            self._build()
+        Fh.mark_fresh(self._params)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if not self._built:
+            self._build()
+        if self.pre_step_hook is not None:
+            self.pre_step_hook()
+        self._step += 1
+        g = self.param_groups[0]
+        lr, (b1, b2), eps = float(g["lr"]), g["betas"], g["eps"]
+        # contiguous runs of parameters that received a gradient this step (normally a single run = everything)
+        runs, start = [], None
+        for i, p in enumerate(self._params):
+            has = (p.grad is not None) and not getattr(p, "_mg_fresh", False)
+            if has and start is None:
+                start = i
+            if not has and start is not None:
+                runs.append((start, i))
+                start = None
+        if start is not None:
+            runs.append((start, len(self._params)))
+        for a, b in runs:
+            lo = self.offsets[a]
+            hi = self.total if b == len(self._params) else self.offsets[b]
+            ops.adam_step(self.flat_p[lo:hi], self.flat_g[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi], lr, b1, b2,
+                          eps, self._step, self.grad_scale)
+        return None

@@ -1,0 +1,372 @@
+"""Model facade with the reference's public surface (models/pix2pixHD_model.py, models/models.py,
+models/base_model.py): Audio2MDCT (:14-200), Pix2PixHDModel.{initialize :215-364, forward :394-414,
+_forward :416-616, inference :618-638, save, update_learning_rate, update_fixed_params}, InferenceModel,
+create_model -- plus optimize_parameters(lr_audio, hr_audio), the G/D step that the reference keeps inline in
+train.py:160-202 (BaseModel.optimize_parameters is an empty stub there).
+
+Everything numerical is a HIP launch through the C ABI; torch provides tensors, autograd bookkeeping and the
+optimiser / module containers.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict
+
+import torch
+
+from . import _lib, networks
+from . import functional as Fh
+from .mdct import IMDCT4, MDCT4, dct4_table, imdct4_codec, kbdwin, mdct4_codec
+from .optim import FusedAdam
+
+
+class Audio2MDCT(torch.nn.Module):
+    """models/pix2pixHD_model.py:14-200.  to_spectro == K1 (MDCT + arcsinh + range-norm in one launch),
+    to_audio == K2 (denorm + sinh + IMDCT + overlap-add in one launch)."""
+
+    def __init__(self, opt) -> None:
+        super().__init__()
+        for k, v in vars(opt).items():
+            setattr(self, k, v)
+        self.device = "cuda" if len(self.gpu_ids) > 0 else "cpu"
+        self.up_ratio = self.hr_sampling_rate / self.lr_sampling_rate
+        self.window = kbdwin(self.win_length).to(self.device)
+        self.min_value = opt.min_value
+        self._mdct = MDCT4(n_fft=self.n_fft, hop_length=self.hop_length, win_length=self.win_length,
+                           window=self.window, device=self.device)
+        self._imdct = IMDCT4(n_fft=self.n_fft, hop_length=self.hop_length, win_length=self.win_length,
+                             window=self.window, device=self.device)
+        if getattr(self, "explicit_encoding", False):
+            raise NotImplementedError("--explicit_encoding (dB pair codec) is outside the HIP hot path")
+        if not (self.arcsinh_transform or self.raw_mdct):
+            raise NotImplementedError("the dB codec branch is outside the HIP hot path; use --arcsinh_transform")
+        self.codec = _lib.MG_CODEC_ARCSINH if self.arcsinh_transform else _lib.MG_CODEC_RANGE
+        self.return_stats = True      # mean / std of norm_param (returned only; costs two atomics per wave)
+        self.return_frames = False    # norm_param['frames'] (dead on the hot path; [B, F, 512] of extra traffic)
+        self.return_pha = False       # pha = sign(X) * noise is dead on the arcsinh / raw paths
+
+    # -- helpers --------------------------------------------------------------------------------
+    def _tables(self, dev):
+        if self.window.device != dev:
+            self.window = self.window.to(dev)
+        return self.window, dct4_table(self.n_fft // 2, dev)
+
+    def _ranges(self):
+        return (float(self.norm_range[0]), float(self.norm_range[1])), (float(self.src_range[0]), float(self.src_range[1]))
+
+    def encode(self, audio, want_pair=False, want_stats=None, want_frames=None):
+        """Fused K1 launch.  Returns the launcher dict (spec [B,F,W], pair [B,F,W,2] NHWC, min/max, stats)."""
+        window, d4 = self._tables(audio.device)
+        nr, sr = self._ranges()
+        return mdct4_codec(audio, window, d4, self.n_fft, codec=self.codec, gain=float(self.arcsinh_gain),
+                           norm_range=nr, src_range=sr, per_sample=not self.abs_norm, want_pair=want_pair,
+                           want_stats=self.return_stats if want_stats is None else want_stats,
+                           want_frames=self.return_frames if want_frames is None else want_frames)
+
+    def _norm_param(self, r, dev):
+        if self.abs_norm:
+            a_min = torch.tensor([self.src_range[0]], device=dev)[None, None, None, :]
+            a_max = torch.tensor([self.src_range[1]], device=dev)[None, None, None, :]
+        else:
+            a_min, a_max = r["min"][:, None, None, None], r["max"][:, None, None, None]
+        mean = std = None
+        if r["stats"] is not None:
+            n = r["spec"].numel()
+            s = r["stats"]
+            mean = (s[0] / n).float()
+            std = ((s[1] - s[0] * s[0] / n) / (n - 1)).clamp_min(0).sqrt().float()
+        return {"max": a_max, "min": a_min, "mean": mean, "std": std, "frames": r["frames"]}
+
+    # -- reference API --------------------------------------------------------------------------
+    def to_spectro(self, audio: torch.Tensor, mask: bool = False, mask_size: int = -1):
+        r = self.encode(audio)
+        log_spectro = r["spec"][:, None]                      # [B, 1, F, W] float32
+        pha = None
+        if self.return_pha:
+            zero = (0.0 - self.src_range[0]) / (self.src_range[1] - self.src_range[0]) * \
+                (self.norm_range[1] - self.norm_range[0]) + self.norm_range[0] if self.abs_norm else None
+            if zero is None:
+                raise NotImplementedError("pha with per-sample normalisation")
+            noise = torch.randn(log_spectro.size(), device=log_spectro.device)
+            noise = (noise - noise.min()) / (noise.max() - noise.min())
+            pha = torch.sign(log_spectro - zero) * noise
+        if mask:   # pix2pixHD_model.py:57-80 (off in every BASELINE config): overwrite the top bins
+            size = log_spectro.size()
+            if mask_size == -1:
+                mask_size = int(size[3] * (1 - 1 / self.up_ratio))
+            if mask_size > 0:
+                if self.fit_residual:
+                    fill = torch.zeros(size[0], size[1], size[2], mask_size, device=log_spectro.device)
+                else:
+                    fill = torch.randn(size[0], size[1], size[2], mask_size, device=log_spectro.device)
+                    fill = fill / (fill.max() - fill.min())
+                log_spectro = torch.cat((log_spectro[:, :, :, :-mask_size], fill), dim=3)
+        return log_spectro, pha, self._norm_param(r, audio.device)
+
+    def normalize(self, spectro):
+        """API-completeness helper (never on the hot path: to_spectro fuses it into K1).  torch elementwise ops."""
+        if self.arcsinh_transform:
+            log_spectro = torch.arcsinh(self.arcsinh_gain * spectro) / torch.log(torch.tensor(10.0))
+        else:
+            log_spectro = spectro
+        mean = log_spectro.mean().float()
+        std = log_spectro.var().sqrt().float()
+        if not self.abs_norm:
+            audio_max = log_spectro.flatten(-2).max(dim=-1).values[:, :, None, None].float()
+            audio_min = log_spectro.flatten(-2).min(dim=-1).values[:, :, None, None].float()
+        else:
+            audio_min = torch.tensor([self.src_range[0]], device=spectro.device)[None, None, None, :]
+            audio_max = torch.tensor([self.src_range[1]], device=spectro.device)[None, None, None, :]
+        log_spectro = (log_spectro - audio_min) / (audio_max - audio_min)
+        log_spectro = log_spectro * (self.norm_range[1] - self.norm_range[0]) + self.norm_range[0]
+        return log_spectro, audio_max, audio_min, mean, std
+
+    def denormalize(self, log_spectro: torch.Tensor, min: torch.Tensor, max: torch.Tensor):
+        """API-completeness helper (to_audio fuses it into K2)."""
+        x = (log_spectro - self.norm_range[0]) / (self.norm_range[1] - self.norm_range[0])
+        x = x * (max - min) + min
+        if self.arcsinh_transform:
+            return torch.sinh(x * torch.log(torch.tensor(10.0))) / self.arcsinh_gain
+        return x
+
+    def to_audio(self, log_spectro: torch.Tensor, norm_param: Dict[str, torch.Tensor], pha: torch.Tensor = None):
+        window, d4 = self._tables(log_spectro.device)
+        nr, sr = self._ranges()
+        mn, mx = norm_param["min"], norm_param["max"]
+        per_sample = mn.numel() > 1
+        if not per_sample:
+            sr = (float(mn.reshape(-1)[0]), float(mx.reshape(-1)[0])) if not self.abs_norm else sr
+        spec = log_spectro.squeeze(1) if log_spectro.dim() == 4 else log_spectro
+        audio, _ = imdct4_codec(spec, window, d4, self.n_fft, codec=self.codec, gain=float(self.arcsinh_gain),
+                                norm_range=nr, src_range=sr, min_b=mn if per_sample else None,
+                                max_b=mx if per_sample else None)
+        return audio[:, None, None, :]
+
+    def forward(self, lr_audio: torch.Tensor):
+        with torch.no_grad():
+            return self.to_spectro(lr_audio, mask=self.mask)
+
+    def hr_forward(self, hr_audio: torch.Tensor):
+        with torch.no_grad():
+            return self.to_spectro(hr_audio, mask=self.mask_hr,
+                                   mask_size=int(self.n_fft * (1 - self.sr_sampling_rate / self.hr_sampling_rate) // 2))
+
+
+class BaseModel(torch.nn.Module):
+    """models/base_model.py (save / load helpers keep the reference's file naming and fall-backs)."""
+
+    def name(self):
+        return "BaseModel"
+
+    def initialize(self, opt):
+        self.opt = opt
+        self.gpu_ids = opt.gpu_ids
+        self.isTrain = opt.isTrain
+        self.save_dir = os.path.join(opt.checkpoints_dir, opt.name)
+        self.device = "cuda" if len(self.gpu_ids) > 0 else "cpu"
+
+    def save_network(self, network, network_label, epoch_label, gpu_ids=None):
+        save_path = os.path.join(self.save_dir, "%s_net_%s.pth" % (epoch_label, network_label))
+        os.makedirs(self.save_dir, exist_ok=True)
+        # plain contiguous NCHW tensors on the host: loads in the reference unchanged
+        sd = {k: v.detach().to("cpu").contiguous() for k, v in network.state_dict().items()}
+        torch.save(sd, save_path)
+
+    def load_network(self, network, network_label, epoch_label, save_dir=""):
+        save_path = os.path.join(save_dir or self.save_dir, "%s_net_%s.pth" % (epoch_label, network_label))
+        if not os.path.isfile(save_path):
+            print("%s not exists yet!" % save_path)
+            if network_label == "G":
+                raise FileNotFoundError("Generator must exist!")
+            return
+        pretrained = torch.load(save_path, map_location="cpu")
+        try:
+            network.load_state_dict(pretrained)
+        except RuntimeError:
+            model_dict = network.state_dict()
+            usable = {k: v for k, v in pretrained.items() if k in model_dict and v.size() == model_dict[k].size()}
+            module_map = getattr(self.opt, "param_key_map", {}) or {}
+            for name, param in pretrained.items():      # base_model.py:72-89 key remapping
+                parts = name.split(".")
+                key = ".".join(parts[:2])
+                if name not in usable and key in module_map:
+                    parts[1] = module_map[key]
+                    mapped = ".".join(parts)
+                    if mapped in model_dict and param.size() == model_dict[mapped].size():
+                        usable[mapped] = param
+            missing = [k for k in model_dict if k not in usable]
+            if missing and getattr(self.opt, "verbose", False):
+                print("Pretrained network %s: %d tensors not initialised" % (network_label, len(missing)))
+            network.load_state_dict(usable, strict=False)
+
+
+class Pix2PixHDModel(BaseModel):
+    def name(self):
+        return "Pix2PixHDModel"
+
+    # -- construction ---------------------------------------------------------------------------
+    def initialize(self, opt):
+        BaseModel.initialize(self, opt)
+        for k, v in vars(opt).items():
+            setattr(self, k, v)
+        self.isTrain = opt.isTrain
+        if getattr(opt, "fp16", False):
+            raise NotImplementedError("--fp16 (AMP) kernels are not built yet on the HIP path; run float32")
+        input_nc = opt.label_nc if opt.label_nc != 0 else opt.input_nc
+        self.preprocess = Audio2MDCT(opt)
+        self.preprocess.return_stats = False
+        self.freeze = opt.freeze_g_d or opt.freeze_g_u or opt.freeze_l_d or opt.freeze_l_u
+        self.netG = networks.define_G(
+            input_nc, opt.output_nc, opt.ngf, opt.netG, opt.n_downsample_global, opt.n_blocks_global,
+            opt.n_local_enhancers, opt.n_blocks_local, opt.norm, gpu_ids=self.gpu_ids,
+            upsample_type=opt.upsample_type, downsample_type=opt.downsample_type,
+            input_size=(opt.bins, opt.n_fft // 2), n_attn_g=opt.n_blocks_attn_g, n_attn_l=opt.n_blocks_attn_l,
+            proj_factor_g=opt.proj_factor_g, heads_g=opt.heads_g, dim_head_g=opt.dim_head_g,
+            proj_factor_l=opt.proj_factor_l, heads_l=opt.heads_l, dim_head_l=opt.dim_head_l)
+        self.netG.set_freeze(opt.freeze_g_d, opt.freeze_g_u, opt.freeze_l_d, opt.freeze_l_u)
+        if self.isTrain:
+            if opt.no_lsgan:
+                raise NotImplementedError("--no_lsgan is outside the HIP hot path")
+            self.netD = networks.define_D(input_nc + opt.output_nc, opt.ndf, opt.n_layers_D, opt.norm, False,
+                                          opt.num_D, not opt.no_ganFeat_loss, gpu_ids=self.gpu_ids)
+        if not self.isTrain or opt.continue_train or opt.load_pretrain:
+            self.load_network(self.netG, "G", opt.which_epoch, opt.load_pretrain)
+            if self.isTrain:
+                self.load_network(self.netD, "D", opt.which_epoch, opt.load_pretrain)
+        if self.isTrain:
+            if opt.pool_size > 0:
+                raise NotImplementedError("--pool_size > 0 (image pool) is outside the hot path (default 0)")
+            self.old_lr = opt.lr
+            self.limit_aux_loss = False
+            self.criterionGAN = networks.GANLoss(use_lsgan=True, device=self.device)
+            self.loss_names = ["G_GAN"] + ([] if opt.no_ganFeat_loss else ["G_GAN_Feat"]) + ["D_real", "D_fake"]
+            if opt.niter_fix_global > 0:
+                params = [v for k, v in self.netG.named_parameters()
+                          if k.startswith("model" + str(opt.n_local_enhancers))]
+            else:
+                params = list(self.netG.parameters())
+            self.optimizer_G = FusedAdam([p for p in params if p.requires_grad], lr=opt.lr, betas=(opt.beta1, 0.999))
+            self.optimizer_D = FusedAdam(list(self.netD.parameters()), lr=opt.lr, betas=(opt.beta1, 0.999))
+        # A D pass whose weight gradients train.py discards (the G-loss pass) skips its wgrad launches; set False
+        # to reproduce the reference's wasted work bit for bit.
+        self.skip_discarded_d_grads = True
+        self.current_lable = self.current_generated = self.current_real = None
+
+    def loss_filter(self, g_gan, g_gan_feat, d_real, d_fake):
+        out = [g_gan]
+        if not self.no_ganFeat_loss:
+            out.append(g_gan_feat)
+        return out + [d_real, d_fake]
+
+    # -- forward --------------------------------------------------------------------------------
+    def _two_channel(self, spectro):
+        if self.abs_spectro and self.arcsinh_transform:
+            return Fh.g_input(spectro, float(self.norm_range[0]))
+        return spectro
+
+    def forward(self, lr_audio, hr_audio):
+        """pix2pixHD_model.py:394-414."""
+        pre = self.preprocess
+        lr_spectro, lr_pha, lr_norm_param = pre.forward(lr_audio)
+        hr_spectro, hr_pha, hr_norm_param = pre.hr_forward(hr_audio)
+        lr_input = self._two_channel(lr_spectro)
+        sr_spectro = self.netG.forward(lr_input)
+        if self.fit_residual:
+            sr_spectro = Fh.add(sr_spectro, lr_spectro)
+        return sr_spectro, None, hr_spectro, hr_pha, hr_norm_param, lr_spectro, lr_pha, lr_norm_param
+
+    def _d_in(self, lr_spectro, x_spectro):
+        if self.abs_spectro and self.arcsinh_transform:
+            return Fh.d_input(lr_spectro, x_spectro, float(self.norm_range[0]))
+        raise NotImplementedError("discriminator input without --abs_spectro --arcsinh_transform")
+
+    def _forward(self, lr_audio, hr_audio, infer=False):
+        """pix2pixHD_model.py:416-616: the four live losses [G_GAN, G_GAN_Feat, D_real, D_fake]."""
+        sr_spectro, _, hr_spectro, _, hr_norm_param, lr_spectro, _, lr_norm_param = self.forward(lr_audio, hr_audio)
+        pred_fake_pool = self.netD.forward(self._d_in(lr_spectro, sr_spectro.detach()))
+        loss_D_fake = self.criterionGAN(pred_fake_pool, False)
+        pred_real = self.netD.forward(self._d_in(lr_spectro, hr_spectro))
+        loss_D_real = self.criterionGAN(pred_real, True)
+        pred_fake = self.netD.forward(self._d_in(lr_spectro, sr_spectro),
+                                      weight_grad=not self.skip_discarded_d_grads)
+        loss_G_GAN = self.criterionGAN(pred_fake, True)
+        loss_G_GAN_Feat = 0
+        if not self.no_ganFeat_loss:
+            feat_weights = 4.0 / (self.n_layers_D + 1)
+            D_weights = 1.0 / self.num_D
+            for i in range(self.num_D):
+                for j in range(len(pred_fake[i]) - 1):
+                    loss_G_GAN_Feat = loss_G_GAN_Feat + Fh.l1_loss(
+                        pred_fake[i][j], pred_real[i][j].detach(), D_weights * feat_weights * self.lambda_feat)
+        # visuals are materialised lazily (the reference copies three tensors to the host every step)
+        self._visual_src = (lr_spectro, sr_spectro.detach(), hr_spectro, lr_norm_param, hr_norm_param)
+        return [self.loss_filter(loss_G_GAN, loss_G_GAN_Feat, loss_D_real, loss_D_fake),
+                torch.empty if not infer else sr_spectro]
+
+    def optimize_parameters(self, lr_audio, hr_audio):
+        """One train.py:160-202 iteration (float32 branch): forward, G step, D step.  Returns the loss dict
+        (device scalars; call .item() only when you need to print)."""
+        losses, _ = self._forward(lr_audio, hr_audio, infer=False)
+        loss_dict = dict(zip(self.loss_names, losses))
+        loss_D = (loss_dict["D_fake"] + loss_dict["D_real"]) * 0.5
+        loss_G = loss_dict["G_GAN"] + loss_dict.get("G_GAN_Feat", 0)
+        self.optimizer_G.zero_grad()
+        loss_G.backward()
+        self.optimizer_G.step()
+        self.optimizer_D.zero_grad()
+        loss_D.backward()
+        self.optimizer_D.step()
+        return loss_dict
+
+    def inference(self, lr_audio):
+        """pix2pixHD_model.py:618-638."""
+        with torch.no_grad():
+            lr_spectro, lr_pha, lr_norm_param = self.preprocess.forward(lr_audio)
+            sr_spectro = self.netG.forward(self._two_channel(lr_spectro))
+            if self.fit_residual:
+                lr_part = int(sr_spectro.size(-1) / self.preprocess.up_ratio)
+                sr_spectro[..., :lr_part] *= 1e-3
+                sr_spectro = Fh.add(sr_spectro, lr_spectro)
+            sr_audio = self.preprocess.to_audio(sr_spectro, lr_norm_param, lr_pha)
+        return sr_spectro, sr_audio, lr_pha, lr_norm_param, lr_spectro
+
+    # -- bookkeeping ----------------------------------------------------------------------------
+    def save(self, which_epoch):
+        self.save_network(self.netG, "G", which_epoch, self.gpu_ids)
+        self.save_network(self.netD, "D", which_epoch, self.gpu_ids)
+
+    def update_fixed_params(self):
+        self.optimizer_G = FusedAdam(list(self.netG.parameters()), lr=self.lr, betas=(self.beta1, 0.999))
+
+    def update_learning_rate(self):
+        lrd = self.lr / self.niter_decay
+        lr = self.old_lr - lrd
+        for opt_ in (self.optimizer_D, self.optimizer_G):
+            for param_group in opt_.param_groups:
+                param_group["lr"] = lr
+        self.old_lr = lr
+
+    def get_current_visuals(self):
+        """Raw denormalised spectrogram arrays of sample 0 (pix2pixHD_model.py:569-590).  The matplotlib rendering
+        of util/spectro_img.py is observability, not part of the hot path."""
+        lr_s, sr_s, hr_s, lr_n, hr_n = self._visual_src
+        nr0, nr1 = self.norm_range
+
+        def den(s, n):
+            return ((s[0, 0].float().cpu() - nr0) / (nr1 - nr0) * (n["max"].reshape(-1)[0].cpu() - n["min"].reshape(-1)[0].cpu())
+                    + n["min"].reshape(-1)[0].cpu()).numpy()
+        return {"lable_spectro": den(lr_s, lr_n), "generated_spectro": den(sr_s, lr_n), "real_spectro": den(hr_s, hr_n)}
+
+
+class InferenceModel(Pix2PixHDModel):
+    def forward(self, lr_audio):
+        return self.inference(lr_audio)
+
+
+def create_model(opt):
+    """models/models.py:3-20."""
+    if opt.model != "pix2pixHD":
+        raise NotImplementedError("only --model pix2pixHD exists on the hot path")
+    model = Pix2PixHDModel() if opt.isTrain else InferenceModel()
+    model.initialize(opt)
+    return model

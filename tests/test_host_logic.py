@@ -1,0 +1,109 @@
+"""Host-side logic that needs no GPU: option contract, module trees / state-dict keys of the HIP-backed
+networks against the keys captured from the reference, layer-pattern compilation, optimiser arena maths."""
+import numpy as np
+import pytest
+import torch
+
+from mdctgan_amd import networks, options
+
+
+def test_train_sh_flags_parse():
+    flags = ("--name x --lr_sampling_rate 16000 --sr_sampling_rate 48000 --batchSize 20 --gpu_id -1 --fp16 "
+             "--nThreads 16 --lr 1.5e-4 --arcsinh_transform --abs_spectro --arcsinh_gain 1000 --center "
+             "--norm_range -1 1 --smooth 0.0 --abs_norm --src_range -5 5 --netG local --ngf 56 "
+             "--n_downsample_global 3 --n_blocks_global 4 --n_blocks_attn_g 3 --dim_head_g 128 --heads_g 6 "
+             "--proj_factor_g 4 --n_blocks_attn_l 0 --n_blocks_local 3 --fit_residual --upsample_type interpolate "
+             "--downsample_type resconv --niter 60 --niter_decay 60 --num_D 3 --eval_freq 32000 "
+             "--save_latest_freq 16000 --save_epoch_freq 10 --display_freq 16000 --tf_log").split()
+    opt = options.TrainOptions().parse(flags)
+    assert opt.gpu_ids == [] and opt.isTrain and opt.netG == "local" and opt.ngf == 56
+    assert opt.norm_range == [-1.0, 1.0] and opt.src_range == [-5.0, 5.0] and opt.arcsinh_gain == 1000
+    assert opt.segment_length == 32512 and opt.n_fft == 512 and opt.hop_length == 256 and opt.bins == 128
+    d = options.TrainOptions().parse([])
+    assert (d.lr, d.beta1, d.num_D, d.n_layers_D, d.lambda_feat, d.input_nc, d.output_nc) == (2e-4, 0.5, 2, 3, 10.0, 2, 1)
+    assert d.n_downsample_global == 4 and d.n_blocks_global == 9 and d.netG == "global" and d.pool_size == 0
+
+
+CFGS = {
+    "global": dict(netG="global", ngf=8, n_downsample_global=4, n_blocks_global=2),
+    "local": dict(netG="local", ngf=4, n_downsample_global=3, n_blocks_global=2, n_blocks_local=1),
+    "global_resconv_interp": dict(netG="global", ngf=4, n_downsample_global=3, n_blocks_global=1,
+                                  upsample_type="interpolate", downsample_type="resconv"),
+}
+
+
+def build_g(tag):
+    c = dict(CFGS[tag])
+    return networks.define_G(2, 1, c.pop("ngf"), c.pop("netG"), input_size=(32, 256), n_attn_g=0, **c)
+
+
+@pytest.mark.parametrize("tag", list(CFGS))
+def test_generator_state_dict_contract(tag, golden):
+    g = golden("g5_netG_" + tag)
+    net = build_g(tag)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(g["keys"])
+    assert [str(tuple(p.shape)) for p in sd.values()] == list(g["shapes"])
+    for k, p in sd.items():
+        if p.dim() == 4:
+            assert p.is_contiguous(memory_format=torch.channels_last), k      # OHWI storage
+    # a reference-layout (contiguous NCHW) checkpoint loads and keeps the OHWI storage
+    ref_sd = {k: torch.randn(p.shape) for k, p in sd.items()}
+    net.load_state_dict(ref_sd)
+    for k, p in net.state_dict().items():
+        assert torch.equal(p, ref_sd[k])
+        if p.dim() == 4:
+            assert p.is_contiguous(memory_format=torch.channels_last), k
+    # the fused plan compiles (no unsupported layer pattern)
+    for name in ("model", "model1_1", "model1_2"):
+        if hasattr(net, name):
+            assert len(networks.FusedSequence(getattr(net, name)).steps) > 0
+
+
+def test_discriminator_state_dict_contract(golden):
+    g = golden("g6_step_global")
+    netD = networks.define_D(3, 8, 3, "instance", False, 2, True)
+    assert list(netD.state_dict().keys()) == list(g["keysD"])
+    for k, p in netD.state_dict().items():
+        assert tuple(p.shape) == g["pD_after/" + k].shape
+
+
+def test_weights_init_statistics():
+    net = build_g("global")
+    w = net.model[16].conv_block[1].weight
+    assert abs(float(w.std()) - 0.02) < 2e-3 and abs(float(w.mean())) < 2e-3
+
+
+def test_unsupported_configs_fail_loudly():
+    with pytest.raises(NotImplementedError):
+        networks.define_G(2, 1, 8, "global", 3, 2, n_attn_g=1, input_size=(32, 256))
+    with pytest.raises(NotImplementedError):
+        networks.get_norm_layer("batch")
+    with pytest.raises(NotImplementedError):
+        networks.GANLoss(use_lsgan=False)
+    net = build_g("global")
+    from mdctgan_amd import _lib
+    with pytest.raises(_lib.HipLibraryError):
+        net(torch.zeros(1, 2, 32, 256))                     # host tensor: no CPU fallback
+
+
+def test_set_freeze_semantics():
+    net = build_g("global")
+    net.set_freeze(False, False, False, False)               # the call the reference makes (TypeError there)
+    assert all(p.requires_grad for p in net.parameters())
+    net.set_freeze(True)
+    frozen = [k for k, p in net.named_parameters() if not p.requires_grad]
+    assert frozen and all(int(k.split(".")[1]) < 16 for k in frozen)
+    loc = build_g("local")
+    loc.set_freeze(True, False, True, False)
+    assert not loc.model1_1[1].weight.requires_grad and loc.model1_2[0].conv_block[1].weight.requires_grad
+
+
+def test_arena_view_roundtrip():
+    from mdctgan_amd.optim import _arena_view
+    flat = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32)
+    p = torch.empty(2, 3, 4, 5).contiguous(memory_format=torch.channels_last)
+    v = _arena_view(flat, 0, p)
+    assert v.shape == p.shape and v.stride() == p.stride()
+    b = torch.empty(7)
+    assert _arena_view(flat, 8, b).shape == (7,)
