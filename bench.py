@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py -- the reference's headline metric on MI355X: train steps/s (G+D) on synthetic VCTK-shaped
+12 kHz -> 48 kHz segments (BASELINE.json configs[1]: netG=global, ngf 64, 9 ResNet blocks, no attention,
+num_D 2, per-GPU batch 8, float32, T = 32512 = 128 frames x 256 bins).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|infer]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one train.py:160-202 iteration (forward, 3 discriminator passes, G backward + Adam, D backward +
+Adam) through Pix2PixHDModel.optimize_parameters; inputs are resident in HBM before the timed region.
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     -- dominant kernel (by event-timed GPU time in the timed region): algorithmic FLOPs per launch /
+                  average launch duration (HIP events on the launch stream) vs the dense f32 MFMA peak.
+  cpu_baseline -- the CPU oracle's train step (torch CPU, all host cores) on a bounded sample, N == 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
+T_SEG, BATCH = 32512, 8
+
+
+def synth_batch(batch, seed, device, lr_rate=12000, hr_rate=48000):
+    """HR = 0.05 * randn([B, 32512]); LR = HR ideally low-passed to lr_rate/2 (stands in for the resample chain of
+    data/audio_dataset.py:66-71).  Built once, outside the timed region."""
+    g = torch.Generator().manual_seed(seed)
+    hr = 0.05 * torch.randn(batch, T_SEG, generator=g)
+    spec = torch.fft.rfft(hr)
+    spec[:, int(spec.shape[-1] * lr_rate / hr_rate):] = 0
+    lr = torch.fft.irfft(spec, n=T_SEG)
+    return lr.to(device), hr.to(device)
+
+
+class KernelTimer:
+    """HIP-event brackets around conv launches (the stream the kernels are launched on is torch's current
+    stream).  mode 'all': every conv launch; mode 'only': only launches of `target` (cheap, used in the timed
+    region)."""
+
+    def __init__(self, ops, target=None):
+        self.ops, self.target, self.open, self.records = ops, target, None, []
+        self.names = {}
+
+    def begin(self, pass_id, g):
+        key = (pass_id, g.B, g.H, g.W, g.Ci, g.Co, g.KH, g.stride, g.reflect)
+        name = self.names.get(key)
+        if name is None:
+            name = self.names[key] = self.ops.plan_name(pass_id, g)
+        if self.target is not None and name != self.target:
+            self.open = None
+            return
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.open = (name, self.ops.conv_flops(g), e0)
+
+    def end(self):
+        if self.open is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.append(self.open + (e1,))
+        self.open = None
+
+    def summary(self):
+        agg = {}
+        for name, flops, e0, e1 in self.records:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += flops
+            a[2] += e0.elapsed_time(e1) * 1e-3
+        return agg
+
+
+def cpu_baseline_train(threads):
+    """The CPU oracle (oracle/step.py, torch CPU float32 + float64 transform == the reference's arithmetic) timed on
+    a bounded sample of the same workload: the full configs[1] networks, ONE step at batch 2 after a batch-1
+    warm-up step, scaled by 2/8 to the batch-8 step rate."""
+    from oracle import nets as onets
+    from oracle import step as ostep
+    torch.set_num_threads(threads)
+    gen = torch.Generator().manual_seed(0)
+    netG = onets.init_weights(onets.build_generator("global", 2, 1, 64, 4, 9, input_size=(128, 256)), gen)
+    netD = onets.init_weights(onets.MultiscaleDRef(3, 64, 3, 2), gen)
+    ref = ostep.HotPathRef(netG, netD, ostep.CodecCfg(), num_D=2)
+    lr, hr = synth_batch(2, 1, "cpu")
+    ref.train_step(lr[:1].numpy(), hr[:1].numpy())
+    t0 = time.perf_counter()
+    ref.train_step(lr.numpy(), hr.numpy())
+    dt = time.perf_counter() - t0
+    return {"value": (1.0 / dt) * (2.0 / BATCH), "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": "1 G+D step of configs[1] at batch 2 (after a batch-1 warm-up), scaled x2/8 to batch 8; %.1f s" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    from mdctgan_amd import ddp, ops, options
+    from mdctgan_amd.pix2pixHD_model import create_model
+    torch.manual_seed(42)
+    opt = options.make_opt(*options.SPECTRAL_FLAGS, "--lr_sampling_rate", "12000", "--netG", "global", "--ngf", "64",
+                           "--n_downsample_global", "4", "--n_blocks_global", "9", "--n_blocks_attn_g", "0",
+                           "--num_D", "2", "--batchSize", str(BATCH), "--gpu_ids", str(local_rank))
+    model = create_model(opt)
+    if world > 1:
+        ddp.attach(model)
+    lr, hr = synth_batch(BATCH, 42 + rank, dev)
+
+    def step():
+        if args.mode == "train":
+            model.optimize_parameters(lr, hr)
+        else:
+            model.inference(lr)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up; the first warm-up step also times every conv kernel to find the dominant one
+    timer_all = KernelTimer(ops)
+    for i in range(max(args.warmup, 1)):
+        if i == 0 and not args.no_roofline:
+            ops.PROFILER = timer_all
+        step()
+        ops.PROFILER = None
+    torch.cuda.synchronize()
+    dominant = None
+    if not args.no_roofline:
+        agg = timer_all.summary()
+        dominant = max(agg, key=lambda k: agg[k][2]) if agg else None
+    timer = KernelTimer(ops, target=dominant) if dominant else None
+
+    fence()
+    ops.PROFILER = timer
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    ops.PROFILER = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    roofline = None
+    if timer is not None and timer.records:
+        n, flops, secs = timer.summary()[dominant]
+        achieved = flops / secs / 1e12
+        roofline = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches": n, "avg_launch_us": round(secs / n * 1e6, 2),
+                    "flops_per_launch": flops / n}
+        tr = os.path.join(REPO, "profiles", "traffic.json")     # HBM bytes/launch from rocprofv3 --pmc passes
+        if os.path.exists(tr):
+            try:
+                roofline["traffic"] = json.load(open(tr)).get(dominant)
+            except Exception:
+                pass
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        if args.mode == "train":
+            metric, value, unit = "train steps/sec (G+D) VCTK 12k->48k", world * args.steps / dt, "steps/s"
+        else:
+            metric, value, unit = "infer audio-sec/sec", world * args.steps * BATCH * T_SEG / 48000.0 / dt, "audio-s/s"
+        out = {"metric": metric, "value": round(value, 4), "unit": unit, "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "configs[1]: netG=global ngf=64 n_blocks_global=9 n_blocks_attn_g=0 num_D=2, "
+                                      "per-GPU batch 8 x 32512 samples (128 frames x 256 bins), 12k->48k, fp32",
+                          "global_batch": BATCH * world, "segment_length": T_SEG,
+                          "parallelism": "dp%d" % world, "steps_counted": "one G+D optimisation step per GPU; value = "
+                          "steps of per-GPU batch 8 completed per second summed over GPUs (weak scaling)"},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline and args.mode == "train":
+            out["cpu_baseline"] = cpu_baseline_train(os.cpu_count() or 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

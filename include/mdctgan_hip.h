@@ -102,6 +102,9 @@ int mg_conv_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const 
 int mg_conv_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias, int accumulate,
                   void* workspace, size_t workspace_bytes, void* stream);
 size_t mg_conv_wgrad_workspace(const mg_conv_geom* g);
+/* Name of the kernel instance a pass (0 fwd, 1 dgrad, 2 wgrad) launches for this geometry -- the symbol
+ * rocprofv3 reports -- so bench.py can attribute event-timed launches per kernel.  out: host buffer >= 64 B. */
+int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len);
 /* column sums: out[c] (+)= sum_m a[m, c]  -- bias gradients of ConvTranspose2d layers */
 int mg_colsum(const float* a, long long M, int C, float* out, int accumulate, void* workspace,
               size_t workspace_bytes, void* stream);

@@ -20,6 +20,7 @@
 // buffering, one barrier per k-chunk; with 64-cycle MFMAs the loader hides completely.
 #include "common.h"
 #include "mdctgan_hip.h"
+#include <stdio.h>
 
 namespace {
 
@@ -618,6 +619,26 @@ ColsumPlan colsum_plan(long long M, int C) {
     return {(int)splits, rps};
 }
 
+// tile selection shared by the launchers and mg_conv_plan_name()
+struct TilePlan { int bm, bn; };
+TilePlan fwd_plan(const mg_conv_geom* g) {
+    const long long M = (long long)g->B * g->OH * g->OW;
+    const int N = g->Co;
+    const long long t128 = ((M + 127) / 128) * ((N + 127) / 128);
+    if (t128 >= 192 && N >= 128) return {128, 128};
+    if (N > 32 || M < 64 * 512) return {64, 64};
+    return {128, 64};
+}
+TilePlan dgrad_plan(const mg_conv_geom* g) {
+    const int s = g->stride;
+    const long long Mc = (long long)g->B * ((g->H + s - 1) / s) * ((g->W + s - 1) / s);
+    const int N = g->Ci;
+    const long long t128 = ((Mc + 127) / 128) * ((N + 127) / 128);
+    if (t128 * s * s >= 192 && N >= 128) return {128, 128};
+    if (N > 32 || Mc < 64 * 512) return {64, 64};
+    return {128, 64};
+}
+
 struct WgradPlan { bool big; int tiles; int splits; int cps; };
 WgradPlan wgrad_plan(const mg_conv_geom* g) {
     const int R = g->Co, N = g->KH * g->KW * g->Ci;
@@ -641,6 +662,27 @@ extern "C" {
 
 int mg_abi_version(void) { return 1; }
 
+// Name of the kernel instance a pass would launch for this geometry (matches the symbol rocprofv3 reports,
+// minus the anonymous-namespace prefix).  pass: 0 fwd, 1 dgrad, 2 wgrad.
+int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
+    if (!geom_ok(g) || !out || out_len < 64) return MG_ERR_ARG;
+    if (pass == 0) {
+        const TilePlan tp = fwd_plan(g);
+        snprintf(out, out_len, "conv_fwd_kernel<%d, %d, %s>", tp.bm, tp.bn, (g->Ci % BK == 0) ? "true" : "false");
+    } else if (pass == 1) {
+        const TilePlan tp = dgrad_plan(g);
+        snprintf(out, out_len, "conv_dgrad_kernel<%d, %d, %s, %s>", tp.bm, tp.bn, (g->Co % BK == 0) ? "true" : "false",
+                 (g->Ci % 4 == 0) ? "true" : "false");
+    } else if (pass == 2) {
+        const WgradPlan p = wgrad_plan(g);
+        snprintf(out, out_len, "conv_wgrad_kernel<%d, %d, %s, %s>", p.big ? 128 : 64, p.big ? 128 : 64,
+                 (g->Co % 4 == 0) ? "true" : "false", (g->Ci % 4 == 0) ? "true" : "false");
+    } else {
+        return MG_ERR_ARG;
+    }
+    return MG_OK;
+}
+
 int mg_conv_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
                 void* stream) {
     if (!geom_ok(g) || !x || !w || !y) return MG_ERR_ARG;
@@ -649,13 +691,12 @@ int mg_conv_fwd(const mg_conv_geom* g, const float* x, const float* w, const flo
     const long long M = (long long)g->B * g->OH * g->OW;
     const int N = g->Co;
     const bool vec = (g->Ci % BK == 0) && aligned16(x) && aligned16(w);
-    const long long t128 = ((M + 127) / 128) * ((N + 127) / 128);
-    const bool big = t128 >= 192 && N >= 128;
-    if (big) {
-        dim3 grid((unsigned)t128);
+    const TilePlan tp = fwd_plan(g);
+    if (tp.bm == 128 && tp.bn == 128) {
+        dim3 grid((unsigned)(((M + 127) / 128) * ((N + 127) / 128)));
         if (vec) hipLaunchKernelGGL((conv_fwd_kernel<128, 128, true>), grid, dim3(256), 0, st, gg, x, w, bias, y, act);
         else hipLaunchKernelGGL((conv_fwd_kernel<128, 128, false>), grid, dim3(256), 0, st, gg, x, w, bias, y, act);
-    } else if (N > 32 || M < 64 * 512) {
+    } else if (tp.bm == 64) {
         dim3 grid((unsigned)(((M + 63) / 64) * ((N + 63) / 64)));
         if (vec) hipLaunchKernelGGL((conv_fwd_kernel<64, 64, true>), grid, dim3(256), 0, st, gg, x, w, bias, y, act);
         else hipLaunchKernelGGL((conv_fwd_kernel<64, 64, false>), grid, dim3(256), 0, st, gg, x, w, bias, y, act);
@@ -680,8 +721,7 @@ int mg_conv_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const 
     const int N = g->Ci;
     const bool veca = (g->Co % BK == 0) && aligned16(dy);
     const bool vecb = (g->Ci % 4 == 0) && aligned16(w);
-    const long long t128 = ((Mc + 127) / 128) * ((N + 127) / 128);
-    const bool big = t128 * s * s >= 192 && N >= 128;
+    const TilePlan tp = dgrad_plan(g);
 #define MG_LAUNCH_DGRAD(BM_, BN_)                                                                                  \
     do {                                                                                                           \
         dim3 grid((unsigned)(((Mc + BM_ - 1) / BM_) * ((N + BN_ - 1) / BN_)), 1, s * s);                           \
@@ -694,8 +734,8 @@ int mg_conv_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const 
         else                                                                                                       \
             hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, false, false>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act);\
     } while (0)
-    if (big) MG_LAUNCH_DGRAD(128, 128);
-    else if (N > 32 || Mc < 64 * 512) MG_LAUNCH_DGRAD(64, 64);
+    if (tp.bm == 128 && tp.bn == 128) MG_LAUNCH_DGRAD(128, 128);
+    else if (tp.bm == 64) MG_LAUNCH_DGRAD(64, 64);
     else MG_LAUNCH_DGRAD(128, 64);
 #undef MG_LAUNCH_DGRAD
     MG_CHECK_LAUNCH();

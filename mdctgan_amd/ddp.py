@@ -1,0 +1,102 @@
+"""Data-parallel gradient reduction over RCCL / xGMI (new capability: the reference is single-GPU).
+
+One process per GPU, per-GPU minibatch, identical initial weights (broadcast of the parameter arena), and a
+bucketed sum all-reduce of the *gradient arena* (the flat float32 buffer FusedAdam owns) that overlaps with
+backward: a bucket is launched on RCCL's stream the moment the last wgrad kernel that writes into it has been
+enqueued.  Averaging (1/world) is folded into the Adam kernel's grad_scale, so no extra pass touches the
+gradients.  Buckets are contiguous arena ranges, sized for xGMI (default 128 MiB: few, large collectives --
+each GPU has 7 point-to-point links, a ring moves 2(N-1)/N of the payload over one link per hop).
+
+Semantics: losses are batch means and every layer is per-sample (InstanceNorm), so the average of
+per-rank gradients equals the single-process gradient on the concatenated batch.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import functional as Fh
+
+
+class ArenaReducer:
+    """Reduces `flat_g` (1-D tensor) across ranks in contiguous buckets.
+
+    slices: [(param, offset, padded_numel)] in arena order.  writes_per_step: how many wgrad launches write each
+    parameter's gradient during one backward (1 for G; 2 for D: the fake and the real pass)."""
+
+    def __init__(self, flat_g, slices, writes_per_step=1, bucket_bytes=128 << 20, group=None):
+        self.flat_g, self.group = flat_g, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.writes_per_step = writes_per_step
+        self.active = True
+        self.buckets = []            # [lo, hi, n_params]
+        self.param_bucket = {}
+        lo, count, cur = 0, 0, 0
+        per_bucket = max(1, bucket_bytes // 4)
+        for p, off, n in slices:
+            self.param_bucket[id(p)] = len(self.buckets)
+            count += 1
+            cur = off + n
+            if cur - lo >= per_bucket:
+                self.buckets.append([lo, cur, count])
+                lo, count = cur, 0
+        if count:
+            self.buckets.append([lo, cur, count])
+        self._reset()
+        self._hook = Fh.register_grad_ready_hook(self._on_ready)
+
+    def _reset(self):
+        self.pending = [b[2] * self.writes_per_step for b in self.buckets]
+        self.works = []
+
+    def close(self):
+        Fh.remove_grad_ready_hook(self._hook)
+
+    def _launch(self, i):
+        lo, hi, _ = self.buckets[i]
+        if self.world > 1:
+            self.works.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
+                                              async_op=True))
+
+    def _on_ready(self, p):
+        if not self.active:
+            return
+        i = self.param_bucket.get(id(p))
+        if i is None:
+            return
+        self.pending[i] -= 1
+        if self.pending[i] == 0:
+            self._launch(i)
+
+    def finish(self):
+        """Called before the optimiser step: flush buckets that never filled (frozen / unused parameters) and make
+        the compute stream wait for every collective."""
+        for i, left in enumerate(self.pending):
+            if left > 0:
+                self._launch(i)
+        for w in self.works:
+            w.wait()
+        self._reset()
+
+
+def broadcast_arena(flat_p, src=0, group=None):
+    """C2: identical initial weights on every rank."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat_p, src=src, group=group)
+
+
+def attach(model, bucket_bytes=128 << 20, group=None):
+    """Wire a Pix2PixHDModel for data parallelism: broadcast both parameter arenas from rank 0, create the G and D
+    reducers and fold 1/world into the Adam kernels."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    reducers = {}
+    for name, opt, writes in (("G", model.optimizer_G, 1), ("D", model.optimizer_D, 2)):
+        slices = opt.arena_slices()
+        broadcast_arena(opt.flat_p, 0, group)
+        red = ArenaReducer(opt.flat_g, slices, writes, bucket_bytes, group)
+        opt.grad_scale = 1.0 / world
+        opt.pre_step_hook = red.finish
+        reducers[name] = red
+    reducers["D"].active = False
+    model.reducers = reducers
+    return reducers

@@ -18,19 +18,43 @@ def _ws(nbytes, dev):
     return _lib.workspace(nbytes, dev)
 
 
+# ---- optional per-kernel event timing (bench.py's roofline leg) ----------------------------------------------
+PROFILER = None     # object with .begin(name, flops) / .end(); set by bench.py, None in normal operation
+
+
+def plan_name(pass_id: int, g: ConvGeom) -> str:
+    import ctypes
+    buf = ctypes.create_string_buffer(96)
+    _lib.check(_lib.load().mg_conv_plan_name(pass_id, g, buf, 96), "mg_conv_plan_name")
+    return buf.value.decode()
+
+
+def conv_flops(g: ConvGeom) -> float:
+    """Algorithmic FLOPs of one pass (fwd == dgrad == wgrad): 2 * B*OH*OW * Co * KH*KW*Ci."""
+    return 2.0 * g.B * g.OH * g.OW * g.Co * g.KH * g.KW * g.Ci
+
+
 def conv_fwd(g: ConvGeom, x, w, bias=None, act=ACT_NONE):
     lib = _lib.load()
     y = torch.empty(g.B, g.OH, g.OW, g.Co, dtype=torch.float32, device=x.device)
+    if PROFILER is not None:
+        PROFILER.begin(0, g)
     _lib.check(lib.mg_conv_fwd(g, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), act, _lib.stream()),
                "mg_conv_fwd")
+    if PROFILER is not None:
+        PROFILER.end()
     return y
 
 
 def conv_dgrad(g: ConvGeom, dy, w, bias=None, act=ACT_NONE):
     lib = _lib.load()
     dx = torch.empty(g.B, g.H, g.W, g.Ci, dtype=torch.float32, device=dy.device)
+    if PROFILER is not None:
+        PROFILER.begin(1, g)
     _lib.check(lib.mg_conv_dgrad(g, _lib.ptr(dy), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(dx), act, _lib.stream()),
                "mg_conv_dgrad")
+    if PROFILER is not None:
+        PROFILER.end()
     return dx
 
 

@@ -310,9 +310,14 @@ class Pix2PixHDModel(BaseModel):
         loss_dict = dict(zip(self.loss_names, losses))
         loss_D = (loss_dict["D_fake"] + loss_dict["D_real"]) * 0.5
         loss_G = loss_dict["G_GAN"] + loss_dict.get("G_GAN_Feat", 0)
+        red = getattr(self, "reducers", None)      # data-parallel gradient reducers (mdctgan_amd.ddp.attach)
+        if red:
+            red["G"].active, red["D"].active = True, False
         self.optimizer_G.zero_grad()
         loss_G.backward()
         self.optimizer_G.step()
+        if red:
+            red["G"].active, red["D"].active = False, True
         self.optimizer_D.zero_grad()
         loss_D.backward()
         self.optimizer_D.step()

@@ -27,6 +27,10 @@ CONV_CASES = [
     ("conv1x1", 2, 64, 4, 8, 48, 1, 1, 0, False),
     ("wide_128tile", 2, 64, 16, 32, 256, 3, 1, 1, True),
     ("bottleneck_like", 8, 128, 8, 16, 128, 3, 1, 1, True),
+    ("down3x3_s2_ci8", 2, 8, 32, 256, 16, 3, 2, 1, False),
+    ("down3x3_s2_ci4", 2, 4, 32, 64, 8, 3, 2, 1, False),
+    ("conv3x3_ci24_reflect", 2, 24, 16, 32, 40, 3, 1, 1, True),
+    ("conv3x3_ci8_co8", 2, 8, 32, 256, 8, 3, 1, 1, True),
 ]
 
 
