@@ -91,12 +91,15 @@ typedef struct {
     int reflect; /* 0: zero padding, 1: reflection padding (ReflectionPad2d(pad) folded into the gather) */
 } mg_conv_geom;
 
-/* y = act(conv(x, w) + bias)            (bias nullable) */
+/* y = act(conv(x, w) + bias)            (bias nullable).  workspace (nullable): mg_conv_fwd_workspace() bytes of
+ * scratch that lets deep-K / small-M*N layers split K across workgroups (without it they run unsplit). */
 int mg_conv_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
-                void* stream);
+                void* workspace, size_t workspace_bytes, void* stream);
+size_t mg_conv_fwd_workspace(const mg_conv_geom* g);
 /* dx = conv^T(dy, w) (+ bias, act)      data gradient of the convolution == ConvTranspose2d forward */
 int mg_conv_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
-                  void* stream);
+                  void* workspace, size_t workspace_bytes, void* stream);
+size_t mg_conv_dgrad_workspace(const mg_conv_geom* g);
 /* dw [Co, KH, KW, Ci] = sum over pixels; dbias [Co] (nullable) = column sums of dy.
  * accumulate != 0 adds into dw / dbias instead of overwriting.  workspace: mg_conv_wgrad_workspace() bytes. */
 int mg_conv_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias, int accumulate,

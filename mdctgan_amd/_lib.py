@@ -35,8 +35,10 @@ SIGNATURES = {
     "mg_mdct4_forward": (_i, [_p, _i, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "mg_mdct4_num_frames": (_i, [_i, _i]),
     "mg_imdct4_forward": (_i, [_p, _i, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _p, _p, _p, _i, _i, _p, _p]),
-    "mg_conv_fwd": (_i, [_G, _p, _p, _p, _p, _i, _p]),
-    "mg_conv_dgrad": (_i, [_G, _p, _p, _p, _p, _i, _p]),
+    "mg_conv_fwd": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p]),
+    "mg_conv_fwd_workspace": (_sz, [_G]),
+    "mg_conv_dgrad": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p]),
+    "mg_conv_dgrad_workspace": (_sz, [_G]),
     "mg_conv_wgrad": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p]),
     "mg_conv_wgrad_workspace": (_sz, [_G]),
     "mg_conv_plan_name": (_i, [_i, _G, C.c_char_p, _i]),
@@ -124,6 +126,9 @@ _workspaces = {}
 
 def workspace(nbytes: int, device) -> torch.Tensor:
     """Persistent per-device scratch (grown on demand; all launches share one stream order)."""
+    if torch.device(device).type != "cuda":
+        raise HipLibraryError("the MI355X hot path needs device tensors (got a %s tensor); "
+                              "there is no CPU fallback" % device)
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:

@@ -86,7 +86,7 @@ template <int BM, int BN, bool VEC>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(Geom g, const float* __restrict__ x,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y,
-                                                       int act) {
+                                                       int act, int chunks_per_split, float* __restrict__ part) {
     constexpr int MB = BM / 64, NB = BN / 64, LDA = BM + 4, LDB = BN + 4;
     constexpr int NVA = BM * 4 / 256, NVB = BN * 4 / 256;
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
@@ -96,7 +96,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geom g, const float* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = g.B * g.OH * g.OW, N = g.Co, K = g.KH * g.KW * g.Ci;
     const int cpt = g.Ci / BK;   // chunks per tap (VEC)
-    const int nchunks = VEC ? g.KH * g.KW * cpt : (K + BK - 1) / BK;
+    const int total_chunks = VEC ? g.KH * g.KW * cpt : (K + BK - 1) / BK;
+    const int c_begin = blockIdx.y * chunks_per_split;
+    const int nchunks = min(total_chunks, c_begin + chunks_per_split);   // exclusive end of this split
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int m0 = (t % tiles_m) * BM, n0 = (t / tiles_m) * BN;
@@ -185,15 +187,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geom g, const float* __re
     const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
 
     float4 va[NVA], vb[NVB];
-    load_a(0, va);
-    load_b(0, vb);
+    load_a(c_begin, va);
+    load_b(c_begin, vb);
 #pragma unroll
     for (int i = 0; i < NVA; ++i) st_kcontig<LDA>(As(0), r0 + 64 * i, q, va[i]);
 #pragma unroll
     for (int i = 0; i < NVB; ++i) st_kcontig<LDB>(Bs(0), r0 + 64 * i, q, vb[i]);
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int cur = c & 1;
+    for (int c = c_begin; c < nchunks; ++c) {
+        const int cur = (c - c_begin) & 1;
         if (c + 1 < nchunks) {
             load_a(c + 1, va);
             load_b(c + 1, vb);
@@ -213,11 +215,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geom g, const float* __re
 #pragma unroll
         for (int ni = 0; ni < NB; ++ni) {
             const int col = n0 + wn0 + 32 * ni + (lane & 31);
-            const float bv = (bias && col < N) ? bias[col] : 0.0f;
+            const float bv = (bias && !part && col < N) ? bias[col] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm0 + 32 * mi + mfma32_row(r, lane);
-                if (row < M && col < N) y[(size_t)row * N + col] = apply_act(acc[mi][ni][r] + bv, act);
+                if (row < M && col < N) {
+                    if (part) part[((size_t)blockIdx.y * M + row) * N + col] = acc[mi][ni][r];
+                    else y[(size_t)row * N + col] = apply_act(acc[mi][ni][r] + bv, act);
+                }
             }
         }
 }
@@ -229,7 +234,8 @@ template <int BM, int BN, bool VECA, bool VECB>
 __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __restrict__ dy,
                                                          const float* __restrict__ w,
                                                          const float* __restrict__ bias,
-                                                         float* __restrict__ dx, int act) {
+                                                         float* __restrict__ dx, int act, int chunks_per_split,
+                                                         float* __restrict__ part) {
     constexpr int MB = BM / 64, NB = BN / 64, LDA = BM + 4, LDB = BN + 4;
     constexpr int NVA = BM * 4 / 256, NVB = BN * 4 / 256;
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
@@ -250,7 +256,9 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
     const int ntap = nky * nkx;
     const int Kc = ntap * g.Co;
     const int cpt = g.Co / BK;
-    const int nchunks = VECA ? ntap * cpt : (Kc + BK - 1) / BK;
+    const int total_chunks = VECA ? ntap * cpt : (Kc + BK - 1) / BK;
+    const int c_begin = blockIdx.y * chunks_per_split;
+    const int nchunks = min(total_chunks, c_begin + chunks_per_split);   // exclusive end of this split
     const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int m0 = (t % tiles_m) * BM, n0 = (t / tiles_m) * BN;
     const int q = tid & 3, r0 = tid >> 2;
@@ -268,6 +276,21 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
         xx[i] = rem - yy[i] * Wc;
     }
 
+    // reflect (stride 1): the padded rows / cols that alias this pixel: i+p, p-i, 2(H-1)-i+p (fixed per row)
+    int cy[NVA][3], cx[NVA][3];
+    if (g.reflect) {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+            const int iy = yy[i], ix = xx[i], p = g.p;
+            cy[i][0] = iy + p;
+            cy[i][1] = (iy >= 1 && iy <= p) ? p - iy : -1000000;
+            cy[i][2] = (iy >= g.H - 1 - p && iy <= g.H - 2) ? 2 * (g.H - 1) - iy + p : -1000000;
+            cx[i][0] = ix + p;
+            cx[i][1] = (ix >= 1 && ix <= p) ? p - ix : -1000000;
+            cx[i][2] = (ix >= g.W - 1 - p && ix <= g.W - 2) ? 2 * (g.W - 1) - ix + p : -1000000;
+        }
+    }
+
     // gather of dY for row i and tap index (tyi, txi): float4 at channel offset co (VEC) or scalar
     auto gather4 = [&](int i, int tyi, int txi, int co) -> float4 {
         float4 v = zero4();
@@ -275,19 +298,14 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
             const int oy = yy[i] + oyb - tyi, ox = xx[i] + oxb - txi;
             if (oy >= 0 && oy < g.OH && ox >= 0 && ox < g.OW)
                 v = ld4(dy + ((size_t)(bb[i] * g.OH + oy) * g.OW + ox) * g.Co + co);
-        } else {   // stride 1: iy = yy, ky = tyi.  Padded rows aliasing iy: iy+p, p-iy, 2(H-1)-iy+p.
-            const int iy = yy[i], ix = xx[i], p = g.p;
-            int cy[3] = {iy + p, (iy >= 1 && iy <= p) ? p - iy : -1000000,
-                         (iy >= g.H - 1 - p && iy <= g.H - 2) ? 2 * (g.H - 1) - iy + p : -1000000};
-            int cx[3] = {ix + p, (ix >= 1 && ix <= p) ? p - ix : -1000000,
-                         (ix >= g.W - 1 - p && ix <= g.W - 2) ? 2 * (g.W - 1) - ix + p : -1000000};
+        } else {   // stride 1: iy = yy, ky = tyi
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                const int oy = cy[a] - tyi;
+                const int oy = cy[i][a] - tyi;
                 if (oy < 0 || oy >= g.OH) continue;
 #pragma unroll
                 for (int c2 = 0; c2 < 3; ++c2) {
-                    const int ox = cx[c2] - txi;
+                    const int ox = cx[i][c2] - txi;
                     if (ox < 0 || ox >= g.OW) continue;
                     add4(v, ld4(dy + ((size_t)(bb[i] * g.OH + oy) * g.OW + ox) * g.Co + co));
                 }
@@ -302,16 +320,13 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
             if (oy >= 0 && oy < g.OH && ox >= 0 && ox < g.OW)
                 v = dy[((size_t)(bb[i] * g.OH + oy) * g.OW + ox) * g.Co + co];
         } else {
-            const int iy = yy[i], ix = xx[i], p = g.p;
-            int cy[3] = {iy + p, (iy >= 1 && iy <= p) ? p - iy : -1000000,
-                         (iy >= g.H - 1 - p && iy <= g.H - 2) ? 2 * (g.H - 1) - iy + p : -1000000};
-            int cx[3] = {ix + p, (ix >= 1 && ix <= p) ? p - ix : -1000000,
-                         (ix >= g.W - 1 - p && ix <= g.W - 2) ? 2 * (g.W - 1) - ix + p : -1000000};
+#pragma unroll
             for (int a = 0; a < 3; ++a) {
-                const int oy = cy[a] - tyi;
+                const int oy = cy[i][a] - tyi;
                 if (oy < 0 || oy >= g.OH) continue;
+#pragma unroll
                 for (int c2 = 0; c2 < 3; ++c2) {
-                    const int ox = cx[c2] - txi;
+                    const int ox = cx[i][c2] - txi;
                     if (ox < 0 || ox >= g.OW) continue;
                     v += dy[((size_t)(bb[i] * g.OH + oy) * g.OW + ox) * g.Co + co];
                 }
@@ -389,14 +404,14 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
 #pragma unroll
         for (int i = 0; i < NVB; ++i) st_rowcontig<LDB>(Bs(buf), bk_l + i * (1024 / BN), 4 * bn_q, vb[i]);
     };
-    if (nchunks > 0) {
-        load_a(0, va);
-        load_b(0, vb);
+    if (c_begin < nchunks) {
+        load_a(c_begin, va);
+        load_b(c_begin, vb);
         stash(0);
     }
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int cur = c & 1;
+    for (int c = c_begin; c < nchunks; ++c) {
+        const int cur = (c - c_begin) & 1;
         if (c + 1 < nchunks) {
             load_a(c + 1, va);
             load_b(c + 1, vb);
@@ -419,8 +434,12 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
             for (int ni = 0; ni < NB; ++ni) {
                 const int col = n0 + wn0 + 32 * ni + (lane & 31);
                 if (col < N) {
-                    const float bv = bias ? bias[col] : 0.0f;
-                    dx[o + col] = apply_act(acc[mi][ni][r] + bv, act);
+                    if (part) {   // split-K (stride 1 only: o == m * Ci)
+                        part[(size_t)blockIdx.y * M * N + o + col] = acc[mi][ni][r];
+                    } else {
+                        const float bv = bias ? bias[col] : 0.0f;
+                        dx[o + col] = apply_act(acc[mi][ni][r] + bv, act);
+                    }
                 }
             }
         }
@@ -569,10 +588,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, int S, size_t n, float* __restrict__ out,
                                      int accumulate) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float s = 0.0f;
-        for (int z = 0; z < S; ++z) s += part[(size_t)z * n + i];
-        out[i] = accumulate ? out[i] + s : s;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 s = zero4();
+        for (int z = 0; z < S; ++z) add4(s, ld4(part + (size_t)z * n + 4 * i));
+        if (accumulate) add4(s, ld4(out + 4 * i));
+        *reinterpret_cast<float4*>(out + 4 * i) = s;
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
+            float s = 0.0f;
+            for (int z = 0; z < S; ++z) s += part[(size_t)z * n + i];
+            out[i] = accumulate ? out[i] + s : s;
+        }
+}
+
+// split-K epilogue of the forward / data-gradient passes: out = act(sum_s part[s] + bias[col])
+__global__ void splitk_epilogue_kernel(const float* __restrict__ part, int S, size_t n, int N,
+                                       const float* __restrict__ bias, int act, float* __restrict__ out) {
+    const size_t n4 = n / 4;   // launcher guarantees N % 4 == 0
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 s = zero4();
+        for (int z = 0; z < S; ++z) add4(s, ld4(part + (size_t)z * n + 4 * i));
+        if (bias) add4(s, ld4(bias + (4 * i) % N));
+        s.x = apply_act(s.x, act); s.y = apply_act(s.y, act); s.z = apply_act(s.z, act); s.w = apply_act(s.w, act);
+        *reinterpret_cast<float4*>(out + 4 * i) = s;
     }
 }
 
@@ -619,24 +659,39 @@ ColsumPlan colsum_plan(long long M, int C) {
     return {(int)splits, rps};
 }
 
-// tile selection shared by the launchers and mg_conv_plan_name()
-struct TilePlan { int bm, bn; };
+// tile / split selection shared by the launchers and mg_conv_plan_name().  A pass needs >= ~2 workgroups per CU
+// (256 CUs) to hide its own global-load latency behind other workgroups' MFMAs; deep-K, small-M*N layers (the
+// 1024-channel 8x16 bottleneck: 64 tiles of 128x128) get there by splitting K across blockIdx.y.
+struct TilePlan { int bm, bn, splits, cps; };
+TilePlan gemm_plan(long long M, int N, int chunks, int classes, bool can_split) {
+    auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * classes; };
+    auto split_for = [&](long long t) {
+        if (!can_split || t >= 384) return 1;
+        int sp = (int)((512 + t - 1) / t);
+        const int max_sp = chunks / 16 > 0 ? chunks / 16 : 1;
+        return sp < max_sp ? sp : max_sp;
+    };
+    int bm, bn;
+    if (N <= 32 && M >= 64 * 512) { bm = 128; bn = 64; }
+    else if (N >= 128 && M >= 128 && tiles(128, 128) * split_for(tiles(128, 128)) >= 256) { bm = 128; bn = 128; }
+    else { bm = 64; bn = 64; }
+    int sp = split_for(tiles(bm, bn));
+    int cps = (chunks + sp - 1) / sp;
+    sp = (chunks + cps - 1) / cps;
+    return {bm, bn, sp, cps};
+}
 TilePlan fwd_plan(const mg_conv_geom* g) {
     const long long M = (long long)g->B * g->OH * g->OW;
-    const int N = g->Co;
-    const long long t128 = ((M + 127) / 128) * ((N + 127) / 128);
-    if (t128 >= 192 && N >= 128) return {128, 128};
-    if (N > 32 || M < 64 * 512) return {64, 64};
-    return {128, 64};
+    const bool vec = g->Ci % BK == 0;
+    const int chunks = vec ? g->KH * g->KW * (g->Ci / BK) : (g->KH * g->KW * g->Ci + BK - 1) / BK;
+    return gemm_plan(M, g->Co, chunks, 1, g->Co % 4 == 0);
 }
 TilePlan dgrad_plan(const mg_conv_geom* g) {
     const int s = g->stride;
     const long long Mc = (long long)g->B * ((g->H + s - 1) / s) * ((g->W + s - 1) / s);
-    const int N = g->Ci;
-    const long long t128 = ((Mc + 127) / 128) * ((N + 127) / 128);
-    if (t128 * s * s >= 192 && N >= 128) return {128, 128};
-    if (N > 32 || Mc < 64 * 512) return {64, 64};
-    return {128, 64};
+    const bool vec = g->Co % BK == 0;
+    const int chunks = vec ? g->KH * g->KW * (g->Co / BK) : (g->KH * g->KW * g->Co + BK - 1) / BK;
+    return gemm_plan(Mc, g->Ci, chunks, s * s, s == 1 && g->Ci % 4 == 0);
 }
 
 struct WgradPlan { bool big; int tiles; int splits; int cps; };
@@ -647,7 +702,7 @@ WgradPlan wgrad_plan(const mg_conv_geom* g) {
     const int t128 = ((R + 127) / 128) * ((N + 127) / 128);
     const bool big = t128 >= 96 && R >= 128;
     const int tiles = big ? t128 : ((R + 63) / 64) * ((N + 63) / 64);
-    int splits = (768 + tiles - 1) / tiles;
+    int splits = tiles >= 512 ? 1 : (768 + tiles - 1) / tiles;
     const int max_splits = chunks / 8 > 0 ? chunks / 8 : 1;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -683,62 +738,96 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
     return MG_OK;
 }
 
+size_t mg_conv_fwd_workspace(const mg_conv_geom* g) {
+    if (!geom_ok(g)) return 0;
+    const TilePlan tp = fwd_plan(g);
+    return tp.splits > 1 ? (size_t)tp.splits * g->B * g->OH * g->OW * g->Co * sizeof(float) + 256 : 256;
+}
+size_t mg_conv_dgrad_workspace(const mg_conv_geom* g) {
+    if (!geom_ok(g)) return 0;
+    const TilePlan tp = dgrad_plan(g);
+    return tp.splits > 1 ? (size_t)tp.splits * g->B * g->H * g->W * g->Ci * sizeof(float) + 256 : 256;
+}
+
 int mg_conv_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
-                void* stream) {
+                void* workspace, size_t workspace_bytes, void* stream) {
     if (!geom_ok(g) || !x || !w || !y) return MG_ERR_ARG;
     const Geom gg = to_geom(g);
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)g->B * g->OH * g->OW;
     const int N = g->Co;
     const bool vec = (g->Ci % BK == 0) && aligned16(x) && aligned16(w);
-    const TilePlan tp = fwd_plan(g);
-    if (tp.bm == 128 && tp.bn == 128) {
-        dim3 grid((unsigned)(((M + 127) / 128) * ((N + 127) / 128)));
-        if (vec) hipLaunchKernelGGL((conv_fwd_kernel<128, 128, true>), grid, dim3(256), 0, st, gg, x, w, bias, y, act);
-        else hipLaunchKernelGGL((conv_fwd_kernel<128, 128, false>), grid, dim3(256), 0, st, gg, x, w, bias, y, act);
-    } else if (tp.bm == 64) {
-        dim3 grid((unsigned)(((M + 63) / 64) * ((N + 63) / 64)));
-        if (vec) hipLaunchKernelGGL((conv_fwd_kernel<64, 64, true>), grid, dim3(256), 0, st, gg, x, w, bias, y, act);
-        else hipLaunchKernelGGL((conv_fwd_kernel<64, 64, false>), grid, dim3(256), 0, st, gg, x, w, bias, y, act);
-    } else {   // few output channels, many pixels
-        dim3 grid((unsigned)(((M + 127) / 128) * ((N + 63) / 64)));
-        if (vec) hipLaunchKernelGGL((conv_fwd_kernel<128, 64, true>), grid, dim3(256), 0, st, gg, x, w, bias, y, act);
-        else hipLaunchKernelGGL((conv_fwd_kernel<128, 64, false>), grid, dim3(256), 0, st, gg, x, w, bias, y, act);
+    TilePlan tp = fwd_plan(g);
+    if (tp.splits > 1 && (!workspace || workspace_bytes < mg_conv_fwd_workspace(g) || !aligned16(y) ||
+                          (bias && !aligned16(bias)))) {
+        tp.splits = 1;
+        tp.cps = 1 << 30;
     }
+    float* part = tp.splits > 1 ? (float*)workspace : nullptr;
+#define MG_LAUNCH_FWD(BM_, BN_)                                                                                    \
+    do {                                                                                                           \
+        dim3 grid((unsigned)(((M + BM_ - 1) / BM_) * ((N + BN_ - 1) / BN_)), tp.splits);                           \
+        if (vec) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, true>), grid, dim3(256), 0, st, gg, x, w, bias, y, act, tp.cps, part);  \
+        else hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, false>), grid, dim3(256), 0, st, gg, x, w, bias, y, act, tp.cps, part);    \
+    } while (0)
+    if (tp.bm == 128 && tp.bn == 128) MG_LAUNCH_FWD(128, 128);
+    else if (tp.bm == 64) MG_LAUNCH_FWD(64, 64);
+    else MG_LAUNCH_FWD(128, 64);
+#undef MG_LAUNCH_FWD
     MG_CHECK_LAUNCH();
+    if (part) {
+        const size_t n = (size_t)M * N;
+        const unsigned blocks = (unsigned)((n / 4 + 255) / 256 > 4096 ? 4096 : (n / 4 + 255) / 256);
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, (const float*)part, tp.splits, n, N,
+                           bias, act, y);
+        MG_CHECK_LAUNCH();
+    }
     return MG_OK;
 }
 
 int mg_conv_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
-                  void* stream) {
+                  void* workspace, size_t workspace_bytes, void* stream) {
     if (!geom_ok(g) || !dy || !w || !dx) return MG_ERR_ARG;
     if (g->reflect && g->stride != 1) return MG_ERR_UNSUPPORTED;
     const Geom gg = to_geom(g);
     hipStream_t st = (hipStream_t)stream;
     const int s = g->stride;
-    // every input pixel must be produced by exactly one class launch; classes cover all of [0,H)x[0,W)
+    // every input pixel is produced by exactly one class launch; classes cover all of [0,H)x[0,W)
     const long long Mc = (long long)g->B * ((g->H + s - 1) / s) * ((g->W + s - 1) / s);   // largest class
     const int N = g->Ci;
     const bool veca = (g->Co % BK == 0) && aligned16(dy);
     const bool vecb = (g->Ci % 4 == 0) && aligned16(w);
-    const TilePlan tp = dgrad_plan(g);
+    TilePlan tp = dgrad_plan(g);
+    if (tp.splits > 1 && (!workspace || workspace_bytes < mg_conv_dgrad_workspace(g) || !aligned16(dx) ||
+                          (bias && !aligned16(bias)))) {
+        tp.splits = 1;
+        tp.cps = 1 << 30;
+    }
+    float* part = tp.splits > 1 ? (float*)workspace : nullptr;
 #define MG_LAUNCH_DGRAD(BM_, BN_)                                                                                  \
     do {                                                                                                           \
-        dim3 grid((unsigned)(((Mc + BM_ - 1) / BM_) * ((N + BN_ - 1) / BN_)), 1, s * s);                           \
+        dim3 grid((unsigned)(((Mc + BM_ - 1) / BM_) * ((N + BN_ - 1) / BN_)), tp.splits, s * s);                   \
         if (veca && vecb)                                                                                          \
-            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, true>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act);  \
+            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, true>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act, tp.cps, part);  \
         else if (veca)                                                                                             \
-            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, false>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act); \
+            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, false>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act, tp.cps, part); \
         else if (vecb)                                                                                             \
-            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, false, true>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act); \
+            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, false, true>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act, tp.cps, part); \
         else                                                                                                       \
-            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, false, false>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act);\
+            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, false, false>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act, tp.cps, part);\
     } while (0)
     if (tp.bm == 128 && tp.bn == 128) MG_LAUNCH_DGRAD(128, 128);
     else if (tp.bm == 64) MG_LAUNCH_DGRAD(64, 64);
     else MG_LAUNCH_DGRAD(128, 64);
 #undef MG_LAUNCH_DGRAD
     MG_CHECK_LAUNCH();
+    if (part) {
+        const size_t n = (size_t)g->B * g->H * g->W * N;
+        const unsigned blocks = (unsigned)((n / 4 + 255) / 256 > 4096 ? 4096 : (n / 4 + 255) / 256);
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, (const float*)part, tp.splits, n, N,
+                           bias, act, dx);
+        MG_CHECK_LAUNCH();
+    }
     return MG_OK;
 }
 
@@ -798,7 +887,7 @@ int mg_conv_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float*
 #undef MG_LAUNCH_WGRAD
     MG_CHECK_LAUNCH();
     if (p.splits > 1) {
-        const unsigned blocks = (unsigned)((n_out + 255) / 256 > 2048 ? 2048 : (n_out + 255) / 256);
+        const unsigned blocks = (unsigned)((n_out / 4 + 255) / 256 > 4096 ? 4096 : (n_out / 4 + 255) / 256 + 1);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, p.splits,
                            n_out, dw, accumulate);
         MG_CHECK_LAUNCH();

@@ -37,10 +37,11 @@ def conv_flops(g: ConvGeom) -> float:
 def conv_fwd(g: ConvGeom, x, w, bias=None, act=ACT_NONE):
     lib = _lib.load()
     y = torch.empty(g.B, g.OH, g.OW, g.Co, dtype=torch.float32, device=x.device)
+    ws = _ws(lib.mg_conv_fwd_workspace(g), x.device)
     if PROFILER is not None:
         PROFILER.begin(0, g)
-    _lib.check(lib.mg_conv_fwd(g, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), act, _lib.stream()),
-               "mg_conv_fwd")
+    _lib.check(lib.mg_conv_fwd(g, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), act, _lib.ptr(ws),
+                               ws.numel(), _lib.stream()), "mg_conv_fwd")
     if PROFILER is not None:
         PROFILER.end()
     return y
@@ -49,10 +50,11 @@ def conv_fwd(g: ConvGeom, x, w, bias=None, act=ACT_NONE):
 def conv_dgrad(g: ConvGeom, dy, w, bias=None, act=ACT_NONE):
     lib = _lib.load()
     dx = torch.empty(g.B, g.H, g.W, g.Ci, dtype=torch.float32, device=dy.device)
+    ws = _ws(lib.mg_conv_dgrad_workspace(g), dy.device)
     if PROFILER is not None:
         PROFILER.begin(1, g)
-    _lib.check(lib.mg_conv_dgrad(g, _lib.ptr(dy), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(dx), act, _lib.stream()),
-               "mg_conv_dgrad")
+    _lib.check(lib.mg_conv_dgrad(g, _lib.ptr(dy), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(dx), act, _lib.ptr(ws),
+                                 ws.numel(), _lib.stream()), "mg_conv_dgrad")
     if PROFILER is not None:
         PROFILER.end()
     return dx
