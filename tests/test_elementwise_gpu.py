@@ -107,4 +107,4 @@ def test_dinput_pair_losses_adam():
         pt.grad = g.clone()
         opt.step()
         ops.adam_step(pd, g.to(DEV), m, v, 2e-4, 0.5, 0.999, 1e-8, step)
-        assert (pd.cpu() - pt.detach()).abs().max().item() < 2e-9 + 1e-6 * 2e-4
+        assert (pd.cpu() - pt.detach()).abs().max().item() <= 2.4e-7   # 1 ulp at |p| < 4: lr * m/denom rounds once differently
