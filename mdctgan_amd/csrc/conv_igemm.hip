@@ -652,6 +652,7 @@ struct ColsumPlan { int splits; long long rows_per_split; };
 ColsumPlan colsum_plan(long long M, int C) {
     const int cb = (C + 63) / 64;
     long long splits = (1024 + cb - 1) / cb;
+    if (splits > 256) splits = 256;
     if (splits > (M + 63) / 64) splits = (M + 63) / 64;
     if (splits < 1) splits = 1;
     long long rps = (M + splits - 1) / splits;
@@ -833,7 +834,7 @@ int mg_conv_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const 
 
 size_t mg_colsum_workspace(long long M, int C) {
     const ColsumPlan p = colsum_plan(M, C);
-    return (size_t)p.splits * C * sizeof(float);
+    return ((size_t)p.splits + 1) * C * sizeof(float);
 }
 
 int mg_colsum(const float* a, long long M, int C, float* out, int accumulate, void* workspace,
@@ -842,10 +843,14 @@ int mg_colsum(const float* a, long long M, int C, float* out, int accumulate, vo
     if (workspace_bytes < mg_colsum_workspace(M, C)) return MG_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const ColsumPlan p = colsum_plan(M, C);
+    float* part = (float*)workspace;                 // [splits][C]
+    float* fin = part + (size_t)p.splits * C;        // [C]: second pass over the partial rows (parallel, not serial)
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, p.splits), dim3(256), 0, st, a, M, C,
-                       p.rows_per_split, (float*)workspace);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)workspace,
-                       p.splits, (size_t)C, out, accumulate);
+                       p.rows_per_split, part);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, 1), dim3(256), 0, st, (const float*)part,
+                       (long long)p.splits, C, (long long)p.splits, fin);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((C / 4 + 255) / 256 + 1), dim3(256), 0, st, (const float*)fin, 1,
+                       (size_t)C, out, accumulate);
     MG_CHECK_LAUNCH();
     return MG_OK;
 }

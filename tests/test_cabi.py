@@ -62,6 +62,10 @@ def test_unsupported_geometry_raises():
 def test_kbdwin_is_the_reference_window(golden):
     import numpy as np
     from mdctgan_amd.mdct import kbdwin
+    from oracle import transform
     g = golden("g1_kbdwin")
-    np.testing.assert_array_equal(kbdwin(512).numpy(), g["w512"])
-    np.testing.assert_array_equal(kbdwin(1024).numpy(), g["w1024"])
+    for n in (512, 1024):
+        # same float32 op chain as util/util.py:179-186 -> identical to the oracle's on this machine, and within
+        # 2 ulp of the vector captured from the reference on the build container's CPU
+        np.testing.assert_array_equal(kbdwin(n).numpy(), transform.kbd_window(n))
+        np.testing.assert_allclose(kbdwin(n).numpy(), g["w%d" % n], atol=2.4e-7, rtol=0)
