@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,11 +131,13 @@ def main():
         ddp.attach(model)
     lr, hr = synth_batch(BATCH, 42 + rank, dev)
 
-    def step():
+    def eager_step():
         if args.mode == "train":
             model.optimize_parameters(lr, hr)
         else:
             model.inference(lr)
+    step = eager_step
+    use_graph = (not args.no_graph) and world == 1 and args.mode == "train"
 
     def fence():
         torch.cuda.synchronize()
@@ -142,12 +145,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warm-up; the first warm-up step also times every conv kernel to find the dominant one
+    # warm-up (eager); its last step times every conv launch with HIP events to find the dominant kernel
     timer_all = KernelTimer(ops)
-    for i in range(max(args.warmup, 1)):
-        if i == 0 and not args.no_roofline:
+    nw = max(args.warmup, 2)
+    for i in range(nw):
+        if i == nw - 1 and not args.no_roofline:
             ops.PROFILER = timer_all
-        step()
+        eager_step()
         ops.PROFILER = None
     torch.cuda.synchronize()
     dominant = None
@@ -155,15 +159,28 @@ def main():
         agg = timer_all.summary()
         dominant = max(agg, key=lambda k: agg[k][2]) if agg else None
     timer = KernelTimer(ops, target=dominant) if dominant else None
+    if use_graph:
+        graphed = model.make_graphed_step(lr, hr, warmup=2)   # whole G+D iteration as one hipGraph
+        step = lambda: graphed()                                # noqa: E731  (inputs already in the captured buffers)
+        step()
 
     fence()
-    ops.PROFILER = timer
+    if not use_graph:
+        ops.PROFILER = timer      # eager: the dominant kernel's launches are event-bracketed inside the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
     ops.PROFILER = None
+    if use_graph and timer is not None:
+        # graph replays cannot be bracketed per kernel: time the same launches of the dominant kernel with HIP
+        # events over K eager iterations of the same step, immediately after the timed region
+        ops.PROFILER = timer
+        for _ in range(args.steps):
+            eager_step()
+        torch.cuda.synchronize()
+        ops.PROFILER = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -176,7 +193,10 @@ def main():
         roofline = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                     "launches": n, "avg_launch_us": round(secs / n * 1e6, 2),
-                    "flops_per_launch": flops / n}
+                    "flops_per_launch": flops / n,
+                    "timed": ("HIP events around every launch of this kernel in %d eager iterations run right after "
+                              "the graph-replayed timed region" % args.steps) if use_graph else
+                             "HIP events around every launch of this kernel inside the timed region"}
         tr = os.path.join(REPO, "profiles", "traffic.json")     # HBM bytes/launch from rocprofv3 --pmc passes
         if os.path.exists(tr):
             try:
@@ -196,7 +216,8 @@ def main():
                "config": {"workload": "configs[1]: netG=global ngf=64 n_blocks_global=9 n_blocks_attn_g=0 num_D=2, "
                                       "per-GPU batch 8 x 32512 samples (128 frames x 256 bins), 12k->48k, fp32",
                           "global_batch": BATCH * world, "segment_length": T_SEG,
-                          "parallelism": "dp%d" % world, "steps_counted": "one G+D optimisation step per GPU; value = "
+                          "parallelism": "dp%d" % world, "launch": "hipGraph replay" if use_graph else "eager",
+                          "steps_counted": "one G+D optimisation step per GPU; value = "
                           "steps of per-GPU batch 8 completed per second summed over GPUs (weak scaling)"},
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline and args.mode == "train":

@@ -166,6 +166,13 @@ int mg_l1_bwd(const float* a, const float* b, long long n, float scale, const fl
 int mg_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                  float eps, int step, float grad_scale, void* stream);
 
+/* hipGraph-replayable variant: the optimiser clock lives in HBM.  state = double[4] {step, lr, lr/(1-beta1^step),
+ * sqrt(1-beta2^step)}; mg_adam_tick advances it on the device (host writes state[1] = lr when the schedule
+ * changes), mg_adam_step_dev reads it -- no step-dependent value is baked into a kernel argument. */
+int mg_adam_tick(double* state, float beta1, float beta2, void* stream);
+int mg_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const double* state, float beta1,
+                     float beta2, float eps, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,8 @@ SIGNATURES = {
     "mg_l1_fwd": (_i, [_p, _p, _ll, _f, _p, _i, _p, _p]),
     "mg_l1_bwd": (_i, [_p, _p, _ll, _f, _p, _p, _p]),
     "mg_adam_step": (_i, [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _f, _p]),
+    "mg_adam_tick": (_i, [_p, _f, _f, _p]),
+    "mg_adam_step_dev": (_i, [_p, _p, _p, _p, _ll, _p, _f, _f, _f, _f, _p]),
 }
 
 _lib = None

@@ -318,6 +318,49 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// Device-resident optimiser clock (hipGraph-replayable: nothing step-dependent is baked into kernel arguments).
+// state = {step, lr, step_size = lr / (1 - beta1^step), sqrt(1 - beta2^step)} as doubles.
+__global__ void adam_tick_kernel(double* __restrict__ state, double b1, double b2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double step = state[0] + 1.0;
+        state[0] = step;
+        state[2] = state[1] / (1.0 - pow(b1, step));
+        state[3] = sqrt(1.0 - pow(b2, step));
+    }
+}
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, size_t n, const double* __restrict__ state, float b1, float b2,
+                                float eps, float gscale) {
+    const float step_size = (float)state[2], bc2_sqrt = (float)state[3];
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 pv = *reinterpret_cast<float4*>(p + 4 * i), mv = *reinterpret_cast<float4*>(m + 4 * i),
+               vv = *reinterpret_cast<float4*>(v + 4 * i);
+        const float4 gv = *reinterpret_cast<const float4*>(g + 4 * i);
+        float* pp = reinterpret_cast<float*>(&pv); float* mm = reinterpret_cast<float*>(&mv);
+        float* vp = reinterpret_cast<float*>(&vv); const float* gg = reinterpret_cast<const float*>(&gv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gi = gg[j] * gscale;
+            const float mi = mm[j] + (gi - mm[j]) * (1.0f - b1);
+            const float vi = vp[j] * b2 + (1.0f - b2) * gi * gi;
+            mm[j] = mi; vp[j] = vi;
+            pp[j] = pp[j] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        }
+        *reinterpret_cast<float4*>(p + 4 * i) = pv;
+        *reinterpret_cast<float4*>(m + 4 * i) = mv;
+        *reinterpret_cast<float4*>(v + 4 * i) = vv;
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
+            const float gi = g[i] * gscale;
+            const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+            const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+            m[i] = mi; v[i] = vi;
+            p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        }
+}
+
 inline unsigned grid_for(size_t n, int per_thread = 1) {
     size_t b = (n + 256 * (size_t)per_thread - 1) / (256 * (size_t)per_thread);
     if (b > 4096) b = 4096;
@@ -502,6 +545,24 @@ int mg_adam_step(float* p, const float* g, float* m, float* v, long long n, floa
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for((size_t)n, 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
                        (size_t)n, (float)((double)lr / bc1), beta1, beta2, eps, (float)sqrt(bc2), grad_scale);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+
+int mg_adam_tick(double* state, float beta1, float beta2, void* stream) {
+    if (!state) return MG_ERR_ARG;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, (double)beta1, (double)beta2);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+int mg_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const double* state, float beta1,
+                     float beta2, float eps, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || !state || n <= 0) return MG_ERR_ARG;
+    if (!al16(p) || !al16(g) || !al16(m) || !al16(v)) return MG_ERR_ARG;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for((size_t)n, 8)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                       (size_t)n, state, beta1, beta2, eps, grad_scale);
     MG_CHECK_LAUNCH();
     return MG_OK;
 }

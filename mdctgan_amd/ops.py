@@ -208,3 +208,14 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     lib = _lib.load()
     _lib.check(lib.mg_adam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), p.numel(), lr, beta1, beta2, eps,
                                 step, grad_scale, _lib.stream()), "mg_adam_step")
+
+
+def adam_tick(state, beta1, beta2):
+    lib = _lib.load()
+    _lib.check(lib.mg_adam_tick(_lib.ptr(state), beta1, beta2, _lib.stream()), "mg_adam_tick")
+
+
+def adam_step_dev(p, g, m, v, state, beta1, beta2, eps, grad_scale=1.0):
+    lib = _lib.load()
+    _lib.check(lib.mg_adam_step_dev(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), p.numel(), _lib.ptr(state),
+                                    beta1, beta2, eps, grad_scale, _lib.stream()), "mg_adam_step_dev")

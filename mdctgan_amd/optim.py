@@ -51,6 +51,9 @@ class FusedAdam(torch.optim.Optimizer):
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
         self.offsets, self.total = offs, total
+        # device-resident clock {step, lr, step_size, sqrt(bias_correction2)}: keeps the step hipGraph-replayable
+        self.state = torch.zeros(4, dtype=torch.float64, device=dev)
+        self._lr_on_device = None
         with torch.no_grad():
             for p, off in zip(ps, offs):
                 view = _arena_view(self.flat_p, off, p)
@@ -87,6 +90,12 @@ class FusedAdam(torch.optim.Optimizer):
         self._step += 1
         g = self.param_groups[0]
         lr, (b1, b2), eps = float(g["lr"]), g["betas"], g["eps"]
+        if lr != self._lr_on_device:          # schedule change (update_learning_rate): refresh the device copy
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("learning-rate changes must happen outside graph capture")
+            self.state[1] = lr
+            self._lr_on_device = lr
+        ops.adam_tick(self.state, b1, b2)
         # contiguous runs of parameters that received a gradient this step (normally a single run = everything)
         runs, start = [], None
         for i, p in enumerate(self._params):
@@ -101,6 +110,6 @@ class FusedAdam(torch.optim.Optimizer):
         for a, b in runs:
             lo = self.offsets[a]
             hi = self.total if b == len(self._params) else self.offsets[b]
-            ops.adam_step(self.flat_p[lo:hi], self.flat_g[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi], lr, b1, b2,
-                          eps, self._step, self.grad_scale)
+            ops.adam_step_dev(self.flat_p[lo:hi], self.flat_g[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi],
+                              self.state, b1, b2, eps, self.grad_scale)
         return None

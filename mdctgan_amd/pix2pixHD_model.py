@@ -65,8 +65,11 @@ class Audio2MDCT(torch.nn.Module):
 
     def _norm_param(self, r, dev):
         if self.abs_norm:
-            a_min = torch.tensor([self.src_range[0]], device=dev)[None, None, None, :]
-            a_max = torch.tensor([self.src_range[1]], device=dev)[None, None, None, :]
+            cache = self.__dict__.setdefault("_range_cache", {})
+            if str(dev) not in cache:     # built once: no per-step host->device copy (hipGraph-capturable)
+                cache[str(dev)] = (torch.tensor([self.src_range[0]], device=dev)[None, None, None, :],
+                                   torch.tensor([self.src_range[1]], device=dev)[None, None, None, :])
+            a_min, a_max = cache[str(dev)]
         else:
             a_min, a_max = r["min"][:, None, None, None], r["max"][:, None, None, None]
         mean = std = None
@@ -322,6 +325,35 @@ class Pix2PixHDModel(BaseModel):
         loss_D.backward()
         self.optimizer_D.step()
         return loss_dict
+
+    def make_graphed_step(self, lr_audio, hr_audio, warmup=3):
+        """Capture one full optimize_parameters() iteration (~760 launches: forward, both backward passes, both Adam
+        steps) into a hipGraph and return run(lr, hr) -> loss dict, which copies the batch into the captured input
+        buffers and replays.  The optimiser clock and learning rate live in HBM, so replays advance Adam exactly
+        like eager steps.  The warm-up iterations are real training steps."""
+        if getattr(self, "reducers", None):
+            raise NotImplementedError("graph capture of the data-parallel step (RCCL inside the graph) is not enabled")
+        static_lr, static_hr = lr_audio.clone(), hr_audio.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 2)):
+                self.optimize_parameters(static_lr, static_hr)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            losses = self.optimize_parameters(static_lr, static_hr)
+
+        def run(lr=None, hr=None):
+            if lr is not None:
+                static_lr.copy_(lr, non_blocking=True)
+            if hr is not None:
+                static_hr.copy_(hr, non_blocking=True)
+            graph.replay()
+            return losses
+        run.graph = graph
+        return run
 
     def inference(self, lr_audio):
         """pix2pixHD_model.py:618-638."""
