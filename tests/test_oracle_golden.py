@@ -191,3 +191,37 @@ def test_stitch(golden):
     out = transform.stitch_segments(g["seg"], 7936, int(g["overlap"]))
     np.testing.assert_allclose(out, g["stitched"], atol=1e-14)
     np.testing.assert_array_equal(transform.stitch_segments(g["seg"], 7936, 0), g["concat"])
+
+
+def test_c_oracle(golden):
+    """oracle/c/mdct_oracle.c (gcc) == the numpy oracle == the reference's captured outputs."""
+    import ctypes
+    from mdctgan_amd import build
+    lib = ctypes.CDLL(build.build_oracle_c(verbose=False))
+    g2, g4, w = golden("g2_mdct4"), golden("g4_codec_abs"), golden("g1_kbdwin")["w512"]
+    fp, dp = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)
+
+    def P(a, t):
+        return a.ctypes.data_as(t)
+    x = np.ascontiguousarray(g2["x"])
+    spec = np.empty((2, 32, 256)); frames = np.empty((2, 32, 512), dtype=np.float32)
+    F = lib.oracle_mdct4(P(x, fp), 2, 7936, 512, P(w, fp), P(spec, dp), P(frames, fp))
+    assert F == 32
+    np.testing.assert_array_equal(frames, g2["frames"])
+    assert np.abs(spec - g2["X"]).max() <= 1e-11 * np.abs(g2["X"]).max()
+    audio = np.empty((2, 7936))
+    assert lib.oracle_imdct4(P(np.ascontiguousarray(g2["X"]), dp), 2, 32, 512, P(w, fp), P(audio, dp)) == 7936
+    assert np.abs(audio - golden("g3_imdct4")["y"][:, 0, 0]).max() <= 1e-12 * 6
+    # codec (abs_norm constants)
+    xa = np.ascontiguousarray(g4["x"])
+    lib.oracle_mdct4(P(xa, fp), 2, 7936, 512, P(w, fp), P(spec, dp), None)
+    out = np.empty((2, 32, 256), dtype=np.float32)
+    c_d, c_ll = ctypes.c_double, ctypes.c_longlong
+    lib.oracle_normalize.argtypes = [dp, c_ll, c_d, c_d, c_d, c_d, c_d, fp]
+    lib.oracle_denormalize.argtypes = [fp, c_ll, c_d, c_d, c_d, c_d, c_d, dp]
+    lib.oracle_normalize(P(spec, dp), spec.size, 1000.0, -5.0, 5.0, -1.0, 1.0, P(out, fp))
+    np.testing.assert_allclose(out, g4["log_spectro"][:, 0], atol=2e-7, rtol=0)
+    back = np.empty_like(spec)
+    lib.oracle_denormalize(P(out, fp), out.size, 1000.0, -5.0, 5.0, -1.0, 1.0, P(back, dp))
+    lib.oracle_imdct4(P(back, dp), 2, 32, 512, P(w, fp), P(audio, dp))
+    assert np.abs(audio - g4["audio"][:, 0, 0]).max() <= 1e-12
