@@ -79,24 +79,37 @@ class KernelTimer:
         return agg
 
 
-def cpu_baseline_train(threads):
-    """The CPU oracle (oracle/step.py, torch CPU float32 + float64 transform == the reference's arithmetic) timed on
-    a bounded sample of the same workload: the full configs[1] networks, ONE step at batch 2 after a batch-1
-    warm-up step, scaled by 2/8 to the batch-8 step rate."""
+def cpu_baseline_train(max_threads):
+    """The CPU oracle (oracle/step.py: torch CPU float32 nets + float64 transform == the reference's arithmetic) timed
+    on a bounded sample of the same workload: the full configs[1] networks, thread count calibrated on batch-1 steps
+    (more threads is NOT faster for these convolutions: 16 beat 32/64/128 on the 256-core box), then ONE G+D step at
+    batch 4, scaled by 4/8 to the batch-8 step rate."""
     from oracle import nets as onets
     from oracle import step as ostep
-    torch.set_num_threads(threads)
     gen = torch.Generator().manual_seed(0)
     netG = onets.init_weights(onets.build_generator("global", 2, 1, 64, 4, 9, input_size=(128, 256)), gen)
     netD = onets.init_weights(onets.MultiscaleDRef(3, 64, 3, 2), gen)
     ref = ostep.HotPathRef(netG, netD, ostep.CodecCfg(), num_D=2)
-    lr, hr = synth_batch(2, 1, "cpu")
-    ref.train_step(lr[:1].numpy(), hr[:1].numpy())
+    lr, hr = synth_batch(4, 1, "cpu")
+    best, best_t = None, None
+    for th in (8, 16, 32):
+        if th > max_threads:
+            break
+        torch.set_num_threads(th)
+        if best is None:
+            ref.train_step(lr[:1].numpy(), hr[:1].numpy())          # allocator / oneDNN warm-up
+        t0 = time.perf_counter()
+        ref.train_step(lr[:1].numpy(), hr[:1].numpy())
+        t = time.perf_counter() - t0
+        if best_t is None or t < best_t:
+            best, best_t = th, t
+    torch.set_num_threads(best)
     t0 = time.perf_counter()
     ref.train_step(lr.numpy(), hr.numpy())
     dt = time.perf_counter() - t0
-    return {"value": (1.0 / dt) * (2.0 / BATCH), "unit": "steps/s", "cores": threads, "kind": "port",
-            "sample": "1 G+D step of configs[1] at batch 2 (after a batch-1 warm-up), scaled x2/8 to batch 8; %.1f s" % dt}
+    return {"value": round((1.0 / dt) * (4.0 / BATCH), 5), "unit": "steps/s", "cores": best, "kind": "port",
+            "sample": "1 G+D step of configs[1] at batch 4 (%.1f s) scaled x4/8 to batch 8; threads calibrated over "
+                      "{8,16,32} on batch-1 steps, host has %d cores" % (dt, max_threads)}
 
 
 def main():
