@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmdctgan_hip.so")
+LIB_PATH = os.environ.get("MDCTGAN_HIP_LIB", os.path.join(_HERE, "libmdctgan_hip.so"))   # override: kernel A/B experiments
 
 MG_CODEC_RAW, MG_CODEC_ARCSINH, MG_CODEC_RANGE = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_TANH = 0, 1, 2, 3
