@@ -744,13 +744,25 @@ WgradPlan wgrad_plan(const mg_conv_geom* g) {
 
 extern "C" {
 
+int mg_conv_rowdot_kq(const mg_conv_geom* g);
+int mg_conv_rowdot_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
+                       void* stream);
+size_t mg_conv_rowdot_wgrad_workspace(const mg_conv_geom* g);
+int mg_conv_rowdot_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias,
+                         int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 int mg_abi_version(void) { return 1; }
 
 // Name of the kernel instance a pass would launch for this geometry (matches the symbol rocprofv3 reports,
 // minus the anonymous-namespace prefix).  pass: 0 fwd, 1 dgrad, 2 wgrad.
 int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
     if (!geom_ok(g) || !out || out_len < 64) return MG_ERR_ARG;
-    if (pass == 0) {
+    const int kq = mg_conv_rowdot_kq(g);
+    if (kq && pass == 0) {
+        snprintf(out, out_len, "conv_rowdot_fwd_kernel<%d>", kq);
+    } else if (kq && pass == 2) {
+        snprintf(out, out_len, "conv_rowdot_wgrad_kernel<%d>", kq);
+    } else if (pass == 0) {
         const TilePlan tp = fwd_plan(g);
         snprintf(out, out_len, "conv_fwd_kernel<%d, %d, %s>", tp.bm, tp.bn, (g->Ci % BK == 0) ? "true" : "false");
     } else if (pass == 1) {
@@ -781,6 +793,7 @@ size_t mg_conv_dgrad_workspace(const mg_conv_geom* g) {
 int mg_conv_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
                 void* workspace, size_t workspace_bytes, void* stream) {
     if (!geom_ok(g) || !x || !w || !y) return MG_ERR_ARG;
+    if (mg_conv_rowdot_kq(g) && aligned16(x) && aligned16(w)) return mg_conv_rowdot_fwd(g, x, w, bias, y, act, stream);
     const Geom gg = to_geom(g);
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)g->B * g->OH * g->OW;
@@ -885,6 +898,7 @@ int mg_colsum(const float* a, long long M, int C, float* out, int accumulate, vo
 
 size_t mg_conv_wgrad_workspace(const mg_conv_geom* g) {
     if (!geom_ok(g)) return 0;
+    if (mg_conv_rowdot_kq(g)) return mg_conv_rowdot_wgrad_workspace(g);
     const WgradPlan p = wgrad_plan(g);
     const size_t wg = p.splits > 1 ? (size_t)p.splits * g->Co * g->KH * g->KW * g->Ci * sizeof(float) : 0;
     const size_t cs = mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co);
@@ -895,6 +909,8 @@ int mg_conv_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float*
                   void* workspace, size_t workspace_bytes, void* stream) {
     if (!geom_ok(g) || !x || !dy || !dw) return MG_ERR_ARG;
     if (workspace_bytes < mg_conv_wgrad_workspace(g) || !workspace) return MG_ERR_ARG;
+    if (mg_conv_rowdot_kq(g) && aligned16(x) && aligned16(workspace))
+        return mg_conv_rowdot_wgrad(g, x, dy, dw, dbias, accumulate, workspace, workspace_bytes, stream);
     const Geom gg = to_geom(g);
     hipStream_t st = (hipStream_t)stream;
     const WgradPlan p = wgrad_plan(g);
