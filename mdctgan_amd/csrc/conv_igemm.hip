@@ -322,18 +322,21 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
             const int oy = yy[i] + oyb - tyi, ox = xx[i] + oxb - txi;
             if (oy >= 0 && oy < g.OH && ox >= 0 && ox < g.OW)
                 v = ld4(dy + ((size_t)(bb[i] * g.OH + oy) * g.OW + ox) * g.Co + co);
-        } else {   // stride 1: iy = yy, ky = tyi
+        } else {   // stride 1: iy = yy, ky = tyi.  Issue every (usually one) aliasing load first, sum afterwards:
+                   // accumulating inside the branches would put a vmcnt wait behind each taken load.
+            float4 t[9];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const int oy = cy[i][a] - tyi;
-                if (oy < 0 || oy >= g.OH) continue;
 #pragma unroll
                 for (int c2 = 0; c2 < 3; ++c2) {
                     const int ox = cx[i][c2] - txi;
-                    if (ox < 0 || ox >= g.OW) continue;
-                    add4(v, ld4(dy + ((size_t)(bb[i] * g.OH + oy) * g.OW + ox) * g.Co + co));
+                    const bool ok = (unsigned)oy < (unsigned)g.OH && (unsigned)ox < (unsigned)g.OW;
+                    t[a * 3 + c2] = ok ? ld4(dy + ((size_t)(bb[i] * g.OH + oy) * g.OW + ox) * g.Co + co) : zero4();
                 }
             }
+#pragma unroll
+            for (int j = 0; j < 9; ++j) add4(v, t[j]);
         }
         return v;
     };

@@ -34,7 +34,8 @@ __device__ __forceinline__ float act_grad_post(float y, int act) {
 struct NormPlan { int cblocks, splits, rows_per_split; };
 NormPlan norm_plan(int B, int HW, int C) {
     const int cb = (C + 63) / 64;
-    int splits = (2048 + B * cb - 1) / (B * cb);
+    int splits = (1024 + B * cb - 1) / (B * cb);
+    if (splits > 32) splits = 32;          // the finalize kernel walks the splits serially: keep that loop short
     if (splits > (HW + 31) / 32) splits = (HW + 31) / 32;
     if (splits < 1) splits = 1;
     int rps = (HW + splits - 1) / splits;
@@ -286,9 +287,11 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restri
 }
 __global__ void loss_final_kernel(const double* __restrict__ part, int nb, double inv_n, float scale,
                                   float* __restrict__ loss, int accumulate) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < nb; ++i) s += part[i];
+    // one wave, fixed lane-strided order then a fixed butterfly: deterministic
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 64) s += part[i];
+    s = wave_sum_d(s);
+    if (threadIdx.x == 0) {
         const float v = (float)(s * inv_n) * scale;
         loss[0] = accumulate ? loss[0] + v : v;
     }
