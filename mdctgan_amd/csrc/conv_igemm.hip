@@ -21,6 +21,8 @@
 #include "common.h"
 #include "mdctgan_hip.h"
 #include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -29,6 +31,19 @@ constexpr int BK = 16;
 struct Geom {
     int B, H, W, Ci, OH, OW, Co, KH, KW, s, p, reflect;
 };
+
+// Batched launches (the 16 Winograd positions run as one grid): element strides between consecutive problems.
+// wino_perm: the data-gradient uses the 180-degree rotated filter, which in the Winograd domain is the position
+// permutation xi -> (3,1,2,0)[xi] on both axes (G * flip == P * G).
+struct Batch {
+    long long sa, sw, so;
+    int wino_perm;
+};
+__device__ __forceinline__ int wino_flip(int z) {
+    const int xi = z >> 2, nu = z & 3;
+    const int fx = (xi == 0) ? 3 : (xi == 3 ? 0 : xi), fn = (nu == 0) ? 3 : (nu == 3 ? 0 : nu);
+    return fx * 4 + fn;
+}
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {
     if (i < 0) i = -i;
@@ -108,7 +123,8 @@ template <int BM, int BN, bool VEC>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(Geom g, const float* __restrict__ x,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y,
-                                                       int act, int chunks_per_split, float* __restrict__ part) {
+                                                       int act, int chunks_per_split, float* __restrict__ part,
+                                                       Batch bt) {
     constexpr int MB = BM / 64, NB = BN / 64, LDA = BM + 4, LDB = BN + 4;
     constexpr int NVA = BM * 4 / 256, NVB = BN * 4 / 256;
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
@@ -117,6 +133,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geom g, const float* __re
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = g.B * g.OH * g.OW, N = g.Co, K = g.KH * g.KW * g.Ci;
+    x += (size_t)blockIdx.z * bt.sa;
+    w += (size_t)blockIdx.z * bt.sw;
+    y += (size_t)blockIdx.z * bt.so;
+    if (part) part += ((size_t)blockIdx.y * gridDim.z + blockIdx.z) * ((size_t)M * N);
     const int cpt = g.Ci / BK;   // chunks per tap (VEC)
     const int total_chunks = VEC ? g.KH * g.KW * cpt : (K + BK - 1) / BK;
     const int c_begin = blockIdx.y * chunks_per_split;
@@ -244,7 +264,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geom g, const float* __re
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm0 + 32 * mi + mfma32_row(r, lane);
                 if (row < M && col < N) {
-                    if (part) part[((size_t)blockIdx.y * M + row) * N + col] = acc[mi][ni][r];
+                    if (part) part[(size_t)row * N + col] = acc[mi][ni][r];
                     else y[(size_t)row * N + col] = apply_act(acc[mi][ni][r] + bv, act);
                 }
             }
@@ -259,7 +279,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
                                                          const float* __restrict__ w,
                                                          const float* __restrict__ bias,
                                                          float* __restrict__ dx, int act, int chunks_per_split,
-                                                         float* __restrict__ part) {
+                                                         float* __restrict__ part, Batch bt) {
     constexpr int MB = BM / 64, NB = BN / 64, LDA = BM + 4, LDB = BN + 4;
     constexpr int NVA = BM * 4 / 256, NVB = BN * 4 / 256;
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
@@ -268,9 +288,14 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = g.s;
-    const int py = blockIdx.z / s, px = blockIdx.z - py * s;
+    const int cls = blockIdx.z % (s * s), batch = blockIdx.z / (s * s);
+    const int py = cls / s, px = cls - py * s;
     const int Hc = (g.H - py + s - 1) / s, Wc = (g.W - px + s - 1) / s;   // pixels of this class
     const int M = g.B * Hc * Wc, N = g.Ci;
+    dy += (size_t)batch * bt.sa;
+    w += (size_t)(bt.wino_perm ? wino_flip(batch) : batch) * bt.sw;
+    dx += (size_t)batch * bt.so;
+    if (part) part += ((size_t)blockIdx.y * (gridDim.z / (s * s)) + batch) * ((size_t)M * N);
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     if ((int)blockIdx.x >= tiles_m * tiles_n) return;
     // taps that reach this class: ky = ky0 + s*i
@@ -464,7 +489,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
                 const int col = n0 + wn0 + 32 * ni + (lane & 31);
                 if (col < N) {
                     if (part) {   // split-K (stride 1 only: o == m * Ci)
-                        part[(size_t)blockIdx.y * M * N + o + col] = acc[mi][ni][r];
+                        part[o + col] = acc[mi][ni][r];
                     } else {
                         const float bv = bias ? bias[col] : 0.0f;
                         dx[o + col] = apply_act(acc[mi][ni][r] + bv, act);
@@ -481,7 +506,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
 template <int BM, int BN, bool VECA, bool VECB>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __restrict__ x,
                                                          const float* __restrict__ dy, float* __restrict__ out,
-                                                         int chunks_per_split, int accumulate) {
+                                                         int chunks_per_split, int accumulate, Batch bt) {
     constexpr int MB = BM / 64, NB = BN / 64, LDA = BM + 4, LDB = BN + 4;
     constexpr int NVA = BM * 4 / 256, NVB = BN * 4 / 256;
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
@@ -491,6 +516,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Mtot = g.B * g.OH * g.OW;          // reduction length
     const int R = g.Co, N = g.KH * g.KW * g.Ci;  // output rows / cols
+    x += (size_t)blockIdx.y * bt.sa;
+    dy += (size_t)blockIdx.y * bt.sw;
     const int tiles_m = (R + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int r_0 = (t % tiles_m) * BM, n0 = (t / tiles_m) * BN;
@@ -600,7 +627,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
         __syncthreads();
     }
 
-    float* o = out + (size_t)blockIdx.z * R * N;
+    float* o = out + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * ((size_t)R * N) ;
+    if (gridDim.z == 1) o = out + (size_t)blockIdx.y * bt.so;
 #pragma unroll
     for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
@@ -663,6 +691,10 @@ __global__ void colsum_partial_kernel(const float* __restrict__ a, long long M, 
         part[(size_t)blockIdx.y * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
                                            red[3][threadIdx.x];
 }
+
+}  // namespace
+#include "wino.h"
+namespace {
 
 Geom to_geom(const mg_conv_geom* g) {
     return Geom{g->B, g->H, g->W, g->Ci, g->OH, g->OW, g->Co, g->KH, g->KW, g->stride, g->pad, g->reflect};
@@ -743,6 +775,175 @@ WgradPlan wgrad_plan(const mg_conv_geom* g) {
     return {big, tiles, splits, cps};
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Winograd F(2x2,3x3) orchestration (transforms in wino.h, the 16 GEMMs as one batched implicit-GEMM launch)
+// ---------------------------------------------------------------------------------------------------------
+bool wino_ok(const mg_conv_geom* g) {
+    static const bool off = getenv("MG_NO_WINOGRAD") != nullptr;
+    return !off && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1 && g->Ci % 16 == 0 && g->Co % 16 == 0 &&
+           g->Ci >= 32 && g->Co >= 32 && g->H % 2 == 0 && g->W % 2 == 0 && g->H >= 2 && g->W >= 2;
+}
+struct WinoDims { long long T, Tp; int TH, TW, THp, TWp; };
+WinoDims wino_dims(const mg_conv_geom* g) {
+    WinoDims d;
+    d.TH = g->H / 2; d.TW = g->W / 2; d.T = (long long)g->B * d.TH * d.TW;
+    d.THp = (g->H + 2) / 2; d.TWp = (g->W + 2) / 2; d.Tp = (long long)g->B * d.THp * d.TWp;
+    return d;
+}
+inline size_t al256(size_t n) { return (n + 63) / 64 * 64; }   // in floats
+
+size_t wino_fwd_ws(const mg_conv_geom* g) {
+    const WinoDims d = wino_dims(g);
+    const TilePlan tp = gemm_plan(d.T, g->Co, g->Ci / BK, 16, true);
+    return (al256((size_t)16 * g->Co * g->Ci) + al256((size_t)16 * d.T * g->Ci) + al256((size_t)16 * d.T * g->Co) +
+            (tp.splits > 1 ? al256((size_t)tp.splits * 16 * d.T * g->Co) : 0)) * sizeof(float) + 256;
+}
+size_t wino_dgrad_ws(const mg_conv_geom* g) {
+    const WinoDims d = wino_dims(g);
+    const long long T = g->reflect ? d.Tp : d.T;
+    const TilePlan tp = gemm_plan(T, g->Ci, g->Co / BK, 16, true);
+    return (al256((size_t)16 * g->Co * g->Ci) + al256((size_t)16 * T * g->Co) + al256((size_t)16 * T * g->Ci) +
+            (g->reflect ? al256((size_t)g->B * (g->H + 2) * (g->W + 2) * g->Ci) : 0) +
+            (tp.splits > 1 ? al256((size_t)tp.splits * 16 * T * g->Ci) : 0)) * sizeof(float) + 256;
+}
+struct WinoWgradPlan { bool big; int tiles, splits, cps; };
+WinoWgradPlan wino_wgrad_plan(const mg_conv_geom* g) {
+    const WinoDims d = wino_dims(g);
+    const int chunks = (int)((d.T + BK - 1) / BK);
+    const int t128 = ((g->Co + 127) / 128) * ((g->Ci + 127) / 128);
+    const bool big = g->Co >= 128 && g->Ci >= 128;
+    const int tiles = big ? t128 : ((g->Co + 63) / 64) * ((g->Ci + 63) / 64);
+    int splits = tiles * 16 >= 512 ? 1 : (768 + tiles * 16 - 1) / (tiles * 16);
+    const int max_splits = chunks / 8 > 0 ? chunks / 8 : 1;
+    if (splits > max_splits) splits = max_splits;
+    int cps = (chunks + splits - 1) / splits;
+    splits = (chunks + cps - 1) / cps;
+    return {big, tiles, splits, cps};
+}
+size_t wino_wgrad_ws(const mg_conv_geom* g) {
+    const WinoDims d = wino_dims(g);
+    const WinoWgradPlan p = wino_wgrad_plan(g);
+    const size_t cs = (mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co) + 255) / 4;
+    return (al256((size_t)16 * d.T * g->Ci) + al256((size_t)16 * d.T * g->Co) + al256((size_t)16 * g->Co * g->Ci) +
+            (p.splits > 1 ? al256((size_t)p.splits * 16 * g->Co * g->Ci) : 0) + al256(cs)) * sizeof(float) + 256;
+}
+
+template <typename Launch>
+int wino_launch_tiles(const TilePlan& tp, Launch&& launch) {
+    if (tp.bm == 128 && tp.bn == 128) launch(std::integral_constant<int, 128>{}, std::integral_constant<int, 128>{});
+    else if (tp.bm == 64) launch(std::integral_constant<int, 64>{}, std::integral_constant<int, 64>{});
+    else launch(std::integral_constant<int, 128>{}, std::integral_constant<int, 64>{});
+    return 0;
+}
+
+int wino_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act, float* ws,
+             hipStream_t st) {
+    const WinoDims d = wino_dims(g);
+    float* U = ws;
+    float* V = U + al256((size_t)16 * g->Co * g->Ci);
+    float* Mx = V + al256((size_t)16 * d.T * g->Ci);
+    float* part = Mx + al256((size_t)16 * d.T * g->Co);
+    hipLaunchKernelGGL(wino_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 4)), dim3(256), 0, st, w, g->Co,
+                       g->Ci, U);
+    hipLaunchKernelGGL(wino_input_xform_kernel, dim3(wino_grid((size_t)d.T * g->Ci / 4)), dim3(256), 0, st, x, g->B, g->H,
+                       g->W, g->Ci, d.TH, d.TW, 1, g->reflect, V);
+    const Geom gg{1, 1, (int)d.T, g->Ci, 1, (int)d.T, g->Co, 1, 1, 1, 0, 0};
+    const TilePlan tp = gemm_plan(d.T, g->Co, g->Ci / BK, 16, true);
+    float* pp = tp.splits > 1 ? part : nullptr;
+    const Batch bt{d.T * g->Ci, (long long)g->Co * g->Ci, d.T * g->Co, 0};
+    wino_launch_tiles(tp, [&](auto bm, auto bn) {
+        constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value;
+        dim3 grid((unsigned)(((d.T + BM_ - 1) / BM_) * ((g->Co + BN_ - 1) / BN_)), tp.splits, 16);
+        hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, true>), grid, dim3(256), 0, st, gg, (const float*)V,
+                           (const float*)U, (const float*)nullptr, Mx, MG_ACT_NONE, tp.cps, pp, bt);
+    });
+    if (pp) {
+        const size_t n = (size_t)16 * d.T * g->Co;
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(wino_grid(n / 4)), dim3(256), 0, st, (const float*)pp, tp.splits,
+                           n, g->Co, (const float*)nullptr, MG_ACT_NONE, Mx);
+    }
+    hipLaunchKernelGGL(wino_output_xform_kernel, dim3(wino_grid((size_t)d.T * g->Co / 4)), dim3(256), 0, st,
+                       (const float*)Mx, g->B, d.TH, d.TW, g->Co, bias, act, y);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+int wino_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act, float* ws,
+               hipStream_t st) {
+    const WinoDims d = wino_dims(g);
+    const long long T = g->reflect ? d.Tp : d.T;
+    const int TH = g->reflect ? d.THp : d.TH, TW = g->reflect ? d.TWp : d.TW;
+    float* U = ws;
+    float* V = U + al256((size_t)16 * g->Co * g->Ci);
+    float* Mx = V + al256((size_t)16 * T * g->Co);
+    float* dxp = Mx + al256((size_t)16 * T * g->Ci);
+    float* part = dxp + (g->reflect ? al256((size_t)g->B * (g->H + 2) * (g->W + 2) * g->Ci) : 0);
+    hipLaunchKernelGGL(wino_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 4)), dim3(256), 0, st, w, g->Co,
+                       g->Ci, U);
+    // dy is [B, OH, OW, Co] with OH == H, OW == W; "full" (origin -2, zero) for reflect, "same" (origin -1) otherwise
+    hipLaunchKernelGGL(wino_input_xform_kernel, dim3(wino_grid((size_t)T * g->Co / 4)), dim3(256), 0, st, dy, g->B, g->H,
+                       g->W, g->Co, TH, TW, g->reflect ? 2 : 1, 0, V);
+    const Geom gg{1, 1, (int)T, g->Ci, 1, (int)T, g->Co, 1, 1, 1, 0, 0};
+    const TilePlan tp = gemm_plan(T, g->Ci, g->Co / BK, 16, true);
+    float* pp = tp.splits > 1 ? part : nullptr;
+    const Batch bt{T * g->Co, (long long)g->Co * g->Ci, T * g->Ci, 1};
+    wino_launch_tiles(tp, [&](auto bm, auto bn) {
+        constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value;
+        dim3 grid((unsigned)(((T + BM_ - 1) / BM_) * ((g->Ci + BN_ - 1) / BN_)), tp.splits, 16);
+        hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, true>), grid, dim3(256), 0, st, gg, (const float*)V,
+                           (const float*)U, (const float*)nullptr, Mx, MG_ACT_NONE, tp.cps, pp, bt);
+    });
+    if (pp) {
+        const size_t n = (size_t)16 * T * g->Ci;
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(wino_grid(n / 4)), dim3(256), 0, st, (const float*)pp, tp.splits,
+                           n, g->Ci, (const float*)nullptr, MG_ACT_NONE, Mx);
+    }
+    if (g->reflect) {
+        hipLaunchKernelGGL(wino_output_xform_kernel, dim3(wino_grid((size_t)T * g->Ci / 4)), dim3(256), 0, st,
+                           (const float*)Mx, g->B, TH, TW, g->Ci, (const float*)nullptr, MG_ACT_NONE, dxp);
+        hipLaunchKernelGGL(wino_fold_reflect_kernel, dim3(wino_grid((size_t)g->B * g->H * g->W * g->Ci / 4)), dim3(256), 0,
+                           st, (const float*)dxp, g->B, g->H, g->W, g->Ci, dx);
+    } else {
+        hipLaunchKernelGGL(wino_output_xform_kernel, dim3(wino_grid((size_t)T * g->Ci / 4)), dim3(256), 0, st,
+                           (const float*)Mx, g->B, TH, TW, g->Ci, bias, act, dx);
+    }
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+int wino_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate, float* ws,
+               hipStream_t st) {
+    const WinoDims d = wino_dims(g);
+    const WinoWgradPlan p = wino_wgrad_plan(g);
+    float* V = ws;
+    float* Md = V + al256((size_t)16 * d.T * g->Ci);
+    float* dU = Md + al256((size_t)16 * d.T * g->Co);
+    float* part = dU + al256((size_t)16 * g->Co * g->Ci);
+    hipLaunchKernelGGL(wino_input_xform_kernel, dim3(wino_grid((size_t)d.T * g->Ci / 4)), dim3(256), 0, st, x, g->B, g->H,
+                       g->W, g->Ci, d.TH, d.TW, 1, g->reflect, V);
+    hipLaunchKernelGGL(wino_dy_xform_kernel, dim3(wino_grid((size_t)d.T * g->Co / 4)), dim3(256), 0, st, dy, g->B, d.TH,
+                       d.TW, g->Co, Md);
+    const Geom gg{1, 1, (int)d.T, g->Ci, 1, (int)d.T, g->Co, 1, 1, 1, 0, 0};
+    float* target = p.splits > 1 ? part : dU;
+    const Batch bt{d.T * g->Ci, d.T * g->Co, (long long)g->Co * g->Ci, 0};
+    dim3 grid((unsigned)p.tiles, 16, p.splits);
+    if (p.big)
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, true, true>), grid, dim3(256), 0, st, gg, (const float*)V,
+                           (const float*)Md, target, p.cps, 0, bt);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, true, true>), grid, dim3(256), 0, st, gg, (const float*)V,
+                           (const float*)Md, target, p.cps, 0, bt);
+    if (p.splits > 1) {
+        const size_t n = (size_t)16 * g->Co * g->Ci;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(wino_grid(n / 4)), dim3(256), 0, st, (const float*)part, p.splits, n,
+                           dU, 0);
+    }
+    hipLaunchKernelGGL(wino_dweight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 4)), dim3(256), 0, st,
+                       (const float*)dU, g->Co, g->Ci, dw, accumulate);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -761,7 +962,19 @@ int mg_abi_version(void) { return 1; }
 int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
     if (!geom_ok(g) || !out || out_len < 64) return MG_ERR_ARG;
     const int kq = mg_conv_rowdot_kq(g);
-    if (kq && pass == 0) {
+    if (wino_ok(g) && !kq) {
+        const WinoDims d = wino_dims(g);
+        if (pass == 0) {
+            const TilePlan tp = gemm_plan(d.T, g->Co, g->Ci / BK, 16, true);
+            snprintf(out, out_len, "winograd:conv_fwd_kernel<%d, %d, true>", tp.bm, tp.bn);
+        } else if (pass == 1) {
+            const TilePlan tp = gemm_plan(g->reflect ? d.Tp : d.T, g->Ci, g->Co / BK, 16, true);
+            snprintf(out, out_len, "winograd:conv_dgrad_kernel<%d, %d, true, true>", tp.bm, tp.bn);
+        } else {
+            const WinoWgradPlan p = wino_wgrad_plan(g);
+            snprintf(out, out_len, "winograd:conv_wgrad_kernel<%d, %d, true, true>", p.big ? 128 : 64, p.big ? 128 : 64);
+        }
+    } else if (kq && pass == 0) {
         snprintf(out, out_len, "conv_rowdot_fwd_kernel<%d>", kq);
     } else if (kq && pass == 2) {
         snprintf(out, out_len, "conv_rowdot_wgrad_kernel<%d>", kq);
@@ -784,11 +997,13 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
 
 size_t mg_conv_fwd_workspace(const mg_conv_geom* g) {
     if (!geom_ok(g)) return 0;
+    if (wino_ok(g)) return wino_fwd_ws(g);
     const TilePlan tp = fwd_plan(g);
     return tp.splits > 1 ? (size_t)tp.splits * g->B * g->OH * g->OW * g->Co * sizeof(float) + 256 : 256;
 }
 size_t mg_conv_dgrad_workspace(const mg_conv_geom* g) {
     if (!geom_ok(g)) return 0;
+    if (wino_ok(g)) return wino_dgrad_ws(g);
     const TilePlan tp = dgrad_plan(g);
     return tp.splits > 1 ? (size_t)tp.splits * g->B * g->H * g->W * g->Ci * sizeof(float) + 256 : 256;
 }
@@ -797,6 +1012,9 @@ int mg_conv_fwd(const mg_conv_geom* g, const float* x, const float* w, const flo
                 void* workspace, size_t workspace_bytes, void* stream) {
     if (!geom_ok(g) || !x || !w || !y) return MG_ERR_ARG;
     if (mg_conv_rowdot_kq(g) && aligned16(x) && aligned16(w)) return mg_conv_rowdot_fwd(g, x, w, bias, y, act, stream);
+    if (wino_ok(g) && workspace && workspace_bytes >= wino_fwd_ws(g) && aligned16(x) && aligned16(w) && aligned16(y) &&
+        aligned16(workspace) && (!bias || aligned16(bias)))
+        return wino_fwd(g, x, w, bias, y, act, (float*)workspace, (hipStream_t)stream);
     const Geom gg = to_geom(g);
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)g->B * g->OH * g->OW;
@@ -812,8 +1030,8 @@ int mg_conv_fwd(const mg_conv_geom* g, const float* x, const float* w, const flo
 #define MG_LAUNCH_FWD(BM_, BN_)                                                                                    \
     do {                                                                                                           \
         dim3 grid((unsigned)(((M + BM_ - 1) / BM_) * ((N + BN_ - 1) / BN_)), tp.splits);                           \
-        if (vec) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, true>), grid, dim3(256), 0, st, gg, x, w, bias, y, act, tp.cps, part);  \
-        else hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, false>), grid, dim3(256), 0, st, gg, x, w, bias, y, act, tp.cps, part);    \
+        if (vec) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, true>), grid, dim3(256), 0, st, gg, x, w, bias, y, act, tp.cps, part, Batch{0, 0, 0, 0});  \
+        else hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, false>), grid, dim3(256), 0, st, gg, x, w, bias, y, act, tp.cps, part, Batch{0, 0, 0, 0});    \
     } while (0)
     if (tp.bm == 128 && tp.bn == 128) MG_LAUNCH_FWD(128, 128);
     else if (tp.bm == 64) MG_LAUNCH_FWD(64, 64);
@@ -834,6 +1052,9 @@ int mg_conv_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const 
                   void* workspace, size_t workspace_bytes, void* stream) {
     if (!geom_ok(g) || !dy || !w || !dx) return MG_ERR_ARG;
     if (g->reflect && g->stride != 1) return MG_ERR_UNSUPPORTED;
+    if (wino_ok(g) && !(g->reflect && (bias || act != MG_ACT_NONE)) && workspace && workspace_bytes >= wino_dgrad_ws(g) &&
+        aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(workspace) && (!bias || aligned16(bias)))
+        return wino_dgrad(g, dy, w, bias, dx, act, (float*)workspace, (hipStream_t)stream);
     const Geom gg = to_geom(g);
     hipStream_t st = (hipStream_t)stream;
     const int s = g->stride;
@@ -853,13 +1074,13 @@ int mg_conv_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const 
     do {                                                                                                           \
         dim3 grid((unsigned)(((Mc + BM_ - 1) / BM_) * ((N + BN_ - 1) / BN_)), tp.splits, s * s);                   \
         if (veca && vecb)                                                                                          \
-            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, true>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act, tp.cps, part);  \
+            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, true>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act, tp.cps, part, Batch{0, 0, 0, 0});  \
         else if (veca)                                                                                             \
-            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, false>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act, tp.cps, part); \
+            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, false>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act, tp.cps, part, Batch{0, 0, 0, 0}); \
         else if (vecb)                                                                                             \
-            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, false, true>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act, tp.cps, part); \
+            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, false, true>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act, tp.cps, part, Batch{0, 0, 0, 0}); \
         else                                                                                                       \
-            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, false, false>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act, tp.cps, part);\
+            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, false, false>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act, tp.cps, part, Batch{0, 0, 0, 0});\
     } while (0)
     if (tp.bm == 128 && tp.bn == 128) MG_LAUNCH_DGRAD(128, 128);
     else if (tp.bm == 64) MG_LAUNCH_DGRAD(64, 64);
@@ -902,6 +1123,7 @@ int mg_colsum(const float* a, long long M, int C, float* out, int accumulate, vo
 size_t mg_conv_wgrad_workspace(const mg_conv_geom* g) {
     if (!geom_ok(g)) return 0;
     if (mg_conv_rowdot_kq(g)) return mg_conv_rowdot_wgrad_workspace(g);
+    if (wino_ok(g)) return wino_wgrad_ws(g);
     const WgradPlan p = wgrad_plan(g);
     const size_t wg = p.splits > 1 ? (size_t)p.splits * g->Co * g->KH * g->KW * g->Ci * sizeof(float) : 0;
     const size_t cs = mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co);
@@ -914,6 +1136,19 @@ int mg_conv_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float*
     if (workspace_bytes < mg_conv_wgrad_workspace(g) || !workspace) return MG_ERR_ARG;
     if (mg_conv_rowdot_kq(g) && aligned16(x) && aligned16(workspace))
         return mg_conv_rowdot_wgrad(g, x, dy, dw, dbias, accumulate, workspace, workspace_bytes, stream);
+    if (wino_ok(g) && aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace)) {
+        const int rc = wino_wgrad(g, x, dy, dw, accumulate, (float*)workspace, (hipStream_t)stream);
+        if (rc != MG_OK) return rc;
+        if (dbias) {
+            const WinoDims d = wino_dims(g);
+            float* cs = (float*)workspace + al256((size_t)16 * d.T * g->Ci) + al256((size_t)16 * d.T * g->Co) +
+                        al256((size_t)16 * g->Co * g->Ci) +
+                        (wino_wgrad_plan(g).splits > 1 ? al256((size_t)wino_wgrad_plan(g).splits * 16 * g->Co * g->Ci) : 0);
+            return mg_colsum(dy, (long long)g->B * g->OH * g->OW, g->Co, dbias, accumulate, cs,
+                             mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co), stream);
+        }
+        return MG_OK;
+    }
     const Geom gg = to_geom(g);
     hipStream_t st = (hipStream_t)stream;
     const WgradPlan p = wgrad_plan(g);
@@ -926,13 +1161,13 @@ int mg_conv_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float*
     do {                                                                                                            \
         dim3 grid((unsigned)p.tiles, 1, p.splits);                                                                  \
         if (veca && vecb)                                                                                           \
-            hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, true, true>), grid, dim3(256), 0, st, gg, x, dy, target, p.cps, acc_direct);  \
+            hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, true, true>), grid, dim3(256), 0, st, gg, x, dy, target, p.cps, acc_direct, Batch{0, 0, 0, 0});  \
         else if (veca)                                                                                              \
-            hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, true, false>), grid, dim3(256), 0, st, gg, x, dy, target, p.cps, acc_direct); \
+            hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, true, false>), grid, dim3(256), 0, st, gg, x, dy, target, p.cps, acc_direct, Batch{0, 0, 0, 0}); \
         else if (vecb)                                                                                              \
-            hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, false, true>), grid, dim3(256), 0, st, gg, x, dy, target, p.cps, acc_direct); \
+            hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, false, true>), grid, dim3(256), 0, st, gg, x, dy, target, p.cps, acc_direct, Batch{0, 0, 0, 0}); \
         else                                                                                                        \
-            hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, false, false>), grid, dim3(256), 0, st, gg, x, dy, target, p.cps, acc_direct);\
+            hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, false, false>), grid, dim3(256), 0, st, gg, x, dy, target, p.cps, acc_direct, Batch{0, 0, 0, 0});\
     } while (0)
     if (p.big) MG_LAUNCH_WGRAD(128, 128);
     else MG_LAUNCH_WGRAD(64, 64);

@@ -1,0 +1,226 @@
+// Winograd F(2x2, 3x3) for the stride-1 3x3 convolutions (the 18 ResnetBlock convs are 81 % of the generator's
+// FLOPs, models/networks.py:440, 456): 16 multiplies per 2x2 output tile and channel pair instead of 36, i.e. the
+// MFMA work drops 2.25x while the result stays float32-exact up to the usual F(2,3) rounding (the reference's own
+// cuDNN path uses the same algorithm family under cudnn.benchmark, train.py:25).
+//
+//   forward   Y  = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A            d: 4x4 input patch (reflect / zero pad 1)
+//   dgrad     dXp = A^T [ sum_co (G g' G^T) .* (B^T dy B) ] A           g' = g rotated 180 deg == position permutation
+//             reflect padding: dXp is the (H+2)x(W+2) "full" gradient, folded back by wino_fold_reflect
+//   wgrad     dg = G^T [ sum_tiles (B^T d B) .* (A dy A^T) ] G
+// The element-wise products summed over channels / tiles are 16 independent GEMMs, run as ONE batched launch of
+// the implicit-GEMM kernels with a 1x1 geometry (conv_igemm.hip); everything here is the HBM-bound transforms.
+// Layouts: V / M: [16][T][C] (T = B * TH * TW tiles), U: [16][Co][Ci].
+#pragma once
+
+namespace {
+
+// ---- 1-D building blocks (applied to rows then columns) -------------------------------------------------------
+__device__ __forceinline__ void bt4(const float4 d0, const float4 d1, const float4 d2, const float4 d3, float4 (&o)[4]) {
+    o[0] = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
+    o[1] = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
+    o[2] = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
+    o[3] = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
+}
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 f4neg(float4 a) { return make_float4(-a.x, -a.y, -a.z, -a.w); }
+
+// V[16][T][C] = B^T d B.  Patch origin (2*ty - org, 2*tx - org); outside [0,H)x[0,W): reflect (org must be 1) or 0.
+__global__ void wino_input_xform_kernel(const float* __restrict__ x, int B, int H, int W, int C, int TH, int TW,
+                                        int org, int reflect, float* __restrict__ V) {
+    const int C4 = C / 4;
+    const size_t T = (size_t)B * TH * TW, total = T * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const size_t t = i / C4;
+        const int tx = (int)(t % TW), ty = (int)((t / TW) % TH), b = (int)(t / ((size_t)TW * TH));
+        float4 d[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int iy = 2 * ty - org + r;
+            bool oky = true;
+            if (reflect) iy = reflect_idx(iy, H); else oky = (iy >= 0 && iy < H);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                int ix = 2 * tx - org + c;
+                bool ok = oky;
+                if (reflect) ix = reflect_idx(ix, W); else ok = ok && (ix >= 0 && ix < W);
+                d[r][c] = ok ? ld4(x + ((size_t)(b * H + iy) * W + ix) * C + 4 * c4) : zero4();
+            }
+        }
+        float4 tmp[4][4];   // tmp[:, c] = B^T d[:, c]
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float4 o[4];
+            bt4(d[0][c], d[1][c], d[2][c], d[3][c], o);
+            tmp[0][c] = o[0]; tmp[1][c] = o[1]; tmp[2][c] = o[2]; tmp[3][c] = o[3];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float4 o[4];
+            bt4(tmp[r][0], tmp[r][1], tmp[r][2], tmp[r][3], o);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                *reinterpret_cast<float4*>(V + ((size_t)(r * 4 + c) * T + t) * C + 4 * c4) = o[c];
+        }
+    }
+}
+
+// U[16][Co][Ci] = G g G^T from OHWI weights [Co][3][3][Ci]
+__global__ void wino_weight_xform_kernel(const float* __restrict__ w, int Co, int Ci, float* __restrict__ U) {
+    const int C4 = Ci / 4;
+    const size_t total = (size_t)Co * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4), co = (int)(i / C4);
+        float4 g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g[r][c] = ld4(w + ((size_t)(co * 3 + r) * 3 + c) * Ci + 4 * c4);
+        float4 tmp[4][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            tmp[0][c] = g[0][c];
+            tmp[1][c] = f4scale(f4add(f4add(g[0][c], g[1][c]), g[2][c]), 0.5f);
+            tmp[2][c] = f4scale(f4add(f4sub(g[0][c], g[1][c]), g[2][c]), 0.5f);
+            tmp[3][c] = g[2][c];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float4 o[4];
+            o[0] = tmp[r][0];
+            o[1] = f4scale(f4add(f4add(tmp[r][0], tmp[r][1]), tmp[r][2]), 0.5f);
+            o[2] = f4scale(f4add(f4sub(tmp[r][0], tmp[r][1]), tmp[r][2]), 0.5f);
+            o[3] = tmp[r][2];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                *reinterpret_cast<float4*>(U + ((size_t)(r * 4 + c) * Co + co) * Ci + 4 * c4) = o[c];
+        }
+    }
+}
+
+// out[B][2TH][2TW][C] = act(A^T M A + bias)
+__global__ void wino_output_xform_kernel(const float* __restrict__ Mx, int B, int TH, int TW, int C,
+                                         const float* __restrict__ bias, int act, float* __restrict__ out) {
+    const int C4 = C / 4;
+    const size_t T = (size_t)B * TH * TW, total = T * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const size_t t = i / C4;
+        const int tx = (int)(t % TW), ty = (int)((t / TW) % TH), b = (int)(t / ((size_t)TW * TH));
+        float4 m[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) m[r][c] = ld4(Mx + ((size_t)(r * 4 + c) * T + t) * C + 4 * c4);
+        float4 tmp[2][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            tmp[0][c] = f4add(f4add(m[0][c], m[1][c]), m[2][c]);
+            tmp[1][c] = f4sub(f4sub(m[1][c], m[2][c]), m[3][c]);
+        }
+        const float4 bv = bias ? ld4(bias + 4 * c4) : zero4();
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float4 y0 = f4add(f4add(f4add(tmp[r][0], tmp[r][1]), tmp[r][2]), bv);
+            float4 y1 = f4add(f4sub(f4sub(tmp[r][1], tmp[r][2]), tmp[r][3]), bv);
+            y0.x = apply_act(y0.x, act); y0.y = apply_act(y0.y, act); y0.z = apply_act(y0.z, act); y0.w = apply_act(y0.w, act);
+            y1.x = apply_act(y1.x, act); y1.y = apply_act(y1.y, act); y1.z = apply_act(y1.z, act); y1.w = apply_act(y1.w, act);
+            float* o = out + ((size_t)(b * 2 * TH + 2 * ty + r) * (2 * TW) + 2 * tx) * C + 4 * c4;
+            *reinterpret_cast<float4*>(o) = y0;
+            *reinterpret_cast<float4*>(o + C) = y1;
+        }
+    }
+}
+
+// ReflectionPad2d(1) backward: dX[i][j] = sum of the padded positions aliasing (i, j).  dXp: [B][H+2][W+2][C]
+__global__ void wino_fold_reflect_kernel(const float* __restrict__ dxp, int B, int H, int W, int C,
+                                         float* __restrict__ dx) {
+    const int C4 = C / 4;
+    const size_t total = (size_t)B * H * W * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        size_t r = i / C4;
+        const int ix = (int)(r % W); r /= W;
+        const int iy = (int)(r % H);
+        const int b = (int)(r / H);
+        const int cy[3] = {iy + 1, (iy == 1) ? 0 : -1, (iy == H - 2) ? H + 1 : -1};
+        const int cx[3] = {ix + 1, (ix == 1) ? 0 : -1, (ix == W - 2) ? W + 1 : -1};
+        float4 s = zero4();
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (cy[a] < 0) continue;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (cx[c] < 0) continue;
+                add4(s, ld4(dxp + ((size_t)(b * (H + 2) + cy[a]) * (W + 2) + cx[c]) * C + 4 * c4));
+            }
+        }
+        *reinterpret_cast<float4*>(dx + i * 4) = s;
+    }
+}
+
+// Mdy[16][T][C] = A dy A^T for the 2x2 tiles of dy [B][2TH][2TW][C]
+__global__ void wino_dy_xform_kernel(const float* __restrict__ dy, int B, int TH, int TW, int C, float* __restrict__ Md) {
+    const int C4 = C / 4;
+    const size_t T = (size_t)B * TH * TW, total = T * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const size_t t = i / C4;
+        const int tx = (int)(t % TW), ty = (int)((t / TW) % TH), b = (int)(t / ((size_t)TW * TH));
+        const float* p = dy + ((size_t)(b * 2 * TH + 2 * ty) * (2 * TW) + 2 * tx) * C + 4 * c4;
+        const float4 y00 = ld4(p), y01 = ld4(p + C), y10 = ld4(p + (size_t)2 * TW * C), y11 = ld4(p + (size_t)2 * TW * C + C);
+        // tmp = A dy (4x2), A = [[1,0],[1,1],[1,-1],[0,-1]]
+        float4 tmp[4][2] = {{y00, y01}, {f4add(y00, y10), f4add(y01, y11)}, {f4sub(y00, y10), f4sub(y01, y11)},
+                            {f4neg(y10), f4neg(y11)}};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float4 o[4] = {tmp[r][0], f4add(tmp[r][0], tmp[r][1]), f4sub(tmp[r][0], tmp[r][1]), f4neg(tmp[r][1])};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                *reinterpret_cast<float4*>(Md + ((size_t)(r * 4 + c) * T + t) * C + 4 * c4) = o[c];
+        }
+    }
+}
+
+// dW [Co][3][3][Ci] (+)= G^T dU G,  dU: [16][Co][Ci]
+__global__ void wino_dweight_xform_kernel(const float* __restrict__ dU, int Co, int Ci, float* __restrict__ dw,
+                                          int accumulate) {
+    const int C4 = Ci / 4;
+    const size_t total = (size_t)Co * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4), co = (int)(i / C4);
+        float4 u[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) u[r][c] = ld4(dU + ((size_t)(r * 4 + c) * Co + co) * Ci + 4 * c4);
+        float4 tmp[3][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 h1 = f4scale(u[1][c], 0.5f), h2 = f4scale(u[2][c], 0.5f);
+            tmp[0][c] = f4add(f4add(u[0][c], h1), h2);
+            tmp[1][c] = f4sub(h1, h2);
+            tmp[2][c] = f4add(f4add(h1, h2), u[3][c]);
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float4 h1 = f4scale(tmp[r][1], 0.5f), h2 = f4scale(tmp[r][2], 0.5f);
+            float4 o[3] = {f4add(f4add(tmp[r][0], h1), h2), f4sub(h1, h2), f4add(f4add(h1, h2), tmp[r][3])};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float* p = dw + ((size_t)(co * 3 + r) * 3 + c) * Ci + 4 * c4;
+                if (accumulate) add4(o[c], ld4(p));
+                *reinterpret_cast<float4*>(p) = o[c];
+            }
+        }
+    }
+}
+
+inline unsigned wino_grid(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+}  // namespace

@@ -31,6 +31,10 @@ CONV_CASES = [
     ("down3x3_s2_ci4", 2, 4, 32, 64, 8, 3, 2, 1, False),
     ("conv3x3_ci24_reflect", 2, 24, 16, 32, 40, 3, 1, 1, True),
     ("conv3x3_ci8_co8", 2, 8, 32, 256, 8, 3, 1, 1, True),
+    ("wino_zero_pad", 2, 32, 12, 20, 48, 3, 1, 1, False),
+    ("wino_reflect_2rows", 3, 64, 2, 16, 64, 3, 1, 1, True),
+    ("wino_reflect_big", 2, 128, 16, 32, 128, 3, 1, 1, True),
+    ("odd_size_no_wino", 2, 32, 7, 9, 32, 3, 1, 1, True),
 ]
 
 
