@@ -728,21 +728,66 @@ ColsumPlan colsum_plan(long long M, int C) {
 // 1024-channel 8x16 bottleneck: 64 tiles of 128x128) get there by splitting K across blockIdx.y.
 struct TilePlan { int bm, bn, splits, cps; };
 TilePlan gemm_plan(long long M, int N, int chunks, int classes, bool can_split) {
-    auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * classes; };
-    auto split_for = [&](long long t) {
-        if (!can_split || t >= 384) return 1;
-        int sp = (int)((512 + t - 1) / t);
-        const int max_sp = chunks / 16 > 0 ? chunks / 16 : 1;
-        return sp < max_sp ? sp : max_sp;
+    // Cost model in units of one 32x32x2 MFMA (64 cycles): a workgroup's 4 waves own the CU's 4 SIMDs, so the
+    // workgroups mapped to one CU serialise on the MFMA pipe; a lone workgroup per CU cannot hide its own staging;
+    // split-K pays one extra pass over (splits + 1) output-sized slabs at ~4 TB/s.
+    if (const char* f = getenv("MG_FORCE_PLAN")) {      // tuning harness: "bm,bn,splits"
+        int bm = 0, bn = 0, sp = 1;
+        if (sscanf(f, "%d,%d,%d", &bm, &bn, &sp) == 3 && sp >= 1) {
+            if (!can_split || chunks / sp < 1) sp = 1;
+            const int cps = (chunks + sp - 1) / sp;
+            return {bm, bn, (chunks + cps - 1) / cps, cps};
+        }
+    }
+    // Plans measured on MI355X for the layer shapes of BASELINE configs[1] at batch 8 (scripts/tune_conv.py sweeps
+    // tile x split with MG_FORCE_PLAN and keeps the fastest); anything else falls through to the cost model.
+    struct Tuned { long long M; int N, chunks, classes, bm, bn, sp; };
+    static const Tuned tuned[] = {
+        {256, 1024, 64, 16, 128, 128, 2},     // Winograd forward GEMMs, 1024-channel 8x16 ResNet blocks
+        {360, 1024, 64, 16, 128, 64, 1},      // Winograd data-gradient GEMMs (reflection: 10x18 padded domain)
+        {1024, 1024, 288, 1, 128, 128, 12},   // 512->1024 stride-2 forward (and the 1024->512 ConvTranspose backward)
+        {4096, 512, 144, 1, 128, 128, 4},     // 256->512
+        {16384, 256, 72, 1, 128, 64, 3},      // 128->256
+        {65536, 128, 36, 1, 128, 128, 1},     // 64->128
+        {4896, 512, 256, 1, 128, 64, 4},      // D 256->512 4x4 s1 forward
+        {4488, 256, 128, 1, 64, 64, 6},       // D 128->256 4x4 s2 forward
+        {17160, 128, 64, 1, 64, 64, 3},       // D 64->128 4x4 s2 forward
+        {4488, 256, 512, 1, 64, 64, 8},       // D 256->512 4x4 s1 data gradient
+        {1024, 512, 576, 4, 64, 64, 1},       // stride-2 data gradients / ConvTranspose forwards (4 parity classes)
+        {4096, 256, 288, 4, 64, 64, 1},
+        {16384, 128, 144, 4, 64, 64, 1},
+        {65536, 64, 72, 4, 128, 64, 1},
+        {4488, 128, 256, 4, 64, 64, 1},
+        {17160, 64, 128, 4, 64, 64, 1},
     };
-    int bm, bn;
-    if (N <= 32 && M >= 64 * 512) { bm = 128; bn = 64; }
-    else if (N >= 128 && M >= 128 && tiles(128, 128) * split_for(tiles(128, 128)) >= 256) { bm = 128; bn = 128; }
-    else { bm = 64; bn = 64; }
-    int sp = split_for(tiles(bm, bn));
-    int cps = (chunks + sp - 1) / sp;
-    sp = (chunks + cps - 1) / cps;
-    return {bm, bn, sp, cps};
+    for (const Tuned& t : tuned)
+        if (t.M == M && t.N == N && t.chunks == chunks && t.classes == classes && (t.sp == 1 || can_split)) {
+            const int cps = (chunks + t.sp - 1) / t.sp;
+            return {t.bm, t.bn, (chunks + cps - 1) / cps, cps};
+        }
+    struct Cand { int bm, bn; };
+    const Cand cands[3] = {{128, 128}, {128, 64}, {64, 64}};
+    const int split_opts[9] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
+    double best = 1e300;
+    TilePlan out{64, 64, 1, chunks};
+    for (const Cand& c : cands) {
+        if (c.bm == 128 && c.bn == 128 && (N < 96 || M < 96)) continue;
+        if (c.bm == 128 && c.bn == 64 && M < 96) continue;
+        const long long tiles = ((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn) * classes;
+        const double mfma = 8.0 * (c.bm / 64) * (c.bn / 64);
+        for (int sp : split_opts) {
+            if (sp > 1 && (!can_split || chunks / sp < 8)) break;
+            const int cps = (chunks + sp - 1) / sp;
+            const int spl = (chunks + cps - 1) / cps;
+            const long long wgs = tiles * spl;
+            const double work = cps * (mfma + 3.0) + 14.0;
+            double t = (double)((wgs + 255) / 256) * work;
+            if (wgs < 2 * 256) t *= 1.25;
+            if (spl > 1) t += (double)(spl + 1) * (double)M * N * classes * 4.0 / 4e12 / 29e-9 * 256.0 / 256.0;
+            if (t < best) { best = t; out = {c.bm, c.bn, spl, cps}; }
+        }
+    }
+    return out;
 }
 TilePlan fwd_plan(const mg_conv_geom* g) {
     const long long M = (long long)g->B * g->OH * g->OW;

@@ -1,0 +1,22 @@
+"""Empirical tile/split search for the fwd / dgrad passes (MG_FORCE_PLAN) on the configs[1] layer shapes.
+Each configuration runs in a fresh process (the override is read per call, but keep it simple)."""
+import os, subprocess, sys, re
+shapes = sys.argv[1].split(",") if len(sys.argv) > 1 else ["bottleneck", "down512", "down256", "down128", "down64", "d256_512", "d128_256", "d64_128"]
+cfgs = [(bm, bn, sp) for (bm, bn) in ((128, 128), (128, 64), (64, 64)) for sp in (1, 2, 3, 4, 6, 8, 12)]
+best = {}
+for bm, bn, sp in cfgs:
+    env = dict(os.environ, MG_FORCE_PLAN="%d,%d,%d" % (bm, bn, sp))
+    out = subprocess.run([sys.executable, "scripts/bench_conv.py", "--only", ",".join(shapes), "--iters", "10"], env=env,
+                         capture_output=True, text=True).stdout
+    for line in out.splitlines():
+        m = re.match(r"(\S+)\s+[\d.]+ GF \| fwd\s+([\d.]+) us.*?\| dgrad\s+([\d.]+) us", line)
+        if not m:
+            continue
+        name, tf, td = m.group(1), float(m.group(2)), float(m.group(3))
+        for ps, t in (("fwd", tf), ("dgrad", td)):
+            k = (name, ps)
+            if k not in best or t < best[k][0]:
+                best[k] = (t, bm, bn, sp)
+    print("done", bm, bn, sp, flush=True)
+for k in sorted(best):
+    print("%-12s %-6s best %.1f us with %dx%d split %d" % (k[0], k[1], *best[k]))
