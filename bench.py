@@ -40,42 +40,60 @@ def synth_batch(batch, seed, device, lr_rate=12000, hr_rate=48000):
     return lr.to(device), hr.to(device)
 
 
-class KernelTimer:
-    """HIP-event brackets around conv launches (the stream the kernels are launched on is torch's current
-    stream).  mode 'all': every conv launch; mode 'only': only launches of `target` (cheap, used in the timed
-    region)."""
+class HipEvents:
+    """Raw HIP events (ctypes on libamdhip64): the library records them on its launch stream right around the main
+    GEMM kernel of a conv call (mg_probe_arm), so the duration is the kernel's own, comparable with rocprofv3."""
 
-    def __init__(self, ops, target=None):
-        self.ops, self.target, self.open, self.records = ops, target, None, []
+    def __init__(self):
+        import ctypes
+        self.c = ctypes
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+
+    def new(self):
+        e = self.c.c_void_p()
+        assert self.hip.hipEventCreate(self.c.byref(e)) == 0
+        return e
+
+    def elapsed_s(self, e0, e1):
+        ms = self.c.c_float()
+        rc = self.hip.hipEventElapsedTime(self.c.byref(ms), e0, e1)
+        return ms.value * 1e-3 if rc == 0 else float("nan")
+
+
+class KernelTimer:
+    """Per-kernel GPU time of the conv launches.  mode 'all' (target None): every conv call, used on one warm-up step
+    to find the dominant kernel; with a target only that kernel's launches are probed (cheap)."""
+
+    def __init__(self, ops, lib, target=None):
+        self.ops, self.lib, self.target, self.records = ops, lib, target, []
+        self.ev = HipEvents()
         self.names = {}
 
     def begin(self, pass_id, g):
         key = (pass_id, g.B, g.H, g.W, g.Ci, g.Co, g.KH, g.stride, g.reflect)
-        name = self.names.get(key)
-        if name is None:
-            name = self.names[key] = self.ops.plan_name(pass_id, g)
-        if self.target is not None and name != self.target:
-            self.open = None
+        info = self.names.get(key)
+        if info is None:
+            info = self.names[key] = (self.ops.plan_name(pass_id, g), self.ops.plan_flops(pass_id, g), self.ops.conv_flops(g))
+        if self.target is not None and info[0] != self.target:
             return
-        e0 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        self.open = (name, self.ops.conv_flops(g), e0)
+        e0, e1 = self.ev.new(), self.ev.new()
+        self.lib.mg_probe_arm(e0, e1)
+        self.records.append(info + (e0, e1))
 
     def end(self):
-        if self.open is None:
-            return
-        e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
-        self.records.append(self.open + (e1,))
-        self.open = None
+        pass
 
     def summary(self):
         agg = {}
-        for name, flops, e0, e1 in self.records:
-            a = agg.setdefault(name, [0, 0.0, 0.0])
+        for name, kflops, cflops, e0, e1 in self.records:
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
             a[0] += 1
-            a[1] += flops
-            a[2] += e0.elapsed_time(e1) * 1e-3
+            a[1] += kflops
+            a[2] += self.ev.elapsed_s(e0, e1)
+            a[3] += cflops
         return agg
 
 
@@ -121,6 +139,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--force-ddp", action="store_true", help="run the data-parallel code path even with one rank (testing)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,8 +148,12 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
-    if world > 1:
+    use_ddp = world > 1 or args.force_ddp
+    if use_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group("nccl", device_id=torch.device(dev))
 
     from mdctgan_amd import ddp, ops, options
@@ -140,7 +163,7 @@ def main():
                            "--n_downsample_global", "4", "--n_blocks_global", "9", "--n_blocks_attn_g", "0",
                            "--num_D", "2", "--batchSize", str(BATCH), "--gpu_ids", str(local_rank))
     model = create_model(opt)
-    if world > 1:
+    if use_ddp:
         ddp.attach(model)
     lr, hr = synth_batch(BATCH, 42 + rank, dev)
 
@@ -150,16 +173,17 @@ def main():
         else:
             model.inference(lr)
     step = eager_step
-    use_graph = (not args.no_graph) and world == 1 and args.mode == "train"
+    use_graph = (not args.no_graph) and not use_ddp and args.mode == "train"
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
     # warm-up (eager); its last step times every conv launch with HIP events to find the dominant kernel
-    timer_all = KernelTimer(ops)
+    from mdctgan_amd import _lib as mglib
+    timer_all = KernelTimer(ops, mglib.load())
     nw = max(args.warmup, 2)
     for i in range(nw):
         if i == nw - 1 and not args.no_roofline:
@@ -171,7 +195,7 @@ def main():
     if not args.no_roofline:
         agg = timer_all.summary()
         dominant = max(agg, key=lambda k: agg[k][2]) if agg else None
-    timer = KernelTimer(ops, target=dominant) if dominant else None
+    timer = KernelTimer(ops, mglib.load(), target=dominant) if dominant else None
     if use_graph:
         graphed = model.make_graphed_step(lr, hr, warmup=2)   # whole G+D iteration as one hipGraph
         step = lambda: graphed()                                # noqa: E731  (inputs already in the captured buffers)
@@ -194,21 +218,24 @@ def main():
             eager_step()
         torch.cuda.synchronize()
         ops.PROFILER = None
-    if world > 1:
+    if use_ddp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     roofline = None
     if timer is not None and timer.records:
-        n, flops, secs = timer.summary()[dominant]
+        n, flops, secs, conv_flops = timer.summary()[dominant]
         achieved = flops / secs / 1e12
         roofline = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                     "launches": n, "avg_launch_us": round(secs / n * 1e6, 2),
                     "flops_per_launch": flops / n,
-                    "timed": ("HIP events around every launch of this kernel in %d eager iterations run right after "
-                              "the graph-replayed timed region" % args.steps) if use_graph else
+                    "flops_definition": "FLOPs the kernel itself issues (2*M*N*K of its GEMM).  A '..., 1>' kernel is the "
+                                        "batched Winograd F(2x2,3x3) GEMM of a 3x3 layer whose direct-convolution cost "
+                                        "(SURVEY 8d, 2*MACs) is %.3g FLOP per launch" % (conv_flops / n),
+                    "timed": ("HIP events recorded by the library on its launch stream right around this kernel, "
+                              "every launch of %d eager iterations run right after the graph-replayed timed region" % args.steps) if use_graph else
                              "HIP events around every launch of this kernel inside the timed region"}
         tr = os.path.join(REPO, "profiles", "traffic.json")     # HBM bytes/launch from rocprofv3 --pmc passes
         if os.path.exists(tr):
@@ -236,7 +263,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.mode == "train":
             out["cpu_baseline"] = cpu_baseline_train(os.cpu_count() or 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_ddp:
         dist.destroy_process_group()
 
 

@@ -108,6 +108,11 @@ size_t mg_conv_wgrad_workspace(const mg_conv_geom* g);
 /* Name of the kernel instance a pass (0 fwd, 1 dgrad, 2 wgrad) launches for this geometry -- the symbol
  * rocprofv3 reports -- so bench.py can attribute event-timed launches per kernel.  out: host buffer >= 64 B. */
 int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len);
+/* FLOPs issued by that kernel for this geometry (direct: 2*MACs; Winograd F(2x2,3x3) layers: the 16 batched GEMMs). */
+double mg_conv_plan_flops(int pass, const mg_conv_geom* g);
+/* One-shot timing probe for bench.py: the next mg_conv_{fwd,dgrad,wgrad} call records hipEvent e0 / e1 on its launch
+ * stream immediately around its main GEMM kernel (not around transforms / split-K epilogues), then disarms. */
+void mg_probe_arm(void* e0, void* e1);
 /* column sums: out[c] (+)= sum_m a[m, c]  -- bias gradients of ConvTranspose2d layers */
 int mg_colsum(const float* a, long long M, int C, float* out, int accumulate, void* workspace,
               size_t workspace_bytes, void* stream);

@@ -29,6 +29,11 @@ def plan_name(pass_id: int, g: ConvGeom) -> str:
     return buf.value.decode()
 
 
+def plan_flops(pass_id: int, g: ConvGeom) -> float:
+    """FLOPs the main GEMM kernel of this pass issues (Winograd layers: the 16 transformed-domain GEMMs)."""
+    return float(_lib.load().mg_conv_plan_flops(pass_id, g))
+
+
 def conv_flops(g: ConvGeom) -> float:
     """Algorithmic FLOPs of one pass (fwd == dgrad == wgrad): 2 * B*OH*OW * Co * KH*KW*Ci."""
     return 2.0 * g.B * g.OH * g.OW * g.Co * g.KH * g.KW * g.Ci
@@ -65,8 +70,12 @@ def conv_wgrad(g: ConvGeom, x, dy, dw, dbias=None, accumulate=False):
     lib = _lib.load()
     nbytes = lib.mg_conv_wgrad_workspace(g)
     ws = _ws(nbytes, x.device)
+    if PROFILER is not None:
+        PROFILER.begin(2, g)
     _lib.check(lib.mg_conv_wgrad(g, _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(dbias), int(accumulate),
                                  _lib.ptr(ws), ws.numel(), _lib.stream()), "mg_conv_wgrad")
+    if PROFILER is not None:
+        PROFILER.end()
 
 
 def colsum(a2d, out, accumulate=False):
