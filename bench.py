@@ -139,6 +139,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2],
+                    help="BASELINE.json configs index: 1 = netG global (the headline bench line); 2 = netG local + 2 "
+                         "bottleneck-attention blocks, num_D 3, run in float32 (the reference config adds --fp16)")
     ap.add_argument("--force-ddp", action="store_true", help="run the data-parallel code path even with one rank (testing)")
     args = ap.parse_args()
 
@@ -159,9 +162,19 @@ def main():
     from mdctgan_amd import ddp, ops, options
     from mdctgan_amd.pix2pixHD_model import create_model
     torch.manual_seed(42)
-    opt = options.make_opt(*options.SPECTRAL_FLAGS, "--lr_sampling_rate", "12000", "--netG", "global", "--ngf", "64",
-                           "--n_downsample_global", "4", "--n_blocks_global", "9", "--n_blocks_attn_g", "0",
-                           "--num_D", "2", "--batchSize", str(BATCH), "--gpu_ids", str(local_rank))
+    if args.config == 1:
+        net_flags = ["--netG", "global", "--ngf", "64", "--n_downsample_global", "4", "--n_blocks_global", "9",
+                     "--n_blocks_attn_g", "0", "--num_D", "2"]
+        workload = ("configs[1]: netG=global ngf=64 n_blocks_global=9 n_blocks_attn_g=0 num_D=2, per-GPU batch 8 x 32512 "
+                    "samples (128 frames x 256 bins), 12k->48k, fp32")
+    else:
+        net_flags = ["--netG", "local", "--ngf", "64", "--n_downsample_global", "4", "--n_blocks_global", "9",
+                     "--n_blocks_local", "3", "--n_blocks_attn_g", "2", "--heads_g", "8", "--dim_head_g", "64",
+                     "--num_D", "3"]
+        workload = ("configs[2] in FLOAT32 (the reference config adds --fp16): netG=local n_blocks_attn_g=2 heads_g=8 "
+                    "dim_head_g=64 num_D=3, per-GPU batch 8 x 32512 samples, 12k->48k")
+    opt = options.make_opt(*options.SPECTRAL_FLAGS, "--lr_sampling_rate", "12000", *net_flags,
+                           "--batchSize", str(BATCH), "--gpu_ids", str(local_rank))
     model = create_model(opt)
     if use_ddp:
         ddp.attach(model)
@@ -253,14 +266,13 @@ def main():
         out = {"metric": metric, "value": round(value, 4), "unit": unit, "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "configs[1]: netG=global ngf=64 n_blocks_global=9 n_blocks_attn_g=0 num_D=2, "
-                                      "per-GPU batch 8 x 32512 samples (128 frames x 256 bins), 12k->48k, fp32",
+               "config": {"workload": workload,
                           "global_batch": BATCH * world, "segment_length": T_SEG,
                           "parallelism": "dp%d" % world, "launch": "hipGraph replay" if use_graph else "eager",
                           "steps_counted": "one G+D optimisation step per GPU; value = "
                           "steps of per-GPU batch 8 completed per second summed over GPUs (weak scaling)"},
                "roofline": roofline}
-        if world == 1 and not args.no_cpu_baseline and args.mode == "train":
+        if world == 1 and not args.no_cpu_baseline and args.mode == "train" and args.config == 1:
             out["cpu_baseline"] = cpu_baseline_train(os.cpu_count() or 1)
         print(json.dumps(out), flush=True)
     if use_ddp:

@@ -130,6 +130,31 @@ int mg_instnorm_bwd(const float* dy, const float* x, const float* mean, const fl
                     int act, float* dx, void* workspace, size_t workspace_bytes, void* stream);
 size_t mg_instnorm_workspace(int B, int HW, int C);
 
+/* ------------------------------------------------------------------------------------------
+ * K10  bottleneck-transformer block pieces (bottleneck_transformer_pytorch==0.1.4 BottleStack, call sites
+ *      models/networks.py:232-235, 341-344; third-party, parity unpinned).  The block's 1x1 convolutions use
+ *      mg_conv_*.
+ *  BatchNorm2d over R = B*H*W rows of an NHWC tensor [R, C]:
+ *      training: batch statistics (biased var for normalisation, unbiased into running_var, momentum m);
+ *      eval: running statistics.  y = act(gamma * xhat + beta + residual)  (act in {NONE, RELU}; residual nullable).
+ */
+int mg_batchnorm_fwd(const float* x, int R, int C, float eps, float momentum, int training, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var, const float* residual, int act,
+                     float* y, float* save_mean, float* save_rstd, void* stream);
+int mg_batchnorm_bwd(const float* dy, const float* x, const float* y, int R, int C, const float* gamma,
+                     const float* mean, const float* rstd, int act, int training, float* dx, float* dresidual,
+                     float* dgamma, float* dbeta, int accumulate, void* stream);
+/*  Multi-head self attention with absolute position embeddings (rel_pos_emb=False):
+ *      qkv [B, fh*fw, 3*heads*d] (channel = which*heads*d + head*d + dd), emb_h [fh, d], emb_w [fw, d];
+ *      sim = (q * d^-0.5) (k + emb_h[y] + emb_w[x])^T, out [B, fh*fw, heads*d] = softmax(sim) v.
+ *      P [B, heads, n, n] receives the probabilities (saved for backward).  fh*fw <= 128, d <= 128. */
+int mg_attention_fwd(const float* qkv, const float* emb_h, const float* emb_w, int B, int fh, int fw, int heads, int d,
+                     float* out, float* P, void* stream);
+int mg_attention_bwd(const float* qkv, const float* emb_h, const float* emb_w, const float* dout, const float* P, int B,
+                     int fh, int fw, int heads, int d, float* dqkv, float* demb_h, float* demb_w, int accumulate,
+                     void* workspace, size_t workspace_bytes, void* stream);
+size_t mg_attention_bwd_workspace(int B, int fh, int fw, int heads, int d);
+
 /* K7  elementwise activation backward for conv epilogues: dx = dy * act'(y)  (in place allowed) */
 int mg_act_bwd(const float* dy, const float* y, float* dx, long long n, int act, void* stream);
 /* out = a + b (residual joins outside a norm), in place allowed */

@@ -49,6 +49,11 @@ SIGNATURES = {
     "mg_instnorm_fwd": (_i, [_p, _i, _i, _i, _f, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "mg_instnorm_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _sz, _p]),
     "mg_instnorm_workspace": (_sz, [_i, _i, _i]),
+    "mg_batchnorm_fwd": (_i, [_p, _i, _i, _f, _f, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
+    "mg_batchnorm_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _p, _i, _p]),
+    "mg_attention_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "mg_attention_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _sz, _p]),
+    "mg_attention_bwd_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "mg_act_bwd": (_i, [_p, _p, _p, _ll, _i, _p]),
     "mg_add": (_i, [_p, _p, _p, _ll, _p]),
     "mg_avgpool3s2_fwd": (_i, [_p, _i, _i, _i, _i, _p, _p]),

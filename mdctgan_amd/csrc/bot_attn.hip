@@ -1,0 +1,373 @@
+// K10: the bottleneck-transformer block pieces that are not 1x1 convolutions (those run on conv_igemm.hip):
+// BatchNorm2d (training statistics + running buffers, affine, fused ReLU / residual) and multi-head self
+// attention with absolute position embeddings, forward and backward, float32.
+//
+// Reference call sites: models/networks.py:232-235, 341-344 (BottleStack(..., downsample=False,
+// rel_pos_emb=False) from bottleneck_transformer_pytorch==0.1.4, a third-party package that is not vendored by the
+// reference; restated from its published algorithm -- parity UNPINNED):
+//     q, k, v = to_qkv(x).chunk(3);  q *= dim_head^-0.5
+//     sim = q k^T + q (h_emb (+) w_emb)^T  ==  q (k + e)^T ;  out = softmax(sim) v
+// Token counts are tiny (32 at 4x8, 128 at 8x16), so this is a latency-bound VALU kernel: one workgroup per
+// (sample, head) keeps K+E and V in LDS; the FLOPs are < 0.01 % of the step.
+#include "common.h"
+#include "mdctgan_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+    if (act == MG_ACT_RELU) return fmaxf(v, 0.0f);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// BatchNorm2d over rows = B*H*W of an NHWC tensor [R, C].  One block per 64 channels, 4 row groups.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ x, int R, int C, float eps,
+                                                     float momentum, int training, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ run_mean,
+                                                     float* __restrict__ run_var, const float* __restrict__ residual,
+                                                     int act, float* __restrict__ y, float* __restrict__ save_mean,
+                                                     float* __restrict__ save_rstd) {
+    __shared__ double red[2][4][64];
+    __shared__ float stat[2][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    if (training) {
+        double s1 = 0.0, s2 = 0.0;
+        if (c < C)
+            for (int r = rg; r < R; r += 4) {
+                const float v = x[(size_t)r * C + c];
+                s1 += (double)v;
+                s2 += (double)v * (double)v;
+            }
+        red[0][rg][cl] = s1;
+        red[1][rg][cl] = s2;
+        __syncthreads();
+        if (rg == 0 && c < C) {
+            const double a = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+            const double b = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+            const double mu = a / R;
+            double var = b / R - mu * mu;
+            if (var < 0.0) var = 0.0;
+            stat[0][cl] = (float)mu;
+            stat[1][cl] = (float)(1.0 / sqrt(var + (double)eps));
+            save_mean[c] = stat[0][cl];
+            save_rstd[c] = stat[1][cl];
+            if (run_mean) {   // nn.BatchNorm2d: running = (1-m) running + m batch (unbiased variance)
+                const double unb = (R > 1) ? var * R / (R - 1) : var;
+                run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)mu;
+                run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)unb;
+            }
+        }
+    } else if (rg == 0 && c < C) {
+        stat[0][cl] = run_mean[c];
+        stat[1][cl] = 1.0f / sqrtf(run_var[c] + eps);
+        if (save_mean) { save_mean[c] = stat[0][cl]; save_rstd[c] = stat[1][cl]; }
+    }
+    __syncthreads();
+    if (c >= C) return;
+    const float mu = stat[0][cl], rs = stat[1][cl], ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
+    for (int r = rg; r < R; r += 4) {
+        const size_t i = (size_t)r * C + c;
+        float z = ga * ((x[i] - mu) * rs) + be;
+        if (residual) z += residual[i];
+        y[i] = act_fwd(z, act);
+    }
+}
+
+// dy -> dx, dgamma, dbeta (+ dresidual = masked dy).  y is the forward output (ReLU mask).
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ y, int R, int C,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, int act, int training,
+                                                     float* __restrict__ dx, float* __restrict__ dres,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     int accumulate) {
+    __shared__ double red[2][4][64];
+    __shared__ float stat[2][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    const float mu = (c < C) ? mean[c] : 0.f, rs = (c < C) ? rstd[c] : 0.f, ga = (c < C && gamma) ? gamma[c] : 1.0f;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int r = rg; r < R; r += 4) {
+            const size_t i = (size_t)r * C + c;
+            float g = dy[i];
+            if (act == MG_ACT_RELU && !(y[i] > 0.0f)) g = 0.0f;
+            s1 += (double)g;
+            s2 += (double)g * (double)((x[i] - mu) * rs);
+        }
+    red[0][rg][cl] = s1;
+    red[1][rg][cl] = s2;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        const double a = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+        const double b = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
+        stat[0][cl] = (float)(a / R);
+        stat[1][cl] = (float)(b / R);
+    }
+    __syncthreads();
+    if (c >= C) return;
+    const float m1 = stat[0][cl], m2 = stat[1][cl];
+    for (int r = rg; r < R; r += 4) {
+        const size_t i = (size_t)r * C + c;
+        float g = dy[i];
+        if (act == MG_ACT_RELU && !(y[i] > 0.0f)) g = 0.0f;
+        if (dres) dres[i] = g;
+        const float xh = (x[i] - mu) * rs;
+        dx[i] = training ? rs * ga * (g - m1 - xh * m2) : rs * ga * g;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// attention.  qkv [B, n, 3*HD] (NHWC of the to_qkv conv, channel = which*HD + head*d + dd), n = fh*fw tokens.
+// One workgroup per (b, head).  LDS: KE [n][d+1] = k + (height[y] + width[x]), V [n][d+1], P row scratch.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ eh,
+                                                       const float* __restrict__ ew, int n, int fw, int heads, int d,
+                                                       float scale, float* __restrict__ out, float* __restrict__ P) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int ld = d + 1, HD = heads * d;
+    float* ke = sm;                 // [n][ld]
+    float* vv = ke + n * ld;        // [n][ld]
+    float* pr = vv + n * ld;        // [4 waves][n]  softmax row per wave
+    float* qs = pr + 4 * n;         // [4 waves][d]  scaled query per wave
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* base = qkv + (size_t)b * n * 3 * HD;
+    for (int i = threadIdx.x; i < n * d; i += 256) {
+        const int j = i / d, dd = i % d;
+        const float e = eh[(j / fw) * d + dd] + ew[(j % fw) * d + dd];
+        ke[j * ld + dd] = base[(size_t)j * 3 * HD + HD + h * d + dd] + e;
+        vv[j * ld + dd] = base[(size_t)j * 3 * HD + 2 * HD + h * d + dd];
+    }
+    __syncthreads();
+    for (int i = wave; i < n; i += 4) {              // query i handled by one wave
+        for (int dd = lane; dd < d; dd += 64) qs[wave * d + dd] = base[(size_t)i * 3 * HD + h * d + dd] * scale;
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        float s[2];                                   // keys lane, lane + 64
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int j = lane + 64 * t;
+            float a = -INFINITY;
+            if (j < n) {
+                a = 0.0f;
+                for (int dd = 0; dd < d; ++dd) a = fmaf(qs[wave * d + dd], ke[j * ld + dd], a);
+            }
+            s[t] = a;
+            mx = fmaxf(mx, a);
+        }
+        mx = wave_max(mx);
+        float sum = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            s[t] = (lane + 64 * t < n) ? expf(s[t] - mx) : 0.0f;
+            sum += s[t];
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int j = lane + 64 * t;
+            if (j < n) {
+                const float p = s[t] * inv;
+                pr[wave * n + j] = p;
+                P[(((size_t)b * heads + h) * n + i) * n + j] = p;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        for (int dd = lane; dd < d; dd += 64) {
+            float o = 0.0f;
+            for (int j = 0; j < n; ++j) o = fmaf(pr[wave * n + j], vv[j * ld + dd], o);
+            out[((size_t)b * n + i) * HD + h * d + dd] = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// backward, part A: dV = P^T dO, dS = P .* (dP - rowsum(P .* dP)), dP = dO V^T.  LDS: dO [n][ld], V [n][ld].
+__global__ __launch_bounds__(256) void attn_bwd_a_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                         const float* __restrict__ P, int n, int heads, int d,
+                                                         float* __restrict__ dqkv, float* __restrict__ dS) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int ld = d + 1, HD = heads * d;
+    float* dos = sm;               // [n][ld]
+    float* vv = dos + n * ld;      // [n][ld]
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* base = qkv + (size_t)b * n * 3 * HD;
+    const float* Pb = P + ((size_t)b * heads + h) * n * n;
+    float* dSb = dS + ((size_t)b * heads + h) * n * n;
+    for (int i = threadIdx.x; i < n * d; i += 256) {
+        const int j = i / d, dd = i % d;
+        dos[j * ld + dd] = dout[((size_t)b * n + j) * HD + h * d + dd];
+        vv[j * ld + dd] = base[(size_t)j * 3 * HD + 2 * HD + h * d + dd];
+    }
+    __syncthreads();
+    for (int i = wave; i < n; i += 4) {              // row i of dS
+        float dp[2], pv[2], dot = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int j = lane + 64 * t;
+            dp[t] = 0.0f;
+            pv[t] = 0.0f;
+            if (j < n) {
+                float a = 0.0f;
+                for (int dd = 0; dd < d; ++dd) a = fmaf(dos[i * ld + dd], vv[j * ld + dd], a);
+                dp[t] = a;
+                pv[t] = Pb[(size_t)i * n + j];
+                dot += pv[t] * a;
+            }
+        }
+        dot = wave_sum(dot);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int j = lane + 64 * t;
+            if (j < n) dSb[(size_t)i * n + j] = pv[t] * (dp[t] - dot);
+        }
+    }
+    // dV[j][dd] = sum_i P[i][j] dO[i][dd]
+    for (int idx = threadIdx.x; idx < n * d; idx += 256) {
+        const int j = idx / d, dd = idx % d;
+        float a = 0.0f;
+        for (int i = 0; i < n; ++i) a = fmaf(Pb[(size_t)i * n + j], dos[i * ld + dd], a);
+        dqkv[((size_t)b * n + j) * 3 * HD + 2 * HD + h * d + dd] = a;
+    }
+}
+
+// backward, part B: dq = scale * dS KE, dKE = dS^T q' (q' = scale * q) -> dk, and the embedding gradient partials
+// dE[b, h][j][dd] = dKE (summed over (b, h) per (y | x) by a later pass).  LDS: KE [n][ld], Q' [n][ld].
+__global__ __launch_bounds__(256) void attn_bwd_b_kernel(const float* __restrict__ qkv, const float* __restrict__ eh,
+                                                         const float* __restrict__ ew, const float* __restrict__ dS,
+                                                         int n, int fw, int heads, int d, float scale,
+                                                         float* __restrict__ dqkv, float* __restrict__ dE) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int ld = d + 1, HD = heads * d;
+    float* ke = sm;
+    float* qq = ke + n * ld;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const float* base = qkv + (size_t)b * n * 3 * HD;
+    const float* dSb = dS + ((size_t)b * heads + h) * n * n;
+    for (int i = threadIdx.x; i < n * d; i += 256) {
+        const int j = i / d, dd = i % d;
+        const float e = eh[(j / fw) * d + dd] + ew[(j % fw) * d + dd];
+        ke[j * ld + dd] = base[(size_t)j * 3 * HD + HD + h * d + dd] + e;
+        qq[j * ld + dd] = base[(size_t)j * 3 * HD + h * d + dd] * scale;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < n * d; idx += 256) {
+        const int i = idx / d, dd = idx % d;
+        float aq = 0.0f, ak = 0.0f;
+        for (int j = 0; j < n; ++j) {
+            aq = fmaf(dSb[(size_t)i * n + j], ke[j * ld + dd], aq);      // dq'_i
+            ak = fmaf(dSb[(size_t)j * n + i], qq[j * ld + dd], ak);      // dKE_i = sum_j dS[j][i] q'_j
+        }
+        dqkv[((size_t)b * n + i) * 3 * HD + h * d + dd] = aq * scale;
+        dqkv[((size_t)b * n + i) * 3 * HD + HD + h * d + dd] = ak;
+        dE[(((size_t)b * heads + h) * n + i) * d + dd] = ak;
+    }
+}
+
+// d height[y][dd] = sum_{b,h,x} dE[b,h][(y,x)][dd];  d width[x][dd] = sum_{b,h,y} dE[...]
+__global__ void posemb_grad_kernel(const float* __restrict__ dE, int BH, int fh, int fw, int d,
+                                   float* __restrict__ dheight, float* __restrict__ dwidth, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = fh * fw;
+    if (i < fh * d) {
+        const int y = i / d, dd = i % d;
+        float a = 0.0f;
+        for (int bh = 0; bh < BH; ++bh)
+            for (int x = 0; x < fw; ++x) a += dE[((size_t)bh * n + y * fw + x) * d + dd];
+        dheight[i] = accumulate ? dheight[i] + a : a;
+    } else if (i < (fh + fw) * d) {
+        const int k = i - fh * d, x = k / d, dd = k % d;
+        float a = 0.0f;
+        for (int bh = 0; bh < BH; ++bh)
+            for (int y = 0; y < fh; ++y) a += dE[((size_t)bh * n + y * fw + x) * d + dd];
+        dwidth[k] = accumulate ? dwidth[k] + a : a;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mg_batchnorm_fwd(const float* x, int R, int C, float eps, float momentum, int training, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var, const float* residual, int act,
+                     float* y, float* save_mean, float* save_rstd, void* stream) {
+    if (!x || !y || R <= 0 || C <= 0) return MG_ERR_ARG;
+    if (training && (!save_mean || !save_rstd)) return MG_ERR_ARG;
+    if (!training && (!running_mean || !running_var)) return MG_ERR_ARG;
+    hipLaunchKernelGGL(bn_fwd_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, R, C, eps, momentum,
+                       training, gamma, beta, running_mean, running_var, residual, act, y, save_mean, save_rstd);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+int mg_batchnorm_bwd(const float* dy, const float* x, const float* y, int R, int C, const float* gamma,
+                     const float* mean, const float* rstd, int act, int training, float* dx, float* dresidual,
+                     float* dgamma, float* dbeta, int accumulate, void* stream) {
+    if (!dy || !x || !y || !mean || !rstd || !dx || R <= 0 || C <= 0) return MG_ERR_ARG;
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, dy, x, y, R, C, gamma,
+                       mean, rstd, act, training, dx, dresidual, dgamma, dbeta, accumulate);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+static size_t attn_lds(int n, int d, bool fwd) {
+    return ((size_t)2 * n * (d + 1) + (fwd ? 4 * n + 4 * d : 0)) * sizeof(float);
+}
+
+int mg_attention_fwd(const float* qkv, const float* emb_h, const float* emb_w, int B, int fh, int fw, int heads, int d,
+                     float* out, float* P, void* stream) {
+    const int n = fh * fw;
+    if (!qkv || !emb_h || !emb_w || !out || !P || B <= 0 || n <= 0 || n > 128 || d <= 0 || d > 128) return MG_ERR_ARG;
+    const size_t lds = attn_lds(n, d, true);
+    if (lds > 160 * 1024) return MG_ERR_UNSUPPORTED;
+    static size_t granted = 0;     // raised once, outside any graph capture (warm-up steps run first)
+    if (lds > 64 * 1024 && lds > granted) {
+        hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        granted = lds;
+    }
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, qkv, emb_h, emb_w, n, fw,
+                       heads, d, 1.0f / sqrtf((float)d), out, P);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+size_t mg_attention_bwd_workspace(int B, int fh, int fw, int heads, int d) {
+    const size_t n = (size_t)fh * fw;
+    return ((size_t)B * heads * n * n + (size_t)B * heads * n * d) * sizeof(float) + 256;
+}
+
+int mg_attention_bwd(const float* qkv, const float* emb_h, const float* emb_w, const float* dout, const float* P, int B,
+                     int fh, int fw, int heads, int d, float* dqkv, float* demb_h, float* demb_w, int accumulate,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    const int n = fh * fw;
+    if (!qkv || !emb_h || !emb_w || !dout || !P || !dqkv || !workspace || n > 128 || d > 128) return MG_ERR_ARG;
+    if (workspace_bytes < mg_attention_bwd_workspace(B, fh, fw, heads, d)) return MG_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    float* dS = (float*)workspace;
+    float* dE = dS + (size_t)B * heads * n * n;
+    const size_t lds = attn_lds(n, d, false);
+    if (lds > 160 * 1024) return MG_ERR_UNSUPPORTED;
+    static size_t granted = 0;
+    if (lds > 64 * 1024 && lds > granted) {
+        hipFuncSetAttribute((const void*)attn_bwd_a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)attn_bwd_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        granted = lds;
+    }
+    hipLaunchKernelGGL(attn_bwd_a_kernel, dim3(B * heads), dim3(256), lds, st, qkv, dout, P, n, heads, d, dqkv, dS);
+    hipLaunchKernelGGL(attn_bwd_b_kernel, dim3(B * heads), dim3(256), lds, st, qkv, emb_h, emb_w, (const float*)dS, n, fw,
+                       heads, d, 1.0f / sqrtf((float)d), dqkv, dE);
+    if (demb_h && demb_w)
+        hipLaunchKernelGGL(posemb_grad_kernel, dim3(((fh + fw) * d + 255) / 256), dim3(256), 0, st, (const float*)dE,
+                           B * heads, fh, fw, d, demb_h, demb_w, accumulate);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+}  // extern "C"

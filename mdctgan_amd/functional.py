@@ -176,6 +176,81 @@ def instance_norm_act(x, act=ACT_NONE, residual=None, eps=1e-5):
     return _InstNormFn.apply(x, residual, act, eps)
 
 
+class _BatchNormFn(torch.autograd.Function):
+    """act(BatchNorm2d(x) + residual), training or eval statistics; gamma / beta gradients go straight to .grad."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, bn, act):
+        x = to_cl(x)
+        res = to_cl(residual) if residual is not None else None
+        training = bn.training or bn.running_mean is None
+        y, mean, rstd = ops.batchnorm_fwd(nhwc_view(x), gamma.detach(), beta.detach(), bn.running_mean, bn.running_var,
+                                          bn.eps, bn.momentum if bn.momentum is not None else 0.1, training,
+                                          nhwc_view(res) if res is not None else None, act)
+        if training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        y = nchw_view(y)
+        ctx.act, ctx.training, ctx.gamma, ctx.beta = act, training, gamma, beta
+        ctx.save_for_backward(x, y, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, mean, rstd = ctx.saved_tensors
+        gamma, beta = ctx.gamma, ctx.beta
+        gy = to_cl(gy)
+        gbuf = bbuf = None
+        acc = False
+        if gamma.requires_grad:
+            gbuf, acc = grad_buffer(gamma)
+            bbuf, acc2 = grad_buffer(beta)
+            assert acc == acc2
+        dx, dres = ops.batchnorm_bwd(nhwc_view(gy), nhwc_view(x), nhwc_view(y), gamma.detach(), mean, rstd, ctx.act,
+                                     ctx.training, gbuf, bbuf, acc, ctx.needs_input_grad[3])
+        if gamma.requires_grad:
+            _notify(gamma)
+            _notify(beta)
+        return nchw_view(dx), None, None, (nchw_view(dres) if dres is not None else None), None, None
+
+
+def batch_norm_act(x, bn, act=ACT_NONE, residual=None):
+    """act(bn(x) + residual) for an nn.BatchNorm2d module `bn` (its buffers are updated in training mode)."""
+    return _BatchNormFn.apply(x, bn.weight, bn.bias, residual, bn, act)
+
+
+class _AttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, emb_h, emb_w, heads, dim_head):
+        qkv = to_cl(qkv)
+        out, P = ops.attention_fwd(nhwc_view(qkv), emb_h.detach().contiguous(), emb_w.detach().contiguous(), heads, dim_head)
+        ctx.heads, ctx.d, ctx.eh, ctx.ew = heads, dim_head, emb_h, emb_w
+        ctx.save_for_backward(qkv, P)
+        return nchw_view(out)
+
+    @staticmethod
+    def backward(ctx, go):
+        qkv, P = ctx.saved_tensors
+        eh, ew = ctx.eh, ctx.ew
+        go = to_cl(go)
+        hbuf = wbuf = None
+        acc = False
+        if eh.requires_grad:
+            hbuf, acc = grad_buffer(eh)
+            wbuf, acc2 = grad_buffer(ew)
+            assert acc == acc2
+        dqkv = ops.attention_bwd(nhwc_view(qkv), eh.detach().contiguous(), ew.detach().contiguous(), nhwc_view(go), P,
+                                 ctx.heads, ctx.d, hbuf, wbuf, acc)
+        if eh.requires_grad:
+            _notify(eh)
+            _notify(ew)
+        return nchw_view(dqkv), None, None, None, None
+
+
+def bot_attention(qkv, emb_h, emb_w, heads, dim_head):
+    """Multi-head self attention of the bottleneck-transformer block on the to_qkv output (abs. position embeddings)."""
+    return _AttentionFn.apply(qkv, emb_h, emb_w, heads, dim_head)
+
+
 class _AddFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):

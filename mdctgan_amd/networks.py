@@ -125,7 +125,7 @@ class FusedSequence:
                     act = _act_code(mods[i])
                     i += 1
                 self.steps.append(("producer", m, reflect, norm, act, eps))
-            elif isinstance(m, (ResnetBlock, FusedModule)):
+            elif isinstance(m, (ResnetBlock, FusedModule, BottleStack)):
                 self.steps.append(("module", m))
             elif isinstance(m, nn.Sequential):
                 self.steps.append(("seq", FusedSequence(m)))
@@ -162,6 +162,99 @@ class FusedModule(nn.Module):
         if name not in cache:
             cache[name] = FusedSequence(modules)
         return cache[name]
+
+
+###############################################################################
+# Bottleneck-transformer stack (bottleneck_transformer_pytorch==0.1.4 BottleStack restated; same module tree /
+# state-dict keys: net.{b}.net.{0,7}.weight, net.{b}.net.{1,5,8}.*, net.{b}.net.3.to_qkv.weight,
+# net.{b}.net.3.pos_emb.{height,width}).  Third-party arithmetic, parity UNPINNED.
+###############################################################################
+class BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d executed by the HIP batch-norm kernel (training statistics + running buffers)."""
+
+    def forward(self, x, act: int = ACT_NONE, residual=None):
+        return Fh.batch_norm_act(x, self, act, residual)
+
+
+class AbsPosEmb(nn.Module):
+    def __init__(self, fmap_size, dim_head):
+        super().__init__()
+        height, width = fmap_size
+        scale = dim_head ** -0.5
+        self.height = nn.Parameter(torch.randn(height, dim_head) * scale)
+        self.width = nn.Parameter(torch.randn(width, dim_head) * scale)
+
+
+class Attention(nn.Module):
+    def __init__(self, *, dim, fmap_size, heads=4, dim_head=128, rel_pos_emb=False):
+        super().__init__()
+        if rel_pos_emb:
+            raise NotImplementedError("relative position embeddings (the reference always passes rel_pos_emb=False)")
+        self.heads, self.dim_head, self.scale = heads, dim_head, dim_head ** -0.5
+        self.fmap_size = tuple(fmap_size)
+        self.to_qkv = Conv2d(dim, heads * dim_head * 3, 1, bias=False)
+        self.pos_emb = AbsPosEmb(fmap_size, dim_head)
+
+    def forward(self, fmap, weight_grad=True):
+        assert tuple(fmap.shape[2:]) == self.fmap_size
+        qkv = self.to_qkv(fmap, weight_grad=weight_grad)
+        return Fh.bot_attention(qkv, self.pos_emb.height, self.pos_emb.width, self.heads, self.dim_head)
+
+
+class BottleBlock(nn.Module):
+    def __init__(self, *, dim, fmap_size, dim_out, proj_factor, downsample, heads=4, dim_head=128, rel_pos_emb=False,
+                 activation=None):
+        super().__init__()
+        if downsample:
+            raise NotImplementedError("BottleBlock(downsample=True) (the reference always passes downsample=False)")
+        if dim != dim_out:
+            self.shortcut = nn.Sequential(Conv2d(dim, dim_out, 1, bias=False), BatchNorm2d(dim_out), nn.ReLU())
+        else:
+            self.shortcut = nn.Identity()
+        attn_dim_in = dim_out // proj_factor
+        attn_dim_out = heads * dim_head
+        self.net = nn.Sequential(
+            Conv2d(dim, attn_dim_in, 1, bias=False), BatchNorm2d(attn_dim_in), nn.ReLU(),
+            Attention(dim=attn_dim_in, fmap_size=fmap_size, heads=heads, dim_head=dim_head, rel_pos_emb=rel_pos_emb),
+            nn.Identity(), BatchNorm2d(attn_dim_out), nn.ReLU(),
+            Conv2d(attn_dim_out, dim_out, 1, bias=False), BatchNorm2d(dim_out))
+        nn.init.zeros_(self.net[-1].weight)      # overwritten by weights_init, like in the reference (SURVEY 3.4)
+
+    def forward(self, x, weight_grad=True):
+        n = self.net
+        if isinstance(self.shortcut, nn.Identity):
+            shortcut = x
+        else:
+            shortcut = self.shortcut[1](self.shortcut[0](x, weight_grad=weight_grad), ACT_RELU)
+        h = n[1](n[0](x, weight_grad=weight_grad), ACT_RELU)
+        h = n[3](h, weight_grad=weight_grad)
+        h = n[5](h, ACT_RELU)
+        h = n[7](h, weight_grad=weight_grad)
+        return n[8](h, ACT_RELU, shortcut)           # relu(bn(h) + shortcut)
+
+
+class BottleStack(FusedModule):
+    def __init__(self, *, dim, fmap_size, dim_out=2048, proj_factor=4, num_layers=3, heads=4, dim_head=128,
+                 downsample=True, rel_pos_emb=False, activation=None):
+        super().__init__()
+        fmap_size = tuple(fmap_size) if isinstance(fmap_size, (tuple, list)) else (fmap_size, fmap_size)
+        self.dim, self.fmap_size = dim, fmap_size
+        if fmap_size[0] * fmap_size[1] > 128 or dim_head > 128:
+            raise NotImplementedError("HIP attention kernel covers <= 128 tokens and dim_head <= 128")
+        layers = []
+        for i in range(num_layers):
+            layers.append(BottleBlock(dim=(dim if i == 0 else dim_out), fmap_size=fmap_size, dim_out=dim_out,
+                                      proj_factor=proj_factor, heads=heads, dim_head=dim_head,
+                                      downsample=(i == 0 and downsample), rel_pos_emb=rel_pos_emb))
+        self.net = nn.Sequential(*layers)
+
+    def forward(self, x, weight_grad=True):
+        _, c, h, w = x.shape
+        assert c == self.dim, "channels of feature map must match channels given at init"
+        assert h == self.fmap_size[0] and w == self.fmap_size[1], "feature map size must match fmap_size at init"
+        for blk in self.net:
+            x = blk(x, weight_grad=weight_grad)
+        return x
 
 
 ###############################################################################
@@ -252,9 +345,13 @@ class GlobalGenerator(FusedModule):
         mult = 2 ** n_downsampling
         bottle_neck = [ResnetBlock(ngf * mult, padding_type=padding_type, activation=activation,
                                    norm_layer=norm_layer) for _ in range(n_blocks)]
-        if n_attn_g > 0:
-            raise NotImplementedError(
-                "bottleneck-transformer attention (n_blocks_attn_g > 0, kernel K10) is not built yet on the HIP path")
+        if n_attn_g > 0:     # networks.py:338-344
+            middle = n_blocks // 2
+            fmap = tuple(map(lambda x: x // mult, input_size))
+            attn_block = BottleStack(dim=ngf * mult, fmap_size=fmap, dim_out=ngf * mult, num_layers=n_attn_g,
+                                     proj_factor=proj_factor_g, downsample=False, heads=heads_g, dim_head=dim_head_g,
+                                     activation=activation, rel_pos_emb=False)
+            bottle_neck.insert(middle, attn_block)
         model += bottle_neck
         for i in range(n_downsampling):
             mult = 2 ** (n_downsampling - i)

@@ -228,3 +228,52 @@ def adam_step_dev(p, g, m, v, state, beta1, beta2, eps, grad_scale=1.0):
     lib = _lib.load()
     _lib.check(lib.mg_adam_step_dev(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), p.numel(), _lib.ptr(state),
                                     beta1, beta2, eps, grad_scale, _lib.stream()), "mg_adam_step_dev")
+
+
+def batchnorm_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, training, residual=None, act=ACT_NONE):
+    """x [B, H, W, C] NHWC -> (y, save_mean [C], save_rstd [C])."""
+    lib = _lib.load()
+    Cc = x.shape[-1]
+    R = x.numel() // Cc
+    y = torch.empty_like(x)
+    mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    _lib.check(lib.mg_batchnorm_fwd(_lib.ptr(x), R, Cc, eps, momentum, int(training), _lib.ptr(gamma), _lib.ptr(beta),
+                                    _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(residual), act, _lib.ptr(y),
+                                    _lib.ptr(mean), _lib.ptr(rstd), _lib.stream()), "mg_batchnorm_fwd")
+    return y, mean, rstd
+
+
+def batchnorm_bwd(dy, x, y, gamma, mean, rstd, act, training, dgamma, dbeta, accumulate, want_dres):
+    lib = _lib.load()
+    Cc = x.shape[-1]
+    R = x.numel() // Cc
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    _lib.check(lib.mg_batchnorm_bwd(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), R, Cc, _lib.ptr(gamma), _lib.ptr(mean),
+                                    _lib.ptr(rstd), act, int(training), _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dgamma),
+                                    _lib.ptr(dbeta), int(accumulate), _lib.stream()), "mg_batchnorm_bwd")
+    return dx, dres
+
+
+def attention_fwd(qkv, emb_h, emb_w, heads, d):
+    """qkv [B, fh, fw, 3*heads*d] NHWC -> (out [B, fh, fw, heads*d], P [B, heads, n, n])."""
+    lib = _lib.load()
+    B, fh, fw, _ = qkv.shape
+    n = fh * fw
+    out = torch.empty(B, fh, fw, heads * d, dtype=torch.float32, device=qkv.device)
+    P = torch.empty(B, heads, n, n, dtype=torch.float32, device=qkv.device)
+    _lib.check(lib.mg_attention_fwd(_lib.ptr(qkv), _lib.ptr(emb_h), _lib.ptr(emb_w), B, fh, fw, heads, d, _lib.ptr(out),
+                                    _lib.ptr(P), _lib.stream()), "mg_attention_fwd")
+    return out, P
+
+
+def attention_bwd(qkv, emb_h, emb_w, dout, P, heads, d, demb_h, demb_w, accumulate):
+    lib = _lib.load()
+    B, fh, fw, _ = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    ws = _ws(lib.mg_attention_bwd_workspace(B, fh, fw, heads, d), qkv.device)
+    _lib.check(lib.mg_attention_bwd(_lib.ptr(qkv), _lib.ptr(emb_h), _lib.ptr(emb_w), _lib.ptr(dout), _lib.ptr(P), B, fh,
+                                    fw, heads, d, _lib.ptr(dqkv), _lib.ptr(demb_h), _lib.ptr(demb_w), int(accumulate),
+                                    _lib.ptr(ws), ws.numel(), _lib.stream()), "mg_attention_bwd")
+    return dqkv

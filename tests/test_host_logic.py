@@ -75,8 +75,8 @@ def test_weights_init_statistics():
 
 
 def test_unsupported_configs_fail_loudly():
-    with pytest.raises(NotImplementedError):
-        networks.define_G(2, 1, 8, "global", 3, 2, n_attn_g=1, input_size=(32, 256))
+    with pytest.raises(NotImplementedError):      # 16 x 32 = 512 tokens > 128
+        networks.define_G(2, 1, 8, "global", 1, 2, n_attn_g=1, input_size=(32, 64))
     with pytest.raises(NotImplementedError):
         networks.get_norm_layer("batch")
     with pytest.raises(NotImplementedError):
@@ -107,3 +107,13 @@ def test_arena_view_roundtrip():
     assert v.shape == p.shape and v.stride() == p.stride()
     b = torch.empty(7)
     assert _arena_view(flat, 8, b).shape == (7,)
+
+
+def test_bot_state_dict_contract(golden):
+    """local + bottleneck-attention generator: identical keys / shapes to the reference tree (captured with the oracle's
+    BottleStack stand-in; numerics of that third-party block are unpinned)."""
+    g = golden("g7_local_bot_keys")
+    net = networks.define_G(2, 1, 8, "local", 3, 2, 1, 1, "instance", input_size=(64, 256), n_attn_g=2, heads_g=2,
+                            dim_head_g=16, proj_factor_g=4)
+    assert list(net.state_dict().keys()) == list(g["keys"])
+    assert [str(tuple(p.shape)) for p in net.state_dict().values()] == list(g["shapes"])
