@@ -679,9 +679,10 @@ __global__ void splitk_epilogue_kernel(const float* __restrict__ part, int S, si
     }
 }
 
-// column sums of a [M, C] matrix: stage 1 -> partial [S][C], stage 2 = splitk_reduce_kernel
+// column sums of a [M, C] matrix.  part[blockIdx.y][c] = sum over this block's row slice; with final != 0 (single
+// slice) the result goes straight to out[c] (+= when accumulate).
 __global__ void colsum_partial_kernel(const float* __restrict__ a, long long M, int C, long long rows_per_split,
-                                      float* __restrict__ part) {
+                                      float* __restrict__ part, int final, int accumulate) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
     const long long m_begin = (long long)blockIdx.y * rows_per_split;
@@ -691,9 +692,11 @@ __global__ void colsum_partial_kernel(const float* __restrict__ a, long long M, 
         for (long long m = m_begin + rg; m < m_end; m += 4) s += a[m * C + c];
     red[rg][threadIdx.x & 63] = s;
     __syncthreads();
-    if (rg == 0 && c < C)
-        part[(size_t)blockIdx.y * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
-                                           red[3][threadIdx.x];
+    if (rg == 0 && c < C) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (final) part[c] = accumulate ? part[c] + v : v;
+        else part[(size_t)blockIdx.y * C + c] = v;
+    }
 }
 
 }  // namespace
@@ -726,6 +729,7 @@ inline void probe_end(hipStream_t st) {
 
 struct ColsumPlan { int splits; long long rows_per_split; };
 ColsumPlan colsum_plan(long long M, int C) {
+    if (M <= 256) return {1, M};                  // one launch: each block walks all rows of its 64 columns
     const int cb = (C + 63) / 64;
     long long splits = (1024 + cb - 1) / cb;
     if (splits > 256) splits = 256;
@@ -1200,13 +1204,14 @@ int mg_colsum(const float* a, long long M, int C, float* out, int accumulate, vo
     hipStream_t st = (hipStream_t)stream;
     const ColsumPlan p = colsum_plan(M, C);
     float* part = (float*)workspace;                 // [splits][C]
-    float* fin = part + (size_t)p.splits * C;        // [C]: second pass over the partial rows (parallel, not serial)
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, p.splits), dim3(256), 0, st, a, M, C,
-                       p.rows_per_split, part);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, 1), dim3(256), 0, st, (const float*)part,
-                       (long long)p.splits, C, (long long)p.splits, fin);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((C / 4 + 255) / 256 + 1), dim3(256), 0, st, (const float*)fin, 1,
-                       (size_t)C, out, accumulate);
+    if (p.splits == 1) {
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, 1), dim3(256), 0, st, a, M, C, M, out, 1, accumulate);
+    } else {
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, p.splits), dim3(256), 0, st, a, M, C,
+                           p.rows_per_split, part, 0, 0);
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, 1), dim3(256), 0, st, (const float*)part,
+                           (long long)p.splits, C, (long long)p.splits, out, 1, accumulate);
+    }
     MG_CHECK_LAUNCH();
     return MG_OK;
 }
