@@ -100,6 +100,17 @@ size_t mg_conv_fwd_workspace(const mg_conv_geom* g);
 int mg_conv_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
                   void* workspace, size_t workspace_bytes, void* stream);
 size_t mg_conv_dgrad_workspace(const mg_conv_geom* g);
+/* 3x3 stride-1 pad-1 layers with channel counts that are multiples of 16 run as Winograd F(2x2,3x3): 16 batched
+ * GEMMs over transformed weights U = G w G^T.  A caller that runs forward and data gradient with the same w can
+ * transform once: mg_conv_wino_weights_bytes() is the size of U (0: the geometry is not a Winograd layer),
+ * mg_conv_wino_prepare() fills it, and the _u entry points take it (u == NULL: transform internally).
+ * u must have been prepared from the w passed in the same call. */
+size_t mg_conv_wino_weights_bytes(const mg_conv_geom* g);
+int mg_conv_wino_prepare(const mg_conv_geom* g, const float* w, float* u, void* stream);
+int mg_conv_fwd_u(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
+                  void* workspace, size_t workspace_bytes, void* stream, const float* u);
+int mg_conv_dgrad_u(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
+                    void* workspace, size_t workspace_bytes, void* stream, const float* u);
 /* dw [Co, KH, KW, Ci] = sum over pixels; dbias [Co] (nullable) = column sums of dy.
  * accumulate != 0 adds into dw / dbias instead of overwriting.  workspace: mg_conv_wgrad_workspace() bytes. */
 int mg_conv_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias, int accumulate,

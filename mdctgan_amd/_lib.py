@@ -37,6 +37,10 @@ SIGNATURES = {
     "mg_imdct4_forward": (_i, [_p, _i, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _p, _p, _p, _i, _i, _p, _p]),
     "mg_conv_fwd": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p]),
     "mg_conv_fwd_workspace": (_sz, [_G]),
+    "mg_conv_wino_weights_bytes": (_sz, [_G]),
+    "mg_conv_wino_prepare": (_i, [_G, _p, _p, _p]),
+    "mg_conv_fwd_u": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p, _p]),
+    "mg_conv_dgrad_u": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p, _p]),
     "mg_conv_dgrad": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p]),
     "mg_conv_dgrad_workspace": (_sz, [_G]),
     "mg_conv_wgrad": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p]),

@@ -276,6 +276,175 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geom g, const float* __re
 }
 
 // ================================================================================================
+// FWD, 32-deep chunks, row-major LDS images ("full-line staging").
+// Both operands of the forward GEMM are k-contiguous in HBM (NHWC activations, OHWI weights, and the Winograd
+// V/U matrices), so a chunk of 32 k is one full 128-byte line per row: a wave-wide global_load_dwordx4 covers
+// 8 rows x 128 B instead of 16 rows x 64 B (half the texture-addresser work for the same bytes), the stage is one
+// ds_write_b128 per 16 bytes instead of four ds_write_b32, and a lane fetches 4 consecutive k of its row with one
+// ds_read_b128.  The MFMA k index inside a chunk is free as long as A and B agree: lane half `kh` owns
+// k = 8*s + 4*kh + j for MFMA (s, j).  Row pitch 36 floats: 16-byte aligned rows, conflict-free for both the
+// 8-lanes-per-row writes and the 32-rows-at-one-k reads.
+// ================================================================================================
+constexpr int BK2 = 32, LDK2 = BK2 + 4;
+
+template <int MB, int NB, typename F0, typename F1>
+__device__ __forceinline__ void mma_chunk32(const float* Ap, const float* Bp, f32x16 (&acc)[MB][NB], int wm0, int wn0,
+                                            int lane, F0&& after_s0, F1&& after_s1) {
+    const int r = lane & 31, kh = lane >> 5;
+    const float* ap = Ap + (wm0 + r) * LDK2 + 4 * kh;
+    const float* bp = Bp + (wn0 + r) * LDK2 + 4 * kh;
+    constexpr int NS = BK2 / 8;
+    float4 a[2][MB], b[2][NB];
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi) a[0][mi] = ld4(ap + 32 * mi * LDK2);
+#pragma unroll
+    for (int ni = 0; ni < NB; ++ni) b[0][ni] = ld4(bp + 32 * ni * LDK2);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        if (s + 1 < NS) {
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi) a[nxt][mi] = ld4(ap + 32 * mi * LDK2 + 8 * (s + 1));
+#pragma unroll
+            for (int ni = 0; ni < NB; ++ni) b[nxt][ni] = ld4(bp + 32 * ni * LDK2 + 8 * (s + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NB; ++ni) {
+                acc[mi][ni] = mfma32x32x2(a[cur][mi].x, b[cur][ni].x, acc[mi][ni]);
+                acc[mi][ni] = mfma32x32x2(a[cur][mi].y, b[cur][ni].y, acc[mi][ni]);
+                acc[mi][ni] = mfma32x32x2(a[cur][mi].z, b[cur][ni].z, acc[mi][ni]);
+                acc[mi][ni] = mfma32x32x2(a[cur][mi].w, b[cur][ni].w, acc[mi][ni]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s == 0) after_s0();
+        if (s == 1) after_s1();
+        if (s <= 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int BM, int BN, int TAG = 0>
+__global__ __launch_bounds__(256) void conv_fwd32_kernel(Geom g, const float* __restrict__ x,
+                                                         const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         int act, int chunks_per_split, float* __restrict__ part,
+                                                         Batch bt) {
+    constexpr int MB = BM / 64, NB = BN / 64;
+    constexpr int NVA = BM / 32, NVB = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem32[];
+    auto As = [&](int buf) -> float* { return smem32 + buf * (BM * LDK2); };
+    auto Bs = [&](int buf) -> float* { return smem32 + 2 * BM * LDK2 + buf * (BN * LDK2); };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = g.B * g.OH * g.OW, N = g.Co, K = g.KH * g.KW * g.Ci;
+    x += (size_t)blockIdx.z * bt.sa;
+    w += (size_t)blockIdx.z * bt.sw;
+    y += (size_t)blockIdx.z * bt.so;
+    if (part) part += ((size_t)blockIdx.y * gridDim.z + blockIdx.z) * ((size_t)M * N);
+    const int cpt = g.Ci / BK2;
+    const int total_chunks = g.KH * g.KW * cpt;
+    const int c_begin = blockIdx.y * chunks_per_split;
+    const int nchunks = min(total_chunks, c_begin + chunks_per_split);
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int m0 = (t % tiles_m) * BM, n0 = (t / tiles_m) * BN;
+    const int q = tid & 7, r0 = tid >> 3;
+
+    int iy0[NVA], ix0[NVA], pb[NVA];
+    bool va_ok[NVA];
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        va_ok[i] = m < M;
+        const int mm = va_ok[i] ? m : 0;
+        const int b = mm / (g.OH * g.OW), rem = mm - b * (g.OH * g.OW);
+        const int oy = rem / g.OW, ox = rem - oy * g.OW;
+        iy0[i] = oy * g.s - g.p;
+        ix0[i] = ox * g.s - g.p;
+        pb[i] = b * g.H * g.W;
+    }
+    const float* wrow[NVB];
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        wrow[i] = (n < N) ? w + (size_t)n * K + 4 * q : nullptr;
+    }
+
+    auto load_a = [&](int c, float4 (&va)[NVA]) {
+        const int tap = c / cpt, ci0 = (c - tap * cpt) * BK2;
+        const int ky = tap / g.KW, kx = tap - ky * g.KW;
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+            va[i] = zero4();
+            if (!va_ok[i]) continue;
+            int iy = iy0[i] + ky, ix = ix0[i] + kx;
+            if (g.reflect) {
+                iy = reflect_idx(iy, g.H);
+                ix = reflect_idx(ix, g.W);
+            } else if (iy < 0 || iy >= g.H || ix < 0 || ix >= g.W) {
+                continue;
+            }
+            va[i] = ld4(x + (size_t)(pb[i] + iy * g.W + ix) * g.Ci + ci0 + 4 * q);
+        }
+    };
+    auto load_b = [&](int c, float4 (&vb)[NVB]) {
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) vb[i] = wrow[i] ? ld4(wrow[i] + (size_t)c * BK2) : zero4();
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = f32x16{0};
+    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+
+    float4 va[NVA], vb[NVB];
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) *reinterpret_cast<float4*>(As(buf) + (r0 + 32 * i) * LDK2 + 4 * q) = va[i];
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) *reinterpret_cast<float4*>(Bs(buf) + (r0 + 32 * i) * LDK2 + 4 * q) = vb[i];
+    };
+    if (c_begin < nchunks) {
+        load_a(c_begin, va);
+        load_b(c_begin, vb);
+        stash(0);
+    }
+    __syncthreads();
+    if (c_begin + 1 < nchunks) {
+        load_a(c_begin + 1, va);
+        load_b(c_begin + 1, vb);
+    }
+    for (int c = c_begin; c < nchunks; ++c) {
+        const int cur = (c - c_begin) & 1;
+        mma_chunk32<MB, NB>(
+            As(cur), Bs(cur), acc, wm0, wn0, lane,
+            [&]() { if (c + 1 < nchunks) stash(cur ^ 1); },
+            [&]() { if (c + 2 < nchunks) { load_a(c + 2, va); load_b(c + 2, vb); } });
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni) {
+            const int col = n0 + wn0 + 32 * ni + (lane & 31);
+            const float bv = (bias && !part && col < N) ? bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm0 + 32 * mi + mfma32_row(r, lane);
+                if (row < M && col < N) {
+                    if (part) part[(size_t)row * N + col] = acc[mi][ni][r];
+                    else y[(size_t)row * N + col] = apply_act(acc[mi][ni][r] + bv, act);
+                }
+            }
+        }
+}
+
+// ================================================================================================
 // DGRAD (== transposed convolution forward).  blockIdx.z = output-parity class (stride^2 of them).
 // ================================================================================================
 template <int BM, int BN, bool VECA, bool VECB, int TAG = 0>
@@ -727,6 +896,22 @@ inline void probe_end(hipStream_t st) {
     g_probe_e0 = g_probe_e1 = nullptr;
 }
 
+
+// The 32-deep forward kernel needs dynamic LDS above the 64 KB static limit for its 128x128 tile.
+inline bool fwd32_enabled() { static const bool off = getenv("MG_NO_BK32") != nullptr; return !off; }
+template <int BM_, int BN_, int TAG_>
+void launch_fwd32(dim3 grid, hipStream_t st, const Geom& gg, const float* x, const float* w, const float* bias, float* y,
+                  int act, int cps32, float* part, const Batch& bt) {
+    constexpr size_t lds = (size_t)2 * (BM_ + BN_) * LDK2 * sizeof(float);
+    static bool once = false;
+    if (!once) {
+        hipFuncSetAttribute((const void*)conv_fwd32_kernel<BM_, BN_, TAG_>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+        once = true;
+    }
+    hipLaunchKernelGGL((conv_fwd32_kernel<BM_, BN_, TAG_>), grid, dim3(256), lds, st, gg, x, w, bias, y, act, cps32, part,
+                       bt);
+}
 struct ColsumPlan { int splits; long long rows_per_split; };
 ColsumPlan colsum_plan(long long M, int C) {
     if (M <= 256) return {1, M};                  // one launch: each block walks all rows of its 64 columns
@@ -743,8 +928,9 @@ ColsumPlan colsum_plan(long long M, int C) {
 // tile / split selection shared by the launchers and mg_conv_plan_name().  A pass needs >= ~2 workgroups per CU
 // (256 CUs) to hide its own global-load latency behind other workgroups' MFMAs; deep-K, small-M*N layers (the
 // 1024-channel 8x16 bottleneck: 64 tiles of 128x128) get there by splitting K across blockIdx.y.
-struct TilePlan { int bm, bn, splits, cps; };
-TilePlan gemm_plan(long long M, int N, int chunks, int classes, bool can_split) {
+struct TilePlan { int bm, bn, splits, cps; bool k32; };
+// pass: 0 = forward-kernel GEMM (k-contiguous operands, may use the 32-deep kernel), 1 = data-gradient kernel
+TilePlan gemm_plan(long long M, int N, int chunks, int classes, bool can_split, int pass) {
     // Cost model in units of one 32x32x2 MFMA (64 cycles): a workgroup's 4 waves own the CU's 4 SIMDs, so the
     // workgroups mapped to one CU serialise on the MFMA pipe; a lone workgroup per CU cannot hide its own staging;
     // split-K pays one extra pass over (splits + 1) output-sized slabs at ~4 TB/s.
@@ -753,40 +939,41 @@ TilePlan gemm_plan(long long M, int N, int chunks, int classes, bool can_split) 
         if (sscanf(f, "%d,%d,%d", &bm, &bn, &sp) == 3 && sp >= 1) {
             if (!can_split || chunks / sp < 1) sp = 1;
             const int cps = (chunks + sp - 1) / sp;
-            return {bm, bn, (chunks + cps - 1) / cps, cps};
+            return {bm, bn, (chunks + cps - 1) / cps, cps, pass == 0};
         }
     }
     // Plans measured on MI355X for the layer shapes of BASELINE configs[1] at batch 8 (scripts/tune_conv.py sweeps
     // tile x split with MG_FORCE_PLAN and keeps the fastest); anything else falls through to the cost model.
-    struct Tuned { long long M; int N, chunks, classes, bm, bn, sp; };
+    struct Tuned { int pass; long long M; int N, chunks, classes, bm, bn, sp, k32; };
     static const Tuned tuned[] = {
-        {256, 1024, 64, 16, 128, 128, 2},     // Winograd forward GEMMs, 1024-channel 8x16 ResNet blocks
-        {360, 1024, 64, 16, 128, 64, 1},      // Winograd data-gradient GEMMs (reflection: 10x18 padded domain)
-        {1024, 1024, 288, 1, 128, 128, 12},   // 512->1024 stride-2 forward (and the 1024->512 ConvTranspose backward)
-        {4096, 512, 144, 1, 128, 128, 4},     // 256->512
-        {16384, 256, 72, 1, 128, 64, 3},      // 128->256
-        {65536, 128, 36, 1, 128, 128, 1},     // 64->128
-        {4896, 512, 256, 1, 128, 64, 4},      // D 256->512 4x4 s1 forward
-        {4488, 256, 128, 1, 64, 64, 6},       // D 128->256 4x4 s2 forward
-        {17160, 128, 64, 1, 64, 64, 3},       // D 64->128 4x4 s2 forward
-        {4488, 256, 512, 1, 64, 64, 8},       // D 256->512 4x4 s1 data gradient
-        {1024, 512, 576, 4, 64, 64, 1},       // stride-2 data gradients / ConvTranspose forwards (4 parity classes)
-        {4096, 256, 288, 4, 64, 64, 1},
-        {16384, 128, 144, 4, 64, 64, 1},
-        {65536, 64, 72, 4, 128, 64, 1},
-        {4488, 128, 256, 4, 64, 64, 1},
-        {17160, 64, 128, 4, 64, 64, 1},
+        {0, 256, 1024, 64, 16, 64, 64, 1, 1},      // Winograd forward GEMMs, 1024-channel 8x16 ResNet blocks
+        {1, 360, 1024, 64, 16, 128, 128, 2, 0},    // Winograd data-gradient GEMMs (reflection: 10x18 padded domain)
+        {0, 1024, 1024, 288, 1, 128, 128, 8, 1},   // 512->1024 stride-2 forward (and the 1024->512 ConvTranspose backward)
+        {0, 4096, 512, 144, 1, 128, 128, 4, 1},    // 256->512
+        {0, 16384, 256, 72, 1, 64, 64, 1, 1},      // 128->256
+        {0, 65536, 128, 36, 1, 128, 128, 1, 1},    // 64->128
+        {0, 4896, 512, 256, 1, 128, 128, 3, 1},    // D 256->512 4x4 s1 forward
+        {0, 4488, 256, 128, 1, 64, 64, 6, 0},      // D 128->256 4x4 s2 forward
+        {0, 17160, 128, 64, 1, 64, 64, 3, 1},      // D 64->128 4x4 s2 forward
+        {1, 4488, 256, 512, 1, 64, 64, 8, 0},      // D 256->512 4x4 s1 data gradient
+        {1, 1024, 512, 576, 4, 64, 64, 1, 0},      // stride-2 data gradients / ConvTranspose forwards (4 parity classes)
+        {1, 4096, 256, 288, 4, 64, 64, 1, 0},
+        {1, 16384, 128, 144, 4, 64, 64, 1, 0},
+        {1, 65536, 64, 72, 4, 128, 64, 1, 0},
+        {1, 4488, 128, 256, 4, 64, 64, 1, 0},
+        {1, 17160, 64, 128, 4, 64, 64, 1, 0},
     };
     for (const Tuned& t : tuned)
-        if (t.M == M && t.N == N && t.chunks == chunks && t.classes == classes && (t.sp == 1 || can_split)) {
+        if (t.pass == pass && t.M == M && t.N == N && t.chunks == chunks && t.classes == classes &&
+            (t.sp == 1 || can_split)) {
             const int cps = (chunks + t.sp - 1) / t.sp;
-            return {t.bm, t.bn, (chunks + cps - 1) / cps, cps};
+            return {t.bm, t.bn, (chunks + cps - 1) / cps, cps, t.k32 != 0};
         }
     struct Cand { int bm, bn; };
     const Cand cands[3] = {{128, 128}, {128, 64}, {64, 64}};
     const int split_opts[9] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
     double best = 1e300;
-    TilePlan out{64, 64, 1, chunks};
+    TilePlan out{64, 64, 1, chunks, false};
     for (const Cand& c : cands) {
         if (c.bm == 128 && c.bn == 128 && (N < 96 || M < 96)) continue;
         if (c.bm == 128 && c.bn == 64 && M < 96) continue;
@@ -801,23 +988,26 @@ TilePlan gemm_plan(long long M, int N, int chunks, int classes, bool can_split) 
             double t = (double)((wgs + 255) / 256) * work;
             if (wgs < 2 * 256) t *= 1.25;
             if (spl > 1) t += (double)(spl + 1) * (double)M * N * classes * 4.0 / 4e12 / 29e-9 * 256.0 / 256.0;
-            if (t < best) { best = t; out = {c.bm, c.bn, spl, cps}; }
+            if (t < best) { best = t; out = {c.bm, c.bn, spl, cps, false}; }
         }
     }
     return out;
+}
+inline bool use_k32(const TilePlan& tp, int Ci) {
+    return tp.k32 && fwd32_enabled() && Ci % BK2 == 0 && (tp.splits == 1 || tp.cps % 2 == 0);
 }
 TilePlan fwd_plan(const mg_conv_geom* g) {
     const long long M = (long long)g->B * g->OH * g->OW;
     const bool vec = g->Ci % BK == 0;
     const int chunks = vec ? g->KH * g->KW * (g->Ci / BK) : (g->KH * g->KW * g->Ci + BK - 1) / BK;
-    return gemm_plan(M, g->Co, chunks, 1, g->Co % 4 == 0);
+    return gemm_plan(M, g->Co, chunks, 1, g->Co % 4 == 0, 0);
 }
 TilePlan dgrad_plan(const mg_conv_geom* g) {
     const int s = g->stride;
     const long long Mc = (long long)g->B * ((g->H + s - 1) / s) * ((g->W + s - 1) / s);
     const bool vec = g->Co % BK == 0;
     const int chunks = vec ? g->KH * g->KW * (g->Co / BK) : (g->KH * g->KW * g->Co + BK - 1) / BK;
-    return gemm_plan(Mc, g->Ci, chunks, s * s, s == 1 && g->Ci % 4 == 0);
+    return gemm_plan(Mc, g->Ci, chunks, s * s, s == 1 && g->Ci % 4 == 0, 1);
 }
 
 struct WgradPlan { bool big; int tiles; int splits; int cps; };
@@ -856,14 +1046,14 @@ inline size_t al256(size_t n) { return (n + 63) / 64 * 64; }   // in floats
 
 size_t wino_fwd_ws(const mg_conv_geom* g) {
     const WinoDims d = wino_dims(g);
-    const TilePlan tp = gemm_plan(d.T, g->Co, g->Ci / BK, 16, true);
+    const TilePlan tp = gemm_plan(d.T, g->Co, g->Ci / BK, 16, true, 0);
     return (al256((size_t)16 * g->Co * g->Ci) + al256((size_t)16 * d.T * g->Ci) + al256((size_t)16 * d.T * g->Co) +
             (tp.splits > 1 ? al256((size_t)tp.splits * 16 * d.T * g->Co) : 0)) * sizeof(float) + 256;
 }
 size_t wino_dgrad_ws(const mg_conv_geom* g) {
     const WinoDims d = wino_dims(g);
     const long long T = g->reflect ? d.Tp : d.T;
-    const TilePlan tp = gemm_plan(T, g->Ci, g->Co / BK, 16, true);
+    const TilePlan tp = gemm_plan(T, g->Ci, g->Co / BK, 16, true, 1);
     return (al256((size_t)16 * g->Co * g->Ci) + al256((size_t)16 * T * g->Co) + al256((size_t)16 * T * g->Ci) +
             (g->reflect ? al256((size_t)g->B * (g->H + 2) * (g->W + 2) * g->Ci) : 0) +
             (tp.splits > 1 ? al256((size_t)tp.splits * 16 * T * g->Ci) : 0)) * sizeof(float) + 256;
@@ -899,26 +1089,32 @@ int wino_launch_tiles(const TilePlan& tp, Launch&& launch) {
 }
 
 int wino_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act, float* ws,
-             hipStream_t st) {
+             hipStream_t st, const float* u_pre) {
     const WinoDims d = wino_dims(g);
     float* U = ws;
     float* V = U + al256((size_t)16 * g->Co * g->Ci);
     float* Mx = V + al256((size_t)16 * d.T * g->Ci);
     float* part = Mx + al256((size_t)16 * d.T * g->Co);
-    hipLaunchKernelGGL(wino_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 4)), dim3(256), 0, st, w, g->Co,
-                       g->Ci, U);
+    if (u_pre) U = const_cast<float*>(u_pre);
+    else hipLaunchKernelGGL(wino_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 4)), dim3(256), 0, st, w,
+                            g->Co, g->Ci, U);
     hipLaunchKernelGGL(wino_input_xform_kernel, dim3(wino_grid((size_t)d.T * g->Ci / 4)), dim3(256), 0, st, x, g->B, g->H,
                        g->W, g->Ci, d.TH, d.TW, 1, g->reflect, V);
     const Geom gg{1, 1, (int)d.T, g->Ci, 1, (int)d.T, g->Co, 1, 1, 1, 0, 0};
-    const TilePlan tp = gemm_plan(d.T, g->Co, g->Ci / BK, 16, true);
+    const TilePlan tp = gemm_plan(d.T, g->Co, g->Ci / BK, 16, true, 0);
     float* pp = tp.splits > 1 ? part : nullptr;
     const Batch bt{d.T * g->Ci, (long long)g->Co * g->Ci, d.T * g->Co, 0};
     probe_begin(st);
+    const bool k32 = use_k32(tp, g->Ci);
     wino_launch_tiles(tp, [&](auto bm, auto bn) {
         constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value;
         dim3 grid((unsigned)(((d.T + BM_ - 1) / BM_) * ((g->Co + BN_ - 1) / BN_)), tp.splits, 16);
-        hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, true, 1>), grid, dim3(256), 0, st, gg, (const float*)V,
-                           (const float*)U, (const float*)nullptr, Mx, MG_ACT_NONE, tp.cps, pp, bt);
+        if (k32)
+            launch_fwd32<BM_, BN_, 1>(grid, st, gg, V, U, nullptr, Mx, MG_ACT_NONE, tp.splits == 1 ? (1 << 29) : tp.cps / 2,
+                                      pp, bt);
+        else
+            hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, true, 1>), grid, dim3(256), 0, st, gg, (const float*)V,
+                               (const float*)U, (const float*)nullptr, Mx, MG_ACT_NONE, tp.cps, pp, bt);
     });
     probe_end(st);
     if (pp) {
@@ -933,7 +1129,7 @@ int wino_fwd(const mg_conv_geom* g, const float* x, const float* w, const float*
 }
 
 int wino_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act, float* ws,
-               hipStream_t st) {
+               hipStream_t st, const float* u_pre) {
     const WinoDims d = wino_dims(g);
     const long long T = g->reflect ? d.Tp : d.T;
     const int TH = g->reflect ? d.THp : d.TH, TW = g->reflect ? d.TWp : d.TW;
@@ -942,13 +1138,14 @@ int wino_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const flo
     float* Mx = V + al256((size_t)16 * T * g->Co);
     float* dxp = Mx + al256((size_t)16 * T * g->Ci);
     float* part = dxp + (g->reflect ? al256((size_t)g->B * (g->H + 2) * (g->W + 2) * g->Ci) : 0);
-    hipLaunchKernelGGL(wino_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 4)), dim3(256), 0, st, w, g->Co,
-                       g->Ci, U);
+    if (u_pre) U = const_cast<float*>(u_pre);
+    else hipLaunchKernelGGL(wino_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 4)), dim3(256), 0, st, w,
+                            g->Co, g->Ci, U);
     // dy is [B, OH, OW, Co] with OH == H, OW == W; "full" (origin -2, zero) for reflect, "same" (origin -1) otherwise
     hipLaunchKernelGGL(wino_input_xform_kernel, dim3(wino_grid((size_t)T * g->Co / 4)), dim3(256), 0, st, dy, g->B, g->H,
                        g->W, g->Co, TH, TW, g->reflect ? 2 : 1, 0, V);
     const Geom gg{1, 1, (int)T, g->Ci, 1, (int)T, g->Co, 1, 1, 1, 0, 0};
-    const TilePlan tp = gemm_plan(T, g->Ci, g->Co / BK, 16, true);
+    const TilePlan tp = gemm_plan(T, g->Ci, g->Co / BK, 16, true, 1);
     float* pp = tp.splits > 1 ? part : nullptr;
     const Batch bt{T * g->Co, (long long)g->Co * g->Ci, T * g->Ci, 1};
     probe_begin(st);
@@ -1051,10 +1248,13 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
     if (wino_ok(g) && !kq) {
         const WinoDims d = wino_dims(g);
         if (pass == 0) {
-            const TilePlan tp = gemm_plan(d.T, g->Co, g->Ci / BK, 16, true);
-            snprintf(out, out_len, "conv_fwd_kernel<%d, %d, true, 1>", tp.bm, tp.bn);
+            const TilePlan tp = gemm_plan(d.T, g->Co, g->Ci / BK, 16, true, 0);
+            if (use_k32(tp, g->Ci))
+                snprintf(out, out_len, "conv_fwd32_kernel<%d, %d, 1>", tp.bm, tp.bn);
+            else
+                snprintf(out, out_len, "conv_fwd_kernel<%d, %d, true, 1>", tp.bm, tp.bn);
         } else if (pass == 1) {
-            const TilePlan tp = gemm_plan(g->reflect ? d.Tp : d.T, g->Ci, g->Co / BK, 16, true);
+            const TilePlan tp = gemm_plan(g->reflect ? d.Tp : d.T, g->Ci, g->Co / BK, 16, true, 1);
             snprintf(out, out_len, "conv_dgrad_kernel<%d, %d, true, true, 1>", tp.bm, tp.bn);
         } else {
             const WinoWgradPlan p = wino_wgrad_plan(g);
@@ -1066,7 +1266,10 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
         snprintf(out, out_len, "conv_rowdot_wgrad_kernel<%d>", kq);
     } else if (pass == 0) {
         const TilePlan tp = fwd_plan(g);
-        snprintf(out, out_len, "conv_fwd_kernel<%d, %d, %s, 0>", tp.bm, tp.bn, (g->Ci % BK == 0) ? "true" : "false");
+        if (use_k32(tp, g->Ci))
+            snprintf(out, out_len, "conv_fwd32_kernel<%d, %d, 0>", tp.bm, tp.bn);
+        else
+            snprintf(out, out_len, "conv_fwd_kernel<%d, %d, %s, 0>", tp.bm, tp.bn, (g->Ci % BK == 0) ? "true" : "false");
     } else if (pass == 1) {
         const TilePlan tp = dgrad_plan(g);
         snprintf(out, out_len, "conv_dgrad_kernel<%d, %d, %s, %s, 0>", tp.bm, tp.bn, (g->Co % BK == 0) ? "true" : "false",
@@ -1094,9 +1297,31 @@ size_t mg_conv_dgrad_workspace(const mg_conv_geom* g) {
     return tp.splits > 1 ? (size_t)tp.splits * g->B * g->H * g->W * g->Ci * sizeof(float) + 256 : 256;
 }
 
+size_t mg_conv_wino_weights_bytes(const mg_conv_geom* g) {
+    if (!geom_ok(g) || !wino_ok(g) || mg_conv_rowdot_kq(g)) return 0;
+    return (size_t)16 * g->Co * g->Ci * sizeof(float);
+}
+int mg_conv_wino_prepare(const mg_conv_geom* g, const float* w, float* u, void* stream) {
+    if (!mg_conv_wino_weights_bytes(g) || !w || !u || !aligned16(w) || !aligned16(u)) return MG_ERR_ARG;
+    hipLaunchKernelGGL(wino_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 4)), dim3(256), 0,
+                       (hipStream_t)stream, w, g->Co, g->Ci, u);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
 int mg_conv_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
                 void* workspace, size_t workspace_bytes, void* stream) {
+    return mg_conv_fwd_u(g, x, w, bias, y, act, workspace, workspace_bytes, stream, nullptr);
+}
+int mg_conv_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
+                  void* workspace, size_t workspace_bytes, void* stream) {
+    return mg_conv_dgrad_u(g, dy, w, bias, dx, act, workspace, workspace_bytes, stream, nullptr);
+}
+
+int mg_conv_fwd_u(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
+                  void* workspace, size_t workspace_bytes, void* stream, const float* u) {
     if (!geom_ok(g) || !x || !w || !y) return MG_ERR_ARG;
+    if (u && (!mg_conv_wino_weights_bytes(g) || !aligned16(u))) return MG_ERR_ARG;
     if (mg_conv_rowdot_kq(g) && aligned16(x) && aligned16(w)) {
         probe_begin((hipStream_t)stream);
         const int rc = mg_conv_rowdot_fwd(g, x, w, bias, y, act, stream);
@@ -1105,7 +1330,7 @@ int mg_conv_fwd(const mg_conv_geom* g, const float* x, const float* w, const flo
     }
     if (wino_ok(g) && workspace && workspace_bytes >= wino_fwd_ws(g) && aligned16(x) && aligned16(w) && aligned16(y) &&
         aligned16(workspace) && (!bias || aligned16(bias)))
-        return wino_fwd(g, x, w, bias, y, act, (float*)workspace, (hipStream_t)stream);
+        return wino_fwd(g, x, w, bias, y, act, (float*)workspace, (hipStream_t)stream, u);
     const Geom gg = to_geom(g);
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)g->B * g->OH * g->OW;
@@ -1118,10 +1343,12 @@ int mg_conv_fwd(const mg_conv_geom* g, const float* x, const float* w, const flo
         tp.cps = 1 << 30;
     }
     float* part = tp.splits > 1 ? (float*)workspace : nullptr;
+    const bool k32 = vec && use_k32(tp, g->Ci);
 #define MG_LAUNCH_FWD(BM_, BN_)                                                                                    \
     do {                                                                                                           \
         dim3 grid((unsigned)(((M + BM_ - 1) / BM_) * ((N + BN_ - 1) / BN_)), tp.splits);                           \
-        if (vec) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, true>), grid, dim3(256), 0, st, gg, x, w, bias, y, act, tp.cps, part, Batch{0, 0, 0, 0});  \
+        if (k32) launch_fwd32<BM_, BN_, 0>(grid, st, gg, x, w, bias, y, act, tp.splits == 1 ? (1 << 29) : tp.cps / 2, part, Batch{0, 0, 0, 0}); \
+        else if (vec) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, true>), grid, dim3(256), 0, st, gg, x, w, bias, y, act, tp.cps, part, Batch{0, 0, 0, 0});  \
         else hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, false>), grid, dim3(256), 0, st, gg, x, w, bias, y, act, tp.cps, part, Batch{0, 0, 0, 0});    \
     } while (0)
     probe_begin(st);
@@ -1141,13 +1368,14 @@ int mg_conv_fwd(const mg_conv_geom* g, const float* x, const float* w, const flo
     return MG_OK;
 }
 
-int mg_conv_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
-                  void* workspace, size_t workspace_bytes, void* stream) {
+int mg_conv_dgrad_u(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
+                    void* workspace, size_t workspace_bytes, void* stream, const float* u) {
     if (!geom_ok(g) || !dy || !w || !dx) return MG_ERR_ARG;
+    if (u && (!mg_conv_wino_weights_bytes(g) || !aligned16(u))) return MG_ERR_ARG;
     if (g->reflect && g->stride != 1) return MG_ERR_UNSUPPORTED;
     if (wino_ok(g) && !(g->reflect && (bias || act != MG_ACT_NONE)) && workspace && workspace_bytes >= wino_dgrad_ws(g) &&
         aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(workspace) && (!bias || aligned16(bias)))
-        return wino_dgrad(g, dy, w, bias, dx, act, (float*)workspace, (hipStream_t)stream);
+        return wino_dgrad(g, dy, w, bias, dx, act, (float*)workspace, (hipStream_t)stream, u);
     const Geom gg = to_geom(g);
     hipStream_t st = (hipStream_t)stream;
     const int s = g->stride;

@@ -6,6 +6,7 @@
 // :650-666; the residual add :462; nn.AvgPool2d(3,2,1,count_include_pad=False) :249-250, :525-526;
 // interpolate(nearest, x2) :396; cat(lr, s, 2|s|+nr0) pix2pixHD_model.py:420-424; MSELoss / L1Loss
 // networks.py:127-137, pix2pixHD_model.py:443-451; torch.optim.Adam pix2pixHD_model.py:350-364.
+#include <cstdlib>
 #include "common.h"
 #include "mdctgan_hip.h"
 
@@ -169,6 +170,161 @@ __global__ void norm_apply_bwd_kernel(const float* __restrict__ dy, const float*
         if (VEC) *reinterpret_cast<float4*>(dx + i) = *reinterpret_cast<float4*>(o);
         else dx[i] = o[0];
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Single-launch InstanceNorm for small maps (HW <= 32 * NP): one workgroup owns a (sample, 32-channel) slab
+// (HW x 128 B, coalesced as 8 pixels x 128 B per wave load), keeps it in registers, reduces the statistics
+// through LDS in double precision, and applies the normalisation without re-reading HBM.  Replaces the
+// partial / finalize / apply sequence (3 launches, 2 reads) for the 8x16 ... 18x34 maps where those launches
+// are pure latency.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void slab_reduce(double s1[4], double s2[4], double (*red)[32][32], int cq, int pl,
+                                            double* o1, double* o2) {
+    // red[0/1][pixel-lane][channel]; then 32 threads... every thread ends with the totals of its 4 channels
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[0][pl][4 * cq + j] = s1[j];
+        red[1][pl][4 * cq + j] = s2[j];
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 31, part = threadIdx.x >> 5;   // 8 parts x 4 pixel-lanes
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a += red[0][4 * part + i][c];
+        b += red[1][4 * part + i][c];
+    }
+    __syncthreads();
+    red[0][part][c] = a;
+    red[1][part][c] = b;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double x = 0.0, y = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            x += red[0][i][4 * cq + j];
+            y += red[1][i][4 * cq + j];
+        }
+        o1[j] = x;
+        o2[j] = y;
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void norm_slab_fwd_kernel(const float* __restrict__ x, int HW, int C, float eps,
+                                                            int act, const float* __restrict__ residual,
+                                                            float* __restrict__ y, float* __restrict__ mean,
+                                                            float* __restrict__ rstd) {
+    __shared__ double red[2][32][32];
+    const int cq = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int b = blockIdx.y, c0 = blockIdx.x * 32 + 4 * cq;
+    const size_t base = (size_t)b * HW * C + c0;
+    float4 v[NP];
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int p = pl + 32 * i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < HW) {
+            v[i] = *reinterpret_cast<const float4*>(x + base + (size_t)p * C);
+            s1[0] += (double)v[i].x; s2[0] += (double)v[i].x * (double)v[i].x;
+            s1[1] += (double)v[i].y; s2[1] += (double)v[i].y * (double)v[i].y;
+            s1[2] += (double)v[i].z; s2[2] += (double)v[i].z * (double)v[i].z;
+            s1[3] += (double)v[i].w; s2[3] += (double)v[i].w * (double)v[i].w;
+        }
+    }
+    double t1[4], t2[4];
+    slab_reduce(s1, s2, red, cq, pl, t1, t2);
+    float mu[4], rs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double m = t1[j] / HW;
+        double var = t2[j] / HW - m * m;
+        if (var < 0.0) var = 0.0;
+        mu[j] = (float)m;
+        rs[j] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    if (pl == 0) {
+        *reinterpret_cast<float4*>(mean + b * C + c0) = make_float4(mu[0], mu[1], mu[2], mu[3]);
+        *reinterpret_cast<float4*>(rstd + b * C + c0) = make_float4(rs[0], rs[1], rs[2], rs[3]);
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int p = pl + 32 * i;
+        if (p < HW) {
+            float4 o;
+            o.x = act_fwd((v[i].x - mu[0]) * rs[0], act);
+            o.y = act_fwd((v[i].y - mu[1]) * rs[1], act);
+            o.z = act_fwd((v[i].z - mu[2]) * rs[2], act);
+            o.w = act_fwd((v[i].w - mu[3]) * rs[3], act);
+            if (residual) {
+                const float4 r = *reinterpret_cast<const float4*>(residual + base + (size_t)p * C);
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            *reinterpret_cast<float4*>(y + base + (size_t)p * C) = o;
+        }
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void norm_slab_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, int HW, int C, int act,
+                                                            float* __restrict__ dx) {
+    __shared__ double red[2][32][32];
+    const int cq = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int b = blockIdx.y, c0 = blockIdx.x * 32 + 4 * cq;
+    const size_t base = (size_t)b * HW * C + c0;
+    const float4 mu4 = *reinterpret_cast<const float4*>(mean + b * C + c0);
+    const float4 rs4 = *reinterpret_cast<const float4*>(rstd + b * C + c0);
+    const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, rs[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
+    float xh[NP][4], gq[NP][4];
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int p = pl + 32 * i;
+        if (p < HW) {
+            float xv[4], gv[4];
+            *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + base + (size_t)p * C);
+            *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(dy + base + (size_t)p * C);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xh[i][j] = (xv[j] - mu[j]) * rs[j];
+                gq[i][j] = gv[j] * act_grad_pre(xh[i][j], act);
+                s1[j] += (double)gq[i][j];
+                s2[j] += (double)gq[i][j] * (double)xh[i][j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xh[i][j] = gq[i][j] = 0.f;
+        }
+    }
+    double t1[4], t2[4];
+    slab_reduce(s1, s2, red, cq, pl, t1, t2);
+    float m1[4], m2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        m1[j] = (float)(t1[j] / HW);
+        m2[j] = (float)(t2[j] / HW);
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int p = pl + 32 * i;
+        if (p < HW) {
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = rs[j] * (gq[i][j] - m1[j] - xh[i][j] * m2[j]);
+            *reinterpret_cast<float4*>(dx + base + (size_t)p * C) = *reinterpret_cast<float4*>(o);
+        }
+    }
+}
+
+inline int slab_np(int HW, int C) {     // 0: not eligible
+    static const bool off = getenv("MG_NO_NORM_SLAB") != nullptr;
+    if (off || C % 32 != 0 || HW > 640) return 0;
+    return HW <= 128 ? 4 : HW <= 256 ? 8 : HW <= 512 ? 16 : 20;
 }
 
 __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
@@ -386,6 +542,14 @@ int mg_instnorm_fwd(const float* x, int B, int HW, int C, float eps, int act, co
     if (!x || !y || !mean || !rstd || !workspace || B <= 0 || HW <= 0 || C <= 0) return MG_ERR_ARG;
     if (workspace_bytes < mg_instnorm_workspace(B, HW, C)) return MG_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (const int np = slab_np(HW, C); np && al16(x) && al16(y) && al16(mean) && al16(rstd) && (!residual || al16(residual))) {
+        const dim3 grid(C / 32, B);
+#define MG_SLAB_FWD(NP_) hipLaunchKernelGGL(norm_slab_fwd_kernel<NP_>, grid, dim3(256), 0, st, x, HW, C, eps, act, residual, y, mean, rstd)
+        if (np == 4) MG_SLAB_FWD(4); else if (np == 8) MG_SLAB_FWD(8); else if (np == 16) MG_SLAB_FWD(16); else MG_SLAB_FWD(20);
+#undef MG_SLAB_FWD
+        MG_CHECK_LAUNCH();
+        return MG_OK;
+    }
     const NormPlan p = norm_plan(B, HW, C);
     double* part = (double*)workspace;
     hipLaunchKernelGGL(norm_partial_kernel<0>, dim3(p.cblocks, B, p.splits), dim3(256), 0, st, x, nullptr, nullptr,
@@ -409,6 +573,14 @@ int mg_instnorm_bwd(const float* dy, const float* x, const float* mean, const fl
     if (!dy || !x || !mean || !rstd || !dx || !workspace || B <= 0 || HW <= 0 || C <= 0) return MG_ERR_ARG;
     if (workspace_bytes < mg_instnorm_workspace(B, HW, C)) return MG_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (const int np = slab_np(HW, C); np && al16(x) && al16(dy) && al16(dx) && al16(mean) && al16(rstd)) {
+        const dim3 grid(C / 32, B);
+#define MG_SLAB_BWD(NP_) hipLaunchKernelGGL(norm_slab_bwd_kernel<NP_>, grid, dim3(256), 0, st, dy, x, mean, rstd, HW, C, act, dx)
+        if (np == 4) MG_SLAB_BWD(4); else if (np == 8) MG_SLAB_BWD(8); else if (np == 16) MG_SLAB_BWD(16); else MG_SLAB_BWD(20);
+#undef MG_SLAB_BWD
+        MG_CHECK_LAUNCH();
+        return MG_OK;
+    }
     const NormPlan p = norm_plan(B, HW, C);
     double* part = (double*)workspace;
     float* m1 = (float*)((char*)workspace + (size_t)B * p.splits * C * 2 * sizeof(double));

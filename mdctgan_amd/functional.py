@@ -9,6 +9,8 @@ a parameter's gradient buffer already holds this step's first contribution.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -52,6 +54,27 @@ def mark_fresh(params):
         p._mg_fresh = True
 
 
+# A bias added right before InstanceNorm2d(affine=False) is removed again by the mean subtraction: its gradient is
+# identically zero (the reference's autograd produces float32 rounding residue there, ~1e-8 of the layer's gradient
+# scale, which no two implementations reproduce).  Such parameters get an exactly-zero gradient without a launch.
+# MDCTGAN_DEAD_BIAS_GRADS=1 computes the column sums anyway.
+COMPUTE_DEAD_BIAS_GRADS = os.environ.get("MDCTGAN_DEAD_BIAS_GRADS", "0") == "1"
+
+
+def mark_bias_feeds_norm(bias):
+    if bias is not None:
+        bias._mg_zero_grad = True
+
+
+def _zero_grad_bias(bias):
+    if bias.grad is None:
+        bias.grad = torch.zeros_like(bias)
+    elif getattr(bias, "_mg_fresh", True) and not getattr(bias, "_mg_known_zero", False):
+        bias.grad.zero_()                 # a buffer someone else may have written: clear it once
+    bias._mg_known_zero = True
+    bias._mg_fresh = False
+
+
 _grad_hooks = []
 
 
@@ -90,7 +113,10 @@ class _ConvFn(torch.autograd.Function):
             Co, Ci = w.shape[0], w.shape[1]
             assert Ci == x.shape[1]
             g = ops.conv_geom(B, H, W, Ci, Co, KH, KW, stride, pad, reflect)
-            y = ops.conv_fwd(g, nhwc_view(x), w, b, act)
+            # Winograd layers: transform the weights once, reuse the image for the data gradient of this step
+            u = ops.wino_weights(g, w) if ctx.needs_input_grad[0] else None
+            y = ops.conv_fwd(g, nhwc_view(x), w, b, act, u)
+            ctx.u = u
         else:
             # nn.ConvTranspose2d(k, stride, pad, output_padding = stride - 1): the data gradient of the conv
             # high-res [B, sH, sW, Cout_T] -> low-res [B, H, W, Cin_T]
@@ -117,14 +143,18 @@ class _ConvFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             if not transposed:
-                dx = nchw_view(ops.conv_dgrad(g, nhwc_view(gy), w))
+                dx = nchw_view(ops.conv_dgrad(g, nhwc_view(gy), w, u=getattr(ctx, "u", None)))
+                ctx.u = None
             else:
                 dx = nchw_view(ops.conv_fwd(g, nhwc_view(gy), w))
         if weight_grad and weight.requires_grad:
             wbuf, wacc = grad_buffer(weight)
             bbuf = bacc = None
             if bias is not None and bias.requires_grad:
-                bbuf, bacc = grad_buffer(bias)
+                if getattr(bias, "_mg_zero_grad", False) and not COMPUTE_DEAD_BIAS_GRADS:
+                    _zero_grad_bias(bias)
+                else:
+                    bbuf, bacc = grad_buffer(bias)
             if not transposed:
                 if bbuf is not None and bacc != wacc:      # keep one accumulate flag per launch
                     ops.colsum(nhwc_view(gy).reshape(-1, g.Co), bbuf, bacc)

@@ -119,6 +119,8 @@ class FusedSequence:
                         raise NotImplementedError("InstanceNorm2d(affine / running stats)")
                     norm, eps = True, n.eps
                     i += 1
+                    if isinstance(m, (Conv2d, ConvTranspose2d)):
+                        Fh.mark_bias_feeds_norm(m.bias)
                 else:
                     eps = 1e-5
                 if i < len(mods) and _act_code(mods[i]) is not None:
@@ -270,6 +272,8 @@ class ResnetBlock(nn.Module):
         self.conv_block = nn.Sequential(
             nn.ReflectionPad2d(1), Conv2d(dim, dim, kernel_size=3, padding=0), norm_layer(dim), activation,
             nn.ReflectionPad2d(1), Conv2d(dim, dim, kernel_size=3, padding=0), norm_layer(dim))
+        Fh.mark_bias_feeds_norm(self.conv_block[1].bias)
+        Fh.mark_bias_feeds_norm(self.conv_block[5].bias)
 
     def forward(self, x, weight_grad=True):
         cb = self.conv_block

@@ -39,27 +39,39 @@ def conv_flops(g: ConvGeom) -> float:
     return 2.0 * g.B * g.OH * g.OW * g.Co * g.KH * g.KW * g.Ci
 
 
-def conv_fwd(g: ConvGeom, x, w, bias=None, act=ACT_NONE):
+def wino_weights(g: ConvGeom, w):
+    """Transformed weights U = G w G^T of a Winograd layer (None when the geometry is not one): lets the forward
+    and the data-gradient pass of one step share a single weight transform."""
+    lib = _lib.load()
+    nbytes = lib.mg_conv_wino_weights_bytes(g)
+    if not nbytes:
+        return None
+    u = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+    _lib.check(lib.mg_conv_wino_prepare(g, _lib.ptr(w), _lib.ptr(u), _lib.stream()), "mg_conv_wino_prepare")
+    return u
+
+
+def conv_fwd(g: ConvGeom, x, w, bias=None, act=ACT_NONE, u=None):
     lib = _lib.load()
     y = torch.empty(g.B, g.OH, g.OW, g.Co, dtype=torch.float32, device=x.device)
     ws = _ws(lib.mg_conv_fwd_workspace(g), x.device)
     if PROFILER is not None:
         PROFILER.begin(0, g)
-    _lib.check(lib.mg_conv_fwd(g, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), act, _lib.ptr(ws),
-                               ws.numel(), _lib.stream()), "mg_conv_fwd")
+    _lib.check(lib.mg_conv_fwd_u(g, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), act, _lib.ptr(ws),
+                                 ws.numel(), _lib.stream(), _lib.ptr(u)), "mg_conv_fwd")
     if PROFILER is not None:
         PROFILER.end()
     return y
 
 
-def conv_dgrad(g: ConvGeom, dy, w, bias=None, act=ACT_NONE):
+def conv_dgrad(g: ConvGeom, dy, w, bias=None, act=ACT_NONE, u=None):
     lib = _lib.load()
     dx = torch.empty(g.B, g.H, g.W, g.Ci, dtype=torch.float32, device=dy.device)
     ws = _ws(lib.mg_conv_dgrad_workspace(g), dy.device)
     if PROFILER is not None:
         PROFILER.begin(1, g)
-    _lib.check(lib.mg_conv_dgrad(g, _lib.ptr(dy), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(dx), act, _lib.ptr(ws),
-                                 ws.numel(), _lib.stream()), "mg_conv_dgrad")
+    _lib.check(lib.mg_conv_dgrad_u(g, _lib.ptr(dy), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(dx), act, _lib.ptr(ws),
+                                   ws.numel(), _lib.stream(), _lib.ptr(u)), "mg_conv_dgrad")
     if PROFILER is not None:
         PROFILER.end()
     return dx

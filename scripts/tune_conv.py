@@ -4,8 +4,10 @@ import os, subprocess, sys, re
 shapes = sys.argv[1].split(",") if len(sys.argv) > 1 else ["bottleneck", "down512", "down256", "down128", "down64", "d256_512", "d128_256", "d64_128"]
 cfgs = [(bm, bn, sp) for (bm, bn) in ((128, 128), (128, 64), (64, 64)) for sp in (1, 2, 3, 4, 6, 8, 12)]
 best = {}
-for bm, bn, sp in cfgs:
+for bm, bn, sp, k32 in [(a, b, c, d) for (a, b, c) in cfgs for d in (1, 0)]:
     env = dict(os.environ, MG_FORCE_PLAN="%d,%d,%d" % (bm, bn, sp))
+    if not k32:
+        env["MG_NO_BK32"] = "1"
     out = subprocess.run([sys.executable, "scripts/bench_conv.py", "--only", ",".join(shapes), "--iters", "10"], env=env,
                          capture_output=True, text=True).stdout
     for line in out.splitlines():
@@ -16,7 +18,10 @@ for bm, bn, sp in cfgs:
         for ps, t in (("fwd", tf), ("dgrad", td)):
             k = (name, ps)
             if k not in best or t < best[k][0]:
-                best[k] = (t, bm, bn, sp)
-    print("done", bm, bn, sp, flush=True)
-for k in sorted(best):
-    print("%-12s %-6s best %.1f us with %dx%d split %d" % (k[0], k[1], *best[k]))
+                best[k] = (t, bm, bn, sp, k32)
+            best.setdefault((name, ps, "all"), []).append((t, bm, bn, sp, k32))
+    print("done", bm, bn, sp, k32, flush=True)
+for k in sorted(k for k in best if len(k) == 2):
+    print("%-12s %-6s best %.1f us with %dx%d split %d k32=%d" % (k[0], k[1], *best[k]))
+    top = sorted(best[(k[0], k[1], "all")])[:4]
+    print("    runners-up: " + "; ".join("%.1f us %dx%d s%d k32=%d" % t for t in top))

@@ -128,3 +128,22 @@ def test_conv_transpose(case):
     db = torch.empty(Cout, dtype=torch.float32, device=DEV)
     ops.colsum(gyd.reshape(-1, Cout), db)
     assert rel_err(db, b.grad) < 3e-5
+
+
+@pytest.mark.parametrize("reflect", [True, False])
+def test_winograd_shared_weight_transform(reflect):
+    """mg_conv_wino_prepare + the _u entry points: forward and data gradient with a caller-held transformed-weight
+    image give bit-identical results to the calls that transform internally; non-Winograd geometries report 0 bytes."""
+    from mdctgan_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    B, C, H, W = 2, 64, 8, 16
+    g = ops.conv_geom(B, H, W, C, C, 3, 3, 1, 1, reflect)
+    x = torch.randn(B, H, W, C, generator=gen).to(DEV)
+    dy = torch.randn(B, H, W, C, generator=gen).to(DEV)
+    w = (torch.randn(C, 3, 3, C, generator=gen) * 0.05).to(DEV)
+    u = ops.wino_weights(g, w)
+    assert u is not None and u.numel() == 16 * C * C
+    assert torch.equal(ops.conv_fwd(g, x, w, None, ops.ACT_NONE, u), ops.conv_fwd(g, x, w))
+    assert torch.equal(ops.conv_dgrad(g, dy, w, u=u), ops.conv_dgrad(g, dy, w))
+    g2 = ops.conv_geom(B, H, W, C, C, 3, 3, 2, 1, False)
+    assert ops.wino_weights(g2, w) is None

@@ -16,7 +16,10 @@ def rel_err(got, want):
     return (got.double().cpu() - want).abs().max().item() / max(want.abs().max().item(), 1e-30)
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 8, 16), (3, 5, 7, 9), (2, 64, 32, 64), (8, 256, 8, 16), (2, 1, 19, 35)])
+@pytest.mark.parametrize("shape", [(2, 16, 8, 16), (3, 5, 7, 9), (2, 64, 32, 64), (8, 256, 8, 16), (2, 1, 19, 35),
+                                   # single-launch slab kernels (C % 32 == 0, HW <= 640): every register depth, ragged HW
+                                   (2, 32, 9, 17), (1, 96, 16, 32), (2, 64, 17, 33), (2, 32, 18, 34), (1, 32, 20, 32),
+                                   (1, 32, 2, 3), (2, 32, 21, 31)])
 @pytest.mark.parametrize("act", ["none", "relu", "lrelu"])
 def test_instnorm_fwd_bwd(shape, act):
     from mdctgan_amd import ops
