@@ -130,18 +130,76 @@ def cpu_baseline_train(max_threads):
                       "{8,16,32} on batch-1 steps, host has %d cores" % (dt, max_threads)}
 
 
+def bench_codec(args, dev, rank, world):
+    """K1 + K2 alone (SURVEY 8d asks for them at a batch where HBM time is measurable): one step = to_spectro
+    (pad, frame, window, fold, 256-point DCT-IV on MFMA, arcsinh range-norm) + to_audio (denormalise, inverse DCT,
+    window, overlap-add) on --codec-batch clips of 32512 samples.  Algorithmic bytes per clip: K1 reads 130 048 B
+    and writes 131 072 B, K2 reads 131 072 B and writes 130 048 B (261 120 B each)."""
+    from mdctgan_amd import options
+    from mdctgan_amd.pix2pixHD_model import Audio2MDCT
+    opt = options.make_opt(*options.SPECTRAL_FLAGS, "--lr_sampling_rate", "12000", "--gpu_ids", str(rank))
+    codec = Audio2MDCT(opt)
+    B = args.codec_batch
+    g = torch.Generator().manual_seed(7)
+    x = (0.05 * torch.randn(B, T_SEG, generator=g)).to(dev)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+
+    def step(e=None):
+        with torch.no_grad():
+            if e:
+                e[0].record()
+            spec, pha, norm = codec.to_spectro(x)
+            if e:
+                e[1].record()
+            y = codec.to_audio(spec, norm, pha)
+            if e:
+                e[2].record()
+        return y
+    for _ in range(max(args.warmup, 2)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(ev[i])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    k1 = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps * 1e-3
+    k2 = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps * 1e-3
+    bytes_k = 261120.0 * B
+    out = {"metric": "codec clips/sec (MDCT4+norm, denorm+IMDCT4)", "value": round(world * args.steps * B / dt, 1),
+           "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "K1+K2 on %d clips x 32512 samples (128 frames x 256 bins), arcsinh codec" % B,
+                      "global_batch": B * world, "segment_length": T_SEG, "parallelism": "dp%d" % world},
+           "roofline": {"bound": "hbm", "kernel": "mdct4_kernel", "achieved": round(bytes_k / k1 / 1e9, 1), "peak": 8000.0,
+                        "unit": "GB/s", "frac": round(bytes_k / k1 / 8e12, 4), "traffic": None,
+                        "k1_ms": round(k1 * 1e3, 4), "k2_ms": round(k2 * 1e3, 4),
+                        "k2_achieved": round(bytes_k / k2 / 1e9, 1), "k2_frac": round(bytes_k / k2 / 8e12, 4),
+                        "bytes_per_clip": 261120,
+                        "mfma_tflops_k1": round(2.0 * 128 * 256 * 256 * B / k1 / 1e12, 2),
+                        "timed": "torch events on the launch stream around to_spectro / to_audio (each is one kernel "
+                                 "launch plus the output allocation)"}}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    ap.add_argument("--mode", default="train", choices=["train", "infer", "codec"],
+                    help="train: G+D step (the headline).  infer: generate_audio path (inference + segment stitching). "
+                         "codec: K1+K2 only (to_spectro + to_audio) on --codec-batch clips, reported against the HBM roofline")
+    ap.add_argument("--codec-batch", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
-    ap.add_argument("--config", type=int, default=1, choices=[1, 2],
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 4],
                     help="BASELINE.json configs index: 1 = netG global (the headline bench line); 2 = netG local + 2 "
-                         "bottleneck-attention blocks, num_D 3, run in float32 (the reference config adds --fp16)")
+                         "bottleneck-attention blocks, num_D 3, run in float32 (the reference config adds --fp16); "
+                         "4 = inference, 8k->48k, batch 64 (implies --mode infer)")
     ap.add_argument("--force-ddp", action="store_true", help="run the data-parallel code path even with one rank (testing)")
     args = ap.parse_args()
 
@@ -162,29 +220,39 @@ def main():
     from mdctgan_amd import ddp, ops, options
     from mdctgan_amd.pix2pixHD_model import create_model
     torch.manual_seed(42)
-    if args.config == 1:
+    if args.config == 4 and args.mode == "train":
+        args.mode = "infer"
+    batch = 64 if args.config == 4 else BATCH
+    lr_rate = 8000 if args.config == 4 else 12000
+    if args.mode == "codec":
+        return bench_codec(args, dev, rank, world)
+    if args.config in (1, 4):
         net_flags = ["--netG", "global", "--ngf", "64", "--n_downsample_global", "4", "--n_blocks_global", "9",
                      "--n_blocks_attn_g", "0", "--num_D", "2"]
         workload = ("configs[1]: netG=global ngf=64 n_blocks_global=9 n_blocks_attn_g=0 num_D=2, per-GPU batch 8 x 32512 "
                     "samples (128 frames x 256 bins), 12k->48k, fp32")
+        if args.config == 4:
+            workload = ("configs[4]: generate_audio path, netG=global ngf=64 n_blocks_global=9, 8k->48k, 64 segments x 32512 "
+                        "samples per step (model.inference + IMDCT overlap-add + segment stitching), fp32")
     else:
         net_flags = ["--netG", "local", "--ngf", "64", "--n_downsample_global", "4", "--n_blocks_global", "9",
                      "--n_blocks_local", "3", "--n_blocks_attn_g", "2", "--heads_g", "8", "--dim_head_g", "64",
                      "--num_D", "3"]
         workload = ("configs[2] in FLOAT32 (the reference config adds --fp16): netG=local n_blocks_attn_g=2 heads_g=8 "
                     "dim_head_g=64 num_D=3, per-GPU batch 8 x 32512 samples, 12k->48k")
-    opt = options.make_opt(*options.SPECTRAL_FLAGS, "--lr_sampling_rate", "12000", *net_flags,
-                           "--batchSize", str(BATCH), "--gpu_ids", str(local_rank))
+    opt = options.make_opt(*options.SPECTRAL_FLAGS, "--lr_sampling_rate", str(lr_rate), *net_flags,
+                           "--batchSize", str(batch), "--gpu_ids", str(local_rank))
     model = create_model(opt)
     if use_ddp:
         ddp.attach(model)
-    lr, hr = synth_batch(BATCH, 42 + rank, dev)
+    lr, hr = synth_batch(batch, 42 + rank, dev, lr_rate=lr_rate)
+    from mdctgan_amd.generate_audio import generate
 
     def eager_step():
         if args.mode == "train":
             model.optimize_parameters(lr, hr)
         else:
-            model.inference(lr)
+            generate(model, lr, batch_size=batch, gen_overlap=0)
     step = eager_step
     use_graph = (not args.no_graph) and not use_ddp and args.mode == "train"
 
@@ -262,15 +330,16 @@ def main():
         if args.mode == "train":
             metric, value, unit = "train steps/sec (G+D) VCTK 12k->48k", world * args.steps / dt, "steps/s"
         else:
-            metric, value, unit = "infer audio-sec/sec", world * args.steps * BATCH * T_SEG / 48000.0 / dt, "audio-s/s"
+            metric, value, unit = "infer audio-sec/sec", world * args.steps * batch * T_SEG / 48000.0 / dt, "audio-s/s"
         out = {"metric": metric, "value": round(value, 4), "unit": unit, "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": workload,
-                          "global_batch": BATCH * world, "segment_length": T_SEG,
+                          "global_batch": batch * world, "segment_length": T_SEG,
                           "parallelism": "dp%d" % world, "launch": "hipGraph replay" if use_graph else "eager",
-                          "steps_counted": "one G+D optimisation step per GPU; value = "
-                          "steps of per-GPU batch 8 completed per second summed over GPUs (weak scaling)"},
+                          "steps_counted": ("one G+D optimisation step per GPU; value = steps of per-GPU batch 8 completed "
+                                            "per second summed over GPUs (weak scaling)") if args.mode == "train" else
+                                           "one step = %d segments through inference + stitching per GPU" % batch},
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline and args.mode == "train" and args.config == 1:
             out["cpu_baseline"] = cpu_baseline_train(os.cpu_count() or 1)

@@ -76,6 +76,13 @@ int mg_imdct4_forward(const float* spec, int B, int F, int n_fft, const float* w
                       const float* min_b, const float* max_b, void* audio, int out_len, int out_f64,
                       float* frames_out, void* stream);
 
+/* Segment stitching of generate_audio.py:40-53: seg [n_seg, seg_len] (the [n_seg,1,1,T] inference outputs) -> one
+ * waveform of mg_stitch_length() samples (-1: invalid arguments; 2*overlap must be < seg_len).  overlap == 0
+ * concatenates; overlap > 0 halves the first/last `overlap` samples of every segment, overlap-adds at stride
+ * seg_len - overlap (F.fold) and crops `overlap` samples from both ends.  float32, or float64 when is_f64. */
+long long mg_stitch_length(int n_seg, int seg_len, int overlap);
+int mg_stitch_segments(const void* seg, int n_seg, int seg_len, int overlap, void* out, int is_f64, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * K3/K4/K6  Implicit-GEMM convolution on the f32 MFMA pipe (exact float32).
  *   Replaces nn.Conv2d / nn.ConvTranspose2d / nn.ReflectionPad2d forward and backward at

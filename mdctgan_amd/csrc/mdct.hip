@@ -261,6 +261,35 @@ __global__ __launch_bounds__(256) void imdct4_kernel(
     }
 }
 
+// generate_audio.py:40-53: segments [n_seg, L] -> one waveform.  overlap == 0: concatenation.  overlap > 0: the first
+// and last `overlap` samples of EVERY segment are halved, segments are overlap-added at stride L - overlap
+// (F.fold), and `overlap` samples are cropped from both ends.  Gather form: each output sample sums the (<= ceil(L /
+// stride)) segments that cover it in ascending segment order -- deterministic, no atomics.
+template <typename T>
+__global__ void stitch_kernel(const T* __restrict__ seg, int n_seg, int L, int overlap, T* __restrict__ out,
+                              long long out_len) {
+    const int stride = L - overlap;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < out_len;
+         o += (long long)gridDim.x * blockDim.x) {
+        if (overlap == 0) {
+            out[o] = seg[o];
+            continue;
+        }
+        const long long t = o + overlap;
+        long long i0 = (t - L + stride) / stride;      // ceil((t - L + 1) / stride)
+        if (t - L + 1 <= 0) i0 = 0;
+        long long i1 = t / stride;
+        if (i1 > n_seg - 1) i1 = n_seg - 1;
+        T acc = (T)0;
+        for (long long i = i0; i <= i1; ++i) {
+            const int k = (int)(t - i * stride);
+            const T v = seg[i * L + k];
+            acc += (k < overlap || k >= L - overlap) ? v * (T)0.5 : v;
+        }
+        out[o] = acc;
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -325,6 +354,26 @@ int mg_imdct4_forward(const float* spec, int B, int F, int n_fft, const float* w
     else
         hipLaunchKernelGGL(imdct4_kernel<float>, grid, dim3(256), lds, st, spec, F, window, dct4, cp,
                            (float*)audio, out_len, frames_out);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+long long mg_stitch_length(int n_seg, int seg_len, int overlap) {
+    if (n_seg <= 0 || seg_len <= 0 || overlap < 0 || 2 * overlap >= seg_len) return -1;
+    if (overlap == 0) return (long long)n_seg * seg_len;
+    return (long long)(n_seg - 1) * (seg_len - overlap) + seg_len - 2LL * overlap;
+}
+
+int mg_stitch_segments(const void* seg, int n_seg, int seg_len, int overlap, void* out, int is_f64, void* stream) {
+    const long long n = mg_stitch_length(n_seg, seg_len, overlap);
+    if (!seg || !out || n <= 0) return MG_ERR_ARG;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    if (is_f64)
+        hipLaunchKernelGGL(stitch_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)seg,
+                           n_seg, seg_len, overlap, (double*)out, n);
+    else
+        hipLaunchKernelGGL(stitch_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)seg,
+                           n_seg, seg_len, overlap, (float*)out, n);
     MG_CHECK_LAUNCH();
     return MG_OK;
 }

@@ -289,3 +289,22 @@ def attention_bwd(qkv, emb_h, emb_w, dout, P, heads, d, demb_h, demb_w, accumula
                                     fw, heads, d, _lib.ptr(dqkv), _lib.ptr(demb_h), _lib.ptr(demb_w), int(accumulate),
                                     _lib.ptr(ws), ws.numel(), _lib.stream()), "mg_attention_bwd")
     return dqkv
+
+
+def stitch_segments(audio, segment_length: int, gen_overlap: int = 0):
+    """generate_audio.py:40-53 on the device: audio [n_seg, 1, 1, T] (or [n_seg, T]) float32 / float64 -> [1, total]."""
+    lib = _lib.load()
+    a = audio.reshape(audio.shape[0], -1)
+    if a.shape[1] != segment_length:
+        raise ValueError("segments are %d samples long, segment_length says %d" % (a.shape[1], segment_length))
+    if a.dtype not in (torch.float32, torch.float64):
+        a = a.float()
+    a = a.contiguous()
+    n = lib.mg_stitch_length(a.shape[0], segment_length, gen_overlap)
+    if n <= 0:
+        raise ValueError("invalid stitching geometry: n_seg=%d segment_length=%d gen_overlap=%d"
+                         % (a.shape[0], segment_length, gen_overlap))
+    out = torch.empty(1, n, dtype=a.dtype, device=a.device)
+    _lib.check(lib.mg_stitch_segments(_lib.ptr(a), a.shape[0], segment_length, gen_overlap, _lib.ptr(out),
+                                      int(a.dtype == torch.float64), _lib.stream()), "mg_stitch_segments")
+    return out

@@ -122,3 +122,27 @@ def test_codec_kernels_golden(mods, golden):
                                 src_range=(-5.0, 5.0), min_b=mn, max_b=mx)
         ref = g["audio"][:, 0, 0]
         assert np.abs(audio.cpu().numpy() - ref).max() <= 2e-6 * np.abs(ref).max() + 1e-7
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_stitch_segments_golden_and_oracle(dtype, golden):
+    """generate_audio.py:40-53 (fixture G8 captured from the reference's fold-based cross-fade) and the oracle on
+    ragged overlaps; float64 is bit-exact (two addends at most), float32 to 1 ulp of the sum."""
+    from mdctgan_amd import ops
+    from oracle import transform as T
+    g = golden("g8_stitch")
+    seg = torch.from_numpy(g["seg"]).to(dtype).to(DEV)
+    ov = int(g["overlap"])
+    tol = 0.0 if dtype == torch.float64 else 1e-6
+    got = ops.stitch_segments(seg, seg.shape[-1], ov).cpu().double().numpy()
+    assert got.shape == g["stitched"].shape and np.abs(got - g["stitched"]).max() <= tol
+    got = ops.stitch_segments(seg, seg.shape[-1], 0).cpu().double().numpy()
+    assert got.shape == g["concat"].shape and np.abs(got - g["concat"]).max() <= tol
+    rng = np.random.default_rng(3)
+    for n_seg, L, ov in ((1, 64, 8), (5, 96, 47), (4, 128, 1), (7, 50, 20)):
+        a = rng.standard_normal((n_seg, 1, 1, L))
+        want = T.stitch_segments(a, L, ov)
+        got = ops.stitch_segments(torch.from_numpy(a).to(dtype).to(DEV), L, ov).cpu().double().numpy()
+        assert got.shape == want.shape and np.abs(got - want).max() <= (1e-12 if dtype == torch.float64 else 1e-6)
+    with pytest.raises(ValueError):
+        ops.stitch_segments(seg, seg.shape[-1], seg.shape[-1] // 2)
