@@ -962,6 +962,20 @@ TilePlan gemm_plan(long long M, int N, int chunks, int classes, bool can_split, 
         {1, 65536, 64, 72, 4, 128, 64, 1, 0},
         {1, 4488, 128, 256, 4, 64, 64, 1, 0},
         {1, 17160, 64, 128, 4, 64, 64, 1, 0},
+        // second discriminator scale (64x128 input), batch 8
+        {0, 1440, 512, 256, 1, 64, 64, 4, 1},
+        {1, 1224, 256, 512, 1, 64, 64, 12, 0},
+        {0, 1224, 256, 128, 1, 64, 64, 6, 1},
+        {0, 4488, 128, 64, 1, 64, 64, 3, 1},
+        // both scales at batch 16 (the stacked fake + real pass of the discriminator loss)
+        {0, 9792, 512, 256, 1, 128, 128, 3, 1},
+        {1, 8976, 256, 512, 1, 128, 128, 12, 0},
+        {0, 8976, 256, 128, 1, 64, 64, 4, 1},
+        {0, 34320, 128, 64, 1, 64, 64, 2, 1},
+        {0, 2880, 512, 256, 1, 64, 64, 4, 1},
+        {1, 2448, 256, 512, 1, 64, 64, 8, 0},
+        {0, 2448, 256, 128, 1, 64, 64, 6, 1},
+        {0, 8976, 128, 64, 1, 64, 64, 3, 1},
     };
     for (const Tuned& t : tuned)
         if (t.pass == pass && t.M == M && t.N == N && t.chunks == chunks && t.classes == classes &&

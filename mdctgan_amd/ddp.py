@@ -91,7 +91,8 @@ def attach(model, bucket_bytes=128 << 20, group=None):
     reducers and fold 1/world into the Adam kernels."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     reducers = {}
-    for name, opt, writes in (("G", model.optimizer_G, 1), ("D", model.optimizer_D, 2)):
+    d_writes = 1 if getattr(model, "stack_d_loss_passes", False) else 2    # wgrad launches per D parameter and step
+    for name, opt, writes in (("G", model.optimizer_G, 1), ("D", model.optimizer_D, d_writes)):
         slices = opt.arena_slices()
         broadcast_arena(opt.flat_p, 0, group)
         red = ArenaReducer(opt.flat_g, slices, writes, bucket_bytes, group)

@@ -360,6 +360,18 @@ def d_input(lr_spectro, s_spectro, nr0):
     return _DInputFn.apply(lr_spectro, s_spectro, nr0)
 
 
+def d_input_pair(lr_spectro, a_spectro, b_spectro, nr0):
+    """The discriminator inputs of two spectrogram batches stacked along the batch axis, [2B, 3, F, W]: rows [0, B)
+    from ``a``, rows [B, 2B) from ``b``.  No gradient path (used for the two passes of the discriminator loss, whose
+    inputs are the detached fake and the real spectrogram)."""
+    lr, a, b = to_cl(lr_spectro.detach()), to_cl(a_spectro.detach()), to_cl(b_spectro.detach())
+    B, _, H, W = a.shape
+    out = torch.empty(2 * B, H, W, 3, dtype=torch.float32, device=a.device)
+    ops.dinput_fwd(nhwc_view(lr), nhwc_view(a), nr0, out=out[:B])
+    ops.dinput_fwd(nhwc_view(lr), nhwc_view(b), nr0, out=out[B:])
+    return nchw_view(out)
+
+
 def g_input(spectro, nr0):
     """cat(s, 2|s| + nr0) (pix2pixHD_model.py:400-402); no gradient path (the generator input is data)."""
     s = to_cl(spectro.detach())
@@ -384,6 +396,37 @@ class _MseConstFn(torch.autograd.Function):
         (pred,) = ctx.saved_tensors
         go = go.reshape(1).float().contiguous()
         return ops.mse_const_bwd(pred, ctx.target, ctx.scale, go), None, None
+
+
+class _MseConstPairFn(torch.autograd.Function):
+    """(mean((pred[:B] - t0)^2), mean((pred[B:] - t1)^2)) of a batch-stacked prediction; one gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, pred, t0, t1):
+        pred = pred.contiguous(memory_format=CL) if pred.dim() == 4 else pred.contiguous()
+        B = pred.shape[0] // 2
+        l0 = torch.empty(1, dtype=torch.float32, device=pred.device)
+        l1 = torch.empty(1, dtype=torch.float32, device=pred.device)
+        ops.mse_const_fwd(pred[:B], t0, 1.0, l0, False)
+        ops.mse_const_fwd(pred[B:], t1, 1.0, l1, False)
+        ctx.targets = (t0, t1)
+        ctx.save_for_backward(pred)
+        return l0.reshape(()), l1.reshape(())
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        (pred,) = ctx.saved_tensors
+        B = pred.shape[0] // 2
+        g = torch.empty_like(pred)
+        ops.mse_const_bwd(pred[:B], ctx.targets[0], 1.0, g0.reshape(1).float().contiguous(), out=g[:B])
+        ops.mse_const_bwd(pred[B:], ctx.targets[1], 1.0, g1.reshape(1).float().contiguous(), out=g[B:])
+        return g, None, None
+
+
+def mse_const_pair_loss(pred, target_first: float, target_second: float):
+    """The two LSGAN terms of a prediction whose batch stacks two passes (first half / second half)."""
+    assert pred.shape[0] % 2 == 0
+    return _MseConstPairFn.apply(pred, float(target_first), float(target_second))
 
 
 def mse_const_loss(pred, target: float, scale: float = 1.0):

@@ -169,11 +169,12 @@ def upsample_bwd(dy):
     return dx
 
 
-def dinput_fwd(lr, s, nr0):
+def dinput_fwd(lr, s, nr0, out=None):
     """lr, s: [B, H, W] or [B, H, W, 1] -> [B, H, W, 3] = (lr, s, 2|s| + nr0)."""
     lib = _lib.load()
     B, H, W = s.shape[:3]
-    out = torch.empty(B, H, W, 3, dtype=torch.float32, device=s.device)
+    if out is None:
+        out = torch.empty(B, H, W, 3, dtype=torch.float32, device=s.device)
     _lib.check(lib.mg_dinput_fwd(_lib.ptr(lr), _lib.ptr(s), s.numel(), nr0, _lib.ptr(out), _lib.stream()),
                "mg_dinput_fwd")
     return out
@@ -202,9 +203,9 @@ def mse_const_fwd(pred, target, scale, loss, accumulate):
                                     _lib.ptr(ws), _lib.stream()), "mg_mse_const_fwd")
 
 
-def mse_const_bwd(pred, target, scale, grad_out):
+def mse_const_bwd(pred, target, scale, grad_out, out=None):
     lib = _lib.load()
-    g = torch.empty_like(pred)
+    g = torch.empty_like(pred) if out is None else out
     _lib.check(lib.mg_mse_const_bwd(_lib.ptr(pred), pred.numel(), target, scale, _lib.ptr(grad_out), _lib.ptr(g),
                                     _lib.stream()), "mg_mse_const_bwd")
     return g

@@ -253,6 +253,7 @@ class Pix2PixHDModel(BaseModel):
         # A D pass whose weight gradients train.py discards (the G-loss pass) skips its wgrad launches; set False
         # to reproduce the reference's wasted work bit for bit.
         self.skip_discarded_d_grads = True
+        self.stack_d_loss_passes = True      # D(fake.detach()) and D(real) run as one pass over 2B samples
         self.current_lable = self.current_generated = self.current_real = None
 
     def loss_filter(self, g_gan, g_gan_feat, d_real, d_fake):
@@ -286,10 +287,23 @@ class Pix2PixHDModel(BaseModel):
     def _forward(self, lr_audio, hr_audio, infer=False):
         """pix2pixHD_model.py:416-616: the four live losses [G_GAN, G_GAN_Feat, D_real, D_fake]."""
         sr_spectro, _, hr_spectro, _, hr_norm_param, lr_spectro, _, lr_norm_param = self.forward(lr_audio, hr_audio)
-        pred_fake_pool = self.netD.forward(self._d_in(lr_spectro, sr_spectro.detach()))
-        loss_D_fake = self.criterionGAN(pred_fake_pool, False)
-        pred_real = self.netD.forward(self._d_in(lr_spectro, hr_spectro))
-        loss_D_real = self.criterionGAN(pred_real, True)
+        if self.stack_d_loss_passes and self.abs_spectro and self.arcsinh_transform:
+            # D(fake.detach()) and D(real) as ONE pass over a batch of 2B: every layer of the discriminator is
+            # per-sample (InstanceNorm), so stacking is exact; half the launches, twice the rows per GEMM
+            B = lr_spectro.shape[0]
+            pred_both = self.netD.forward(Fh.d_input_pair(lr_spectro, sr_spectro, hr_spectro,
+                                                          float(self.norm_range[0])))
+            loss_D_fake = loss_D_real = 0
+            for scale_out in pred_both:
+                l_fake, l_real = Fh.mse_const_pair_loss(scale_out[-1], self.criterionGAN.fake_label,
+                                                        self.criterionGAN.real_label)
+                loss_D_fake, loss_D_real = loss_D_fake + l_fake, loss_D_real + l_real
+            pred_real = [[t.detach()[B:] for t in scale_out] for scale_out in pred_both]
+        else:
+            pred_fake_pool = self.netD.forward(self._d_in(lr_spectro, sr_spectro.detach()))
+            loss_D_fake = self.criterionGAN(pred_fake_pool, False)
+            pred_real = self.netD.forward(self._d_in(lr_spectro, hr_spectro))
+            loss_D_real = self.criterionGAN(pred_real, True)
         pred_fake = self.netD.forward(self._d_in(lr_spectro, sr_spectro),
                                       weight_grad=not self.skip_discarded_d_grads)
         loss_G_GAN = self.criterionGAN(pred_fake, True)

@@ -14,6 +14,9 @@ SHAPES = {   # name: (B, H, W, Ci, Co, k, stride, pad, reflect)
     "d256_512": (8, 17, 33, 256, 512, 4, 1, 2, False),
     "d128_256": (8, 33, 65, 128, 256, 4, 2, 2, False),
     "d64_128": (8, 65, 129, 64, 128, 4, 2, 2, False),
+    "d1_256_512": (8, 9, 17, 256, 512, 4, 1, 2, False),     # second discriminator scale (64x128 input)
+    "d1_128_256": (8, 17, 33, 128, 256, 4, 2, 2, False),
+    "d1_64_128": (8, 33, 65, 64, 128, 4, 2, 2, False),
     "head": (8, 128, 256, 64, 1, 7, 1, 3, True),
     "dlast": (8, 18, 34, 512, 1, 4, 1, 2, False),
     "stem": (8, 128, 256, 2, 64, 7, 1, 3, True),
@@ -41,6 +44,7 @@ def main():
     for name, (B, H, W, Ci, Co, k, s, p, refl) in SHAPES.items():
         if a.only and name not in a.only.split(","):
             continue
+        B = int(os.environ.get("MG_BENCH_BATCH", B))
         g = ops.conv_geom(B, H, W, Ci, Co, k, k, s, p, refl)
         x = torch.randn(B, H, W, Ci, device="cuda")
         w = torch.randn(Co, k, k, Ci, device="cuda") * 0.02
