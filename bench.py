@@ -322,6 +322,10 @@ def main():
         if os.path.exists(tr):
             try:
                 roofline["traffic"] = json.load(open(tr)).get(dominant)
+                roofline["traffic_definition"] = ("HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 from separate "
+                                                  "rocprofv3 --pmc passes on this kernel at this layer shape (gfx950 reports "
+                                                  "half of a wide coalesced read: MI355X_MICROARCH.md, HBM section); "
+                                                  "profiles/r01c_pmc_hbm_traffic.csv")
             except Exception:
                 pass
 

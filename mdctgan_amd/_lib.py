@@ -140,11 +140,12 @@ _workspaces = {}
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Persistent per-device scratch (grown on demand; all launches share one stream order)."""
+    """Persistent scratch per (device, launch stream), grown on demand; launches on one stream are ordered."""
     if torch.device(device).type != "cuda":
         raise HipLibraryError("the MI355X hot path needs device tensors (got a %s tensor); "
                               "there is no CPU fallback" % device)
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    dev_index = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = (dev_index, torch.cuda.current_stream(dev_index).cuda_stream)     # one scratch per launch stream
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes * 1.25), 1 << 22), dtype=torch.uint8, device=device)

@@ -6,17 +6,22 @@
 //       + :400-402 (the |x|*2+nr0 second channel)
 //   K2  models/pix2pixHD_model.py:127-137 (denormalize) + models/mdct.py:457-489 (IMDCT4.forward)
 //
-// Geometry: n_fft = win = 2*M, hop = M (M = 256 on the hot path).  One workgroup = 32 frames of
-// one clip = one 32x256x256 GEMM tile; 4 waves, each owning 64 output columns (2 MFMA
-// 32x32 blocks).  A (frames x k) is staged in LDS row-major with a 257-float row pitch (odd ->
-// conflict-free ds_read_b32 for the MFMA A fragment and conflict-free scalar writes);
-// B = the DCT-IV cosine table streams from L2 straight into VGPRs (no inter-wave reuse).
+// Geometry: n_fft = win = 2*M, hop = M (M = 256 on the hot path).  One workgroup = FT frames of one clip = one
+// FT x 256 x 256 GEMM tile; 4 waves, each owning 64 output columns of every frame (FT/32 x 2 MFMA 32x32
+// blocks).  A (frames x k) is folded straight from HBM into LDS, row-major with a 257-float row pitch (odd ->
+// conflict-free ds_read_b32 for the MFMA A fragment and conflict-free scalar writes); B = the DCT-IV cosine table
+// streams from L2 straight into VGPRs.  The contraction is MFMA-bound, not HBM-bound (64 FLOP per algorithmic byte
+// vs a ridge of ~20).  FT is a template parameter (32 / 64 / 128 frames; MG_MDCT_FT overrides): larger tiles reuse
+// each B element for more MFMAs but leave fewer waves per CU to hide the L2 latency of the B stream, and FT = 32
+// (34 KB of LDS, 4 workgroups per CU) measures fastest; spectra are bit-identical for every FT.  Known limit: the B
+// stream is fetched per wave (16 FLOP per L2 byte), which holds K1 at ~22 % and K2 at ~37 % of the f32 MFMA peak --
+// the next step is staging B through LDS in a 128 x 128 GEMM tiling like csrc/conv_igemm.hip.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
 
 constexpr int M = 256;          // bins per frame = hop
-constexpr int FT = 32;          // frames per workgroup
 constexpr int LDA = M + 1;      // LDS row pitch (floats)
 
 enum Codec { CODEC_RAW = 0, CODEC_ARCSINH = 1, CODEC_RANGE = 2 };
@@ -46,64 +51,71 @@ __device__ __forceinline__ float decode(float v, const CodecParams& c, float mn,
 //   optionally windowed frames [B, F, 512], optionally pre-normalisation L plus per-clip min/max
 //   and global sum / sum-of-squares for the returned statistics).
 // ---------------------------------------------------------------------------------------------
+template <int FT>
 __global__ __launch_bounds__(256) void mdct4_kernel(
     const float* __restrict__ audio, int T, int F, const float* __restrict__ window,
     const float* __restrict__ dct4, CodecParams cp, float* __restrict__ spec, float* __restrict__ in2,
     float* __restrict__ frames_out, int defer_norm, unsigned* __restrict__ minmax_ord,
     double* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xs = smem;                    // [(FT + 1) * M] raw padded samples
-    float* us = xs + (FT + 1) * M;       // [FT][LDA] folded, windowed frames (A operand)
+    float* us = smem;                    // [FT][LDA] folded, windowed frames (A operand)
     float* ws = us + FT * LDA;           // [2 * M] window
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, f0 = blockIdx.x * FT;
     const float* x = audio + (size_t)b * T;
-
-    // stage samples: padded position p = f0*M + i maps to audio index p - M (centre padding)
-    for (int i = tid; i < (FT + 1) * M; i += 256) {
-        const int t = f0 * M + i - M;
-        xs[i] = (t >= 0 && t < T) ? x[t] : 0.0f;
-    }
     for (int i = tid; i < 2 * M; i += 256) ws[i] = window[i];
     __syncthreads();
 
+    // sample n of frame f sits at padded position f*M + n, i.e. audio index f*M + n - M (centre padding, zeros outside)
+    auto sample = [&](int f, int n) -> float {
+        const int t = f * M + n - M;
+        return (t >= 0 && t < T) ? x[t] : 0.0f;
+    };
     // windowed frame z_f[n] = fl32(x[f*M + n] * w[n]) (mdct.py:410, float32 like the reference), then the
     // TDAC fold  u = [-c_r - d, a - b_r]  with quarters a, b, c, d of z.
     constexpr int Q = M / 2;
+#pragma unroll 8
     for (int i = tid; i < FT * M; i += 256) {
-        const int j = i / M, n = i % M;
-        const float* xf = xs + j * M;
-        float u;
-        if (n < Q) {
-            const int n1 = 3 * Q - 1 - n, n2 = 3 * Q + n;
-            u = -__fmul_rn(xf[n1], ws[n1]) - __fmul_rn(xf[n2], ws[n2]);
-        } else {
-            const int m = n - Q, n1 = m, n2 = 2 * Q - 1 - m;
-            u = __fmul_rn(xf[n1], ws[n1]) - __fmul_rn(xf[n2], ws[n2]);
+        const int j = i / M, n = i % M, f = f0 + j;
+        float u = 0.0f;
+        if (f < F) {
+            if (n < Q) {
+                const int n1 = 3 * Q - 1 - n, n2 = 3 * Q + n;
+                u = -__fmul_rn(sample(f, n1), ws[n1]) - __fmul_rn(sample(f, n2), ws[n2]);
+            } else {
+                const int m = n - Q, n1 = m, n2 = 2 * Q - 1 - m;
+                u = __fmul_rn(sample(f, n1), ws[n1]) - __fmul_rn(sample(f, n2), ws[n2]);
+            }
         }
-        us[j * LDA + n] = (f0 + j < F) ? u : 0.0f;
+        us[j * LDA + n] = u;
     }
     if (frames_out) {
         for (int i = tid; i < FT * 2 * M; i += 256) {
             const int j = i / (2 * M), n = i % (2 * M);
-            if (f0 + j < F) frames_out[((size_t)b * F + f0 + j) * (2 * M) + n] = xs[j * M + n] * ws[n];
+            if (f0 + j < F) frames_out[((size_t)b * F + f0 + j) * (2 * M) + n] = sample(f0 + j, n) * ws[n];
         }
     }
     __syncthreads();
 
-    // 32 x 64 (per wave) x 256 contraction on the f32 MFMA pipe
-    f32x16 acc0 = {0}, acc1 = {0};
+    // FT x 64 (per wave) x 256 contraction on the f32 MFMA pipe
+    constexpr int RB = FT / 32;
+    f32x16 acc[RB][2];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) { acc[rb][0] = f32x16{0}; acc[rb][1] = f32x16{0}; }
     const int arow = lane & 31, khalf = lane >> 5;
     const float* ap = us + arow * LDA + khalf;
     const float* bp = dct4 + (size_t)khalf * M + wave * 64 + (lane & 31);
 #pragma unroll 8
     for (int kp = 0; kp < M / 2; ++kp) {
-        const float a = ap[2 * kp];
         const float b0 = bp[(size_t)(2 * kp) * M];
         const float b1 = bp[(size_t)(2 * kp) * M + 32];
-        acc0 = mfma32x32x2(a, b0, acc0);
-        acc1 = mfma32x32x2(a, b1, acc1);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const float a = ap[rb * 32 * LDA + 2 * kp];
+            acc[rb][0] = mfma32x32x2(a, b0, acc[rb][0]);
+            acc[rb][1] = mfma32x32x2(a, b1, acc[rb][1]);
+        }
     }
 
     // epilogue: codec + stores
@@ -111,12 +123,14 @@ __global__ __launch_bounds__(256) void mdct4_kernel(
     double s1 = 0.0, s2 = 0.0;
     float vmin = INFINITY, vmax = -INFINITY;
 #pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int f = f0 + mfma32_row(r, lane);
+            const int f = f0 + rb * 32 + mfma32_row(r, lane);
             const int col = wave * 64 + nb * 32 + (lane & 31);
-            const float xv = nb ? acc1[r] : acc0[r];
+            const float xv = acc[rb][nb][r];
             if (f >= F) continue;
             float l = xv;
             if (cp.mode == CODEC_ARCSINH) l = asinhf(cp.gain * xv) / LN10F;
@@ -173,12 +187,12 @@ __global__ void fill_u32_pairs(unsigned* p, int n_pairs) {
 //   half overlaps hop-block f0) as a VALU dot product riding in the MFMA shadow, then emits hop-blocks
 //   h = f0 .. f0+31:  out[(h-1)*M + n] = 4/N * ( w[n] * y_h[n] + w[n+M] * y_{h-1}[n+M] ).
 // ---------------------------------------------------------------------------------------------
-template <typename OutT>
+template <typename OutT, int FT>
 __global__ __launch_bounds__(256) void imdct4_kernel(
     const float* __restrict__ spec, int F, const float* __restrict__ window, const float* __restrict__ dct4,
     CodecParams cp, OutT* __restrict__ audio, int out_len, float* __restrict__ frames_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* as = smem;                     // [(FT + 1)][LDA]: rows 0..31 = frames f0.., row 32 = halo frame f0-1
+    float* as = smem;                     // [(FT + 1)][LDA]: rows 0..FT-1 = frames f0.., row FT = halo frame f0-1
     float* ws = as + (FT + 1) * LDA;      // [2 * M]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -186,6 +200,7 @@ __global__ __launch_bounds__(256) void imdct4_kernel(
     float mn = cp.mn, mx = cp.mx;
     if (cp.per_sample) { mn = cp.mn_b[b]; mx = cp.mx_b[b]; }
 
+#pragma unroll 8
     for (int i = tid; i < (FT + 1) * M; i += 256) {
         const int j = i / M, k = i % M;
         const int f = (j == FT) ? f0 - 1 : f0 + j;
@@ -196,7 +211,10 @@ __global__ __launch_bounds__(256) void imdct4_kernel(
     for (int i = tid; i < 2 * M; i += 256) ws[i] = window[i];
     __syncthreads();
 
-    f32x16 acc0 = {0}, acc1 = {0};
+    constexpr int RB = FT / 32;
+    f32x16 acc[RB][2];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) { acc[rb][0] = f32x16{0}; acc[rb][1] = f32x16{0}; }
     float h0 = 0.0f, h1 = 0.0f;
     const int arow = lane & 31, khalf = lane >> 5;
     const float* ap = as + arow * LDA + khalf;
@@ -204,12 +222,15 @@ __global__ __launch_bounds__(256) void imdct4_kernel(
     const float* bp = dct4 + (size_t)khalf * M + wave * 64 + (lane & 31);
 #pragma unroll 8
     for (int kp = 0; kp < M / 2; ++kp) {
-        const float a = ap[2 * kp];
         const float xh = hp[2 * kp];
         const float b0 = bp[(size_t)(2 * kp) * M];
         const float b1 = bp[(size_t)(2 * kp) * M + 32];
-        acc0 = mfma32x32x2(a, b0, acc0);
-        acc1 = mfma32x32x2(a, b1, acc1);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const float a = ap[rb * 32 * LDA + 2 * kp];
+            acc[rb][0] = mfma32x32x2(a, b0, acc[rb][0]);
+            acc[rb][1] = mfma32x32x2(a, b1, acc[rb][1]);
+        }
         h0 = fmaf(xh, b0, h0);
         h1 = fmaf(xh, b1, h1);
     }
@@ -217,13 +238,15 @@ __global__ __launch_bounds__(256) void imdct4_kernel(
     h1 += __shfl_xor(h1, 32, 64);
     __syncthreads();                       // everyone is done reading `as` as the A operand
 
-    // v = DCT-IV(X) back into LDS (same buffer): rows 0..31 frames, row 32 halo
+    // v = DCT-IV(X) back into LDS (same buffer): rows 0..FT-1 frames, row FT halo
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int j = mfma32_row(r, lane);
-            as[j * LDA + wave * 64 + nb * 32 + (lane & 31)] = nb ? acc1[r] : acc0[r];
+            const int j = rb * 32 + mfma32_row(r, lane);
+            as[j * LDA + wave * 64 + nb * 32 + (lane & 31)] = acc[rb][nb][r];
         }
     }
     if (lane < 32) {
@@ -292,12 +315,22 @@ __global__ void stitch_kernel(const T* __restrict__ seg, int n_seg, int L, int o
 
 }  // namespace
 
+// frames per workgroup: a whole-clip tile (4 MFMAs per B fetch) once the launch fills the chip, 32 otherwise
+static int frames_per_wg(int B, int F) {
+    if (const char* f = getenv("MG_MDCT_FT")) { const int v = atoi(f); return (v == 128 || v == 64) ? v : 32; }
+    (void)B; (void)F;
+    return 32;      // measured on MI355X at 4096 clips: K1 1.99 / 1.87 / 2.95 ms and K2 1.19 / 1.54 / 2.49 ms for 32 / 64 / 128
+}
+template <typename K>
+static void allow_lds(K kernel, size_t lds) {
+    hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
-size_t mg_mdct4_lds_bytes() { return ((FT + 1) * M + FT * LDA + 2 * M) * sizeof(float); }
+size_t mg_mdct4_lds_bytes() { return (128 * LDA + 2 * M) * sizeof(float); }
 
 // See include/mdctgan_hip.h for the contract.
 int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* window, const float* dct4,
@@ -311,17 +344,24 @@ int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* w
     const int pad_tail = (T % M) ? (M - T % M) : 0;
     const int F = (T + 2 * M + pad_tail - 2 * M) / M + 1;
     CodecParams cp{codec, gain, nr0, nr1, src_min, src_max, nullptr, nullptr, per_sample};
-    const size_t lds = mg_mdct4_lds_bytes();
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute((const void*)mdct4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        allow_lds(mdct4_kernel<128>, (128 * LDA + 2 * M) * sizeof(float));
+        allow_lds(mdct4_kernel<64>, (64 * LDA + 2 * M) * sizeof(float));
         attr_done = true;
     }
     if (stats) hipMemsetAsync(stats, 0, 2 * sizeof(double), st);
     if (per_sample) hipLaunchKernelGGL(fill_u32_pairs, dim3((B + 255) / 256), dim3(256), 0, st, scratch_u32, B);
-    dim3 grid((F + FT - 1) / FT, B);
-    hipLaunchKernelGGL(mdct4_kernel, grid, dim3(256), lds, st, audio, T, F, window, dct4, cp, spec, in2,
-                       frames_out, per_sample, scratch_u32, stats);
+    const int ft = frames_per_wg(B, F);
+    if (ft == 128)
+        hipLaunchKernelGGL(mdct4_kernel<128>, dim3((F + 127) / 128, B), dim3(256), (128 * LDA + 2 * M) * sizeof(float), st,
+                           audio, T, F, window, dct4, cp, spec, in2, frames_out, per_sample, scratch_u32, stats);
+    else if (ft == 64)
+        hipLaunchKernelGGL(mdct4_kernel<64>, dim3((F + 63) / 64, B), dim3(256), (64 * LDA + 2 * M) * sizeof(float), st,
+                           audio, T, F, window, dct4, cp, spec, in2, frames_out, per_sample, scratch_u32, stats);
+    else
+        hipLaunchKernelGGL(mdct4_kernel<32>, dim3((F + 31) / 32, B), dim3(256), (32 * LDA + 2 * M) * sizeof(float), st,
+                           audio, T, F, window, dct4, cp, spec, in2, frames_out, per_sample, scratch_u32, stats);
     MG_CHECK_LAUNCH();
     if (per_sample) {
         hipLaunchKernelGGL(range_norm_kernel, dim3(64, B), dim3(256), 0, st, spec, in2, F * M, scratch_u32, nr0,
@@ -346,14 +386,27 @@ int mg_imdct4_forward(const float* spec, int B, int F, int n_fft, const float* w
     if (out_len <= 0 || out_len > (F - 1) * M) return MG_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     CodecParams cp{codec, gain, nr0, nr1, src_min, src_max, min_b, max_b, (min_b && max_b) ? 1 : 0};
-    const size_t lds = ((FT + 1) * LDA + 2 * M) * sizeof(float);
-    dim3 grid((F + FT - 1) / FT, B);
-    if (out_f64)
-        hipLaunchKernelGGL(imdct4_kernel<double>, grid, dim3(256), lds, st, spec, F, window, dct4, cp,
-                           (double*)audio, out_len, frames_out);
-    else
-        hipLaunchKernelGGL(imdct4_kernel<float>, grid, dim3(256), lds, st, spec, F, window, dct4, cp,
-                           (float*)audio, out_len, frames_out);
+    static bool attr_done = false;
+    if (!attr_done) {
+        allow_lds(imdct4_kernel<float, 128>, (129 * LDA + 2 * M) * sizeof(float));
+        allow_lds(imdct4_kernel<double, 128>, (129 * LDA + 2 * M) * sizeof(float));
+        allow_lds(imdct4_kernel<float, 64>, (65 * LDA + 2 * M) * sizeof(float));
+        allow_lds(imdct4_kernel<double, 64>, (65 * LDA + 2 * M) * sizeof(float));
+        attr_done = true;
+    }
+#define MG_IMDCT(T_, FT_)                                                                                            \
+    hipLaunchKernelGGL((imdct4_kernel<T_, FT_>), dim3((F + FT_ - 1) / FT_, B), dim3(256),                            \
+                       ((FT_ + 1) * LDA + 2 * M) * sizeof(float), st, spec, F, window, dct4, cp, (T_*)audio, out_len, \
+                       frames_out)
+    const int ft = frames_per_wg(B, F);
+    if (ft == 128) {
+        if (out_f64) MG_IMDCT(double, 128); else MG_IMDCT(float, 128);
+    } else if (ft == 64) {
+        if (out_f64) MG_IMDCT(double, 64); else MG_IMDCT(float, 64);
+    } else {
+        if (out_f64) MG_IMDCT(double, 32); else MG_IMDCT(float, 32);
+    }
+#undef MG_IMDCT
     MG_CHECK_LAUNCH();
     return MG_OK;
 }

@@ -146,3 +146,22 @@ def test_stitch_segments_golden_and_oracle(dtype, golden):
         assert got.shape == want.shape and np.abs(got - want).max() <= (1e-12 if dtype == torch.float64 else 1e-6)
     with pytest.raises(ValueError):
         ops.stitch_segments(seg, seg.shape[-1], seg.shape[-1] // 2)
+
+
+def test_frame_tile_sizes_agree(mods, monkeypatch):
+    """The 32 / 64 / 128-frame workgroup tiles give bit-identical spectra and frames (every output element sees the same
+    k-ordered MFMA accumulation); the waveform agrees to rounding (the hop block at a tile boundary takes its
+    predecessor frame from the VALU halo path instead of the MFMA tile)."""
+    mdct, imdct, _ = mods
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 32512 + 77, generator=gen).to(DEV)        # ragged: 129 frames
+    outs = {}
+    for ft in ("32", "64", "128"):
+        monkeypatch.setenv("MG_MDCT_FT", ft)
+        X, fr = mdct(x, True)
+        y, yfr = imdct(X, True)
+        outs[ft] = (X.clone(), fr.clone(), y.clone(), yfr.clone())
+    for ft in ("64", "128"):
+        for i in (0, 1, 3):
+            assert torch.equal(outs["32"][i], outs[ft][i])
+        assert (outs["32"][2] - outs[ft][2]).abs().max().item() <= 2e-6 * outs["32"][2].abs().max().item()
