@@ -96,7 +96,14 @@ typedef struct {
     int OH, OW, Co;
     int KH, KW, stride, pad;
     int reflect; /* 0: zero padding, 1: reflection padding (ReflectionPad2d(pad) folded into the gather) */
+    int precision; /* MG_PRECISION_F32: exact float32 on the f32 MFMA pipe.  MG_PRECISION_F16: the arithmetic of
+                    * torch.autocast(float16) for convolutions (train.py:161-164 with --fp16): operands rounded to
+                    * float16 as they are staged, products on the f16 MFMA pipe, float32 accumulation, outputs of the
+                    * forward / data-gradient passes rounded through float16 (overflow -> inf, as a float16 tensor
+                    * would), weight gradients kept in float32.  Tensors stay float32 in memory. */
 } mg_conv_geom;
+#define MG_PRECISION_F32 0
+#define MG_PRECISION_F16 1
 
 /* y = act(conv(x, w) + bias)            (bias nullable).  workspace (nullable): mg_conv_fwd_workspace() bytes of
  * scratch that lets deep-K / small-M*N layers split K across workgroups (without it they run unsplit). */
@@ -220,6 +227,22 @@ int mg_adam_step(float* p, const float* g, float* m, float* v, long long n, floa
 int mg_adam_tick(double* state, float beta1, float beta2, void* stream);
 int mg_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const double* state, float beta1,
                      float beta2, float eps, float grad_scale, void* stream);
+
+/* torch.cuda.amp.GradScaler on the device (train.py:65-70: one scaler; :183-199: scale(loss).backward(),
+ * scaler.step(optimizer) per optimiser, scaler.update() once per iteration) -- no host synchronisation, so the AMP
+ * step stays hipGraph-capturable.  scaler: float[2 + MG_SCALER_SLOTS] = {loss scale S, growth tracker,
+ * found_inf[slot]...} (one slot per optimiser; the caller initialises {init_scale, 0, 0...}).
+ *   mg_scaler_check   found_inf[slot] = 1 if any gradient in g[0..n) is inf / nan  (GradScaler.unscale_'s check)
+ *   mg_adam_tick_amp / mg_adam_step_amp   mg_adam_tick / mg_adam_step_dev with the gradients divided by S, and a
+ *                     no-op -- parameters, moments and step counter untouched -- when found_inf[slot] != 0
+ *   mg_scaler_update  any found_inf: S *= backoff_factor, tracker = 0; else tracker += 1 and, at growth_interval,
+ *                     S *= growth_factor, tracker = 0.  Clears every found_inf slot. */
+#define MG_SCALER_SLOTS 2
+int mg_scaler_check(const float* g, long long n, float* scaler, int slot, void* stream);
+int mg_scaler_update(float* scaler, float growth_factor, float backoff_factor, int growth_interval, void* stream);
+int mg_adam_tick_amp(double* state, float beta1, float beta2, const float* scaler, int slot, void* stream);
+int mg_adam_step_amp(float* p, const float* g, float* m, float* v, long long n, const double* state, float beta1,
+                     float beta2, float eps, float grad_scale, const float* scaler, int slot, void* stream);
 
 #ifdef __cplusplus
 }

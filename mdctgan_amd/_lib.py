@@ -23,7 +23,10 @@ class HipLibraryError(RuntimeError):
 
 class ConvGeom(C.Structure):
     _fields_ = [(n, C.c_int) for n in
-                ("B", "H", "W", "Ci", "OH", "OW", "Co", "KH", "KW", "stride", "pad", "reflect")]
+                ("B", "H", "W", "Ci", "OH", "OW", "Co", "KH", "KW", "stride", "pad", "reflect", "precision")]
+
+
+PRECISION_F32, PRECISION_F16 = 0, 1
 
 
 _p, _i, _f, _ll, _sz = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
@@ -77,6 +80,10 @@ SIGNATURES = {
     "mg_adam_step": (_i, [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _f, _p]),
     "mg_adam_tick": (_i, [_p, _f, _f, _p]),
     "mg_adam_step_dev": (_i, [_p, _p, _p, _p, _ll, _p, _f, _f, _f, _f, _p]),
+    "mg_scaler_check": (_i, [_p, _ll, _p, _i, _p]),
+    "mg_scaler_update": (_i, [_p, _f, _f, _i, _p]),
+    "mg_adam_tick_amp": (_i, [_p, _f, _f, _p, _i, _p]),
+    "mg_adam_step_amp": (_i, [_p, _p, _p, _p, _ll, _p, _f, _f, _f, _f, _p, _i, _p]),
 }
 
 _lib = None

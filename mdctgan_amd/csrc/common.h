@@ -16,6 +16,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x16 mfma32x32x2(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+// f16-input MFMA (v_mfma_f32_32x32x16_f16): D(32x32) += A(32x16) * B(16x32), exact f16 products, f32 accumulate.
+// Lane l supplies 8 halves of row i = l & 31 of A (and of column j = l & 31 of B) for the k-group l >> 5; A and B use
+// the same slot -> k map, so any chunk layout that gives both operands the same 8 k per (lane half, slot) is correct.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x16 mfma32x32x16h(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {      // round-to-nearest-even, like Tensor.half()
+    f16x2 h = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ float round_h(float v) { return (float)(_Float16)v; }
 __device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 __device__ __forceinline__ float wave_sum(float v) {

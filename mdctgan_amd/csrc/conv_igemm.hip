@@ -62,18 +62,61 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ void add4(float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 
-// k-contiguous float4 (4 consecutive k of one row) -> k-major LDS tile
-template <int LD>
+// k-contiguous float4 (4 consecutive k of one row) -> k-major LDS tile.
+// P = 1 (f16 compute, TAG 2 kernels): the tile holds halves, two consecutive k of a row packed in one 32-bit word at
+// [k / 2][row] (same pitch in words), so a lane's 8 k of one MFMA step are 4 words of its row.
+template <int LD, int P = 0>
 __device__ __forceinline__ void st_kcontig(float* S, int row, int q, const float4 v) {
-    S[(4 * q + 0) * LD + row] = v.x;
-    S[(4 * q + 1) * LD + row] = v.y;
-    S[(4 * q + 2) * LD + row] = v.z;
-    S[(4 * q + 3) * LD + row] = v.w;
+    if (P) {
+        uint32_t* W = reinterpret_cast<uint32_t*>(S);
+        W[(2 * q + 0) * LD + row] = pack_h2(v.x, v.y);
+        W[(2 * q + 1) * LD + row] = pack_h2(v.z, v.w);
+    } else {
+        S[(4 * q + 0) * LD + row] = v.x;
+        S[(4 * q + 1) * LD + row] = v.y;
+        S[(4 * q + 2) * LD + row] = v.z;
+        S[(4 * q + 3) * LD + row] = v.w;
+    }
 }
 // row-contiguous float4 (4 consecutive rows at one k)
-template <int LD>
+template <int LD, int P = 0>
 __device__ __forceinline__ void st_rowcontig(float* S, int k, int row, const float4 v) {
-    *reinterpret_cast<float4*>(S + k * LD + row) = v;
+    if (P) {
+        _Float16* H = reinterpret_cast<_Float16*>(S) + (((k >> 1) * LD + row) << 1) + (k & 1);
+        H[0] = (_Float16)v.x;
+        H[2] = (_Float16)v.y;
+        H[4] = (_Float16)v.z;
+        H[6] = (_Float16)v.w;
+    } else {
+        *reinterpret_cast<float4*>(S + k * LD + row) = v;
+    }
+}
+
+// One 16-deep chunk on the f16 MFMA pipe: one 32x32x16 instruction per accumulator tile.
+template <int MB, int NB, int LDA, int LDB, typename F0, typename F1>
+__device__ __forceinline__ void mma_chunk_h(const float* Ap, const float* Bp, f32x16 (&acc)[MB][NB], int wm0, int wn0,
+                                            int lane, F0&& after_kp0, F1&& after_kp1) {
+    const int r = lane & 31, kh = lane >> 5;
+    const uint32_t* ap = reinterpret_cast<const uint32_t*>(Ap) + (4 * kh) * LDA + wm0 + r;
+    const uint32_t* bp = reinterpret_cast<const uint32_t*>(Bp) + (4 * kh) * LDB + wn0 + r;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 a[MB], b[NB];
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[mi][j] = ap[j * LDA + 32 * mi];
+#pragma unroll
+    for (int ni = 0; ni < NB; ++ni)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[ni][j] = bp[j * LDB + 32 * ni];
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni)
+            acc[mi][ni] = mfma32x32x16h(__builtin_bit_cast(f16x8, a[mi]), __builtin_bit_cast(f16x8, b[ni]), acc[mi][ni]);
+    __builtin_amdgcn_sched_barrier(0);
+    after_kp0();
+    after_kp1();
 }
 
 // One 16-deep k-chunk of MFMAs, software-pipelined by hand (the compiler will not do either on its own):
@@ -235,9 +278,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geom g, const float* __re
     float4 va[NVA], vb[NVB];
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) st_kcontig<LDA>(As(buf), r0 + 64 * i, q, va[i]);
+        for (int i = 0; i < NVA; ++i) st_kcontig<LDA, (TAG == 2)>(As(buf), r0 + 64 * i, q, va[i]);
 #pragma unroll
-        for (int i = 0; i < NVB; ++i) st_kcontig<LDB>(Bs(buf), r0 + 64 * i, q, vb[i]);
+        for (int i = 0; i < NVB; ++i) st_kcontig<LDB, (TAG == 2)>(Bs(buf), r0 + 64 * i, q, vb[i]);
     };
     if (c_begin < nchunks) {
         load_a(c_begin, va);
@@ -251,10 +294,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geom g, const float* __re
     }
     for (int c = c_begin; c < nchunks; ++c) {
         const int cur = (c - c_begin) & 1;
-        mma_chunk<MB, NB, LDA, LDB>(
-            As(cur), Bs(cur), acc, wm0, wn0, lane,
-            [&]() { if (c + 1 < nchunks) stash(cur ^ 1); },
-            [&]() { if (c + 2 < nchunks) { load_a(c + 2, va); load_b(c + 2, vb); } });
+        auto f0 = [&]() { if (c + 1 < nchunks) stash(cur ^ 1); };
+        auto f1 = [&]() { if (c + 2 < nchunks) { load_a(c + 2, va); load_b(c + 2, vb); } };
+        if (TAG == 2) mma_chunk_h<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
+        else mma_chunk<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
         __syncthreads();
     }
 
@@ -269,7 +312,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geom g, const float* __re
                 const int row = m0 + wm0 + 32 * mi + mfma32_row(r, lane);
                 if (row < M && col < N) {
                     if (part) part[(size_t)row * N + col] = acc[mi][ni][r];
-                    else y[(size_t)row * N + col] = apply_act(acc[mi][ni][r] + bv, act);
+                    else {
+                        const float v = apply_act(acc[mi][ni][r] + bv, act);
+                        y[(size_t)row * N + col] = (TAG == 2) ? round_h(v) : v;
+                    }
                 }
             }
         }
@@ -625,9 +671,9 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
     float4 va[NVA], vb[NVB];
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) st_kcontig<LDA>(As(buf), r0 + 64 * i, q, va[i]);
+        for (int i = 0; i < NVA; ++i) st_kcontig<LDA, (TAG == 2)>(As(buf), r0 + 64 * i, q, va[i]);
 #pragma unroll
-        for (int i = 0; i < NVB; ++i) st_rowcontig<LDB>(Bs(buf), bk_l + i * (1024 / BN), 4 * bn_q, vb[i]);
+        for (int i = 0; i < NVB; ++i) st_rowcontig<LDB, (TAG == 2)>(Bs(buf), bk_l + i * (1024 / BN), 4 * bn_q, vb[i]);
     };
     if (c_begin < nchunks) {
         load_a(c_begin, va);
@@ -641,10 +687,10 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
     }
     for (int c = c_begin; c < nchunks; ++c) {
         const int cur = (c - c_begin) & 1;
-        mma_chunk<MB, NB, LDA, LDB>(
-            As(cur), Bs(cur), acc, wm0, wn0, lane,
-            [&]() { if (c + 1 < nchunks) stash(cur ^ 1); },
-            [&]() { if (c + 2 < nchunks) { load_a(c + 2, va); load_b(c + 2, vb); } });
+        auto f0 = [&]() { if (c + 1 < nchunks) stash(cur ^ 1); };
+        auto f1 = [&]() { if (c + 2 < nchunks) { load_a(c + 2, va); load_b(c + 2, vb); } };
+        if (TAG == 2) mma_chunk_h<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
+        else mma_chunk<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
         __syncthreads();
     }
 
@@ -665,7 +711,8 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
                         part[o + col] = acc[mi][ni][r];
                     } else {
                         const float bv = bias ? bias[col] : 0.0f;
-                        dx[o + col] = apply_act(acc[mi][ni][r] + bv, act);
+                        const float v = apply_act(acc[mi][ni][r] + bv, act);
+                        dx[o + col] = (TAG == 2) ? round_h(v) : v;
                     }
                 }
             }
@@ -777,9 +824,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
     float4 va[NVA], vb[NVB];
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) st_rowcontig<LDA>(As(buf), ak_l + i * (1024 / BM), 4 * a_q, va[i]);
+        for (int i = 0; i < NVA; ++i) st_rowcontig<LDA, (TAG == 2)>(As(buf), ak_l + i * (1024 / BM), 4 * a_q, va[i]);
 #pragma unroll
-        for (int i = 0; i < NVB; ++i) st_rowcontig<LDB>(Bs(buf), bk_l + i * (1024 / BN), 4 * b_q, vb[i]);
+        for (int i = 0; i < NVB; ++i) st_rowcontig<LDB, (TAG == 2)>(Bs(buf), bk_l + i * (1024 / BN), 4 * b_q, vb[i]);
     };
     if (c_begin < c_end) {
         load_a(c_begin, va);
@@ -793,10 +840,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
     }
     for (int c = c_begin; c < c_end; ++c) {
         const int cur = (c - c_begin) & 1;
-        mma_chunk<MB, NB, LDA, LDB>(
-            As(cur), Bs(cur), acc, wm0, wn0, lane,
-            [&]() { if (c + 1 < c_end) stash(cur ^ 1); },
-            [&]() { if (c + 2 < c_end) { load_a(c + 2, va); load_b(c + 2, vb); } });
+        auto f0 = [&]() { if (c + 1 < c_end) stash(cur ^ 1); };
+        auto f1 = [&]() { if (c + 2 < c_end) { load_a(c + 2, va); load_b(c + 2, vb); } };
+        if (TAG == 2) mma_chunk_h<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
+        else mma_chunk<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
         __syncthreads();
     }
 
@@ -837,13 +884,15 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, int S, size
 
 // split-K epilogue of the forward / data-gradient passes: out = act(sum_s part[s] + bias[col])
 __global__ void splitk_epilogue_kernel(const float* __restrict__ part, int S, size_t n, int N,
-                                       const float* __restrict__ bias, int act, float* __restrict__ out) {
+                                       const float* __restrict__ bias, int act, float* __restrict__ out,
+                                       int round_f16 = 0) {
     const size_t n4 = n / 4;   // launcher guarantees N % 4 == 0
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 s = zero4();
         for (int z = 0; z < S; ++z) add4(s, ld4(part + (size_t)z * n + 4 * i));
         if (bias) add4(s, ld4(bias + (4 * i) % N));
         s.x = apply_act(s.x, act); s.y = apply_act(s.y, act); s.z = apply_act(s.z, act); s.w = apply_act(s.w, act);
+        if (round_f16) { s.x = round_h(s.x); s.y = round_h(s.y); s.z = round_h(s.z); s.w = round_h(s.w); }
         *reinterpret_cast<float4*>(out + 4 * i) = s;
     }
 }
@@ -876,7 +925,10 @@ Geom to_geom(const mg_conv_geom* g) {
     return Geom{g->B, g->H, g->W, g->Ci, g->OH, g->OW, g->Co, g->KH, g->KW, g->stride, g->pad, g->reflect};
 }
 
+inline bool prec_h(const mg_conv_geom* g) { return g->precision == MG_PRECISION_F16; }
+
 bool geom_ok(const mg_conv_geom* g) {
+    if (g && g->precision != MG_PRECISION_F32 && g->precision != MG_PRECISION_F16) return false;
     if (!g || g->B <= 0 || g->H <= 0 || g->W <= 0 || g->Ci <= 0 || g->Co <= 0 || g->KH <= 0 || g->KW <= 0) return false;
     if (g->stride < 1 || g->stride > 2 || g->pad < 0) return false;
     if (g->OH != (g->H + 2 * g->pad - g->KH) / g->stride + 1) return false;
@@ -1046,7 +1098,7 @@ WgradPlan wgrad_plan(const mg_conv_geom* g) {
 // ---------------------------------------------------------------------------------------------------------
 bool wino_ok(const mg_conv_geom* g) {
     static const bool off = getenv("MG_NO_WINOGRAD") != nullptr;
-    return !off && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1 && g->Ci % 16 == 0 && g->Co % 16 == 0 &&
+    return !off && !prec_h(g) && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1 && g->Ci % 16 == 0 && g->Co % 16 == 0 &&
            g->Ci >= 32 && g->Co >= 32 && g->H % 2 == 0 && g->W % 2 == 0 && g->H >= 2 && g->W >= 2;
 }
 struct WinoDims { long long T, Tp; int TH, TW, THp, TWp; };
@@ -1234,7 +1286,7 @@ size_t mg_conv_rowdot_wgrad_workspace(const mg_conv_geom* g);
 int mg_conv_rowdot_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias,
                          int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
-int mg_abi_version(void) { return 1; }
+int mg_abi_version(void) { return 2; }
 
 void mg_probe_arm(void* e0, void* e1) {
     g_probe_e0 = (hipEvent_t)e0;
@@ -1258,7 +1310,7 @@ double mg_conv_plan_flops(int pass, const mg_conv_geom* g) {
 // minus the anonymous-namespace prefix).  pass: 0 fwd, 1 dgrad, 2 wgrad.
 int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
     if (!geom_ok(g) || !out || out_len < 64) return MG_ERR_ARG;
-    const int kq = mg_conv_rowdot_kq(g);
+    const int kq = prec_h(g) ? 0 : mg_conv_rowdot_kq(g);
     if (wino_ok(g) && !kq) {
         const WinoDims d = wino_dims(g);
         if (pass == 0) {
@@ -1283,7 +1335,8 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
         if (use_k32(tp, g->Ci))
             snprintf(out, out_len, "conv_fwd32_kernel<%d, %d, 0>", tp.bm, tp.bn);
         else
-            snprintf(out, out_len, "conv_fwd_kernel<%d, %d, %s, 0>", tp.bm, tp.bn, (g->Ci % BK == 0) ? "true" : "false");
+            snprintf(out, out_len, "conv_fwd_kernel<%d, %d, %s, %d>", tp.bm, tp.bn, (g->Ci % BK == 0) ? "true" : "false",
+                     prec_h(g) ? 2 : 0);
     } else if (pass == 1) {
         const TilePlan tp = dgrad_plan(g);
         snprintf(out, out_len, "conv_dgrad_kernel<%d, %d, %s, %s, 0>", tp.bm, tp.bn, (g->Co % BK == 0) ? "true" : "false",
@@ -1336,7 +1389,7 @@ int mg_conv_fwd_u(const mg_conv_geom* g, const float* x, const float* w, const f
                   void* workspace, size_t workspace_bytes, void* stream, const float* u) {
     if (!geom_ok(g) || !x || !w || !y) return MG_ERR_ARG;
     if (u && (!mg_conv_wino_weights_bytes(g) || !aligned16(u))) return MG_ERR_ARG;
-    if (mg_conv_rowdot_kq(g) && aligned16(x) && aligned16(w)) {
+    if (!prec_h(g) && mg_conv_rowdot_kq(g) && aligned16(x) && aligned16(w)) {
         probe_begin((hipStream_t)stream);
         const int rc = mg_conv_rowdot_fwd(g, x, w, bias, y, act, stream);
         probe_end((hipStream_t)stream);
@@ -1357,11 +1410,14 @@ int mg_conv_fwd_u(const mg_conv_geom* g, const float* x, const float* w, const f
         tp.cps = 1 << 30;
     }
     float* part = tp.splits > 1 ? (float*)workspace : nullptr;
-    const bool k32 = vec && use_k32(tp, g->Ci);
+    const bool hp = prec_h(g);
+    const bool k32 = vec && !hp && use_k32(tp, g->Ci);
 #define MG_LAUNCH_FWD(BM_, BN_)                                                                                    \
     do {                                                                                                           \
         dim3 grid((unsigned)(((M + BM_ - 1) / BM_) * ((N + BN_ - 1) / BN_)), tp.splits);                           \
         if (k32) launch_fwd32<BM_, BN_, 0>(grid, st, gg, x, w, bias, y, act, tp.splits == 1 ? (1 << 29) : tp.cps / 2, part, Batch{0, 0, 0, 0}); \
+        else if (hp && vec) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, true, 2>), grid, dim3(256), 0, st, gg, x, w, bias, y, act, tp.cps, part, Batch{0, 0, 0, 0});  \
+        else if (hp) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, false, 2>), grid, dim3(256), 0, st, gg, x, w, bias, y, act, tp.cps, part, Batch{0, 0, 0, 0});    \
         else if (vec) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, true>), grid, dim3(256), 0, st, gg, x, w, bias, y, act, tp.cps, part, Batch{0, 0, 0, 0});  \
         else hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, false>), grid, dim3(256), 0, st, gg, x, w, bias, y, act, tp.cps, part, Batch{0, 0, 0, 0});    \
     } while (0)
@@ -1376,7 +1432,7 @@ int mg_conv_fwd_u(const mg_conv_geom* g, const float* x, const float* w, const f
         const size_t n = (size_t)M * N;
         const unsigned blocks = (unsigned)((n / 4 + 255) / 256 > 4096 ? 4096 : (n / 4 + 255) / 256);
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, (const float*)part, tp.splits, n, N,
-                           bias, act, y);
+                           bias, act, y, (int)hp);
         MG_CHECK_LAUNCH();
     }
     return MG_OK;
@@ -1405,30 +1461,33 @@ int mg_conv_dgrad_u(const mg_conv_geom* g, const float* dy, const float* w, cons
         tp.cps = 1 << 30;
     }
     float* part = tp.splits > 1 ? (float*)workspace : nullptr;
-#define MG_LAUNCH_DGRAD(BM_, BN_)                                                                                  \
+    const bool hp = prec_h(g);
+#define MG_LAUNCH_DGRAD_T(BM_, BN_, TAG_)                                                                          \
     do {                                                                                                           \
         dim3 grid((unsigned)(((Mc + BM_ - 1) / BM_) * ((N + BN_ - 1) / BN_)), tp.splits, s * s);                   \
         if (veca && vecb)                                                                                          \
-            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, true>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act, tp.cps, part, Batch{0, 0, 0, 0});  \
+            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, true, TAG_>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act, tp.cps, part, Batch{0, 0, 0, 0});  \
         else if (veca)                                                                                             \
-            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, false>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act, tp.cps, part, Batch{0, 0, 0, 0}); \
+            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, false, TAG_>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act, tp.cps, part, Batch{0, 0, 0, 0}); \
         else if (vecb)                                                                                             \
-            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, false, true>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act, tp.cps, part, Batch{0, 0, 0, 0}); \
+            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, false, true, TAG_>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act, tp.cps, part, Batch{0, 0, 0, 0}); \
         else                                                                                                       \
-            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, false, false>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act, tp.cps, part, Batch{0, 0, 0, 0});\
+            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, false, false, TAG_>), grid, dim3(256), 0, st, gg, dy, w, bias, dx, act, tp.cps, part, Batch{0, 0, 0, 0});\
     } while (0)
+#define MG_LAUNCH_DGRAD(BM_, BN_) do { if (hp) MG_LAUNCH_DGRAD_T(BM_, BN_, 2); else MG_LAUNCH_DGRAD_T(BM_, BN_, 0); } while (0)
     probe_begin(st);
     if (tp.bm == 128 && tp.bn == 128) MG_LAUNCH_DGRAD(128, 128);
     else if (tp.bm == 64) MG_LAUNCH_DGRAD(64, 64);
     else MG_LAUNCH_DGRAD(128, 64);
     probe_end(st);
+#undef MG_LAUNCH_DGRAD_T
 #undef MG_LAUNCH_DGRAD
     MG_CHECK_LAUNCH();
     if (part) {
         const size_t n = (size_t)g->B * g->H * g->W * N;
         const unsigned blocks = (unsigned)((n / 4 + 255) / 256 > 4096 ? 4096 : (n / 4 + 255) / 256);
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, (const float*)part, tp.splits, n, N,
-                           bias, act, dx);
+                           bias, act, dx, (int)hp);
         MG_CHECK_LAUNCH();
     }
     return MG_OK;
@@ -1460,7 +1519,7 @@ int mg_colsum(const float* a, long long M, int C, float* out, int accumulate, vo
 
 size_t mg_conv_wgrad_workspace(const mg_conv_geom* g) {
     if (!geom_ok(g)) return 0;
-    if (mg_conv_rowdot_kq(g)) return mg_conv_rowdot_wgrad_workspace(g);
+    if (!prec_h(g) && mg_conv_rowdot_kq(g)) return mg_conv_rowdot_wgrad_workspace(g);
     if (wino_ok(g)) return wino_wgrad_ws(g);
     const WgradPlan p = wgrad_plan(g);
     const size_t wg = p.splits > 1 ? (size_t)p.splits * g->Co * g->KH * g->KW * g->Ci * sizeof(float) : 0;
@@ -1472,7 +1531,7 @@ int mg_conv_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float*
                   void* workspace, size_t workspace_bytes, void* stream) {
     if (!geom_ok(g) || !x || !dy || !dw) return MG_ERR_ARG;
     if (workspace_bytes < mg_conv_wgrad_workspace(g) || !workspace) return MG_ERR_ARG;
-    if (mg_conv_rowdot_kq(g) && aligned16(x) && aligned16(workspace)) {
+    if (!prec_h(g) && mg_conv_rowdot_kq(g) && aligned16(x) && aligned16(workspace)) {
         probe_begin((hipStream_t)stream);
         const int rc = mg_conv_rowdot_wgrad(g, x, dy, dw, dbias, accumulate, workspace, workspace_bytes, stream);
         probe_end((hipStream_t)stream);
@@ -1499,22 +1558,25 @@ int mg_conv_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float*
     const size_t n_out = (size_t)g->Co * g->KH * g->KW * g->Ci;
     float* target = p.splits > 1 ? (float*)workspace : dw;
     const int acc_direct = (p.splits > 1) ? 0 : accumulate;
-#define MG_LAUNCH_WGRAD(BM_, BN_)                                                                                   \
+    const bool hp = prec_h(g);
+#define MG_LAUNCH_WGRAD_T(BM_, BN_, TAG_)                                                                           \
     do {                                                                                                            \
         dim3 grid((unsigned)p.tiles, 1, p.splits);                                                                  \
         if (veca && vecb)                                                                                           \
-            hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, true, true>), grid, dim3(256), 0, st, gg, x, dy, target, p.cps, acc_direct, Batch{0, 0, 0, 0});  \
+            hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, true, true, TAG_>), grid, dim3(256), 0, st, gg, x, dy, target, p.cps, acc_direct, Batch{0, 0, 0, 0});  \
         else if (veca)                                                                                              \
-            hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, true, false>), grid, dim3(256), 0, st, gg, x, dy, target, p.cps, acc_direct, Batch{0, 0, 0, 0}); \
+            hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, true, false, TAG_>), grid, dim3(256), 0, st, gg, x, dy, target, p.cps, acc_direct, Batch{0, 0, 0, 0}); \
         else if (vecb)                                                                                              \
-            hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, false, true>), grid, dim3(256), 0, st, gg, x, dy, target, p.cps, acc_direct, Batch{0, 0, 0, 0}); \
+            hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, false, true, TAG_>), grid, dim3(256), 0, st, gg, x, dy, target, p.cps, acc_direct, Batch{0, 0, 0, 0}); \
         else                                                                                                        \
-            hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, false, false>), grid, dim3(256), 0, st, gg, x, dy, target, p.cps, acc_direct, Batch{0, 0, 0, 0});\
+            hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, false, false, TAG_>), grid, dim3(256), 0, st, gg, x, dy, target, p.cps, acc_direct, Batch{0, 0, 0, 0});\
     } while (0)
+#define MG_LAUNCH_WGRAD(BM_, BN_) do { if (hp) MG_LAUNCH_WGRAD_T(BM_, BN_, 2); else MG_LAUNCH_WGRAD_T(BM_, BN_, 0); } while (0)
     probe_begin(st);
     if (p.big) MG_LAUNCH_WGRAD(128, 128);
     else MG_LAUNCH_WGRAD(64, 64);
     probe_end(st);
+#undef MG_LAUNCH_WGRAD_T
 #undef MG_LAUNCH_WGRAD
     MG_CHECK_LAUNCH();
     if (p.splits > 1) {

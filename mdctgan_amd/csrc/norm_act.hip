@@ -487,9 +487,46 @@ __global__ void adam_tick_kernel(double* __restrict__ state, double b1, double b
         state[3] = sqrt(1.0 - pow(b2, step));
     }
 }
+// ---- GradScaler on the device (train.py:65-70, 183-199).  scaler = {scale, growth_tracker, found_inf[slot]...} ----
+__global__ __launch_bounds__(256) void scaler_check_kernel(const float* __restrict__ g, size_t n, float* __restrict__ flag) {
+    bool bad = false;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = *reinterpret_cast<const float4*>(g + 4 * i);
+        bad |= !(fabsf(v.x) <= 3.4028234663852886e38f) | !(fabsf(v.y) <= 3.4028234663852886e38f) |
+               !(fabsf(v.z) <= 3.4028234663852886e38f) | !(fabsf(v.w) <= 3.4028234663852886e38f);
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) bad |= !(fabsf(g[i]) <= 3.4028234663852886e38f);
+    if (__any(bad) && (threadIdx.x & 63) == 0) *flag = 1.0f;     // every writer stores the same value
+}
+__global__ void scaler_update_kernel(float* __restrict__ sc, int slots, float growth, float backoff, int interval) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float found = 0.0f;
+    for (int i = 0; i < slots; ++i) { found += sc[2 + i]; sc[2 + i] = 0.0f; }
+    if (found != 0.0f) {
+        sc[0] *= backoff;
+        sc[1] = 0.0f;
+    } else {
+        const float t = sc[1] + 1.0f;
+        if (t >= (float)interval) { sc[0] *= growth; sc[1] = 0.0f; }
+        else sc[1] = t;
+    }
+}
+__global__ void adam_tick_amp_kernel(double* __restrict__ state, double b1, double b2, const float* __restrict__ flag) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && *flag == 0.0f) {
+        const double step = state[0] + 1.0;
+        state[0] = step;
+        state[2] = state[1] / (1.0 - pow(b1, step));
+        state[3] = sqrt(1.0 - pow(b2, step));
+    }
+}
 __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                 float* __restrict__ v, size_t n, const double* __restrict__ state, float b1, float b2,
-                                float eps, float gscale) {
+                                float eps, float gscale, const float* __restrict__ loss_scale,
+                                const float* __restrict__ found_inf) {
+    if (found_inf && *found_inf != 0.0f) return;          // GradScaler.step: skip the update on inf / nan gradients
+    if (loss_scale) gscale = gscale / *loss_scale;        // unscale
     const float step_size = (float)state[2], bc2_sqrt = (float)state[3];
     const size_t n4 = n / 4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -737,7 +774,41 @@ int mg_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, 
     if (!p || !g || !m || !v || !state || n <= 0) return MG_ERR_ARG;
     if (!al16(p) || !al16(g) || !al16(m) || !al16(v)) return MG_ERR_ARG;
     hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for((size_t)n, 8)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                       (size_t)n, state, beta1, beta2, eps, grad_scale);
+                       (size_t)n, state, beta1, beta2, eps, grad_scale, (const float*)nullptr, (const float*)nullptr);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+int mg_scaler_check(const float* g, long long n, float* scaler, int slot, void* stream) {
+    if (!g || !scaler || n <= 0 || slot < 0 || slot >= MG_SCALER_SLOTS || !al16(g)) return MG_ERR_ARG;
+    hipLaunchKernelGGL(scaler_check_kernel, dim3(grid_for((size_t)n, 16)), dim3(256), 0, (hipStream_t)stream, g, (size_t)n,
+                       scaler + 2 + slot);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+int mg_scaler_update(float* scaler, float growth_factor, float backoff_factor, int growth_interval, void* stream) {
+    if (!scaler || growth_interval < 1) return MG_ERR_ARG;
+    hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scaler, MG_SCALER_SLOTS,
+                       growth_factor, backoff_factor, growth_interval);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+int mg_adam_tick_amp(double* state, float beta1, float beta2, const float* scaler, int slot, void* stream) {
+    if (!state || !scaler || slot < 0 || slot >= MG_SCALER_SLOTS) return MG_ERR_ARG;
+    hipLaunchKernelGGL(adam_tick_amp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, (double)beta1,
+                       (double)beta2, scaler + 2 + slot);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+int mg_adam_step_amp(float* p, const float* g, float* m, float* v, long long n, const double* state, float beta1,
+                     float beta2, float eps, float grad_scale, const float* scaler, int slot, void* stream) {
+    if (!p || !g || !m || !v || !state || !scaler || n <= 0 || slot < 0 || slot >= MG_SCALER_SLOTS) return MG_ERR_ARG;
+    if (!al16(p) || !al16(g) || !al16(m) || !al16(v)) return MG_ERR_ARG;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for((size_t)n, 8)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                       (size_t)n, state, beta1, beta2, eps, grad_scale, scaler, scaler + 2 + slot);
     MG_CHECK_LAUNCH();
     return MG_OK;
 }

@@ -13,7 +13,7 @@ import os
 
 import torch
 
-from . import ops
+from . import amp, ops
 from ._lib import ACT_LRELU02, ACT_NONE, ACT_RELU, ACT_TANH  # noqa: F401
 
 CL = torch.channels_last
@@ -112,7 +112,7 @@ class _ConvFn(torch.autograd.Function):
         if not transposed:
             Co, Ci = w.shape[0], w.shape[1]
             assert Ci == x.shape[1]
-            g = ops.conv_geom(B, H, W, Ci, Co, KH, KW, stride, pad, reflect)
+            g = ops.conv_geom(B, H, W, Ci, Co, KH, KW, stride, pad, reflect, amp.current_precision())
             # Winograd layers: transform the weights once, reuse the image for the data gradient of this step
             u = ops.wino_weights(g, w) if ctx.needs_input_grad[0] else None
             y = ops.conv_fwd(g, nhwc_view(x), w, b, act, u)
@@ -122,7 +122,8 @@ class _ConvFn(torch.autograd.Function):
             # high-res [B, sH, sW, Cout_T] -> low-res [B, H, W, Cin_T]
             cin_t, cout_t = w.shape[0], w.shape[1]
             assert cin_t == x.shape[1]
-            g = ops.conv_geom(B, stride * H, stride * W, cout_t, cin_t, KH, KW, stride, pad, False)
+            g = ops.conv_geom(B, stride * H, stride * W, cout_t, cin_t, KH, KW, stride, pad, False,
+                              amp.current_precision())
             assert (g.OH, g.OW) == (H, W), "unsupported ConvTranspose2d geometry"
             y = ops.conv_dgrad(g, nhwc_view(x), w, b, act)
         y = nchw_view(y)

@@ -8,10 +8,12 @@ from . import _lib
 from ._lib import ACT_LRELU02, ACT_NONE, ACT_RELU, ACT_TANH, ConvGeom  # noqa: F401
 
 
-def conv_geom(B, H, W, Ci, Co, KH, KW, stride, pad, reflect) -> ConvGeom:
+def conv_geom(B, H, W, Ci, Co, KH, KW, stride, pad, reflect, precision=0) -> ConvGeom:
+    """precision: _lib.PRECISION_F32 (exact float32) or _lib.PRECISION_F16 (autocast arithmetic: f16 MFMA products,
+    float32 accumulation, forward / data-gradient outputs rounded through float16)."""
     OH = (H + 2 * pad - KH) // stride + 1
     OW = (W + 2 * pad - KW) // stride + 1
-    return ConvGeom(B, H, W, Ci, OH, OW, Co, KH, KW, stride, pad, int(bool(reflect)))
+    return ConvGeom(B, H, W, Ci, OH, OW, Co, KH, KW, stride, pad, int(bool(reflect)), int(precision))
 
 
 def _ws(nbytes, dev):
@@ -241,6 +243,30 @@ def adam_step_dev(p, g, m, v, state, beta1, beta2, eps, grad_scale=1.0):
     lib = _lib.load()
     _lib.check(lib.mg_adam_step_dev(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), p.numel(), _lib.ptr(state),
                                     beta1, beta2, eps, grad_scale, _lib.stream()), "mg_adam_step_dev")
+
+
+def scaler_check(g, scaler, slot):
+    lib = _lib.load()
+    _lib.check(lib.mg_scaler_check(_lib.ptr(g), g.numel(), _lib.ptr(scaler), slot, _lib.stream()), "mg_scaler_check")
+
+
+def scaler_update(scaler, growth_factor, backoff_factor, growth_interval):
+    lib = _lib.load()
+    _lib.check(lib.mg_scaler_update(_lib.ptr(scaler), growth_factor, backoff_factor, growth_interval, _lib.stream()),
+               "mg_scaler_update")
+
+
+def adam_tick_amp(state, beta1, beta2, scaler, slot):
+    lib = _lib.load()
+    _lib.check(lib.mg_adam_tick_amp(_lib.ptr(state), beta1, beta2, _lib.ptr(scaler), slot, _lib.stream()),
+               "mg_adam_tick_amp")
+
+
+def adam_step_amp(p, g, m, v, state, beta1, beta2, eps, grad_scale, scaler, slot):
+    lib = _lib.load()
+    _lib.check(lib.mg_adam_step_amp(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), p.numel(), _lib.ptr(state),
+                                    beta1, beta2, eps, grad_scale, _lib.ptr(scaler), slot, _lib.stream()),
+               "mg_adam_step_amp")
 
 
 def batchnorm_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, training, residual=None, act=ACT_NONE):

@@ -82,7 +82,10 @@ class FusedAdam(torch.optim.Optimizer):
         Fh.mark_fresh(self._params)
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, scaler_state=None, scaler_slot=0):
+        """scaler_state (mdctgan_amd.amp.GradScaler.state): the gradients hold loss-scaled values; check them for
+        inf / nan, divide by the scale inside the Adam kernel and skip the whole update -- step counter included --
+        when the check fired (GradScaler.step semantics), all on the device."""
         if not self._built:
             self._build()
         if self.pre_step_hook is not None:
@@ -95,7 +98,6 @@ class FusedAdam(torch.optim.Optimizer):
                 raise RuntimeError("learning-rate changes must happen outside graph capture")
             self.state[1] = lr
             self._lr_on_device = lr
-        ops.adam_tick(self.state, b1, b2)
         # contiguous runs of parameters that received a gradient this step (normally a single run = everything)
         runs, start = [], None
         for i, p in enumerate(self._params):
@@ -107,9 +109,21 @@ class FusedAdam(torch.optim.Optimizer):
                 start = None
         if start is not None:
             runs.append((start, len(self._params)))
+        spans = []
         for a, b in runs:
             lo = self.offsets[a]
             hi = self.total if b == len(self._params) else self.offsets[b]
-            ops.adam_step_dev(self.flat_p[lo:hi], self.flat_g[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi],
-                              self.state, b1, b2, eps, self.grad_scale)
+            spans.append((lo, hi))
+        if scaler_state is None:
+            ops.adam_tick(self.state, b1, b2)
+            for lo, hi in spans:
+                ops.adam_step_dev(self.flat_p[lo:hi], self.flat_g[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi],
+                                  self.state, b1, b2, eps, self.grad_scale)
+        else:
+            for lo, hi in spans:
+                ops.scaler_check(self.flat_g[lo:hi], scaler_state, scaler_slot)
+            ops.adam_tick_amp(self.state, b1, b2, scaler_state, scaler_slot)
+            for lo, hi in spans:
+                ops.adam_step_amp(self.flat_p[lo:hi], self.flat_g[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi],
+                                  self.state, b1, b2, eps, self.grad_scale, scaler_state, scaler_slot)
         return None

@@ -15,6 +15,7 @@ from typing import Dict
 import torch
 
 from . import _lib, networks
+from . import amp
 from . import functional as Fh
 from .mdct import IMDCT4, MDCT4, dct4_table, imdct4_codec, kbdwin, mdct4_codec
 from .optim import FusedAdam
@@ -213,8 +214,10 @@ class Pix2PixHDModel(BaseModel):
         for k, v in vars(opt).items():
             setattr(self, k, v)
         self.isTrain = opt.isTrain
-        if getattr(opt, "fp16", False):
-            raise NotImplementedError("--fp16 (AMP) kernels are not built yet on the HIP path; run float32")
+        # --fp16 (train.py:65-70): autocast arithmetic for the convolutions + one device-side GradScaler
+        self.fp16 = bool(getattr(opt, "fp16", False))
+        self.scaler = amp.GradScaler(device=self.device if hasattr(self, "device") else "cuda") if (
+            self.fp16 and self.isTrain) else None
         input_nc = opt.label_nc if opt.label_nc != 0 else opt.input_nc
         self.preprocess = Audio2MDCT(opt)
         self.preprocess.return_stats = False
@@ -323,21 +326,32 @@ class Pix2PixHDModel(BaseModel):
     def optimize_parameters(self, lr_audio, hr_audio):
         """One train.py:160-202 iteration (float32 branch): forward, G step, D step.  Returns the loss dict
         (device scalars; call .item() only when you need to print)."""
-        losses, _ = self._forward(lr_audio, hr_audio, infer=False)
+        with amp.autocast(self.fp16):
+            losses, _ = self._forward(lr_audio, hr_audio, infer=False)
         loss_dict = dict(zip(self.loss_names, losses))
         loss_D = (loss_dict["D_fake"] + loss_dict["D_real"]) * 0.5
         loss_G = loss_dict["G_GAN"] + loss_dict.get("G_GAN_Feat", 0)
         red = getattr(self, "reducers", None)      # data-parallel gradient reducers (mdctgan_amd.ddp.attach)
+        sc = self.scaler                           # train.py:183-199: one GradScaler, updated once per iteration
         if red:
             red["G"].active, red["D"].active = True, False
         self.optimizer_G.zero_grad()
-        loss_G.backward()
-        self.optimizer_G.step()
+        if sc is not None:
+            sc.scale(loss_G).backward()
+            sc.step(self.optimizer_G)
+        else:
+            loss_G.backward()
+            self.optimizer_G.step()
         if red:
             red["G"].active, red["D"].active = False, True
         self.optimizer_D.zero_grad()
-        loss_D.backward()
-        self.optimizer_D.step()
+        if sc is not None:
+            sc.scale(loss_D).backward()
+            sc.step(self.optimizer_D)
+            sc.update()
+        else:
+            loss_D.backward()
+            self.optimizer_D.step()
         return loss_dict
 
     def make_graphed_step(self, lr_audio, hr_audio, warmup=3):

@@ -224,6 +224,48 @@ def main():
     save("g8_stitch", seg=seg.numpy(), overlap=np.array(ov), stitched=a.numpy(),
          concat=seg.reshape(1, -1).numpy())
 
+    # ---- G9 the --fp16 branch of train.py:160-202: autocast forward + one GradScaler ----------------------
+    # torch.autocast("cpu", float16) stands in for torch.cuda.amp.autocast (same cast policy for conv / conv_transpose
+    # -> float16, instance_norm / relu / tanh follow their input, mse_loss / l1_loss -> float32); torch.amp.GradScaler
+    # ("cpu") for torch.cuda.amp.GradScaler (same defaults: 65536, x2 / x0.5, interval 2000).
+    model = quiet(lambda: rmodel.Pix2PixHDModel())
+    quiet(model.initialize, opt)
+    onets.fill_deterministic(model.netG)
+    onets.fill_deterministic(model.netD)
+    hr = 0.05 * torch.randn(2, 7936, generator=g)
+    spec = torch.fft.rfft(hr)
+    spec[:, spec.shape[-1] // 4:] = 0
+    lr = torch.fft.irfft(spec, n=hr.shape[-1])
+    scaler = torch.amp.GradScaler("cpu")
+    hist = []
+    for it in range(2):
+        torch.manual_seed(0)
+        with torch.autocast("cpu", dtype=torch.float16):
+            losses, _ = model._forward(lr, hr, infer=False)
+        ld = dict(zip(model.loss_names, [torch.mean(v) for v in losses]))
+        loss_D = (ld["D_fake"] + ld["D_real"]) * 0.5
+        loss_G = ld["G_GAN"] + ld["G_GAN_Feat"]
+        model.optimizer_G.zero_grad()
+        scaler.scale(loss_G).backward()
+        if it == 0:
+            gG = {k: p.grad.clone() / scaler.get_scale() for k, p in model.netG.named_parameters()}
+        scaler.step(model.optimizer_G)
+        model.optimizer_D.zero_grad()
+        scaler.scale(loss_D).backward()
+        if it == 0:
+            gD = {k: p.grad.clone() / scaler.get_scale() for k, p in model.netD.named_parameters()}
+        scaler.step(model.optimizer_D)
+        scaler.update()
+        hist.append([float(ld[k]) for k in model.loss_names] + [scaler.get_scale()])
+    arrs = dict(lr=lr.numpy(), hr=hr.numpy(), loss_names=np.array(model.loss_names),
+                losses=np.array(hist[0][:-1]), losses_step2=np.array(hist[1][:-1]),
+                scale_after=np.array([h[-1] for h in hist]))
+    for k, v in gG.items():
+        arrs["gG/" + k] = v.numpy()
+    for k, v in gD.items():
+        arrs["gD/" + k] = v.numpy()
+    save("g9_step_global_fp16", **arrs)
+
 
 if __name__ == "__main__":
     main()

@@ -66,17 +66,33 @@ class HotPathRef:
         losses = {"G_GAN": loss_G_GAN, "G_GAN_Feat": loss_G_feat, "D_real": loss_D_real, "D_fake": loss_D_fake}
         return losses, sr_s
 
-    def train_step(self, lr_audio, hr_audio):
-        """One train.py:160-202 iteration (fp32 branch).  Returns the loss dict (floats)."""
-        losses, _ = self.forward_losses(lr_audio, hr_audio)
+    def train_step(self, lr_audio, hr_audio, amp=False, scaler=None):
+        """One train.py:160-202 iteration.  amp=False: the fp32 branch.  amp=True: the --fp16 branch -- the forward
+        under torch.autocast(float16) (train.py:161-164; on the CPU here, same op lists for conv / norm / losses) and
+        one GradScaler (torch.amp.GradScaler("cpu")): scale(loss).backward(), scaler.step(opt) for G then D,
+        scaler.update() once (train.py:183-199).  Returns the loss dict (floats)."""
+        if amp:
+            with torch.autocast("cpu", dtype=torch.float16):
+                losses, _ = self.forward_losses(lr_audio, hr_audio)
+        else:
+            losses, _ = self.forward_losses(lr_audio, hr_audio)
         loss_D = (losses["D_fake"] + losses["D_real"]) * 0.5
         loss_G = losses["G_GAN"] + losses["G_GAN_Feat"]
         self.opt_G.zero_grad()
-        loss_G.backward()
-        self.opt_G.step()
+        if amp:
+            scaler.scale(loss_G).backward()
+            scaler.step(self.opt_G)
+        else:
+            loss_G.backward()
+            self.opt_G.step()
         self.opt_D.zero_grad()
-        loss_D.backward()
-        self.opt_D.step()
+        if amp:
+            scaler.scale(loss_D).backward()
+            scaler.step(self.opt_D)
+            scaler.update()
+        else:
+            loss_D.backward()
+            self.opt_D.step()
         return {k: float(v) for k, v in losses.items()}
 
     # -- inference -----------------------------------------------------

@@ -1,0 +1,184 @@
+"""--fp16 (train.py:65-70, 161-164, 183-199) on the HIP path: MG_PRECISION_F16 convolutions against a float64
+evaluation of the same autocast arithmetic (operands rounded to float16, exact products, wide accumulation, outputs
+rounded through float16), the device-side GradScaler against torch's rules, and the whole AMP step against the
+reference's captured losses (fixture G9) and the oracle's CPU-autocast step.
+Tolerances: a float16-rounded output may land one float16 ulp (2^-10 relative) from the float64 evaluation's rounding;
+weight gradients stay float32 (3e-5 of max, as in test_conv_gpu.py); losses rtol 2e-2."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import nets as onets
+from oracle import step as ostep
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+# (name, B, Ci, H, W, Co, k, stride, pad, reflect)
+CASES = [
+    ("res3x3_reflect", 2, 32, 8, 16, 32, 3, 1, 1, True),
+    ("stem7x7_reflect_ci2", 2, 2, 32, 64, 16, 7, 1, 3, True),
+    ("head7x7_reflect_co1", 2, 16, 32, 64, 1, 7, 1, 3, True),
+    ("down3x3_s2", 2, 16, 32, 64, 32, 3, 2, 1, False),
+    ("d4x4_s2_ci3", 2, 3, 32, 64, 16, 4, 2, 2, False),
+    ("d4x4_s1", 2, 32, 5, 9, 64, 4, 1, 2, False),
+    ("d4x4_s1_co1", 2, 64, 6, 10, 1, 4, 1, 2, False),
+    ("wide_128tile", 2, 64, 16, 32, 256, 3, 1, 1, True),
+    ("bottleneck_like", 8, 128, 8, 16, 128, 3, 1, 1, True),
+    ("conv1x1", 2, 64, 4, 8, 48, 1, 1, 0, False),
+]
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def h(t):
+    """Tensor.half() rounding, kept in float64."""
+    return t.float().half().double()
+
+
+def close_f16(got, want):
+    """got: float32 values that went through float16; want: float64 before rounding.  1.5 float16 ulps of the element
+    plus half an ulp of the largest element: the float32 accumulation error scales with the terms, not with a
+    cancelling result, and a reflection-padded data gradient sums its aliased dy taps BEFORE the float16 rounding
+    (autocast rounds the padded-domain gradient first and folds afterwards -- one rounding either way)."""
+    got = got.double().cpu()
+    tol = 1.5 * 2.0 ** -10 * want.abs() + 2.0 ** -11 * want.abs().max()
+    bad = (got - want).abs() > tol
+    assert not bad.any(), ((got - want).abs().max().item(), want.abs().max().item(), int(bad.sum()))
+    assert torch.equal(got.float().half().float().double(), got), "output is not float16-representable"
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_f16_precision(case):
+    from mdctgan_amd import _lib, ops
+    name, B, Ci, H, W, Co, k, s, p, reflect = case
+    gen = torch.Generator().manual_seed(len(name) * 7 + Ci)
+    x = torch.randn(B, Ci, H, W, generator=gen, dtype=torch.float64)
+    w = torch.randn(Co, Ci, k, k, generator=gen, dtype=torch.float64) / np.sqrt(Ci * k * k)
+    b = torch.randn(Co, generator=gen, dtype=torch.float64)
+    xh, wh = h(x).requires_grad_(), h(w).requires_grad_()
+    xp = F.pad(xh, (p, p, p, p), mode="reflect") if (reflect and p) else xh
+    y = F.conv2d(xp, wh, b, stride=s, padding=0 if (reflect and p) else p)
+    gy = torch.randn(y.shape, generator=gen, dtype=torch.float64)
+    y.backward(h(gy))
+
+    g = ops.conv_geom(B, H, W, Ci, Co, k, k, s, p, reflect, _lib.PRECISION_F16)
+    xd, wd, bd = nhwc(x).float().to(DEV), nhwc(w).float().to(DEV), b.float().to(DEV)
+    gyd = nhwc(gy).float().to(DEV)
+    close_f16(ops.conv_fwd(g, xd, wd, bd), nhwc(y.detach()))
+    close_f16(ops.conv_dgrad(g, gyd, wd), nhwc(xh.grad))
+    dw = torch.full((Co, k, k, Ci), 7.0, dtype=torch.float32, device=DEV)
+    ops.conv_wgrad(g, xd, gyd, dw, None)
+    want = nhwc(wh.grad)
+    assert (dw.double().cpu() - want).abs().max().item() <= 3e-5 * want.abs().max().item()
+    ops.conv_wgrad(g, xd, gyd, dw, None, accumulate=True)
+    assert (dw.double().cpu() - 2 * want).abs().max().item() <= 6e-5 * want.abs().max().item()
+
+
+def test_conv_f16_overflow_becomes_inf():
+    """A forward / data-gradient output beyond 65504 rounds to inf, as a float16 tensor would."""
+    from mdctgan_amd import _lib, ops
+    g = ops.conv_geom(1, 4, 4, 16, 16, 1, 1, 1, 0, False, _lib.PRECISION_F16)
+    x = torch.full((1, 4, 4, 16), 300.0, device=DEV)
+    w = torch.full((16, 1, 1, 16), 20.0, device=DEV)
+    assert torch.isinf(ops.conv_fwd(g, x, w, None)).all()           # 16 * 300 * 20 = 96000
+    assert torch.isinf(ops.conv_dgrad(g, x, w)).all()
+    dw = torch.empty(16, 1, 1, 16, device=DEV)
+    ops.conv_wgrad(g, x, x, dw, None)
+    assert torch.isfinite(dw).all() and dw[0, 0, 0, 0].item() == 16 * 300.0 * 300.0   # weight gradients stay float32
+
+
+def test_grad_scaler_kernels():
+    """mg_scaler_check / mg_adam_*_amp / mg_scaler_update == GradScaler.step / update semantics."""
+    from mdctgan_amd import amp
+    from mdctgan_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    p = torch.nn.Parameter(torch.randn(1000, device=DEV))
+    q = torch.nn.Parameter(torch.randn(1000, device=DEV))
+    opt_p, opt_q = FusedAdam([p], lr=1e-2, betas=(0.5, 0.999)), FusedAdam([q], lr=1e-2, betas=(0.5, 0.999))
+    ref_p = p.detach().clone().cpu().requires_grad_()
+    ref_opt = torch.optim.Adam([ref_p], lr=1e-2, betas=(0.5, 0.999))
+    sc = amp.GradScaler(init_scale=1024.0, growth_interval=2)
+    for it in range(5):
+        gp, gq = torch.randn(1000), torch.randn(1000)
+        overflow = it == 1
+        opt_p.zero_grad(); opt_q.zero_grad()
+        p.grad.copy_((gp * sc.get_scale()).to(DEV)); p._mg_fresh = False
+        q.grad.copy_((gq * sc.get_scale()).to(DEV)); q._mg_fresh = False
+        if overflow:
+            q.grad[17] = float("inf")
+        scale_before = sc.get_scale()
+        q_before = q.detach().clone()
+        sc.step(opt_p)
+        sc.step(opt_q)
+        sc.update()
+        ref_opt.zero_grad(); ref_p.grad = gp.clone(); ref_opt.step()      # p never overflows: steps every iteration
+        assert (p.detach().cpu() - ref_p.detach()).abs().max().item() < 1e-6
+        if overflow:
+            assert torch.equal(q.detach(), q_before), "step must be skipped on inf gradients"
+            assert sc.get_scale() == scale_before * 0.5
+        else:
+            assert not torch.equal(q.detach(), q_before)
+    # iterations 0 (ok) 1 (inf: x0.5, tracker 0) 2, 3 (ok, ok: x2 at interval 2) 4 (ok)
+    assert sc.get_scale() == 1024.0 and int(sc.state[1].item()) == 1
+    assert sc.state_dict()["scale"] == 1024.0
+
+
+def make_fp16_model():
+    from mdctgan_amd import options
+    from mdctgan_amd.pix2pixHD_model import create_model
+    opt = options.make_opt(*options.SPECTRAL_FLAGS, "--lr_sampling_rate", "12000", "--netG", "global", "--ngf", "4",
+                           "--n_blocks_global", "2", "--n_blocks_attn_g", "0", "--num_D", "2", "--ndf", "8",
+                           "--batchSize", "2", "--bins", "32", "--segment_length", "7936", "--gpu_ids", "0", "--fp16")
+    model = create_model(opt)
+    onets.fill_deterministic(model.netG)
+    onets.fill_deterministic(model.netD)
+    return model
+
+
+def oracle_model():
+    netG = onets.fill_deterministic(onets.build_generator("global", 2, 1, 4, 4, 2, input_size=(32, 256)))
+    netD = onets.fill_deterministic(onets.MultiscaleDRef(3, ndf=8, n_layers=3, num_D=2))
+    return ostep.HotPathRef(netG, netD, ostep.CodecCfg(), num_D=2)
+
+
+def test_fp16_step_against_reference_and_oracle(golden):
+    g = golden("g9_step_global_fp16")
+    lr, hr = torch.from_numpy(g["lr"]).to(DEV), torch.from_numpy(g["hr"]).to(DEV)
+    model = make_fp16_model()
+    assert model.fp16 and model.scaler is not None and model.scaler.get_scale() == 65536.0
+    # 1) forward losses under autocast vs the reference's (captured under torch.autocast(float16))
+    want = dict(zip(g["loss_names"], g["losses"]))
+    ld = model.optimize_parameters(lr, hr)
+    for k in model.loss_names:
+        assert abs(ld[k].item() - want[k]) <= 2e-2 * abs(want[k]) + 1e-3, (k, ld[k].item(), want[k])
+    # 2) an overflowing scale: every update is skipped, the scale halves once per iteration (train.py:199)
+    model2 = make_fp16_model()
+    model2.scaler.state[0] = 2.0 ** 60
+    before = {k: v.detach().clone() for k, v in model2.netG.state_dict().items()}
+    model2.optimize_parameters(lr, hr)
+    assert model2.scaler.get_scale() == 2.0 ** 59
+    for k, v in model2.netG.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    assert model2.optimizer_G.state[0].item() == 0        # Adam's step counter did not advance
+    # 3) a scale at which the reference's float16 gradients stay finite (256: the oracle's scale stops halving there):
+    #    three AMP iterations of the HIP path beside the oracle's CPU-autocast iterations.  The first Adam step moves
+    #    every weight by +-lr whatever the gradient's size, so float16-noise sign flips on this 1000x-amplifying toy
+    #    net separate the trajectories by a few percent after one update: 2e-2 before any update, 1e-1 after.
+    model3, ref = make_fp16_model(), oracle_model()
+    model3.scaler.state[0] = 256.0
+    rs = torch.amp.GradScaler("cpu", init_scale=256.0)
+    for it in range(3):
+        lh = model3.optimize_parameters(lr, hr)
+        lo = ref.train_step(g["lr"], g["hr"], amp=True, scaler=rs)
+        rtol = 2e-2 if it == 0 else 1e-1
+        for k in model3.loss_names:
+            assert abs(lh[k].item() - lo[k]) <= rtol * abs(lo[k]) + 2e-3, (it, k, lh[k].item(), lo[k])
+    assert model3.scaler.get_scale() == rs.get_scale() == 256.0
+    assert model3.optimizer_G.state[0].item() == 3 and model3.optimizer_D.state[0].item() == 3
+    # inference is float32 (generate_audio.py has no autocast)
+    sr_spectro, sr_audio, *_ = model3.inference(lr)
+    assert torch.isfinite(sr_audio).all() and sr_spectro.dtype == torch.float32

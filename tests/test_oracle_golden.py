@@ -186,6 +186,27 @@ def test_step_matches_reference(golden):
     assert np.abs(audio_ref_in - g["inf_sr_audio"]).max() <= 1e-12 * max(1.0, np.abs(g["inf_sr_audio"]).max())
 
 
+def test_amp_step_matches_reference(golden):
+    """train.py:160-202, --fp16 branch (fixture G9: the reference's _forward under autocast(float16) + one GradScaler,
+    two iterations).  With these weights the scaled generator gradients overflow float16 at 65536 and 32768: both
+    iterations are skipped and the scale halves twice -- the oracle must reproduce losses, skips and scale."""
+    g = golden("g9_step_global_fp16")
+    netG = nets.fill_deterministic(nets.build_generator("global", 2, 1, 4, 4, 2, input_size=(32, 256)))
+    netD = nets.fill_deterministic(nets.MultiscaleDRef(3, ndf=8, n_layers=3, num_D=2))
+    ref = step.HotPathRef(netG, netD, step.CodecCfg(), num_D=2)
+    scaler = torch.amp.GradScaler("cpu")
+    want = dict(zip(g["loss_names"], g["losses"]))
+    want2 = dict(zip(g["loss_names"], g["losses_step2"]))
+    l1 = ref.train_step(g["lr"], g["hr"], amp=True, scaler=scaler)
+    for k, v in l1.items():
+        np.testing.assert_allclose(v, want[k], rtol=2e-3)      # float16 activations: 1e-3 steps
+    assert scaler.get_scale() == g["scale_after"][0]
+    l2 = ref.train_step(g["lr"], g["hr"], amp=True, scaler=scaler)
+    for k, v in l2.items():
+        np.testing.assert_allclose(v, want2[k], rtol=2e-3)
+    assert scaler.get_scale() == g["scale_after"][1]
+
+
 def test_stitch(golden):
     g = golden("g8_stitch")
     out = transform.stitch_segments(g["seg"], 7936, int(g["overlap"]))
