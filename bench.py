@@ -26,6 +26,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_F16_MFMA_TFLOPS = 2500.0     # dense f16 MFMA peak (same guide); kernels named "..., 2>" compute on it
 T_SEG, BATCH = 32512, 8
 
 
@@ -200,6 +201,7 @@ def main():
                     help="BASELINE.json configs index: 1 = netG global (the headline bench line); 2 = netG local + 2 "
                          "bottleneck-attention blocks, num_D 3, run in float32 (the reference config adds --fp16); "
                          "4 = inference, 8k->48k, batch 64 (implies --mode infer)")
+    ap.add_argument("--fp16", action="store_true", help="train.py --fp16: autocast convolutions (f16 MFMA) + GradScaler")
     ap.add_argument("--force-ddp", action="store_true", help="run the data-parallel code path even with one rank (testing)")
     args = ap.parse_args()
 
@@ -240,6 +242,10 @@ def main():
                      "--num_D", "3"]
         workload = ("configs[2] in FLOAT32 (the reference config adds --fp16): netG=local n_blocks_attn_g=2 heads_g=8 "
                     "dim_head_g=64 num_D=3, per-GPU batch 8 x 32512 samples, 12k->48k")
+    if args.fp16:
+        net_flags = net_flags + ["--fp16"]
+        workload = workload.replace("in FLOAT32 (the reference config adds --fp16)", "with --fp16").replace(
+            ", fp32", ", --fp16 (autocast convolutions on the f16 MFMA pipe, float32 storage, GradScaler)")
     opt = options.make_opt(*options.SPECTRAL_FLAGS, "--lr_sampling_rate", str(lr_rate), *net_flags,
                            "--batchSize", str(batch), "--gpu_ids", str(local_rank))
     model = create_model(opt)
@@ -308,8 +314,9 @@ def main():
     if timer is not None and timer.records:
         n, flops, secs, conv_flops = timer.summary()[dominant]
         achieved = flops / secs / 1e12
-        roofline = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        peak = PEAK_F16_MFMA_TFLOPS if dominant.rstrip().endswith(", 2>") else PEAK_F32_MFMA_TFLOPS
+        roofline = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                     "launches": n, "avg_launch_us": round(secs / n * 1e6, 2),
                     "flops_per_launch": flops / n,
                     "flops_definition": "FLOPs the kernel itself issues (2*M*N*K of its GEMM).  A '..., 1>' kernel is the "
@@ -337,7 +344,8 @@ def main():
             metric, value, unit = "infer audio-sec/sec", world * args.steps * batch * T_SEG / 48000.0 / dt, "audio-s/s"
         out = {"metric": metric, "value": round(value, 4), "unit": unit, "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "vs_baseline": None, "dtype": "f16 products / f32 accumulate (autocast)" if args.fp16 else "f32",
+               "data": "synthetic",
                "config": {"workload": workload,
                           "global_batch": batch * world, "segment_length": T_SEG,
                           "parallelism": "dp%d" % world, "launch": "hipGraph replay" if use_graph else "eager",

@@ -1339,12 +1339,12 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
                      prec_h(g) ? 2 : 0);
     } else if (pass == 1) {
         const TilePlan tp = dgrad_plan(g);
-        snprintf(out, out_len, "conv_dgrad_kernel<%d, %d, %s, %s, 0>", tp.bm, tp.bn, (g->Co % BK == 0) ? "true" : "false",
-                 (g->Ci % 4 == 0) ? "true" : "false");
+        snprintf(out, out_len, "conv_dgrad_kernel<%d, %d, %s, %s, %d>", tp.bm, tp.bn, (g->Co % BK == 0) ? "true" : "false",
+                 (g->Ci % 4 == 0) ? "true" : "false", prec_h(g) ? 2 : 0);
     } else if (pass == 2) {
         const WgradPlan p = wgrad_plan(g);
-        snprintf(out, out_len, "conv_wgrad_kernel<%d, %d, %s, %s, 0>", p.big ? 128 : 64, p.big ? 128 : 64,
-                 (g->Co % 4 == 0) ? "true" : "false", (g->Ci % 4 == 0) ? "true" : "false");
+        snprintf(out, out_len, "conv_wgrad_kernel<%d, %d, %s, %s, %d>", p.big ? 128 : 64, p.big ? 128 : 64,
+                 (g->Co % 4 == 0) ? "true" : "false", (g->Ci % 4 == 0) ? "true" : "false", prec_h(g) ? 2 : 0);
     } else {
         return MG_ERR_ARG;
     }
