@@ -26,7 +26,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
-PEAK_F16_MFMA_TFLOPS = 2500.0     # dense f16 MFMA peak (same guide); kernels named "..., 2>" compute on it
+PEAK_F16_MFMA_TFLOPS = 2500.0     # dense f16 MFMA peak (same guide); kernels named "..., 2>" / "..., 3>" compute on it
 T_SEG, BATCH = 32512, 8
 
 
@@ -316,7 +316,7 @@ def main():
     if timer is not None and timer.records:
         n, flops, secs, conv_flops = timer.summary()[dominant]
         achieved = flops / secs / 1e12
-        peak = PEAK_F16_MFMA_TFLOPS if dominant.rstrip().endswith(", 2>") else PEAK_F32_MFMA_TFLOPS
+        peak = PEAK_F16_MFMA_TFLOPS if dominant.rstrip().endswith((", 2>", ", 3>")) else PEAK_F32_MFMA_TFLOPS
         roofline = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                     "launches": n, "avg_launch_us": round(secs / n * 1e6, 2),

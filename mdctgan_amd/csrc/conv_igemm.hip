@@ -278,9 +278,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geom g, const float* __re
     float4 va[NVA], vb[NVB];
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) st_kcontig<LDA, (TAG == 2)>(As(buf), r0 + 64 * i, q, va[i]);
+        for (int i = 0; i < NVA; ++i) st_kcontig<LDA, (TAG >= 2)>(As(buf), r0 + 64 * i, q, va[i]);
 #pragma unroll
-        for (int i = 0; i < NVB; ++i) st_kcontig<LDB, (TAG == 2)>(Bs(buf), r0 + 64 * i, q, vb[i]);
+        for (int i = 0; i < NVB; ++i) st_kcontig<LDB, (TAG >= 2)>(Bs(buf), r0 + 64 * i, q, vb[i]);
     };
     if (c_begin < nchunks) {
         load_a(c_begin, va);
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geom g, const float* __re
         const int cur = (c - c_begin) & 1;
         auto f0 = [&]() { if (c + 1 < nchunks) stash(cur ^ 1); };
         auto f1 = [&]() { if (c + 2 < nchunks) { load_a(c + 2, va); load_b(c + 2, vb); } };
-        if (TAG == 2) mma_chunk_h<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
+        if (TAG >= 2) mma_chunk_h<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
         else mma_chunk<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
         __syncthreads();
     }
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geom g, const float* __re
                     if (part) part[(size_t)row * N + col] = acc[mi][ni][r];
                     else {
                         const float v = apply_act(acc[mi][ni][r] + bv, act);
-                        y[(size_t)row * N + col] = (TAG == 2) ? round_h(v) : v;
+                        y[(size_t)row * N + col] = (TAG >= 2) ? round_h(v) : v;
                     }
                 }
             }
@@ -508,13 +508,24 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = g.s;
     const int cls = blockIdx.z % (s * s), batch = blockIdx.z / (s * s);
-    const int py = cls / s, px = cls - py * s;
+    // Parity classes differ in tap count (3x3 stride 2: 1, 2, 2, 4 taps).  Workgroups are dispatched in blockIdx.z
+    // order, so the class with the most taps goes first (longest-processing-time-first: the short ones fill the tail).
+    int py = 0, px = 0;
+    if (s > 1) {
+        const int zi = cls / s, zj = cls - zi * s;
+        const int t0y = (g.KH - (g.p % s) + s - 1) / s, t1y = (g.KH - ((1 + g.p) % s) + s - 1) / s;
+        const int t0x = (g.KW - (g.p % s) + s - 1) / s, t1x = (g.KW - ((1 + g.p) % s) + s - 1) / s;
+        const int hy = t1y > t0y ? 1 : 0, hx = t1x > t0x ? 1 : 0;      // the heavier parity per axis (s == 2)
+        py = zi == 0 ? hy : 1 - hy;
+        px = zj == 0 ? hx : 1 - hx;
+    }
     const int Hc = (g.H - py + s - 1) / s, Wc = (g.W - px + s - 1) / s;   // pixels of this class
     const int M = g.B * Hc * Wc, N = g.Ci;
     dy += (size_t)batch * bt.sa;
     w += (size_t)(bt.wino_perm ? wino_flip(batch) : batch) * bt.sw;
     dx += (size_t)batch * bt.so;
-    if (part) part += ((size_t)blockIdx.y * (gridDim.z / (s * s)) + batch) * ((size_t)M * N);
+    // split-K slabs are whole dx images (classes write disjoint pixels of the same slab)
+    if (part) part += ((size_t)blockIdx.y * (gridDim.z / (s * s)) + batch) * ((size_t)g.B * g.H * g.W * N);
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     if ((int)blockIdx.x >= tiles_m * tiles_n) return;
     // taps that reach this class: ky = ky0 + s*i
@@ -525,8 +536,10 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
     const int Kc = ntap * g.Co;
     const int cpt = g.Co / BK;
     const int total_chunks = VECA ? ntap * cpt : (Kc + BK - 1) / BK;
-    const int c_begin = blockIdx.y * chunks_per_split;
-    const int nchunks = min(total_chunks, c_begin + chunks_per_split);   // exclusive end of this split
+    // stride > 1: the classes have different K, so each splits its own chunk range evenly over gridDim.y
+    const int cps = (s > 1 && gridDim.y > 1) ? (total_chunks + (int)gridDim.y - 1) / (int)gridDim.y : chunks_per_split;
+    const int c_begin = blockIdx.y * cps;
+    const int nchunks = min(total_chunks, c_begin + cps);   // exclusive end of this split
     const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int m0 = (t % tiles_m) * BM, n0 = (t / tiles_m) * BN;
     const int q = tid & 3, r0 = tid >> 2;
@@ -671,9 +684,9 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
     float4 va[NVA], vb[NVB];
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) st_kcontig<LDA, (TAG == 2)>(As(buf), r0 + 64 * i, q, va[i]);
+        for (int i = 0; i < NVA; ++i) st_kcontig<LDA, (TAG >= 2)>(As(buf), r0 + 64 * i, q, va[i]);
 #pragma unroll
-        for (int i = 0; i < NVB; ++i) st_rowcontig<LDB, (TAG == 2)>(Bs(buf), bk_l + i * (1024 / BN), 4 * bn_q, vb[i]);
+        for (int i = 0; i < NVB; ++i) st_rowcontig<LDB, (TAG >= 2)>(Bs(buf), bk_l + i * (1024 / BN), 4 * bn_q, vb[i]);
     };
     if (c_begin < nchunks) {
         load_a(c_begin, va);
@@ -689,7 +702,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
         const int cur = (c - c_begin) & 1;
         auto f0 = [&]() { if (c + 1 < nchunks) stash(cur ^ 1); };
         auto f1 = [&]() { if (c + 2 < nchunks) { load_a(c + 2, va); load_b(c + 2, vb); } };
-        if (TAG == 2) mma_chunk_h<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
+        if (TAG >= 2) mma_chunk_h<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
         else mma_chunk<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
         __syncthreads();
     }
@@ -707,12 +720,12 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
             for (int ni = 0; ni < NB; ++ni) {
                 const int col = n0 + wn0 + 32 * ni + (lane & 31);
                 if (col < N) {
-                    if (part) {   // split-K (stride 1 only: o == m * Ci)
+                    if (part) {   // split-K: raw partial sums at the pixel's own offset in the slab
                         part[o + col] = acc[mi][ni][r];
                     } else {
                         const float bv = bias ? bias[col] : 0.0f;
                         const float v = apply_act(acc[mi][ni][r] + bv, act);
-                        dx[o + col] = (TAG == 2) ? round_h(v) : v;
+                        dx[o + col] = (TAG >= 2) ? round_h(v) : v;
                     }
                 }
             }
@@ -824,9 +837,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
     float4 va[NVA], vb[NVB];
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) st_rowcontig<LDA, (TAG == 2)>(As(buf), ak_l + i * (1024 / BM), 4 * a_q, va[i]);
+        for (int i = 0; i < NVA; ++i) st_rowcontig<LDA, (TAG >= 2)>(As(buf), ak_l + i * (1024 / BM), 4 * a_q, va[i]);
 #pragma unroll
-        for (int i = 0; i < NVB; ++i) st_rowcontig<LDB, (TAG == 2)>(Bs(buf), bk_l + i * (1024 / BN), 4 * b_q, vb[i]);
+        for (int i = 0; i < NVB; ++i) st_rowcontig<LDB, (TAG >= 2)>(Bs(buf), bk_l + i * (1024 / BN), 4 * b_q, vb[i]);
     };
     if (c_begin < c_end) {
         load_a(c_begin, va);
@@ -842,7 +855,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
         const int cur = (c - c_begin) & 1;
         auto f0 = [&]() { if (c + 1 < c_end) stash(cur ^ 1); };
         auto f1 = [&]() { if (c + 2 < c_end) { load_a(c + 2, va); load_b(c + 2, vb); } };
-        if (TAG == 2) mma_chunk_h<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
+        if (TAG >= 2) mma_chunk_h<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
         else mma_chunk<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
         __syncthreads();
     }
@@ -1008,12 +1021,18 @@ TilePlan gemm_plan(long long M, int N, int chunks, int classes, bool can_split, 
         {0, 4488, 256, 128, 1, 64, 64, 6, 0},      // D 128->256 4x4 s2 forward
         {0, 17160, 128, 64, 1, 64, 64, 3, 1},      // D 64->128 4x4 s2 forward
         {1, 4488, 256, 512, 1, 64, 64, 8, 0},      // D 256->512 4x4 s1 data gradient
-        {1, 1024, 512, 576, 4, 64, 64, 1, 0},      // stride-2 data gradients / ConvTranspose forwards (4 parity classes)
-        {1, 4096, 256, 288, 4, 64, 64, 1, 0},
-        {1, 16384, 128, 144, 4, 64, 64, 1, 0},
+        {1, 1024, 512, 576, 4, 128, 64, 4, 0},     // stride-2 data gradients / ConvTranspose forwards (4 parity classes,
+        {1, 4096, 256, 288, 4, 64, 64, 1, 0},      //  each splitting its own K range)
+        {1, 16384, 128, 144, 4, 128, 64, 1, 0},
         {1, 65536, 64, 72, 4, 128, 64, 1, 0},
-        {1, 4488, 128, 256, 4, 64, 64, 1, 0},
+        {1, 4488, 128, 256, 4, 64, 64, 2, 0},
         {1, 17160, 64, 128, 4, 64, 64, 1, 0},
+        {1, 1224, 128, 256, 4, 64, 64, 3, 0},      // second discriminator scale
+        {1, 4488, 64, 128, 4, 64, 64, 3, 0},
+        {1, 8976, 128, 256, 4, 64, 64, 1, 0},      // batch 16 (stacked discriminator-loss pass)
+        {1, 34320, 64, 128, 4, 64, 64, 1, 0},
+        {1, 2448, 128, 256, 4, 64, 64, 4, 0},
+        {1, 8976, 64, 128, 4, 64, 64, 2, 0},
         // second discriminator scale (64x128 input), batch 8
         {0, 1440, 512, 256, 1, 64, 64, 4, 1},
         {1, 1224, 256, 512, 1, 64, 64, 12, 0},
@@ -1073,7 +1092,7 @@ TilePlan dgrad_plan(const mg_conv_geom* g) {
     const long long Mc = (long long)g->B * ((g->H + s - 1) / s) * ((g->W + s - 1) / s);
     const bool vec = g->Co % BK == 0;
     const int chunks = vec ? g->KH * g->KW * (g->Co / BK) : (g->KH * g->KW * g->Co + BK - 1) / BK;
-    return gemm_plan(Mc, g->Ci, chunks, s * s, s == 1 && g->Ci % 4 == 0, 1);
+    return gemm_plan(Mc, g->Ci, chunks, s * s, g->Ci % 4 == 0, 1);
 }
 
 struct WgradPlan { bool big; int tiles; int splits; int cps; };
@@ -1098,7 +1117,12 @@ WgradPlan wgrad_plan(const mg_conv_geom* g) {
 // ---------------------------------------------------------------------------------------------------------
 bool wino_ok(const mg_conv_geom* g) {
     static const bool off = getenv("MG_NO_WINOGRAD") != nullptr;
-    return !off && !prec_h(g) && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1 && g->Ci % 16 == 0 && g->Co % 16 == 0 &&
+    static const bool off_h = getenv("MG_NO_WINOGRAD_F16") != nullptr;
+    // f16 GEMMs are fast enough that Winograd only pays where the 16 transformed-weight matrices are amortised over
+    // many tiles: wide layers (>= 256 channels) with >= 256 tiles (the 1024-channel 8x16 blocks of configs[1]; not the
+    // 2048-channel 4x8 trunk of configs[2], where reading 16 * Co * Ci transformed weights would dominate)
+    if (prec_h(g) && (off_h || g->Ci < 256 || g->Co < 256 || (long long)g->B * (g->H / 2) * (g->W / 2) < 256)) return false;
+    return !off && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1 && g->Ci % 16 == 0 && g->Co % 16 == 0 &&
            g->Ci >= 32 && g->Co >= 32 && g->H % 2 == 0 && g->W % 2 == 0 && g->H >= 2 && g->W >= 2;
 }
 struct WinoDims { long long T, Tp; int TH, TW, THp, TWp; };
@@ -1171,11 +1195,15 @@ int wino_fwd(const mg_conv_geom* g, const float* x, const float* w, const float*
     float* pp = tp.splits > 1 ? part : nullptr;
     const Batch bt{d.T * g->Ci, (long long)g->Co * g->Ci, d.T * g->Co, 0};
     probe_begin(st);
-    const bool k32 = use_k32(tp, g->Ci);
+    const bool hp = prec_h(g);
+    const bool k32 = !hp && use_k32(tp, g->Ci);
     wino_launch_tiles(tp, [&](auto bm, auto bn) {
         constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value;
         dim3 grid((unsigned)(((d.T + BM_ - 1) / BM_) * ((g->Co + BN_ - 1) / BN_)), tp.splits, 16);
-        if (k32)
+        if (hp)
+            hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, true, 3>), grid, dim3(256), 0, st, gg, (const float*)V,
+                               (const float*)U, (const float*)nullptr, Mx, MG_ACT_NONE, tp.cps, pp, bt);
+        else if (k32)
             launch_fwd32<BM_, BN_, 1>(grid, st, gg, V, U, nullptr, Mx, MG_ACT_NONE, tp.splits == 1 ? (1 << 29) : tp.cps / 2,
                                       pp, bt);
         else
@@ -1189,7 +1217,7 @@ int wino_fwd(const mg_conv_geom* g, const float* x, const float* w, const float*
                            n, g->Co, (const float*)nullptr, MG_ACT_NONE, Mx);
     }
     hipLaunchKernelGGL(wino_output_xform_kernel, dim3(wino_grid((size_t)d.T * g->Co / 4)), dim3(256), 0, st,
-                       (const float*)Mx, g->B, d.TH, d.TW, g->Co, bias, act, y);
+                       (const float*)Mx, g->B, d.TH, d.TW, g->Co, bias, act, y, (int)hp);
     MG_CHECK_LAUNCH();
     return MG_OK;
 }
@@ -1218,8 +1246,12 @@ int wino_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const flo
     wino_launch_tiles(tp, [&](auto bm, auto bn) {
         constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value;
         dim3 grid((unsigned)(((T + BM_ - 1) / BM_) * ((g->Ci + BN_ - 1) / BN_)), tp.splits, 16);
-        hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, true, 1>), grid, dim3(256), 0, st, gg, (const float*)V,
-                           (const float*)U, (const float*)nullptr, Mx, MG_ACT_NONE, tp.cps, pp, bt);
+        if (prec_h(g))
+            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, true, 3>), grid, dim3(256), 0, st, gg, (const float*)V,
+                               (const float*)U, (const float*)nullptr, Mx, MG_ACT_NONE, tp.cps, pp, bt);
+        else
+            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, true, 1>), grid, dim3(256), 0, st, gg, (const float*)V,
+                               (const float*)U, (const float*)nullptr, Mx, MG_ACT_NONE, tp.cps, pp, bt);
     });
     probe_end(st);
     if (pp) {
@@ -1229,12 +1261,12 @@ int wino_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const flo
     }
     if (g->reflect) {
         hipLaunchKernelGGL(wino_output_xform_kernel, dim3(wino_grid((size_t)T * g->Ci / 4)), dim3(256), 0, st,
-                           (const float*)Mx, g->B, TH, TW, g->Ci, (const float*)nullptr, MG_ACT_NONE, dxp);
+                           (const float*)Mx, g->B, TH, TW, g->Ci, (const float*)nullptr, MG_ACT_NONE, dxp, (int)prec_h(g));
         hipLaunchKernelGGL(wino_fold_reflect_kernel, dim3(wino_grid((size_t)g->B * g->H * g->W * g->Ci / 4)), dim3(256), 0,
-                           st, (const float*)dxp, g->B, g->H, g->W, g->Ci, dx);
+                           st, (const float*)dxp, g->B, g->H, g->W, g->Ci, dx, (int)prec_h(g));
     } else {
         hipLaunchKernelGGL(wino_output_xform_kernel, dim3(wino_grid((size_t)T * g->Ci / 4)), dim3(256), 0, st,
-                           (const float*)Mx, g->B, TH, TW, g->Ci, bias, act, dx);
+                           (const float*)Mx, g->B, TH, TW, g->Ci, bias, act, dx, (int)prec_h(g));
     }
     MG_CHECK_LAUNCH();
     return MG_OK;
@@ -1257,8 +1289,14 @@ int wino_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw
     const Batch bt{d.T * g->Ci, d.T * g->Co, (long long)g->Co * g->Ci, 0};
     dim3 grid((unsigned)p.tiles, 16, p.splits);
     probe_begin(st);
-    if (p.big)
+    if (p.big && prec_h(g))
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, true, true, 3>), grid, dim3(256), 0, st, gg, (const float*)V,
+                           (const float*)Md, target, p.cps, 0, bt);
+    else if (p.big)
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, true, true, 1>), grid, dim3(256), 0, st, gg, (const float*)V,
+                           (const float*)Md, target, p.cps, 0, bt);
+    else if (prec_h(g))
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, true, true, 3>), grid, dim3(256), 0, st, gg, (const float*)V,
                            (const float*)Md, target, p.cps, 0, bt);
     else
         hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, true, true, 1>), grid, dim3(256), 0, st, gg, (const float*)V,
@@ -1315,16 +1353,19 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
         const WinoDims d = wino_dims(g);
         if (pass == 0) {
             const TilePlan tp = gemm_plan(d.T, g->Co, g->Ci / BK, 16, true, 0);
-            if (use_k32(tp, g->Ci))
+            if (prec_h(g))
+                snprintf(out, out_len, "conv_fwd_kernel<%d, %d, true, 3>", tp.bm, tp.bn);
+            else if (use_k32(tp, g->Ci))
                 snprintf(out, out_len, "conv_fwd32_kernel<%d, %d, 1>", tp.bm, tp.bn);
             else
                 snprintf(out, out_len, "conv_fwd_kernel<%d, %d, true, 1>", tp.bm, tp.bn);
         } else if (pass == 1) {
             const TilePlan tp = gemm_plan(g->reflect ? d.Tp : d.T, g->Ci, g->Co / BK, 16, true, 1);
-            snprintf(out, out_len, "conv_dgrad_kernel<%d, %d, true, true, 1>", tp.bm, tp.bn);
+            snprintf(out, out_len, "conv_dgrad_kernel<%d, %d, true, true, %d>", tp.bm, tp.bn, prec_h(g) ? 3 : 1);
         } else {
             const WinoWgradPlan p = wino_wgrad_plan(g);
-            snprintf(out, out_len, "conv_wgrad_kernel<%d, %d, true, true, 1>", p.big ? 128 : 64, p.big ? 128 : 64);
+            snprintf(out, out_len, "conv_wgrad_kernel<%d, %d, true, true, %d>", p.big ? 128 : 64, p.big ? 128 : 64,
+                     prec_h(g) ? 3 : 1);
         }
     } else if (kq && pass == 0) {
         snprintf(out, out_len, "conv_rowdot_fwd_kernel<%d>", kq);

@@ -102,7 +102,8 @@ __global__ void wino_weight_xform_kernel(const float* __restrict__ w, int Co, in
 
 // out[B][2TH][2TW][C] = act(A^T M A + bias)
 __global__ void wino_output_xform_kernel(const float* __restrict__ Mx, int B, int TH, int TW, int C,
-                                         const float* __restrict__ bias, int act, float* __restrict__ out) {
+                                         const float* __restrict__ bias, int act, float* __restrict__ out,
+                                         int round_f16 = 0) {
     const int C4 = C / 4;
     const size_t T = (size_t)B * TH * TW, total = T * C4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -127,6 +128,10 @@ __global__ void wino_output_xform_kernel(const float* __restrict__ Mx, int B, in
             float4 y1 = f4add(f4sub(f4sub(tmp[r][1], tmp[r][2]), tmp[r][3]), bv);
             y0.x = apply_act(y0.x, act); y0.y = apply_act(y0.y, act); y0.z = apply_act(y0.z, act); y0.w = apply_act(y0.w, act);
             y1.x = apply_act(y1.x, act); y1.y = apply_act(y1.y, act); y1.z = apply_act(y1.z, act); y1.w = apply_act(y1.w, act);
+            if (round_f16) {     // MG_PRECISION_F16: the pass output is a float16 value
+                y0.x = round_h(y0.x); y0.y = round_h(y0.y); y0.z = round_h(y0.z); y0.w = round_h(y0.w);
+                y1.x = round_h(y1.x); y1.y = round_h(y1.y); y1.z = round_h(y1.z); y1.w = round_h(y1.w);
+            }
             float* o = out + ((size_t)(b * 2 * TH + 2 * ty + r) * (2 * TW) + 2 * tx) * C + 4 * c4;
             *reinterpret_cast<float4*>(o) = y0;
             *reinterpret_cast<float4*>(o + C) = y1;
@@ -136,7 +141,7 @@ __global__ void wino_output_xform_kernel(const float* __restrict__ Mx, int B, in
 
 // ReflectionPad2d(1) backward: dX[i][j] = sum of the padded positions aliasing (i, j).  dXp: [B][H+2][W+2][C]
 __global__ void wino_fold_reflect_kernel(const float* __restrict__ dxp, int B, int H, int W, int C,
-                                         float* __restrict__ dx) {
+                                         float* __restrict__ dx, int round_f16 = 0) {
     const int C4 = C / 4;
     const size_t total = (size_t)B * H * W * C4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -157,6 +162,7 @@ __global__ void wino_fold_reflect_kernel(const float* __restrict__ dxp, int B, i
                 add4(s, ld4(dxp + ((size_t)(b * (H + 2) + cy[a]) * (W + 2) + cx[c]) * C + 4 * c4));
             }
         }
+        if (round_f16) { s.x = round_h(s.x); s.y = round_h(s.y); s.z = round_h(s.z); s.w = round_h(s.w); }
         *reinterpret_cast<float4*>(dx + i * 4) = s;
     }
 }

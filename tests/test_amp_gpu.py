@@ -26,6 +26,8 @@ CASES = [
     ("d4x4_s1_co1", 2, 64, 6, 10, 1, 4, 1, 2, False),
     ("wide_128tile", 2, 64, 16, 32, 256, 3, 1, 1, True),
     ("bottleneck_like", 8, 128, 8, 16, 128, 3, 1, 1, True),
+    ("bottleneck_wino_f16", 8, 256, 8, 16, 256, 3, 1, 1, True),      # wide + 256 tiles: Winograd with f16 GEMMs
+    ("wino_f16_zero_pad", 4, 256, 16, 16, 256, 3, 1, 1, False),
     ("conv1x1", 2, 64, 4, 8, 48, 1, 1, 0, False),
 ]
 
@@ -39,13 +41,13 @@ def h(t):
     return t.float().half().double()
 
 
-def close_f16(got, want):
+def close_f16(got, want, ulps=1.5, floor=2.0 ** -11):
     """got: float32 values that went through float16; want: float64 before rounding.  1.5 float16 ulps of the element
     plus half an ulp of the largest element: the float32 accumulation error scales with the terms, not with a
     cancelling result, and a reflection-padded data gradient sums its aliased dy taps BEFORE the float16 rounding
     (autocast rounds the padded-domain gradient first and folds afterwards -- one rounding either way)."""
     got = got.double().cpu()
-    tol = 1.5 * 2.0 ** -10 * want.abs() + 2.0 ** -11 * want.abs().max()
+    tol = ulps * 2.0 ** -10 * want.abs() + floor * want.abs().max()
     bad = (got - want).abs() > tol
     assert not bad.any(), ((got - want).abs().max().item(), want.abs().max().item(), int(bad.sum()))
     assert torch.equal(got.float().half().float().double(), got), "output is not float16-representable"
@@ -68,14 +70,20 @@ def test_conv_f16_precision(case):
     g = ops.conv_geom(B, H, W, Ci, Co, k, k, s, p, reflect, _lib.PRECISION_F16)
     xd, wd, bd = nhwc(x).float().to(DEV), nhwc(w).float().to(DEV), b.float().to(DEV)
     gyd = nhwc(gy).float().to(DEV)
-    close_f16(ops.conv_fwd(g, xd, wd, bd), nhwc(y.detach()))
-    close_f16(ops.conv_dgrad(g, gyd, wd), nhwc(xh.grad))
+    # 3x3 stride-1 layers run as Winograd F(2x2,3x3) with float16 GEMM operands (the transformed tiles V = B^T d B and
+    # U = G g G^T are what gets rounded, as in cuDNN's float16 Winograd algorithms that cudnn.benchmark may pick for the
+    # reference): the rounding error of 16 transformed products folds into each output -> a few float16 ulps.
+    wino = bool(_lib.load().mg_conv_wino_weights_bytes(g))
+    tol = dict(ulps=4.0, floor=2.0 ** -9) if wino else {}
+    close_f16(ops.conv_fwd(g, xd, wd, bd), nhwc(y.detach()), **tol)
+    close_f16(ops.conv_dgrad(g, gyd, wd), nhwc(xh.grad), **tol)
     dw = torch.full((Co, k, k, Ci), 7.0, dtype=torch.float32, device=DEV)
     ops.conv_wgrad(g, xd, gyd, dw, None)
     want = nhwc(wh.grad)
-    assert (dw.double().cpu() - want).abs().max().item() <= 3e-5 * want.abs().max().item()
+    wtol = 2e-3 if wino else 3e-5       # Winograd: float16-rounded transformed operands in the weight gradient too
+    assert (dw.double().cpu() - want).abs().max().item() <= wtol * want.abs().max().item()
     ops.conv_wgrad(g, xd, gyd, dw, None, accumulate=True)
-    assert (dw.double().cpu() - 2 * want).abs().max().item() <= 6e-5 * want.abs().max().item()
+    assert (dw.double().cpu() - 2 * want).abs().max().item() <= 2 * wtol * want.abs().max().item()
 
 
 def test_conv_f16_overflow_becomes_inf():
