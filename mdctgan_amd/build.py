@@ -33,7 +33,7 @@ def _stale(out, deps):
 def build_hip(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hdrs.append(os.path.join(REPO, "include", "mdctgan_hip.h"))
     jobs = []
     for s in srcs:

@@ -1101,9 +1101,22 @@ WgradPlan wgrad_plan(const mg_conv_geom* g) {
     const long long Mtot = (long long)g->B * g->OH * g->OW;
     const int chunks = (int)((Mtot + BK - 1) / BK);
     const int t128 = ((R + 127) / 128) * ((N + 127) / 128);
-    const bool big = t128 >= 96 && R >= 128;
+    bool big = t128 >= 96 && R >= 128;
+    int want = -1;
+    if (const char* f = getenv("MG_FORCE_WGRAD")) {      // tuning harness: "big(0|1),splits"
+        int b = 0, sp = 1;
+        if (sscanf(f, "%d,%d", &b, &sp) == 2 && sp >= 1) { big = b != 0 && R >= 64; want = sp; }
+    } else {
+        // measured on MI355X (scripts/tune_conv.py --wgrad) for the configs[1] layers; the heuristic below covers the rest
+        struct Tuned { int R, N; long long M; int big, sp; };
+        static const Tuned tuned[] = {
+#include "wgrad_plans.inc"
+        };
+        for (const Tuned& t : tuned)
+            if (t.R == R && t.N == N && t.M == Mtot) { big = t.big != 0; want = t.sp; break; }
+    }
     const int tiles = big ? t128 : ((R + 63) / 64) * ((N + 63) / 64);
-    int splits = tiles >= 512 ? 1 : (768 + tiles - 1) / tiles;
+    int splits = want > 0 ? want : (tiles >= 512 ? 1 : (768 + tiles - 1) / tiles);
     const int max_splits = chunks / 8 > 0 ? chunks / 8 : 1;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
