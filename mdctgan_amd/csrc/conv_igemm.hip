@@ -1166,9 +1166,14 @@ WinoWgradPlan wino_wgrad_plan(const mg_conv_geom* g) {
     const WinoDims d = wino_dims(g);
     const int chunks = (int)((d.T + BK - 1) / BK);
     const int t128 = ((g->Co + 127) / 128) * ((g->Ci + 127) / 128);
-    const bool big = g->Co >= 128 && g->Ci >= 128;
+    bool big = g->Co >= 128 && g->Ci >= 128;
+    int want = -1;
+    if (const char* f = getenv("MG_FORCE_WINO_WGRAD")) {      // tuning harness: "big(0|1),splits"
+        int b = 0, sp = 1;
+        if (sscanf(f, "%d,%d", &b, &sp) == 2 && sp >= 1) { big = b != 0; want = sp; }
+    }
     const int tiles = big ? t128 : ((g->Co + 63) / 64) * ((g->Ci + 63) / 64);
-    int splits = tiles * 16 >= 512 ? 1 : (768 + tiles * 16 - 1) / (tiles * 16);
+    int splits = want > 0 ? want : (tiles * 16 >= 512 ? 1 : (768 + tiles * 16 - 1) / (tiles * 16));
     const int max_splits = chunks / 8 > 0 ? chunks / 8 : 1;
     if (splits > max_splits) splits = max_splits;
     int cps = (chunks + splits - 1) / splits;

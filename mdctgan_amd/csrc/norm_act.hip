@@ -46,40 +46,65 @@ NormPlan norm_plan(int B, int HW, int C) {
 
 // partial per-(b, c) sums over a slice of pixels.  MODE 0: (sum x, sum x^2).
 // MODE 1 (backward): g = dy * act'(xhat); (sum g, sum g * xhat).
-template <int MODE>
+// VEC: 16 lanes x float4 cover the block's 64 channels (256 B per pixel), 16 pixel rows in flight per iteration.
+template <int MODE, bool VEC>
 __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, int HW, int C,
                                                            int rows_per_split, int act, double* __restrict__ part) {
-    __shared__ double red[2][4][64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl, b = blockIdx.y, sp = blockIdx.z;
+    constexpr int V = VEC ? 4 : 1, CL = 64 / V, RG = 256 / CL;
+    __shared__ double red[2][RG][64];
+    const int cl = threadIdx.x % CL, rg = threadIdx.x / CL;
+    const int c = blockIdx.x * 64 + cl * V, b = blockIdx.y, sp = blockIdx.z;
     const int p0 = sp * rows_per_split, p1 = min(HW, p0 + rows_per_split);
-    double s1 = 0.0, s2 = 0.0;
+    double s1[V], s2[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) s1[j] = s2[j] = 0.0;
     if (c < C) {
         const size_t base = (size_t)b * HW * C + c;
-        float mu = 0.f, rs = 0.f;
-        if (MODE == 1) { mu = mean[b * C + c]; rs = rstd[b * C + c]; }
-        for (int p = p0 + rg; p < p1; p += 4) {
-            const float v = x[base + (size_t)p * C];
-            if (MODE == 0) {
-                s1 += (double)v;
-                s2 += (double)v * (double)v;
+        float mu[V], rs[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { mu[j] = 0.f; rs[j] = 0.f; }
+        if (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) { mu[j] = mean[b * C + c + j]; rs[j] = rstd[b * C + c + j]; }
+        }
+        for (int p = p0 + rg; p < p1; p += RG) {
+            float xv[V], gv[V];
+            if (VEC) {
+                *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + base + (size_t)p * C);
+                if (MODE == 1) *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(dy + base + (size_t)p * C);
             } else {
-                const float xh = (v - mu) * rs;
-                const float gq = dy[base + (size_t)p * C] * act_grad_pre(xh, act);
-                s1 += (double)gq;
-                s2 += (double)gq * (double)xh;
+                xv[0] = x[base + (size_t)p * C];
+                if (MODE == 1) gv[0] = dy[base + (size_t)p * C];
+            }
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                if (MODE == 0) {
+                    s1[j] += (double)xv[j];
+                    s2[j] += (double)xv[j] * (double)xv[j];
+                } else {
+                    const float xh = (xv[j] - mu[j]) * rs[j];
+                    const float gq = gv[j] * act_grad_pre(xh, act);
+                    s1[j] += (double)gq;
+                    s2[j] += (double)gq * (double)xh;
+                }
             }
         }
     }
-    red[0][rg][cl] = s1;
-    red[1][rg][cl] = s2;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        red[0][rg][cl * V + j] = s1[j];
+        red[1][rg][cl * V + j] = s2[j];
+    }
     __syncthreads();
-    if (rg == 0 && c < C) {
-        const size_t o = (((size_t)b * gridDim.z + sp) * C + c) * 2;
-        part[o] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-        part[o + 1] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < C) {
+        double a = 0.0, q = 0.0;
+#pragma unroll
+        for (int i = 0; i < RG; ++i) { a += red[0][i][threadIdx.x]; q += red[1][i][threadIdx.x]; }
+        const size_t o = (((size_t)b * gridDim.z + sp) * C + blockIdx.x * 64 + threadIdx.x) * 2;
+        part[o] = a;
+        part[o + 1] = q;
     }
 }
 
@@ -589,8 +614,12 @@ int mg_instnorm_fwd(const float* x, int B, int HW, int C, float eps, int act, co
     }
     const NormPlan p = norm_plan(B, HW, C);
     double* part = (double*)workspace;
-    hipLaunchKernelGGL(norm_partial_kernel<0>, dim3(p.cblocks, B, p.splits), dim3(256), 0, st, x, nullptr, nullptr,
-                       nullptr, HW, C, p.rows_per_split, act, part);
+    if (C % 4 == 0 && al16(x))
+        hipLaunchKernelGGL((norm_partial_kernel<0, true>), dim3(p.cblocks, B, p.splits), dim3(256), 0, st, x, nullptr,
+                           nullptr, nullptr, HW, C, p.rows_per_split, act, part);
+    else
+        hipLaunchKernelGGL((norm_partial_kernel<0, false>), dim3(p.cblocks, B, p.splits), dim3(256), 0, st, x, nullptr,
+                           nullptr, nullptr, HW, C, p.rows_per_split, act, part);
     hipLaunchKernelGGL(norm_finalize_kernel<0>, dim3((B * C + 255) / 256), dim3(256), 0, st, part, B, p.splits, C, HW,
                        eps, mean, rstd);
     const size_t total = (size_t)B * HW * C;
@@ -622,8 +651,12 @@ int mg_instnorm_bwd(const float* dy, const float* x, const float* mean, const fl
     double* part = (double*)workspace;
     float* m1 = (float*)((char*)workspace + (size_t)B * p.splits * C * 2 * sizeof(double));
     float* m2 = m1 + (size_t)B * C;
-    hipLaunchKernelGGL(norm_partial_kernel<1>, dim3(p.cblocks, B, p.splits), dim3(256), 0, st, x, dy, mean, rstd, HW,
-                       C, p.rows_per_split, act, part);
+    if (C % 4 == 0 && al16(x) && al16(dy))
+        hipLaunchKernelGGL((norm_partial_kernel<1, true>), dim3(p.cblocks, B, p.splits), dim3(256), 0, st, x, dy, mean,
+                           rstd, HW, C, p.rows_per_split, act, part);
+    else
+        hipLaunchKernelGGL((norm_partial_kernel<1, false>), dim3(p.cblocks, B, p.splits), dim3(256), 0, st, x, dy, mean,
+                           rstd, HW, C, p.rows_per_split, act, part);
     hipLaunchKernelGGL(norm_finalize_kernel<1>, dim3((B * C + 255) / 256), dim3(256), 0, st, part, B, p.splits, C, HW,
                        0.0f, m1, m2);
     const size_t total = (size_t)B * HW * C;
