@@ -22,6 +22,7 @@
 #include "mdctgan_hip.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <cstring>
 #include <type_traits>
 
 namespace {
@@ -1012,7 +1013,8 @@ TilePlan gemm_plan(long long M, int N, int chunks, int classes, bool can_split, 
     struct Tuned { int pass; long long M; int N, chunks, classes, bm, bn, sp, k32; };
     static const Tuned tuned[] = {
         {0, 256, 1024, 64, 16, 64, 64, 1, 1},      // Winograd forward GEMMs, 1024-channel 8x16 ResNet blocks
-        {1, 360, 1024, 64, 16, 128, 128, 2, 0},    // Winograd data-gradient GEMMs (reflection: 10x18 padded domain)
+        {1, 256, 1024, 64, 16, 128, 128, 2, 0},    // Winograd data-gradient GEMMs (transposed pipeline: same 256 tiles)
+        {1, 360, 1024, 64, 16, 128, 128, 2, 0},    // ... and over the 10x18 padded domain (MG_WINO_DGRAD=padded)
         {0, 1024, 1024, 288, 1, 128, 128, 8, 1},   // 512->1024 stride-2 forward (and the 1024->512 ConvTranspose backward)
         {0, 4096, 512, 144, 1, 128, 128, 4, 1},    // 256->512
         {0, 16384, 256, 72, 1, 64, 64, 1, 1},      // 128->256
@@ -1153,8 +1155,17 @@ size_t wino_fwd_ws(const mg_conv_geom* g) {
     return (al256((size_t)16 * g->Co * g->Ci) + al256((size_t)16 * d.T * g->Ci) + al256((size_t)16 * d.T * g->Co) +
             (tp.splits > 1 ? al256((size_t)tp.splits * 16 * d.T * g->Co) : 0)) * sizeof(float) + 256;
 }
+inline bool wino_dgrad_padded() {
+    static const bool v = [] { const char* e = getenv("MG_WINO_DGRAD"); return e && !strcmp(e, "padded"); }();
+    return v;
+}
 size_t wino_dgrad_ws(const mg_conv_geom* g) {
     const WinoDims d = wino_dims(g);
+    if (!wino_dgrad_padded()) {      // U | A dy A^T | dV | dd | split-K slabs
+        const TilePlan tp = gemm_plan(d.T, g->Ci, g->Co / BK, 16, true, 1);
+        return (al256((size_t)16 * g->Co * g->Ci) + al256((size_t)16 * d.T * g->Co) + 2 * al256((size_t)16 * d.T * g->Ci) +
+                (tp.splits > 1 ? al256((size_t)tp.splits * 16 * d.T * g->Ci) : 0)) * sizeof(float) + 256;
+    }
     const long long T = g->reflect ? d.Tp : d.T;
     const TilePlan tp = gemm_plan(T, g->Ci, g->Co / BK, 16, true, 1);
     return (al256((size_t)16 * g->Co * g->Ci) + al256((size_t)16 * T * g->Co) + al256((size_t)16 * T * g->Ci) +
@@ -1240,8 +1251,53 @@ int wino_fwd(const mg_conv_geom* g, const float* x, const float* w, const float*
     return MG_OK;
 }
 
+// Data gradient as the transpose of the forward pipeline (wino.h): T tiles, no padded domain.
+int wino_dgrad_t(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act, float* ws,
+                 hipStream_t st, const float* u_pre) {
+    const WinoDims d = wino_dims(g);
+    const long long T = d.T;
+    float* U = ws;
+    float* Md = U + al256((size_t)16 * g->Co * g->Ci);
+    float* dV = Md + al256((size_t)16 * T * g->Co);
+    float* dd = dV + al256((size_t)16 * T * g->Ci);
+    float* part = dd + al256((size_t)16 * T * g->Ci);
+    if (u_pre) U = const_cast<float*>(u_pre);
+    else hipLaunchKernelGGL(wino_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 4)), dim3(256), 0, st, w,
+                            g->Co, g->Ci, U);
+    hipLaunchKernelGGL(wino_dy_xform_kernel, dim3(wino_grid((size_t)T * g->Co / 4)), dim3(256), 0, st, dy, g->B, d.TH,
+                       d.TW, g->Co, Md);
+    const Geom gg{1, 1, (int)T, g->Ci, 1, (int)T, g->Co, 1, 1, 1, 0, 0};
+    const TilePlan tp = gemm_plan(T, g->Ci, g->Co / BK, 16, true, 1);
+    float* pp = tp.splits > 1 ? part : nullptr;
+    const Batch bt{T * g->Co, (long long)g->Co * g->Ci, T * g->Ci, 0};      // dV_z = dM_z U_z: same position, no flip
+    probe_begin(st);
+    wino_launch_tiles(tp, [&](auto bm, auto bn) {
+        constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value;
+        dim3 grid((unsigned)(((T + BM_ - 1) / BM_) * ((g->Ci + BN_ - 1) / BN_)), tp.splits, 16);
+        if (prec_h(g))
+            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, true, 3>), grid, dim3(256), 0, st, gg, (const float*)Md,
+                               (const float*)U, (const float*)nullptr, dV, MG_ACT_NONE, tp.cps, pp, bt);
+        else
+            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, true, 1>), grid, dim3(256), 0, st, gg, (const float*)Md,
+                               (const float*)U, (const float*)nullptr, dV, MG_ACT_NONE, tp.cps, pp, bt);
+    });
+    probe_end(st);
+    if (pp) {
+        const size_t n = (size_t)16 * T * g->Ci;
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(wino_grid(n / 4)), dim3(256), 0, st, (const float*)pp, tp.splits,
+                           n, g->Ci, (const float*)nullptr, MG_ACT_NONE, dV);
+    }
+    hipLaunchKernelGGL(wino_dd_xform_kernel, dim3(wino_grid((size_t)T * g->Ci / 4)), dim3(256), 0, st, (const float*)dV, T,
+                       g->Ci, dd);
+    hipLaunchKernelGGL(wino_dx_gather_kernel, dim3(wino_grid((size_t)g->B * g->H * g->W * g->Ci / 4)), dim3(256), 0, st,
+                       (const float*)dd, g->B, g->H, g->W, g->Ci, g->reflect, bias, act, dx, (int)prec_h(g));
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
 int wino_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act, float* ws,
                hipStream_t st, const float* u_pre) {
+    if (!wino_dgrad_padded()) return wino_dgrad_t(g, dy, w, bias, dx, act, ws, st, u_pre);
     const WinoDims d = wino_dims(g);
     const long long T = g->reflect ? d.Tp : d.T;
     const int TH = g->reflect ? d.THp : d.TH, TW = g->reflect ? d.TWp : d.TW;
@@ -1356,7 +1412,7 @@ double mg_conv_plan_flops(int pass, const mg_conv_geom* g) {
     const double direct = 2.0 * g->B * g->OH * g->OW * (double)g->Co * g->KH * g->KW * g->Ci;
     if (wino_ok(g) && !mg_conv_rowdot_kq(g)) {
         const WinoDims d = wino_dims(g);
-        const double T = (pass == 1 && g->reflect) ? (double)d.Tp : (double)d.T;
+        const double T = (pass == 1 && g->reflect && wino_dgrad_padded()) ? (double)d.Tp : (double)d.T;
         return 2.0 * 16.0 * T * (double)g->Co * g->Ci;
     }
     return direct;
@@ -1378,7 +1434,7 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
             else
                 snprintf(out, out_len, "conv_fwd_kernel<%d, %d, true, 1>", tp.bm, tp.bn);
         } else if (pass == 1) {
-            const TilePlan tp = gemm_plan(g->reflect ? d.Tp : d.T, g->Ci, g->Co / BK, 16, true, 1);
+            const TilePlan tp = gemm_plan((g->reflect && wino_dgrad_padded()) ? d.Tp : d.T, g->Ci, g->Co / BK, 16, true, 1);
             snprintf(out, out_len, "conv_dgrad_kernel<%d, %d, true, true, %d>", tp.bm, tp.bn, prec_h(g) ? 3 : 1);
         } else {
             const WinoWgradPlan p = wino_wgrad_plan(g);
@@ -1502,7 +1558,8 @@ int mg_conv_dgrad_u(const mg_conv_geom* g, const float* dy, const float* w, cons
     if (!geom_ok(g) || !dy || !w || !dx) return MG_ERR_ARG;
     if (u && (!mg_conv_wino_weights_bytes(g) || !aligned16(u))) return MG_ERR_ARG;
     if (g->reflect && g->stride != 1) return MG_ERR_UNSUPPORTED;
-    if (wino_ok(g) && !(g->reflect && (bias || act != MG_ACT_NONE)) && workspace && workspace_bytes >= wino_dgrad_ws(g) &&
+    if (wino_ok(g) && !(wino_dgrad_padded() && g->reflect && (bias || act != MG_ACT_NONE)) && workspace &&
+        workspace_bytes >= wino_dgrad_ws(g) &&
         aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(workspace) && (!bias || aligned16(bias)))
         return wino_dgrad(g, dy, w, bias, dx, act, (float*)workspace, (hipStream_t)stream, u);
     const Geom gg = to_geom(g);

@@ -4,8 +4,9 @@
 // cuDNN path uses the same algorithm family under cudnn.benchmark, train.py:25).
 //
 //   forward   Y  = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A            d: 4x4 input patch (reflect / zero pad 1)
-//   dgrad     dXp = A^T [ sum_co (G g' G^T) .* (B^T dy B) ] A           g' = g rotated 180 deg == position permutation
-//             reflect padding: dXp is the (H+2)x(W+2) "full" gradient, folded back by wino_fold_reflect
+//   dgrad     the exact transpose of forward: dd_t = B [ (A dy A^T) x U ] B^T per tile, gathered back into dx (the
+//             reflection / zero padding is the transpose of the forward gather); MG_WINO_DGRAD=padded selects the older
+//             formulation dXp = A^T [ sum_co (G g' G^T) .* (B^T dy B) ] A over the (H+2)x(W+2) padded domain
 //   wgrad     dg = G^T [ sum_tiles (B^T d B) .* (A dy A^T) ] G
 // The element-wise products summed over channels / tiles are 16 independent GEMMs, run as ONE batched launch of
 // the implicit-GEMM kernels with a 1x1 geometry (conv_igemm.hip); everything here is the HBM-bound transforms.
@@ -162,6 +163,88 @@ __global__ void wino_fold_reflect_kernel(const float* __restrict__ dxp, int B, i
                 add4(s, ld4(dxp + ((size_t)(b * (H + 2) + cy[a]) * (W + 2) + cx[c]) * C + 4 * c4));
             }
         }
+        if (round_f16) { s.x = round_h(s.x); s.y = round_h(s.y); s.z = round_h(s.z); s.w = round_h(s.w); }
+        *reinterpret_cast<float4*>(dx + i * 4) = s;
+    }
+}
+
+// ---- data gradient as the exact transpose of the forward pipeline -----------------------------------------------
+// forward:  x --gather (reflect / zero pad)--> d_t --B^T . B--> V --GEMM--> M --A^T . A--> y
+// backward: dy --A . A^T (wino_dy_xform)--> dM --GEMM with U--> dV --B . B^T (below)--> dd_t --scatter^T--> dx
+// so the GEMMs run over the same T = B*H/2*W/2 tiles as the forward pass (no padded (H+2)x(W+2) domain).
+// dd[T][16][C] = B dV B^T,  B = (B^T)^T: rows [1,0,0,0], [0,1,-1,1], [-1,1,1,0], [0,0,0,-1].
+__device__ __forceinline__ void b4(const float4 v0, const float4 v1, const float4 v2, const float4 v3, float4 (&o)[4]) {
+    o[0] = v0;
+    o[1] = f4add(f4sub(v1, v2), v3);
+    o[2] = f4sub(f4add(v1, v2), v0);
+    o[3] = f4neg(v3);
+}
+__global__ void wino_dd_xform_kernel(const float* __restrict__ dV, long long T, int C, float* __restrict__ dd) {
+    const int C4 = C / 4;
+    const size_t total = (size_t)T * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const size_t t = i / C4;
+        float4 v[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[r][c] = ld4(dV + ((size_t)(r * 4 + c) * T + t) * C + 4 * c4);
+        float4 tmp[4][4];   // tmp[:, c] = B v[:, c]
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float4 o[4];
+            b4(v[0][c], v[1][c], v[2][c], v[3][c], o);
+            tmp[0][c] = o[0]; tmp[1][c] = o[1]; tmp[2][c] = o[2]; tmp[3][c] = o[3];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float4 o[4];
+            b4(tmp[r][0], tmp[r][1], tmp[r][2], tmp[r][3], o);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) *reinterpret_cast<float4*>(dd + ((size_t)t * 16 + r * 4 + c) * C + 4 * c4) = o[c];
+        }
+    }
+}
+
+// Transpose of the forward gather: pixel (iy, ix) collects dd_t[r][c] from every (tile, patch position) that read it --
+// patch rows 2*ty - 1 + r == iy, plus (reflect) the padded rows -1 and H that alias rows 1 and H - 2; same for columns.
+// At most 3 x 3 terms, summed in a fixed order.
+__device__ __forceinline__ int wino_sources(int i, int n, int tiles, int reflect, int (&tt)[3], int (&rr)[3]) {
+    int cnt = 0;
+    const int cand[3] = {i, (reflect && i == 1) ? -1 : -1000, (reflect && i == n - 2) ? n : -1000};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int p = cand[a];
+        if (p < -1) continue;
+        const int t0 = (p + 1) >> 1;            // floor((p + 1) / 2), p >= -1
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int t = t0 - k, r = p + 1 - 2 * t;
+            if (t >= 0 && t < tiles && r >= 0 && r < 4 && cnt < 3) { tt[cnt] = t; rr[cnt] = r; ++cnt; }
+        }
+    }
+    return cnt;
+}
+__global__ void wino_dx_gather_kernel(const float* __restrict__ dd, int B, int H, int W, int C, int reflect,
+                                      const float* __restrict__ bias, int act, float* __restrict__ dx, int round_f16) {
+    const int C4 = C / 4, TH = H / 2, TW = W / 2;
+    const size_t total = (size_t)B * H * W * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        size_t q = i / C4;
+        const int ix = (int)(q % W); q /= W;
+        const int iy = (int)(q % H);
+        const int b = (int)(q / H);
+        int ty[3], ry[3], tx[3], rx[3];
+        const int ny = wino_sources(iy, H, TH, reflect, ty, ry), nx = wino_sources(ix, W, TW, reflect, tx, rx);
+        float4 s = bias ? ld4(bias + 4 * c4) : zero4();
+        float4 acc = zero4();
+        for (int a = 0; a < ny; ++a)
+            for (int c = 0; c < nx; ++c)
+                add4(acc, ld4(dd + (((size_t)(b * TH + ty[a]) * TW + tx[c]) * 16 + ry[a] * 4 + rx[c]) * C + 4 * c4));
+        add4(s, acc);
+        s.x = apply_act(s.x, act); s.y = apply_act(s.y, act); s.z = apply_act(s.z, act); s.w = apply_act(s.w, act);
         if (round_f16) { s.x = round_h(s.x); s.y = round_h(s.y); s.z = round_h(s.z); s.w = round_h(s.w); }
         *reinterpret_cast<float4*>(dx + i * 4) = s;
     }
