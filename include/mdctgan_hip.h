@@ -115,21 +115,34 @@ int mg_conv_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const 
                   void* workspace, size_t workspace_bytes, void* stream);
 size_t mg_conv_dgrad_workspace(const mg_conv_geom* g);
 /* 3x3 stride-1 pad-1 layers with channel counts that are multiples of 16 run as Winograd F(2x2,3x3): 16 batched
- * GEMMs over transformed weights U = G w G^T.  A caller that runs forward and data gradient with the same w can
- * transform once: mg_conv_wino_weights_bytes() is the size of U (0: the geometry is not a Winograd layer),
- * mg_conv_wino_prepare() fills it, and the _u entry points take it (u == NULL: transform internally).
- * u must have been prepared from the w passed in the same call. */
+ * GEMMs over transformed operands.  A training step runs forward, data gradient and weight gradient of a layer with the
+ * same weights / activations / output gradient, so the caller may hold the transformed images and hand them to the _w
+ * entry points (every pointer optional; NULL = transform internally, which is what the plain entry points do):
+ *   u   U = G w G^T            16*Co*Ci floats   mg_conv_wino_prepare() fills it; read by fwd and dgrad
+ *   v   V = B^T x B            16*T*Ci floats    WRITTEN by mg_conv_fwd_w, read by mg_conv_wgrad_w
+ *   md  Md = A dy A^T          16*T*Co floats    WRITTEN by mg_conv_dgrad_w, read by mg_conv_wgrad_w
+ * (T = B*H/2*W/2 tiles).  Sizes: mg_conv_wino_weights_bytes() and mg_conv_wino_tiles_bytes(g, 0 = v | 1 = md); 0 means
+ * "this geometry / configuration does not use that image" and the pointer must stay NULL.  Every image must come
+ * from the tensors passed in the same step. */
+typedef struct {
+    const float* u;
+    float* v;
+    float* md;
+} mg_wino_tiles;
 size_t mg_conv_wino_weights_bytes(const mg_conv_geom* g);
+size_t mg_conv_wino_tiles_bytes(const mg_conv_geom* g, int which);
 int mg_conv_wino_prepare(const mg_conv_geom* g, const float* w, float* u, void* stream);
-int mg_conv_fwd_u(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
-                  void* workspace, size_t workspace_bytes, void* stream, const float* u);
-int mg_conv_dgrad_u(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
-                    void* workspace, size_t workspace_bytes, void* stream, const float* u);
+int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
+                  void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* tiles);
+int mg_conv_dgrad_w(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
+                    void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* tiles);
 /* dw [Co, KH, KW, Ci] = sum over pixels; dbias [Co] (nullable) = column sums of dy.
  * accumulate != 0 adds into dw / dbias instead of overwriting.  workspace: mg_conv_wgrad_workspace() bytes. */
 int mg_conv_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias, int accumulate,
                   void* workspace, size_t workspace_bytes, void* stream);
 size_t mg_conv_wgrad_workspace(const mg_conv_geom* g);
+int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias, int accumulate,
+                    void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* tiles);
 /* Name of the kernel instance a pass (0 fwd, 1 dgrad, 2 wgrad) launches for this geometry -- the symbol
  * rocprofv3 reports -- so bench.py can attribute event-timed launches per kernel.  out: host buffer >= 64 B. */
 int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len);

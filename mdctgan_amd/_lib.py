@@ -32,6 +32,14 @@ PRECISION_F32, PRECISION_F16 = 0, 1
 _p, _i, _f, _ll, _sz = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
 _G = C.POINTER(ConvGeom)
 
+
+class WinoTiles(C.Structure):
+    """mg_wino_tiles: caller-held Winograd images (u: transformed weights, v: B^T x B, md: A dy A^T)."""
+    _fields_ = [("u", C.c_void_p), ("v", C.c_void_p), ("md", C.c_void_p)]
+
+
+_W = C.POINTER(WinoTiles)
+
 # name -> (restype, argtypes); must list every symbol include/mdctgan_hip.h declares
 SIGNATURES = {
     "mg_abi_version": (_i, []),
@@ -42,8 +50,10 @@ SIGNATURES = {
     "mg_conv_fwd_workspace": (_sz, [_G]),
     "mg_conv_wino_weights_bytes": (_sz, [_G]),
     "mg_conv_wino_prepare": (_i, [_G, _p, _p, _p]),
-    "mg_conv_fwd_u": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p, _p]),
-    "mg_conv_dgrad_u": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p, _p]),
+    "mg_conv_wino_tiles_bytes": (_sz, [_G, _i]),
+    "mg_conv_fwd_w": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p, _W]),
+    "mg_conv_dgrad_w": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p, _W]),
+    "mg_conv_wgrad_w": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p, _W]),
     "mg_conv_dgrad": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p]),
     "mg_conv_dgrad_workspace": (_sz, [_G]),
     "mg_conv_wgrad": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p]),

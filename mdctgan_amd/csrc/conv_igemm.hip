@@ -1208,7 +1208,7 @@ int wino_launch_tiles(const TilePlan& tp, Launch&& launch) {
 }
 
 int wino_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act, float* ws,
-             hipStream_t st, const float* u_pre) {
+             hipStream_t st, const float* u_pre, float* v_keep) {
     const WinoDims d = wino_dims(g);
     float* U = ws;
     float* V = U + al256((size_t)16 * g->Co * g->Ci);
@@ -1217,6 +1217,7 @@ int wino_fwd(const mg_conv_geom* g, const float* x, const float* w, const float*
     if (u_pre) U = const_cast<float*>(u_pre);
     else hipLaunchKernelGGL(wino_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 4)), dim3(256), 0, st, w,
                             g->Co, g->Ci, U);
+    if (v_keep) V = v_keep;          // the caller keeps B^T x B for the weight gradient
     hipLaunchKernelGGL(wino_input_xform_kernel, dim3(wino_grid((size_t)d.T * g->Ci / 4)), dim3(256), 0, st, x, g->B, g->H,
                        g->W, g->Ci, d.TH, d.TW, 1, g->reflect, V);
     const Geom gg{1, 1, (int)d.T, g->Ci, 1, (int)d.T, g->Co, 1, 1, 1, 0, 0};
@@ -1253,7 +1254,7 @@ int wino_fwd(const mg_conv_geom* g, const float* x, const float* w, const float*
 
 // Data gradient as the transpose of the forward pipeline (wino.h): T tiles, no padded domain.
 int wino_dgrad_t(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act, float* ws,
-                 hipStream_t st, const float* u_pre) {
+                 hipStream_t st, const float* u_pre, float* md_keep) {
     const WinoDims d = wino_dims(g);
     const long long T = d.T;
     float* U = ws;
@@ -1264,6 +1265,7 @@ int wino_dgrad_t(const mg_conv_geom* g, const float* dy, const float* w, const f
     if (u_pre) U = const_cast<float*>(u_pre);
     else hipLaunchKernelGGL(wino_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 4)), dim3(256), 0, st, w,
                             g->Co, g->Ci, U);
+    if (md_keep) Md = md_keep;       // the caller keeps A dy A^T for the weight gradient
     hipLaunchKernelGGL(wino_dy_xform_kernel, dim3(wino_grid((size_t)T * g->Co / 4)), dim3(256), 0, st, dy, g->B, d.TH,
                        d.TW, g->Co, Md);
     const Geom gg{1, 1, (int)T, g->Ci, 1, (int)T, g->Co, 1, 1, 1, 0, 0};
@@ -1296,8 +1298,8 @@ int wino_dgrad_t(const mg_conv_geom* g, const float* dy, const float* w, const f
 }
 
 int wino_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act, float* ws,
-               hipStream_t st, const float* u_pre) {
-    if (!wino_dgrad_padded()) return wino_dgrad_t(g, dy, w, bias, dx, act, ws, st, u_pre);
+               hipStream_t st, const float* u_pre, float* md_keep) {
+    if (!wino_dgrad_padded()) return wino_dgrad_t(g, dy, w, bias, dx, act, ws, st, u_pre, md_keep);
     const WinoDims d = wino_dims(g);
     const long long T = g->reflect ? d.Tp : d.T;
     const int TH = g->reflect ? d.THp : d.TH, TW = g->reflect ? d.TWp : d.TW;
@@ -1347,17 +1349,19 @@ int wino_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const flo
 }
 
 int wino_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate, float* ws,
-               hipStream_t st) {
+               hipStream_t st, const float* v_in, const float* md_in) {
     const WinoDims d = wino_dims(g);
     const WinoWgradPlan p = wino_wgrad_plan(g);
     float* V = ws;
     float* Md = V + al256((size_t)16 * d.T * g->Ci);
     float* dU = Md + al256((size_t)16 * d.T * g->Co);
     float* part = dU + al256((size_t)16 * g->Co * g->Ci);
-    hipLaunchKernelGGL(wino_input_xform_kernel, dim3(wino_grid((size_t)d.T * g->Ci / 4)), dim3(256), 0, st, x, g->B, g->H,
-                       g->W, g->Ci, d.TH, d.TW, 1, g->reflect, V);
-    hipLaunchKernelGGL(wino_dy_xform_kernel, dim3(wino_grid((size_t)d.T * g->Co / 4)), dim3(256), 0, st, dy, g->B, d.TH,
-                       d.TW, g->Co, Md);
+    if (v_in) V = const_cast<float*>(v_in);
+    else hipLaunchKernelGGL(wino_input_xform_kernel, dim3(wino_grid((size_t)d.T * g->Ci / 4)), dim3(256), 0, st, x, g->B,
+                            g->H, g->W, g->Ci, d.TH, d.TW, 1, g->reflect, V);
+    if (md_in) Md = const_cast<float*>(md_in);
+    else hipLaunchKernelGGL(wino_dy_xform_kernel, dim3(wino_grid((size_t)d.T * g->Co / 4)), dim3(256), 0, st, dy, g->B,
+                            d.TH, d.TW, g->Co, Md);
     const Geom gg{1, 1, (int)d.T, g->Ci, 1, (int)d.T, g->Co, 1, 1, 1, 0, 0};
     float* target = p.splits > 1 ? part : dU;
     const Batch bt{d.T * g->Ci, d.T * g->Co, (long long)g->Co * g->Ci, 0};
@@ -1491,19 +1495,37 @@ int mg_conv_wino_prepare(const mg_conv_geom* g, const float* w, float* u, void* 
     return MG_OK;
 }
 
+size_t mg_conv_wino_tiles_bytes(const mg_conv_geom* g, int which) {
+    if (!mg_conv_wino_weights_bytes(g)) return 0;
+    const WinoDims d = wino_dims(g);
+    if (which == 0) return (size_t)16 * d.T * g->Ci * sizeof(float);
+    if (which == 1) return wino_dgrad_padded() ? 0 : (size_t)16 * d.T * g->Co * sizeof(float);
+    return 0;
+}
+static bool wino_tiles_ok(const mg_conv_geom* g, const mg_wino_tiles* t) {
+    if (!t || (!t->u && !t->v && !t->md)) return true;
+    if (!mg_conv_wino_weights_bytes(g)) return false;
+    return (!t->u || aligned16(t->u)) && (!t->v || aligned16(t->v)) && (!t->md || aligned16(t->md));
+}
+
 int mg_conv_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
                 void* workspace, size_t workspace_bytes, void* stream) {
-    return mg_conv_fwd_u(g, x, w, bias, y, act, workspace, workspace_bytes, stream, nullptr);
+    return mg_conv_fwd_w(g, x, w, bias, y, act, workspace, workspace_bytes, stream, nullptr);
 }
 int mg_conv_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
                   void* workspace, size_t workspace_bytes, void* stream) {
-    return mg_conv_dgrad_u(g, dy, w, bias, dx, act, workspace, workspace_bytes, stream, nullptr);
+    return mg_conv_dgrad_w(g, dy, w, bias, dx, act, workspace, workspace_bytes, stream, nullptr);
+}
+int mg_conv_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias, int accumulate,
+                  void* workspace, size_t workspace_bytes, void* stream) {
+    return mg_conv_wgrad_w(g, x, dy, dw, dbias, accumulate, workspace, workspace_bytes, stream, nullptr);
 }
 
-int mg_conv_fwd_u(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
-                  void* workspace, size_t workspace_bytes, void* stream, const float* u) {
+int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
+                  void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* wt) {
     if (!geom_ok(g) || !x || !w || !y) return MG_ERR_ARG;
-    if (u && (!mg_conv_wino_weights_bytes(g) || !aligned16(u))) return MG_ERR_ARG;
+    if (!wino_tiles_ok(g, wt)) return MG_ERR_ARG;
+    const float* u = wt ? wt->u : nullptr;
     if (!prec_h(g) && mg_conv_rowdot_kq(g) && aligned16(x) && aligned16(w)) {
         probe_begin((hipStream_t)stream);
         const int rc = mg_conv_rowdot_fwd(g, x, w, bias, y, act, stream);
@@ -1512,7 +1534,7 @@ int mg_conv_fwd_u(const mg_conv_geom* g, const float* x, const float* w, const f
     }
     if (wino_ok(g) && workspace && workspace_bytes >= wino_fwd_ws(g) && aligned16(x) && aligned16(w) && aligned16(y) &&
         aligned16(workspace) && (!bias || aligned16(bias)))
-        return wino_fwd(g, x, w, bias, y, act, (float*)workspace, (hipStream_t)stream, u);
+        return wino_fwd(g, x, w, bias, y, act, (float*)workspace, (hipStream_t)stream, u, wt ? wt->v : nullptr);
     const Geom gg = to_geom(g);
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)g->B * g->OH * g->OW;
@@ -1553,15 +1575,16 @@ int mg_conv_fwd_u(const mg_conv_geom* g, const float* x, const float* w, const f
     return MG_OK;
 }
 
-int mg_conv_dgrad_u(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
-                    void* workspace, size_t workspace_bytes, void* stream, const float* u) {
+int mg_conv_dgrad_w(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
+                    void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* wt) {
     if (!geom_ok(g) || !dy || !w || !dx) return MG_ERR_ARG;
-    if (u && (!mg_conv_wino_weights_bytes(g) || !aligned16(u))) return MG_ERR_ARG;
+    if (!wino_tiles_ok(g, wt)) return MG_ERR_ARG;
+    const float* u = wt ? wt->u : nullptr;
     if (g->reflect && g->stride != 1) return MG_ERR_UNSUPPORTED;
     if (wino_ok(g) && !(wino_dgrad_padded() && g->reflect && (bias || act != MG_ACT_NONE)) && workspace &&
         workspace_bytes >= wino_dgrad_ws(g) &&
         aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(workspace) && (!bias || aligned16(bias)))
-        return wino_dgrad(g, dy, w, bias, dx, act, (float*)workspace, (hipStream_t)stream, u);
+        return wino_dgrad(g, dy, w, bias, dx, act, (float*)workspace, (hipStream_t)stream, u, wt ? wt->md : nullptr);
     const Geom gg = to_geom(g);
     hipStream_t st = (hipStream_t)stream;
     const int s = g->stride;
@@ -1643,9 +1666,10 @@ size_t mg_conv_wgrad_workspace(const mg_conv_geom* g) {
     return (wg > cs ? wg : cs) + 256;
 }
 
-int mg_conv_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias, int accumulate,
-                  void* workspace, size_t workspace_bytes, void* stream) {
+int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias, int accumulate,
+                    void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* wt) {
     if (!geom_ok(g) || !x || !dy || !dw) return MG_ERR_ARG;
+    if (!wino_tiles_ok(g, wt)) return MG_ERR_ARG;
     if (workspace_bytes < mg_conv_wgrad_workspace(g) || !workspace) return MG_ERR_ARG;
     if (!prec_h(g) && mg_conv_rowdot_kq(g) && aligned16(x) && aligned16(workspace)) {
         probe_begin((hipStream_t)stream);
@@ -1654,7 +1678,8 @@ int mg_conv_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float*
         return rc;
     }
     if (wino_ok(g) && aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace)) {
-        const int rc = wino_wgrad(g, x, dy, dw, accumulate, (float*)workspace, (hipStream_t)stream);
+        const int rc = wino_wgrad(g, x, dy, dw, accumulate, (float*)workspace, (hipStream_t)stream, wt ? wt->v : nullptr,
+                                  wt ? wt->md : nullptr);
         if (rc != MG_OK) return rc;
         if (dbias) {
             const WinoDims d = wino_dims(g);

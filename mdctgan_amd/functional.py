@@ -115,8 +115,12 @@ class _ConvFn(torch.autograd.Function):
             g = ops.conv_geom(B, H, W, Ci, Co, KH, KW, stride, pad, reflect, amp.current_precision())
             # Winograd layers: transform the weights once, reuse the image for the data gradient of this step
             u = ops.wino_weights(g, w) if ctx.needs_input_grad[0] else None
-            y = ops.conv_fwd(g, nhwc_view(x), w, b, act, u)
-            ctx.u = u
+            # ... and keep B^T x B for the weight gradient (A dy A^T is shared between dgrad and wgrad in backward)
+            v = None
+            if u is not None and weight_grad and weight.requires_grad:
+                v, _ = ops.wino_tile_buffers(g, x.device, want_md=False)
+            y = ops.conv_fwd(g, nhwc_view(x), w, b, act, u, v)
+            ctx.u, ctx.v = u, v
         else:
             # nn.ConvTranspose2d(k, stride, pad, output_padding = stride - 1): the data gradient of the conv
             # high-res [B, sH, sW, Cout_T] -> low-res [B, H, W, Cin_T]
@@ -142,9 +146,13 @@ class _ConvFn(torch.autograd.Function):
             gy = nchw_view(ops.act_bwd(nhwc_view(gy), nhwc_view(y), act))
         w = weight.detach()
         dx = None
+        md = None
         if ctx.needs_input_grad[0]:
             if not transposed:
-                dx = nchw_view(ops.conv_dgrad(g, nhwc_view(gy), w, u=getattr(ctx, "u", None)))
+                u = getattr(ctx, "u", None)
+                if u is not None and getattr(ctx, "v", None) is not None:
+                    _, md = ops.wino_tile_buffers(g, gy.device, want_v=False)
+                dx = nchw_view(ops.conv_dgrad(g, nhwc_view(gy), w, u=u, md_out=md))
                 ctx.u = None
             else:
                 dx = nchw_view(ops.conv_fwd(g, nhwc_view(gy), w))
@@ -160,7 +168,9 @@ class _ConvFn(torch.autograd.Function):
                 if bbuf is not None and bacc != wacc:      # keep one accumulate flag per launch
                     ops.colsum(nhwc_view(gy).reshape(-1, g.Co), bbuf, bacc)
                     bbuf = None
-                ops.conv_wgrad(g, nhwc_view(x), nhwc_view(gy), wbuf, bbuf, wacc)
+                v = getattr(ctx, "v", None) if md is not None else None
+                ops.conv_wgrad(g, nhwc_view(x), nhwc_view(gy), wbuf, bbuf, wacc, v=v, md=md)
+                ctx.v = None
             else:
                 ops.conv_wgrad(g, nhwc_view(gy), nhwc_view(x), wbuf, None, wacc)
                 if bbuf is not None:

@@ -53,41 +53,58 @@ def wino_weights(g: ConvGeom, w):
     return u
 
 
-def conv_fwd(g: ConvGeom, x, w, bias=None, act=ACT_NONE, u=None):
+def wino_tile_buffers(g: ConvGeom, device, want_v=True, want_md=True):
+    """(v, md) float32 buffers for the Winograd images a training step shares between its passes (None where the
+    geometry / configuration does not use one)."""
+    lib = _lib.load()
+    nv = lib.mg_conv_wino_tiles_bytes(g, 0) if want_v else 0
+    nm = lib.mg_conv_wino_tiles_bytes(g, 1) if want_md else 0
+    v = torch.empty(nv // 4, dtype=torch.float32, device=device) if nv else None
+    md = torch.empty(nm // 4, dtype=torch.float32, device=device) if nm else None
+    return v, md
+
+
+def _tiles(u=None, v=None, md=None):
+    if u is None and v is None and md is None:
+        return None
+    return _lib.WinoTiles(_lib.ptr(u), _lib.ptr(v), _lib.ptr(md))
+
+
+def conv_fwd(g: ConvGeom, x, w, bias=None, act=ACT_NONE, u=None, v_out=None):
     lib = _lib.load()
     y = torch.empty(g.B, g.OH, g.OW, g.Co, dtype=torch.float32, device=x.device)
     ws = _ws(lib.mg_conv_fwd_workspace(g), x.device)
     if PROFILER is not None:
         PROFILER.begin(0, g)
-    _lib.check(lib.mg_conv_fwd_u(g, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), act, _lib.ptr(ws),
-                                 ws.numel(), _lib.stream(), _lib.ptr(u)), "mg_conv_fwd")
+    _lib.check(lib.mg_conv_fwd_w(g, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), act, _lib.ptr(ws),
+                                 ws.numel(), _lib.stream(), _tiles(u, v_out, None)), "mg_conv_fwd")
     if PROFILER is not None:
         PROFILER.end()
     return y
 
 
-def conv_dgrad(g: ConvGeom, dy, w, bias=None, act=ACT_NONE, u=None):
+def conv_dgrad(g: ConvGeom, dy, w, bias=None, act=ACT_NONE, u=None, md_out=None):
     lib = _lib.load()
     dx = torch.empty(g.B, g.H, g.W, g.Ci, dtype=torch.float32, device=dy.device)
     ws = _ws(lib.mg_conv_dgrad_workspace(g), dy.device)
     if PROFILER is not None:
         PROFILER.begin(1, g)
-    _lib.check(lib.mg_conv_dgrad_u(g, _lib.ptr(dy), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(dx), act, _lib.ptr(ws),
-                                   ws.numel(), _lib.stream(), _lib.ptr(u)), "mg_conv_dgrad")
+    _lib.check(lib.mg_conv_dgrad_w(g, _lib.ptr(dy), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(dx), act, _lib.ptr(ws),
+                                   ws.numel(), _lib.stream(), _tiles(u, None, md_out)), "mg_conv_dgrad")
     if PROFILER is not None:
         PROFILER.end()
     return dx
 
 
-def conv_wgrad(g: ConvGeom, x, dy, dw, dbias=None, accumulate=False):
+def conv_wgrad(g: ConvGeom, x, dy, dw, dbias=None, accumulate=False, v=None, md=None):
     """dw: float32 buffer of Co*KH*KW*Ci elements in OHWI order (written / accumulated in place)."""
     lib = _lib.load()
     nbytes = lib.mg_conv_wgrad_workspace(g)
     ws = _ws(nbytes, x.device)
     if PROFILER is not None:
         PROFILER.begin(2, g)
-    _lib.check(lib.mg_conv_wgrad(g, _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(dbias), int(accumulate),
-                                 _lib.ptr(ws), ws.numel(), _lib.stream()), "mg_conv_wgrad")
+    _lib.check(lib.mg_conv_wgrad_w(g, _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(dbias), int(accumulate),
+                                   _lib.ptr(ws), ws.numel(), _lib.stream(), _tiles(None, v, md)), "mg_conv_wgrad")
     if PROFILER is not None:
         PROFILER.end()
 

@@ -145,5 +145,15 @@ def test_winograd_shared_weight_transform(reflect):
     assert u is not None and u.numel() == 16 * C * C
     assert torch.equal(ops.conv_fwd(g, x, w, None, ops.ACT_NONE, u), ops.conv_fwd(g, x, w))
     assert torch.equal(ops.conv_dgrad(g, dy, w, u=u), ops.conv_dgrad(g, dy, w))
+    # the tile images a step shares: V = B^T x B kept by forward, Md = A dy A^T kept by the data gradient, both consumed
+    # by the weight gradient -- same bits as the calls that transform internally
+    v, md = ops.wino_tile_buffers(g, x.device)
+    assert v is not None and v.numel() == 16 * (B * H * W // 4) * C and md is not None and md.numel() == v.numel()
+    assert torch.equal(ops.conv_fwd(g, x, w, None, ops.ACT_NONE, u, v), ops.conv_fwd(g, x, w))
+    assert torch.equal(ops.conv_dgrad(g, dy, w, u=u, md_out=md), ops.conv_dgrad(g, dy, w))
+    dw0, dw1 = torch.empty(C, 3, 3, C, device=DEV), torch.empty(C, 3, 3, C, device=DEV)
+    ops.conv_wgrad(g, x, dy, dw0, None)
+    ops.conv_wgrad(g, x, dy, dw1, None, v=v, md=md)
+    assert torch.equal(dw0, dw1)
     g2 = ops.conv_geom(B, H, W, C, C, 3, 3, 2, 1, False)
     assert ops.wino_weights(g2, w) is None
