@@ -1426,7 +1426,7 @@ double mg_conv_plan_flops(int pass, const mg_conv_geom* g) {
 // minus the anonymous-namespace prefix).  pass: 0 fwd, 1 dgrad, 2 wgrad.
 int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
     if (!geom_ok(g) || !out || out_len < 64) return MG_ERR_ARG;
-    const int kq = prec_h(g) ? 0 : mg_conv_rowdot_kq(g);
+    const int kq = mg_conv_rowdot_kq(g);
     if (wino_ok(g) && !kq) {
         const WinoDims d = wino_dims(g);
         if (pass == 0) {
@@ -1526,7 +1526,7 @@ int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const f
     if (!geom_ok(g) || !x || !w || !y) return MG_ERR_ARG;
     if (!wino_tiles_ok(g, wt)) return MG_ERR_ARG;
     const float* u = wt ? wt->u : nullptr;
-    if (!prec_h(g) && mg_conv_rowdot_kq(g) && aligned16(x) && aligned16(w)) {
+    if (mg_conv_rowdot_kq(g) && aligned16(x) && aligned16(w)) {
         probe_begin((hipStream_t)stream);
         const int rc = mg_conv_rowdot_fwd(g, x, w, bias, y, act, stream);
         probe_end((hipStream_t)stream);
@@ -1658,7 +1658,7 @@ int mg_colsum(const float* a, long long M, int C, float* out, int accumulate, vo
 
 size_t mg_conv_wgrad_workspace(const mg_conv_geom* g) {
     if (!geom_ok(g)) return 0;
-    if (!prec_h(g) && mg_conv_rowdot_kq(g)) return mg_conv_rowdot_wgrad_workspace(g);
+    if (mg_conv_rowdot_kq(g)) return mg_conv_rowdot_wgrad_workspace(g);
     if (wino_ok(g)) return wino_wgrad_ws(g);
     const WgradPlan p = wgrad_plan(g);
     const size_t wg = p.splits > 1 ? (size_t)p.splits * g->Co * g->KH * g->KW * g->Ci * sizeof(float) : 0;
@@ -1671,7 +1671,7 @@ int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, floa
     if (!geom_ok(g) || !x || !dy || !dw) return MG_ERR_ARG;
     if (!wino_tiles_ok(g, wt)) return MG_ERR_ARG;
     if (workspace_bytes < mg_conv_wgrad_workspace(g) || !workspace) return MG_ERR_ARG;
-    if (!prec_h(g) && mg_conv_rowdot_kq(g) && aligned16(x) && aligned16(workspace)) {
+    if (mg_conv_rowdot_kq(g) && aligned16(x) && aligned16(workspace)) {
         probe_begin((hipStream_t)stream);
         const int rc = mg_conv_rowdot_wgrad(g, x, dy, dw, dbias, accumulate, workspace, workspace_bytes, stream);
         probe_end((hipStream_t)stream);

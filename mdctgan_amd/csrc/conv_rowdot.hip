@@ -48,9 +48,12 @@ __device__ __forceinline__ void make_meta(const Geom& g, int lane, int (&meta)[K
     }
 }
 
+__device__ __forceinline__ float4 round_h4(float4 v) { return make_float4(round_h(v.x), round_h(v.y), round_h(v.z), round_h(v.w)); }
+
+// hp != 0 (MG_PRECISION_F16): operands are rounded to float16 as they are loaded, products / sums stay float32
 template <int KQ>
 __device__ __forceinline__ void gather_row(const Geom& g, const float* __restrict__ x, int b, int oy, int ox,
-                                           const int (&meta)[KQ], float4 (&a)[KQ]) {
+                                           const int (&meta)[KQ], float4 (&a)[KQ], int hp) {
 #pragma unroll
     for (int j = 0; j < KQ; ++j) {
         a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -63,6 +66,7 @@ __device__ __forceinline__ void gather_row(const Geom& g, const float* __restric
             continue;
         }
         a[j] = *reinterpret_cast<const float4*>(x + ((size_t)(b * g.H + iy) * g.W + ix) * g.Ci + (meta[j] >> 16));
+        if (hp) a[j] = round_h4(a[j]);
     }
 }
 
@@ -70,7 +74,7 @@ template <int KQ>
 __global__ __launch_bounds__(256) void conv_rowdot_fwd_kernel(Geom g, const float* __restrict__ x,
                                                               const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ y,
-                                                              int act) {
+                                                              int act, int hp) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     const int M = g.B * g.OH * g.OW;
@@ -80,17 +84,24 @@ __global__ __launch_bounds__(256) void conv_rowdot_fwd_kernel(Geom g, const floa
 #pragma unroll
     for (int j = 0; j < KQ; ++j)
         wv[j] = (meta[j] >= 0) ? *reinterpret_cast<const float4*>(w + 4 * (j * 64 + lane)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (hp) {
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) wv[j] = round_h4(wv[j]);
+    }
     const float bv = bias ? bias[0] : 0.0f;
     for (int m = wave; m < M; m += nwaves) {
         const int b = m / (g.OH * g.OW), rem = m - b * (g.OH * g.OW);
         const int oy = rem / g.OW, ox = rem - oy * g.OW;
         float4 a[KQ];
-        gather_row<KQ>(g, x, b, oy, ox, meta, a);
+        gather_row<KQ>(g, x, b, oy, ox, meta, a, hp);
         float s = 0.0f;
 #pragma unroll
         for (int j = 0; j < KQ; ++j) s += a[j].x * wv[j].x + a[j].y * wv[j].y + a[j].z * wv[j].z + a[j].w * wv[j].w;
         s = wave_sum(s);
-        if (lane == 0) y[m] = apply_act(s + bv, act);
+        if (lane == 0) {
+            const float v = apply_act(s + bv, act);
+            y[m] = hp ? round_h(v) : v;
+        }
     }
 }
 
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(256) void conv_rowdot_fwd_kernel(Geom g, const floa
 template <int KQ>
 __global__ __launch_bounds__(256) void conv_rowdot_wgrad_kernel(Geom g, const float* __restrict__ x,
                                                                 const float* __restrict__ dy, float* __restrict__ part,
-                                                                int KP) {
+                                                                int KP, int hp) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     const int M = g.B * g.OH * g.OW, K = g.KH * g.KW * g.Ci;
@@ -111,14 +122,15 @@ __global__ __launch_bounds__(256) void conv_rowdot_wgrad_kernel(Geom g, const fl
     for (int m = wave; m < M; m += nwaves) {
         const int b = m / (g.OH * g.OW), rem = m - b * (g.OH * g.OW);
         const int oy = rem / g.OW, ox = rem - oy * g.OW;
-        const float gv = dy[m];
+        const float g0 = dy[m];
+        const float gv = hp ? round_h(g0) : g0;
         float4 a[KQ];
-        gather_row<KQ>(g, x, b, oy, ox, meta, a);
+        gather_row<KQ>(g, x, b, oy, ox, meta, a, hp);
 #pragma unroll
         for (int j = 0; j < KQ; ++j) {
             acc[j].x += gv * a[j].x; acc[j].y += gv * a[j].y; acc[j].z += gv * a[j].z; acc[j].w += gv * a[j].w;
         }
-        gsum += gv;
+        gsum += g0;
     }
     float* row = part + (size_t)wave * KP;
 #pragma unroll
@@ -162,9 +174,11 @@ int mg_conv_rowdot_fwd(const mg_conv_geom* g, const float* x, const float* w, co
     const Geom gg{g->B, g->H, g->W, g->Ci, g->OH, g->OW, g->Co, g->KH, g->KW, g->stride, g->pad, g->reflect};
     const int nw = rowdot_waves((long long)g->B * g->OH * g->OW);
     if (kq == 16)
-        hipLaunchKernelGGL(conv_rowdot_fwd_kernel<16>, dim3(nw / 4), dim3(256), 0, (hipStream_t)stream, gg, x, w, bias, y, act);
+        hipLaunchKernelGGL(conv_rowdot_fwd_kernel<16>, dim3(nw / 4), dim3(256), 0, (hipStream_t)stream, gg, x, w, bias, y, act,
+                           g->precision);
     else
-        hipLaunchKernelGGL(conv_rowdot_fwd_kernel<32>, dim3(nw / 4), dim3(256), 0, (hipStream_t)stream, gg, x, w, bias, y, act);
+        hipLaunchKernelGGL(conv_rowdot_fwd_kernel<32>, dim3(nw / 4), dim3(256), 0, (hipStream_t)stream, gg, x, w, bias, y, act,
+                           g->precision);
     MG_CHECK_LAUNCH();
     return MG_OK;
 }
@@ -189,9 +203,9 @@ int mg_conv_rowdot_wgrad(const mg_conv_geom* g, const float* x, const float* dy,
     char* cs_ws = (char*)(sums + KP);
     cs_ws += (16 - (reinterpret_cast<uintptr_t>(cs_ws) & 15)) & 15;
     if (kq == 16)
-        hipLaunchKernelGGL(conv_rowdot_wgrad_kernel<16>, dim3(nw / 4), dim3(256), 0, st, gg, x, dy, part, KP);
+        hipLaunchKernelGGL(conv_rowdot_wgrad_kernel<16>, dim3(nw / 4), dim3(256), 0, st, gg, x, dy, part, KP, g->precision);
     else
-        hipLaunchKernelGGL(conv_rowdot_wgrad_kernel<32>, dim3(nw / 4), dim3(256), 0, st, gg, x, dy, part, KP);
+        hipLaunchKernelGGL(conv_rowdot_wgrad_kernel<32>, dim3(nw / 4), dim3(256), 0, st, gg, x, dy, part, KP, g->precision);
     MG_CHECK_LAUNCH();
     const int rc = mg_colsum(part, nw, KP, sums, 0, cs_ws, mg_colsum_workspace(nw, KP), stream);
     if (rc != MG_OK) return rc;

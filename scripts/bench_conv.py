@@ -42,12 +42,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--f16", action="store_true", help="MG_PRECISION_F16 (autocast arithmetic)")
     a = ap.parse_args()
     for name, (B, H, W, Ci, Co, k, s, p, refl) in SHAPES.items():
         if a.only and name not in a.only.split(","):
             continue
         B = int(os.environ.get("MG_BENCH_BATCH", B))
-        g = ops.conv_geom(B, H, W, Ci, Co, k, k, s, p, refl)
+        g = ops.conv_geom(B, H, W, Ci, Co, k, k, s, p, refl, 1 if a.f16 else 0)
         x = torch.randn(B, H, W, Ci, device="cuda")
         w = torch.randn(Co, k, k, Ci, device="cuda") * 0.02
         b = torch.randn(Co, device="cuda")
