@@ -9,7 +9,8 @@ for bm, bn, sp, k32 in ([] if WGRAD_ONLY else [(a, b, c, d) for (a, b, c) in cfg
     env = dict(os.environ, MG_FORCE_PLAN="%d,%d,%d" % (bm, bn, sp))
     if not k32:
         env["MG_NO_BK32"] = "1"
-    out = subprocess.run([sys.executable, "scripts/bench_conv.py", "--only", ",".join(shapes), "--iters", "10"], env=env,
+    out = subprocess.run([sys.executable, "scripts/bench_conv.py", "--only", ",".join(shapes), "--iters", "10"] +
+                         (["--f16"] if os.environ.get("MG_TUNE_F16") else []), env=env,
                          capture_output=True, text=True).stdout
     for line in out.splitlines():
         m = re.match(r"(\S+)\s+[\d.]+ GF \| fwd\s+([\d.]+) us.*?\| dgrad\s+([\d.]+) us", line)
@@ -36,7 +37,8 @@ def tune_wgrad(shapes):
     for big in (0, 1):
         for sp in [int(v) for v in os.environ.get('MG_TUNE_SPLITS', '1,2,3,4,6,8,12,16,24,32,48').split(',')]:
             env = dict(os.environ, MG_FORCE_WGRAD="%d,%d" % (big, sp))
-            out = subprocess.run([sys.executable, "scripts/bench_conv.py", "--only", ",".join(shapes), "--iters", "10"],
+            out = subprocess.run([sys.executable, "scripts/bench_conv.py", "--only", ",".join(shapes), "--iters", "10"] +
+                                 (["--f16"] if os.environ.get("MG_TUNE_F16") else []),
                                  env=env, capture_output=True, text=True).stdout
             for line in out.splitlines():
                 m = re.match(r"(\S+)\s+[\d.]+ GF \|.*\| wgrad\s+([\d.]+) us", line)
