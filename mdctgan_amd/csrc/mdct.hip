@@ -160,6 +160,131 @@ __global__ __launch_bounds__(256) void mdct4_kernel(
     }
 }
 
+#include "gemm32.h"
+
+// ---------------------------------------------------------------------------------------------
+// K1 as a tiled GEMM (large batches): U [B*F, 256] x D4 [256, 256] with 128 x 128 output tiles, both operands staged
+// through LDS in 32-deep row-major chunks (gemm32.h) so a D4 element fetched from L2 feeds 128 frames instead of the
+// 32 of mdct4_kernel's per-wave B stream.  The A operand never exists in memory: a thread builds four consecutive
+// folded samples u[n..n+3] of its frame from two float4 loads of the signal (one of them reversed) and the matching
+// window values.  D4 is symmetric, so row `bin` of the table is the k-contiguous B row.  Requirements: T % 4 == 0
+// (float4 loads never straddle the zero padding), the fixed-range codec (--abs_norm) or raw output, no frames_out.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 rev4(const float4 v) { return make_float4(v.w, v.z, v.y, v.x); }
+
+__global__ __launch_bounds__(256) void mdct4_gemm_kernel(const float* __restrict__ audio, int B, int T, int F,
+                                                         const float* __restrict__ window,
+                                                         const float* __restrict__ dct4, CodecParams cp,
+                                                         float* __restrict__ spec, float* __restrict__ in2,
+                                                         double* __restrict__ stats) {
+    constexpr int BM = 128, BN = 128, MB = 2, NB = 2, NV = 4, Q = M / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem32[];
+    auto As = [&](int buf) -> float* { return smem32 + buf * (BM * LDK2); };
+    auto Bs = [&](int buf) -> float* { return smem32 + 2 * BM * LDK2 + buf * (BN * LDK2); };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rows = B * F;
+    const int m0 = (blockIdx.x >> 1) * BM, n0 = (blockIdx.x & 1) * BN;     // the two column tiles of a row tile are neighbours
+    const int q = tid & 7, r0 = tid >> 3;
+
+    const float* xrow[NV];      // audio of the clip + the frame's offset (sample of padded position f*M is xrow[-M])
+    int tbase[NV];              // f * M - M: sample index of the frame's first padded position
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        if (m < rows) {
+            const int b = m / F, f = m - b * F;
+            xrow[i] = audio + (size_t)b * T;
+            tbase[i] = f * M - M;
+        } else {
+            xrow[i] = nullptr;
+            tbase[i] = 0;
+        }
+    }
+    auto ldx = [&](int i, int off) -> float4 {         // 4 samples at frame position `off` (multiple of 4), 0 outside
+        const int t = tbase[i] + off;
+        return (xrow[i] && t >= 0 && t + 3 < T) ? g32_ld4(xrow[i] + t) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto zmul = [&](const float4 x4, const float4 w4) -> float4 {     // fl32(x * w), like mdct.py:410
+        return make_float4(__fmul_rn(x4.x, w4.x), __fmul_rn(x4.y, w4.y), __fmul_rn(x4.z, w4.z), __fmul_rn(x4.w, w4.w));
+    };
+    auto load_a = [&](int c, float4 (&va)[NV]) {
+        const int n = c * BK2 + 4 * q;                 // u[n .. n+3]; a chunk never straddles Q
+        int o1, o2;
+        if (n < Q) { o1 = 3 * Q - 4 - n; o2 = 3 * Q + n; }       // -z[3Q-1-n-j] - z[3Q+n+j]
+        else { o1 = n - Q; o2 = 3 * Q - 4 - n; }                 //  z[n-Q+j]    - z[2Q-1-(n-Q)-j]  (2Q-4-(n-Q) = 3Q-4-n)
+        const float4 w1 = g32_ld4(window + o1), w2 = g32_ld4(window + o2);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float4 z1 = zmul(ldx(i, o1), w1), z2 = zmul(ldx(i, o2), w2);
+            if (n < Q) {
+                const float4 r1 = rev4(z1);
+                va[i] = make_float4(-r1.x - z2.x, -r1.y - z2.y, -r1.z - z2.z, -r1.w - z2.w);
+            } else {
+                const float4 r2 = rev4(z2);
+                va[i] = make_float4(z1.x - r2.x, z1.y - r2.y, z1.z - r2.z, z1.w - r2.w);
+            }
+        }
+    };
+    auto load_b = [&](int c, float4 (&vb)[NV]) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) vb[i] = g32_ld4(dct4 + (size_t)(n0 + r0 + 32 * i) * M + c * BK2 + 4 * q);
+    };
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = f32x16{0};
+    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+    float4 va[NV], vb[NV];
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(As(buf) + (r0 + 32 * i) * LDK2 + 4 * q) = va[i];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(Bs(buf) + (r0 + 32 * i) * LDK2 + 4 * q) = vb[i];
+    };
+    constexpr int NCH = M / BK2;
+    load_a(0, va); load_b(0, vb); stash(0);
+    __syncthreads();
+    load_a(1, va); load_b(1, vb);
+    for (int c = 0; c < NCH; ++c) {
+        const int cur = c & 1;
+        mma_chunk32<MB, NB>(
+            As(cur), Bs(cur), acc, wm0, wn0, lane,
+            [&]() { if (c + 1 < NCH) stash(cur ^ 1); },
+            [&]() { if (c + 2 < NCH) { load_a(c + 2, va); load_b(c + 2, vb); } });
+        __syncthreads();
+    }
+
+    // epilogue: codec + stores (fixed-range normalisation or raw)
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni) {
+            const int col = n0 + wn0 + 32 * ni + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + 32 * mi + mfma32_row(r, lane);
+                if (m >= rows) continue;
+                const float xv = acc[mi][ni][r];
+                float v = xv;
+                if (cp.mode != CODEC_RAW) {
+                    float l = xv;
+                    if (cp.mode == CODEC_ARCSINH) l = asinhf(cp.gain * xv) / LN10F;
+                    if (stats) { s1 += (double)l; s2 += (double)l * (double)l; }
+                    v = (l - cp.mn) / (cp.mx - cp.mn) * (cp.nr1 - cp.nr0) + cp.nr0;
+                }
+                const size_t o = (size_t)m * M + col;
+                spec[o] = v;
+                if (in2) *reinterpret_cast<float2*>(in2 + 2 * o) = make_float2(v, fabsf(v) * 2.0f + cp.nr0);
+            }
+        }
+    if (stats && cp.mode != CODEC_RAW) {
+        s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+        if (lane == 0) { atomicAdd(stats, s1); atomicAdd(stats + 1, s2); }
+    }
+}
+
 // second pass of the per-sample min/max normalisation (no --abs_norm): in place over spec [B, n]
 __global__ void range_norm_kernel(float* __restrict__ spec, float* __restrict__ in2, int n,
                                   const unsigned* __restrict__ minmax_ord, float nr0, float nr1,
@@ -352,6 +477,20 @@ int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* w
     }
     if (stats) hipMemsetAsync(stats, 0, 2 * sizeof(double), st);
     if (per_sample) hipLaunchKernelGGL(fill_u32_pairs, dim3((B + 255) / 256), dim3(256), 0, st, scratch_u32, B);
+    // large batches: the tiled GEMM kernel (B operand shared through LDS); MG_MDCT_GEMM=0/1 overrides
+    const long long row_tiles = ((long long)B * F + 127) / 128;
+    bool gemm = row_tiles >= 256;
+    if (const char* e = getenv("MG_MDCT_GEMM")) gemm = atoi(e) != 0;
+    if (gemm && T % 4 == 0 && !per_sample && !frames_out && (reinterpret_cast<uintptr_t>(audio) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(window) & 15) == 0 && (reinterpret_cast<uintptr_t>(dct4) & 15) == 0) {
+        constexpr size_t lds = (size_t)2 * (128 + 128) * LDK2 * sizeof(float);
+        static bool attr2 = false;
+        if (!attr2) { allow_lds(mdct4_gemm_kernel, lds); attr2 = true; }
+        hipLaunchKernelGGL(mdct4_gemm_kernel, dim3((unsigned)(row_tiles * 2)), dim3(256), lds, st, audio, B, T, F, window,
+                           dct4, cp, spec, in2, stats);
+        MG_CHECK_LAUNCH();
+        return MG_OK;
+    }
     const int ft = frames_per_wg(B, F);
     if (ft == 128)
         hipLaunchKernelGGL(mdct4_kernel<128>, dim3((F + 127) / 128, B), dim3(256), (128 * LDA + 2 * M) * sizeof(float), st,

@@ -165,3 +165,34 @@ def test_frame_tile_sizes_agree(mods, monkeypatch):
         for i in (0, 1, 3):
             assert torch.equal(outs["32"][i], outs[ft][i])
         assert (outs["32"][2] - outs[ft][2]).abs().max().item() <= 2e-6 * outs["32"][2].abs().max().item()
+
+
+def test_mdct_gemm_kernel_matches(mods, golden, monkeypatch):
+    """The tiled-GEMM K1 kernel (used for large batches) against the golden spectra and against the per-wave kernel:
+    same float32 window products and fold, a different (still exact-f32) accumulation order -> 2e-6 * max|X|; the codec
+    epilogue (arcsinh + fixed range + pair + statistics) agrees to 1e-6."""
+    from mdctgan_amd import _lib
+    from mdctgan_amd.mdct import dct4_table, mdct4_codec
+    mdct, _, w = mods
+    g = golden("g2_mdct4")
+    monkeypatch.setenv("MG_MDCT_GEMM", "1")
+    X, _ = mdct(torch.from_numpy(g["x"]).to(DEV))
+    Xc = X.cpu().numpy().astype(np.float64)
+    for b in range(2):
+        assert np.abs(Xc[b] - g["X"][b]).max() <= 2e-6 * np.abs(g["X"][b]).max()
+    gen = torch.Generator().manual_seed(3)
+    x = (0.05 * torch.randn(5, 32512, generator=gen)).to(DEV)     # 5 clips x 128 frames = 5 row tiles
+    win, d4 = torch.from_numpy(w).to(DEV), dct4_table(256, DEV)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MG_MDCT_GEMM", mode)
+        r = mdct4_codec(x, win, d4, 512, codec=_lib.MG_CODEC_ARCSINH, gain=1000.0, norm_range=(-1.0, 1.0), src_range=(-5.0, 5.0),
+                        per_sample=False, want_pair=True, want_stats=True, want_frames=False)
+        outs[mode] = (r["spec"].clone(), r["pair"].clone(), r["stats"].clone())
+    want, _ = transform.to_spectro(x.cpu().numpy(), w, 512, 256, arcsinh_transform=True, raw_mdct=False,
+                                   arcsinh_gain=1000.0, abs_norm=True, src_range=(-5.0, 5.0), norm_range=(-1.0, 1.0))
+    for mode in ("0", "1"):     # both kernels within the header's 5e-4 of the float64 oracle (gain 1000 amplifies near-zero bins)
+        assert np.abs(outs[mode][0].cpu().numpy() - want[:, 0]).max() <= 5e-4, mode
+        pair = outs[mode][1].cpu().numpy()
+        assert np.abs(pair[..., 0] - want[:, 0]).max() <= 5e-4 and np.abs(pair[..., 1] - (2 * np.abs(want[:, 0]) - 1.0)).max() <= 1e-3
+    assert torch.allclose(outs["0"][2], outs["1"][2], rtol=1e-5)
