@@ -413,9 +413,15 @@ __global__ __launch_bounds__(256) void conv_fwd32_kernel(Geom g, const float* __
     float4 va[NVA], vb[NVB];
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) *reinterpret_cast<float4*>(As(buf) + (r0 + 32 * i) * LDK2 + 4 * q) = va[i];
+        for (int i = 0; i < NVA; ++i) {
+            if (TAG >= 2) g32_st_h4(As(buf) + (r0 + 32 * i) * LDK2, q, va[i]);
+            else *reinterpret_cast<float4*>(As(buf) + (r0 + 32 * i) * LDK2 + 4 * q) = va[i];
+        }
 #pragma unroll
-        for (int i = 0; i < NVB; ++i) *reinterpret_cast<float4*>(Bs(buf) + (r0 + 32 * i) * LDK2 + 4 * q) = vb[i];
+        for (int i = 0; i < NVB; ++i) {
+            if (TAG >= 2) g32_st_h4(Bs(buf) + (r0 + 32 * i) * LDK2, q, vb[i]);
+            else *reinterpret_cast<float4*>(Bs(buf) + (r0 + 32 * i) * LDK2 + 4 * q) = vb[i];
+        }
     };
     if (c_begin < nchunks) {
         load_a(c_begin, va);
@@ -429,10 +435,10 @@ __global__ __launch_bounds__(256) void conv_fwd32_kernel(Geom g, const float* __
     }
     for (int c = c_begin; c < nchunks; ++c) {
         const int cur = (c - c_begin) & 1;
-        mma_chunk32<MB, NB>(
-            As(cur), Bs(cur), acc, wm0, wn0, lane,
-            [&]() { if (c + 1 < nchunks) stash(cur ^ 1); },
-            [&]() { if (c + 2 < nchunks) { load_a(c + 2, va); load_b(c + 2, vb); } });
+        auto f0 = [&]() { if (c + 1 < nchunks) stash(cur ^ 1); };
+        auto f1 = [&]() { if (c + 2 < nchunks) { load_a(c + 2, va); load_b(c + 2, vb); } };
+        if (TAG >= 2) mma_chunk32_h<MB, NB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
+        else mma_chunk32<MB, NB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
         __syncthreads();
     }
 
@@ -447,7 +453,10 @@ __global__ __launch_bounds__(256) void conv_fwd32_kernel(Geom g, const float* __
                 const int row = m0 + wm0 + 32 * mi + mfma32_row(r, lane);
                 if (row < M && col < N) {
                     if (part) part[(size_t)row * N + col] = acc[mi][ni][r];
-                    else y[(size_t)row * N + col] = apply_act(acc[mi][ni][r] + bv, act);
+                    else {
+                        const float v = apply_act(acc[mi][ni][r] + bv, act);
+                        y[(size_t)row * N + col] = (TAG >= 2) ? round_h(v) : v;
+                    }
                 }
             }
         }
@@ -1188,11 +1197,14 @@ int wino_fwd(const mg_conv_geom* g, const float* x, const float* w, const float*
     const Batch bt{d.T * g->Ci, (long long)g->Co * g->Ci, d.T * g->Co, 0};
     probe_begin(st);
     const bool hp = prec_h(g);
-    const bool k32 = !hp && use_k32(tp, g->Ci);
+    const bool k32 = hp ? (fwd32_enabled() && g->Ci % BK2 == 0 && (tp.splits == 1 || tp.cps % 2 == 0)) : use_k32(tp, g->Ci);
     wino_launch_tiles(tp, [&](auto bm, auto bn) {
         constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value;
         dim3 grid((unsigned)(((d.T + BM_ - 1) / BM_) * ((g->Co + BN_ - 1) / BN_)), tp.splits, 16);
-        if (hp)
+        if (hp && k32)
+            launch_fwd32<BM_, BN_, 3>(grid, st, gg, V, U, nullptr, Mx, MG_ACT_NONE, tp.splits == 1 ? (1 << 29) : tp.cps / 2,
+                                      pp, bt);
+        else if (hp)
             hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, true, 3>), grid, dim3(256), 0, st, gg, (const float*)V,
                                (const float*)U, (const float*)nullptr, Mx, MG_ACT_NONE, tp.cps, pp, bt);
         else if (k32)
@@ -1393,7 +1405,10 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
         const WinoDims d = wino_dims(g);
         if (pass == 0) {
             const TilePlan tp = gemm_plan(d.T, g->Co, g->Ci / BK, 16, true, 0);
-            if (prec_h(g))
+            const bool k32h = fwd32_enabled() && g->Ci % BK2 == 0 && (tp.splits == 1 || tp.cps % 2 == 0);
+            if (prec_h(g) && k32h)
+                snprintf(out, out_len, "conv_fwd32_kernel<%d, %d, 3>", tp.bm, tp.bn);
+            else if (prec_h(g))
                 snprintf(out, out_len, "conv_fwd_kernel<%d, %d, true, 3>", tp.bm, tp.bn);
             else if (use_k32(tp, g->Ci))
                 snprintf(out, out_len, "conv_fwd32_kernel<%d, %d, 1>", tp.bm, tp.bn);
@@ -1413,7 +1428,11 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
         snprintf(out, out_len, "conv_rowdot_wgrad_kernel<%d>", kq);
     } else if (pass == 0) {
         const TilePlan tp = fwd_plan(g);
-        if (use_k32(tp, g->Ci))
+        const bool vec16 = g->Ci % BK == 0;
+        const bool k32h = vec16 && fwd32_enabled() && g->Ci % BK2 == 0 && (tp.splits == 1 || tp.cps % 2 == 0);
+        if (prec_h(g) && k32h)
+            snprintf(out, out_len, "conv_fwd32_kernel<%d, %d, 2>", tp.bm, tp.bn);
+        else if (!prec_h(g) && use_k32(tp, g->Ci))
             snprintf(out, out_len, "conv_fwd32_kernel<%d, %d, 0>", tp.bm, tp.bn);
         else
             snprintf(out, out_len, "conv_fwd_kernel<%d, %d, %s, %d>", tp.bm, tp.bn, (g->Ci % BK == 0) ? "true" : "false",
@@ -1510,11 +1529,14 @@ int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const f
     }
     float* part = tp.splits > 1 ? (float*)workspace : nullptr;
     const bool hp = prec_h(g);
-    const bool k32 = vec && !hp && use_k32(tp, g->Ci);
+    // f16: the 32-deep kernel whenever the shape allows it (its stage / fragment traffic is what the f16 loop is made of)
+    const bool k32 = vec && (hp ? (fwd32_enabled() && g->Ci % BK2 == 0 && (tp.splits == 1 || tp.cps % 2 == 0))
+                                : use_k32(tp, g->Ci));
 #define MG_LAUNCH_FWD(BM_, BN_)                                                                                    \
     do {                                                                                                           \
         dim3 grid((unsigned)(((M + BM_ - 1) / BM_) * ((N + BN_ - 1) / BN_)), tp.splits);                           \
-        if (k32) launch_fwd32<BM_, BN_, 0>(grid, st, gg, x, w, bias, y, act, tp.splits == 1 ? (1 << 29) : tp.cps / 2, part, Batch{0, 0, 0, 0}); \
+        if (k32 && hp) launch_fwd32<BM_, BN_, 2>(grid, st, gg, x, w, bias, y, act, tp.splits == 1 ? (1 << 29) : tp.cps / 2, part, Batch{0, 0, 0, 0}); \
+        else if (k32) launch_fwd32<BM_, BN_, 0>(grid, st, gg, x, w, bias, y, act, tp.splits == 1 ? (1 << 29) : tp.cps / 2, part, Batch{0, 0, 0, 0}); \
         else if (hp && vec) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, true, 2>), grid, dim3(256), 0, st, gg, x, w, bias, y, act, tp.cps, part, Batch{0, 0, 0, 0});  \
         else if (hp) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, false, 2>), grid, dim3(256), 0, st, gg, x, w, bias, y, act, tp.cps, part, Batch{0, 0, 0, 0});    \
         else if (vec) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, true>), grid, dim3(256), 0, st, gg, x, w, bias, y, act, tp.cps, part, Batch{0, 0, 0, 0});  \
