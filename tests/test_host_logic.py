@@ -117,3 +117,27 @@ def test_bot_state_dict_contract(golden):
                             dim_head_g=16, proj_factor_g=4)
     assert list(net.state_dict().keys()) == list(g["keys"])
     assert [str(tuple(p.shape)) for p in net.state_dict().values()] == list(g["shapes"])
+
+
+def test_segment_audio_and_amp_context():
+    """Host-side pieces that need no GPU: utterance segmentation for generate_audio, the autocast precision switch and
+    the geometry's precision field."""
+    from mdctgan_amd import _lib, amp, ops
+    from mdctgan_amd.generate_audio import segment_audio
+    x = torch.arange(100.0)
+    seg = segment_audio(x, 40, 0)
+    assert seg.shape == (3, 40) and torch.equal(seg[0], x[:40]) and seg[2, 20:].abs().sum() == 0
+    seg = segment_audio(x, 40, 10)                       # stride 30: 0, 30, 60 -> 3 segments cover the 100 samples exactly
+    assert seg.shape == (3, 40) and torch.equal(seg[1], x[30:70]) and torch.equal(seg[2], x[60:])
+    seg = segment_audio(x, 40, 8)                        # stride 32: 0, 32, 64 -> the last one runs 4 samples past the end
+    assert seg.shape == (3, 40) and torch.equal(seg[2, :36], x[64:]) and seg[2, 36:].abs().sum() == 0
+    with pytest.raises(ValueError):
+        segment_audio(x, 40, 40)
+    assert amp.current_precision() == _lib.PRECISION_F32
+    with amp.autocast(True):
+        assert amp.current_precision() == _lib.PRECISION_F16
+        with amp.autocast(False):
+            assert amp.current_precision() == _lib.PRECISION_F32
+        assert ops.conv_geom(1, 8, 8, 4, 4, 3, 3, 1, 1, True, amp.current_precision()).precision == _lib.PRECISION_F16
+    assert amp.current_precision() == _lib.PRECISION_F32
+    assert ops.conv_geom(1, 8, 8, 4, 4, 3, 3, 1, 1, True).precision == _lib.PRECISION_F32
