@@ -984,7 +984,7 @@ TilePlan gemm_plan(long long M, int N, int chunks, int classes, bool can_split, 
     struct Tuned { int pass; long long M; int N, chunks, classes, bm, bn, sp, k32; };
     static const Tuned tuned[] = {
         {0, 256, 1024, 64, 16, 64, 64, 1, 1},      // Winograd forward GEMMs, 1024-channel 8x16 ResNet blocks
-        {1, 256, 1024, 64, 16, 128, 128, 2, 0},    // Winograd data-gradient GEMMs (transposed pipeline: same 256 tiles)
+        {1, 256, 1024, 64, 16, 64, 64, 1, 0},      // Winograd data-gradient GEMMs (transposed pipeline: same 256 tiles)
         {1, 360, 1024, 64, 16, 128, 128, 2, 0},    // ... and over the 10x18 padded domain (MG_WINO_DGRAD=padded)
         {0, 1024, 1024, 288, 1, 128, 128, 8, 1},   // 512->1024 stride-2 forward (and the 1024->512 ConvTranspose backward)
         {0, 4096, 512, 144, 1, 128, 128, 4, 1},    // 256->512
