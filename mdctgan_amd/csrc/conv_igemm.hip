@@ -381,7 +381,23 @@ __global__ __launch_bounds__(256) void conv_fwd32_kernel(Geom g, const float* __
         wrow[i] = (n < N) ? w + (size_t)n * K + 4 * q : nullptr;
     }
 
+    // TAG 1 / 3 (batched plain GEMM of the Winograd path): both operands are dense row-major matrices, so staging is a
+    // pointer per row fixed for the whole K loop + one load per chunk -- no tap / padding / reflection arithmetic.  An
+    // MFMA-bound loop pays ~2.6 cycles for every staging instruction even in the MFMAs' shadow (scripts/ubench), so the
+    // instruction count of the stage, not its placement, is what the remaining efficiency hangs on.  Rows past M / N
+    // re-read the last row: their accumulators are never stored.
+    const float* pa[NVA];
+    const float* pbq[NVB];
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) pa[i] = x + (size_t)min(m0 + r0 + 32 * i, M - 1) * K + 4 * q;
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) pbq[i] = w + (size_t)min(n0 + r0 + 32 * i, N - 1) * K + 4 * q;
     auto load_a = [&](int c, float4 (&va)[NVA]) {
+        if (TAG & 1) {
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) va[i] = ld4(pa[i] + (size_t)c * BK2);
+            return;
+        }
         const int tap = c / cpt, ci0 = (c - tap * cpt) * BK2;
         const int ky = tap / g.KW, kx = tap - ky * g.KW;
 #pragma unroll
@@ -399,6 +415,11 @@ __global__ __launch_bounds__(256) void conv_fwd32_kernel(Geom g, const float* __
         }
     };
     auto load_b = [&](int c, float4 (&vb)[NVB]) {
+        if (TAG & 1) {
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) vb[i] = ld4(pbq[i] + (size_t)c * BK2);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NVB; ++i) vb[i] = wrow[i] ? ld4(wrow[i] + (size_t)c * BK2) : zero4();
     };
@@ -591,7 +612,24 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
         return v;
     };
 
+    // TAG 1 / 3 (batched plain GEMM of the Winograd path: 1x1 geometry, one class, dense operands): a pointer per
+    // staged row fixed for the whole K loop, one load per chunk (see conv_fwd32_kernel).  Rows / columns past the
+    // edge re-read the last valid ones; their accumulators are never stored.
+    const float* pa[NVA];
+    const float* pbq[NVB];
+    if (TAG & 1) {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) pa[i] = dy + (size_t)min(m0 + r0 + 64 * i, M - 1) * g.Co + 4 * q;
+#pragma unroll
+        for (int i = 0; i < NVB; ++i)
+            pbq[i] = w + (size_t)(tid / (BN / 4) + i * (1024 / BN)) * g.Ci + min(n0 + 4 * (tid % (BN / 4)), N - 4);
+    }
     auto load_a = [&](int c, float4 (&va)[NVA]) {
+        if (TAG & 1) {
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) va[i] = ld4(pa[i] + (size_t)c * BK);
+            return;
+        }
         if (VECA) {
             const int tap = c / cpt, co0 = (c - tap * cpt) * BK;
             const int tyi = tap / nkx, txi = tap - tyi * nkx;
@@ -618,6 +656,11 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
     // B[k=(tap,co)][n=ci] = W[co][ky][kx][ci]: contiguous along n
     const int bk_l = tid / (BN / 4), bn_q = tid % (BN / 4);       // NVB passes step k by 256/(BN/4)
     auto load_b = [&](int c, float4 (&vb)[NVB]) {
+        if (TAG & 1) {
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) vb[i] = ld4(pbq[i] + (size_t)c * BK * g.Ci);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
             const int kl = bk_l + i * (1024 / BN);
@@ -745,7 +788,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
         }
     }
 
+    // TAG 1 / 3 with a reduction length that is a multiple of 16 (the Winograd tile count): dense [t][channel]
+    // operands, a pointer per staged row + one load per chunk
+    const bool plain = (TAG & 1) && (Mtot % BK == 0);
+    const float* pa[NVA];
+    const float* pbq[NVB];
+    if (TAG & 1) {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) pa[i] = dy + (size_t)(ak_l + i * (1024 / BM)) * g.Co + min(r_0 + 4 * a_q, R - 4);
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) pbq[i] = x + (size_t)(bk_l + i * (1024 / BN)) * g.Ci + min(n0 + 4 * b_q, N - 4);
+    }
     auto load_a = [&](int c, float4 (&va)[NVA]) {
+        if (plain) {
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) va[i] = ld4(pa[i] + (size_t)c * BK * g.Co);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
             const int m = c * BK + ak_l + i * (1024 / BM);
@@ -774,6 +833,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
         return (b * g.H + iy) * g.W + ix;
     };
     auto load_b = [&](int c, float4 (&vb)[NVB]) {
+        if (plain) {
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) vb[i] = ld4(pbq[i] + (size_t)c * BK * g.Ci);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
             const int m = c * BK + bk_l + i * (1024 / BN);
