@@ -1212,7 +1212,8 @@ WinoWgradPlan wino_wgrad_plan(const mg_conv_geom* g) {
     const WinoDims d = wino_dims(g);
     const int chunks = (int)((d.T + BK - 1) / BK);
     const int t128 = ((g->Co + 127) / 128) * ((g->Ci + 127) / 128);
-    bool big = g->Co >= 128 && g->Ci >= 128;
+    // short reductions (<= 1024 tiles per position, the 8x16 blocks of configs[1]): 64x64 tiles measured 125 vs 148 us
+    bool big = g->Co >= 128 && g->Ci >= 128 && d.T > 1024;
     int want = -1;
     if (const char* f = getenv("MG_FORCE_WINO_WGRAD")) {      // tuning harness: "big(0|1),splits"
         int b = 0, sp = 1;
