@@ -821,8 +821,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
             }
         }
     };
-    auto src_pixel = [&](int b, int oy, int ox, int tap) -> int {
-        const int ky = tap / g.KW, kx = tap - ky * g.KW;
+    // This thread's B taps as (ky, kx) (fixed through the loop), and its reduction pixels (b, oy, ox): chunk c stages
+    // pixel m = 16 c + row, so consecutive load_b calls (which come in increasing c, each chunk exactly once) advance
+    // every staged pixel by 16 -- kept as a running (b, oy, ox) instead of two integer divisions per row and chunk.
+    int b_ky[4], b_kx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        b_ky[j] = b_tap[j] >= 0 ? b_tap[j] / g.KW : 0;
+        b_kx[j] = b_tap[j] >= 0 ? b_tap[j] - b_ky[j] * g.KW : 0;
+    }
+    const int adv_oy = BK / g.OW, adv_ox = BK - adv_oy * g.OW;
+    int pm[NVB], pbb[NVB], poy[NVB], pox[NVB];
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) {
+        pm[i] = c_begin * BK + bk_l + i * (1024 / BN);
+        pbb[i] = pm[i] / (g.OH * g.OW);
+        const int rem = pm[i] - pbb[i] * (g.OH * g.OW);
+        poy[i] = rem / g.OW;
+        pox[i] = rem - poy[i] * g.OW;
+    }
+    auto src_pixel = [&](int b, int oy, int ox, int ky, int kx) -> int {
         int iy = oy * g.s - g.p + ky, ix = ox * g.s - g.p + kx;
         if (g.reflect) {
             iy = reflect_idx(iy, g.H);
@@ -840,14 +858,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
         }
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
-            const int m = c * BK + bk_l + i * (1024 / BN);
+            const int m = pm[i], b = pbb[i], oy = poy[i], ox = pox[i];
+            // advance this row's pixel to the next chunk
+            pm[i] += BK;
+            pox[i] += adv_ox;
+            poy[i] += adv_oy;
+            if (pox[i] >= g.OW) { pox[i] -= g.OW; ++poy[i]; }
+            while (poy[i] >= g.OH) { poy[i] -= g.OH; ++pbb[i]; }
             vb[i] = zero4();
             if (m >= Mtot) continue;
-            const int b = m / (g.OH * g.OW), rem = m - b * (g.OH * g.OW);
-            const int oy = rem / g.OW, ox = rem - oy * g.OW;
             if (VECB) {
                 if (b_tap[0] < 0) continue;
-                const int px = src_pixel(b, oy, ox, b_tap[0]);
+                const int px = src_pixel(b, oy, ox, b_ky[0], b_kx[0]);
                 if (px >= 0) vb[i] = ld4(x + (size_t)px * g.Ci + b_ci[0]);
             } else {
                 float e[4];
@@ -855,7 +877,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
                 for (int j = 0; j < 4; ++j) {
                     e[j] = 0.0f;
                     if (b_tap[j] < 0) continue;
-                    const int px = src_pixel(b, oy, ox, b_tap[j]);
+                    const int px = src_pixel(b, oy, ox, b_ky[j], b_kx[j]);
                     if (px >= 0) e[j] = x[(size_t)px * g.Ci + b_ci[j]];
                 }
                 vb[i] = make_float4(e[0], e[1], e[2], e[3]);
