@@ -392,14 +392,26 @@ __global__ __launch_bounds__(256) void conv_fwd32_kernel(Geom g, const float* __
     for (int i = 0; i < NVA; ++i) pa[i] = x + (size_t)min(m0 + r0 + 32 * i, M - 1) * K + 4 * q;
 #pragma unroll
     for (int i = 0; i < NVB; ++i) pbq[i] = w + (size_t)min(n0 + r0 + 32 * i, N - 1) * K + 4 * q;
+    int a_ky, a_kx, a_ci0;       // position of the next chunk load_a will stage
+    {
+        const int tap = c_begin / cpt;
+        a_ci0 = (c_begin - tap * cpt) * BK2;
+        a_ky = tap / g.KW;
+        a_kx = tap - a_ky * g.KW;
+    }
     auto load_a = [&](int c, float4 (&va)[NVA]) {
         if (TAG & 1) {
 #pragma unroll
             for (int i = 0; i < NVA; ++i) va[i] = ld4(pa[i] + (size_t)c * BK2);
             return;
         }
-        const int tap = c / cpt, ci0 = (c - tap * cpt) * BK2;
-        const int ky = tap / g.KW, kx = tap - ky * g.KW;
+        // load_a runs once per chunk in increasing c, so (ky, kx, ci0) is a running wave-uniform state, not c / cpt
+        const int ky = a_ky, kx = a_kx, ci0 = a_ci0;
+        a_ci0 += BK2;
+        if (a_ci0 >= g.Ci) {
+            a_ci0 = 0;
+            if (++a_kx == g.KW) { a_kx = 0; ++a_ky; }
+        }
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
             va[i] = zero4();
@@ -411,7 +423,8 @@ __global__ __launch_bounds__(256) void conv_fwd32_kernel(Geom g, const float* __
             } else if (iy < 0 || iy >= g.H || ix < 0 || ix >= g.W) {
                 continue;
             }
-            va[i] = ld4(x + (size_t)(pb[i] + iy * g.W + ix) * g.Ci + ci0 + 4 * q);
+            // 32-bit element offset (geom_ok bounds every tensor below 2^31 elements): base + voffset addressing
+            va[i] = ld4(x + (unsigned)(pb[i] + iy * g.W + ix) * (unsigned)g.Ci + (unsigned)(ci0 + 4 * q));
         }
     };
     auto load_b = [&](int c, float4 (&vb)[NVB]) {
@@ -1005,6 +1018,10 @@ bool geom_ok(const mg_conv_geom* g) {
     if (g->OH != (g->H + 2 * g->pad - g->KH) / g->stride + 1) return false;
     if (g->OW != (g->W + 2 * g->pad - g->KW) / g->stride + 1) return false;
     if (g->reflect && (g->pad >= g->H || g->pad >= g->W)) return false;
+    const long long lim = 1LL << 31;      // kernels index activations / weights with 32-bit element offsets
+    if ((long long)g->B * g->H * g->W * g->Ci >= lim || (long long)g->B * g->OH * g->OW * g->Co >= lim ||
+        (long long)g->Co * g->KH * g->KW * g->Ci >= lim)
+        return false;
     return true;
 }
 
