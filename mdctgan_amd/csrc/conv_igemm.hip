@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
         if (!g.reflect) {
             const int oy = yy[i] + oyb - tyi, ox = xx[i] + oxb - txi;
             if (oy >= 0 && oy < g.OH && ox >= 0 && ox < g.OW)
-                v = ld4(dy + ((size_t)(bb[i] * g.OH + oy) * g.OW + ox) * g.Co + co);
+                v = ld4(dy + (unsigned)((bb[i] * g.OH + oy) * g.OW + ox) * (unsigned)g.Co + (unsigned)co);
         } else {   // stride 1: iy = yy, ky = tyi.  Issue every (usually one) aliasing load first, sum afterwards:
                    // accumulating inside the branches would put a vmcnt wait behind each taken load.
             float4 t[9];
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
                 for (int c2 = 0; c2 < 3; ++c2) {
                     const int ox = cx[i][c2] - txi;
                     const bool ok = (unsigned)oy < (unsigned)g.OH && (unsigned)ox < (unsigned)g.OW;
-                    t[a * 3 + c2] = ok ? ld4(dy + ((size_t)(bb[i] * g.OH + oy) * g.OW + ox) * g.Co + co) : zero4();
+                    t[a * 3 + c2] = ok ? ld4(dy + (unsigned)((bb[i] * g.OH + oy) * g.OW + ox) * (unsigned)g.Co + (unsigned)co) : zero4();
                 }
             }
 #pragma unroll
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
             }
             const int tyi = tap / nkx, txi = tap - tyi * nkx;
             const int ky = ky0 + s * tyi, kx = kx0 + s * txi;
-            const float* wp = w + ((size_t)(co * g.KH + ky) * g.KW + kx) * g.Ci;
+            const float* wp = w + (unsigned)((co * g.KH + ky) * g.KW + kx) * (unsigned)g.Ci;
             const int n = n0 + 4 * bn_q;
             if (VECB) {
                 vb[i] = (n < N) ? ld4(wp + n) : zero4();
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
             va[i] = zero4();
             if (m >= Mtot) continue;
             if (VECA) {
-                if (co < R) va[i] = ld4(dy + (size_t)m * g.Co + co);
+                if (co < R) va[i] = ld4(dy + (unsigned)m * (unsigned)g.Co + (unsigned)co);
             } else {
                 float e[4];
 #pragma unroll
@@ -883,7 +883,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
             if (VECB) {
                 if (b_tap[0] < 0) continue;
                 const int px = src_pixel(b, oy, ox, b_ky[0], b_kx[0]);
-                if (px >= 0) vb[i] = ld4(x + (size_t)px * g.Ci + b_ci[0]);
+                if (px >= 0) vb[i] = ld4(x + (unsigned)px * (unsigned)g.Ci + (unsigned)b_ci[0]);
             } else {
                 float e[4];
 #pragma unroll
