@@ -1,3 +1,4 @@
+"""Event-timed Winograd forward GEMM of the 1024-channel 8x16 layer under MG_FORCE_PLAN (library-side probe events)."""
 import sys, os
 sys.path.insert(0, "/root/repo")
 import torch
@@ -18,4 +19,4 @@ def timeit(n=30):
         torch.cuda.synchronize()
         if i>=5: ts.append(ev.elapsed_s(e0,e1)*1e6)
     ts.sort(); return ts[len(ts)//2]
-print("REPS", os.environ.get("MG_EXP_REPS","0"), "PLAN", os.environ.get("MG_FORCE_PLAN","-"), "gemm us", round(timeit(),1))
+print("PLAN", os.environ.get("MG_FORCE_PLAN","-"), "gemm us", round(timeit(),1))
