@@ -414,17 +414,20 @@ __global__ __launch_bounds__(256) void conv_fwd32_kernel(Geom g, const float* __
         }
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
-            va[i] = zero4();
-            if (!va_ok[i]) continue;
+            // branch-free: out-of-range taps load pixel (0, 0) of the row's sample and are masked afterwards
             int iy = iy0[i] + ky, ix = ix0[i] + kx;
+            bool ok = va_ok[i];
             if (g.reflect) {
                 iy = reflect_idx(iy, g.H);
                 ix = reflect_idx(ix, g.W);
-            } else if (iy < 0 || iy >= g.H || ix < 0 || ix >= g.W) {
-                continue;
+            } else {
+                ok = ok && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
             }
+            iy = ok ? iy : 0;
+            ix = ok ? ix : 0;
             // 32-bit element offset (geom_ok bounds every tensor below 2^31 elements): base + voffset addressing
-            va[i] = ld4(x + (unsigned)(pb[i] + iy * g.W + ix) * (unsigned)g.Ci + (unsigned)(ci0 + 4 * q));
+            const float4 v = ld4(x + (unsigned)(pb[i] + iy * g.W + ix) * (unsigned)g.Ci + (unsigned)(ci0 + 4 * q));
+            va[i] = ok ? v : zero4();
         }
     };
     auto load_b = [&](int c, float4 (&vb)[NVB]) {
