@@ -1112,6 +1112,11 @@ TilePlan gemm_plan(long long M, int N, int chunks, int classes, bool can_split, 
         {1, 34320, 64, 128, 4, 64, 64, 1, 0},
         {1, 2448, 128, 256, 4, 64, 64, 4, 0},
         {1, 8976, 64, 128, 4, 64, 64, 2, 0},
+        // configs[2] (LocalEnhancer) Winograd GEMMs: 2048-channel 4x8 trunk blocks (64 tiles), 128-channel 64x128 local blocks
+        {0, 64, 2048, 128, 16, 64, 64, 4, 1},
+        {1, 64, 2048, 128, 16, 64, 64, 1, 0},
+        {0, 16384, 128, 8, 16, 64, 64, 1, 0},
+        {1, 16384, 128, 8, 16, 128, 128, 1, 0},
         // second discriminator scale (64x128 input), batch 8
         {0, 1440, 512, 256, 1, 64, 64, 4, 1},
         {1, 1224, 256, 512, 1, 64, 64, 12, 0},
