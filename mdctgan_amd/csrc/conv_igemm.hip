@@ -1218,7 +1218,8 @@ bool wino_ok(const mg_conv_geom* g) {
     // f16 GEMMs are fast enough that Winograd only pays where the 16 transformed-weight matrices are amortised over
     // many tiles: wide layers (>= 256 channels) with >= 256 tiles (the 1024-channel 8x16 blocks of configs[1]; not the
     // 2048-channel 4x8 trunk of configs[2], where reading 16 * Co * Ci transformed weights would dominate)
-    if (prec_h(g) && (off_h || g->Ci < 256 || g->Co < 256 || (long long)g->B * (g->H / 2) * (g->W / 2) < 256)) return false;
+    static const int min_tiles_h = getenv("MG_WINO_F16_MIN_TILES") ? atoi(getenv("MG_WINO_F16_MIN_TILES")) : 256;
+    if (prec_h(g) && (off_h || g->Ci < 256 || g->Co < 256 || (long long)g->B * (g->H / 2) * (g->W / 2) < min_tiles_h)) return false;
     return !off && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1 && g->Ci % 16 == 0 && g->Co % 16 == 0 &&
            g->Ci >= 32 && g->Co >= 32 && g->H % 2 == 0 && g->W % 2 == 0 && g->H >= 2 && g->W >= 2;
 }
