@@ -105,16 +105,17 @@ __global__ __launch_bounds__(256) void mdct4_kernel(
     for (int rb = 0; rb < RB; ++rb) { acc[rb][0] = f32x16{0}; acc[rb][1] = f32x16{0}; }
     const int arow = lane & 31, khalf = lane >> 5;
     const float* ap = us + arow * LDA + khalf;
-    const float* bp = dct4 + (size_t)khalf * M + wave * 64 + (lane & 31);
+    // the wave's 64 columns as two interleaved MFMA blocks (block nb = columns 2j + nb): lane j fetches both with
+    // one 8-byte load per k
+    const float* bp = dct4 + (size_t)khalf * M + wave * 64 + 2 * (lane & 31);
 #pragma unroll 8
     for (int kp = 0; kp < M / 2; ++kp) {
-        const float b0 = bp[(size_t)(2 * kp) * M];
-        const float b1 = bp[(size_t)(2 * kp) * M + 32];
+        const float2 bb = *reinterpret_cast<const float2*>(bp + (size_t)(2 * kp) * M);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             const float a = ap[rb * 32 * LDA + 2 * kp];
-            acc[rb][0] = mfma32x32x2(a, b0, acc[rb][0]);
-            acc[rb][1] = mfma32x32x2(a, b1, acc[rb][1]);
+            acc[rb][0] = mfma32x32x2(a, bb.x, acc[rb][0]);
+            acc[rb][1] = mfma32x32x2(a, bb.y, acc[rb][1]);
         }
     }
 
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void mdct4_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = f0 + rb * 32 + mfma32_row(r, lane);
-            const int col = wave * 64 + nb * 32 + (lane & 31);
+            const int col = wave * 64 + 2 * (lane & 31) + nb;
             const float xv = acc[rb][nb][r];
             if (f >= F) continue;
             float l = xv;
@@ -344,12 +345,12 @@ __global__ __launch_bounds__(256) void imdct4_kernel(
     const int arow = lane & 31, khalf = lane >> 5;
     const float* ap = as + arow * LDA + khalf;
     const float* hp = as + FT * LDA + khalf;
-    const float* bp = dct4 + (size_t)khalf * M + wave * 64 + (lane & 31);
+    const float* bp = dct4 + (size_t)khalf * M + wave * 64 + 2 * (lane & 31);     // interleaved column blocks, as in K1
 #pragma unroll 8
     for (int kp = 0; kp < M / 2; ++kp) {
         const float xh = hp[2 * kp];
-        const float b0 = bp[(size_t)(2 * kp) * M];
-        const float b1 = bp[(size_t)(2 * kp) * M + 32];
+        const float2 bb = *reinterpret_cast<const float2*>(bp + (size_t)(2 * kp) * M);
+        const float b0 = bb.x, b1 = bb.y;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             const float a = ap[rb * 32 * LDA + 2 * kp];
@@ -371,12 +372,12 @@ __global__ __launch_bounds__(256) void imdct4_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = rb * 32 + mfma32_row(r, lane);
-            as[j * LDA + wave * 64 + nb * 32 + (lane & 31)] = acc[rb][nb][r];
+            as[j * LDA + wave * 64 + 2 * (lane & 31) + nb] = acc[rb][nb][r];
         }
     }
     if (lane < 32) {
-        as[FT * LDA + wave * 64 + lane] = h0;
-        as[FT * LDA + wave * 64 + 32 + lane] = h1;
+        as[FT * LDA + wave * 64 + 2 * lane] = h0;
+        as[FT * LDA + wave * 64 + 2 * lane + 1] = h1;
     }
     __syncthreads();
 
