@@ -76,6 +76,15 @@ int mg_imdct4_forward(const float* spec, int B, int F, int n_fft, const float* w
                       const float* min_b, const float* max_b, void* audio, int out_len, int out_f64,
                       float* frames_out, void* stream);
 
+/* F1  torchaudio.functional.resample(waveform, orig_freq, new_freq) with its defaults (sinc_interp_hann,
+ * lowpass_filter_width 6, rolloff 0.99) as the reference's data path calls it (data/audio_dataset.py:66-71, 171-177):
+ * x [B, L] -> out [B, mg_resample_length(L, orig, new)], orig / new the gcd-reduced rates.  kern [new, 2*width + orig]
+ * is the polyphase filter bank torchaudio's _get_sinc_resample_kernel builds (the host computes it once per rate pair
+ * in float64 and passes it in float32, as torchaudio does). */
+long long mg_resample_length(long long L, int orig, int new_);
+int mg_resample(const float* x, int B, int L, const float* kern, int orig, int new_, int width, float* out, int out_len,
+                void* stream);
+
 /* Segment stitching of generate_audio.py:40-53: seg [n_seg, seg_len] (the [n_seg,1,1,T] inference outputs) -> one
  * waveform of mg_stitch_length() samples (-1: invalid arguments; 2*overlap must be < seg_len).  overlap == 0
  * concatenates; overlap > 0 halves the first/last `overlap` samples of every segment, overlap-adds at stride

@@ -61,6 +61,8 @@ SIGNATURES = {
     "mg_conv_plan_name": (_i, [_i, _G, C.c_char_p, _i]),
     "mg_conv_plan_flops": (C.c_double, [_i, _G]),
     "mg_probe_arm": (None, [_p, _p]),
+    "mg_resample_length": (_ll, [_ll, _i, _i]),
+    "mg_resample": (_i, [_p, _i, _i, _p, _i, _i, _i, _p, _i, _p]),
     "mg_stitch_length": (_ll, [_i, _i, _i]),
     "mg_stitch_segments": (_i, [_p, _i, _i, _i, _p, _i, _p]),
     "mg_colsum": (_i, [_p, _ll, _i, _p, _i, _p, _sz, _p]),

@@ -12,18 +12,19 @@ import torch
 from . import ops
 
 
-def segment_audio(lr_audio: torch.Tensor, segment_length: int, gen_overlap: int = 0) -> torch.Tensor:
-    """[T] or [1, T] waveform -> [n_seg, segment_length] at stride ``segment_length - gen_overlap``, zero padded at the
-    end (what the reference's dataset does with ``--gen_overlap`` when it unfolds the utterance)."""
-    x = lr_audio.reshape(-1)
-    stride = segment_length - gen_overlap
-    if stride <= 0:
-        raise ValueError("gen_overlap must be smaller than segment_length")
-    n_seg = max(1, -(-(x.numel() - gen_overlap) // stride))
-    total = (n_seg - 1) * stride + segment_length
-    if total > x.numel():
-        x = torch.cat([x, x.new_zeros(total - x.numel())])
-    return x.unfold(0, segment_length, stride).contiguous()
+def segment_audio(audio: torch.Tensor, segment_length: int, gen_overlap: int = 0) -> torch.Tensor:
+    """AudioTestDataset.seg_pad_audio (data/audio_dataset.py:153-167): [T] or [1, T] waveform -> [n_seg, segment_length].
+    A waveform of at least one segment is zero padded by ``gen_overlap`` in front and up to ``ceil(T / L) * L +
+    gen_overlap`` behind, then unfolded at stride ``L - gen_overlap``; a shorter one is padded to a single segment."""
+    x = audio.reshape(-1)
+    length = x.numel()
+    if gen_overlap < 0 or gen_overlap >= segment_length:
+        raise ValueError("gen_overlap must be in [0, segment_length)")
+    if length >= segment_length:
+        num_segments = -(-length // segment_length)
+        x = torch.nn.functional.pad(x, (gen_overlap, segment_length * num_segments - length + gen_overlap))
+        return x.unfold(0, segment_length, segment_length - gen_overlap).contiguous()
+    return torch.nn.functional.pad(x, (0, segment_length - length)).unsqueeze(0)
 
 
 def generate(model, lr_segments: torch.Tensor, batch_size: int = 64, gen_overlap: int = 0) -> torch.Tensor:

@@ -124,13 +124,13 @@ def test_segment_audio_and_amp_context():
     the geometry's precision field."""
     from mdctgan_amd import _lib, amp, ops
     from mdctgan_amd.generate_audio import segment_audio
-    x = torch.arange(100.0)
-    seg = segment_audio(x, 40, 0)
+    x = torch.arange(1.0, 101.0)
+    seg = segment_audio(x, 40, 0)                        # audio_dataset.py:153-167 with overlap 0: ceil(100/40) = 3 segments
     assert seg.shape == (3, 40) and torch.equal(seg[0], x[:40]) and seg[2, 20:].abs().sum() == 0
-    seg = segment_audio(x, 40, 10)                       # stride 30: 0, 30, 60 -> 3 segments cover the 100 samples exactly
-    assert seg.shape == (3, 40) and torch.equal(seg[1], x[30:70]) and torch.equal(seg[2], x[60:])
-    seg = segment_audio(x, 40, 8)                        # stride 32: 0, 32, 64 -> the last one runs 4 samples past the end
-    assert seg.shape == (3, 40) and torch.equal(seg[2, :36], x[64:]) and seg[2, 36:].abs().sum() == 0
+    seg = segment_audio(x, 40, 10)                       # 10 zeros in front, padded to 10 + 120 + 10, stride 30
+    assert seg.shape == (4, 40) and seg[0, :10].abs().sum() == 0 and torch.equal(seg[0, 10:], x[:30])
+    assert torch.equal(seg[1], x[20:60]) and torch.equal(seg[3, :10], x[80:90]) and torch.equal(seg[3, 10:20], x[90:])
+    assert segment_audio(x[:25], 40, 10).shape == (1, 40)
     with pytest.raises(ValueError):
         segment_audio(x, 40, 40)
     assert amp.current_precision() == _lib.PRECISION_F32
