@@ -85,6 +85,19 @@ long long mg_resample_length(long long L, int orig, int new_);
 int mg_resample(const float* x, int B, int L, const float* kern, int orig, int new_, int width, float* out, int out_len,
                 void* stream);
 
+/* F2  util/util.py:132-177 compute_matrics on the device (train.py:104-134 eval_model, generate_audio.py:60).
+ *   mg_metrics_rows   out[b] = {sum hr^2, sum (sr - hr)^2, sum (lr - hr)^2} (double) for clips [B, T]  -> MSE / SNR
+ *   mg_stft_frames    reflect-padded (center != 0), windowed frames [B * F, n_fft], F = mg_stft_num_frames(): the A
+ *                     operand of the DFT, which the caller runs as the 1x1 case of mg_conv_fwd against a
+ *                     [2 * (n_fft/2 + 1), n_fft] table of (cos, -sin) rows  (aF.spectrogram, util.py:170-171)
+ *   mg_lsd_frames     per frame, from two interleaved (re, im) spectra [n_frames, 2 * n_bins]:
+ *                     sqrt(mean_k (log10(|a_k|^2 + 1e-6) - log10(|b_k|^2 + 1e-6))^2)        (util.py:172-174) */
+int mg_metrics_rows(const float* hr, const float* lr, const float* sr, int B, int T, double* out, void* stream);
+int mg_stft_num_frames(int T, int n_fft, int hop, int center);
+int mg_stft_frames(const float* x, int B, int T, const float* window, int n_fft, int hop, int center, float* frames,
+                   void* stream);
+int mg_lsd_frames(const float* spec_a, const float* spec_b, long long n_frames, int n_bins, float* out, void* stream);
+
 /* Segment stitching of generate_audio.py:40-53: seg [n_seg, seg_len] (the [n_seg,1,1,T] inference outputs) -> one
  * waveform of mg_stitch_length() samples (-1: invalid arguments; 2*overlap must be < seg_len).  overlap == 0
  * concatenates; overlap > 0 halves the first/last `overlap` samples of every segment, overlap-adds at stride

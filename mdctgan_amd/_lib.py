@@ -63,6 +63,10 @@ SIGNATURES = {
     "mg_probe_arm": (None, [_p, _p]),
     "mg_resample_length": (_ll, [_ll, _i, _i]),
     "mg_resample": (_i, [_p, _i, _i, _p, _i, _i, _i, _p, _i, _p]),
+    "mg_metrics_rows": (_i, [_p, _p, _p, _i, _i, _p, _p]),
+    "mg_stft_num_frames": (_i, [_i, _i, _i, _i]),
+    "mg_stft_frames": (_i, [_p, _i, _i, _p, _i, _i, _i, _p, _p]),
+    "mg_lsd_frames": (_i, [_p, _p, _ll, _i, _p, _p]),
     "mg_stitch_length": (_ll, [_i, _i, _i]),
     "mg_stitch_segments": (_i, [_p, _i, _i, _i, _p, _i, _p]),
     "mg_colsum": (_i, [_p, _ll, _i, _p, _i, _p, _sz, _p]),

@@ -1,0 +1,40 @@
+"""Oracle (test infrastructure): the evaluation metrics of the reference, util/util.py:132-177 ``compute_matrics``
+(MSE, SNR of the super-resolved and of the low-rate waveform against the ground truth, log-spectral distance), called
+from train.py:104-134 ``eval_model`` and generate_audio.py:60-61.
+
+MSE / SNR are plain tensor arithmetic.  The LSD goes through ``torchaudio.functional.spectrogram`` -- torchaudio is not
+installed here, so that one call is restated from its published definition (functional.py ``spectrogram``: optional
+pad, ``torch.stft(n_fft, hop_length, win_length, window, center, pad_mode="reflect", normalized=False, onesided=True,
+return_complex=True)``, then ``abs() ** power``); the LSD's parity is therefore pinned to torch.stft, not to a torchaudio
+run ("unpinned" for that dependency).  float64 throughout.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import transform
+
+
+def spectrogram_power(x, n_fft, hop_length, win_length, window, center=True):
+    """torchaudio.functional.spectrogram(..., pad=0, power=2, normalized=False): [..., T] -> [..., n_fft//2+1, frames]."""
+    xt = torch.as_tensor(np.asarray(x), dtype=torch.float64)
+    shape = xt.shape
+    s = torch.stft(xt.reshape(-1, shape[-1]), n_fft=n_fft, hop_length=hop_length, win_length=win_length,
+                   window=torch.as_tensor(np.asarray(window), dtype=torch.float64), center=center, pad_mode="reflect",
+                   normalized=False, onesided=True, return_complex=True)
+    return (s.abs() ** 2).reshape(shape[:-1] + s.shape[-2:]).numpy()
+
+
+def compute_matrics(hr_audio, lr_audio, sr_audio, n_fft=512, hop_length=256, win_length=512, center=True):
+    """util/util.py:132-177.  [B, T] (or [T]) arrays -> (mse, snr_sr, snr_lr, 0, 0, 0, lsd)."""
+    hr, lr, sr = (np.asarray(a, dtype=np.float64) for a in (hr_audio, lr_audio, sr_audio))
+    mse = float(((sr - hr) ** 2).mean())
+    snr_sr = float((10 * np.log10((hr ** 2).sum(-1) / ((sr - hr) ** 2).sum(-1))).mean())
+    snr_lr = float((10 * np.log10((hr ** 2).sum(-1) / ((lr - hr) ** 2).sum(-1))).mean())
+    window = transform.kbd_window(2 * win_length)                 # kbdwin(2 * win_length), util.py:170
+    kw = dict(n_fft=2 * n_fft, hop_length=2 * hop_length, win_length=2 * win_length, window=window, center=center)
+    hr_log = np.log10(spectrogram_power(hr, **kw) + 1e-6)
+    sr_log = np.log10(spectrogram_power(sr, **kw) + 1e-6)
+    lsd = float(np.sqrt(((hr_log - sr_log) ** 2).mean(-2)).mean())
+    return mse, snr_sr, snr_lr, 0, 0, 0, lsd

@@ -1,0 +1,52 @@
+"""F2: compute_matrics (util/util.py:132-177) -- oracle sanity on the CPU, the HIP path against the oracle on
+the GPU.  The LSD's spectrogram is torchaudio's in the reference; torchaudio is not installed, the oracle restates it
+through torch.stft (oracle/metrics.py header), so that term is pinned to torch.stft only."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import metrics as M
+
+
+def _signals(B=3, T=32512, seed=0):
+    rng = np.random.default_rng(seed)
+    hr = 0.1 * rng.standard_normal((B, T))
+    sr = hr + 0.01 * rng.standard_normal((B, T))
+    lr = hr + 0.03 * rng.standard_normal((B, T))
+    return hr.astype(np.float32), lr.astype(np.float32), sr.astype(np.float32)
+
+
+def test_oracle_metrics_sanity():
+    hr, lr, sr = _signals()
+    mse, snr_sr, snr_lr, a, b, c, lsd = M.compute_matrics(hr, lr, sr)
+    assert (a, b, c) == (0, 0, 0)
+    assert abs(mse - 1e-4) < 1e-5                                  # noise variance 0.01^2
+    assert abs(snr_sr - 20.0) < 0.2 and abs(snr_lr - 10.46) < 0.2     # 10 log10(0.1^2 / sigma^2)
+    assert 0.05 < lsd < 0.5
+    assert M.compute_matrics(hr, lr, hr + 0.0)[6] == 0.0
+    p = M.spectrogram_power(hr, 1024, 512, 1024, np.ones(1024))
+    assert p.shape == (3, 513, 64)
+    # Parseval on one interior frame (rectangular window, onesided): sum_k c_k |X_k|^2 = N sum_n x_n^2
+    x = hr[0, 512 * 4 - 512: 512 * 4 + 512].astype(np.float64)
+    c = np.ones(513); c[1:-1] = 2.0
+    assert abs((c * p[0, :, 4]).sum() - 1024 * (x ** 2).sum()) < 1e-6 * 1024 * (x ** 2).sum()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("center", [True, False])
+def test_compute_matrics_on_device(center):
+    from mdctgan_amd.metrics import compute_matrics
+    hr, lr, sr = _signals(seed=3)
+    opt = types.SimpleNamespace(n_fft=512, hop_length=256, win_length=512, center=center)
+    want = M.compute_matrics(hr, lr, sr, center=center)
+    got = compute_matrics(torch.from_numpy(hr), torch.from_numpy(lr), torch.from_numpy(sr).to("cuda"), opt)
+    assert len(got) == 7 and got[3:6] == (0, 0, 0)
+    assert abs(got[0] - want[0]) <= 1e-5 * want[0]
+    assert abs(got[1] - want[1]) <= 1e-4 and abs(got[2] - want[2]) <= 1e-4          # dB
+    assert abs(got[6] - want[6]) <= 2e-4 * want[6]
+    # 1-D waveforms (generate_audio.py:60 passes [1, n] / squeezed tensors)
+    got1 = compute_matrics(torch.from_numpy(hr[0]), torch.from_numpy(lr[0]), torch.from_numpy(sr[0]).to("cuda"), opt)
+    want1 = M.compute_matrics(hr[0], lr[0], sr[0], center=center)
+    assert abs(got1[6] - want1[6]) <= 2e-4 * want1[6] and abs(got1[1] - want1[1]) <= 1e-4
