@@ -312,3 +312,44 @@ def test_local_enhancer_with_attention_step():
     # every parameter, including BatchNorm affine and position embeddings, moved by one Adam step
     for k, p in model.netG.named_parameters():
         assert p.grad is not None, k
+
+
+def test_published_checkpoint_architecture_runs():
+    """The flags of the reference's train.sh / generate_audio.sh (the architecture of the published vctk checkpoints,
+    SURVEY F3): netG local, ngf 56 (channel counts that are NOT multiples of 16 in the local branch), resconv / interpolate
+    sampling, 3 bottleneck-attention blocks of 6 x 128 heads on 8 x 16 tokens, num_D 3, fit_residual, 16 kHz input.  One
+    optimisation step in float32 and one under --fp16 stay finite, inference returns a waveform, and the state dict
+    round-trips through save / load_network."""
+    import os, tempfile
+    from mdctgan_amd import options
+    from mdctgan_amd.pix2pixHD_model import create_model
+    flags = ["--lr_sampling_rate", "16000", "--sr_sampling_rate", "48000", "--arcsinh_transform", "--abs_spectro",
+             "--arcsinh_gain", "1000", "--center", "--norm_range", "-1", "1", "--smooth", "0.0", "--abs_norm", "--src_range", "-5", "5",
+             "--netG", "local", "--ngf", "56", "--n_downsample_global", "3", "--n_blocks_global", "4", "--n_blocks_attn_g", "3",
+             "--dim_head_g", "128", "--heads_g", "6", "--proj_factor_g", "4", "--n_blocks_attn_l", "0", "--n_blocks_local", "3",
+             "--fit_residual", "--upsample_type", "interpolate", "--downsample_type", "resconv", "--num_D", "3"]
+    gen = torch.Generator().manual_seed(2)
+    hr = 0.05 * torch.randn(1, 32512, generator=gen)
+    spec = torch.fft.rfft(hr)
+    spec[:, spec.shape[-1] // 3:] = 0
+    lr = torch.fft.irfft(spec, n=hr.shape[-1])
+    for extra in ([], ["--fp16"]):
+        with tempfile.TemporaryDirectory() as tmp:
+            opt = options.make_opt(*flags, *extra, "--batchSize", "1", "--gpu_ids", "0", "--checkpoints_dir", tmp, "--name", "pub")
+            model = create_model(opt)
+            keys = list(model.netG.state_dict().keys())
+            assert any(k.startswith("model1_1.") for k in keys) and any(".conv_res." in k for k in keys)
+            assert any("to_qkv" in k for k in keys) and any("pos_emb.height" in k for k in keys)
+            ld = model.optimize_parameters(lr.to(DEV), hr.to(DEV))
+            assert all(np.isfinite(v.item()) for v in ld.values())
+            sr_spectro, sr_audio, *_ = model.inference(lr.to(DEV))
+            assert sr_audio.shape == (1, 1, 1, 32512) and torch.isfinite(sr_audio).all()
+            os.makedirs(model.save_dir, exist_ok=True)
+            model.save("latest")
+            before = {k: v.detach().clone() for k, v in model.netG.state_dict().items()}
+            with torch.no_grad():
+                for p in model.netG.parameters():
+                    p.add_(1.0)
+            model.load_network(model.netG, "G", "latest")
+            for k, v in model.netG.state_dict().items():
+                assert torch.equal(v, before[k]), k
