@@ -95,6 +95,47 @@ def _notify(p):
 
 
 # ------------------------------------------------------------------------------------------------
+# one discriminator forward, two backward passes
+# ------------------------------------------------------------------------------------------------
+# train.py:160-202 evaluates D three times per iteration: D(fake.detach()) and D(real) for the D loss, D(fake) for the
+# G loss.  The two fake passes see the same weights and the same input, so their activations are identical: the model
+# runs ONE forward over the batch-stacked [fake, real] input (weight_grad="D0") and backpropagates twice through it --
+#   * pass "G" (loss_G): data gradients only, and only for the first `rows` samples (the fake half; every discriminator
+#     layer is per-sample).  Gradient buffers keep the stacked shape autograd expects; their second half is never
+#     written and never read.
+#   * pass "D" (loss_D): weight gradients + data gradients over the whole stack, nothing flows back into the generator.
+class _BackwardPass:
+    kind, rows = None, 0
+
+
+class backward_pass:
+    """with backward_pass("G", B): loss_G.backward(retain_graph=True) / with backward_pass("D", B): loss_D.backward(...)"""
+
+    def __init__(self, kind, rows):
+        self.kind, self.rows = kind, int(rows)
+
+    def __enter__(self):
+        self.prev = (_BackwardPass.kind, _BackwardPass.rows)
+        _BackwardPass.kind, _BackwardPass.rows = self.kind, self.rows
+        return self
+
+    def __exit__(self, *exc):
+        _BackwardPass.kind, _BackwardPass.rows = self.prev
+        return False
+
+
+def _live_rows(t):
+    """Samples of a stacked tensor that carry gradient in the running pass (None: all of them)."""
+    if _BackwardPass.kind == "G" and 0 < _BackwardPass.rows < t.shape[0]:
+        return _BackwardPass.rows
+    return None
+
+
+def _is_shared(weight_grad):
+    return weight_grad in ("D", "D0")
+
+
+# ------------------------------------------------------------------------------------------------
 # convolution
 # ------------------------------------------------------------------------------------------------
 class _ConvFn(torch.autograd.Function):
@@ -142,21 +183,38 @@ class _ConvFn(torch.autograd.Function):
         stride, pad, reflect, act, transposed, weight_grad = ctx.cfg
         g, weight, bias = ctx.g, ctx.weight, ctx.bias
         gy = to_cl(gy)
+        kind = _BackwardPass.kind
+        shared = _is_shared(weight_grad)
+        last_use = not shared or kind != "G"                   # a shared layer is walked again by the D pass
+        want_dx = ctx.needs_input_grad[0] and not (weight_grad == "D0" and kind == "D")
+        want_dw = bool(weight_grad) and weight.requires_grad and not (shared and kind == "G")
+        rows = _live_rows(x) if shared else None
+        x_full = x
+        if rows is not None:                                   # pass "G" over a stacked batch: the fake half only
+            assert not transposed and not want_dw
+            x, gy = x[:rows], gy[:rows]
+            y = y[:rows] if y is not None else None
+            g = ops.conv_geom(rows, g.H, g.W, g.Ci, g.Co, g.KH, g.KW, g.stride, g.pad, g.reflect, g.precision)
         if act != ACT_NONE:
             gy = nchw_view(ops.act_bwd(nhwc_view(gy), nhwc_view(y), act))
         w = weight.detach()
         dx = None
         md = None
-        if ctx.needs_input_grad[0]:
+        if want_dx:
             if not transposed:
                 u = getattr(ctx, "u", None)
-                if u is not None and getattr(ctx, "v", None) is not None:
+                if u is not None and getattr(ctx, "v", None) is not None and want_dw:
                     _, md = ops.wino_tile_buffers(g, gy.device, want_v=False)
-                dx = nchw_view(ops.conv_dgrad(g, nhwc_view(gy), w, u=u, md_out=md))
-                ctx.u = None
+                if rows is not None:
+                    dx = torch.empty_like(x_full)
+                    ops.conv_dgrad(g, nhwc_view(gy), w, u=u, out=nhwc_view(dx[:rows]))
+                else:
+                    dx = nchw_view(ops.conv_dgrad(g, nhwc_view(gy), w, u=u, md_out=md))
+                if last_use:
+                    ctx.u = None
             else:
                 dx = nchw_view(ops.conv_fwd(g, nhwc_view(gy), w))
-        if weight_grad and weight.requires_grad:
+        if want_dw:
             wbuf, wacc = grad_buffer(weight)
             bbuf = bacc = None
             if bias is not None and bias.requires_grad:
@@ -206,8 +264,15 @@ class _InstNormFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, mean, rstd = ctx.saved_tensors
         gy = to_cl(gy)
-        dx = nchw_view(ops.instnorm_bwd(nhwc_view(gy), nhwc_view(x), mean, rstd, ctx.act)) \
-            if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            rows = _live_rows(x)
+            if rows is not None:                               # pass "G" over a stacked discriminator batch
+                dx = torch.empty_like(x)
+                ops.instnorm_bwd(nhwc_view(gy[:rows]), nhwc_view(x[:rows]), mean[:rows], rstd[:rows], ctx.act,
+                                 out=nhwc_view(dx[:rows]))
+            else:
+                dx = nchw_view(ops.instnorm_bwd(nhwc_view(gy), nhwc_view(x), mean, rstd, ctx.act))
         dres = gy if ctx.needs_input_grad[1] else None
         return dx, dres, None, None
 
@@ -316,7 +381,14 @@ class _AvgPoolFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        return nchw_view(ops.avgpool_bwd(nhwc_view(to_cl(gy)), tuple(ctx.in_shape)))
+        gy = to_cl(gy)
+        rows = _live_rows(gy)
+        if rows is not None:                                   # pass "G" over a stacked discriminator batch
+            B, H, W, Cc = ctx.in_shape
+            dx = torch.empty(B, H, W, Cc, dtype=torch.float32, device=gy.device)
+            ops.avgpool_bwd(nhwc_view(gy[:rows]), (rows, H, W, Cc), out=dx[:rows])
+            return nchw_view(dx)
+        return nchw_view(ops.avgpool_bwd(nhwc_view(gy), tuple(ctx.in_shape)))
 
 
 def avg_pool_3s2(x):
@@ -383,6 +455,34 @@ def d_input_pair(lr_spectro, a_spectro, b_spectro, nr0):
     return nchw_view(out)
 
 
+class _DInputSharedFn(torch.autograd.Function):
+    """d_input_pair whose first half keeps its gradient path (the generator output): the input of the single
+    discriminator forward that serves both the D loss and the G loss (see backward_pass)."""
+
+    @staticmethod
+    def forward(ctx, lr, a, b, nr0):
+        lr, a, b = to_cl(lr), to_cl(a), to_cl(b)
+        B, _, H, W = a.shape
+        out = torch.empty(2 * B, H, W, 3, dtype=torch.float32, device=a.device)
+        ops.dinput_fwd(nhwc_view(lr), nhwc_view(a), nr0, out=out[:B])
+        ops.dinput_fwd(nhwc_view(lr), nhwc_view(b), nr0, out=out[B:])
+        ctx.save_for_backward(a)
+        return nchw_view(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        (a,) = ctx.saved_tensors
+        if not ctx.needs_input_grad[1] or _BackwardPass.kind == "D":
+            return None, None, None, None
+        g = to_cl(g)
+        return None, nchw_view(ops.dinput_bwd(nhwc_view(g[:a.shape[0]]), nhwc_view(a))), None, None
+
+
+def d_input_shared(lr_spectro, fake_spectro, real_spectro, nr0):
+    """[2B, 3, F, W]: rows [0, B) from the (attached) generator output, rows [B, 2B) from the real spectrogram."""
+    return _DInputSharedFn.apply(lr_spectro.detach(), fake_spectro, real_spectro.detach(), nr0)
+
+
 def g_input(spectro, nr0):
     """cat(s, 2|s| + nr0) (pix2pixHD_model.py:400-402); no gradient path (the generator input is data)."""
     s = to_cl(spectro.detach())
@@ -438,6 +538,65 @@ def mse_const_pair_loss(pred, target_first: float, target_second: float):
     """The two LSGAN terms of a prediction whose batch stacks two passes (first half / second half)."""
     assert pred.shape[0] % 2 == 0
     return _MseConstPairFn.apply(pred, float(target_first), float(target_second))
+
+
+class _MseConstFirstHalfFn(torch.autograd.Function):
+    """mean((pred[:B] - t)^2) of a batch-stacked prediction; the gradient buffer has the stacked shape, second half
+    unwritten (consumed by pass "G" only, which never reads it)."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        pred = pred.contiguous(memory_format=CL) if pred.dim() == 4 else pred.contiguous()
+        B = pred.shape[0] // 2
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        ops.mse_const_fwd(pred[:B], target, 1.0, loss, False)
+        ctx.target = target
+        ctx.save_for_backward(pred)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, go):
+        (pred,) = ctx.saved_tensors
+        B = pred.shape[0] // 2
+        g = torch.empty_like(pred)
+        if _BackwardPass.kind != "G":
+            g[B:].zero_()
+        ops.mse_const_bwd(pred[:B], ctx.target, 1.0, go.reshape(1).float().contiguous(), out=g[:B])
+        return g, None
+
+
+def mse_const_first_half_loss(pred, target: float):
+    assert pred.shape[0] % 2 == 0
+    return _MseConstFirstHalfFn.apply(pred, float(target))
+
+
+class _L1HalvesFn(torch.autograd.Function):
+    """scale * mean(|t[:B] - t[B:].detach()|): the feature-matching term of a batch-stacked [fake, real] feature map."""
+
+    @staticmethod
+    def forward(ctx, t, scale):
+        t = t.contiguous(memory_format=CL) if t.dim() == 4 else t.contiguous()
+        B = t.shape[0] // 2
+        loss = torch.empty(1, dtype=torch.float32, device=t.device)
+        ops.l1_fwd(t[:B], t[B:], scale, loss, False)
+        ctx.scale = scale
+        ctx.save_for_backward(t)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, go):
+        (t,) = ctx.saved_tensors
+        B = t.shape[0] // 2
+        g = torch.empty_like(t)
+        if _BackwardPass.kind != "G":
+            g[B:].zero_()
+        ops.l1_bwd(t[:B], t[B:], ctx.scale, go.reshape(1).float().contiguous(), out=g[:B])
+        return g, None
+
+
+def l1_halves_loss(t, scale: float = 1.0):
+    assert t.shape[0] % 2 == 0
+    return _L1HalvesFn.apply(t, float(scale))
 
 
 def mse_const_loss(pred, target: float, scale: float = 1.0):

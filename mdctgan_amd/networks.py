@@ -136,23 +136,29 @@ class FusedSequence:
 
     def __call__(self, x, weight_grad=True):
         for st in self.steps:
-            if st[0] == "producer":
-                _, m, reflect, norm, act, eps = st
-                conv_act = ACT_NONE if norm else act
-                if isinstance(m, Conv2d):
-                    x = m(x, reflect, conv_act, weight_grad)
-                elif isinstance(m, ConvTranspose2d):
-                    x = m(x, conv_act, weight_grad)
-                else:
-                    x = m(x, weight_grad=weight_grad)
-                    if not norm and act != ACT_NONE:
-                        raise NotImplementedError("activation directly after %s" % m.__class__.__name__)
-                if norm:
-                    x = Fh.instance_norm_act(x, act, None, eps)
-            elif st[0] == "module":
-                x = st[1](x, weight_grad=weight_grad)
+            x = self._step(st, x, weight_grad)
+            if weight_grad == "D0":          # Fh.backward_pass: only the first layer of a shared pass is the boundary
+                weight_grad = "D"
+        return x
+
+    def _step(self, st, x, weight_grad):
+        if st[0] == "producer":
+            _, m, reflect, norm, act, eps = st
+            conv_act = ACT_NONE if norm else act
+            if isinstance(m, Conv2d):
+                x = m(x, reflect, conv_act, weight_grad)
+            elif isinstance(m, ConvTranspose2d):
+                x = m(x, conv_act, weight_grad)
             else:
-                x = st[1](x, weight_grad)
+                x = m(x, weight_grad=weight_grad)
+                if not norm and act != ACT_NONE:
+                    raise NotImplementedError("activation directly after %s" % m.__class__.__name__)
+            if norm:
+                x = Fh.instance_norm_act(x, act, None, eps)
+        elif st[0] == "module":
+            x = st[1](x, weight_grad=weight_grad)
+        else:
+            x = st[1](x, weight_grad)
         return x
 
 
@@ -497,6 +503,8 @@ class NLayerDiscriminator(nn.Module):
             res = [input]
             for n in range(self.n_layers + 2):
                 res.append(FusedSequence(getattr(self, "model" + str(n)))(res[-1], weight_grad))
+                if weight_grad == "D0":
+                    weight_grad = "D"
             return res[1:]
         return FusedSequence(self.model)(input, weight_grad)
 
@@ -522,12 +530,15 @@ class MultiscaleDiscriminator(FusedModule):
             result = [input]
             for n in names:
                 result.append(self._plan(n, getattr(self, n))(result[-1], weight_grad))
+                if weight_grad == "D0":      # shared pass (Fh.backward_pass): the boundary is the first layer only
+                    weight_grad = "D"
             return result[1:]
         return [self._plan(names, getattr(self, names))(input, weight_grad)]
 
     def forward(self, input, weight_grad=True):
         """weight_grad=False marks a pass whose discriminator weight gradients are discarded by the caller
-        (the generator-loss pass: train.py:182-194 zeroes them before the D step)."""
+        (the generator-loss pass: train.py:182-194 zeroes them before the D step); "D0" the single batch-stacked pass
+        that serves both losses (weight gradients in Fh.backward_pass("D") only, see functional.py)."""
         num_D = self.num_D
         result = []
         x = input

@@ -83,9 +83,9 @@ def conv_fwd(g: ConvGeom, x, w, bias=None, act=ACT_NONE, u=None, v_out=None):
     return y
 
 
-def conv_dgrad(g: ConvGeom, dy, w, bias=None, act=ACT_NONE, u=None, md_out=None):
+def conv_dgrad(g: ConvGeom, dy, w, bias=None, act=ACT_NONE, u=None, md_out=None, out=None):
     lib = _lib.load()
-    dx = torch.empty(g.B, g.H, g.W, g.Ci, dtype=torch.float32, device=dy.device)
+    dx = torch.empty(g.B, g.H, g.W, g.Ci, dtype=torch.float32, device=dy.device) if out is None else out
     ws = _ws(lib.mg_conv_dgrad_workspace(g), dy.device)
     if PROFILER is not None:
         PROFILER.begin(1, g)
@@ -131,10 +131,10 @@ def instnorm_fwd(x, act=ACT_NONE, residual=None, eps=1e-5):
     return y, mean, rstd
 
 
-def instnorm_bwd(dy, x, mean, rstd, act=ACT_NONE):
+def instnorm_bwd(dy, x, mean, rstd, act=ACT_NONE, out=None):
     lib = _lib.load()
     B, H, W, Cc = x.shape
-    dx = torch.empty_like(x)
+    dx = torch.empty_like(x) if out is None else out
     ws = _ws(lib.mg_instnorm_workspace(B, H * W, Cc), x.device)
     _lib.check(lib.mg_instnorm_bwd(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), B, H * W, Cc, act,
                                    _lib.ptr(dx), _lib.ptr(ws), ws.numel(), _lib.stream()), "mg_instnorm_bwd")
@@ -163,10 +163,10 @@ def avgpool_fwd(x):
     return y
 
 
-def avgpool_bwd(dy, in_shape):
+def avgpool_bwd(dy, in_shape, out=None):
     lib = _lib.load()
     B, H, W, Cc = in_shape
-    dx = torch.empty(B, H, W, Cc, dtype=torch.float32, device=dy.device)
+    dx = torch.empty(B, H, W, Cc, dtype=torch.float32, device=dy.device) if out is None else out
     _lib.check(lib.mg_avgpool3s2_bwd(_lib.ptr(dy), B, H, W, Cc, _lib.ptr(dx), _lib.stream()), "mg_avgpool3s2_bwd")
     return dx
 
@@ -237,9 +237,9 @@ def l1_fwd(a, b, scale, loss, accumulate):
                              _lib.ptr(ws), _lib.stream()), "mg_l1_fwd")
 
 
-def l1_bwd(a, b, scale, grad_out):
+def l1_bwd(a, b, scale, grad_out, out=None):
     lib = _lib.load()
-    g = torch.empty_like(a)
+    g = torch.empty_like(a) if out is None else out
     _lib.check(lib.mg_l1_bwd(_lib.ptr(a), _lib.ptr(b), a.numel(), scale, _lib.ptr(grad_out), _lib.ptr(g),
                              _lib.stream()), "mg_l1_bwd")
     return g

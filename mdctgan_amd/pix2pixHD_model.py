@@ -257,6 +257,10 @@ class Pix2PixHDModel(BaseModel):
         # to reproduce the reference's wasted work bit for bit.
         self.skip_discarded_d_grads = True
         self.stack_d_loss_passes = True      # D(fake.detach()) and D(real) run as one pass over 2B samples
+        # ... and D(fake) of the G loss reuses the fake half of that pass (same weights, same input: identical
+        # activations) -- one discriminator forward per iteration, two backward passes through it (Fh.backward_pass)
+        self.share_d_fake_pass = os.environ.get("MDCTGAN_SHARE_D_PASS", "1") != "0"
+        self._shared_rows = 0
         self.current_lable = self.current_generated = self.current_real = None
 
     def loss_filter(self, g_gan, g_gan_feat, d_real, d_fake):
@@ -287,37 +291,59 @@ class Pix2PixHDModel(BaseModel):
             return Fh.d_input(lr_spectro, x_spectro, float(self.norm_range[0]))
         raise NotImplementedError("discriminator input without --abs_spectro --arcsinh_transform")
 
-    def _forward(self, lr_audio, hr_audio, infer=False):
-        """pix2pixHD_model.py:416-616: the four live losses [G_GAN, G_GAN_Feat, D_real, D_fake]."""
+    def _forward(self, lr_audio, hr_audio, infer=False, share_d_pass=False):
+        """pix2pixHD_model.py:416-616: the four live losses [G_GAN, G_GAN_Feat, D_real, D_fake].  share_d_pass: the
+        caller backpropagates the two losses under Fh.backward_pass (optimize_parameters does); otherwise every loss
+        keeps its own discriminator pass and plain loss.backward() calls work as in train.py."""
         sr_spectro, _, hr_spectro, _, hr_norm_param, lr_spectro, _, lr_norm_param = self.forward(lr_audio, hr_audio)
-        if self.stack_d_loss_passes and self.abs_spectro and self.arcsinh_transform:
+        stacked = self.stack_d_loss_passes and self.abs_spectro and self.arcsinh_transform
+        shared = (share_d_pass and stacked and self.share_d_fake_pass and self.skip_discarded_d_grads
+                  and torch.is_grad_enabled() and sr_spectro.requires_grad)
+        self._shared_rows = 0
+        B = lr_spectro.shape[0]
+        if shared:
+            # ONE discriminator forward over [fake, real]: D loss from both halves, G loss from the fake half
+            self._shared_rows = B
+            pred_both = self.netD.forward(Fh.d_input_shared(lr_spectro, sr_spectro, hr_spectro,
+                                                            float(self.norm_range[0])), weight_grad="D0")
+        elif stacked:
             # D(fake.detach()) and D(real) as ONE pass over a batch of 2B: every layer of the discriminator is
             # per-sample (InstanceNorm), so stacking is exact; half the launches, twice the rows per GEMM
-            B = lr_spectro.shape[0]
             pred_both = self.netD.forward(Fh.d_input_pair(lr_spectro, sr_spectro, hr_spectro,
                                                           float(self.norm_range[0])))
+        if stacked:
             loss_D_fake = loss_D_real = 0
             for scale_out in pred_both:
                 l_fake, l_real = Fh.mse_const_pair_loss(scale_out[-1], self.criterionGAN.fake_label,
                                                         self.criterionGAN.real_label)
                 loss_D_fake, loss_D_real = loss_D_fake + l_fake, loss_D_real + l_real
-            pred_real = [[t.detach()[B:] for t in scale_out] for scale_out in pred_both]
         else:
             pred_fake_pool = self.netD.forward(self._d_in(lr_spectro, sr_spectro.detach()))
             loss_D_fake = self.criterionGAN(pred_fake_pool, False)
             pred_real = self.netD.forward(self._d_in(lr_spectro, hr_spectro))
             loss_D_real = self.criterionGAN(pred_real, True)
-        pred_fake = self.netD.forward(self._d_in(lr_spectro, sr_spectro),
-                                      weight_grad=not self.skip_discarded_d_grads)
-        loss_G_GAN = self.criterionGAN(pred_fake, True)
+        feat_weights = 4.0 / (self.n_layers_D + 1)
+        D_weights = 1.0 / self.num_D
         loss_G_GAN_Feat = 0
-        if not self.no_ganFeat_loss:
-            feat_weights = 4.0 / (self.n_layers_D + 1)
-            D_weights = 1.0 / self.num_D
-            for i in range(self.num_D):
-                for j in range(len(pred_fake[i]) - 1):
-                    loss_G_GAN_Feat = loss_G_GAN_Feat + Fh.l1_loss(
-                        pred_fake[i][j], pred_real[i][j].detach(), D_weights * feat_weights * self.lambda_feat)
+        if shared:
+            loss_G_GAN = 0
+            for scale_out in pred_both:
+                loss_G_GAN = loss_G_GAN + Fh.mse_const_first_half_loss(scale_out[-1], self.criterionGAN.real_label)
+                if not self.no_ganFeat_loss:
+                    for t in scale_out[:-1]:
+                        loss_G_GAN_Feat = loss_G_GAN_Feat + Fh.l1_halves_loss(
+                            t, D_weights * feat_weights * self.lambda_feat)
+        else:
+            if stacked:
+                pred_real = [[t.detach()[B:] for t in scale_out] for scale_out in pred_both]
+            pred_fake = self.netD.forward(self._d_in(lr_spectro, sr_spectro),
+                                          weight_grad=not self.skip_discarded_d_grads)
+            loss_G_GAN = self.criterionGAN(pred_fake, True)
+            if not self.no_ganFeat_loss:
+                for i in range(self.num_D):
+                    for j in range(len(pred_fake[i]) - 1):
+                        loss_G_GAN_Feat = loss_G_GAN_Feat + Fh.l1_loss(
+                            pred_fake[i][j], pred_real[i][j].detach(), D_weights * feat_weights * self.lambda_feat)
         # visuals are materialised lazily (the reference copies three tensors to the host every step)
         self._visual_src = (lr_spectro, sr_spectro.detach(), hr_spectro, lr_norm_param, hr_norm_param)
         return [self.loss_filter(loss_G_GAN, loss_G_GAN_Feat, loss_D_real, loss_D_fake),
@@ -327,7 +353,7 @@ class Pix2PixHDModel(BaseModel):
         """One train.py:160-202 iteration (float32 branch): forward, G step, D step.  Returns the loss dict
         (device scalars; call .item() only when you need to print)."""
         with amp.autocast(self.fp16):
-            losses, _ = self._forward(lr_audio, hr_audio, infer=False)
+            losses, _ = self._forward(lr_audio, hr_audio, infer=False, share_d_pass=True)
         loss_dict = dict(zip(self.loss_names, losses))
         loss_D = (loss_dict["D_fake"] + loss_dict["D_real"]) * 0.5
         loss_G = loss_dict["G_GAN"] + loss_dict.get("G_GAN_Feat", 0)
@@ -335,23 +361,28 @@ class Pix2PixHDModel(BaseModel):
         sc = self.scaler                           # train.py:183-199: one GradScaler, updated once per iteration
         if red:
             red["G"].active, red["D"].active = True, False
+        rows = self._shared_rows      # > 0: both losses hang off one discriminator forward (see _forward)
+        g_kw = dict(retain_graph=True) if rows else {}
+        d_kw = dict(inputs=[p for p in self.netD.parameters() if p.requires_grad]) if rows else {}
         self.optimizer_G.zero_grad()
-        if sc is not None:
-            sc.scale(loss_G).backward()
-            sc.step(self.optimizer_G)
-        else:
-            loss_G.backward()
-            self.optimizer_G.step()
+        with Fh.backward_pass("G" if rows else None, rows):
+            if sc is not None:
+                sc.scale(loss_G).backward(**g_kw)
+                sc.step(self.optimizer_G)
+            else:
+                loss_G.backward(**g_kw)
+                self.optimizer_G.step()
         if red:
             red["G"].active, red["D"].active = False, True
         self.optimizer_D.zero_grad()
-        if sc is not None:
-            sc.scale(loss_D).backward()
-            sc.step(self.optimizer_D)
-            sc.update()
-        else:
-            loss_D.backward()
-            self.optimizer_D.step()
+        with Fh.backward_pass("D" if rows else None, rows):
+            if sc is not None:
+                sc.scale(loss_D).backward(**d_kw)
+                sc.step(self.optimizer_D)
+                sc.update()
+            else:
+                loss_D.backward(**d_kw)
+                self.optimizer_D.step()
         return loss_dict
 
     def make_graphed_step(self, lr_audio, hr_audio, warmup=3):

@@ -283,6 +283,50 @@ def test_bottleneck_transformer_stack(cfg):
     assert np.abs(ye.cpu().numpy() - want.numpy()).max() <= 2e-4 * np.abs(want.numpy()).max()
 
 
+@pytest.mark.parametrize("num_D", [2, 3])
+def test_shared_discriminator_pass_matches_separate_passes(num_D):
+    """optimize_parameters() runs ONE discriminator forward over [fake, real] and backpropagates the G loss (fake half,
+    data gradients only) and the D loss (whole stack, weight gradients) through it.  Same losses, same gradients and
+    the same parameters after two Adam steps as the three-pass form of train.py:160-202 (share_d_fake_pass = False):
+    float32 rounding of different GEMM plans only (2e-5 of each tensor's largest element)."""
+    from mdctgan_amd import options
+    from mdctgan_amd.pix2pixHD_model import create_model
+
+    def build(share):
+        opt = options.make_opt(*options.SPECTRAL_FLAGS, "--lr_sampling_rate", "12000", "--netG", "global", "--ngf", "4",
+                               "--n_blocks_global", "2", "--n_blocks_attn_g", "0", "--num_D", str(num_D), "--ndf", "8",
+                               "--batchSize", "3", "--bins", "64", "--segment_length", "16128", "--gpu_ids", "0")
+        m = create_model(opt)
+        onets.fill_deterministic(m.netG)
+        onets.fill_deterministic(m.netD)
+        m.share_d_fake_pass = share
+        return m
+
+    a, b = build(True), build(False)
+    gen = torch.Generator().manual_seed(21)
+    for it in range(2):
+        hr = (0.05 * torch.randn(3, 16128, generator=gen)).to(DEV)
+        lr = (0.05 * torch.randn(3, 16128, generator=gen)).to(DEV)
+        la, lb = a.optimize_parameters(lr, hr), b.optimize_parameters(lr, hr)
+        assert a._shared_rows == 3 and b._shared_rows == 0
+        # iteration 0 starts from identical weights: tight.  Adam's first update is +-lr wherever the gradient sign is
+        # defined, so elements with a rounding-level gradient may step apart and iteration 1 is compared loosely.
+        tol = 2e-5 if it == 0 else 5e-2
+        for k in la:
+            assert abs(la[k].item() - lb[k].item()) <= tol * abs(lb[k].item()) + 1e-7, (it, k)
+        for net in ("netG", "netD"):
+            pa, pb = dict(getattr(a, net).named_parameters()), dict(getattr(b, net).named_parameters())
+            for k in pa:
+                ga, gb = pa[k].grad, pb[k].grad
+                assert ga is not None and gb is not None, (net, k)
+                scale = gb.abs().max().item()
+                assert (ga - gb).abs().max().item() <= tol * scale + 1e-12, (it, net, k)
+    for net in ("netG", "netD"):
+        pa, pb = dict(getattr(a, net).named_parameters()), dict(getattr(b, net).named_parameters())
+        for k in pa:
+            assert (pa[k] - pb[k]).abs().max().item() <= 2 * 2e-4 * 2 + 1e-6, (net, k)
+
+
 def test_local_enhancer_with_attention_step():
     """configs[2]-shaped model at toy width (netG=local, 2 bottleneck-attention blocks, num_D=3), float32: one full
     optimize_parameters() step against the oracle's step on the same deterministic weights."""
