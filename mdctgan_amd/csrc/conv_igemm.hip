@@ -1006,6 +1006,7 @@ __global__ void colsum_partial_kernel(const float* __restrict__ a, long long M, 
 
 }  // namespace
 #include "wino.h"
+#include "wino4.h"
 namespace {
 
 Geom to_geom(const mg_conv_geom* g) {
@@ -1478,6 +1479,177 @@ int wino_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw
     return MG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Winograd F(2x2,4x4) orchestration (transforms in wino4.h): the stride-1 4x4 PatchGAN layers.  25 GEMMs as one
+// batched launch of the same kernels the F(2x2,3x3) path uses.
+// ---------------------------------------------------------------------------------------------------------
+bool wino4_ok(const mg_conv_geom* g) {
+    static const bool off = getenv("MG_NO_WINOGRAD4") != nullptr;
+    static const int min_c = getenv("MG_WINO4_MIN_C") ? atoi(getenv("MG_WINO4_MIN_C")) : 32;
+    return !off && !prec_h(g) && g->KH == 4 && g->KW == 4 && g->stride == 1 && g->pad == 2 && !g->reflect &&
+           g->Ci % 16 == 0 && g->Co % 16 == 0 && g->Ci >= min_c && g->Co >= min_c && (g->H & 1) && (g->W & 1);
+}
+struct Wino4Dims { long long T; int TH, TW; };
+Wino4Dims wino4_dims(const mg_conv_geom* g) {
+    Wino4Dims d;
+    d.TH = (g->H + 1) / 2; d.TW = (g->W + 1) / 2; d.T = (long long)g->B * d.TH * d.TW;
+    return d;
+}
+WinoWgradPlan wino4_wgrad_plan(const mg_conv_geom* g) {
+    const Wino4Dims d = wino4_dims(g);
+    const int chunks = (int)((d.T + BK - 1) / BK);
+    bool big = g->Co >= 128 && g->Ci >= 128 && d.T > 1024;
+    int want = -1;
+    if (const char* f = getenv("MG_FORCE_WINO4_WGRAD")) {      // tuning harness: "big(0|1),splits"
+        int b = 0, sp = 1;
+        if (sscanf(f, "%d,%d", &b, &sp) == 2 && sp >= 1) { big = b != 0; want = sp; }
+    }
+    const int tiles = big ? ((g->Co + 127) / 128) * ((g->Ci + 127) / 128) : ((g->Co + 63) / 64) * ((g->Ci + 63) / 64);
+    int splits = want > 0 ? want : (tiles * 25 >= 512 ? 1 : (768 + tiles * 25 - 1) / (tiles * 25));
+    const int max_splits = chunks / 8 > 0 ? chunks / 8 : 1;
+    if (splits > max_splits) splits = max_splits;
+    int cps = (chunks + splits - 1) / splits;
+    splits = (chunks + cps - 1) / cps;
+    return {big, tiles, splits, cps};
+}
+size_t wino4_fwd_ws(const mg_conv_geom* g) {
+    const Wino4Dims d = wino4_dims(g);
+    const TilePlan tp = gemm_plan(d.T, g->Co, g->Ci / BK, 25, true, 0);
+    return (al256((size_t)25 * g->Co * g->Ci) + al256((size_t)25 * d.T * g->Ci) + al256((size_t)25 * d.T * g->Co) +
+            (tp.splits > 1 ? al256((size_t)tp.splits * 25 * d.T * g->Co) : 0)) * sizeof(float) + 256;
+}
+size_t wino4_dgrad_ws(const mg_conv_geom* g) {      // U | A dy A^T | dV | dd | split-K slabs
+    const Wino4Dims d = wino4_dims(g);
+    const TilePlan tp = gemm_plan(d.T, g->Ci, g->Co / BK, 25, true, 1);
+    return (al256((size_t)25 * g->Co * g->Ci) + al256((size_t)25 * d.T * g->Co) + 2 * al256((size_t)25 * d.T * g->Ci) +
+            (tp.splits > 1 ? al256((size_t)tp.splits * 25 * d.T * g->Ci) : 0)) * sizeof(float) + 256;
+}
+size_t wino4_wgrad_ws(const mg_conv_geom* g) {
+    const Wino4Dims d = wino4_dims(g);
+    const WinoWgradPlan p = wino4_wgrad_plan(g);
+    const size_t cs = (mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co) + 255) / 4;
+    return (al256((size_t)25 * d.T * g->Ci) + al256((size_t)25 * d.T * g->Co) + al256((size_t)25 * g->Co * g->Ci) +
+            (p.splits > 1 ? al256((size_t)p.splits * 25 * g->Co * g->Ci) : 0) + al256(cs)) * sizeof(float) + 256;
+}
+
+int wino4_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act, float* ws,
+              hipStream_t st, const float* u_pre, float* v_keep) {
+    const Wino4Dims d = wino4_dims(g);
+    float* U = ws;
+    float* V = U + al256((size_t)25 * g->Co * g->Ci);
+    float* Mx = V + al256((size_t)25 * d.T * g->Ci);
+    float* part = Mx + al256((size_t)25 * d.T * g->Co);
+    if (u_pre) U = const_cast<float*>(u_pre);
+    else hipLaunchKernelGGL(wino4_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 2)), dim3(256), 0, st, w,
+                            g->Co, g->Ci, U);
+    if (v_keep) V = v_keep;
+    hipLaunchKernelGGL(wino4_input_xform_kernel, dim3(wino_grid((size_t)d.T * g->Ci / 2)), dim3(256), 0, st, x, g->B, g->H,
+                       g->W, g->Ci, d.TH, d.TW, V);
+    const Geom gg{1, 1, (int)d.T, g->Ci, 1, (int)d.T, g->Co, 1, 1, 1, 0, 0};
+    const TilePlan tp = gemm_plan(d.T, g->Co, g->Ci / BK, 25, true, 0);
+    float* pp = tp.splits > 1 ? part : nullptr;
+    const Batch bt{d.T * g->Ci, (long long)g->Co * g->Ci, d.T * g->Co, 0};
+    probe_begin(st);
+    const bool k32 = use_k32(tp, g->Ci);
+    wino_launch_tiles(tp, [&](auto bm, auto bn) {
+        constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value;
+        dim3 grid((unsigned)(((d.T + BM_ - 1) / BM_) * ((g->Co + BN_ - 1) / BN_)), tp.splits, 25);
+        if (k32)
+            launch_fwd32<BM_, BN_, 1>(grid, st, gg, V, U, nullptr, Mx, MG_ACT_NONE, tp.splits == 1 ? (1 << 29) : tp.cps / 2,
+                                      pp, bt);
+        else
+            hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, true, 1>), grid, dim3(256), 0, st, gg, (const float*)V,
+                               (const float*)U, (const float*)nullptr, Mx, MG_ACT_NONE, tp.cps, pp, bt);
+    });
+    probe_end(st);
+    if (pp) {
+        const size_t n = (size_t)25 * d.T * g->Co;
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(wino_grid(n / 4)), dim3(256), 0, st, (const float*)pp, tp.splits,
+                           n, g->Co, (const float*)nullptr, MG_ACT_NONE, Mx);
+    }
+    hipLaunchKernelGGL(wino4_output_xform_kernel, dim3(wino_grid((size_t)d.T * g->Co / 2)), dim3(256), 0, st,
+                       (const float*)Mx, g->B, d.TH, d.TW, g->Co, bias, act, y);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+int wino4_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* dx, float* ws, hipStream_t st,
+                const float* u_pre, float* md_keep) {
+    const Wino4Dims d = wino4_dims(g);
+    const long long T = d.T;
+    float* U = ws;
+    float* Md = U + al256((size_t)25 * g->Co * g->Ci);
+    float* dV = Md + al256((size_t)25 * T * g->Co);
+    float* dd = dV + al256((size_t)25 * T * g->Ci);
+    float* part = dd + al256((size_t)25 * T * g->Ci);
+    if (u_pre) U = const_cast<float*>(u_pre);
+    else hipLaunchKernelGGL(wino4_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 2)), dim3(256), 0, st, w,
+                            g->Co, g->Ci, U);
+    if (md_keep) Md = md_keep;
+    hipLaunchKernelGGL(wino4_dy_xform_kernel, dim3(wino_grid((size_t)T * g->Co / 2)), dim3(256), 0, st, dy, g->B, d.TH,
+                       d.TW, g->Co, Md);
+    const Geom gg{1, 1, (int)T, g->Ci, 1, (int)T, g->Co, 1, 1, 1, 0, 0};
+    const TilePlan tp = gemm_plan(T, g->Ci, g->Co / BK, 25, true, 1);
+    float* pp = tp.splits > 1 ? part : nullptr;
+    const Batch bt{T * g->Co, (long long)g->Co * g->Ci, T * g->Ci, 0};
+    probe_begin(st);
+    wino_launch_tiles(tp, [&](auto bm, auto bn) {
+        constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value;
+        dim3 grid((unsigned)(((T + BM_ - 1) / BM_) * ((g->Ci + BN_ - 1) / BN_)), tp.splits, 25);
+        hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, true, 1>), grid, dim3(256), 0, st, gg, (const float*)Md,
+                           (const float*)U, (const float*)nullptr, dV, MG_ACT_NONE, tp.cps, pp, bt);
+    });
+    probe_end(st);
+    if (pp) {
+        const size_t n = (size_t)25 * T * g->Ci;
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(wino_grid(n / 4)), dim3(256), 0, st, (const float*)pp, tp.splits,
+                           n, g->Ci, (const float*)nullptr, MG_ACT_NONE, dV);
+    }
+    hipLaunchKernelGGL(wino4_dd_xform_kernel, dim3(wino_grid((size_t)T * g->Ci / 2)), dim3(256), 0, st, (const float*)dV, T,
+                       g->Ci, dd);
+    hipLaunchKernelGGL(wino4_dx_gather_kernel, dim3(wino_grid((size_t)g->B * g->H * g->W * g->Ci / 4)), dim3(256), 0, st,
+                       (const float*)dd, g->B, g->H, g->W, g->Ci, d.TH, d.TW, dx);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+int wino4_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate, float* ws,
+                hipStream_t st, const float* v_in, const float* md_in) {
+    const Wino4Dims d = wino4_dims(g);
+    const WinoWgradPlan p = wino4_wgrad_plan(g);
+    float* V = ws;
+    float* Md = V + al256((size_t)25 * d.T * g->Ci);
+    float* dU = Md + al256((size_t)25 * d.T * g->Co);
+    float* part = dU + al256((size_t)25 * g->Co * g->Ci);
+    if (v_in) V = const_cast<float*>(v_in);
+    else hipLaunchKernelGGL(wino4_input_xform_kernel, dim3(wino_grid((size_t)d.T * g->Ci / 2)), dim3(256), 0, st, x, g->B,
+                            g->H, g->W, g->Ci, d.TH, d.TW, V);
+    if (md_in) Md = const_cast<float*>(md_in);
+    else hipLaunchKernelGGL(wino4_dy_xform_kernel, dim3(wino_grid((size_t)d.T * g->Co / 2)), dim3(256), 0, st, dy, g->B,
+                            d.TH, d.TW, g->Co, Md);
+    const Geom gg{1, 1, (int)d.T, g->Ci, 1, (int)d.T, g->Co, 1, 1, 1, 0, 0};
+    float* target = p.splits > 1 ? part : dU;
+    const Batch bt{d.T * g->Ci, d.T * g->Co, (long long)g->Co * g->Ci, 0};
+    dim3 grid((unsigned)p.tiles, 25, p.splits);
+    probe_begin(st);
+    if (p.big)
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, true, true, 1>), grid, dim3(256), 0, st, gg, (const float*)V,
+                           (const float*)Md, target, p.cps, 0, bt);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, true, true, 1>), grid, dim3(256), 0, st, gg, (const float*)V,
+                           (const float*)Md, target, p.cps, 0, bt);
+    probe_end(st);
+    if (p.splits > 1) {
+        const size_t n = (size_t)25 * g->Co * g->Ci;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(wino_grid(n / 4)), dim3(256), 0, st, (const float*)part, p.splits, n,
+                           dU, 0);
+    }
+    hipLaunchKernelGGL(wino4_dweight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 2)), dim3(256), 0, st,
+                       (const float*)dU, g->Co, g->Ci, dw, accumulate);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1506,6 +1678,7 @@ double mg_conv_plan_flops(int pass, const mg_conv_geom* g) {
         const double T = (pass == 1 && g->reflect && wino_dgrad_padded()) ? (double)d.Tp : (double)d.T;
         return 2.0 * 16.0 * T * (double)g->Co * g->Ci;
     }
+    if (wino4_ok(g) && !mg_conv_rowdot_kq(g)) return 2.0 * 25.0 * (double)wino4_dims(g).T * (double)g->Co * g->Ci;
     return direct;
 }
 
@@ -1534,6 +1707,19 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
             const WinoWgradPlan p = wino_wgrad_plan(g);
             snprintf(out, out_len, "conv_wgrad_kernel<%d, %d, true, true, %d>", p.big ? 128 : 64, p.big ? 128 : 64,
                      prec_h(g) ? 3 : 1);
+        }
+    } else if (wino4_ok(g) && !kq) {
+        const Wino4Dims d = wino4_dims(g);
+        if (pass == 0) {
+            const TilePlan tp = gemm_plan(d.T, g->Co, g->Ci / BK, 25, true, 0);
+            if (use_k32(tp, g->Ci)) snprintf(out, out_len, "conv_fwd32_kernel<%d, %d, 1>", tp.bm, tp.bn);
+            else snprintf(out, out_len, "conv_fwd_kernel<%d, %d, true, 1>", tp.bm, tp.bn);
+        } else if (pass == 1) {
+            const TilePlan tp = gemm_plan(d.T, g->Ci, g->Co / BK, 25, true, 1);
+            snprintf(out, out_len, "conv_dgrad_kernel<%d, %d, true, true, 1>", tp.bm, tp.bn);
+        } else {
+            const WinoWgradPlan p = wino4_wgrad_plan(g);
+            snprintf(out, out_len, "conv_wgrad_kernel<%d, %d, true, true, 1>", p.big ? 128 : 64, p.big ? 128 : 64);
         }
     } else if (kq && pass == 0) {
         snprintf(out, out_len, "conv_rowdot_fwd_kernel<%d>", kq);
@@ -1567,22 +1753,32 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
 size_t mg_conv_fwd_workspace(const mg_conv_geom* g) {
     if (!geom_ok(g)) return 0;
     if (wino_ok(g)) return wino_fwd_ws(g);
+    if (wino4_ok(g) && !mg_conv_rowdot_kq(g)) return wino4_fwd_ws(g);
     const TilePlan tp = fwd_plan(g);
     return tp.splits > 1 ? (size_t)tp.splits * g->B * g->OH * g->OW * g->Co * sizeof(float) + 256 : 256;
 }
 size_t mg_conv_dgrad_workspace(const mg_conv_geom* g) {
     if (!geom_ok(g)) return 0;
     if (wino_ok(g)) return wino_dgrad_ws(g);
+    if (wino4_ok(g)) return wino4_dgrad_ws(g);
     const TilePlan tp = dgrad_plan(g);
     return tp.splits > 1 ? (size_t)tp.splits * g->B * g->H * g->W * g->Ci * sizeof(float) + 256 : 256;
 }
 
 size_t mg_conv_wino_weights_bytes(const mg_conv_geom* g) {
-    if (!geom_ok(g) || !wino_ok(g) || mg_conv_rowdot_kq(g)) return 0;
+    if (!geom_ok(g) || mg_conv_rowdot_kq(g)) return 0;
+    if (wino4_ok(g)) return (size_t)25 * g->Co * g->Ci * sizeof(float);
+    if (!wino_ok(g)) return 0;
     return (size_t)16 * g->Co * g->Ci * sizeof(float);
 }
 int mg_conv_wino_prepare(const mg_conv_geom* g, const float* w, float* u, void* stream) {
     if (!mg_conv_wino_weights_bytes(g) || !w || !u || !aligned16(w) || !aligned16(u)) return MG_ERR_ARG;
+    if (wino4_ok(g)) {
+        hipLaunchKernelGGL(wino4_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 2)), dim3(256), 0,
+                           (hipStream_t)stream, w, g->Co, g->Ci, u);
+        MG_CHECK_LAUNCH();
+        return MG_OK;
+    }
     hipLaunchKernelGGL(wino_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 4)), dim3(256), 0,
                        (hipStream_t)stream, w, g->Co, g->Ci, u);
     MG_CHECK_LAUNCH();
@@ -1591,6 +1787,10 @@ int mg_conv_wino_prepare(const mg_conv_geom* g, const float* w, float* u, void* 
 
 size_t mg_conv_wino_tiles_bytes(const mg_conv_geom* g, int which) {
     if (!mg_conv_wino_weights_bytes(g)) return 0;
+    if (wino4_ok(g)) {
+        const Wino4Dims d4 = wino4_dims(g);
+        return which == 0 ? (size_t)25 * d4.T * g->Ci * sizeof(float) : which == 1 ? (size_t)25 * d4.T * g->Co * sizeof(float) : 0;
+    }
     const WinoDims d = wino_dims(g);
     if (which == 0) return (size_t)16 * d.T * g->Ci * sizeof(float);
     if (which == 1) return wino_dgrad_padded() ? 0 : (size_t)16 * d.T * g->Co * sizeof(float);
@@ -1629,6 +1829,9 @@ int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const f
     if (wino_ok(g) && workspace && workspace_bytes >= wino_fwd_ws(g) && aligned16(x) && aligned16(w) && aligned16(y) &&
         aligned16(workspace) && (!bias || aligned16(bias)))
         return wino_fwd(g, x, w, bias, y, act, (float*)workspace, (hipStream_t)stream, u, wt ? wt->v : nullptr);
+    if (wino4_ok(g) && workspace && workspace_bytes >= wino4_fwd_ws(g) && aligned16(x) && aligned16(w) && aligned16(y) &&
+        aligned16(workspace) && (!bias || aligned16(bias)))
+        return wino4_fwd(g, x, w, bias, y, act, (float*)workspace, (hipStream_t)stream, u, wt ? wt->v : nullptr);
     const Geom gg = to_geom(g);
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)g->B * g->OH * g->OW;
@@ -1682,6 +1885,9 @@ int mg_conv_dgrad_w(const mg_conv_geom* g, const float* dy, const float* w, cons
         workspace_bytes >= wino_dgrad_ws(g) &&
         aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(workspace) && (!bias || aligned16(bias)))
         return wino_dgrad(g, dy, w, bias, dx, act, (float*)workspace, (hipStream_t)stream, u, wt ? wt->md : nullptr);
+    if (wino4_ok(g) && !bias && act == MG_ACT_NONE && workspace && workspace_bytes >= wino4_dgrad_ws(g) && aligned16(dy) &&
+        aligned16(w) && aligned16(dx) && aligned16(workspace))
+        return wino4_dgrad(g, dy, w, dx, (float*)workspace, (hipStream_t)stream, u, wt ? wt->md : nullptr);
     const Geom gg = to_geom(g);
     hipStream_t st = (hipStream_t)stream;
     const int s = g->stride;
@@ -1757,6 +1963,7 @@ size_t mg_conv_wgrad_workspace(const mg_conv_geom* g) {
     if (!geom_ok(g)) return 0;
     if (mg_conv_rowdot_kq(g)) return mg_conv_rowdot_wgrad_workspace(g);
     if (wino_ok(g)) return wino_wgrad_ws(g);
+    if (wino4_ok(g)) return wino4_wgrad_ws(g);
     const WgradPlan p = wgrad_plan(g);
     const size_t wg = p.splits > 1 ? (size_t)p.splits * g->Co * g->KH * g->KW * g->Ci * sizeof(float) : 0;
     const size_t cs = mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co);
@@ -1783,6 +1990,20 @@ int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, floa
             float* cs = (float*)workspace + al256((size_t)16 * d.T * g->Ci) + al256((size_t)16 * d.T * g->Co) +
                         al256((size_t)16 * g->Co * g->Ci) +
                         (wino_wgrad_plan(g).splits > 1 ? al256((size_t)wino_wgrad_plan(g).splits * 16 * g->Co * g->Ci) : 0);
+            return mg_colsum(dy, (long long)g->B * g->OH * g->OW, g->Co, dbias, accumulate, cs,
+                             mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co), stream);
+        }
+        return MG_OK;
+    }
+    if (wino4_ok(g) && aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace)) {
+        const int rc = wino4_wgrad(g, x, dy, dw, accumulate, (float*)workspace, (hipStream_t)stream, wt ? wt->v : nullptr,
+                                   wt ? wt->md : nullptr);
+        if (rc != MG_OK) return rc;
+        if (dbias) {
+            const Wino4Dims d = wino4_dims(g);
+            const WinoWgradPlan p4 = wino4_wgrad_plan(g);
+            float* cs = (float*)workspace + al256((size_t)25 * d.T * g->Ci) + al256((size_t)25 * d.T * g->Co) +
+                        al256((size_t)25 * g->Co * g->Ci) + (p4.splits > 1 ? al256((size_t)p4.splits * 25 * g->Co * g->Ci) : 0);
             return mg_colsum(dy, (long long)g->B * g->OH * g->OW, g->Co, dbias, accumulate, cs,
                              mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co), stream);
         }

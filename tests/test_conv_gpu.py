@@ -35,6 +35,11 @@ CONV_CASES = [
     ("wino_reflect_2rows", 3, 64, 2, 16, 64, 3, 1, 1, True),
     ("wino_reflect_big", 2, 128, 16, 32, 128, 3, 1, 1, True),
     ("odd_size_no_wino", 2, 32, 7, 9, 32, 3, 1, 1, True),
+    # 4x4 stride-1 PatchGAN layers: Winograd F(2x2,4x4) when H, W are odd (csrc/wino4.h), direct otherwise
+    ("wino4_17x33", 2, 64, 17, 33, 128, 4, 1, 2, False),
+    ("wino4_9x17_b3", 3, 128, 9, 17, 64, 4, 1, 2, False),
+    ("wino4_1x3", 3, 32, 1, 3, 32, 4, 1, 2, False),
+    ("d4x4_s1_even_direct", 2, 32, 6, 10, 64, 4, 1, 2, False),
 ]
 
 
@@ -157,3 +162,28 @@ def test_winograd_shared_weight_transform(reflect):
     assert torch.equal(dw0, dw1)
     g2 = ops.conv_geom(B, H, W, C, C, 3, 3, 2, 1, False)
     assert ops.wino_weights(g2, w) is None
+
+
+def test_winograd4_shared_images():
+    """The F(2x2,4x4) path behind the same caller-held images: U (25 x Co x Ci), V and Md (25 x tiles x C) shared
+    between forward, data gradient and weight gradient give the bits of the self-contained calls."""
+    from mdctgan_amd import ops
+    gen = torch.Generator().manual_seed(6)
+    B, Ci, Co, H, W = 2, 64, 96, 9, 17
+    g = ops.conv_geom(B, H, W, Ci, Co, 4, 4, 1, 2, False)
+    assert (g.OH, g.OW) == (H + 1, W + 1)
+    x = torch.randn(B, H, W, Ci, generator=gen).to(DEV)
+    dy = torch.randn(B, H + 1, W + 1, Co, generator=gen).to(DEV)
+    w = (torch.randn(Co, 4, 4, Ci, generator=gen) * 0.05).to(DEV)
+    u = ops.wino_weights(g, w)
+    assert u is not None and u.numel() == 25 * Co * Ci
+    T = B * ((H + 1) // 2) * ((W + 1) // 2)
+    v, md = ops.wino_tile_buffers(g, x.device)
+    assert v.numel() == 25 * T * Ci and md.numel() == 25 * T * Co
+    assert torch.equal(ops.conv_fwd(g, x, w, None, ops.ACT_NONE, u, v), ops.conv_fwd(g, x, w))
+    assert torch.equal(ops.conv_dgrad(g, dy, w, u=u, md_out=md), ops.conv_dgrad(g, dy, w))
+    dw0, dw1 = torch.empty(Co, 4, 4, Ci, device=DEV), torch.empty(Co, 4, 4, Ci, device=DEV)
+    ops.conv_wgrad(g, x, dy, dw0, None)
+    ops.conv_wgrad(g, x, dy, dw1, None, v=v, md=md)
+    assert torch.equal(dw0, dw1)
+    assert "true, 1>" in ops.plan_name(1, g)        # the batched Winograd-domain GEMM
