@@ -1007,6 +1007,7 @@ __global__ void colsum_partial_kernel(const float* __restrict__ a, long long M, 
 }  // namespace
 #include "wino.h"
 #include "wino4.h"
+#include "conv_smallc.h"
 namespace {
 
 Geom to_geom(const mg_conv_geom* g) {
@@ -1650,6 +1651,77 @@ int wino4_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* d
     return MG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Ci <= 4 layers (conv_smallc.h): VALU kernels for the data gradient and the weight gradient
+// ---------------------------------------------------------------------------------------------------------
+bool smallc_enabled() {
+    static const bool off = getenv("MG_NO_SMALLC") != nullptr;
+    return !off;
+}
+bool smallc_dgrad_ok(const mg_conv_geom* g) {
+    return smallc_enabled() && !prec_h(g) && g->Ci >= 1 && g->Ci <= 4 && !g->reflect && g->Co % 4 == 0 && g->Co >= 16;
+}
+// 0: not eligible; otherwise the template instance id
+int smallc_wgrad_kind(const mg_conv_geom* g) {
+    if (!smallc_enabled() || prec_h(g) || g->Co < 16 || ((g->stride * g->Ci) & 1)) return 0;
+    if ((size_t)g->KH * (((g->OW - 1) * g->stride + g->KW) * g->Ci + 4) * sizeof(float) > 60000) return 0;
+    if ((long long)g->B * g->OH > 65535LL * 32) return 0;
+    if (g->KH == 4 && g->KW == 4 && g->Ci == 3) return 1;
+    if (g->KH == 7 && g->KW == 7 && g->Ci == 2) return 2;
+    if (g->KH == 3 && g->KW == 3 && g->Ci == 4) return 3;
+    return 0;
+}
+// even stride * Ci keeps every pixel's patch segment 8-byte aligned in the staged rows
+struct SmallcWgradPlan { int wgs, rowlen; size_t lds; };
+SmallcWgradPlan smallc_wgrad_plan(const mg_conv_geom* g) {
+    const int ncols = (g->OW - 1) * g->stride + g->KW;
+    const int rowlen = (ncols * g->Ci + 3) / 4 * 4;
+    return {g->B * g->OH, rowlen, (size_t)g->KH * rowlen * sizeof(float)};
+}
+// workspace: per-row partials | column-sum scratch of their reduction | column-sum scratch of the bias gradient
+struct SmallcWs { size_t part, red, cs, total; };      // float offsets / counts
+SmallcWs smallc_wgrad_layout(const mg_conv_geom* g) {
+    const SmallcWgradPlan p = smallc_wgrad_plan(g);
+    const size_t n = (size_t)g->Co * g->KH * g->KW * g->Ci;
+    SmallcWs w;
+    w.part = 0;
+    w.red = al256((size_t)p.wgs * n);
+    w.cs = w.red + al256((mg_colsum_workspace(p.wgs, (int)n) + 255) / 4);
+    w.total = w.cs + al256((mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co) + 255) / 4);
+    return w;
+}
+size_t smallc_wgrad_ws(const mg_conv_geom* g) { return smallc_wgrad_layout(g).total * sizeof(float) + 256; }
+int smallc_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate, float* ws,
+                 hipStream_t st) {
+    const SmallcWgradPlan p = smallc_wgrad_plan(g);
+    const SmallcWs lay = smallc_wgrad_layout(g);
+    const Geom gg = to_geom(g);
+    const dim3 grid((unsigned)p.wgs, (unsigned)((g->Co + 63) / 64));
+    switch (smallc_wgrad_kind(g)) {
+    case 1: hipLaunchKernelGGL((conv_smallc_wgrad_kernel<4, 4, 3>), grid, dim3(256), p.lds, st, gg, x, dy, ws, p.rowlen); break;
+    case 2: hipLaunchKernelGGL((conv_smallc_wgrad_kernel<7, 7, 2>), grid, dim3(448), p.lds, st, gg, x, dy, ws, p.rowlen); break;
+    case 3: hipLaunchKernelGGL((conv_smallc_wgrad_kernel<3, 3, 4>), grid, dim3(192), p.lds, st, gg, x, dy, ws, p.rowlen); break;
+    default: return MG_ERR_UNSUPPORTED;
+    }
+    MG_CHECK_LAUNCH();
+    const size_t n = (size_t)g->Co * g->KH * g->KW * g->Ci;
+    return mg_colsum(ws, p.wgs, (int)n, dw, accumulate, ws + lay.red, mg_colsum_workspace(p.wgs, (int)n), st);
+}
+int smallc_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* dx, hipStream_t st) {
+    const Geom gg = to_geom(g);
+    const int s = g->stride;
+    const long long Mc = (long long)g->B * ((g->H + s - 1) / s) * ((g->W + s - 1) / s);
+    const dim3 grid((unsigned)((Mc + 255) / 256), (unsigned)(s * s));
+    switch (g->Ci) {
+    case 1: hipLaunchKernelGGL(conv_smallc_dgrad_kernel<1>, grid, dim3(256), 0, st, gg, dy, w, dx); break;
+    case 2: hipLaunchKernelGGL(conv_smallc_dgrad_kernel<2>, grid, dim3(256), 0, st, gg, dy, w, dx); break;
+    case 3: hipLaunchKernelGGL(conv_smallc_dgrad_kernel<3>, grid, dim3(256), 0, st, gg, dy, w, dx); break;
+    default: hipLaunchKernelGGL(conv_smallc_dgrad_kernel<4>, grid, dim3(256), 0, st, gg, dy, w, dx); break;
+    }
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1721,6 +1793,10 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
             const WinoWgradPlan p = wino4_wgrad_plan(g);
             snprintf(out, out_len, "conv_wgrad_kernel<%d, %d, true, true, 1>", p.big ? 128 : 64, p.big ? 128 : 64);
         }
+    } else if (pass == 1 && smallc_dgrad_ok(g)) {
+        snprintf(out, out_len, "conv_smallc_dgrad_kernel<%d>", g->Ci);
+    } else if (pass == 2 && !kq && smallc_wgrad_kind(g)) {
+        snprintf(out, out_len, "conv_smallc_wgrad_kernel<%d, %d, %d>", g->KH, g->KW, g->Ci);
     } else if (kq && pass == 0) {
         snprintf(out, out_len, "conv_rowdot_fwd_kernel<%d>", kq);
     } else if (kq && pass == 2) {
@@ -1881,6 +1957,12 @@ int mg_conv_dgrad_w(const mg_conv_geom* g, const float* dy, const float* w, cons
     if (!wino_tiles_ok(g, wt)) return MG_ERR_ARG;
     const float* u = wt ? wt->u : nullptr;
     if (g->reflect && g->stride != 1) return MG_ERR_UNSUPPORTED;
+    if (smallc_dgrad_ok(g) && !bias && act == MG_ACT_NONE && aligned16(dy)) {
+        probe_begin((hipStream_t)stream);
+        const int rc = smallc_dgrad(g, dy, w, dx, (hipStream_t)stream);
+        probe_end((hipStream_t)stream);
+        return rc;
+    }
     if (wino_ok(g) && !(wino_dgrad_padded() && g->reflect && (bias || act != MG_ACT_NONE)) && workspace &&
         workspace_bytes >= wino_dgrad_ws(g) &&
         aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(workspace) && (!bias || aligned16(bias)))
@@ -1964,6 +2046,7 @@ size_t mg_conv_wgrad_workspace(const mg_conv_geom* g) {
     if (mg_conv_rowdot_kq(g)) return mg_conv_rowdot_wgrad_workspace(g);
     if (wino_ok(g)) return wino_wgrad_ws(g);
     if (wino4_ok(g)) return wino4_wgrad_ws(g);
+    if (smallc_wgrad_kind(g)) return smallc_wgrad_ws(g);
     const WgradPlan p = wgrad_plan(g);
     const size_t wg = p.splits > 1 ? (size_t)p.splits * g->Co * g->KH * g->KW * g->Ci * sizeof(float) : 0;
     const size_t cs = mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co);
@@ -1990,6 +2073,18 @@ int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, floa
             float* cs = (float*)workspace + al256((size_t)16 * d.T * g->Ci) + al256((size_t)16 * d.T * g->Co) +
                         al256((size_t)16 * g->Co * g->Ci) +
                         (wino_wgrad_plan(g).splits > 1 ? al256((size_t)wino_wgrad_plan(g).splits * 16 * g->Co * g->Ci) : 0);
+            return mg_colsum(dy, (long long)g->B * g->OH * g->OW, g->Co, dbias, accumulate, cs,
+                             mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co), stream);
+        }
+        return MG_OK;
+    }
+    if (smallc_wgrad_kind(g) && aligned16(dw) && aligned16(workspace)) {
+        probe_begin((hipStream_t)stream);
+        const int rc = smallc_wgrad(g, x, dy, dw, accumulate, (float*)workspace, (hipStream_t)stream);
+        probe_end((hipStream_t)stream);
+        if (rc != MG_OK) return rc;
+        if (dbias) {
+            float* cs = (float*)workspace + smallc_wgrad_layout(g).cs;
             return mg_colsum(dy, (long long)g->B * g->OH * g->OW, g->Co, dbias, accumulate, cs,
                              mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co), stream);
         }

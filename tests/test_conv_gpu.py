@@ -40,6 +40,12 @@ CONV_CASES = [
     ("wino4_9x17_b3", 3, 128, 9, 17, 64, 4, 1, 2, False),
     ("wino4_1x3", 3, 32, 1, 3, 32, 4, 1, 2, False),
     ("d4x4_s1_even_direct", 2, 32, 6, 10, 64, 4, 1, 2, False),
+    # Ci <= 4: VALU data- / weight-gradient kernels (csrc/conv_smallc.h)
+    ("smallc_4x4_s2_co80", 1, 3, 17, 33, 80, 4, 2, 2, False),
+    ("smallc_4x4_s2_b5", 5, 3, 64, 128, 64, 4, 2, 2, False),
+    ("smallc_3x3_ci4", 2, 4, 16, 24, 32, 3, 1, 1, False),
+    ("smallc_7x7_reflect_b3", 3, 2, 20, 36, 64, 7, 1, 3, True),
+    ("smallc_dgrad_ci1", 2, 1, 9, 14, 16, 3, 1, 1, False),
 ]
 
 
