@@ -1007,6 +1007,7 @@ __global__ void colsum_partial_kernel(const float* __restrict__ a, long long M, 
 }  // namespace
 #include "wino.h"
 #include "wino4.h"
+#include "wino42.h"
 #include "conv_smallc.h"
 namespace {
 
@@ -1114,6 +1115,11 @@ TilePlan gemm_plan(long long M, int N, int chunks, int classes, bool can_split, 
         {1, 34320, 64, 128, 4, 64, 64, 1, 0},
         {1, 2448, 128, 256, 4, 64, 64, 4, 0},
         {1, 8976, 64, 128, 4, 64, 64, 2, 0},
+        {0, 2448, 512, 16, 25, 64, 64, 1, 1},      // F(2x2,4x4) forward GEMMs of the 256->512 discriminator layer, batch 16
+        {0, 2448, 256, 32, 25, 64, 64, 1, 1},      // F(4x4,2x2) GEMMs of the stride-2 discriminator layers, batch 16 / 8
+        {0, 2448, 128, 16, 25, 128, 128, 1, 1},
+        {1, 2448, 512, 16, 25, 64, 64, 1, 0},
+        {1, 1224, 512, 16, 25, 64, 64, 1, 0},
         // configs[2] (LocalEnhancer) Winograd GEMMs: 2048-channel 4x8 trunk blocks (64 tiles), 128-channel 64x128 local blocks
         {0, 64, 2048, 128, 16, 64, 64, 4, 1},
         {1, 64, 2048, 128, 16, 64, 64, 1, 0},
@@ -1499,14 +1505,14 @@ Wino4Dims wino4_dims(const mg_conv_geom* g) {
 WinoWgradPlan wino4_wgrad_plan(const mg_conv_geom* g) {
     const Wino4Dims d = wino4_dims(g);
     const int chunks = (int)((d.T + BK - 1) / BK);
-    bool big = g->Co >= 128 && g->Ci >= 128 && d.T > 1024;
+    bool big = g->Co >= 128 && g->Ci >= 128 && d.T > 4096;      // measured at 2448 tiles: 64x64 232 us, 128x128 252 us
     int want = -1;
     if (const char* f = getenv("MG_FORCE_WINO4_WGRAD")) {      // tuning harness: "big(0|1),splits"
         int b = 0, sp = 1;
         if (sscanf(f, "%d,%d", &b, &sp) == 2 && sp >= 1) { big = b != 0; want = sp; }
     }
     const int tiles = big ? ((g->Co + 127) / 128) * ((g->Ci + 127) / 128) : ((g->Co + 63) / 64) * ((g->Ci + 63) / 64);
-    int splits = want > 0 ? want : (tiles * 25 >= 512 ? 1 : (768 + tiles * 25 - 1) / (tiles * 25));
+    int splits = want > 0 ? want : (tiles * 25 >= 512 ? (chunks >= 128 ? 3 : 1) : (768 + tiles * 25 - 1) / (tiles * 25));
     const int max_splits = chunks / 8 > 0 ? chunks / 8 : 1;
     if (splits > max_splits) splits = max_splits;
     int cps = (chunks + splits - 1) / splits;
@@ -1652,6 +1658,183 @@ int wino4_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* d
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Winograd F(4x4,2x2) over the space-to-depth view (wino42.h): the stride-2 4x4 PatchGAN layers.  K = 4 Ci.
+// ---------------------------------------------------------------------------------------------------------
+bool wino42_ok(const mg_conv_geom* g) {
+    static const bool off = getenv("MG_NO_WINOGRAD42") != nullptr;
+    static const int min_c = getenv("MG_WINO42_MIN_C") ? atoi(getenv("MG_WINO42_MIN_C")) : 16;
+    if (off || prec_h(g) || g->KH != 4 || g->KW != 4 || g->stride != 2 || g->pad != 2 || g->reflect || g->Ci % 16 ||
+        g->Co % 16 || g->Ci < min_c || g->Co < min_c || g->H < 2 || g->W < 2)
+        return false;
+    // the transforms move 25/16 of the phase-channel data per pass: measured faster than the direct kernels from ~1000
+    // tiles (batch 16 at 33x65: 136 -> 92 us forward), slower below (720 tiles: 40 -> 60 us).  Read per call so the
+    // parity tests can exercise small shapes.
+    const char* mt = getenv("MG_WINO42_MIN_TILES");
+    const long long min_tiles = mt ? atoll(mt) : 1000;
+    return (long long)g->B * ((g->OH + 3) / 4) * ((g->OW + 3) / 4) >= min_tiles;
+}
+struct Wino42Dims { long long T; int TH, TW, K4; };
+Wino42Dims wino42_dims(const mg_conv_geom* g) {
+    Wino42Dims d;
+    d.TH = (g->OH + 3) / 4; d.TW = (g->OW + 3) / 4; d.T = (long long)g->B * d.TH * d.TW; d.K4 = 4 * g->Ci;
+    return d;
+}
+WinoWgradPlan wino42_wgrad_plan(const mg_conv_geom* g) {
+    const Wino42Dims d = wino42_dims(g);
+    const int chunks = (int)((d.T + BK - 1) / BK);
+    bool big = g->Co >= 128 && d.K4 >= 128 && d.T > 4096;
+    int want = -1;
+    if (const char* f = getenv("MG_FORCE_WINO42_WGRAD")) {      // tuning harness: "big(0|1),splits"
+        int b = 0, sp = 1;
+        if (sscanf(f, "%d,%d", &b, &sp) == 2 && sp >= 1) { big = b != 0; want = sp; }
+    }
+    const int tiles = big ? ((g->Co + 127) / 128) * ((d.K4 + 127) / 128) : ((g->Co + 63) / 64) * ((d.K4 + 63) / 64);
+    int splits = want > 0 ? want : (tiles * 25 >= 512 ? (chunks >= 128 ? 3 : 1) : (768 + tiles * 25 - 1) / (tiles * 25));
+    const int max_splits = chunks / 8 > 0 ? chunks / 8 : 1;
+    if (splits > max_splits) splits = max_splits;
+    int cps = (chunks + splits - 1) / splits;
+    splits = (chunks + cps - 1) / cps;
+    return {big, tiles, splits, cps};
+}
+size_t wino42_fwd_ws(const mg_conv_geom* g) {
+    const Wino42Dims d = wino42_dims(g);
+    const TilePlan tp = gemm_plan(d.T, g->Co, d.K4 / BK, 25, true, 0);
+    return (al256((size_t)25 * g->Co * d.K4) + al256((size_t)25 * d.T * d.K4) + al256((size_t)25 * d.T * g->Co) +
+            (tp.splits > 1 ? al256((size_t)tp.splits * 25 * d.T * g->Co) : 0)) * sizeof(float) + 256;
+}
+size_t wino42_dgrad_ws(const mg_conv_geom* g) {      // U | A dy A^T | dV | dd | split-K slabs
+    const Wino42Dims d = wino42_dims(g);
+    const TilePlan tp = gemm_plan(d.T, d.K4, g->Co / BK, 25, true, 1);
+    return (al256((size_t)25 * g->Co * d.K4) + al256((size_t)25 * d.T * g->Co) + 2 * al256((size_t)25 * d.T * d.K4) +
+            (tp.splits > 1 ? al256((size_t)tp.splits * 25 * d.T * d.K4) : 0)) * sizeof(float) + 256;
+}
+size_t wino42_wgrad_ws(const mg_conv_geom* g) {
+    const Wino42Dims d = wino42_dims(g);
+    const WinoWgradPlan p = wino42_wgrad_plan(g);
+    const size_t cs = (mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co) + 255) / 4;
+    return (al256((size_t)25 * d.T * d.K4) + al256((size_t)25 * d.T * g->Co) + al256((size_t)25 * g->Co * d.K4) +
+            (p.splits > 1 ? al256((size_t)p.splits * 25 * g->Co * d.K4) : 0) + al256(cs)) * sizeof(float) + 256;
+}
+
+int wino42_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act, float* ws,
+               hipStream_t st, const float* u_pre, float* v_keep) {
+    const Wino42Dims d = wino42_dims(g);
+    float* U = ws;
+    float* V = U + al256((size_t)25 * g->Co * d.K4);
+    float* Mx = V + al256((size_t)25 * d.T * d.K4);
+    float* part = Mx + al256((size_t)25 * d.T * g->Co);
+    if (u_pre) U = const_cast<float*>(u_pre);
+    else hipLaunchKernelGGL(wino42_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * d.K4 / 2)), dim3(256), 0, st, w,
+                            g->Co, g->Ci, U);
+    if (v_keep) V = v_keep;
+    hipLaunchKernelGGL(wino42_input_xform_kernel, dim3(wino_grid((size_t)d.T * d.K4 / 2)), dim3(256), 0, st, x, g->B, g->H,
+                       g->W, g->Ci, d.TH, d.TW, V);
+    const Geom gg{1, 1, (int)d.T, d.K4, 1, (int)d.T, g->Co, 1, 1, 1, 0, 0};
+    const TilePlan tp = gemm_plan(d.T, g->Co, d.K4 / BK, 25, true, 0);
+    float* pp = tp.splits > 1 ? part : nullptr;
+    const Batch bt{d.T * d.K4, (long long)g->Co * d.K4, d.T * g->Co, 0};
+    probe_begin(st);
+    const bool k32 = use_k32(tp, d.K4);
+    wino_launch_tiles(tp, [&](auto bm, auto bn) {
+        constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value;
+        dim3 grid((unsigned)(((d.T + BM_ - 1) / BM_) * ((g->Co + BN_ - 1) / BN_)), tp.splits, 25);
+        if (k32)
+            launch_fwd32<BM_, BN_, 1>(grid, st, gg, V, U, nullptr, Mx, MG_ACT_NONE, tp.splits == 1 ? (1 << 29) : tp.cps / 2,
+                                      pp, bt);
+        else
+            hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, true, 1>), grid, dim3(256), 0, st, gg, (const float*)V,
+                               (const float*)U, (const float*)nullptr, Mx, MG_ACT_NONE, tp.cps, pp, bt);
+    });
+    probe_end(st);
+    if (pp) {
+        const size_t n = (size_t)25 * d.T * g->Co;
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(wino_grid(n / 4)), dim3(256), 0, st, (const float*)pp, tp.splits,
+                           n, g->Co, (const float*)nullptr, MG_ACT_NONE, Mx);
+    }
+    hipLaunchKernelGGL(wino42_output_xform_kernel, dim3(wino_grid((size_t)d.T * g->Co / 2)), dim3(256), 0, st,
+                       (const float*)Mx, g->B, g->OH, g->OW, d.TH, d.TW, g->Co, bias, act, y);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+int wino42_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* dx, float* ws, hipStream_t st,
+                 const float* u_pre, float* md_keep) {
+    const Wino42Dims d = wino42_dims(g);
+    const long long T = d.T;
+    float* U = ws;
+    float* Md = U + al256((size_t)25 * g->Co * d.K4);
+    float* dV = Md + al256((size_t)25 * T * g->Co);
+    float* dd = dV + al256((size_t)25 * T * d.K4);
+    float* part = dd + al256((size_t)25 * T * d.K4);
+    if (u_pre) U = const_cast<float*>(u_pre);
+    else hipLaunchKernelGGL(wino42_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * d.K4 / 2)), dim3(256), 0, st, w,
+                            g->Co, g->Ci, U);
+    if (md_keep) Md = md_keep;
+    hipLaunchKernelGGL(wino42_dy_xform_kernel, dim3(wino_grid((size_t)T * g->Co / 2)), dim3(256), 0, st, dy, g->B, g->OH,
+                       g->OW, d.TH, d.TW, g->Co, Md);
+    const Geom gg{1, 1, (int)T, d.K4, 1, (int)T, g->Co, 1, 1, 1, 0, 0};
+    const TilePlan tp = gemm_plan(T, d.K4, g->Co / BK, 25, true, 1);
+    float* pp = tp.splits > 1 ? part : nullptr;
+    const Batch bt{T * g->Co, (long long)g->Co * d.K4, T * d.K4, 0};
+    probe_begin(st);
+    wino_launch_tiles(tp, [&](auto bm, auto bn) {
+        constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value;
+        dim3 grid((unsigned)(((T + BM_ - 1) / BM_) * ((d.K4 + BN_ - 1) / BN_)), tp.splits, 25);
+        hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, true, 1>), grid, dim3(256), 0, st, gg, (const float*)Md,
+                           (const float*)U, (const float*)nullptr, dV, MG_ACT_NONE, tp.cps, pp, bt);
+    });
+    probe_end(st);
+    if (pp) {
+        const size_t n = (size_t)25 * T * d.K4;
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(wino_grid(n / 4)), dim3(256), 0, st, (const float*)pp, tp.splits,
+                           n, d.K4, (const float*)nullptr, MG_ACT_NONE, dV);
+    }
+    hipLaunchKernelGGL(wino4_dd_xform_kernel, dim3(wino_grid((size_t)T * d.K4 / 2)), dim3(256), 0, st, (const float*)dV, T,
+                       d.K4, dd);
+    hipLaunchKernelGGL(wino42_dx_gather_kernel, dim3(wino_grid((size_t)g->B * g->H * g->W * g->Ci / 4)), dim3(256), 0, st,
+                       (const float*)dd, g->B, g->H, g->W, g->Ci, d.TH, d.TW, dx);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+int wino42_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate, float* ws,
+                 hipStream_t st, const float* v_in, const float* md_in) {
+    const Wino42Dims d = wino42_dims(g);
+    const WinoWgradPlan p = wino42_wgrad_plan(g);
+    float* V = ws;
+    float* Md = V + al256((size_t)25 * d.T * d.K4);
+    float* dU = Md + al256((size_t)25 * d.T * g->Co);
+    float* part = dU + al256((size_t)25 * g->Co * d.K4);
+    if (v_in) V = const_cast<float*>(v_in);
+    else hipLaunchKernelGGL(wino42_input_xform_kernel, dim3(wino_grid((size_t)d.T * d.K4 / 2)), dim3(256), 0, st, x, g->B,
+                            g->H, g->W, g->Ci, d.TH, d.TW, V);
+    if (md_in) Md = const_cast<float*>(md_in);
+    else hipLaunchKernelGGL(wino42_dy_xform_kernel, dim3(wino_grid((size_t)d.T * g->Co / 2)), dim3(256), 0, st, dy, g->B,
+                            g->OH, g->OW, d.TH, d.TW, g->Co, Md);
+    const Geom gg{1, 1, (int)d.T, d.K4, 1, (int)d.T, g->Co, 1, 1, 1, 0, 0};
+    float* target = p.splits > 1 ? part : dU;
+    const Batch bt{d.T * d.K4, d.T * g->Co, (long long)g->Co * d.K4, 0};
+    dim3 grid((unsigned)p.tiles, 25, p.splits);
+    probe_begin(st);
+    if (p.big)
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, true, true, 1>), grid, dim3(256), 0, st, gg, (const float*)V,
+                           (const float*)Md, target, p.cps, 0, bt);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, true, true, 1>), grid, dim3(256), 0, st, gg, (const float*)V,
+                           (const float*)Md, target, p.cps, 0, bt);
+    probe_end(st);
+    if (p.splits > 1) {
+        const size_t n = (size_t)25 * g->Co * d.K4;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(wino_grid(n / 4)), dim3(256), 0, st, (const float*)part, p.splits, n,
+                           dU, 0);
+    }
+    hipLaunchKernelGGL(wino42_dweight_xform_kernel, dim3(wino_grid((size_t)g->Co * d.K4 / 2)), dim3(256), 0, st,
+                       (const float*)dU, g->Co, g->Ci, dw, accumulate);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Ci <= 4 layers (conv_smallc.h): VALU kernels for the data gradient and the weight gradient
 // ---------------------------------------------------------------------------------------------------------
 bool smallc_enabled() {
@@ -1751,6 +1934,7 @@ double mg_conv_plan_flops(int pass, const mg_conv_geom* g) {
         return 2.0 * 16.0 * T * (double)g->Co * g->Ci;
     }
     if (wino4_ok(g) && !mg_conv_rowdot_kq(g)) return 2.0 * 25.0 * (double)wino4_dims(g).T * (double)g->Co * g->Ci;
+    if (wino42_ok(g)) return 2.0 * 25.0 * (double)wino42_dims(g).T * (double)g->Co * 4.0 * g->Ci;
     return direct;
 }
 
@@ -1793,6 +1977,19 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
             const WinoWgradPlan p = wino4_wgrad_plan(g);
             snprintf(out, out_len, "conv_wgrad_kernel<%d, %d, true, true, 1>", p.big ? 128 : 64, p.big ? 128 : 64);
         }
+    } else if (wino42_ok(g) && !kq) {
+        const Wino42Dims d = wino42_dims(g);
+        if (pass == 0) {
+            const TilePlan tp = gemm_plan(d.T, g->Co, d.K4 / BK, 25, true, 0);
+            if (use_k32(tp, d.K4)) snprintf(out, out_len, "conv_fwd32_kernel<%d, %d, 1>", tp.bm, tp.bn);
+            else snprintf(out, out_len, "conv_fwd_kernel<%d, %d, true, 1>", tp.bm, tp.bn);
+        } else if (pass == 1) {
+            const TilePlan tp = gemm_plan(d.T, d.K4, g->Co / BK, 25, true, 1);
+            snprintf(out, out_len, "conv_dgrad_kernel<%d, %d, true, true, 1>", tp.bm, tp.bn);
+        } else {
+            const WinoWgradPlan p = wino42_wgrad_plan(g);
+            snprintf(out, out_len, "conv_wgrad_kernel<%d, %d, true, true, 1>", p.big ? 128 : 64, p.big ? 128 : 64);
+        }
     } else if (pass == 1 && smallc_dgrad_ok(g)) {
         snprintf(out, out_len, "conv_smallc_dgrad_kernel<%d>", g->Ci);
     } else if (pass == 2 && !kq && smallc_wgrad_kind(g)) {
@@ -1830,6 +2027,7 @@ size_t mg_conv_fwd_workspace(const mg_conv_geom* g) {
     if (!geom_ok(g)) return 0;
     if (wino_ok(g)) return wino_fwd_ws(g);
     if (wino4_ok(g) && !mg_conv_rowdot_kq(g)) return wino4_fwd_ws(g);
+    if (wino42_ok(g)) return wino42_fwd_ws(g);
     const TilePlan tp = fwd_plan(g);
     return tp.splits > 1 ? (size_t)tp.splits * g->B * g->OH * g->OW * g->Co * sizeof(float) + 256 : 256;
 }
@@ -1837,6 +2035,7 @@ size_t mg_conv_dgrad_workspace(const mg_conv_geom* g) {
     if (!geom_ok(g)) return 0;
     if (wino_ok(g)) return wino_dgrad_ws(g);
     if (wino4_ok(g)) return wino4_dgrad_ws(g);
+    if (wino42_ok(g)) return wino42_dgrad_ws(g);
     const TilePlan tp = dgrad_plan(g);
     return tp.splits > 1 ? (size_t)tp.splits * g->B * g->H * g->W * g->Ci * sizeof(float) + 256 : 256;
 }
@@ -1844,6 +2043,7 @@ size_t mg_conv_dgrad_workspace(const mg_conv_geom* g) {
 size_t mg_conv_wino_weights_bytes(const mg_conv_geom* g) {
     if (!geom_ok(g) || mg_conv_rowdot_kq(g)) return 0;
     if (wino4_ok(g)) return (size_t)25 * g->Co * g->Ci * sizeof(float);
+    if (wino42_ok(g)) return (size_t)25 * g->Co * 4 * g->Ci * sizeof(float);
     if (!wino_ok(g)) return 0;
     return (size_t)16 * g->Co * g->Ci * sizeof(float);
 }
@@ -1851,6 +2051,12 @@ int mg_conv_wino_prepare(const mg_conv_geom* g, const float* w, float* u, void* 
     if (!mg_conv_wino_weights_bytes(g) || !w || !u || !aligned16(w) || !aligned16(u)) return MG_ERR_ARG;
     if (wino4_ok(g)) {
         hipLaunchKernelGGL(wino4_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 2)), dim3(256), 0,
+                           (hipStream_t)stream, w, g->Co, g->Ci, u);
+        MG_CHECK_LAUNCH();
+        return MG_OK;
+    }
+    if (wino42_ok(g)) {
+        hipLaunchKernelGGL(wino42_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * 4 * g->Ci / 2)), dim3(256), 0,
                            (hipStream_t)stream, w, g->Co, g->Ci, u);
         MG_CHECK_LAUNCH();
         return MG_OK;
@@ -1866,6 +2072,10 @@ size_t mg_conv_wino_tiles_bytes(const mg_conv_geom* g, int which) {
     if (wino4_ok(g)) {
         const Wino4Dims d4 = wino4_dims(g);
         return which == 0 ? (size_t)25 * d4.T * g->Ci * sizeof(float) : which == 1 ? (size_t)25 * d4.T * g->Co * sizeof(float) : 0;
+    }
+    if (wino42_ok(g)) {
+        const Wino42Dims d2 = wino42_dims(g);
+        return which == 0 ? (size_t)25 * d2.T * d2.K4 * sizeof(float) : which == 1 ? (size_t)25 * d2.T * g->Co * sizeof(float) : 0;
     }
     const WinoDims d = wino_dims(g);
     if (which == 0) return (size_t)16 * d.T * g->Ci * sizeof(float);
@@ -1908,6 +2118,9 @@ int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const f
     if (wino4_ok(g) && workspace && workspace_bytes >= wino4_fwd_ws(g) && aligned16(x) && aligned16(w) && aligned16(y) &&
         aligned16(workspace) && (!bias || aligned16(bias)))
         return wino4_fwd(g, x, w, bias, y, act, (float*)workspace, (hipStream_t)stream, u, wt ? wt->v : nullptr);
+    if (wino42_ok(g) && workspace && workspace_bytes >= wino42_fwd_ws(g) && aligned16(x) && aligned16(w) && aligned16(y) &&
+        aligned16(workspace) && (!bias || aligned16(bias)))
+        return wino42_fwd(g, x, w, bias, y, act, (float*)workspace, (hipStream_t)stream, u, wt ? wt->v : nullptr);
     const Geom gg = to_geom(g);
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)g->B * g->OH * g->OW;
@@ -1970,6 +2183,9 @@ int mg_conv_dgrad_w(const mg_conv_geom* g, const float* dy, const float* w, cons
     if (wino4_ok(g) && !bias && act == MG_ACT_NONE && workspace && workspace_bytes >= wino4_dgrad_ws(g) && aligned16(dy) &&
         aligned16(w) && aligned16(dx) && aligned16(workspace))
         return wino4_dgrad(g, dy, w, dx, (float*)workspace, (hipStream_t)stream, u, wt ? wt->md : nullptr);
+    if (wino42_ok(g) && !bias && act == MG_ACT_NONE && workspace && workspace_bytes >= wino42_dgrad_ws(g) && aligned16(dy) &&
+        aligned16(w) && aligned16(dx) && aligned16(workspace))
+        return wino42_dgrad(g, dy, w, dx, (float*)workspace, (hipStream_t)stream, u, wt ? wt->md : nullptr);
     const Geom gg = to_geom(g);
     hipStream_t st = (hipStream_t)stream;
     const int s = g->stride;
@@ -2046,6 +2262,7 @@ size_t mg_conv_wgrad_workspace(const mg_conv_geom* g) {
     if (mg_conv_rowdot_kq(g)) return mg_conv_rowdot_wgrad_workspace(g);
     if (wino_ok(g)) return wino_wgrad_ws(g);
     if (wino4_ok(g)) return wino4_wgrad_ws(g);
+    if (wino42_ok(g)) return wino42_wgrad_ws(g);
     if (smallc_wgrad_kind(g)) return smallc_wgrad_ws(g);
     const WgradPlan p = wgrad_plan(g);
     const size_t wg = p.splits > 1 ? (size_t)p.splits * g->Co * g->KH * g->KW * g->Ci * sizeof(float) : 0;
@@ -2099,6 +2316,20 @@ int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, floa
             const WinoWgradPlan p4 = wino4_wgrad_plan(g);
             float* cs = (float*)workspace + al256((size_t)25 * d.T * g->Ci) + al256((size_t)25 * d.T * g->Co) +
                         al256((size_t)25 * g->Co * g->Ci) + (p4.splits > 1 ? al256((size_t)p4.splits * 25 * g->Co * g->Ci) : 0);
+            return mg_colsum(dy, (long long)g->B * g->OH * g->OW, g->Co, dbias, accumulate, cs,
+                             mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co), stream);
+        }
+        return MG_OK;
+    }
+    if (wino42_ok(g) && aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace)) {
+        const int rc = wino42_wgrad(g, x, dy, dw, accumulate, (float*)workspace, (hipStream_t)stream, wt ? wt->v : nullptr,
+                                    wt ? wt->md : nullptr);
+        if (rc != MG_OK) return rc;
+        if (dbias) {
+            const Wino42Dims d = wino42_dims(g);
+            const WinoWgradPlan p4 = wino42_wgrad_plan(g);
+            float* cs = (float*)workspace + al256((size_t)25 * d.T * d.K4) + al256((size_t)25 * d.T * g->Co) +
+                        al256((size_t)25 * g->Co * d.K4) + (p4.splits > 1 ? al256((size_t)p4.splits * 25 * g->Co * d.K4) : 0);
             return mg_colsum(dy, (long long)g->B * g->OH * g->OW, g->Co, dbias, accumulate, cs,
                              mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co), stream);
         }

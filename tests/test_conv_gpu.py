@@ -40,6 +40,11 @@ CONV_CASES = [
     ("wino4_9x17_b3", 3, 128, 9, 17, 64, 4, 1, 2, False),
     ("wino4_1x3", 3, 32, 1, 3, 32, 4, 1, 2, False),
     ("d4x4_s1_even_direct", 2, 32, 6, 10, 64, 4, 1, 2, False),
+    # 4x4 stride-2 PatchGAN layers: Winograd F(4x4,2x2) over the space-to-depth view (csrc/wino42.h)
+    ("wino42_33x65", 2, 64, 33, 65, 128, 4, 2, 2, False),
+    ("wino42_even_16x24", 2, 32, 16, 24, 48, 4, 2, 2, False),
+    ("wino42_3x5", 3, 16, 3, 5, 16, 4, 2, 2, False),
+    ("wino42_2x2", 1, 16, 2, 2, 32, 4, 2, 2, False),
     # Ci <= 4: VALU data- / weight-gradient kernels (csrc/conv_smallc.h)
     ("smallc_4x4_s2_co80", 1, 3, 17, 33, 80, 4, 2, 2, False),
     ("smallc_4x4_s2_b5", 5, 3, 64, 128, 64, 4, 2, 2, False),
@@ -51,6 +56,12 @@ CONV_CASES = [
 
 def nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.fixture
+def small_wino42(monkeypatch):
+    """F(4x4,2x2) is only selected from ~1000 tiles up (where it is faster); the parity cases are small."""
+    monkeypatch.setenv("MG_WINO42_MIN_TILES", "0")
 
 
 def ref_conv(x, w, b, stride, pad, reflect):
@@ -65,7 +76,7 @@ def rel_err(got, want):
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-def test_conv_fwd_dgrad_wgrad(case):
+def test_conv_fwd_dgrad_wgrad(case, small_wino42):
     from mdctgan_amd import ops
     name, B, Ci, H, W, Co, k, s, p, reflect = case
     gen = torch.Generator().manual_seed(hash(name) % 1000)
@@ -80,6 +91,8 @@ def test_conv_fwd_dgrad_wgrad(case):
     assert (g.OH, g.OW) == tuple(y.shape[2:])
     xd, wd, bd = nhwc(x.detach()).float().to(DEV), nhwc(w.detach()).float().to(DEV), b.detach().float().to(DEV)
     gyd = nhwc(gy).float().to(DEV)
+    if name.startswith("wino42"):
+        assert "true, 1>" in ops.plan_name(1, g)      # the batched Winograd-domain GEMM, not the direct kernel
     yd = ops.conv_fwd(g, xd, wd, bd)
     assert rel_err(yd, nhwc(y.detach())) < 3e-5
     dxd = ops.conv_dgrad(g, gyd, wd)
@@ -168,6 +181,29 @@ def test_winograd_shared_weight_transform(reflect):
     assert torch.equal(dw0, dw1)
     g2 = ops.conv_geom(B, H, W, C, C, 3, 3, 2, 1, False)
     assert ops.wino_weights(g2, w) is None
+
+
+def test_winograd42_shared_images(small_wino42):
+    """F(4x4,2x2) over the space-to-depth view (stride-2 4x4 layers) behind the caller-held images."""
+    from mdctgan_amd import ops
+    gen = torch.Generator().manual_seed(7)
+    B, Ci, Co, H, W = 2, 32, 64, 17, 33
+    g = ops.conv_geom(B, H, W, Ci, Co, 4, 4, 2, 2, False)
+    assert (g.OH, g.OW) == (H // 2 + 1, W // 2 + 1)
+    x = torch.randn(B, H, W, Ci, generator=gen).to(DEV)
+    dy = torch.randn(B, g.OH, g.OW, Co, generator=gen).to(DEV)
+    w = (torch.randn(Co, 4, 4, Ci, generator=gen) * 0.05).to(DEV)
+    u = ops.wino_weights(g, w)
+    assert u is not None and u.numel() == 25 * Co * 4 * Ci
+    T = B * ((g.OH + 3) // 4) * ((g.OW + 3) // 4)
+    v, md = ops.wino_tile_buffers(g, x.device)
+    assert v.numel() == 25 * T * 4 * Ci and md.numel() == 25 * T * Co
+    assert torch.equal(ops.conv_fwd(g, x, w, None, ops.ACT_NONE, u, v), ops.conv_fwd(g, x, w))
+    assert torch.equal(ops.conv_dgrad(g, dy, w, u=u, md_out=md), ops.conv_dgrad(g, dy, w))
+    dw0, dw1 = torch.empty(Co, 4, 4, Ci, device=DEV), torch.empty(Co, 4, 4, Ci, device=DEV)
+    ops.conv_wgrad(g, x, dy, dw0, None)
+    ops.conv_wgrad(g, x, dy, dw1, None, v=v, md=md)
+    assert torch.equal(dw0, dw1)
 
 
 def test_winograd4_shared_images():
