@@ -167,7 +167,8 @@ __device__ __forceinline__ void mma_chunk(const float* Ap, const float* Bp, f32x
 // ================================================================================================
 // FWD
 // ================================================================================================
-template <int BM, int BN, bool VEC, int TAG = 0>   // TAG 1: the batched Winograd GEMM (distinct symbol for profilers)
+template <int BM, int BN, bool VEC, int TAG = 0>   // TAG bit 0: dense batched GEMM operands (1: Winograd F(2x2,3x3), 5: the
+                                                   // 25-position families of wino4.h / wino42.h -- distinct symbols for profilers); bit 1: f16 compute
 __global__ __launch_bounds__(256) void conv_fwd_kernel(Geom g, const float* __restrict__ x,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y,
@@ -279,9 +280,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geom g, const float* __re
     float4 va[NVA], vb[NVB];
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) st_kcontig<LDA, (TAG >= 2)>(As(buf), r0 + 64 * i, q, va[i]);
+        for (int i = 0; i < NVA; ++i) st_kcontig<LDA, ((TAG & 2) != 0)>(As(buf), r0 + 64 * i, q, va[i]);
 #pragma unroll
-        for (int i = 0; i < NVB; ++i) st_kcontig<LDB, (TAG >= 2)>(Bs(buf), r0 + 64 * i, q, vb[i]);
+        for (int i = 0; i < NVB; ++i) st_kcontig<LDB, ((TAG & 2) != 0)>(Bs(buf), r0 + 64 * i, q, vb[i]);
     };
     if (c_begin < nchunks) {
         load_a(c_begin, va);
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geom g, const float* __re
         const int cur = (c - c_begin) & 1;
         auto f0 = [&]() { if (c + 1 < nchunks) stash(cur ^ 1); };
         auto f1 = [&]() { if (c + 2 < nchunks) { load_a(c + 2, va); load_b(c + 2, vb); } };
-        if (TAG >= 2) mma_chunk_h<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
+        if ((TAG & 2) != 0) mma_chunk_h<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
         else mma_chunk<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
         __syncthreads();
     }
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geom g, const float* __re
                     if (part) part[(size_t)row * N + col] = acc[mi][ni][r];
                     else {
                         const float v = apply_act(acc[mi][ni][r] + bv, act);
-                        y[(size_t)row * N + col] = (TAG >= 2) ? round_h(v) : v;
+                        y[(size_t)row * N + col] = ((TAG & 2) != 0) ? round_h(v) : v;
                     }
                 }
             }
@@ -451,12 +452,12 @@ __global__ __launch_bounds__(256) void conv_fwd32_kernel(Geom g, const float* __
     auto stash = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
-            if (TAG >= 2) g32_st_h4(As(buf) + (r0 + 32 * i) * LDK2, q, va[i]);
+            if ((TAG & 2) != 0) g32_st_h4(As(buf) + (r0 + 32 * i) * LDK2, q, va[i]);
             else *reinterpret_cast<float4*>(As(buf) + (r0 + 32 * i) * LDK2 + 4 * q) = va[i];
         }
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
-            if (TAG >= 2) g32_st_h4(Bs(buf) + (r0 + 32 * i) * LDK2, q, vb[i]);
+            if ((TAG & 2) != 0) g32_st_h4(Bs(buf) + (r0 + 32 * i) * LDK2, q, vb[i]);
             else *reinterpret_cast<float4*>(Bs(buf) + (r0 + 32 * i) * LDK2 + 4 * q) = vb[i];
         }
     };
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(256) void conv_fwd32_kernel(Geom g, const float* __
         const int cur = (c - c_begin) & 1;
         auto f0 = [&]() { if (c + 1 < nchunks) stash(cur ^ 1); };
         auto f1 = [&]() { if (c + 2 < nchunks) { load_a(c + 2, va); load_b(c + 2, vb); } };
-        if (TAG >= 2) mma_chunk32_h<MB, NB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
+        if ((TAG & 2) != 0) mma_chunk32_h<MB, NB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
         else mma_chunk32<MB, NB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
         __syncthreads();
     }
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(256) void conv_fwd32_kernel(Geom g, const float* __
                     if (part) part[(size_t)row * N + col] = acc[mi][ni][r];
                     else {
                         const float v = apply_act(acc[mi][ni][r] + bv, act);
-                        y[(size_t)row * N + col] = (TAG >= 2) ? round_h(v) : v;
+                        y[(size_t)row * N + col] = ((TAG & 2) != 0) ? round_h(v) : v;
                     }
                 }
             }
@@ -715,9 +716,9 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
     float4 va[NVA], vb[NVB];
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) st_kcontig<LDA, (TAG >= 2)>(As(buf), r0 + 64 * i, q, va[i]);
+        for (int i = 0; i < NVA; ++i) st_kcontig<LDA, ((TAG & 2) != 0)>(As(buf), r0 + 64 * i, q, va[i]);
 #pragma unroll
-        for (int i = 0; i < NVB; ++i) st_rowcontig<LDB, (TAG >= 2)>(Bs(buf), bk_l + i * (1024 / BN), 4 * bn_q, vb[i]);
+        for (int i = 0; i < NVB; ++i) st_rowcontig<LDB, ((TAG & 2) != 0)>(Bs(buf), bk_l + i * (1024 / BN), 4 * bn_q, vb[i]);
     };
     if (c_begin < nchunks) {
         load_a(c_begin, va);
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
         const int cur = (c - c_begin) & 1;
         auto f0 = [&]() { if (c + 1 < nchunks) stash(cur ^ 1); };
         auto f1 = [&]() { if (c + 2 < nchunks) { load_a(c + 2, va); load_b(c + 2, vb); } };
-        if (TAG >= 2) mma_chunk_h<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
+        if ((TAG & 2) != 0) mma_chunk_h<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
         else mma_chunk<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
         __syncthreads();
     }
@@ -756,7 +757,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(Geom g, const float* __
                     } else {
                         const float bv = bias ? bias[col] : 0.0f;
                         const float v = apply_act(acc[mi][ni][r] + bv, act);
-                        dx[o + col] = (TAG >= 2) ? round_h(v) : v;
+                        dx[o + col] = ((TAG & 2) != 0) ? round_h(v) : v;
                     }
                 }
             }
@@ -911,9 +912,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
     float4 va[NVA], vb[NVB];
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) st_rowcontig<LDA, (TAG >= 2)>(As(buf), ak_l + i * (1024 / BM), 4 * a_q, va[i]);
+        for (int i = 0; i < NVA; ++i) st_rowcontig<LDA, ((TAG & 2) != 0)>(As(buf), ak_l + i * (1024 / BM), 4 * a_q, va[i]);
 #pragma unroll
-        for (int i = 0; i < NVB; ++i) st_rowcontig<LDB, (TAG >= 2)>(Bs(buf), bk_l + i * (1024 / BN), 4 * b_q, vb[i]);
+        for (int i = 0; i < NVB; ++i) st_rowcontig<LDB, ((TAG & 2) != 0)>(Bs(buf), bk_l + i * (1024 / BN), 4 * b_q, vb[i]);
     };
     if (c_begin < c_end) {
         load_a(c_begin, va);
@@ -929,7 +930,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
         const int cur = (c - c_begin) & 1;
         auto f0 = [&]() { if (c + 1 < c_end) stash(cur ^ 1); };
         auto f1 = [&]() { if (c + 2 < c_end) { load_a(c + 2, va); load_b(c + 2, vb); } };
-        if (TAG >= 2) mma_chunk_h<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
+        if ((TAG & 2) != 0) mma_chunk_h<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
         else mma_chunk<MB, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
         __syncthreads();
     }
@@ -1562,10 +1563,10 @@ int wino4_fwd(const mg_conv_geom* g, const float* x, const float* w, const float
         constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value;
         dim3 grid((unsigned)(((d.T + BM_ - 1) / BM_) * ((g->Co + BN_ - 1) / BN_)), tp.splits, 25);
         if (k32)
-            launch_fwd32<BM_, BN_, 1>(grid, st, gg, V, U, nullptr, Mx, MG_ACT_NONE, tp.splits == 1 ? (1 << 29) : tp.cps / 2,
+            launch_fwd32<BM_, BN_, 5>(grid, st, gg, V, U, nullptr, Mx, MG_ACT_NONE, tp.splits == 1 ? (1 << 29) : tp.cps / 2,
                                       pp, bt);
         else
-            hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, true, 1>), grid, dim3(256), 0, st, gg, (const float*)V,
+            hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, true, 5>), grid, dim3(256), 0, st, gg, (const float*)V,
                                (const float*)U, (const float*)nullptr, Mx, MG_ACT_NONE, tp.cps, pp, bt);
     });
     probe_end(st);
@@ -1603,7 +1604,7 @@ int wino4_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* d
     wino_launch_tiles(tp, [&](auto bm, auto bn) {
         constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value;
         dim3 grid((unsigned)(((T + BM_ - 1) / BM_) * ((g->Ci + BN_ - 1) / BN_)), tp.splits, 25);
-        hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, true, 1>), grid, dim3(256), 0, st, gg, (const float*)Md,
+        hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, true, 5>), grid, dim3(256), 0, st, gg, (const float*)Md,
                            (const float*)U, (const float*)nullptr, dV, MG_ACT_NONE, tp.cps, pp, bt);
     });
     probe_end(st);
@@ -1640,10 +1641,10 @@ int wino4_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* d
     dim3 grid((unsigned)p.tiles, 25, p.splits);
     probe_begin(st);
     if (p.big)
-        hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, true, true, 1>), grid, dim3(256), 0, st, gg, (const float*)V,
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, true, true, 5>), grid, dim3(256), 0, st, gg, (const float*)V,
                            (const float*)Md, target, p.cps, 0, bt);
     else
-        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, true, true, 1>), grid, dim3(256), 0, st, gg, (const float*)V,
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, true, true, 5>), grid, dim3(256), 0, st, gg, (const float*)V,
                            (const float*)Md, target, p.cps, 0, bt);
     probe_end(st);
     if (p.splits > 1) {
@@ -1666,12 +1667,13 @@ bool wino42_ok(const mg_conv_geom* g) {
     if (off || prec_h(g) || g->KH != 4 || g->KW != 4 || g->stride != 2 || g->pad != 2 || g->reflect || g->Ci % 16 ||
         g->Co % 16 || g->Ci < min_c || g->Co < min_c || g->H < 2 || g->W < 2)
         return false;
-    // the transforms move 25/16 of the phase-channel data per pass: measured faster than the direct kernels from ~1000
-    // tiles (batch 16 at 33x65: 136 -> 92 us forward), slower below (720 tiles: 40 -> 60 us).  Read per call so the
-    // parity tests can exercise small shapes.
-    const char* mt = getenv("MG_WINO42_MIN_TILES");
-    const long long min_tiles = mt ? atoll(mt) : 1000;
-    return (long long)g->B * ((g->OH + 3) / 4) * ((g->OW + 3) / 4) >= min_tiles;
+    // the transforms move 25/16 of the phase-channel data per pass: measured faster than the direct kernels from
+    // T * 4Ci * Co ~ 4e7 up (batch 16: 64->128 at 33x65 out 124 -> 91 us, 128->256 at 17x33 out 136 -> 97 us forward),
+    // slower below (64->128 at 17x33 out: 39 -> 48 us).  Read per call so the parity tests can exercise small shapes.
+    const char* mw = getenv("MG_WINO42_MIN_WORK");
+    const double min_work = mw ? atof(mw) : 4e7;
+    const double T = (double)g->B * ((g->OH + 3) / 4) * ((g->OW + 3) / 4);
+    return T * 4.0 * g->Ci * g->Co >= min_work;
 }
 struct Wino42Dims { long long T; int TH, TW, K4; };
 Wino42Dims wino42_dims(const mg_conv_geom* g) {
@@ -1739,10 +1741,10 @@ int wino42_fwd(const mg_conv_geom* g, const float* x, const float* w, const floa
         constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value;
         dim3 grid((unsigned)(((d.T + BM_ - 1) / BM_) * ((g->Co + BN_ - 1) / BN_)), tp.splits, 25);
         if (k32)
-            launch_fwd32<BM_, BN_, 1>(grid, st, gg, V, U, nullptr, Mx, MG_ACT_NONE, tp.splits == 1 ? (1 << 29) : tp.cps / 2,
+            launch_fwd32<BM_, BN_, 5>(grid, st, gg, V, U, nullptr, Mx, MG_ACT_NONE, tp.splits == 1 ? (1 << 29) : tp.cps / 2,
                                       pp, bt);
         else
-            hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, true, 1>), grid, dim3(256), 0, st, gg, (const float*)V,
+            hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, true, 5>), grid, dim3(256), 0, st, gg, (const float*)V,
                                (const float*)U, (const float*)nullptr, Mx, MG_ACT_NONE, tp.cps, pp, bt);
     });
     probe_end(st);
@@ -1780,7 +1782,7 @@ int wino42_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* 
     wino_launch_tiles(tp, [&](auto bm, auto bn) {
         constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value;
         dim3 grid((unsigned)(((T + BM_ - 1) / BM_) * ((d.K4 + BN_ - 1) / BN_)), tp.splits, 25);
-        hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, true, 1>), grid, dim3(256), 0, st, gg, (const float*)Md,
+        hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, true, 5>), grid, dim3(256), 0, st, gg, (const float*)Md,
                            (const float*)U, (const float*)nullptr, dV, MG_ACT_NONE, tp.cps, pp, bt);
     });
     probe_end(st);
@@ -1817,10 +1819,10 @@ int wino42_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* 
     dim3 grid((unsigned)p.tiles, 25, p.splits);
     probe_begin(st);
     if (p.big)
-        hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, true, true, 1>), grid, dim3(256), 0, st, gg, (const float*)V,
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, true, true, 5>), grid, dim3(256), 0, st, gg, (const float*)V,
                            (const float*)Md, target, p.cps, 0, bt);
     else
-        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, true, true, 1>), grid, dim3(256), 0, st, gg, (const float*)V,
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, true, true, 5>), grid, dim3(256), 0, st, gg, (const float*)V,
                            (const float*)Md, target, p.cps, 0, bt);
     probe_end(st);
     if (p.splits > 1) {
@@ -1968,27 +1970,27 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
         const Wino4Dims d = wino4_dims(g);
         if (pass == 0) {
             const TilePlan tp = gemm_plan(d.T, g->Co, g->Ci / BK, 25, true, 0);
-            if (use_k32(tp, g->Ci)) snprintf(out, out_len, "conv_fwd32_kernel<%d, %d, 1>", tp.bm, tp.bn);
-            else snprintf(out, out_len, "conv_fwd_kernel<%d, %d, true, 1>", tp.bm, tp.bn);
+            if (use_k32(tp, g->Ci)) snprintf(out, out_len, "conv_fwd32_kernel<%d, %d, 5>", tp.bm, tp.bn);
+            else snprintf(out, out_len, "conv_fwd_kernel<%d, %d, true, 5>", tp.bm, tp.bn);
         } else if (pass == 1) {
             const TilePlan tp = gemm_plan(d.T, g->Ci, g->Co / BK, 25, true, 1);
-            snprintf(out, out_len, "conv_dgrad_kernel<%d, %d, true, true, 1>", tp.bm, tp.bn);
+            snprintf(out, out_len, "conv_dgrad_kernel<%d, %d, true, true, 5>", tp.bm, tp.bn);
         } else {
             const WinoWgradPlan p = wino4_wgrad_plan(g);
-            snprintf(out, out_len, "conv_wgrad_kernel<%d, %d, true, true, 1>", p.big ? 128 : 64, p.big ? 128 : 64);
+            snprintf(out, out_len, "conv_wgrad_kernel<%d, %d, true, true, 5>", p.big ? 128 : 64, p.big ? 128 : 64);
         }
     } else if (wino42_ok(g) && !kq) {
         const Wino42Dims d = wino42_dims(g);
         if (pass == 0) {
             const TilePlan tp = gemm_plan(d.T, g->Co, d.K4 / BK, 25, true, 0);
-            if (use_k32(tp, d.K4)) snprintf(out, out_len, "conv_fwd32_kernel<%d, %d, 1>", tp.bm, tp.bn);
-            else snprintf(out, out_len, "conv_fwd_kernel<%d, %d, true, 1>", tp.bm, tp.bn);
+            if (use_k32(tp, d.K4)) snprintf(out, out_len, "conv_fwd32_kernel<%d, %d, 5>", tp.bm, tp.bn);
+            else snprintf(out, out_len, "conv_fwd_kernel<%d, %d, true, 5>", tp.bm, tp.bn);
         } else if (pass == 1) {
             const TilePlan tp = gemm_plan(d.T, d.K4, g->Co / BK, 25, true, 1);
-            snprintf(out, out_len, "conv_dgrad_kernel<%d, %d, true, true, 1>", tp.bm, tp.bn);
+            snprintf(out, out_len, "conv_dgrad_kernel<%d, %d, true, true, 5>", tp.bm, tp.bn);
         } else {
             const WinoWgradPlan p = wino42_wgrad_plan(g);
-            snprintf(out, out_len, "conv_wgrad_kernel<%d, %d, true, true, 1>", p.big ? 128 : 64, p.big ? 128 : 64);
+            snprintf(out, out_len, "conv_wgrad_kernel<%d, %d, true, true, 5>", p.big ? 128 : 64, p.big ? 128 : 64);
         }
     } else if (pass == 1 && smallc_dgrad_ok(g)) {
         snprintf(out, out_len, "conv_smallc_dgrad_kernel<%d>", g->Ci);

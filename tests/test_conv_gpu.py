@@ -60,8 +60,8 @@ def nhwc(t):
 
 @pytest.fixture
 def small_wino42(monkeypatch):
-    """F(4x4,2x2) is only selected from ~1000 tiles up (where it is faster); the parity cases are small."""
-    monkeypatch.setenv("MG_WINO42_MIN_TILES", "0")
+    """F(4x4,2x2) is only selected for large problems (where it is faster); the parity cases are small."""
+    monkeypatch.setenv("MG_WINO42_MIN_WORK", "0")
 
 
 def ref_conv(x, w, b, stride, pad, reflect):
@@ -92,7 +92,7 @@ def test_conv_fwd_dgrad_wgrad(case, small_wino42):
     xd, wd, bd = nhwc(x.detach()).float().to(DEV), nhwc(w.detach()).float().to(DEV), b.detach().float().to(DEV)
     gyd = nhwc(gy).float().to(DEV)
     if name.startswith("wino42"):
-        assert "true, 1>" in ops.plan_name(1, g)      # the batched Winograd-domain GEMM, not the direct kernel
+        assert "true, 5>" in ops.plan_name(1, g)      # the batched Winograd-domain GEMM, not the direct kernel
     yd = ops.conv_fwd(g, xd, wd, bd)
     assert rel_err(yd, nhwc(y.detach())) < 3e-5
     dxd = ops.conv_dgrad(g, gyd, wd)
@@ -228,4 +228,4 @@ def test_winograd4_shared_images():
     ops.conv_wgrad(g, x, dy, dw0, None)
     ops.conv_wgrad(g, x, dy, dw1, None, v=v, md=md)
     assert torch.equal(dw0, dw1)
-    assert "true, 1>" in ops.plan_name(1, g)        # the batched Winograd-domain GEMM
+    assert "true, 5>" in ops.plan_name(1, g)        # the batched 25-position Winograd-domain GEMM
