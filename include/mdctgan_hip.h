@@ -136,14 +136,18 @@ size_t mg_conv_fwd_workspace(const mg_conv_geom* g);
 int mg_conv_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
                   void* workspace, size_t workspace_bytes, void* stream);
 size_t mg_conv_dgrad_workspace(const mg_conv_geom* g);
-/* 3x3 stride-1 pad-1 layers with channel counts that are multiples of 16 run as Winograd F(2x2,3x3): 16 batched
- * GEMMs over transformed operands.  A training step runs forward, data gradient and weight gradient of a layer with the
+/* Layers with channel counts that are multiples of 16 run as batched GEMMs over Winograd-transformed operands:
+ *   3x3 stride-1 pad-1 (ResnetBlock)            F(2x2,3x3), P = 16 positions, K = Ci,   T = B*(H/2)*(W/2) tiles (H, W even)
+ *   4x4 stride-1 pad-2 (PatchGAN, H and W odd)  F(2x2,4x4), P = 25,           K = Ci,   T = B*((H+1)/2)*((W+1)/2)
+ *   4x4 stride-2 pad-2 (PatchGAN, large only)   F(4x4,2x2) over the space-to-depth view, P = 25, K = 4*Ci,
+ *                                               T = B*ceil(OH/4)*ceil(OW/4)
+ * A training step runs forward, data gradient and weight gradient of a layer with the
  * same weights / activations / output gradient, so the caller may hold the transformed images and hand them to the _w
  * entry points (every pointer optional; NULL = transform internally, which is what the plain entry points do):
- *   u   U = G w G^T            16*Co*Ci floats   mg_conv_wino_prepare() fills it; read by fwd and dgrad
- *   v   V = B^T x B            16*T*Ci floats    WRITTEN by mg_conv_fwd_w, read by mg_conv_wgrad_w
- *   md  Md = A dy A^T          16*T*Co floats    WRITTEN by mg_conv_dgrad_w, read by mg_conv_wgrad_w
- * (T = B*H/2*W/2 tiles).  Sizes: mg_conv_wino_weights_bytes() and mg_conv_wino_tiles_bytes(g, 0 = v | 1 = md); 0 means
+ *   u   U = G w G^T            P*Co*K floats   mg_conv_wino_prepare() fills it; read by fwd and dgrad
+ *   v   V = B^T x B            P*T*K floats    WRITTEN by mg_conv_fwd_w, read by mg_conv_wgrad_w
+ *   md  Md = A dy A^T          P*T*Co floats   WRITTEN by mg_conv_dgrad_w, read by mg_conv_wgrad_w
+ * Sizes (never computed by the caller): mg_conv_wino_weights_bytes() and mg_conv_wino_tiles_bytes(g, 0 = v | 1 = md); 0 means
  * "this geometry / configuration does not use that image" and the pointer must stay NULL.  Every image must come
  * from the tensors passed in the same step. */
 typedef struct {
@@ -168,7 +172,7 @@ int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, floa
 /* Name of the kernel instance a pass (0 fwd, 1 dgrad, 2 wgrad) launches for this geometry -- the symbol
  * rocprofv3 reports -- so bench.py can attribute event-timed launches per kernel.  out: host buffer >= 64 B. */
 int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len);
-/* FLOPs issued by that kernel for this geometry (direct: 2*MACs; Winograd F(2x2,3x3) layers: the 16 batched GEMMs). */
+/* FLOPs issued by that kernel for this geometry (direct: 2*MACs; Winograd layers: the P batched GEMMs, 2*P*T*Co*K). */
 double mg_conv_plan_flops(int pass, const mg_conv_geom* g);
 /* One-shot timing probe for bench.py: the next mg_conv_{fwd,dgrad,wgrad} call records hipEvent e0 / e1 on its launch
  * stream immediately around its main GEMM kernel (not around transforms / split-K epilogues), then disarms. */
