@@ -1116,6 +1116,10 @@ TilePlan gemm_plan(long long M, int N, int chunks, int classes, bool can_split, 
         {1, 34320, 64, 128, 4, 64, 64, 1, 0},
         {1, 2448, 128, 256, 4, 64, 64, 4, 0},
         {1, 8976, 64, 128, 4, 64, 64, 2, 0},
+        // batch-64 inference (BASELINE configs[4]): forward only
+        {0, 2048, 1024, 64, 16, 128, 128, 1, 1},   // F(2x2,3x3) forward GEMMs, 2048 tiles
+        {0, 8192, 1024, 288, 1, 128, 128, 1, 1},   // 512->1024 stride-2 forward
+        {0, 32768, 512, 144, 1, 128, 128, 1, 1},   // 256->512
         {0, 2448, 512, 16, 25, 64, 64, 1, 1},      // F(2x2,4x4) forward GEMMs of the 256->512 discriminator layer, batch 16
         {0, 2448, 256, 32, 25, 64, 64, 1, 1},      // F(4x4,2x2) GEMMs of the stride-2 discriminator layers, batch 16 / 8
         {0, 2448, 128, 16, 25, 128, 128, 1, 1},
@@ -1166,7 +1170,8 @@ TilePlan gemm_plan(long long M, int N, int chunks, int classes, bool can_split, 
             double t = (double)((wgs + 255) / 256) * work;
             if (wgs < 2 * 256) t *= 1.25;
             if (spl > 1) t += (double)(spl + 1) * (double)M * N * classes * 4.0 / 4e12 / 29e-9 * 256.0 / 256.0;
-            if (t < best) { best = t; out = {c.bm, c.bn, spl, cps, false}; }
+            // deep reductions measured faster on the 32-deep forward kernel wherever it was tried (>= 144 chunks)
+            if (t < best) { best = t; out = {c.bm, c.bn, spl, cps, pass == 0 && chunks >= 128}; }
         }
     }
     return out;

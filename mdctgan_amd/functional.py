@@ -95,6 +95,33 @@ def _notify(p):
 
 
 # ------------------------------------------------------------------------------------------------
+# transformed-weight cache for inference
+# ------------------------------------------------------------------------------------------------
+# Under torch.no_grad() the weights are frozen, so a Winograd layer's U = G w G^T is computed once and kept on the
+# parameter instead of once per call (18 x 22 us per batch on configs[4]).  The kernels update parameters through raw
+# pointers, which torch's version counter does not see: everything that writes weights that way (FusedAdam.step, a
+# replay of the captured training step) bumps WEIGHT_EPOCH, and a cached image is only valid for the (version, epoch,
+# storage) it was made from.
+WEIGHT_EPOCH = [0]
+
+
+def bump_weight_epoch():
+    WEIGHT_EPOCH[0] += 1
+
+
+def _cached_wino_weights(g, weight):
+    w = weight.detach()
+    key = (weight._version, WEIGHT_EPOCH[0], w.data_ptr(), g.Ci, g.Co, g.KH, g.stride, g.precision,
+           ops.wino_weights_bytes(g))
+    hit = getattr(weight, "_mg_u_cache", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    u = ops.wino_weights(g, w)
+    weight._mg_u_cache = (key, u)
+    return u
+
+
+# ------------------------------------------------------------------------------------------------
 # one discriminator forward, two backward passes
 # ------------------------------------------------------------------------------------------------
 # train.py:160-202 evaluates D three times per iteration: D(fake.detach()) and D(real) for the D loss, D(fake) for the
@@ -155,7 +182,12 @@ class _ConvFn(torch.autograd.Function):
             assert Ci == x.shape[1]
             g = ops.conv_geom(B, H, W, Ci, Co, KH, KW, stride, pad, reflect, amp.current_precision())
             # Winograd layers: transform the weights once, reuse the image for the data gradient of this step
-            u = ops.wino_weights(g, w) if ctx.needs_input_grad[0] else None
+            if ctx.needs_input_grad[0]:
+                u = ops.wino_weights(g, w)
+            elif not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing():
+                u = _cached_wino_weights(g, weight)        # inference: once per weight version
+            else:
+                u = None
             # ... and keep B^T x B for the weight gradient (A dy A^T is shared between dgrad and wgrad in backward)
             v = None
             if u is not None and weight_grad and weight.requires_grad:

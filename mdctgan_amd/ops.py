@@ -41,6 +41,11 @@ def conv_flops(g: ConvGeom) -> float:
     return 2.0 * g.B * g.OH * g.OW * g.Co * g.KH * g.KW * g.Ci
 
 
+def wino_weights_bytes(g: ConvGeom) -> int:
+    """Size of the transformed-weight image of this geometry (0: not a Winograd layer in the current configuration)."""
+    return int(_lib.load().mg_conv_wino_weights_bytes(g))
+
+
 def wino_weights(g: ConvGeom, w):
     """Transformed weights U = G w G^T of a Winograd layer (None when the geometry is not one): lets the forward
     and the data-gradient pass of one step share a single weight transform."""

@@ -90,6 +90,8 @@ class FusedAdam(torch.optim.Optimizer):
             self._build()
         if self.pre_step_hook is not None:
             self.pre_step_hook()
+        from .functional import bump_weight_epoch
+        bump_weight_epoch()                   # parameters change through raw pointers: invalidate cached weight images
         self._step += 1
         g = self.param_groups[0]
         lr, (b1, b2), eps = float(g["lr"]), g["betas"], g["eps"]

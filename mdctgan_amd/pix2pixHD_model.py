@@ -410,6 +410,7 @@ class Pix2PixHDModel(BaseModel):
             if hr is not None:
                 static_hr.copy_(hr, non_blocking=True)
             graph.replay()
+            Fh.bump_weight_epoch()            # the replay ran both Adam steps
             return losses
         run.graph = graph
         return run

@@ -283,6 +283,28 @@ def test_bottleneck_transformer_stack(cfg):
     assert np.abs(ye.cpu().numpy() - want.numpy()).max() <= 2e-4 * np.abs(want.numpy()).max()
 
 
+def test_inference_weight_image_cache_follows_updates(golden):
+    """Under no_grad the Winograd layers keep their transformed weights between calls; an optimiser step (raw-pointer
+    update, invisible to torch's version counter) or a state-dict load must invalidate them."""
+    g = golden("g6_step_global")
+    lr, hr = torch.from_numpy(g["lr"]).to(DEV), torch.from_numpy(g["hr"]).to(DEV)
+    model = make_model()
+    a1 = model.inference(lr)[0].clone()
+    a2 = model.inference(lr)[0].clone()
+    assert torch.equal(a1, a2)
+    cached = [p for p in model.netG.parameters() if getattr(p, "_mg_u_cache", None) is not None]
+    assert cached, "no Winograd layer took the cached path"
+    model.optimize_parameters(lr, hr)
+    b1 = model.inference(lr)[0].clone()
+    assert not torch.equal(a1, b1)
+    fresh = make_model()
+    fresh.netG.load_state_dict(model.netG.state_dict())
+    assert torch.equal(fresh.inference(lr)[0], b1)
+    # ... and loading other weights into the same modules drops the images too
+    model.netG.load_state_dict(make_model().netG.state_dict())
+    assert torch.equal(model.inference(lr)[0], a1)
+
+
 @pytest.mark.parametrize("num_D", [2, 3])
 def test_shared_discriminator_pass_matches_separate_passes(num_D):
     """optimize_parameters() runs ONE discriminator forward over [fake, real] and backpropagates the G loss (fake half,
