@@ -1849,11 +1849,11 @@ bool smallc_enabled() {
     return !off;
 }
 bool smallc_dgrad_ok(const mg_conv_geom* g) {
-    return smallc_enabled() && !prec_h(g) && g->Ci >= 1 && g->Ci <= 4 && !g->reflect && g->Co % 4 == 0 && g->Co >= 16;
+    return smallc_enabled() && g->Ci >= 1 && g->Ci <= 4 && !g->reflect && g->Co % 4 == 0 && g->Co >= 16;
 }
 // 0: not eligible; otherwise the template instance id
 int smallc_wgrad_kind(const mg_conv_geom* g) {
-    if (!smallc_enabled() || prec_h(g) || g->Co < 16 || ((g->stride * g->Ci) & 1)) return 0;
+    if (!smallc_enabled() || g->Co < 16 || ((g->stride * g->Ci) & 1)) return 0;
     if ((size_t)g->KH * (((g->OW - 1) * g->stride + g->KW) * g->Ci + 4) * sizeof(float) > 60000) return 0;
     if ((long long)g->B * g->OH > 65535LL * 32) return 0;
     if (g->KH == 4 && g->KW == 4 && g->Ci == 3) return 1;
@@ -1888,9 +1888,9 @@ int smallc_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* 
     const Geom gg = to_geom(g);
     const dim3 grid((unsigned)p.wgs, (unsigned)((g->Co + 63) / 64));
     switch (smallc_wgrad_kind(g)) {
-    case 1: hipLaunchKernelGGL((conv_smallc_wgrad_kernel<4, 4, 3>), grid, dim3(256), p.lds, st, gg, x, dy, ws, p.rowlen); break;
-    case 2: hipLaunchKernelGGL((conv_smallc_wgrad_kernel<7, 7, 2>), grid, dim3(448), p.lds, st, gg, x, dy, ws, p.rowlen); break;
-    case 3: hipLaunchKernelGGL((conv_smallc_wgrad_kernel<3, 3, 4>), grid, dim3(192), p.lds, st, gg, x, dy, ws, p.rowlen); break;
+    case 1: hipLaunchKernelGGL((conv_smallc_wgrad_kernel<4, 4, 3>), grid, dim3(256), p.lds, st, gg, x, dy, ws, p.rowlen, (int)prec_h(g)); break;
+    case 2: hipLaunchKernelGGL((conv_smallc_wgrad_kernel<7, 7, 2>), grid, dim3(448), p.lds, st, gg, x, dy, ws, p.rowlen, (int)prec_h(g)); break;
+    case 3: hipLaunchKernelGGL((conv_smallc_wgrad_kernel<3, 3, 4>), grid, dim3(192), p.lds, st, gg, x, dy, ws, p.rowlen, (int)prec_h(g)); break;
     default: return MG_ERR_UNSUPPORTED;
     }
     MG_CHECK_LAUNCH();
@@ -1903,10 +1903,10 @@ int smallc_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* 
     const long long Mc = (long long)g->B * ((g->H + s - 1) / s) * ((g->W + s - 1) / s);
     const dim3 grid((unsigned)((Mc + 255) / 256), (unsigned)(s * s));
     switch (g->Ci) {
-    case 1: hipLaunchKernelGGL(conv_smallc_dgrad_kernel<1>, grid, dim3(256), 0, st, gg, dy, w, dx); break;
-    case 2: hipLaunchKernelGGL(conv_smallc_dgrad_kernel<2>, grid, dim3(256), 0, st, gg, dy, w, dx); break;
-    case 3: hipLaunchKernelGGL(conv_smallc_dgrad_kernel<3>, grid, dim3(256), 0, st, gg, dy, w, dx); break;
-    default: hipLaunchKernelGGL(conv_smallc_dgrad_kernel<4>, grid, dim3(256), 0, st, gg, dy, w, dx); break;
+    case 1: hipLaunchKernelGGL(conv_smallc_dgrad_kernel<1>, grid, dim3(256), 0, st, gg, dy, w, dx, (int)prec_h(g)); break;
+    case 2: hipLaunchKernelGGL(conv_smallc_dgrad_kernel<2>, grid, dim3(256), 0, st, gg, dy, w, dx, (int)prec_h(g)); break;
+    case 3: hipLaunchKernelGGL(conv_smallc_dgrad_kernel<3>, grid, dim3(256), 0, st, gg, dy, w, dx, (int)prec_h(g)); break;
+    default: hipLaunchKernelGGL(conv_smallc_dgrad_kernel<4>, grid, dim3(256), 0, st, gg, dy, w, dx, (int)prec_h(g)); break;
     }
     MG_CHECK_LAUNCH();
     return MG_OK;

@@ -15,7 +15,9 @@ namespace {
 // out of L1 / L2).
 template <int CI>
 __global__ __launch_bounds__(256) void conv_smallc_dgrad_kernel(Geom g, const float* __restrict__ dy,
-                                                                const float* __restrict__ w, float* __restrict__ dx) {
+                                                                const float* __restrict__ w, float* __restrict__ dx,
+                                                                int hp) {
+    // hp (MG_PRECISION_F16): operands rounded to float16 before the multiply, float32 accumulation, float16-valued output
     const int s = g.s, cls = blockIdx.y, py = cls / s, px = cls - py * s;
     const int Hc = (g.H - py + s - 1) / s, Wc = (g.W - px + s - 1) / s;
     const int Mc = g.B * Hc * Wc;
@@ -42,18 +44,26 @@ __global__ __launch_bounds__(256) void conv_smallc_dgrad_kernel(Geom g, const fl
             for (int co = 0; co < g.Co; co += 4) {
                 float4 d = ld4(dp + co);
                 if (!ok) d = zero4();
-                const float dv[4] = {d.x, d.y, d.z, d.w};
+                float dv[4] = {d.x, d.y, d.z, d.w};
+                if (hp) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dv[j] = round_h(dv[j]);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int c = 0; c < CI; ++c) acc[c] = fmaf(dv[j], wp[(size_t)(co + j) * wstride + c], acc[c]);
+                    for (int c = 0; c < CI; ++c) {
+                        float wv = wp[(size_t)(co + j) * wstride + c];
+                        if (hp) wv = round_h(wv);
+                        acc[c] = fmaf(dv[j], wv, acc[c]);
+                    }
             }
         }
     }
     if (live) {
         float* o = dx + (size_t)((b * g.H + iy) * g.W + ix) * CI;
 #pragma unroll
-        for (int c = 0; c < CI; ++c) o[c] = acc[c];
+        for (int c = 0; c < CI; ++c) o[c] = hp ? round_h(acc[c]) : acc[c];
     }
 }
 
@@ -66,7 +76,7 @@ __global__ __launch_bounds__(256) void conv_smallc_dgrad_kernel(Geom g, const fl
 template <int KH, int KW, int CI>
 __global__ __launch_bounds__(KH * 64) void conv_smallc_wgrad_kernel(Geom g, const float* __restrict__ x,
                                                                     const float* __restrict__ dy,
-                                                                    float* __restrict__ part, int rowlen) {
+                                                                    float* __restrict__ part, int rowlen, int hp) {
     constexpr int KWC = KW * CI, U = 8;
     static_assert(KWC % 2 == 0, "patch segments are read as float2");
     extern __shared__ __attribute__((aligned(16))) float xs_smallc[];
@@ -86,7 +96,8 @@ __global__ __launch_bounds__(KH * 64) void conv_smallc_wgrad_kernel(Geom g, cons
             int ix = jx - g.p;
             bool ok = rok && jx < ncols;
             if (g.reflect) ix = reflect_idx(ix, g.W); else ok = ok && ix >= 0 && ix < g.W;
-            xs_smallc[r * rowlen + e] = ok ? xr[(size_t)ix * CI + c] : 0.0f;
+            const float xv = ok ? xr[(size_t)ix * CI + c] : 0.0f;
+            xs_smallc[r * rowlen + e] = hp ? round_h(xv) : xv;
         }
     }
     __syncthreads();
@@ -100,6 +111,10 @@ __global__ __launch_bounds__(KH * 64) void conv_smallc_wgrad_kernel(Geom g, cons
         float d[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) d[j] = (co_ok && ox + j < g.OW) ? dyp[(size_t)(ox + j) * g.Co] : 0.0f;
+        if (hp) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) d[j] = round_h(d[j]);
+        }
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int oxx = min(ox + j, g.OW - 1);      // past-the-end pixels carry d == 0

@@ -29,6 +29,8 @@ CASES = [
     ("bottleneck_wino_f16", 8, 256, 8, 16, 256, 3, 1, 1, True),      # wide + 256 tiles: Winograd with f16 GEMMs
     ("wino_f16_zero_pad", 4, 256, 16, 16, 256, 3, 1, 1, False),
     ("conv1x1", 2, 64, 4, 8, 48, 1, 1, 0, False),
+    ("smallc_4x4_s2", 2, 3, 33, 65, 64, 4, 2, 2, False),         # csrc/conv_smallc.h with float16-rounded operands
+    ("smallc_7x7_reflect", 2, 2, 20, 36, 32, 7, 1, 3, True),
 ]
 
 
