@@ -112,15 +112,26 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
 template <int MODE>
 __global__ void norm_finalize_kernel(const double* __restrict__ part, int B, int S, int C, int HW, float eps,
                                      float* __restrict__ o1, float* __restrict__ o2) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * C) return;
-    const int b = i / C, c = i - b * C;
+    // eight lanes per (b, c): the S partials are a serial chain of dependent-latency loads otherwise (9 us for 512
+    // outputs); fixed summation order -> deterministic
+    constexpr int G = 8;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = t / G, sl = t % G;
+    const bool live = i < B * C;
+    const int b = live ? i / C : 0, c = live ? i - b * C : 0;
     double s1 = 0.0, s2 = 0.0;
-    for (int s = 0; s < S; ++s) {
-        const size_t o = (((size_t)b * S + s) * C + c) * 2;
-        s1 += part[o];
-        s2 += part[o + 1];
+    if (live)
+        for (int s = sl; s < S; s += G) {
+            const size_t o = (((size_t)b * S + s) * C + c) * 2;
+            s1 += part[o];
+            s2 += part[o + 1];
+        }
+#pragma unroll
+    for (int d = 1; d < G; d <<= 1) {
+        s1 += __shfl_xor(s1, d, G);
+        s2 += __shfl_xor(s2, d, G);
     }
+    if (!live || sl != 0) return;
     if (MODE == 0) {
         const double mu = s1 / HW;
         double var = s2 / HW - mu * mu;
@@ -620,7 +631,7 @@ int mg_instnorm_fwd(const float* x, int B, int HW, int C, float eps, int act, co
     else
         hipLaunchKernelGGL((norm_partial_kernel<0, false>), dim3(p.cblocks, B, p.splits), dim3(256), 0, st, x, nullptr,
                            nullptr, nullptr, HW, C, p.rows_per_split, act, part);
-    hipLaunchKernelGGL(norm_finalize_kernel<0>, dim3((B * C + 255) / 256), dim3(256), 0, st, part, B, p.splits, C, HW,
+    hipLaunchKernelGGL(norm_finalize_kernel<0>, dim3((B * C * 8 + 255) / 256), dim3(256), 0, st, part, B, p.splits, C, HW,
                        eps, mean, rstd);
     const size_t total = (size_t)B * HW * C;
     const bool vec = (C % 4 == 0) && al16(x) && al16(y) && (!residual || al16(residual));
@@ -657,7 +668,7 @@ int mg_instnorm_bwd(const float* dy, const float* x, const float* mean, const fl
     else
         hipLaunchKernelGGL((norm_partial_kernel<1, false>), dim3(p.cblocks, B, p.splits), dim3(256), 0, st, x, dy, mean,
                            rstd, HW, C, p.rows_per_split, act, part);
-    hipLaunchKernelGGL(norm_finalize_kernel<1>, dim3((B * C + 255) / 256), dim3(256), 0, st, part, B, p.splits, C, HW,
+    hipLaunchKernelGGL(norm_finalize_kernel<1>, dim3((B * C * 8 + 255) / 256), dim3(256), 0, st, part, B, p.splits, C, HW,
                        0.0f, m1, m2);
     const size_t total = (size_t)B * HW * C;
     const bool vec = (C % 4 == 0) && al16(x) && al16(dy) && al16(dx);
