@@ -1121,10 +1121,14 @@ TilePlan gemm_plan(long long M, int N, int chunks, int classes, bool can_split, 
         {0, 8192, 1024, 288, 1, 128, 128, 1, 1},   // 512->1024 stride-2 forward
         {0, 32768, 512, 144, 1, 128, 128, 1, 1},   // 256->512
         {0, 2448, 512, 16, 25, 64, 64, 1, 1},      // F(2x2,4x4) forward GEMMs of the 256->512 discriminator layer, batch 16
-        {0, 2448, 256, 32, 25, 64, 64, 1, 1},      // F(4x4,2x2) GEMMs of the stride-2 discriminator layers, batch 16 / 8
+        // F(4x4,2x2) GEMMs of the stride-2 discriminator layers (K = 4 Ci): 128->256 at 17x33 out (720 tiles at batch 16,
+        // 360 at batch 8), 64->128 at 33x65 out (2448 / 1224 tiles)
+        {0, 720, 256, 32, 25, 64, 64, 1, 1},
         {0, 2448, 128, 16, 25, 128, 128, 1, 1},
-        {1, 2448, 512, 16, 25, 64, 64, 1, 0},
-        {1, 1224, 512, 16, 25, 64, 64, 1, 0},
+        {1, 720, 512, 16, 25, 64, 64, 1, 0},
+        {1, 360, 512, 16, 25, 64, 64, 1, 0},
+        {1, 2448, 256, 8, 25, 64, 64, 1, 0},
+        {1, 1224, 256, 8, 25, 128, 128, 1, 0},
         // configs[2] (LocalEnhancer) Winograd GEMMs: 2048-channel 4x8 trunk blocks (64 tiles), 128-channel 64x128 local blocks
         {0, 64, 2048, 128, 16, 64, 64, 4, 1},
         {1, 64, 2048, 128, 16, 64, 64, 1, 0},

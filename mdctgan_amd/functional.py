@@ -184,7 +184,7 @@ class _ConvFn(torch.autograd.Function):
             # Winograd layers: transform the weights once, reuse the image for the data gradient of this step
             if ctx.needs_input_grad[0]:
                 u = ops.wino_weights(g, w)
-            elif not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing():
+            elif x.is_cuda and not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing():
                 u = _cached_wino_weights(g, weight)        # inference: once per weight version
             else:
                 u = None

@@ -206,6 +206,16 @@ def test_winograd42_shared_images(small_wino42):
     assert torch.equal(dw0, dw1)
 
 
+def test_winograd42_selected_by_problem_size():
+    """Default gating: the batch-16 layers of the first discriminator scale take F(4x4,2x2), the small second-scale
+    layers keep the direct kernels (measured slower there)."""
+    from mdctgan_amd import ops
+    big = ops.conv_geom(16, 65, 129, 64, 128, 4, 4, 2, 2, False)
+    small = ops.conv_geom(16, 33, 65, 64, 128, 4, 4, 2, 2, False)
+    assert ", 5>" in ops.plan_name(0, big) and ops.wino_weights_bytes(big) == 25 * 128 * 256 * 4
+    assert ", 0>" in ops.plan_name(0, small) and ops.wino_weights_bytes(small) == 0
+
+
 def test_winograd4_shared_images():
     """The F(2x2,4x4) path behind the same caller-held images: U (25 x Co x Ci), V and Md (25 x tiles x C) shared
     between forward, data gradient and weight gradient give the bits of the self-contained calls."""

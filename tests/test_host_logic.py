@@ -141,3 +141,24 @@ def test_segment_audio_and_amp_context():
         assert ops.conv_geom(1, 8, 8, 4, 4, 3, 3, 1, 1, True, amp.current_precision()).precision == _lib.PRECISION_F16
     assert amp.current_precision() == _lib.PRECISION_F32
     assert ops.conv_geom(1, 8, 8, 4, 4, 3, 3, 1, 1, True).precision == _lib.PRECISION_F32
+
+
+def test_backward_pass_bookkeeping():
+    """The two-backward-passes-over-one-discriminator-forward bookkeeping (functional.backward_pass) without a GPU: the
+    context nests and restores, only pass "G" restricts a batch-stacked tensor to its first rows, and the weight-image
+    epoch moves when an optimiser writes parameters through raw pointers."""
+    from mdctgan_amd import functional as Fh
+    stacked, single = torch.zeros(6, 1, 2, 2), torch.zeros(3, 1, 2, 2)
+    assert Fh._live_rows(stacked) is None
+    with Fh.backward_pass("G", 3):
+        assert Fh._live_rows(stacked) == 3 and Fh._live_rows(single) is None
+        with Fh.backward_pass("D", 3):
+            assert Fh._live_rows(stacked) is None and Fh._BackwardPass.kind == "D"
+        assert Fh._BackwardPass.kind == "G"
+    assert Fh._BackwardPass.kind is None and Fh._BackwardPass.rows == 0
+    with Fh.backward_pass(None, 0):
+        assert Fh._live_rows(stacked) is None
+    assert Fh._is_shared("D0") and Fh._is_shared("D") and not Fh._is_shared(True) and not Fh._is_shared(False)
+    e = Fh.WEIGHT_EPOCH[0]
+    Fh.bump_weight_epoch()
+    assert Fh.WEIGHT_EPOCH[0] == e + 1
