@@ -953,6 +953,133 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
         }
 }
 
+// ================================================================================================
+// Lean dense C[M][N] = A^T B for the Winograd-domain weight gradients (A = Md [K][M], B = V [K][N], K = tiles): the
+// same 64x64 tile, k-major LDS images and hand-pipelined chunk as conv_wgrad_kernel<64, 64, true, true, 1>, without
+// the convolution geometry (tap / pixel state, border cases, the generic loaders) that a K = 256 reduction -- 128 MFMAs
+// per wave -- cannot amortise, and with NSUB 16-deep sub-chunks per barrier.  M, N multiples of 64, K of 16 * NSUB.
+// grid: x = tiles (XCD-remapped), y = batch, z = K splits.
+// ================================================================================================
+template <int NSUB, int TAG>      // TAG: 1 = F(2x2,3x3), 5 = the 25-position families (distinct symbols for profilers)
+__global__ __launch_bounds__(256) void dense_tn64_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                         float* __restrict__ C, int M, int N, int K, long long sa,
+                                                         long long sb, long long sc, int cps) {
+    constexpr int BKW = BK * NSUB, LD = 64;
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BKW * LD];
+    auto As = [&](int buf) -> float* { return smem + buf * (BKW * LD); };
+    auto Bs = [&](int buf) -> float* { return smem + 2 * BKW * LD + buf * (BKW * LD); };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_m = M / 64, tiles_n = N / 64;
+    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int m0 = (t % tiles_m) * 64, n0 = (t / tiles_m) * 64;
+    const int total_chunks = K / BKW;
+    const int c_begin = blockIdx.z * cps, c_end = min(total_chunks, c_begin + cps);
+    const int kl = tid >> 4, q = tid & 15;            // this thread's k row inside a 16-deep sub-chunk, its float4 column
+    const float* pa = A + (size_t)blockIdx.y * sa + (size_t)(c_begin * BKW + kl) * M + m0 + 4 * q;
+    const float* pb = B + (size_t)blockIdx.y * sb + (size_t)(c_begin * BKW + kl) * N + n0 + 4 * q;
+    const size_t stepa = (size_t)BK * M, stepb = (size_t)BK * N;
+    float4 va[NSUB], vb[NSUB];
+    auto load = [&]() {
+#pragma unroll
+        for (int i = 0; i < NSUB; ++i) {
+            va[i] = ld4(pa);
+            vb[i] = ld4(pb);
+            pa += stepa;
+            pb += stepb;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NSUB; ++i) {
+            *reinterpret_cast<float4*>(As(buf) + (kl + BK * i) * LD + 4 * q) = va[i];
+            *reinterpret_cast<float4*>(Bs(buf) + (kl + BK * i) * LD + 4 * q) = vb[i];
+        }
+    };
+    f32x16 acc[1][1];
+    acc[0][0] = f32x16{0};
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    if (c_begin < c_end) {
+        load();
+        stash(0);
+    }
+    __syncthreads();
+    if (c_begin + 1 < c_end) load();
+    for (int c = c_begin; c < c_end; ++c) {
+        const int cur = (c - c_begin) & 1;
+        auto f0 = [&]() { if (c + 1 < c_end) stash(cur ^ 1); };
+        auto f1 = [&]() { if (c + 2 < c_end) load(); };
+        auto nop = [&]() {};
+        mma_chunk<1, 1, LD, LD>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
+#pragma unroll
+        for (int sc_ = 1; sc_ < NSUB; ++sc_)
+            mma_chunk<1, 1, LD, LD>(As(cur) + sc_ * BK * LD, Bs(cur) + sc_ * BK * LD, acc, wm0, wn0, lane, nop, nop);
+        __syncthreads();
+    }
+    float* o = C + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * ((size_t)M * N);
+    if (gridDim.z == 1) o = C + (size_t)blockIdx.y * sc;
+    const int col = n0 + wn0 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[(size_t)(m0 + wm0 + mfma32_row(r, lane)) * N + col] = acc[0][0][r];
+}
+
+// Lean dense C[M][N] = A B for the Winograd-domain data gradients (A = Md [M][K] with K = Co contiguous, B = U [K][N]):
+// conv_dgrad_kernel<64, 64, true, true, 1>'s tile and chunk without the convolution geometry.  N, K multiples of 64 / 16;
+// rows past M re-read the last row and are not stored.  grid: x = tiles (XCD-remapped), y = K splits, z = batch.
+template <int TAG>
+__global__ __launch_bounds__(256) void dense_nn64_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                         float* __restrict__ C, float* __restrict__ part, int M, int N,
+                                                         int K, long long sa, long long sb, long long sc, int cps) {
+    constexpr int LDA = 64 + 4, LDB = 64;           // A is scattered in with ds_write_b32 (2-way at pitch 68), B row-wise
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
+    auto As = [&](int buf) -> float* { return smem + buf * (BK * LDA); };
+    auto Bs = [&](int buf) -> float* { return smem + 2 * BK * LDA + buf * (BK * LDB); };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_m = (M + 63) / 64, tiles_n = N / 64;
+    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int m0 = (t % tiles_m) * 64, n0 = (t / tiles_m) * 64;
+    const int total_chunks = K / BK;
+    const int c_begin = blockIdx.y * cps, c_end = min(total_chunks, c_begin + cps);
+    const int qa = tid & 3, ra = tid >> 2;            // A: 4 consecutive k of row ra
+    const int kb = tid >> 4, qb = tid & 15;           // B: row kb of the chunk, float4 column qb
+    const float* pa = A + (size_t)blockIdx.z * sa + (size_t)min(m0 + ra, M - 1) * K + c_begin * BK + 4 * qa;
+    const float* pb = B + (size_t)blockIdx.z * sb + (size_t)(c_begin * BK + kb) * N + n0 + 4 * qb;
+    const size_t stepb = (size_t)BK * N;
+    float4 va, vb;
+    auto load = [&]() {
+        va = ld4(pa);
+        vb = ld4(pb);
+        pa += BK;
+        pb += stepb;
+    };
+    auto stash = [&](int buf) {
+        st_kcontig<LDA>(As(buf), ra, qa, va);
+        *reinterpret_cast<float4*>(Bs(buf) + kb * LDB + 4 * qb) = vb;
+    };
+    f32x16 acc[1][1];
+    acc[0][0] = f32x16{0};
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    if (c_begin < c_end) {
+        load();
+        stash(0);
+    }
+    __syncthreads();
+    if (c_begin + 1 < c_end) load();
+    for (int c = c_begin; c < c_end; ++c) {
+        const int cur = (c - c_begin) & 1;
+        auto f0 = [&]() { if (c + 1 < c_end) stash(cur ^ 1); };
+        auto f1 = [&]() { if (c + 2 < c_end) load(); };
+        mma_chunk<1, 1, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
+        __syncthreads();
+    }
+    float* o = part ? part + ((size_t)blockIdx.y * gridDim.z + blockIdx.z) * ((size_t)M * N) : C + (size_t)blockIdx.z * sc;
+    const int col = n0 + wn0 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + mfma32_row(r, lane);
+        if (row < M) o[(size_t)row * N + col] = acc[0][0][r];
+    }
+}
+
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, int S, size_t n, float* __restrict__ out,
                                      int accumulate) {
     const size_t n4 = n / 4;
@@ -1309,6 +1436,40 @@ int wino_launch_tiles(const TilePlan& tp, Launch&& launch) {
     return 0;
 }
 
+// The Winograd-domain weight-gradient GEMM on dense_tn64_kernel (64x64 tiles, float32): Kc = Ci, or 4 Ci for wino42
+inline bool lean_wgrad_ok(const WinoWgradPlan& p, long long T, int Co, int Kc, bool hp) {
+    static const bool off = getenv("MG_NO_LEAN_WGRAD") != nullptr;
+    return !off && !hp && !p.big && Co % 64 == 0 && Kc % 64 == 0 && T % BK == 0;
+}
+inline void launch_lean_wgrad(const WinoWgradPlan& p, int P, long long T, int Co, int Kc, const float* Md, const float* V,
+                              float* target, hipStream_t st) {
+    dim3 grid((unsigned)((Co / 64) * (Kc / 64)), P, p.splits);
+    const int cps = p.splits == 1 ? (1 << 29) : p.cps;
+    if (P == 16)
+        hipLaunchKernelGGL((dense_tn64_kernel<1, 1>), grid, dim3(256), 0, st, Md, V, target, Co, Kc, (int)T, T * Co, T * Kc,
+                           (long long)Co * Kc, cps);
+    else
+        hipLaunchKernelGGL((dense_tn64_kernel<1, 5>), grid, dim3(256), 0, st, Md, V, target, Co, Kc, (int)T, T * Co, T * Kc,
+                           (long long)Co * Kc, cps);
+}
+
+// ... and the data-gradient GEMM on dense_nn64_kernel (64x64 plans only)
+inline bool lean_dgrad_ok(const TilePlan& tp, long long T, int Nc, int Kc, bool hp) {
+    static const bool off = getenv("MG_NO_LEAN_DGRAD") != nullptr;
+    return !off && !hp && tp.bm == 64 && tp.bn == 64 && Nc % 64 == 0 && Kc % BK == 0 && T >= 1;
+}
+inline void launch_lean_dgrad(const TilePlan& tp, int P, long long T, int Nc, int Kc, const float* Md, const float* U,
+                              float* dV, float* part, hipStream_t st) {
+    dim3 grid((unsigned)(((T + 63) / 64) * (Nc / 64)), tp.splits, P);
+    const int cps = tp.splits == 1 ? (1 << 29) : tp.cps;
+    if (P == 16)
+        hipLaunchKernelGGL(dense_nn64_kernel<1>, grid, dim3(256), 0, st, Md, U, dV, part, (int)T, Nc, Kc, T * Kc,
+                           (long long)Kc * Nc, T * Nc, cps);
+    else
+        hipLaunchKernelGGL(dense_nn64_kernel<5>, grid, dim3(256), 0, st, Md, U, dV, part, (int)T, Nc, Kc, T * Kc,
+                           (long long)Kc * Nc, T * Nc, cps);
+}
+
 int wino_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act, float* ws,
              hipStream_t st, const float* u_pre, float* v_keep) {
     const WinoDims d = wino_dims(g);
@@ -1378,6 +1539,9 @@ int wino_dgrad_t(const mg_conv_geom* g, const float* dy, const float* w, const f
     float* pp = tp.splits > 1 ? part : nullptr;
     const Batch bt{T * g->Co, (long long)g->Co * g->Ci, T * g->Ci, 0};      // dV_z = dM_z U_z: same position, no flip
     probe_begin(st);
+    if (lean_dgrad_ok(tp, T, g->Ci, g->Co, prec_h(g)))
+        launch_lean_dgrad(tp, 16, T, g->Ci, g->Co, Md, U, dV, pp, st);
+    else
     wino_launch_tiles(tp, [&](auto bm, auto bn) {
         constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value;
         dim3 grid((unsigned)(((T + BM_ - 1) / BM_) * ((g->Ci + BN_ - 1) / BN_)), tp.splits, 16);
@@ -1472,6 +1636,9 @@ int wino_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw
     const Batch bt{d.T * g->Ci, d.T * g->Co, (long long)g->Co * g->Ci, 0};
     dim3 grid((unsigned)p.tiles, 16, p.splits);
     probe_begin(st);
+    if (lean_wgrad_ok(p, d.T, g->Co, g->Ci, prec_h(g)))
+        launch_lean_wgrad(p, 16, d.T, g->Co, g->Ci, Md, V, target, st);
+    else
     if (p.big && prec_h(g))
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, true, true, 3>), grid, dim3(256), 0, st, gg, (const float*)V,
                            (const float*)Md, target, p.cps, 0, bt);
@@ -1610,6 +1777,9 @@ int wino4_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* d
     float* pp = tp.splits > 1 ? part : nullptr;
     const Batch bt{T * g->Co, (long long)g->Co * g->Ci, T * g->Ci, 0};
     probe_begin(st);
+    if (lean_dgrad_ok(tp, T, g->Ci, g->Co, false))
+        launch_lean_dgrad(tp, 25, T, g->Ci, g->Co, Md, U, dV, pp, st);
+    else
     wino_launch_tiles(tp, [&](auto bm, auto bn) {
         constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value;
         dim3 grid((unsigned)(((T + BM_ - 1) / BM_) * ((g->Ci + BN_ - 1) / BN_)), tp.splits, 25);
@@ -1649,7 +1819,9 @@ int wino4_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* d
     const Batch bt{d.T * g->Ci, d.T * g->Co, (long long)g->Co * g->Ci, 0};
     dim3 grid((unsigned)p.tiles, 25, p.splits);
     probe_begin(st);
-    if (p.big)
+    if (lean_wgrad_ok(p, d.T, g->Co, g->Ci, false))
+        launch_lean_wgrad(p, 25, d.T, g->Co, g->Ci, Md, V, target, st);
+    else if (p.big)
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, true, true, 5>), grid, dim3(256), 0, st, gg, (const float*)V,
                            (const float*)Md, target, p.cps, 0, bt);
     else
@@ -1788,6 +1960,9 @@ int wino42_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* 
     float* pp = tp.splits > 1 ? part : nullptr;
     const Batch bt{T * g->Co, (long long)g->Co * d.K4, T * d.K4, 0};
     probe_begin(st);
+    if (lean_dgrad_ok(tp, T, d.K4, g->Co, false))
+        launch_lean_dgrad(tp, 25, T, d.K4, g->Co, Md, U, dV, pp, st);
+    else
     wino_launch_tiles(tp, [&](auto bm, auto bn) {
         constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value;
         dim3 grid((unsigned)(((T + BM_ - 1) / BM_) * ((d.K4 + BN_ - 1) / BN_)), tp.splits, 25);
@@ -1827,7 +2002,9 @@ int wino42_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* 
     const Batch bt{d.T * d.K4, d.T * g->Co, (long long)g->Co * d.K4, 0};
     dim3 grid((unsigned)p.tiles, 25, p.splits);
     probe_begin(st);
-    if (p.big)
+    if (lean_wgrad_ok(p, d.T, g->Co, d.K4, false))
+        launch_lean_wgrad(p, 25, d.T, g->Co, d.K4, Md, V, target, st);
+    else if (p.big)
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, true, true, 5>), grid, dim3(256), 0, st, gg, (const float*)V,
                            (const float*)Md, target, p.cps, 0, bt);
     else
@@ -1969,9 +2146,13 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
                 snprintf(out, out_len, "conv_fwd_kernel<%d, %d, true, 1>", tp.bm, tp.bn);
         } else if (pass == 1) {
             const TilePlan tp = gemm_plan((g->reflect && wino_dgrad_padded()) ? d.Tp : d.T, g->Ci, g->Co / BK, 16, true, 1);
+            if (!wino_dgrad_padded() && lean_dgrad_ok(tp, d.T, g->Ci, g->Co, prec_h(g))) snprintf(out, out_len, "dense_nn64_kernel<1>");
+            else
             snprintf(out, out_len, "conv_dgrad_kernel<%d, %d, true, true, %d>", tp.bm, tp.bn, prec_h(g) ? 3 : 1);
         } else {
             const WinoWgradPlan p = wino_wgrad_plan(g);
+            if (lean_wgrad_ok(p, d.T, g->Co, g->Ci, prec_h(g))) snprintf(out, out_len, "dense_tn64_kernel<1, 1>");
+            else
             snprintf(out, out_len, "conv_wgrad_kernel<%d, %d, true, true, %d>", p.big ? 128 : 64, p.big ? 128 : 64,
                      prec_h(g) ? 3 : 1);
         }
@@ -1983,9 +2164,13 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
             else snprintf(out, out_len, "conv_fwd_kernel<%d, %d, true, 5>", tp.bm, tp.bn);
         } else if (pass == 1) {
             const TilePlan tp = gemm_plan(d.T, g->Ci, g->Co / BK, 25, true, 1);
+            if (lean_dgrad_ok(tp, d.T, g->Ci, g->Co, false)) snprintf(out, out_len, "dense_nn64_kernel<5>");
+            else
             snprintf(out, out_len, "conv_dgrad_kernel<%d, %d, true, true, 5>", tp.bm, tp.bn);
         } else {
             const WinoWgradPlan p = wino4_wgrad_plan(g);
+            if (lean_wgrad_ok(p, d.T, g->Co, g->Ci, false)) snprintf(out, out_len, "dense_tn64_kernel<1, 5>");
+            else
             snprintf(out, out_len, "conv_wgrad_kernel<%d, %d, true, true, 5>", p.big ? 128 : 64, p.big ? 128 : 64);
         }
     } else if (wino42_ok(g) && !kq) {
@@ -1996,9 +2181,13 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
             else snprintf(out, out_len, "conv_fwd_kernel<%d, %d, true, 5>", tp.bm, tp.bn);
         } else if (pass == 1) {
             const TilePlan tp = gemm_plan(d.T, d.K4, g->Co / BK, 25, true, 1);
+            if (lean_dgrad_ok(tp, d.T, d.K4, g->Co, false)) snprintf(out, out_len, "dense_nn64_kernel<5>");
+            else
             snprintf(out, out_len, "conv_dgrad_kernel<%d, %d, true, true, 5>", tp.bm, tp.bn);
         } else {
             const WinoWgradPlan p = wino42_wgrad_plan(g);
+            if (lean_wgrad_ok(p, d.T, g->Co, d.K4, false)) snprintf(out, out_len, "dense_tn64_kernel<1, 5>");
+            else
             snprintf(out, out_len, "conv_wgrad_kernel<%d, %d, true, true, 5>", p.big ? 128 : 64, p.big ? 128 : 64);
         }
     } else if (pass == 1 && smallc_dgrad_ok(g)) {
