@@ -24,7 +24,7 @@ class ArenaReducer:
     slices: [(param, offset, padded_numel)] in arena order.  writes_per_step: how many wgrad launches write each
     parameter's gradient during one backward (1 for G; 2 for D: the fake and the real pass)."""
 
-    def __init__(self, flat_g, slices, writes_per_step=1, bucket_bytes=128 << 20, group=None):
+    def __init__(self, flat_g, slices, writes_per_step=1, bucket_bytes=128 << 20, group=None, tail_bytes=None):
         self.flat_g, self.group = flat_g, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.writes_per_step = writes_per_step
@@ -32,15 +32,20 @@ class ArenaReducer:
         self.force = dist.is_initialized()       # a 1-rank group still goes through RCCL (used to test the code path)
         self.buckets = []            # [lo, hi, n_params]
         self.param_bucket = {}
-        lo, count, cur = 0, 0, 0
+        # Backward fills the arena from its end, so the bucket that holds the FIRST parameters is the last one to
+        # launch and the only one whose all-reduce cannot hide behind remaining backward work: keep it small
+        # (tail_bytes, default a quarter of a bucket) and never let a large late-arena tensor ride in it.
+        tail = max(1, (bucket_bytes // 4 if tail_bytes is None else tail_bytes) // 4)
         per_bucket = max(1, bucket_bytes // 4)
+        lo, count, cur = 0, 0, 0
         for p, off, n in slices:
+            cap = tail if not self.buckets else per_bucket
+            if count and off + n - lo > cap:                   # close before a tensor that would overflow the cap
+                self.buckets.append([lo, off, count])
+                lo, count = off, 0
             self.param_bucket[id(p)] = len(self.buckets)
             count += 1
             cur = off + n
-            if cur - lo >= per_bucket:
-                self.buckets.append([lo, cur, count])
-                lo, count = cur, 0
         if count:
             self.buckets.append([lo, cur, count])
         self._reset()

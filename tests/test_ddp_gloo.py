@@ -104,4 +104,9 @@ def test_bucket_layout_single_process():
     assert all(a[1] == b[0] for a, b in zip(red.buckets, red.buckets[1:]))     # contiguous, no gaps
     assert sum(b[2] for b in red.buckets) == len(params)
     assert red.pending == [2 * b[2] for b in red.buckets]
+    # the bucket holding the first parameters launches last (backward fills the arena from its end): it is capped at a
+    # quarter of a bucket so the one all-reduce that cannot overlap with backward stays small
+    first = red.buckets[0]
+    assert first[1] - first[0] <= 4096 // 4 // 4 or first[2] == 1
+    assert all(b[1] - b[0] <= 4096 // 4 or b[2] == 1 for b in red.buckets)
     red.close()
