@@ -321,9 +321,10 @@ def main():
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                     "launches": n, "avg_launch_us": round(secs / n * 1e6, 2),
                     "flops_per_launch": flops / n,
-                    "flops_definition": "FLOPs the kernel itself issues (2*M*N*K of its GEMM).  A '..., 1>' kernel is the "
-                                        "batched Winograd F(2x2,3x3) GEMM of a 3x3 layer whose direct-convolution cost "
-                                        "(SURVEY 8d, 2*MACs) is %.3g FLOP per launch" % (conv_flops / n),
+                    "flops_definition": "FLOPs the kernel itself issues (2*M*N*K of its GEMM).  dense_nn64_kernel<1> / "
+                                        "dense_tn64_kernel<1, 1> / conv_fwd32_kernel<.., 1> are the batched Winograd "
+                                        "F(2x2,3x3) data-gradient / weight-gradient / forward GEMMs of a 3x3 layer whose "
+                                        "direct-convolution cost (SURVEY 8d, 2*MACs) is %.3g FLOP per launch" % (conv_flops / n),
                     "timed": ("HIP events recorded by the library on its launch stream right around this kernel, "
                               "every launch of %d eager iterations run right after the graph-replayed timed region" % args.steps) if use_graph else
                              "HIP events around every launch of this kernel inside the timed region"}
