@@ -957,47 +957,53 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Geom g, const float* __
 // Lean dense C[M][N] = A^T B for the Winograd-domain weight gradients (A = Md [K][M], B = V [K][N], K = tiles): the
 // same 64x64 tile, k-major LDS images and hand-pipelined chunk as conv_wgrad_kernel<64, 64, true, true, 1>, without
 // the convolution geometry (tap / pixel state, border cases, the generic loaders) that a K = 256 reduction -- 128 MFMAs
-// per wave -- cannot amortise, and with NSUB 16-deep sub-chunks per barrier.  M, N multiples of 64, K of 16 * NSUB.
+// per wave -- cannot amortise, and with NSUB 16-deep sub-chunks per barrier.  M multiple of 64, N of 64 NB, K of 16 * NSUB.
 // grid: x = tiles (XCD-remapped), y = batch, z = K splits.
 // ================================================================================================
-template <int NSUB, int TAG>      // TAG: 1 = F(2x2,3x3), 5 = the 25-position families (distinct symbols for profilers)
+template <int NSUB, int TAG, int NB = 1>      // TAG: 1 = F(2x2,3x3), 5 = the 25-position families; tile 64 x (64 NB)
 __global__ __launch_bounds__(256) void dense_tn64_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                          float* __restrict__ C, int M, int N, int K, long long sa,
                                                          long long sb, long long sc, int cps) {
-    constexpr int BKW = BK * NSUB, LD = 64;
-    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BKW * LD];
-    auto As = [&](int buf) -> float* { return smem + buf * (BKW * LD); };
-    auto Bs = [&](int buf) -> float* { return smem + 2 * BKW * LD + buf * (BKW * LD); };
+    constexpr int BKW = BK * NSUB, LDA = 64, BN = 64 * NB, LDB = BN;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BKW * (LDA + LDB)];
+    auto As = [&](int buf) -> float* { return smem + buf * (BKW * LDA); };
+    auto Bs = [&](int buf) -> float* { return smem + 2 * BKW * LDA + buf * (BKW * LDB); };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_m = M / 64, tiles_n = N / 64;
+    const int tiles_m = M / 64, tiles_n = N / BN;
     const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int m0 = (t % tiles_m) * 64, n0 = (t / tiles_m) * 64;
+    const int m0 = (t % tiles_m) * 64, n0 = (t / tiles_m) * BN;
     const int total_chunks = K / BKW;
     const int c_begin = blockIdx.z * cps, c_end = min(total_chunks, c_begin + cps);
-    const int kl = tid >> 4, q = tid & 15;            // this thread's k row inside a 16-deep sub-chunk, its float4 column
+    const int kl = tid >> 4, q = tid & 15;            // A: k row inside a 16-deep sub-chunk, float4 column
+    const int klb = tid / (BN / 4), qb = tid % (BN / 4);   // B: 256 / (BN/4) k rows per pass
+    constexpr int BROWS = 1024 / BN, NVB = BK / BROWS;
     const float* pa = A + (size_t)blockIdx.y * sa + (size_t)(c_begin * BKW + kl) * M + m0 + 4 * q;
-    const float* pb = B + (size_t)blockIdx.y * sb + (size_t)(c_begin * BKW + kl) * N + n0 + 4 * q;
-    const size_t stepa = (size_t)BK * M, stepb = (size_t)BK * N;
-    float4 va[NSUB], vb[NSUB];
+    const float* pb = B + (size_t)blockIdx.y * sb + (size_t)(c_begin * BKW + klb) * N + n0 + 4 * qb;
+    const size_t stepa = (size_t)BK * M;
+    float4 va[NSUB], vb[NSUB][NVB];
     auto load = [&]() {
 #pragma unroll
         for (int i = 0; i < NSUB; ++i) {
             va[i] = ld4(pa);
-            vb[i] = ld4(pb);
             pa += stepa;
-            pb += stepb;
+#pragma unroll
+            for (int j = 0; j < NVB; ++j) vb[i][j] = ld4(pb + (size_t)(j * BROWS) * N);
+            pb += (size_t)BK * N;
         }
     };
     auto stash = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NSUB; ++i) {
-            *reinterpret_cast<float4*>(As(buf) + (kl + BK * i) * LD + 4 * q) = va[i];
-            *reinterpret_cast<float4*>(Bs(buf) + (kl + BK * i) * LD + 4 * q) = vb[i];
+            *reinterpret_cast<float4*>(As(buf) + (kl + BK * i) * LDA + 4 * q) = va[i];
+#pragma unroll
+            for (int j = 0; j < NVB; ++j)
+                *reinterpret_cast<float4*>(Bs(buf) + (klb + j * BROWS + BK * i) * LDB + 4 * qb) = vb[i][j];
         }
     };
-    f32x16 acc[1][1];
-    acc[0][0] = f32x16{0};
-    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    f32x16 acc[1][NB];
+#pragma unroll
+    for (int ni = 0; ni < NB; ++ni) acc[0][ni] = f32x16{0};
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * (BN / 2);
     if (c_begin < c_end) {
         load();
         stash(0);
@@ -1009,17 +1015,20 @@ __global__ __launch_bounds__(256) void dense_tn64_kernel(const float* __restrict
         auto f0 = [&]() { if (c + 1 < c_end) stash(cur ^ 1); };
         auto f1 = [&]() { if (c + 2 < c_end) load(); };
         auto nop = [&]() {};
-        mma_chunk<1, 1, LD, LD>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
+        mma_chunk<1, NB, LDA, LDB>(As(cur), Bs(cur), acc, wm0, wn0, lane, f0, f1);
 #pragma unroll
         for (int sc_ = 1; sc_ < NSUB; ++sc_)
-            mma_chunk<1, 1, LD, LD>(As(cur) + sc_ * BK * LD, Bs(cur) + sc_ * BK * LD, acc, wm0, wn0, lane, nop, nop);
+            mma_chunk<1, NB, LDA, LDB>(As(cur) + sc_ * BK * LDA, Bs(cur) + sc_ * BK * LDB, acc, wm0, wn0, lane, nop, nop);
         __syncthreads();
     }
     float* o = C + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * ((size_t)M * N);
     if (gridDim.z == 1) o = C + (size_t)blockIdx.y * sc;
-    const int col = n0 + wn0 + (lane & 31);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[(size_t)(m0 + wm0 + mfma32_row(r, lane)) * N + col] = acc[0][0][r];
+    for (int ni = 0; ni < NB; ++ni) {
+        const int col = n0 + wn0 + 32 * ni + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[(size_t)(m0 + wm0 + mfma32_row(r, lane)) * N + col] = acc[0][ni][r];
+    }
 }
 
 // Lean dense C[M][N] = A B for the Winograd-domain data gradients (A = Md [M][K] with K = Co contiguous, B = U [K][N]):
@@ -1441,10 +1450,22 @@ inline bool lean_wgrad_ok(const WinoWgradPlan& p, long long T, int Co, int Kc, b
     static const bool off = getenv("MG_NO_LEAN_WGRAD") != nullptr;
     return !off && !hp && !p.big && Co % 64 == 0 && Kc % 64 == 0 && T % BK == 0;
 }
+// 64 x 128 tiles (two MFMAs per A fragment) where they still give >= 4 workgroups per CU: 83 -> 79.5 us on the
+// 1024-channel layer
+inline bool lean_wgrad_wide(const WinoWgradPlan& p, int P, int Co, int Kc) {
+    static const bool on = getenv("MG_NO_TN_WIDE") == nullptr;
+    return on && P == 16 && Kc % 128 == 0 && (long long)(Co / 64) * (Kc / 128) * P * p.splits >= 1024;
+}
 inline void launch_lean_wgrad(const WinoWgradPlan& p, int P, long long T, int Co, int Kc, const float* Md, const float* V,
                               float* target, hipStream_t st) {
     dim3 grid((unsigned)((Co / 64) * (Kc / 64)), P, p.splits);
     const int cps = p.splits == 1 ? (1 << 29) : p.cps;
+    if (lean_wgrad_wide(p, P, Co, Kc)) {
+        dim3 g2((unsigned)((Co / 64) * (Kc / 128)), P, p.splits);
+        hipLaunchKernelGGL((dense_tn64_kernel<1, 1, 2>), g2, dim3(256), 0, st, Md, V, target, Co, Kc, (int)T, T * Co, T * Kc,
+                           (long long)Co * Kc, cps);
+        return;
+    }
     if (P == 16)
         hipLaunchKernelGGL((dense_tn64_kernel<1, 1>), grid, dim3(256), 0, st, Md, V, target, Co, Kc, (int)T, T * Co, T * Kc,
                            (long long)Co * Kc, cps);
@@ -2151,7 +2172,8 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
             snprintf(out, out_len, "conv_dgrad_kernel<%d, %d, true, true, %d>", tp.bm, tp.bn, prec_h(g) ? 3 : 1);
         } else {
             const WinoWgradPlan p = wino_wgrad_plan(g);
-            if (lean_wgrad_ok(p, d.T, g->Co, g->Ci, prec_h(g))) snprintf(out, out_len, "dense_tn64_kernel<1, 1>");
+            if (lean_wgrad_ok(p, d.T, g->Co, g->Ci, prec_h(g)))
+                snprintf(out, out_len, lean_wgrad_wide(p, 16, g->Co, g->Ci) ? "dense_tn64_kernel<1, 1, 2>" : "dense_tn64_kernel<1, 1, 1>");
             else
             snprintf(out, out_len, "conv_wgrad_kernel<%d, %d, true, true, %d>", p.big ? 128 : 64, p.big ? 128 : 64,
                      prec_h(g) ? 3 : 1);
@@ -2169,7 +2191,7 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
             snprintf(out, out_len, "conv_dgrad_kernel<%d, %d, true, true, 5>", tp.bm, tp.bn);
         } else {
             const WinoWgradPlan p = wino4_wgrad_plan(g);
-            if (lean_wgrad_ok(p, d.T, g->Co, g->Ci, false)) snprintf(out, out_len, "dense_tn64_kernel<1, 5>");
+            if (lean_wgrad_ok(p, d.T, g->Co, g->Ci, false)) snprintf(out, out_len, "dense_tn64_kernel<1, 5, 1>");
             else
             snprintf(out, out_len, "conv_wgrad_kernel<%d, %d, true, true, 5>", p.big ? 128 : 64, p.big ? 128 : 64);
         }
@@ -2186,7 +2208,7 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
             snprintf(out, out_len, "conv_dgrad_kernel<%d, %d, true, true, 5>", tp.bm, tp.bn);
         } else {
             const WinoWgradPlan p = wino42_wgrad_plan(g);
-            if (lean_wgrad_ok(p, d.T, g->Co, d.K4, false)) snprintf(out, out_len, "dense_tn64_kernel<1, 5>");
+            if (lean_wgrad_ok(p, d.T, g->Co, d.K4, false)) snprintf(out, out_len, "dense_tn64_kernel<1, 5, 1>");
             else
             snprintf(out, out_len, "conv_wgrad_kernel<%d, %d, true, true, 5>", p.big ? 128 : 64, p.big ? 128 : 64);
         }
