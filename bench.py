@@ -98,37 +98,62 @@ class KernelTimer:
         return agg
 
 
+CPU_THREADS = 16      # torch CPU threads of the cpu_baseline legs: 16 measured fastest on the 256-core GPU-box host for
+                      # these convolutions (8: -10 %, 32: -25 %, 64/128 slower still; scripts/cpu_threads_probe.py)
+
+
+def _median_time(fn, warmups=3, iters=5):
+    """BASELINE.md section 3 protocol: 3 warm-ups, >= 5 timed iterations, median."""
+    for _ in range(warmups):
+        fn()
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2], ts
+
+
 def cpu_baseline_train(max_threads):
     """The CPU oracle (oracle/step.py: torch CPU float32 nets + float64 transform == the reference's arithmetic) timed
-    on a bounded sample of the same workload: the full configs[1] networks, thread count calibrated on batch-1 steps
-    (more threads is NOT faster for these convolutions: 16 beat 32/64/128 on the 256-core box), then ONE G+D step at
-    batch 4, scaled by 4/8 to the batch-8 step rate."""
+    on a bounded sample of the same workload: the full configs[1] networks, G+D steps at batch 2 (3 warm-ups + 5 timed,
+    median) on a fixed thread count, scaled by 2/8 to the batch-8 step rate (the step is linear in the batch on the
+    CPU: convolutions dominate)."""
     from oracle import nets as onets
     from oracle import step as ostep
     gen = torch.Generator().manual_seed(0)
     netG = onets.init_weights(onets.build_generator("global", 2, 1, 64, 4, 9, input_size=(128, 256)), gen)
     netD = onets.init_weights(onets.MultiscaleDRef(3, 64, 3, 2), gen)
     ref = ostep.HotPathRef(netG, netD, ostep.CodecCfg(), num_D=2)
-    lr, hr = synth_batch(4, 1, "cpu")
-    best, best_t = None, None
-    for th in (8, 16, 32):
-        if th > max_threads:
-            break
-        torch.set_num_threads(th)
-        if best is None:
-            ref.train_step(lr[:1].numpy(), hr[:1].numpy())          # allocator / oneDNN warm-up
-        t0 = time.perf_counter()
-        ref.train_step(lr[:1].numpy(), hr[:1].numpy())
-        t = time.perf_counter() - t0
-        if best_t is None or t < best_t:
-            best, best_t = th, t
-    torch.set_num_threads(best)
-    t0 = time.perf_counter()
-    ref.train_step(lr.numpy(), hr.numpy())
-    dt = time.perf_counter() - t0
-    return {"value": round((1.0 / dt) * (4.0 / BATCH), 5), "unit": "steps/s", "cores": best, "kind": "port",
-            "sample": "1 G+D step of configs[1] at batch 4 (%.1f s) scaled x4/8 to batch 8; threads calibrated over "
-                      "{8,16,32} on batch-1 steps, host has %d cores" % (dt, max_threads)}
+    lr, hr = synth_batch(2, 1, "cpu")
+    threads = min(CPU_THREADS, max_threads)
+    torch.set_num_threads(threads)
+    lrn, hrn = lr.numpy(), hr.numpy()
+    med, ts = _median_time(lambda: ref.train_step(lrn, hrn))
+    return {"value": round((1.0 / med) * (2.0 / BATCH), 5), "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": "G+D steps of configs[1] at batch 2: 3 warm-ups + 5 timed, median %.2f s (min %.2f, max %.2f), "
+                      "scaled x2/8 to batch 8; torch CPU float32 nets + float64 transform on %d threads (fixed; host has "
+                      "%d cores)" % (med, ts[0], ts[-1], threads, max_threads)}
+
+
+def cpu_baseline_infer(max_threads, lr_rate):
+    """configs[4]'s path on the CPU oracle: HotPathRef.inference (to_spectro, generator forward, to_audio) on 2 segments
+    of 32512 samples, 3 warm-ups + 5 timed, median; audio-s/s = 2 * 32512 / 48000 / median."""
+    from oracle import nets as onets
+    from oracle import step as ostep
+    gen = torch.Generator().manual_seed(0)
+    netG = onets.init_weights(onets.build_generator("global", 2, 1, 64, 4, 9, input_size=(128, 256)), gen)
+    ref = ostep.HotPathRef(netG, None, ostep.CodecCfg(lr_rate=lr_rate), num_D=2)
+    lr, _ = synth_batch(2, 1, "cpu", lr_rate=lr_rate)
+    threads = min(CPU_THREADS, max_threads)
+    torch.set_num_threads(threads)
+    lrn = lr.numpy()
+    med, ts = _median_time(lambda: ref.inference(lrn))
+    return {"value": round(2 * T_SEG / 48000.0 / med, 4), "unit": "audio-s/s", "cores": threads, "kind": "port",
+            "sample": "oracle inference (float64 MDCT + float32 generator + float64 IMDCT) on 2 segments x 32512 samples: "
+                      "3 warm-ups + 5 timed, median %.2f s (min %.2f, max %.2f), %d threads (fixed; host has %d cores)"
+                      % (med, ts[0], ts[-1], threads, max_threads)}
 
 
 def bench_codec(args, dev, rank, world):
@@ -252,7 +277,7 @@ def main():
     if use_ddp:
         ddp.attach(model)
     lr, hr = synth_batch(batch, 42 + rank, dev, lr_rate=lr_rate)
-    from mdctgan_amd.generate_audio import generate
+    from mdctgan_amd.generate_audio import generate, make_graphed_generate
 
     def eager_step():
         if args.mode == "train":
@@ -260,7 +285,7 @@ def main():
         else:
             generate(model, lr, batch_size=batch, gen_overlap=0)
     step = eager_step
-    use_graph = (not args.no_graph) and not use_ddp and args.mode == "train"
+    use_graph = (not args.no_graph) and (not use_ddp or os.environ.get("MDCTGAN_DDP_GRAPH", "0") == "1")
 
     def fence():
         torch.cuda.synchronize()
@@ -273,7 +298,7 @@ def main():
     timer_all = KernelTimer(ops, mglib.load())
     # untimed warm-up: at least 6 eager iterations -- the caching allocator and the per-stream workspaces only reach
     # their steady state after a few steps (measured: 27.7 ms/step when timing starts after 2, 19.8 ms after 5)
-    nw = max(args.warmup, 6 if not ((not args.no_graph) and not use_ddp and args.mode == "train") else 2)
+    nw = max(args.warmup, 6 if not use_graph else 2)
     for i in range(nw):
         if i == nw - 1 and not args.no_roofline:
             ops.PROFILER = timer_all
@@ -285,9 +310,13 @@ def main():
         agg = timer_all.summary()
         dominant = max(agg, key=lambda k: agg[k][2]) if agg else None
     timer = KernelTimer(ops, mglib.load(), target=dominant) if dominant else None
-    if use_graph:
+    if use_graph and args.mode == "train":
         graphed = model.make_graphed_step(lr, hr, warmup=2)   # whole G+D iteration as one hipGraph
         step = lambda: graphed()                                # noqa: E731  (inputs already in the captured buffers)
+        step()
+    elif use_graph:
+        graphed = make_graphed_generate(model, lr, batch_size=batch, gen_overlap=0)   # K1 + generator + K2 + stitch
+        step = lambda: graphed()                                # noqa: E731
         step()
 
     fence()
@@ -335,9 +364,32 @@ def main():
                 roofline["traffic_definition"] = ("HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 from separate "
                                                   "rocprofv3 --pmc passes on this kernel at this layer shape (gfx950 reports "
                                                   "half of a wide coalesced read: MI355X_MICROARCH.md, HBM section); "
-                                                  "profiles/r01c_pmc_hbm_traffic.csv")
+                                                  "source file named in profiles/traffic.json[\"_source\"]")
             except Exception:
                 pass
+
+    codec_line = None
+    if args.mode == "infer" and not args.no_roofline:
+        # the HBM-bound leg of configs[4]: K1 (to_spectro) and K2 (to_audio) on the same 64 segments, torch events on the
+        # launch stream around each call, averaged over K eager iterations after the timed region
+        pre = model.preprocess
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(max(args.steps, 5))]
+        with torch.no_grad():
+            for e in evs:
+                e[0].record()
+                spec, pha, norm = pre.to_spectro(lr)
+                e[1].record()
+                pre.to_audio(spec, norm, pha)
+                e[2].record()
+        torch.cuda.synchronize()
+        k1 = sum(e[0].elapsed_time(e[1]) for e in evs) / len(evs) * 1e-3
+        k2 = sum(e[1].elapsed_time(e[2]) for e in evs) / len(evs) * 1e-3
+        bytes_k = 261120.0 * batch
+        codec_line = {"bound": "hbm", "k1_us": round(k1 * 1e6, 2), "k2_us": round(k2 * 1e6, 2),
+                      "k1_GBps": round(bytes_k / k1 / 1e9, 1), "k2_GBps": round(bytes_k / k2 / 1e9, 1), "peak_GBps": 8000.0,
+                      "k2_frac": round(bytes_k / k2 / 8e12, 5), "bytes_per_clip": 261120,
+                      "note": "K1 / K2 move 16.7 MB each at batch 64 (2 us at 8 TB/s): launch-latency-dominated at this "
+                              "size (SURVEY 8d); bench.py --mode codec reports them at 4096 clips"}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -356,8 +408,12 @@ def main():
                                             "per second summed over GPUs (weak scaling)") if args.mode == "train" else
                                            "one step = %d segments through inference + stitching per GPU" % batch},
                "roofline": roofline}
+        if codec_line is not None:
+            out["roofline_codec"] = codec_line
         if world == 1 and not args.no_cpu_baseline and args.mode == "train" and args.config == 1:
             out["cpu_baseline"] = cpu_baseline_train(os.cpu_count() or 1)
+        if world == 1 and not args.no_cpu_baseline and args.mode == "infer":
+            out["cpu_baseline"] = cpu_baseline_infer(os.cpu_count() or 1, lr_rate)
         print(json.dumps(out), flush=True)
     if use_ddp:
         dist.destroy_process_group()

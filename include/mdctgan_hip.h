@@ -44,6 +44,8 @@ extern "C" {
 #define MG_ACT_TANH 3
 
 int mg_abi_version(void);
+/* sizeof(mg_conv_geom) as the library was built (13 ints = 52 bytes): a binding checks its own struct against it */
+int mg_conv_geom_size(void);
 
 /* ------------------------------------------------------------------------------------------
  * K1  MDCT4.forward (models/mdct.py:392-425) fused with Audio2MDCT.normalize

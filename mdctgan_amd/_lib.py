@@ -43,6 +43,7 @@ _W = C.POINTER(WinoTiles)
 # name -> (restype, argtypes); must list every symbol include/mdctgan_hip.h declares
 SIGNATURES = {
     "mg_abi_version": (_i, []),
+    "mg_conv_geom_size": (_i, []),
     "mg_mdct4_forward": (_i, [_p, _i, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "mg_mdct4_num_frames": (_i, [_i, _i]),
     "mg_imdct4_forward": (_i, [_p, _i, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _p, _p, _p, _i, _i, _p, _p]),

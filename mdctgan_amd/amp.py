@@ -50,12 +50,27 @@ class GradScaler:
         self._slots = {}
 
     def _slot(self, optimizer) -> int:
-        key = id(optimizer)
-        if key not in self._slots:
-            if len(self._slots) >= self.SLOTS:
-                raise RuntimeError("GradScaler tracks at most %d optimisers" % self.SLOTS)
-            self._slots[key] = len(self._slots)
-        return self._slots[key]
+        """One found_inf slot per live optimiser.  Slots are keyed by the optimiser object (a weak reference, so a
+        recycled id() can never alias a dead optimiser's slot); an optimiser that was replaced
+        (Pix2PixHDModel.update_fixed_params) hands its slot over through release()."""
+        import weakref
+        for slot, ref in list(self._slots.items()):
+            o = ref()
+            if o is optimizer:
+                return slot
+            if o is None:
+                del self._slots[slot]
+        for slot in range(self.SLOTS):
+            if slot not in self._slots:
+                self._slots[slot] = weakref.ref(optimizer)
+                return slot
+        raise RuntimeError("GradScaler tracks at most %d optimisers" % self.SLOTS)
+
+    def release(self, optimizer):
+        """Free the slot of an optimiser that is being discarded."""
+        for slot, ref in list(self._slots.items()):
+            if ref() is optimizer or ref() is None:
+                del self._slots[slot]
 
     def scale(self, loss):
         return loss * self.state[0] if self.enabled else loss

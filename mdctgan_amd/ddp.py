@@ -7,10 +7,17 @@ enqueued.  Averaging (1/world) is folded into the Adam kernel's grad_scale, so n
 gradients.  Buckets are contiguous arena ranges, sized for xGMI (default 128 MiB: few, large collectives --
 each GPU has 7 point-to-point links, a ring moves 2(N-1)/N of the payload over one link per hop).
 
-Semantics: losses are batch means and every layer is per-sample (InstanceNorm), so the average of
-per-rank gradients equals the single-process gradient on the concatenated batch.
+Semantics: losses are batch means and every convolution / InstanceNorm layer is per-sample, so the average
+of per-rank gradients equals the single-process gradient on the concatenated batch.  The ONE cross-sample coupling is
+the BatchNorm2d inside the bottleneck-transformer blocks (``--n_blocks_attn_g > 0``, the default and configs[2]/[3]):
+each rank normalises with its own batch statistics -- what torch's DistributedDataParallel does with a plain
+``nn.BatchNorm2d`` -- so N ranks x batch 8 is not bit-equivalent to one rank x batch 8N there.  The running buffers
+are broadcast from rank 0 at attach() time and then evolve per rank; ``sync_buffers(model)`` averages them across
+ranks (call it before saving a checkpoint so rank 0's file does not carry rank-0-only statistics).
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.distributed as dist
@@ -24,9 +31,18 @@ class ArenaReducer:
     slices: [(param, offset, padded_numel)] in arena order.  writes_per_step: how many wgrad launches write each
     parameter's gradient during one backward (1 for G; 2 for D: the fake and the real pass)."""
 
-    def __init__(self, flat_g, slices, writes_per_step=1, bucket_bytes=128 << 20, group=None, tail_bytes=None):
+    def __init__(self, flat_g, slices, writes_per_step=1, bucket_bytes=128 << 20, group=None, tail_bytes=None,
+                 mode=None):
         self.flat_g, self.group = flat_g, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # "allreduce": one RCCL all-reduce per bucket (RCCL picks its own rings over the 7 xGMI links);
+        # "rs_ag": reduce-scatter + all-gather per bucket -- the two halves of the same collective issued separately,
+        # so each moves (N-1)/N of the bucket over all links at once on a fully connected node and the all-gather of
+        # bucket i overlaps the reduce-scatter of bucket i+1 on RCCL's stream (SURVEY section 5).  Needs a backend with
+        # reduce_scatter_tensor (RCCL; not gloo), buckets are then padded to a multiple of the world size.
+        self.mode = mode or os.environ.get("MDCTGAN_DDP_MODE", "allreduce")
+        if self.mode not in ("allreduce", "rs_ag"):
+            raise ValueError("MDCTGAN_DDP_MODE must be allreduce or rs_ag")
         self.writes_per_step = writes_per_step
         self.active = True
         self.force = dist.is_initialized()       # a 1-rank group still goes through RCCL (used to test the code path)
@@ -60,7 +76,16 @@ class ArenaReducer:
 
     def _launch(self, i):
         lo, hi, _ = self.buckets[i]
-        if self.world > 1 or self.force:
+        if not (self.world > 1 or self.force):
+            return
+        n = hi - lo
+        if self.mode == "rs_ag" and n % self.world == 0:
+            shard = n // self.world
+            rank = dist.get_rank(self.group)
+            mine = self.flat_g[lo + rank * shard:lo + (rank + 1) * shard]
+            dist.reduce_scatter_tensor(mine, self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.works.append(dist.all_gather_into_tensor(self.flat_g[lo:hi], mine, group=self.group, async_op=True))
+        else:
             self.works.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
                                               async_op=True))
 
@@ -91,19 +116,57 @@ def broadcast_arena(flat_p, src=0, group=None):
         dist.broadcast(flat_p, src=src, group=group)
 
 
-def attach(model, bucket_bytes=128 << 20, group=None):
-    """Wire a Pix2PixHDModel for data parallelism: broadcast both parameter arenas from rank 0, create the G and D
-    reducers and fold 1/world into the Adam kernels."""
+def attach_optimizer(opt, writes_per_step=1, bucket_bytes=128 << 20, group=None):
+    """Broadcast one FusedAdam's parameter arena from rank 0, create its gradient reducer and fold 1/world into the Adam
+    kernel.  Returns the reducer (also used by Pix2PixHDModel.update_fixed_params when it replaces optimizer_G)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    slices = opt.arena_slices()
+    broadcast_arena(opt.flat_p, 0, group)
+    red = ArenaReducer(opt.flat_g, slices, writes_per_step, bucket_bytes, group)
+    red.bucket_bytes = bucket_bytes
+    opt.grad_scale = 1.0 / world
+    opt.pre_step_hook = red.finish
+    return red
+
+
+def _loose_tensors(model, arena_params):
+    """Every parameter that is NOT in an optimiser arena (frozen / not optimised yet: --niter_fix_global) and every
+    floating-point module buffer (BatchNorm running statistics)."""
+    out = []
+    for net in (getattr(model, "netG", None), getattr(model, "netD", None)):
+        if net is None:
+            continue
+        out += [p.data for p in net.parameters() if id(p) not in arena_params]
+        out += [b for b in net.buffers() if b.dtype.is_floating_point]
+    return out
+
+
+def sync_buffers(model, group=None):
+    """Average the BatchNorm running statistics over ranks (see the module docstring)."""
+    if not dist.is_initialized():
+        return
+    world = dist.get_world_size(group)
+    for net in (getattr(model, "netG", None), getattr(model, "netD", None)):
+        if net is None:
+            continue
+        for name, b in net.named_buffers():
+            if b.dtype.is_floating_point:
+                dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
+                b.div_(world)
+
+
+def attach(model, bucket_bytes=128 << 20, group=None):
+    """Wire a Pix2PixHDModel for data parallelism: broadcast both parameter arenas, every parameter outside them and
+    every floating-point buffer from rank 0, create the G and D reducers and fold 1/world into the Adam kernels."""
     reducers = {}
     d_writes = 1 if getattr(model, "stack_d_loss_passes", False) else 2    # wgrad launches per D parameter and step
+    arena_params = set()
     for name, opt, writes in (("G", model.optimizer_G, 1), ("D", model.optimizer_D, d_writes)):
-        slices = opt.arena_slices()
-        broadcast_arena(opt.flat_p, 0, group)
-        red = ArenaReducer(opt.flat_g, slices, writes, bucket_bytes, group)
-        opt.grad_scale = 1.0 / world
-        opt.pre_step_hook = red.finish
-        reducers[name] = red
+        reducers[name] = attach_optimizer(opt, writes, bucket_bytes, group)
+        arena_params.update(id(p) for p, _, _ in opt.arena_slices())
+    if dist.is_initialized():
+        for t in _loose_tensors(model, arena_params):
+            dist.broadcast(t, src=0, group=group)
     reducers["D"].active = False
     model.reducers = reducers
     return reducers

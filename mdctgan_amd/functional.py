@@ -109,13 +109,17 @@ def bump_weight_epoch():
     WEIGHT_EPOCH[0] += 1
 
 
-def _cached_wino_weights(g, weight):
+def _cached_wino_weights(g, weight, fill=True):
+    """fill=False (graph capture): a valid cached image is used (it was made by an eager warm-up call and outlives the
+    graph), a miss returns None -- a tensor allocated from the capturing graph's pool must not be cached."""
     w = weight.detach()
     key = (weight._version, WEIGHT_EPOCH[0], w.data_ptr(), g.Ci, g.Co, g.KH, g.stride, g.precision,
            ops.wino_weights_bytes(g))
     hit = getattr(weight, "_mg_u_cache", None)
     if hit is not None and hit[0] == key:
         return hit[1]
+    if not fill:
+        return None
     u = ops.wino_weights(g, w)
     weight._mg_u_cache = (key, u)
     return u
@@ -184,8 +188,9 @@ class _ConvFn(torch.autograd.Function):
             # Winograd layers: transform the weights once, reuse the image for the data gradient of this step
             if ctx.needs_input_grad[0]:
                 u = ops.wino_weights(g, w)
-            elif x.is_cuda and not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing():
-                u = _cached_wino_weights(g, weight)        # inference: once per weight version
+            elif x.is_cuda and not torch.is_grad_enabled():
+                # inference: once per weight version (a captured inference graph reads the images its warm-up made)
+                u = _cached_wino_weights(g, weight, fill=not torch.cuda.is_current_stream_capturing())
             else:
                 u = None
             # ... and keep B^T x B for the weight gradient (A dy A^T is shared between dgrad and wgrad in backward)

@@ -32,9 +32,42 @@ def generate(model, lr_segments: torch.Tensor, batch_size: int = 64, gen_overlap
     if lr_segments.dim() != 2:
         raise ValueError("lr_segments must be [n_seg, T]")
     outs = []
-    with torch.no_grad():
-        for i in range(0, lr_segments.shape[0], batch_size):
-            _, sr_audio, _, _, _ = model.inference(lr_segments[i:i + batch_size])
-            outs.append(sr_audio)
+    # generate_audio.py:27 calls model.eval() first: the BatchNorm2d layers of the bottleneck-attention blocks must use
+    # their running statistics (and must not update them) during inference
+    was_training = model.training
+    model.eval()
+    try:
+        with torch.no_grad():
+            for i in range(0, lr_segments.shape[0], batch_size):
+                _, sr_audio, _, _, _ = model.inference(lr_segments[i:i + batch_size])
+                outs.append(sr_audio)
+    finally:
+        model.train(was_training)
     audio = torch.cat(outs, dim=0)                      # [n_seg, 1, 1, T]
     return ops.stitch_segments(audio, audio.shape[-1], gen_overlap)
+
+
+def make_graphed_generate(model, lr_segments: torch.Tensor, batch_size: int = 64, gen_overlap: int = 0, warmup: int = 2):
+    """Capture generate() for a fixed segment count into one hipGraph (K1, ~120 generator launches, K2 and the stitch
+    kernel per batch) and return run(lr_segments) -> stitched waveform (a buffer that the next replay overwrites).  The
+    generator weights must not change between capture and replay without re-capturing: the Winograd layers read the
+    transformed-weight images cached by the warm-up calls."""
+    static_in = lr_segments.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(max(warmup, 1)):
+            generate(model, static_in, batch_size, gen_overlap)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = generate(model, static_in, batch_size, gen_overlap)
+
+    def run(lr=None):
+        if lr is not None:
+            static_in.copy_(lr, non_blocking=True)
+        graph.replay()
+        return out
+    run.graph = graph
+    return run

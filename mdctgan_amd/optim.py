@@ -82,6 +82,22 @@ class FusedAdam(torch.optim.Optimizer):
         Fh.mark_fresh(self._params)
 
     @torch.no_grad()
+    def sync_lr(self):
+        """Copy param_groups[0]['lr'] into the device-resident clock when it changed.  step() calls this; a captured
+        (hipGraph) step never runs step() again, so its replay wrapper calls it before every replay
+        (Pix2PixHDModel.make_graphed_step) -- otherwise update_learning_rate() would have no effect on graphed training."""
+        if not self._built:
+            self._build()
+        if not self._params:
+            return
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_on_device:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("learning-rate changes must happen outside graph capture")
+            self.state[1] = lr
+            self._lr_on_device = lr
+
+    @torch.no_grad()
     def step(self, closure=None, scaler_state=None, scaler_slot=0):
         """scaler_state (mdctgan_amd.amp.GradScaler.state): the gradients hold loss-scaled values; check them for
         inf / nan, divide by the scale inside the Adam kernel and skip the whole update -- step counter included --
@@ -94,12 +110,8 @@ class FusedAdam(torch.optim.Optimizer):
         bump_weight_epoch()                   # parameters change through raw pointers: invalidate cached weight images
         self._step += 1
         g = self.param_groups[0]
-        lr, (b1, b2), eps = float(g["lr"]), g["betas"], g["eps"]
-        if lr != self._lr_on_device:          # schedule change (update_learning_rate): refresh the device copy
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("learning-rate changes must happen outside graph capture")
-            self.state[1] = lr
-            self._lr_on_device = lr
+        (b1, b2), eps = g["betas"], g["eps"]
+        self.sync_lr()                        # schedule change (update_learning_rate): refresh the device copy
         # contiguous runs of parameters that received a gradient this step (normally a single run = everything)
         runs, start = [], None
         for i, p in enumerate(self._params):

@@ -383,15 +383,19 @@ class Pix2PixHDModel(BaseModel):
             else:
                 loss_D.backward(**d_kw)
                 self.optimizer_D.step()
-        return loss_dict
+        # detached: the caller only prints / logs these; handing out the graph would keep one generator's worth of
+        # saved activations alive until the next iteration overwrites the dict
+        return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss_dict.items()}
 
     def make_graphed_step(self, lr_audio, hr_audio, warmup=3):
         """Capture one full optimize_parameters() iteration (~540 launches: forward, both backward passes, both Adam
         steps) into a hipGraph and return run(lr, hr) -> loss dict, which copies the batch into the captured input
         buffers and replays.  The optimiser clock and learning rate live in HBM, so replays advance Adam exactly
         like eager steps.  The warm-up iterations are real training steps."""
-        if getattr(self, "reducers", None):
-            raise NotImplementedError("graph capture of the data-parallel step (RCCL inside the graph) is not enabled")
+        if getattr(self, "reducers", None) and os.environ.get("MDCTGAN_DDP_GRAPH", "0") != "1":
+            # RCCL collectives are capturable (ProcessGroupNCCL records them into the graph from its own stream), but
+            # that path has only been exercised with a 1-rank group on this hardware pool: opt-in
+            raise NotImplementedError("graph capture of the data-parallel step is opt-in: MDCTGAN_DDP_GRAPH=1")
         static_lr, static_hr = lr_audio.clone(), hr_audio.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -404,7 +408,16 @@ class Pix2PixHDModel(BaseModel):
         with torch.cuda.graph(graph):
             losses = self.optimize_parameters(static_lr, static_hr)
 
+        captured = (self.optimizer_G, self.optimizer_D)
+
         def run(lr=None, hr=None):
+            if (self.optimizer_G, self.optimizer_D) != captured:
+                raise RuntimeError("an optimiser was replaced after capture (update_fixed_params): "
+                                   "call make_graphed_step() again")
+            # the captured launches read lr from the device-resident Adam clock; FusedAdam.step() -- which refreshes
+            # it -- is not called again after capture, so pick up update_learning_rate() here
+            self.optimizer_G.sync_lr()
+            self.optimizer_D.sync_lr()
             if lr is not None:
                 static_lr.copy_(lr, non_blocking=True)
             if hr is not None:
@@ -433,7 +446,22 @@ class Pix2PixHDModel(BaseModel):
         self.save_network(self.netD, "D", which_epoch, self.gpu_ids)
 
     def update_fixed_params(self):
-        self.optimizer_G = FusedAdam(list(self.netG.parameters()), lr=self.lr, betas=(self.beta1, 0.999))
+        """pix2pixHD_model.py:640-646 (after --niter_fix_global epochs: optimise the whole generator).  The new optimiser
+        owns a new arena, so everything that was wired to the old one follows: the GradScaler's found_inf slot, and under
+        data parallelism the gradient reducer, the 1/world gradient scale and the pre-step hook."""
+        old = self.optimizer_G
+        params = [p for p in self.netG.parameters() if p.requires_grad]
+        for p in params:                       # the new arena copies the current values; gradients start fresh
+            p.grad = None
+        self.optimizer_G = FusedAdam(params, lr=self.lr, betas=(self.beta1, 0.999))
+        if self.scaler is not None:
+            self.scaler.release(old)
+        red = getattr(self, "reducers", None)
+        if red:
+            from . import ddp
+            red["G"].close()
+            red["G"] = ddp.attach_optimizer(self.optimizer_G, 1, red["G"].bucket_bytes, red["G"].group)
+            red["G"].active = True
 
     def update_learning_rate(self):
         lrd = self.lr / self.niter_decay

@@ -35,6 +35,17 @@ def test_library_exports_every_declared_symbol():
     assert _lib.load().mg_mdct4_num_frames(7936, 512) == 32
 
 
+def test_conv_geom_layout_matches_library_and_integration_doc():
+    """The binding's struct, the library's sizeof and the struct INTEGRATION.md tells a maintainer to write agree
+    (a 12-field struct would make the library read garbage as `precision`)."""
+    assert ctypes.sizeof(_lib.ConvGeom) == _lib.load().mg_conv_geom_size() == 52
+    doc = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    m = re.search(r"class ConvGeom\(ctypes\.Structure\):.*?for n in \((.*?)\)\]", doc, flags=re.S)
+    assert m, "INTEGRATION.md no longer shows the ConvGeom binding"
+    fields = re.findall(r'"(\w+)"', m.group(1))
+    assert fields == [f[0] for f in _lib.ConvGeom._fields_]
+
+
 def test_host_tensors_are_refused():
     import torch
     with pytest.raises(_lib.HipLibraryError):

@@ -1,6 +1,8 @@
-"""The convolution passes at the FULL layer sizes of BASELINE configs[1] (the shapes bench.py runs: tuned tile / split
-plans, Winograd, 32-deep kernels, per-class split-K, tiled single-channel kernels), where a float64 CPU reference of the
-whole tensor would take minutes.  Size-independent properties instead:
+"""The convolution passes at the FULL layer sizes of BASELINE configs[1], configs[2] (netG=local: the 2048-channel 4x8
+trunk, the 128-channel 64x128 local blocks, the ngf-128 stride-2 ladder, the third discriminator scale) and configs[4]
+(batch-64 inference plans) -- the shapes bench.py runs: tuned tile / split plans, Winograd, 32-deep kernels, per-class
+split-K, tiled single-channel kernels -- where a float64 CPU reference of the whole tensor would take minutes.
+Size-independent properties instead:
 
 * exactness on a sample: 48 random output pixels (all output channels) of the forward pass against a float64
   evaluation of those pixels' receptive fields;
@@ -31,6 +33,43 @@ SHAPES = [
     ("d256_512_b16", 16, 17, 33, 256, 512, 4, 1, 2, False),
     ("dlast_b16", 16, 18, 34, 512, 1, 4, 1, 2, False),
     ("d1_256_512", 8, 9, 17, 256, 512, 4, 1, 2, False),
+]
+
+# configs[2] (netG=local ngf 64 -> global branch ngf 128 on the 64x128 average-pooled input, 4 stride-2 stages, 2048-channel
+# 4x8 trunk; local branch: 128-channel blocks at 64x128; num_D 3: a third discriminator scale on the 32x64 input).  The
+# discriminator runs the batch-stacked [fake, real] pass, i.e. batch 16.
+SHAPES_CFG2 = [
+    ("c2_trunk2048", 8, 4, 8, 2048, 2048, 3, 1, 1, True),
+    ("c2_local128", 8, 64, 128, 128, 128, 3, 1, 1, True),
+    ("c2_gstem128", 8, 64, 128, 2, 128, 7, 1, 3, True),
+    ("c2_gdown128", 8, 64, 128, 128, 256, 3, 2, 1, False),
+    ("c2_gdown256", 8, 32, 64, 256, 512, 3, 2, 1, False),
+    ("c2_gdown512", 8, 16, 32, 512, 1024, 3, 2, 1, False),
+    ("c2_gdown1024", 8, 8, 16, 1024, 2048, 3, 2, 1, False),
+    ("c2_bot_in", 8, 4, 8, 2048, 512, 1, 1, 0, False),          # bottleneck-transformer 1x1 projections
+    ("c2_bot_qkv", 8, 4, 8, 512, 1536, 1, 1, 0, False),
+    ("c2_bot_out", 8, 4, 8, 512, 2048, 1, 1, 0, False),
+    ("c2_d2_3_64_b16", 16, 64, 128, 3, 64, 4, 2, 2, False),     # second scale, stacked batch
+    ("c2_d2_64_128_b16", 16, 33, 65, 64, 128, 4, 2, 2, False),
+    ("c2_d2_128_256_b16", 16, 17, 33, 128, 256, 4, 2, 2, False),
+    ("c2_d2_256_512_b16", 16, 9, 17, 256, 512, 4, 1, 2, False),
+    ("c2_d2_last_b16", 16, 10, 18, 512, 1, 4, 1, 2, False),
+    ("c2_d3_3_64_b16", 16, 32, 64, 3, 64, 4, 2, 2, False),      # third scale
+    ("c2_d3_64_128_b16", 16, 17, 33, 64, 128, 4, 2, 2, False),
+    ("c2_d3_128_256_b16", 16, 9, 17, 128, 256, 4, 2, 2, False),
+    ("c2_d3_256_512_b16", 16, 5, 9, 256, 512, 4, 1, 2, False),
+    ("c2_d3_last_b16", 16, 6, 10, 512, 1, 4, 1, 2, False),
+]
+
+# configs[4]: generate_audio at batch 64 (forward only; tile plans added for these M).  (name, B, H, W, Ci, Co, k, s, p, reflect)
+SHAPES_CFG4 = [
+    ("c4_bottleneck", 64, 8, 16, 1024, 1024, 3, 1, 1, True),
+    ("c4_down512", 64, 16, 32, 512, 1024, 3, 2, 1, False),
+    ("c4_down256", 64, 32, 64, 256, 512, 3, 2, 1, False),
+    ("c4_down128", 64, 64, 128, 128, 256, 3, 2, 1, False),
+    ("c4_down64", 64, 128, 256, 64, 128, 3, 2, 1, False),
+    ("c4_stem", 64, 128, 256, 2, 64, 7, 1, 3, True),
+    ("c4_head", 64, 128, 256, 64, 1, 7, 1, 3, True),
 ]
 
 
@@ -66,7 +105,7 @@ def sample_reference(x, w, bias, B, H, W, Ci, Co, k, s, p, reflect, OH, OW, n=48
 
 
 @pytest.mark.parametrize("prec", ["f32", "f16"])
-@pytest.mark.parametrize("shape", SHAPES, ids=[s[0] for s in SHAPES])
+@pytest.mark.parametrize("shape", SHAPES + SHAPES_CFG2, ids=[s[0] for s in SHAPES + SHAPES_CFG2])
 def test_full_size_layer_properties(shape, prec):
     from mdctgan_amd import _lib, ops
     name, B, H, W, Ci, Co, k, s, p, reflect = shape
@@ -74,7 +113,7 @@ def test_full_size_layer_properties(shape, prec):
     g = ops.conv_geom(B, H, W, Ci, Co, k, k, s, p, reflect, _lib.PRECISION_F16 if hp else _lib.PRECISION_F32)
     gen = torch.Generator().manual_seed(len(name) + Ci)
     x = torch.randn(B, H, W, Ci, generator=gen)
-    w = torch.randn(Co, k, k, Ci, generator=gen) / np.sqrt(Ci * k * k)
+    w = torch.randn(Co * k * k * Ci, generator=gen).reshape(Co, k, k, Ci) / np.sqrt(Ci * k * k)
     bias = torch.randn(Co, generator=gen)
     dy = torch.randn(B, g.OH, g.OW, Co, generator=gen)
     if hp:   # the properties are stated for the values the kernels actually multiply
@@ -98,3 +137,26 @@ def test_full_size_layer_properties(shape, prec):
     ops.conv_wgrad(g, xd, dyd, dw, db)
     assert abs(lhs - dot64(wd, dw)) <= rtol * scale, (name, "wgrad", lhs, dot64(wd, dw), scale)
     assert (db.double().cpu() - dy.double().sum((0, 1, 2))).abs().max().item() <= 1e-4 * np.sqrt(B * g.OH * g.OW) * 4
+
+
+@pytest.mark.parametrize("shape", SHAPES_CFG4, ids=[s[0] for s in SHAPES_CFG4])
+def test_batch64_inference_plans(shape):
+    """configs[4] runs the generator forward at batch 64: every layer takes a tile plan (and, for the 3x3 blocks, a
+    Winograd GEMM shape) that no training shape exercises.  Forward exactness on 48 sampled output pixels against float64,
+    plus the no-grad path's cached transformed weights giving the same bits as the uncached call."""
+    from mdctgan_amd import _lib, ops
+    name, B, H, W, Ci, Co, k, s, p, reflect = shape
+    g = ops.conv_geom(B, H, W, Ci, Co, k, k, s, p, reflect, _lib.PRECISION_F32)
+    gen = torch.Generator(device=DEV).manual_seed(len(name) + Ci)
+    xd = torch.randn(B, H, W, Ci, generator=gen, device=DEV)          # up to 0.5 GB: drawn on the device
+    wd = torch.randn(Co * k * k * Ci, generator=gen, device=DEV).reshape(Co, k, k, Ci) / np.sqrt(Ci * k * k)
+    bd = torch.randn(Co, generator=gen, device=DEV)
+    y = ops.conv_fwd(g, xd, wd, bd)
+    idx, want = sample_reference(xd.cpu(), wd.cpu(), bd.cpu(), B, H, W, Ci, Co, k, s, p, reflect, g.OH, g.OW)
+    got = y[idx[:, 0], idx[:, 1], idx[:, 2]].double().cpu()
+    tol = 3e-5 * want.abs().max().item()
+    assert (got - want).abs().max().item() <= tol, (name, (got - want).abs().max().item(), want.abs().max().item())
+    u = ops.wino_weights(g, wd)
+    if u is not None:
+        y2 = ops.conv_fwd(g, xd, wd, bd, u=u)
+        assert torch.equal(y, y2), name

@@ -167,6 +167,21 @@ def test_step_matches_reference(golden):
             continue
         gr = g["gD/" + k]
         assert np.abs(p.grad.numpy() - gr).max() <= 1e-2 * np.abs(gr).max() + 1e-9, k  # conditioning-limited (see above)
+    # the generator gradients of the same iteration (gG/*: loss_G.backward() in the reference).  train_step has already
+    # stepped the weights, so redo the G backward on fresh deterministic nets.
+    netG2 = nets.fill_deterministic(nets.build_generator("global", 2, 1, 4, 4, 2, input_size=(32, 256)))
+    netD2 = nets.fill_deterministic(nets.MultiscaleDRef(3, ndf=8, n_layers=3, num_D=2))
+    ref2 = step.HotPathRef(netG2, netD2, step.CodecCfg(), num_D=2)
+    l2, _ = ref2.forward_losses(g["lr"], g["hr"])
+    (l2["G_GAN"] + l2["G_GAN_Feat"]).backward()
+    n_g = 0
+    for k, p in netG2.named_parameters():
+        if dead_bias(k):
+            continue
+        gr = g["gG/" + k]
+        assert np.abs(p.grad.numpy() - gr).max() <= 1e-2 * np.abs(gr).max() + 1e-9, k
+        n_g += 1
+    assert n_g >= 14
     for net, pre in ((netG, "pG_after/"), (netD, "pD_after/")):
         for k, p in net.state_dict().items():
             if not dead_bias(k):
