@@ -345,15 +345,17 @@ def main():
     if timer is not None and timer.records:
         n, flops, secs, conv_flops = timer.summary()[dominant]
         achieved = flops / secs / 1e12
-        peak = PEAK_F16_MFMA_TFLOPS if dominant.rstrip().endswith((", 2>", ", 3>")) else PEAK_F32_MFMA_TFLOPS
+        f16_kernel = dominant.startswith("conv_") and dominant.rstrip().endswith((", 2>", ", 3>"))   # TAG bit 1 instances
+        peak = PEAK_F16_MFMA_TFLOPS if f16_kernel else PEAK_F32_MFMA_TFLOPS
         roofline = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                     "launches": n, "avg_launch_us": round(secs / n * 1e6, 2),
                     "flops_per_launch": flops / n,
-                    "flops_definition": "FLOPs the kernel itself issues (2*M*N*K of its GEMM).  dense_nn64_kernel<1> / "
-                                        "dense_tn64_kernel<1, 1> / conv_fwd32_kernel<.., 1> are the batched Winograd "
-                                        "F(2x2,3x3) data-gradient / weight-gradient / forward GEMMs of a 3x3 layer whose "
-                                        "direct-convolution cost (SURVEY 8d, 2*MACs) is %.3g FLOP per launch" % (conv_flops / n),
+                    "flops_definition": "FLOPs the kernel itself issues (2*M*N*K of its GEMM, summed over the launches of this "
+                                        "symbol).  dgemm32g_kernel<BM, BN, 2, 2, A, B, 2> (csrc/dense_gemm.h) are the batched "
+                                        "Winograd-domain GEMMs: layouts (0, 0) forward, (0, 1) data gradient, (1, 1) weight gradient "
+                                        "of the F(2x2,3x3) / F(2x2,4x4) / F(4x4,2x2) layers; the direct-convolution cost of the same "
+                                        "layers (SURVEY 8d, 2*MACs) averages %.3g FLOP per launch" % (conv_flops / n),
                     "timed": ("HIP events recorded by the library on its launch stream right around this kernel, "
                               "every launch of %d eager iterations run right after the graph-replayed timed region" % args.steps) if use_graph else
                              "HIP events around every launch of this kernel inside the timed region"}

@@ -1147,6 +1147,88 @@ __global__ void colsum_partial_kernel(const float* __restrict__ a, long long M, 
 #include "wino42.h"
 #include "conv_smallc.h"
 namespace {
+#include "dense_gemm.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// Batched dense GEMMs of the Winograd families on dense_gemm.h (float32 precision; the f16 path keeps the convolution
+// kernels' dense instances).  pass 0: C[T][Co] = V[T][Kc] U[Co][Kc]^T; pass 1: dV[T][Kc] = Md[T][Co] U[Co][Kc];
+// pass 2: dU[Co][Kc] = Md[T][Co]^T V[T][Kc].
+// ---------------------------------------------------------------------------------------------------------
+struct DensePlan { int bm, bn, splits, cps; bool dma, ok; };
+struct DenseDims { long long M; int N, K; };
+inline DenseDims dense_dims(int pass, long long T, int Co, int Kc) {
+    if (pass == 0) return {T, Co, Kc};
+    if (pass == 1) return {T, Kc, Co};
+    return {(long long)Co, Kc, (int)T};
+}
+DensePlan dense_plan(int pass, int P, long long T, int Co, int Kc, bool hp) {
+    static const bool off = getenv("MG_NO_DENSE_GEMM") != nullptr;
+    static const bool no_dma = getenv("MG_DENSE_NO_DMA") != nullptr;
+    const DenseDims dd = dense_dims(pass, T, Co, Kc);
+    DensePlan p{64, 64, 1, 1 << 28, false, false};
+    if (off || hp || dd.N % 64 != 0 || dd.K % 4 != 0 || dd.K < 4 || dd.M < 1 || T >= (1LL << 31)) return p;
+    if (pass == 2 && dd.M % 4 != 0) return p;
+    // every operand of one position must stay below 2 GiB (32-bit byte offsets of the LDS-DMA path)
+    if ((double)dd.M * dd.K * 4.0 >= 2e9 || (double)dd.N * dd.K * 4.0 >= 2e9) return p;
+    p.ok = true;
+    // LDS-DMA staging: whole 32-deep chunks, or the weight-gradient GEMM (both operands [K][rows]: the K tail is zero-filled
+    // by the buffer range check)
+    p.dma = (dd.K % DG_BK == 0 || pass == 2) && !no_dma;
+    // Cost model calibrated on scripts/ubench/gemm_bench.hip (MI355X): the workgroups of one CU share its MFMA pipe, so a
+    // launch takes ceil(workgroups / 256) tile-times; efficiencies are the measured large-grid figures per tile; a grid with
+    // fewer than two workgroups per CU cannot cover its barrier drains (x 0.85); split-K pays one pass over the slabs.
+    struct Cand { int bm, bn; double eff_dma, eff_reg; };
+    static const Cand cands[4] = {{64, 64, 0.83, 0.71}, {64, 128, 0.885, 0.74}, {128, 64, 0.855, 0.74}, {128, 128, 0.91, 0.80}};
+    static const int split_opts[8] = {1, 2, 3, 4, 6, 8, 12, 16};
+    const int chunks = (dd.K + DG_BK - 1) / DG_BK;
+    int f_bm = 0, f_bn = 0, f_sp = 0;
+    if (const char* f = getenv("MG_FORCE_DENSE")) {      // tuning harness: "bm,bn,splits"
+        if (sscanf(f, "%d,%d,%d", &f_bm, &f_bn, &f_sp) != 3) f_bm = f_bn = f_sp = 0;
+    }
+    double best = 1e300;
+    for (const Cand& c : cands) {
+        if (dd.N % c.bn != 0) continue;
+        if (!p.dma && !((c.bm == 64 && c.bn == 64) || (c.bm == 128 && c.bn == 128))) continue;   // register-path instances
+        if (f_bm && (c.bm != f_bm || c.bn != f_bn)) continue;
+        const long long w = ((dd.M + c.bm - 1) / c.bm) * (long long)(dd.N / c.bn) * P;
+        const double tile_us = 2.0 * c.bm * c.bn * DG_BK / (157.3e12 / 256.0) * 1e6 / (p.dma ? c.eff_dma : c.eff_reg);
+        for (int sp : split_opts) {
+            if (sp > 1 && chunks / sp < 8) break;
+            if (f_sp && sp != f_sp) continue;
+            const int cps = (chunks + sp - 1) / sp;
+            const int spl = (chunks + cps - 1) / cps;
+            const long long wg = w * spl;
+            double t = (double)((wg + 255) / 256) * tile_us * (cps + 1.2);
+            if (wg < 512) t /= 0.85;
+            if (spl > 1) t += (double)(spl + 1) * P * (double)dd.M * dd.N * 4.0 / 4e12 * 1e6 + 3.0;
+            if (t < best) { best = t; p.bm = c.bm; p.bn = c.bn; p.splits = spl; p.cps = cps; }
+        }
+    }
+    if (best == 1e300) { p.ok = false; return p; }
+    if (p.splits == 1) p.cps = 1 << 28;
+    return p;
+}
+inline int dense_splits(int pass, int P, long long T, int Co, int Kc, bool hp) {
+    const DensePlan p = dense_plan(pass, P, T, Co, Kc, hp);
+    return p.ok ? p.splits : 0;
+}
+template <int AL, int BL>
+void dense_launch(const DensePlan& p, const DgArgs& a, hipStream_t st) {
+    if (p.dma) {
+        if (p.bm == 128 && p.bn == 128) dgemm32g_launch<128, 128, 2, 2, AL, BL>(a, st);
+        else if (p.bm == 64 && p.bn == 128) dgemm32g_launch<64, 128, 2, 2, AL, BL>(a, st);
+        else if (p.bm == 128 && p.bn == 64) dgemm32g_launch<128, 64, 2, 2, AL, BL>(a, st);
+        else dgemm32g_launch<64, 64, 2, 2, AL, BL>(a, st);
+    } else {
+        if (p.bm == 128) dgemm32_launch<128, 128, 4, 2, AL, BL>(a, st);
+        else dgemm32_launch<64, 64, 2, 2, AL, BL>(a, st);
+    }
+}
+void dense_name(int pass, const DensePlan& p, char* out, int out_len) {
+    const int al = pass == 2 ? DG_RC : DG_KC, bl = pass == 0 ? DG_KC : DG_RC;
+    if (p.dma) snprintf(out, out_len, "dgemm32g_kernel<%d, %d, 2, 2, %d, %d, 2>", p.bm, p.bn, al, bl);
+    else snprintf(out, out_len, "dgemm32_kernel<%d, %d, %d, 2, %d, %d, 0>", p.bm, p.bn, p.bm == 128 ? 4 : 2, al, bl);
+}
 
 Geom to_geom(const mg_conv_geom* g) {
     return Geom{g->B, g->H, g->W, g->Ci, g->OH, g->OW, g->Co, g->KH, g->KW, g->stride, g->pad, g->reflect};
@@ -1177,6 +1259,45 @@ inline void probe_begin(hipStream_t st) { if (g_probe_e0) hipEventRecord(g_probe
 inline void probe_end(hipStream_t st) {
     if (g_probe_e1) hipEventRecord(g_probe_e1, st);
     g_probe_e0 = g_probe_e1 = nullptr;
+}
+
+inline unsigned dense_grid(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+// Runs the GEMM (and its split-K combine) when the shape is eligible; false: the caller takes the convolution kernels.
+bool dense_wino_gemm(int pass, int P, long long T, int Co, int Kc, const float* A, const float* B, float* C, float* part,
+                     bool hp, hipStream_t st) {
+    const DensePlan p = dense_plan(pass, P, T, Co, Kc, hp);
+    if (!p.ok) return false;
+    const DenseDims dd = dense_dims(pass, T, Co, Kc);
+    DgArgs a{};
+    a.A = A; a.B = B; a.C = C; a.part = p.splits > 1 ? part : nullptr;
+    a.M = (int)dd.M; a.N = dd.N; a.K = dd.K;
+    a.P = P; a.splits = p.splits; a.cps = p.cps;
+    a.sc = dd.M * dd.N;
+    probe_begin(st);
+    if (pass == 0) {            // V [T][Kc] x U [Co][Kc]^T
+        a.lda = Kc; a.ldb = Kc; a.sa = T * Kc; a.sb = (long long)Co * Kc;
+        dense_launch<DG_KC, DG_KC>(p, a, st);
+    } else if (pass == 1) {     // Md [T][Co] x U [Co][Kc]
+        a.lda = Co; a.ldb = Kc; a.sa = T * Co; a.sb = (long long)Co * Kc;
+        dense_launch<DG_KC, DG_RC>(p, a, st);
+    } else {                    // Md [T][Co]^T x V [T][Kc]
+        a.lda = Co; a.ldb = Kc; a.sa = T * Co; a.sb = T * Kc;
+        dense_launch<DG_RC, DG_RC>(p, a, st);
+    }
+    probe_end(st);
+    if (p.splits > 1) {
+        const size_t n = (size_t)P * dd.M * dd.N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(dense_grid(n / 4)), dim3(256), 0, st, (const float*)part, p.splits, n, C,
+                           0);
+    }
+    return true;
+}
+inline size_t slab_count(int old_splits, int dense) {      // split-K slabs a workspace must hold (either path may run)
+    const int m = old_splits > dense ? old_splits : dense;
+    return m > 1 ? (size_t)m : 0;
 }
 
 
@@ -1390,7 +1511,7 @@ size_t wino_fwd_ws(const mg_conv_geom* g) {
     const WinoDims d = wino_dims(g);
     const TilePlan tp = gemm_plan(d.T, g->Co, g->Ci / BK, 16, true, 0);
     return (al256((size_t)16 * g->Co * g->Ci) + al256((size_t)16 * d.T * g->Ci) + al256((size_t)16 * d.T * g->Co) +
-            (tp.splits > 1 ? al256((size_t)tp.splits * 16 * d.T * g->Co) : 0)) * sizeof(float) + 256;
+            al256(slab_count(tp.splits, dense_splits(0, 16, d.T, g->Co, g->Ci, prec_h(g))) * 16 * d.T * g->Co)) * sizeof(float) + 256;
 }
 inline bool wino_dgrad_padded() {
     static const bool v = [] { const char* e = getenv("MG_WINO_DGRAD"); return e && !strcmp(e, "padded"); }();
@@ -1401,7 +1522,7 @@ size_t wino_dgrad_ws(const mg_conv_geom* g) {
     if (!wino_dgrad_padded()) {      // U | A dy A^T | dV | dd | split-K slabs
         const TilePlan tp = gemm_plan(d.T, g->Ci, g->Co / BK, 16, true, 1);
         return (al256((size_t)16 * g->Co * g->Ci) + al256((size_t)16 * d.T * g->Co) + 2 * al256((size_t)16 * d.T * g->Ci) +
-                (tp.splits > 1 ? al256((size_t)tp.splits * 16 * d.T * g->Ci) : 0)) * sizeof(float) + 256;
+                al256(slab_count(tp.splits, dense_splits(1, 16, d.T, g->Co, g->Ci, prec_h(g))) * 16 * d.T * g->Ci)) * sizeof(float) + 256;
     }
     const long long T = g->reflect ? d.Tp : d.T;
     const TilePlan tp = gemm_plan(T, g->Ci, g->Co / BK, 16, true, 1);
@@ -1429,12 +1550,15 @@ WinoWgradPlan wino_wgrad_plan(const mg_conv_geom* g) {
     splits = (chunks + cps - 1) / cps;
     return {big, tiles, splits, cps};
 }
+inline size_t wino_wgrad_slabs(const mg_conv_geom* g) {
+    return slab_count(wino_wgrad_plan(g).splits, dense_splits(2, 16, wino_dims(g).T, g->Co, g->Ci, prec_h(g)));
+}
 size_t wino_wgrad_ws(const mg_conv_geom* g) {
     const WinoDims d = wino_dims(g);
     const WinoWgradPlan p = wino_wgrad_plan(g);
     const size_t cs = (mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co) + 255) / 4;
     return (al256((size_t)16 * d.T * g->Ci) + al256((size_t)16 * d.T * g->Co) + al256((size_t)16 * g->Co * g->Ci) +
-            (p.splits > 1 ? al256((size_t)p.splits * 16 * g->Co * g->Ci) : 0) + al256(cs)) * sizeof(float) + 256;
+            al256(wino_wgrad_slabs(g) * 16 * g->Co * g->Ci) + al256(cs)) * sizeof(float) + 256;
 }
 
 template <typename Launch>
@@ -1504,6 +1628,7 @@ int wino_fwd(const mg_conv_geom* g, const float* x, const float* w, const float*
     if (v_keep) V = v_keep;          // the caller keeps B^T x B for the weight gradient
     hipLaunchKernelGGL(wino_input_xform_kernel, dim3(wino_grid((size_t)d.T * g->Ci / 4)), dim3(256), 0, st, x, g->B, g->H,
                        g->W, g->Ci, d.TH, d.TW, 1, g->reflect, V);
+    if (!dense_wino_gemm(0, 16, d.T, g->Co, g->Ci, V, U, Mx, part, prec_h(g), st)) {
     const Geom gg{1, 1, (int)d.T, g->Ci, 1, (int)d.T, g->Co, 1, 1, 1, 0, 0};
     const TilePlan tp = gemm_plan(d.T, g->Co, g->Ci / BK, 16, true, 0);
     float* pp = tp.splits > 1 ? part : nullptr;
@@ -1533,8 +1658,9 @@ int wino_fwd(const mg_conv_geom* g, const float* x, const float* w, const float*
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(wino_grid(n / 4)), dim3(256), 0, st, (const float*)pp, tp.splits,
                            n, g->Co, (const float*)nullptr, MG_ACT_NONE, Mx);
     }
+    }
     hipLaunchKernelGGL(wino_output_xform_kernel, dim3(wino_grid((size_t)d.T * g->Co / 4)), dim3(256), 0, st,
-                       (const float*)Mx, g->B, d.TH, d.TW, g->Co, bias, act, y, (int)hp);
+                       (const float*)Mx, g->B, d.TH, d.TW, g->Co, bias, act, y, (int)prec_h(g));
     MG_CHECK_LAUNCH();
     return MG_OK;
 }
@@ -1555,6 +1681,7 @@ int wino_dgrad_t(const mg_conv_geom* g, const float* dy, const float* w, const f
     if (md_keep) Md = md_keep;       // the caller keeps A dy A^T for the weight gradient
     hipLaunchKernelGGL(wino_dy_xform_kernel, dim3(wino_grid((size_t)T * g->Co / 4)), dim3(256), 0, st, dy, g->B, d.TH,
                        d.TW, g->Co, Md);
+    if (!dense_wino_gemm(1, 16, T, g->Co, g->Ci, Md, U, dV, part, prec_h(g), st)) {
     const Geom gg{1, 1, (int)T, g->Ci, 1, (int)T, g->Co, 1, 1, 1, 0, 0};
     const TilePlan tp = gemm_plan(T, g->Ci, g->Co / BK, 16, true, 1);
     float* pp = tp.splits > 1 ? part : nullptr;
@@ -1578,6 +1705,7 @@ int wino_dgrad_t(const mg_conv_geom* g, const float* dy, const float* w, const f
         const size_t n = (size_t)16 * T * g->Ci;
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(wino_grid(n / 4)), dim3(256), 0, st, (const float*)pp, tp.splits,
                            n, g->Ci, (const float*)nullptr, MG_ACT_NONE, dV);
+    }
     }
     hipLaunchKernelGGL(wino_dd_xform_kernel, dim3(wino_grid((size_t)T * g->Ci / 4)), dim3(256), 0, st, (const float*)dV, T,
                        g->Ci, dd);
@@ -1652,6 +1780,7 @@ int wino_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw
     if (md_in) Md = const_cast<float*>(md_in);
     else hipLaunchKernelGGL(wino_dy_xform_kernel, dim3(wino_grid((size_t)d.T * g->Co / 4)), dim3(256), 0, st, dy, g->B,
                             d.TH, d.TW, g->Co, Md);
+    if (!dense_wino_gemm(2, 16, d.T, g->Co, g->Ci, Md, V, dU, part, prec_h(g), st)) {
     const Geom gg{1, 1, (int)d.T, g->Ci, 1, (int)d.T, g->Co, 1, 1, 1, 0, 0};
     float* target = p.splits > 1 ? part : dU;
     const Batch bt{d.T * g->Ci, d.T * g->Co, (long long)g->Co * g->Ci, 0};
@@ -1677,6 +1806,7 @@ int wino_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw
         const size_t n = (size_t)16 * g->Co * g->Ci;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(wino_grid(n / 4)), dim3(256), 0, st, (const float*)part, p.splits, n,
                            dU, 0);
+    }
     }
     hipLaunchKernelGGL(wino_dweight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 4)), dim3(256), 0, st,
                        (const float*)dU, g->Co, g->Ci, dw, accumulate);
@@ -1717,24 +1847,27 @@ WinoWgradPlan wino4_wgrad_plan(const mg_conv_geom* g) {
     splits = (chunks + cps - 1) / cps;
     return {big, tiles, splits, cps};
 }
+inline size_t wino4_wgrad_slabs(const mg_conv_geom* g) {
+    return slab_count(wino4_wgrad_plan(g).splits, dense_splits(2, 25, wino4_dims(g).T, g->Co, g->Ci, false));
+}
 size_t wino4_fwd_ws(const mg_conv_geom* g) {
     const Wino4Dims d = wino4_dims(g);
     const TilePlan tp = gemm_plan(d.T, g->Co, g->Ci / BK, 25, true, 0);
     return (al256((size_t)25 * g->Co * g->Ci) + al256((size_t)25 * d.T * g->Ci) + al256((size_t)25 * d.T * g->Co) +
-            (tp.splits > 1 ? al256((size_t)tp.splits * 25 * d.T * g->Co) : 0)) * sizeof(float) + 256;
+            al256(slab_count(tp.splits, dense_splits(0, 25, d.T, g->Co, g->Ci, false)) * 25 * d.T * g->Co)) * sizeof(float) + 256;
 }
 size_t wino4_dgrad_ws(const mg_conv_geom* g) {      // U | A dy A^T | dV | dd | split-K slabs
     const Wino4Dims d = wino4_dims(g);
     const TilePlan tp = gemm_plan(d.T, g->Ci, g->Co / BK, 25, true, 1);
     return (al256((size_t)25 * g->Co * g->Ci) + al256((size_t)25 * d.T * g->Co) + 2 * al256((size_t)25 * d.T * g->Ci) +
-            (tp.splits > 1 ? al256((size_t)tp.splits * 25 * d.T * g->Ci) : 0)) * sizeof(float) + 256;
+            al256(slab_count(tp.splits, dense_splits(1, 25, d.T, g->Co, g->Ci, false)) * 25 * d.T * g->Ci)) * sizeof(float) + 256;
 }
 size_t wino4_wgrad_ws(const mg_conv_geom* g) {
     const Wino4Dims d = wino4_dims(g);
     const WinoWgradPlan p = wino4_wgrad_plan(g);
     const size_t cs = (mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co) + 255) / 4;
     return (al256((size_t)25 * d.T * g->Ci) + al256((size_t)25 * d.T * g->Co) + al256((size_t)25 * g->Co * g->Ci) +
-            (p.splits > 1 ? al256((size_t)p.splits * 25 * g->Co * g->Ci) : 0) + al256(cs)) * sizeof(float) + 256;
+            al256(wino4_wgrad_slabs(g) * 25 * g->Co * g->Ci) + al256(cs)) * sizeof(float) + 256;
 }
 
 int wino4_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act, float* ws,
@@ -1750,6 +1883,7 @@ int wino4_fwd(const mg_conv_geom* g, const float* x, const float* w, const float
     if (v_keep) V = v_keep;
     hipLaunchKernelGGL(wino4_input_xform_kernel, dim3(wino_grid((size_t)d.T * g->Ci / 2)), dim3(256), 0, st, x, g->B, g->H,
                        g->W, g->Ci, d.TH, d.TW, V);
+    if (!dense_wino_gemm(0, 25, d.T, g->Co, g->Ci, V, U, Mx, part, false, st)) {
     const Geom gg{1, 1, (int)d.T, g->Ci, 1, (int)d.T, g->Co, 1, 1, 1, 0, 0};
     const TilePlan tp = gemm_plan(d.T, g->Co, g->Ci / BK, 25, true, 0);
     float* pp = tp.splits > 1 ? part : nullptr;
@@ -1772,6 +1906,7 @@ int wino4_fwd(const mg_conv_geom* g, const float* x, const float* w, const float
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(wino_grid(n / 4)), dim3(256), 0, st, (const float*)pp, tp.splits,
                            n, g->Co, (const float*)nullptr, MG_ACT_NONE, Mx);
     }
+    }
     hipLaunchKernelGGL(wino4_output_xform_kernel, dim3(wino_grid((size_t)d.T * g->Co / 2)), dim3(256), 0, st,
                        (const float*)Mx, g->B, d.TH, d.TW, g->Co, bias, act, y);
     MG_CHECK_LAUNCH();
@@ -1793,6 +1928,7 @@ int wino4_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* d
     if (md_keep) Md = md_keep;
     hipLaunchKernelGGL(wino4_dy_xform_kernel, dim3(wino_grid((size_t)T * g->Co / 2)), dim3(256), 0, st, dy, g->B, d.TH,
                        d.TW, g->Co, Md);
+    if (!dense_wino_gemm(1, 25, T, g->Co, g->Ci, Md, U, dV, part, false, st)) {
     const Geom gg{1, 1, (int)T, g->Ci, 1, (int)T, g->Co, 1, 1, 1, 0, 0};
     const TilePlan tp = gemm_plan(T, g->Ci, g->Co / BK, 25, true, 1);
     float* pp = tp.splits > 1 ? part : nullptr;
@@ -1812,6 +1948,7 @@ int wino4_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* d
         const size_t n = (size_t)25 * T * g->Ci;
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(wino_grid(n / 4)), dim3(256), 0, st, (const float*)pp, tp.splits,
                            n, g->Ci, (const float*)nullptr, MG_ACT_NONE, dV);
+    }
     }
     hipLaunchKernelGGL(wino4_dd_xform_kernel, dim3(wino_grid((size_t)T * g->Ci / 2)), dim3(256), 0, st, (const float*)dV, T,
                        g->Ci, dd);
@@ -1835,6 +1972,7 @@ int wino4_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* d
     if (md_in) Md = const_cast<float*>(md_in);
     else hipLaunchKernelGGL(wino4_dy_xform_kernel, dim3(wino_grid((size_t)d.T * g->Co / 2)), dim3(256), 0, st, dy, g->B,
                             d.TH, d.TW, g->Co, Md);
+    if (!dense_wino_gemm(2, 25, d.T, g->Co, g->Ci, Md, V, dU, part, false, st)) {
     const Geom gg{1, 1, (int)d.T, g->Ci, 1, (int)d.T, g->Co, 1, 1, 1, 0, 0};
     float* target = p.splits > 1 ? part : dU;
     const Batch bt{d.T * g->Ci, d.T * g->Co, (long long)g->Co * g->Ci, 0};
@@ -1853,6 +1991,7 @@ int wino4_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* d
         const size_t n = (size_t)25 * g->Co * g->Ci;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(wino_grid(n / 4)), dim3(256), 0, st, (const float*)part, p.splits, n,
                            dU, 0);
+    }
     }
     hipLaunchKernelGGL(wino4_dweight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 2)), dim3(256), 0, st,
                        (const float*)dU, g->Co, g->Ci, dw, accumulate);
@@ -1900,24 +2039,27 @@ WinoWgradPlan wino42_wgrad_plan(const mg_conv_geom* g) {
     splits = (chunks + cps - 1) / cps;
     return {big, tiles, splits, cps};
 }
+inline size_t wino42_wgrad_slabs(const mg_conv_geom* g) {
+    return slab_count(wino42_wgrad_plan(g).splits, dense_splits(2, 25, wino42_dims(g).T, g->Co, wino42_dims(g).K4, false));
+}
 size_t wino42_fwd_ws(const mg_conv_geom* g) {
     const Wino42Dims d = wino42_dims(g);
     const TilePlan tp = gemm_plan(d.T, g->Co, d.K4 / BK, 25, true, 0);
     return (al256((size_t)25 * g->Co * d.K4) + al256((size_t)25 * d.T * d.K4) + al256((size_t)25 * d.T * g->Co) +
-            (tp.splits > 1 ? al256((size_t)tp.splits * 25 * d.T * g->Co) : 0)) * sizeof(float) + 256;
+            al256(slab_count(tp.splits, dense_splits(0, 25, d.T, g->Co, d.K4, false)) * 25 * d.T * g->Co)) * sizeof(float) + 256;
 }
 size_t wino42_dgrad_ws(const mg_conv_geom* g) {      // U | A dy A^T | dV | dd | split-K slabs
     const Wino42Dims d = wino42_dims(g);
     const TilePlan tp = gemm_plan(d.T, d.K4, g->Co / BK, 25, true, 1);
     return (al256((size_t)25 * g->Co * d.K4) + al256((size_t)25 * d.T * g->Co) + 2 * al256((size_t)25 * d.T * d.K4) +
-            (tp.splits > 1 ? al256((size_t)tp.splits * 25 * d.T * d.K4) : 0)) * sizeof(float) + 256;
+            al256(slab_count(tp.splits, dense_splits(1, 25, d.T, g->Co, d.K4, false)) * 25 * d.T * d.K4)) * sizeof(float) + 256;
 }
 size_t wino42_wgrad_ws(const mg_conv_geom* g) {
     const Wino42Dims d = wino42_dims(g);
     const WinoWgradPlan p = wino42_wgrad_plan(g);
     const size_t cs = (mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co) + 255) / 4;
     return (al256((size_t)25 * d.T * d.K4) + al256((size_t)25 * d.T * g->Co) + al256((size_t)25 * g->Co * d.K4) +
-            (p.splits > 1 ? al256((size_t)p.splits * 25 * g->Co * d.K4) : 0) + al256(cs)) * sizeof(float) + 256;
+            al256(wino42_wgrad_slabs(g) * 25 * g->Co * d.K4) + al256(cs)) * sizeof(float) + 256;
 }
 
 int wino42_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act, float* ws,
@@ -1933,6 +2075,7 @@ int wino42_fwd(const mg_conv_geom* g, const float* x, const float* w, const floa
     if (v_keep) V = v_keep;
     hipLaunchKernelGGL(wino42_input_xform_kernel, dim3(wino_grid((size_t)d.T * d.K4 / 2)), dim3(256), 0, st, x, g->B, g->H,
                        g->W, g->Ci, d.TH, d.TW, V);
+    if (!dense_wino_gemm(0, 25, d.T, g->Co, d.K4, V, U, Mx, part, false, st)) {
     const Geom gg{1, 1, (int)d.T, d.K4, 1, (int)d.T, g->Co, 1, 1, 1, 0, 0};
     const TilePlan tp = gemm_plan(d.T, g->Co, d.K4 / BK, 25, true, 0);
     float* pp = tp.splits > 1 ? part : nullptr;
@@ -1955,6 +2098,7 @@ int wino42_fwd(const mg_conv_geom* g, const float* x, const float* w, const floa
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(wino_grid(n / 4)), dim3(256), 0, st, (const float*)pp, tp.splits,
                            n, g->Co, (const float*)nullptr, MG_ACT_NONE, Mx);
     }
+    }
     hipLaunchKernelGGL(wino42_output_xform_kernel, dim3(wino_grid((size_t)d.T * g->Co / 2)), dim3(256), 0, st,
                        (const float*)Mx, g->B, g->OH, g->OW, d.TH, d.TW, g->Co, bias, act, y);
     MG_CHECK_LAUNCH();
@@ -1976,6 +2120,7 @@ int wino42_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* 
     if (md_keep) Md = md_keep;
     hipLaunchKernelGGL(wino42_dy_xform_kernel, dim3(wino_grid((size_t)T * g->Co / 2)), dim3(256), 0, st, dy, g->B, g->OH,
                        g->OW, d.TH, d.TW, g->Co, Md);
+    if (!dense_wino_gemm(1, 25, T, g->Co, d.K4, Md, U, dV, part, false, st)) {
     const Geom gg{1, 1, (int)T, d.K4, 1, (int)T, g->Co, 1, 1, 1, 0, 0};
     const TilePlan tp = gemm_plan(T, d.K4, g->Co / BK, 25, true, 1);
     float* pp = tp.splits > 1 ? part : nullptr;
@@ -1995,6 +2140,7 @@ int wino42_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* 
         const size_t n = (size_t)25 * T * d.K4;
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(wino_grid(n / 4)), dim3(256), 0, st, (const float*)pp, tp.splits,
                            n, d.K4, (const float*)nullptr, MG_ACT_NONE, dV);
+    }
     }
     hipLaunchKernelGGL(wino4_dd_xform_kernel, dim3(wino_grid((size_t)T * d.K4 / 2)), dim3(256), 0, st, (const float*)dV, T,
                        d.K4, dd);
@@ -2018,6 +2164,7 @@ int wino42_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* 
     if (md_in) Md = const_cast<float*>(md_in);
     else hipLaunchKernelGGL(wino42_dy_xform_kernel, dim3(wino_grid((size_t)d.T * g->Co / 2)), dim3(256), 0, st, dy, g->B,
                             g->OH, g->OW, d.TH, d.TW, g->Co, Md);
+    if (!dense_wino_gemm(2, 25, d.T, g->Co, d.K4, Md, V, dU, part, false, st)) {
     const Geom gg{1, 1, (int)d.T, d.K4, 1, (int)d.T, g->Co, 1, 1, 1, 0, 0};
     float* target = p.splits > 1 ? part : dU;
     const Batch bt{d.T * d.K4, d.T * g->Co, (long long)g->Co * d.K4, 0};
@@ -2036,6 +2183,7 @@ int wino42_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* 
         const size_t n = (size_t)25 * g->Co * d.K4;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(wino_grid(n / 4)), dim3(256), 0, st, (const float*)part, p.splits, n,
                            dU, 0);
+    }
     }
     hipLaunchKernelGGL(wino42_dweight_xform_kernel, dim3(wino_grid((size_t)g->Co * d.K4 / 2)), dim3(256), 0, st,
                        (const float*)dU, g->Co, g->Ci, dw, accumulate);
@@ -2153,7 +2301,14 @@ double mg_conv_plan_flops(int pass, const mg_conv_geom* g) {
 int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
     if (!geom_ok(g) || !out || out_len < 64) return MG_ERR_ARG;
     const int kq = mg_conv_rowdot_kq(g);
-    if (wino_ok(g) && !kq) {
+    if (wino_ok(g) && !kq && !(pass == 1 && wino_dgrad_padded()) &&
+        dense_plan(pass, 16, wino_dims(g).T, g->Co, g->Ci, prec_h(g)).ok) {
+        dense_name(pass, dense_plan(pass, 16, wino_dims(g).T, g->Co, g->Ci, prec_h(g)), out, out_len);
+    } else if (wino4_ok(g) && !kq && dense_plan(pass, 25, wino4_dims(g).T, g->Co, g->Ci, false).ok) {
+        dense_name(pass, dense_plan(pass, 25, wino4_dims(g).T, g->Co, g->Ci, false), out, out_len);
+    } else if (wino42_ok(g) && !kq && dense_plan(pass, 25, wino42_dims(g).T, g->Co, wino42_dims(g).K4, false).ok) {
+        dense_name(pass, dense_plan(pass, 25, wino42_dims(g).T, g->Co, wino42_dims(g).K4, false), out, out_len);
+    } else if (wino_ok(g) && !kq) {
         const WinoDims d = wino_dims(g);
         if (pass == 0) {
             const TilePlan tp = gemm_plan(d.T, g->Co, g->Ci / BK, 16, true, 0);
@@ -2512,7 +2667,7 @@ int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, floa
             const WinoDims d = wino_dims(g);
             float* cs = (float*)workspace + al256((size_t)16 * d.T * g->Ci) + al256((size_t)16 * d.T * g->Co) +
                         al256((size_t)16 * g->Co * g->Ci) +
-                        (wino_wgrad_plan(g).splits > 1 ? al256((size_t)wino_wgrad_plan(g).splits * 16 * g->Co * g->Ci) : 0);
+                        al256(wino_wgrad_slabs(g) * 16 * g->Co * g->Ci);
             return mg_colsum(dy, (long long)g->B * g->OH * g->OW, g->Co, dbias, accumulate, cs,
                              mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co), stream);
         }
@@ -2538,7 +2693,7 @@ int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, floa
             const Wino4Dims d = wino4_dims(g);
             const WinoWgradPlan p4 = wino4_wgrad_plan(g);
             float* cs = (float*)workspace + al256((size_t)25 * d.T * g->Ci) + al256((size_t)25 * d.T * g->Co) +
-                        al256((size_t)25 * g->Co * g->Ci) + (p4.splits > 1 ? al256((size_t)p4.splits * 25 * g->Co * g->Ci) : 0);
+                        al256((size_t)25 * g->Co * g->Ci) + al256(wino4_wgrad_slabs(g) * 25 * g->Co * g->Ci);
             return mg_colsum(dy, (long long)g->B * g->OH * g->OW, g->Co, dbias, accumulate, cs,
                              mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co), stream);
         }
@@ -2552,7 +2707,7 @@ int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, floa
             const Wino42Dims d = wino42_dims(g);
             const WinoWgradPlan p4 = wino42_wgrad_plan(g);
             float* cs = (float*)workspace + al256((size_t)25 * d.T * d.K4) + al256((size_t)25 * d.T * g->Co) +
-                        al256((size_t)25 * g->Co * d.K4) + (p4.splits > 1 ? al256((size_t)p4.splits * 25 * g->Co * d.K4) : 0);
+                        al256((size_t)25 * g->Co * d.K4) + al256(wino42_wgrad_slabs(g) * 25 * g->Co * d.K4);
             return mg_colsum(dy, (long long)g->B * g->OH * g->OW, g->Co, dbias, accumulate, cs,
                              mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co), stream);
         }

@@ -93,7 +93,7 @@ def test_generator_backward(tag):
     grads, dxs = {}, {}
     for name, dt in (("f64", torch.float64), ("f32", torch.float32)):
         net = oracle_g(tag, dt)
-        xx = x.to(dt).requires_grad_()
+        xx = x.clone().to(dt).requires_grad_()      # clone: x.to(float32) is x itself
         (net(xx) * gy.to(dt)).sum().backward()
         grads[name] = {k: p.grad.numpy() for k, p in net.named_parameters()}
         dxs[name] = xx.grad.numpy()
@@ -233,12 +233,29 @@ def test_step_gradients_against_reference_golden(golden):
     l64, _ = o64.forward_losses(g["lr"], g["hr"])
     (l64["G_GAN"] + l64["G_GAN_Feat"]).backward()
     g64G = {k: p.grad.numpy().copy() for k, p in o64.netG.named_parameters()}
-    o64.netG.zero_grad(); o64.netD.zero_grad()
-    l64, _ = o64.forward_losses(g["lr"], g["hr"])
-    ((l64["D_fake"] + l64["D_real"]) * 0.5).backward()
+    # The discriminator gradients depend on the fake spectrogram, i.e. on the toy generator's conditioning-limited
+    # output (1e-3 between any two float32 runs): isolate the discriminator-loss wiring by feeding the HIP discriminator
+    # the REFERENCE's own fake (fixture `sr_spectro`) through the same batch-stacked pass the step uses.
+    from mdctgan_amd import functional as Fh
+    model_d = make_model()                  # fresh deterministic weights (the step above has already moved `model`'s)
+    model_d.optimizer_D.zero_grad()
+    sr_gold = torch.from_numpy(g["sr_spectro"]).to(DEV)
+    pred = model_d.netD.forward(Fh.d_input_pair(lr_d, sr_gold, hr_d, float(model.norm_range[0])))
+    loss_D = 0
+    for scale_out in pred:
+        l_fake, l_real = Fh.mse_const_pair_loss(scale_out[-1], 0.0, 1.0)
+        loss_D = loss_D + (l_fake + l_real) * 0.5
+    loss_D.backward()
+    # ... and the float64 yardstick on the same fake
+    o64.netD.zero_grad()
+    two = o64.two_channel
+    srg = torch.from_numpy(g["sr_spectro"]).double()
+    l64D = 0.5 * (onets.lsgan_loss(o64.netD(torch.cat((lr_s, two(srg)), 1)), False)
+                  + onets.lsgan_loss(o64.netD(torch.cat((lr_s, two(hr_s)), 1)), True))
+    l64D.backward()
     g64D = {k: p.grad.numpy().copy() for k, p in o64.netD.named_parameters()}
     checked = 0
-    for net, pre, g64 in ((model.netG, "gG/", g64G), (model.netD, "gD/", g64D)):
+    for net, pre, g64 in ((model.netG, "gG/", g64G), (model_d.netD, "gD/", g64D)):
         for k, p in net.named_parameters():
             if _dead_bias(k, g64[k], g64):
                 continue
@@ -346,7 +363,7 @@ def test_graphed_step_equals_eager_steps(golden):
 
 @pytest.mark.parametrize("cfg", [dict(dim=64, fmap=(4, 8), heads=2, dim_head=16, layers=2, B=2),
                                  dict(dim=128, fmap=(8, 16), heads=2, dim_head=128, layers=1, B=2),
-                                 dict(dim=2048, fmap=(4, 8), heads=8, dim_head=64, layers=2, B=8)],
+                                 dict(dim=2048, fmap=(4, 8), heads=8, dim_head=64, layers=2, B=8, init="normal")],
                          ids=["tokens32", "tokens128_d128", "configs2_dim2048_8x64_tokens32"])
 def test_bottleneck_transformer_stack(cfg):
     """K10 (BatchNorm2d + MHSA kernels + 1x1 convs) against the oracle's restatement of BottleStack (parity of that
@@ -357,17 +374,29 @@ def test_bottleneck_transformer_stack(cfg):
     x = torch.randn(cfg["B"], cfg["dim"], *cfg["fmap"], generator=gen)
     gy = torch.randn(cfg["B"], cfg["dim"], *cfg["fmap"], generator=gen)
     res = {}
+
+    def fill(net):
+        # configs[2] size: the closed-form sine fill drives the 2048-channel softmax logits to +-40 (float32 CPU itself is
+        # then 5 % off float64: nothing to judge against), so this case uses weights_init's N(0, 0.02) from a fixed seed
+        if cfg.get("init") == "normal":
+            torch.manual_seed(5)
+            ref = onets.BotStackRef(cfg["dim"], cfg["fmap"], cfg["dim"], cfg["layers"], 4, cfg["heads"], cfg["dim_head"])
+            onets.init_weights(ref, torch.Generator().manual_seed(17))
+            net.load_state_dict(ref.state_dict())
+            return net
+        return onets.fill_deterministic(net)
+
     for name, dt in (("f64", torch.float64), ("f32", torch.float32)):
-        net = onets.fill_deterministic(onets.BotStackRef(cfg["dim"], cfg["fmap"], cfg["dim"], cfg["layers"], 4,
-                                                         cfg["heads"], cfg["dim_head"])).to(dt).train()
+        net = fill(onets.BotStackRef(cfg["dim"], cfg["fmap"], cfg["dim"], cfg["layers"], 4,
+                                     cfg["heads"], cfg["dim_head"])).to(dt).train()
         xx = x.clone().to(dt).requires_grad_()
         y = net(xx)
         (y * gy.to(dt)).sum().backward()
         res[name] = dict(y=y.detach().numpy(), dx=xx.grad.numpy(), grads={k: p.grad.numpy() for k, p in net.named_parameters()},
                          bufs={k: b.numpy() for k, b in net.named_buffers()})
-    hip = onets.fill_deterministic(networks.BottleStack(dim=cfg["dim"], fmap_size=cfg["fmap"], dim_out=cfg["dim"],
-                                                        num_layers=cfg["layers"], proj_factor=4, heads=cfg["heads"],
-                                                        dim_head=cfg["dim_head"], downsample=False)).to(DEV).train()
+    hip = fill(networks.BottleStack(dim=cfg["dim"], fmap_size=cfg["fmap"], dim_out=cfg["dim"],
+                                    num_layers=cfg["layers"], proj_factor=4, heads=cfg["heads"],
+                                    dim_head=cfg["dim_head"], downsample=False)).to(DEV).train()
     assert list(hip.state_dict().keys()) == list(onets.BotStackRef(cfg["dim"], cfg["fmap"], cfg["dim"], cfg["layers"], 4,
                                                                    cfg["heads"], cfg["dim_head"]).state_dict().keys())
     xd = x.clone().to(DEV).requires_grad_()
@@ -385,8 +414,7 @@ def test_bottleneck_transformer_stack(cfg):
             np.testing.assert_allclose(b.cpu().numpy(), res["f64"]["bufs"][k], rtol=1e-4, atol=1e-6, err_msg=k)
     # eval mode uses the running statistics
     hip.eval()
-    ref = onets.fill_deterministic(onets.BotStackRef(cfg["dim"], cfg["fmap"], cfg["dim"], cfg["layers"], 4,
-                                                     cfg["heads"], cfg["dim_head"])).double().eval()
+    ref = onets.BotStackRef(cfg["dim"], cfg["fmap"], cfg["dim"], cfg["layers"], 4, cfg["heads"], cfg["dim_head"]).double().eval()
     with torch.no_grad():
         ye = hip(x.to(DEV))
     sd = {k: v.double().cpu() for k, v in hip.state_dict().items()}
