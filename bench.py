@@ -345,7 +345,8 @@ def main():
     if timer is not None and timer.records:
         n, flops, secs, conv_flops = timer.summary()[dominant]
         achieved = flops / secs / 1e12
-        f16_kernel = dominant.startswith("conv_") and dominant.rstrip().endswith((", 2>", ", 3>"))   # TAG bit 1 instances
+        f16_kernel = dominant.startswith("hgemm") or (     # float16 GEMMs (conv_h16.h) / TAG bit 1 convolution instances
+            dominant.startswith("conv_") and dominant.rstrip().endswith((", 2>", ", 3>")))
         peak = PEAK_F16_MFMA_TFLOPS if f16_kernel else PEAK_F32_MFMA_TFLOPS
         roofline = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,

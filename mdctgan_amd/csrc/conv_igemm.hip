@@ -1300,6 +1300,9 @@ inline size_t slab_count(int old_splits, int dense) {      // split-K slabs a wo
     return m > 1 ? (size_t)m : 0;
 }
 
+#include "dense_gemm_h.h"
+#include "conv_h16.h"
+
 
 // The 32-deep forward kernel needs dynamic LDS above the 64 KB static limit for its 128x128 tile.
 inline bool fwd32_enabled() { static const bool off = getenv("MG_NO_BK32") != nullptr; return !off; }
@@ -1487,8 +1490,10 @@ WgradPlan wgrad_plan(const mg_conv_geom* g) {
 // ---------------------------------------------------------------------------------------------------------
 // Winograd F(2x2,3x3) orchestration (transforms in wino.h, the 16 GEMMs as one batched implicit-GEMM launch)
 // ---------------------------------------------------------------------------------------------------------
+bool h16_ok(const mg_conv_geom* g);
 bool wino_ok(const mg_conv_geom* g) {
     static const bool off = getenv("MG_NO_WINOGRAD") != nullptr;
+    if (h16_ok(g)) return false;             // weight-dominated autocast layers take the float16 GEMM path (conv_h16.h)
     static const bool off_h = getenv("MG_NO_WINOGRAD_F16") != nullptr;
     // f16 GEMMs are fast enough that Winograd only pays where the 16 transformed-weight matrices are amortised over
     // many tiles: wide layers (>= 256 channels) with >= 256 tiles (the 1024-channel 8x16 blocks of configs[1]; not the
@@ -2301,7 +2306,9 @@ double mg_conv_plan_flops(int pass, const mg_conv_geom* g) {
 int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
     if (!geom_ok(g) || !out || out_len < 64) return MG_ERR_ARG;
     const int kq = mg_conv_rowdot_kq(g);
-    if (wino_ok(g) && !kq && !(pass == 1 && wino_dgrad_padded()) &&
+    if (h16_ok(g) && !kq) {
+        snprintf(out, out_len, pass == 1 ? "hgemm_kernel<128, 64, 2, 2, true>" : "hgemm_kernel<128, 128, 4, 2, false>");
+    } else if (wino_ok(g) && !kq && !(pass == 1 && wino_dgrad_padded()) &&
         dense_plan(pass, 16, wino_dims(g).T, g->Co, g->Ci, prec_h(g)).ok) {
         dense_name(pass, dense_plan(pass, 16, wino_dims(g).T, g->Co, g->Ci, prec_h(g)), out, out_len);
     } else if (wino4_ok(g) && !kq && dense_plan(pass, 25, wino4_dims(g).T, g->Co, g->Ci, false).ok) {
@@ -2403,6 +2410,7 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
 
 size_t mg_conv_fwd_workspace(const mg_conv_geom* g) {
     if (!geom_ok(g)) return 0;
+    if (h16_ok(g)) return h16_fwd_ws(g);
     if (wino_ok(g)) return wino_fwd_ws(g);
     if (wino4_ok(g) && !mg_conv_rowdot_kq(g)) return wino4_fwd_ws(g);
     if (wino42_ok(g)) return wino42_fwd_ws(g);
@@ -2411,6 +2419,7 @@ size_t mg_conv_fwd_workspace(const mg_conv_geom* g) {
 }
 size_t mg_conv_dgrad_workspace(const mg_conv_geom* g) {
     if (!geom_ok(g)) return 0;
+    if (h16_ok(g)) return h16_dgrad_ws(g);
     if (wino_ok(g)) return wino_dgrad_ws(g);
     if (wino4_ok(g)) return wino4_dgrad_ws(g);
     if (wino42_ok(g)) return wino42_dgrad_ws(g);
@@ -2420,6 +2429,7 @@ size_t mg_conv_dgrad_workspace(const mg_conv_geom* g) {
 
 size_t mg_conv_wino_weights_bytes(const mg_conv_geom* g) {
     if (!geom_ok(g) || mg_conv_rowdot_kq(g)) return 0;
+    if (h16_ok(g)) return h16_weights_bytes(g);         // the float16 weight copy of the autocast GEMM path (conv_h16.h)
     if (wino4_ok(g)) return (size_t)25 * g->Co * g->Ci * sizeof(float);
     if (wino42_ok(g)) return (size_t)25 * g->Co * 4 * g->Ci * sizeof(float);
     if (!wino_ok(g)) return 0;
@@ -2427,6 +2437,7 @@ size_t mg_conv_wino_weights_bytes(const mg_conv_geom* g) {
 }
 int mg_conv_wino_prepare(const mg_conv_geom* g, const float* w, float* u, void* stream) {
     if (!mg_conv_wino_weights_bytes(g) || !w || !u || !aligned16(w) || !aligned16(u)) return MG_ERR_ARG;
+    if (h16_ok(g)) return h16_prepare(g, w, u, (hipStream_t)stream);
     if (wino4_ok(g)) {
         hipLaunchKernelGGL(wino4_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 2)), dim3(256), 0,
                            (hipStream_t)stream, w, g->Co, g->Ci, u);
@@ -2446,7 +2457,7 @@ int mg_conv_wino_prepare(const mg_conv_geom* g, const float* w, float* u, void* 
 }
 
 size_t mg_conv_wino_tiles_bytes(const mg_conv_geom* g, int which) {
-    if (!mg_conv_wino_weights_bytes(g)) return 0;
+    if (!mg_conv_wino_weights_bytes(g) || h16_ok(g)) return 0;
     if (wino4_ok(g)) {
         const Wino4Dims d4 = wino4_dims(g);
         return which == 0 ? (size_t)25 * d4.T * g->Ci * sizeof(float) : which == 1 ? (size_t)25 * d4.T * g->Co * sizeof(float) : 0;
@@ -2484,6 +2495,9 @@ int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const f
     if (!geom_ok(g) || !x || !w || !y) return MG_ERR_ARG;
     if (!wino_tiles_ok(g, wt)) return MG_ERR_ARG;
     const float* u = wt ? wt->u : nullptr;
+    if (h16_ok(g) && workspace && workspace_bytes >= h16_fwd_ws(g) && aligned16(x) && aligned16(w) && aligned16(y) &&
+        aligned16(workspace) && (!bias || aligned16(bias)))
+        return h16_fwd(g, x, w, bias, y, act, (char*)workspace, (hipStream_t)stream, u);
     if (mg_conv_rowdot_kq(g) && aligned16(x) && aligned16(w)) {
         probe_begin((hipStream_t)stream);
         const int rc = mg_conv_rowdot_fwd(g, x, w, bias, y, act, stream);
@@ -2548,6 +2562,9 @@ int mg_conv_dgrad_w(const mg_conv_geom* g, const float* dy, const float* w, cons
     if (!wino_tiles_ok(g, wt)) return MG_ERR_ARG;
     const float* u = wt ? wt->u : nullptr;
     if (g->reflect && g->stride != 1) return MG_ERR_UNSUPPORTED;
+    if (h16_ok(g) && !bias && act == MG_ACT_NONE && workspace && workspace_bytes >= h16_dgrad_ws(g) && aligned16(dy) &&
+        aligned16(w) && aligned16(dx) && aligned16(workspace))
+        return h16_dgrad(g, dy, w, dx, (char*)workspace, (hipStream_t)stream, u);
     if (smallc_dgrad_ok(g) && !bias && act == MG_ACT_NONE && aligned16(dy)) {
         probe_begin((hipStream_t)stream);
         const int rc = smallc_dgrad(g, dy, w, dx, (hipStream_t)stream);
@@ -2638,6 +2655,7 @@ int mg_colsum(const float* a, long long M, int C, float* out, int accumulate, vo
 size_t mg_conv_wgrad_workspace(const mg_conv_geom* g) {
     if (!geom_ok(g)) return 0;
     if (mg_conv_rowdot_kq(g)) return mg_conv_rowdot_wgrad_workspace(g);
+    if (h16_ok(g)) return h16_wgrad_ws(g);
     if (wino_ok(g)) return wino_wgrad_ws(g);
     if (wino4_ok(g)) return wino4_wgrad_ws(g);
     if (wino42_ok(g)) return wino42_wgrad_ws(g);
@@ -2658,6 +2676,14 @@ int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, floa
         const int rc = mg_conv_rowdot_wgrad(g, x, dy, dw, dbias, accumulate, workspace, workspace_bytes, stream);
         probe_end((hipStream_t)stream);
         return rc;
+    }
+    if (h16_ok(g) && aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace)) {
+        const int rc = h16_wgrad(g, x, dy, dw, accumulate, (char*)workspace, (hipStream_t)stream);
+        if (rc != MG_OK) return rc;
+        if (dbias)
+            return mg_colsum(dy, (long long)g->B * g->OH * g->OW, g->Co, dbias, accumulate, (char*)workspace + h16_wgrad_cs_offset(g),
+                             mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co), stream);
+        return MG_OK;
     }
     if (wino_ok(g) && aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace)) {
         const int rc = wino_wgrad(g, x, dy, dw, accumulate, (float*)workspace, (hipStream_t)stream, wt ? wt->v : nullptr,

@@ -1,0 +1,203 @@
+// Dense GEMM on the f16 MFMA pipe (v_mfma_f32_32x32x16_f16, float32 accumulation) for the autocast (--fp16) path:
+//   C[M][N] (float32) = A[M][K] (float16) * B[N][K]^T (float16), both operands k-contiguous, staged by LDS-DMA.
+// Used for the small-spatial, weight-dominated convolutions of BASELINE configs[2]/[3] (the 2048-channel 4x8 trunk: 75 MB of
+// float16 weights against 1 MB of activations per layer): the activation side is materialised as a float16 im2col matrix
+// by a pre-pass (conv_h16.h), so forward, data gradient and weight gradient are all this one kernel --
+//   forward        Y    [px][Co]       = Xcol  [px][(tap, ci)]  * W16  [Co][(tap, ci)]^T
+//   data gradient  dX   [px][Ci]       = dYcol [px][(tap, co)]  * W16t [Ci][(tap, co)]^T
+//   weight grad.   dW   [Co][(tap,ci)] = dYt   [Co][px]         * XcolT[(tap, ci)][px]^T
+// Same structure as dgemm32g_kernel (dense_gemm.h): 64-deep chunks = 128-byte rows, XOR-swizzled unpadded LDS images,
+// buffer_load ... lds issued from inline asm with counted vmcnt, two buffers, one barrier per chunk; one ds_read_b128 is the
+// 8-half operand of one MFMA.  K % 64 == 0.  Included inside the anonymous namespace, after dense_gemm.h.
+#pragma once
+
+constexpr int HG_BK = 64;          // halves per chunk row (128 bytes)
+
+struct HgArgs {
+    const void* A;           // float16 [M][lda]
+    const void* B;           // float16 [N][ldb]
+    float* C;                // float32 [M][N]
+    float* part;             // split-K slabs [splits][M][N] (nullptr: direct)
+    const float* bias;       // [N] or nullptr (direct path only)
+    int M, N, K, lda, ldb;
+    int tiles_m, tiles_n, splits, cps;
+    int round_f16;           // round the result through float16 (autocast output), direct path only
+    int accumulate;          // C += result (direct path only)
+    // BRC instances (data gradient): B is [K][N] with N contiguous -- the OHWI weights W[co][tap][n = ci] read with
+    // k = tap * Co + co, i.e. k row (tap, co) starts at element (co * ldb + tap * b_tap_stride); ldb = KH*KW*Ci is the
+    // distance between consecutive co, b_cpt = Co / 64 the chunks per tap.  A plain [K][N] matrix: ldb = N, b_cpt = 1 << 30.
+    int b_cpt, b_tap_stride;
+};
+
+template <int BM, int BN, int WGM, int WGN, bool BRC = false>
+struct HgCfg {
+    static constexpr int NT = 64 * WGM * WGN, NW = WGM * WGN;
+    static constexpr int MB = BM / WGM / 32, NB = BN / WGN / 32;
+    static constexpr int ASZ = BM * 32, BSZ = BN * 32;                // 32-bit words per buffer (64 halves per row)
+    static constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;          // 1 KiB pieces per wave and chunk
+    static constexpr size_t LDS_BYTES = (size_t)2 * (ASZ + BSZ) * 4;
+    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "pieces must divide evenly over the waves");
+    static_assert(!BRC || (BN == 64 || BN == 128), "row-contiguous B: a 1 KiB piece is 8 or 4 whole k rows");
+};
+
+// BRC: B is row-contiguous ([K][N], see HgArgs).  Its LDS image is k-major ([64][BN] halves, filled by the same DMA in
+// pieces of 1024 / (2 BN) whole k rows); a lane gathers the 8 k of its column with eight 16-bit LDS reads -- 8x the LDS
+// instructions of the k-contiguous form, affordable where the kernel is bound by streaming the weights (the 4x8 trunk) and
+// it saves keeping a second, transposed float16 copy of every weight tensor.
+template <int BM, int BN, int WGM, int WGN, bool BRC = false>
+__global__ __launch_bounds__(64 * WGM * WGN) void hgemm_kernel(HgArgs g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using Cfg = HgCfg<BM, BN, WGM, WGN, BRC>;
+    constexpr int MB = Cfg::MB, NB = Cfg::NB, PA = Cfg::PA, PB = Cfg::PB;
+    extern __shared__ __attribute__((aligned(1024))) float hg_smem[];
+    float* As0 = hg_smem;
+    float* Bs0 = hg_smem + 2 * Cfg::ASZ;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = g.tiles_m * g.tiles_n;
+    const int L = xcd_remap(blockIdx.x, tiles * g.splits);
+    // consecutive L share the K split and the n tile: an XCD streams one [BN][K / splits] weight panel through its L2 for
+    // all m tiles before moving on
+    const int sp = L / tiles;
+    const int rem = L - sp * tiles;
+    const int tn = rem / g.tiles_m, tm = rem - tn * g.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int total_chunks = g.K / HG_BK;
+    const int c_begin = sp * g.cps, c_end = min(total_chunks, c_begin + g.cps);
+
+    auto make_rsrc = [](const void* p, unsigned bytes) -> dg_v4i {
+        const unsigned long long a = (unsigned long long)p;
+        dg_v4i r;
+        r[0] = (int)(unsigned)a;
+        r[1] = (int)((unsigned)(a >> 32) & 0xffffu);
+        r[2] = (int)bytes;
+        r[3] = 0x00020000;
+        return r;
+    };
+    const dg_v4i ra = make_rsrc(g.A, (unsigned)g.M * (unsigned)g.lda * 2u);
+    const dg_v4i rb = make_rsrc(g.B, BRC ? 0x7fffffffu : (unsigned)g.N * (unsigned)g.ldb * 2u);
+    unsigned va[PA], vb[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int row = 8 * (wave * PA + i) + (lane >> 3), q = (lane & 7) ^ ((row >> 1) & 7);
+        va[i] = (unsigned)min(m0 + row, g.M - 1) * (unsigned)g.lda * 2u + 16u * q;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        if (BRC) {
+            constexpr int LPR = BN / 8;                   // lanes per k row (16 bytes = 8 halves each)
+            const int k = (wave * PB + i) * (64 / LPR) + lane / LPR, c8 = lane % LPR;
+            vb[i] = ((unsigned)k * (unsigned)g.ldb + (unsigned)min(n0 + 8 * c8, g.N - 8)) * 2u;
+        } else {
+            const int row = 8 * (wave * PB + i) + (lane >> 3), q = (lane & 7) ^ ((row >> 1) & 7);
+            vb[i] = (unsigned)min(n0 + row, g.N - 1) * (unsigned)g.ldb * 2u + 16u * q;
+        }
+    }
+    const unsigned lds_a0 = (unsigned)(size_t)(dg_lds_ptr)As0 + (unsigned)(wave * PA) * 1024u;
+    const unsigned lds_b0 = (unsigned)(size_t)(dg_lds_ptr)Bs0 + (unsigned)(wave * PB) * 1024u;
+    auto issue = [&](int c, int buf) {
+        const unsigned off = (unsigned)c * (HG_BK * 2u);
+        unsigned off_b = off;
+        if (BRC) {
+            const int tap = c / g.b_cpt, cc = c - tap * g.b_cpt;
+            off_b = ((unsigned)tap * (unsigned)g.b_tap_stride + (unsigned)cc * (unsigned)HG_BK * (unsigned)g.ldb) * 2u;
+        }
+        const unsigned la = lds_a0 + (unsigned)buf * (unsigned)(Cfg::ASZ * 4), lb = lds_b0 + (unsigned)buf * (unsigned)(Cfg::BSZ * 4);
+#pragma unroll
+        for (int i = 0; i < PA; ++i) dg_dma16(va[i], ra, la + 1024u * i, off);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) dg_dma16(vb[i], rb, lb + 1024u * i, off_b);
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = f32x16{0};
+    const int wm0 = (wave / WGN) * (BM / WGM), wn0 = (wave % WGN) * (BN / WGN);
+    const int r = lane & 31, kh = lane >> 5;
+
+    if (c_begin < c_end) issue(c_begin, 0);
+    for (int c = c_begin; c < c_end; ++c) {
+        const int cur = (c - c_begin) & 1;
+        dg_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < c_end) issue(c + 1, cur ^ 1);
+        const float* As = As0 + cur * Cfg::ASZ;
+        const float* Bs = Bs0 + cur * Cfg::BSZ;
+        f16x8 a[2][MB], b[2][NB];
+        auto fetch = [&](int s, int buf) {
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi) {
+                const int row = wm0 + 32 * mi + r;
+                a[buf][mi] = *reinterpret_cast<const f16x8*>(As + row * 32 + 4 * ((2 * s + kh) ^ ((row >> 1) & 7)));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NB; ++ni) {
+                const int row = wn0 + 32 * ni + r;
+                if (BRC) {
+                    const _Float16* bh = reinterpret_cast<const _Float16*>(Bs) + (16 * s + 8 * kh) * BN + row;
+                    f16x8 t;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t[j] = bh[j * BN];
+                    b[buf][ni] = t;
+                } else {
+                    b[buf][ni] = *reinterpret_cast<const f16x8*>(Bs + row * 32 + 4 * ((2 * s + kh) ^ ((row >> 1) & 7)));
+                }
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s + 1 < 4) fetch(s + 1, (s + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = mfma32x32x16h(a[s & 1][mi], b[s & 1][ni], acc[mi][ni]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    float* o = g.part ? g.part + (size_t)sp * ((size_t)g.M * g.N) : g.C;
+    const bool direct = g.part == nullptr;
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni) {
+            const int col = n0 + wn0 + 32 * ni + (lane & 31);
+            const float bv = (direct && g.bias && col < g.N) ? g.bias[col] : 0.0f;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int row = m0 + wm0 + 32 * mi + mfma32_row(rr, lane);
+                if (row < g.M && col < g.N) {
+                    float v = acc[mi][ni][rr];
+                    if (direct) {
+                        v += bv;
+                        if (g.round_f16) v = round_h(v);
+                        if (g.accumulate) v += o[(size_t)row * g.N + col];
+                    }
+                    o[(size_t)row * g.N + col] = v;
+                }
+            }
+        }
+#endif
+}
+
+template <int BM, int BN, int WGM, int WGN, bool BRC = false>
+inline void hgemm_launch(const HgArgs& a0, hipStream_t st) {
+    using Cfg = HgCfg<BM, BN, WGM, WGN, BRC>;
+    HgArgs a = a0;
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.N + BN - 1) / BN;
+    static bool once = false;
+    if (!once) {
+        hipFuncSetAttribute((const void*)hgemm_kernel<BM, BN, WGM, WGN, BRC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)Cfg::LDS_BYTES);
+        once = true;
+    }
+    const unsigned grid = (unsigned)((long long)a.tiles_m * a.tiles_n * a.splits);
+    hipLaunchKernelGGL((hgemm_kernel<BM, BN, WGM, WGN, BRC>), dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, a);
+}

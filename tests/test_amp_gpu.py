@@ -31,6 +31,11 @@ CASES = [
     ("conv1x1", 2, 64, 4, 8, 48, 1, 1, 0, False),
     ("smallc_4x4_s2", 2, 3, 33, 65, 64, 4, 2, 2, False),         # csrc/conv_smallc.h with float16-rounded operands
     ("smallc_7x7_reflect", 2, 2, 20, 36, 32, 7, 1, 3, True),
+    # weight-dominated layers (pixels <= Co, channels % 64 == 0): float16 im2col GEMMs with LDS-DMA staging (csrc/conv_h16.h)
+    ("h16_trunk_like", 2, 128, 4, 8, 128, 3, 1, 1, True),
+    ("h16_1x1", 4, 128, 4, 8, 192, 1, 1, 0, False),
+    ("h16_5x5_zero_pad_ragged", 1, 64, 6, 10, 64, 5, 1, 2, False),       # 60 pixels: the K padding of the weight gradient
+    ("h16_4x4_pad2", 1, 64, 5, 9, 128, 4, 1, 2, False),                   # output larger than the input (6 x 10)
 ]
 
 
@@ -75,10 +80,18 @@ def test_conv_f16_precision(case):
     # 3x3 stride-1 layers run as Winograd F(2x2,3x3) with float16 GEMM operands (the transformed tiles V = B^T d B and
     # U = G g G^T are what gets rounded, as in cuDNN's float16 Winograd algorithms that cudnn.benchmark may pick for the
     # reference): the rounding error of 16 transformed products folds into each output -> a few float16 ulps.
-    wino = bool(_lib.load().mg_conv_wino_weights_bytes(g))
+    h16 = ops.plan_name(0, g).startswith("hgemm")
+    assert h16 == name.startswith("h16_"), ops.plan_name(0, g)
+    wino = bool(_lib.load().mg_conv_wino_weights_bytes(g)) and not h16
     tol = dict(ulps=4.0, floor=2.0 ** -9) if wino else {}
     close_f16(ops.conv_fwd(g, xd, wd, bd), nhwc(y.detach()), **tol)
     close_f16(ops.conv_dgrad(g, gyd, wd), nhwc(xh.grad), **tol)
+    if h16:      # the caller-held float16 weight copy (one cast per step, shared by forward and data gradient): same bits
+        u = ops.wino_weights(g, wd)
+        assert u is not None and u.numel() * 4 == Co * k * k * Ci * 2
+        assert torch.equal(ops.conv_fwd(g, xd, wd, bd, u=u), ops.conv_fwd(g, xd, wd, bd))
+        assert torch.equal(ops.conv_dgrad(g, gyd, wd, u=u), ops.conv_dgrad(g, gyd, wd))
+        close_f16(ops.conv_fwd(g, xd, wd, bd, act=ops.ACT_RELU), torch.relu(nhwc(y.detach())))
     dw = torch.full((Co, k, k, Ci), 7.0, dtype=torch.float32, device=DEV)
     ops.conv_wgrad(g, xd, gyd, dw, None)
     want = nhwc(wh.grad)

@@ -55,7 +55,10 @@ def judged(got, f32, f64, what, k=4.0):
     # floor 5e-4: one mask flip in either float32 run already costs ~1e-4 (the op-level tests in test_conv_gpu /
     # test_elementwise_gpu hold the tight 3e-5 bars; this test guards the wiring, where a bug costs O(1))
     assert e_hip <= max(k * e_32, 5e-4) + 2e-6, "%s: HIP rel-L2 err %.3e vs fp32-CPU %.3e" % (what, e_hip, e_32)
-    assert np.abs(got - f64).max() <= 2e-2 * max(np.abs(f64).max(), 1e-30), what
+    # localised-garbage guard: 2 % of the tensor's scale, or 4x float32-CPU's own worst element where that is larger (a
+    # ReLU-mask flip behind a 2048-channel reduction moves single elements by more than 2 % in ANY float32 run)
+    worst, worst32 = np.abs(got - f64).max(), np.abs(f32 - f64).max()
+    assert worst <= max(2e-2 * max(np.abs(f64).max(), 1e-30), 4.0 * worst32), "%s: max-abs %.3e (fp32-CPU %.3e)" % (what, worst, worst32)
 
 
 @pytest.mark.parametrize("tag", list(CFGS))
