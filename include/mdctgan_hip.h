@@ -108,6 +108,29 @@ long long mg_stitch_length(int n_seg, int seg_len, int overlap);
 int mg_stitch_segments(const void* seg, int n_seg, int seg_len, int overlap, void* out, int is_f64, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Generic-geometry transform and the remaining codec branches (csrc/codec_generic.hip): MDCT4 / IMDCT4 for any
+ * win_length <= n_fft, hop_length <= win_length (models/mdct.py:365-489; the dense cosine contraction itself runs as the 1x1
+ * case of mg_conv_fwd), and Audio2MDCT.normalize / denormalize (models/pix2pixHD_model.py:83-137) in every mode.
+ * ------------------------------------------------------------------------------------------ */
+#define MG_CODEC_DB 3        /* 20 log10(max(|X| + min_value, min_value)) - 20  (torchaudio amplitude_to_DB, unpinned) */
+#define MG_CODEC_EXPLICIT 4  /* --explicit_encoding: two dB channels of alpha-mixed positive / negative parts */
+/* frames[b, f, k] = fl32(x[b, f*hop + k - start_pad] * window[k]), zero outside [0, T)   (mdct.py:393-410) */
+int mg_frames_window(const float* x, int B, int T, int win, int hop, int start_pad, int F, const float* window,
+                     float* frames, void* stream);
+/* X [B][n] raw coefficients -> out [B][C][n] (C = 2 for MG_CODEC_EXPLICIT, else 1), optional pair [B][n][2] =
+ * (v, 2|v| + nr0) (C == 1), per_sample: min/max per (b, channel) into min_out / max_out [B*C] (scratch_u32: 2*B*C words),
+ * stats: double[2] = sum, sum of squares of the pre-normalisation values. */
+int mg_codec_forward(const float* X, int B, int n, int mode, float gain, float alpha, float min_value, float nr0, float nr1,
+                     float src_min, float src_max, int per_sample, float* out, float* pair, float* min_out, float* max_out,
+                     void* scratch_u32, double* stats, void* stream);
+/* spec [B][C][n] -> X [B][n]; min_b / max_b [B*C] or both null (src_min / src_max) */
+int mg_codec_inverse(const float* spec, int B, int n, int mode, float gain, float alpha, float min_value, float nr0, float nr1,
+                     float src_min, float src_max, const float* min_b, const float* max_b, float* X, void* stream);
+/* out[b, t] = 4/n_fft * sum_f window[k] * Y[b, f, k], k = t + crop - f*hop   (mdct.py:469-486), float32 or float64 out */
+int mg_overlap_add(const float* Y, int B, int F, int win, int hop, int n_fft, const float* window, int crop, void* out,
+                   int out_len, int is_f64, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * K3/K4/K6  Implicit-GEMM convolution on the f32 MFMA pipe (exact float32).
  *   Replaces nn.Conv2d / nn.ConvTranspose2d / nn.ReflectionPad2d forward and backward at
  *   models/networks.py:207-210, 308-309, 329, 349-352, 387-392, 406-411, 440, 456, 649-670.

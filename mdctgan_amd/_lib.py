@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDCTGAN_HIP_LIB", os.path.join(_HERE, "libmdctgan_hip.so"))   # override: kernel A/B experiments
 
-MG_CODEC_RAW, MG_CODEC_ARCSINH, MG_CODEC_RANGE = 0, 1, 2
+MG_CODEC_RAW, MG_CODEC_ARCSINH, MG_CODEC_RANGE, MG_CODEC_DB, MG_CODEC_EXPLICIT = 0, 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_TANH = 0, 1, 2, 3
 
 
@@ -68,6 +68,10 @@ SIGNATURES = {
     "mg_stft_num_frames": (_i, [_i, _i, _i, _i]),
     "mg_stft_frames": (_i, [_p, _i, _i, _p, _i, _i, _i, _p, _p]),
     "mg_lsd_frames": (_i, [_p, _p, _ll, _i, _p, _p]),
+    "mg_frames_window": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "mg_codec_forward": (_i, [_p, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "mg_codec_inverse": (_i, [_p, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _p, _p, _p, _p]),
+    "mg_overlap_add": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p]),
     "mg_stitch_length": (_ll, [_i, _i, _i]),
     "mg_stitch_segments": (_i, [_p, _i, _i, _i, _p, _i, _p]),
     "mg_colsum": (_i, [_p, _ll, _i, _p, _i, _p, _sz, _p]),

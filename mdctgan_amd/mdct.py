@@ -9,8 +9,11 @@ Differences from the reference, all deliberate and documented in DESIGN.md:
   (then the float32 result is widened, for code that relies on the reference's float64 outputs).
 * frame padding follows the signal length T (the reference uses ``len(signal)`` == batch size for
   2-D input, SURVEY A2'); identical for every legal segment length (T % hop == 0).
-* supported geometry: win_length == n_fft == 2 * hop_length, n_fft == 512 (the hot path).  Anything
-  else raises NotImplementedError -- there is no eager fallback.
+* geometry: win_length == n_fft == 2 * hop_length == 512 (the hot path) runs the fused kernels K1 / K2 (csrc/mdct.hip:
+  TDAC fold + 256-point DCT-IV); every other legal geometry of the reference (win_length <= n_fft, hop_length <=
+  win_length, e.g. the class default n_fft = 2048) runs the generic path of csrc/codec_generic.hip: framing + window, the
+  [frames, win] x [win, n_fft/2] cosine contraction as a dense exact-float32 MFMA GEMM (the 1x1 case of mg_conv_fwd),
+  window + overlap-add.  There is no eager / CPU fallback.
 """
 from __future__ import annotations
 
@@ -57,12 +60,123 @@ def _make_window(window, win_length, device):
 
 
 def _check_geometry(n_fft, hop_length, win_length):
+    """True: the fused n_fft = 512 kernels apply; False: the generic path."""
     assert win_length <= n_fft, "Window lenth %d should be no more than fft length %d" % (win_length, n_fft)
     assert hop_length <= win_length, "You hopped more than one frame"
-    if not (n_fft == 512 and win_length == n_fft and hop_length * 2 == n_fft):
-        raise NotImplementedError(
-            "HIP MDCT kernels cover n_fft == win_length == 2*hop_length == 512 (got n_fft=%d win=%d hop=%d)"
-            % (n_fft, win_length, hop_length))
+    if n_fft % 2 or n_fft < 4:
+        raise NotImplementedError("n_fft must be even")
+    return n_fft == 512 and win_length == n_fft and hop_length * 2 == n_fft
+
+
+_mdct_tab_cache = {}
+
+
+def mdct_table(n_fft: int, win_length: int, device, transposed: bool) -> torch.Tensor:
+    """C[n, k] = cos(2 pi / N (n + 1/2 + N/4)(k + 1/2)), n < win_length, k < N/2 (float64 on the host, rounded once).
+    transposed: [N/2][win] (rows are the k-contiguous weight rows of the forward GEMM); else [win][N/2] (inverse)."""
+    key = (n_fft, win_length, str(device), transposed)
+    t = _mdct_tab_cache.get(key)
+    if t is None:
+        n = torch.arange(win_length, dtype=torch.float64)[:, None] + 0.5 + n_fft / 4.0
+        k = torch.arange(n_fft // 2, dtype=torch.float64)[None, :] + 0.5
+        c = torch.cos((2.0 * math.pi / n_fft) * n * k)
+        t = (c.t() if transposed else c).contiguous().to(torch.float32).to(device)
+        _mdct_tab_cache[key] = t
+    return t
+
+
+def num_frames(T: int, win_length: int, hop_length: int, center: bool = True) -> int:
+    """Frames MDCT4.forward produces for a T-sample signal (mdct.py:393-407 with the T-based tail padding, SURVEY A2')."""
+    start = hop_length if center else 0
+    end = start + (hop_length - T % hop_length if T % hop_length else 0)
+    return (T + start + end - win_length) // hop_length + 1
+
+
+def _dense(a2d: torch.Tensor, w2d: torch.Tensor) -> torch.Tensor:
+    """[R, K] x [N, K]^T on the exact-float32 MFMA GEMM (a 1x1 convolution over R 'pixels')."""
+    from . import ops
+    R, K = a2d.shape
+    g = ops.conv_geom(1, 1, R, K, w2d.shape[0], 1, 1, 1, 0, False)
+    return ops.conv_fwd(g, a2d.view(1, 1, R, K), w2d.view(w2d.shape[0], 1, 1, K)).view(R, w2d.shape[0])
+
+
+def mdct4_generic(audio, window, n_fft, hop_length, center=True, want_frames=False):
+    """MDCT4.forward for any legal geometry: audio [B, T] -> (raw coefficients [B, F, n_fft/2], frames [B, F, win] | None)."""
+    lib = _lib.load()
+    audio = _lib.f32c(audio)
+    B, T = audio.shape
+    win = window.numel()
+    F = num_frames(T, win, hop_length, center)
+    if F <= 0:
+        raise ValueError("signal of %d samples is too short for win_length=%d" % (T, win))
+    frames = torch.empty(B, F, win, dtype=torch.float32, device=audio.device)
+    _lib.check(lib.mg_frames_window(_lib.ptr(audio), B, T, win, hop_length, hop_length if center else 0, F,
+                                    _lib.ptr(window), _lib.ptr(frames), _lib.stream()), "mg_frames_window")
+    spec = _dense(frames.view(B * F, win), mdct_table(n_fft, win, audio.device, True)).view(B, F, n_fft // 2)
+    return spec, (frames if want_frames else None)
+
+
+def imdct4_generic(spec, window, n_fft, hop_length, center=True, out_length=None, out_dtype=torch.float32,
+                   want_frames=False):
+    """IMDCT4.forward for any legal geometry: raw coefficients [B, F, n_fft/2] -> (audio [B, T_out], frames | None)."""
+    lib = _lib.load()
+    spec = _lib.f32c(spec)
+    B, F, M = spec.shape
+    win = window.numel()
+    y = _dense(spec.view(B * F, M), mdct_table(n_fft, win, spec.device, False)).view(B, F, win)
+    full = (F - 1) * hop_length + win
+    crop = win // 2 if center else 0
+    t_out = full - crop - ((win + 1) // 2 if center else 0)          # signal[win//2 : -win//2]  (mdct.py:484-486)
+    if out_length is not None:
+        t_out = min(t_out, int(out_length))
+    audio = torch.empty(B, t_out, dtype=out_dtype, device=spec.device)
+    _lib.check(lib.mg_overlap_add(_lib.ptr(y), B, F, win, hop_length, n_fft, _lib.ptr(window), crop, _lib.ptr(audio), t_out,
+                                  int(out_dtype == torch.float64), _lib.stream()), "mg_overlap_add")
+    frames = None
+    if want_frames:
+        frames = y * window
+    return audio, frames
+
+
+def codec_forward(raw, *, codec, gain=1.0, alpha=0.6, min_value=1e-7, norm_range=(0.0, 1.0), src_range=(0.0, 1.0),
+                  per_sample=False, want_pair=False, want_stats=False):
+    """Audio2MDCT.normalize on raw coefficients [B, F, M] (any codec, csrc/codec_generic.hip) -> dict like mdct4_codec,
+    spec [B, C, F, M] with C = 2 for the explicit encoding."""
+    lib = _lib.load()
+    raw = _lib.f32c(raw)
+    B, F, M = raw.shape
+    C = 2 if codec == _lib.MG_CODEC_EXPLICIT else 1
+    dev = raw.device
+    spec = torch.empty(B, C, F, M, dtype=torch.float32, device=dev)
+    pair = torch.empty(B, F, M, 2, dtype=torch.float32, device=dev) if (want_pair and C == 1) else None
+    stats = torch.empty(2, dtype=torch.float64, device=dev) if want_stats else None
+    mn = mx = scratch = None
+    if per_sample:
+        mn = torch.empty(B * C, dtype=torch.float32, device=dev)
+        mx = torch.empty(B * C, dtype=torch.float32, device=dev)
+        scratch = torch.empty(2 * B * C, dtype=torch.int32, device=dev)
+    _lib.check(lib.mg_codec_forward(_lib.ptr(raw), B, F * M, codec, gain, alpha, min_value, norm_range[0], norm_range[1],
+                                    src_range[0], src_range[1], int(per_sample), _lib.ptr(spec), _lib.ptr(pair), _lib.ptr(mn),
+                                    _lib.ptr(mx), _lib.ptr(scratch), _lib.ptr(stats), _lib.stream()), "mg_codec_forward")
+    return {"spec4": spec, "spec": spec[:, 0] if C == 1 else None, "pair": pair, "frames": None,
+            "min": mn.view(B, C) if per_sample else None, "max": mx.view(B, C) if per_sample else None, "stats": stats}
+
+
+def codec_inverse(spec4, *, codec, gain=1.0, alpha=0.6, min_value=1e-7, norm_range=(0.0, 1.0), src_range=(0.0, 1.0),
+                  min_b=None, max_b=None):
+    """Audio2MDCT.denormalize (+ the explicit-encoding channel combination of to_audio): [B, C, F, M] -> raw [B, F, M]."""
+    lib = _lib.load()
+    spec4 = _lib.f32c(spec4)
+    B, C, F, M = spec4.shape
+    assert C == (2 if codec == _lib.MG_CODEC_EXPLICIT else 1)
+    raw = torch.empty(B, F, M, dtype=torch.float32, device=spec4.device)
+    if min_b is not None:
+        min_b, max_b = _lib.f32c(min_b.reshape(-1)), _lib.f32c(max_b.reshape(-1))
+        assert min_b.numel() == B * C and max_b.numel() == B * C
+    _lib.check(lib.mg_codec_inverse(_lib.ptr(spec4), B, F * M, codec, gain, alpha, min_value, norm_range[0], norm_range[1],
+                                    src_range[0], src_range[1], _lib.ptr(min_b), _lib.ptr(max_b), _lib.ptr(raw),
+                                    _lib.stream()), "mg_codec_inverse")
+    return raw
 
 
 def mdct4_codec(audio, window, dct4, n_fft, *, codec=_lib.MG_CODEC_RAW, gain=1.0, norm_range=(0.0, 1.0),
@@ -123,9 +237,9 @@ class MDCT4(torch.nn.Module):
         super().__init__()
         self.n_fft, self.pad_mode, self.device, self.hop_length, self.center = n_fft, pad_mode, device, hop_length, center
         self.window, self.win_length = _make_window(window, win_length, device)
-        _check_geometry(self.n_fft, self.hop_length, self.win_length)
-        if not center or pad_mode != "constant":
-            raise NotImplementedError("HIP MDCT4 implements center=True with zero ('constant') padding")
+        self.fused = _check_geometry(self.n_fft, self.hop_length, self.win_length) and center
+        if pad_mode != "constant":
+            raise NotImplementedError("HIP MDCT4 implements zero ('constant') padding")
         self.out_dtype = dtype
 
     def forward(self, signal, return_frames: bool = False):
@@ -133,9 +247,13 @@ class MDCT4(torch.nn.Module):
         x = signal.reshape(-1, signal.shape[-1])
         if self.window.device != x.device:
             self.window = self.window.to(x.device)
-        r = mdct4_codec(x, self.window, dct4_table(self.n_fft // 2, x.device), self.n_fft, want_frames=return_frames)
-        spec = r["spec"].reshape(*lead, *r["spec"].shape[1:]).to(self.out_dtype)
-        frames = r["frames"].reshape(*lead, *r["frames"].shape[1:]) if return_frames else torch.empty(1)
+        if self.fused:
+            r = mdct4_codec(x, self.window, dct4_table(self.n_fft // 2, x.device), self.n_fft, want_frames=return_frames)
+            sp, fr = r["spec"], r["frames"]
+        else:
+            sp, fr = mdct4_generic(x, self.window, self.n_fft, self.hop_length, self.center, return_frames)
+        spec = sp.reshape(*lead, *sp.shape[1:]).to(self.out_dtype)
+        frames = fr.reshape(*lead, *fr.shape[1:]) if return_frames else torch.empty(1)
         return spec, frames
 
 
@@ -148,9 +266,7 @@ class IMDCT4(torch.nn.Module):
         self.n_fft, self.pad_mode, self.device, self.hop_length = n_fft, pad_mode, device, hop_length
         self.center, self.out_length = center, out_length
         self.window, self.win_length = _make_window(window, win_length, device)
-        _check_geometry(self.n_fft, self.hop_length, self.win_length)
-        if not center:
-            raise NotImplementedError("HIP IMDCT4 implements center=True")
+        self.fused = _check_geometry(self.n_fft, self.hop_length, self.win_length) and center
         self.out_dtype = dtype
 
     def forward(self, signal, return_frames: bool = False):
@@ -160,6 +276,10 @@ class IMDCT4(torch.nn.Module):
             "The last dim of input tensor should match the n_fft. Expected %d ,got %d" % (self.n_fft, signal.size()[-1])
         if self.window.device != signal.device:
             self.window = self.window.to(signal.device)
-        audio, frames = imdct4_codec(signal, self.window, dct4_table(self.n_fft // 2, signal.device), self.n_fft,
-                                     out_length=self.out_length, out_dtype=self.out_dtype, want_frames=return_frames)
+        if self.fused:
+            audio, frames = imdct4_codec(signal, self.window, dct4_table(self.n_fft // 2, signal.device), self.n_fft,
+                                         out_length=self.out_length, out_dtype=self.out_dtype, want_frames=return_frames)
+        else:
+            audio, frames = imdct4_generic(signal, self.window, self.n_fft, self.hop_length, self.center, self.out_length,
+                                           self.out_dtype, return_frames)
         return audio[:, None, None, :], (frames if return_frames else torch.zeros(1))

@@ -71,3 +71,43 @@ def compute_matrics(hr_audio, lr_audio, sr_audio, opt):
                                  _lib.stream()), "mg_lsd_frames")
     lsd = per_frame.double().mean().item()
     return mse, snr_sr, snr_lr, 0, 0, 0, lsd
+
+
+def eval_model(model, eval_batches, opt, eval_path=None):
+    """train.py:104-134: run ``model.inference`` over the evaluation batches (dicts with ``LR_audio`` / ``HR_audio`` like the
+    reference's dataloader items, or ``(lr, hr)`` pairs), score every batch with ``compute_matrics`` and average -- the
+    same five columns, appended to ``eval_path`` as a CSV row when given.  Everything up to the per-batch Python floats
+    stays on the device; the model is put in eval mode for the loop (BatchNorm running statistics of the attention
+    blocks) and back in train mode afterwards, like the reference."""
+    import csv
+    import numpy as np
+    err, snr, snr_seg, pesq, lsd = [], [], [], [], []
+    was_training = model.training
+    dev = getattr(model, "device", "cuda")
+    try:
+        for j, item in enumerate(eval_batches):
+            model.eval()
+            lr_audio, hr_audio = (item["LR_audio"], item["HR_audio"]) if isinstance(item, dict) else item
+            lr_audio, hr_audio = lr_audio.to(dev), hr_audio.to(dev)
+            with torch.no_grad():
+                _, sr_audio, _, _, _ = model.inference(lr_audio)
+                _mse, _snr_sr, _snr_lr, _ssnr_sr, _ssnr_lr, _pesq, _lsd = compute_matrics(
+                    hr_audio.squeeze(), lr_audio.squeeze(), sr_audio.squeeze(), opt)
+            err.append(_mse)
+            snr.append((_snr_lr, _snr_sr))
+            snr_seg.append((_ssnr_lr, _ssnr_sr))
+            pesq.append(_pesq)
+            lsd.append(_lsd)
+            if j >= opt.eval_size:
+                break
+    finally:
+        model.train(was_training)
+    result = {"err": float(np.mean(err)), "snr": float(np.mean(snr)), "snr_seg": float(np.mean(snr_seg)),
+              "pesq": float(np.mean(pesq)), "lsd": float(np.mean(lsd))}
+    if eval_path:
+        with open(eval_path, "a") as f:
+            writer = csv.DictWriter(f, fieldnames=result.keys())
+            if f.tell() == 0:
+                writer.writeheader()
+            writer.writerow(result)
+    return result

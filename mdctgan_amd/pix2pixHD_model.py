@@ -17,7 +17,8 @@ import torch
 from . import _lib, networks
 from . import amp
 from . import functional as Fh
-from .mdct import IMDCT4, MDCT4, dct4_table, imdct4_codec, kbdwin, mdct4_codec
+from .mdct import (IMDCT4, MDCT4, _check_geometry, codec_forward, codec_inverse, dct4_table, imdct4_codec, imdct4_generic,
+                   kbdwin, mdct4_codec, mdct4_generic)
 from .optim import FusedAdam
 
 
@@ -37,11 +38,19 @@ class Audio2MDCT(torch.nn.Module):
                            window=self.window, device=self.device)
         self._imdct = IMDCT4(n_fft=self.n_fft, hop_length=self.hop_length, win_length=self.win_length,
                              window=self.window, device=self.device)
+        # models/pix2pixHD_model.py:84-106: explicit encoding > arcsinh > raw > dB
         if getattr(self, "explicit_encoding", False):
-            raise NotImplementedError("--explicit_encoding (dB pair codec) is outside the HIP hot path")
-        if not (self.arcsinh_transform or self.raw_mdct):
-            raise NotImplementedError("the dB codec branch is outside the HIP hot path; use --arcsinh_transform")
-        self.codec = _lib.MG_CODEC_ARCSINH if self.arcsinh_transform else _lib.MG_CODEC_RANGE
+            self.codec = _lib.MG_CODEC_EXPLICIT
+        elif self.arcsinh_transform:
+            self.codec = _lib.MG_CODEC_ARCSINH
+        elif self.raw_mdct:
+            self.codec = _lib.MG_CODEC_RANGE
+        else:
+            self.codec = _lib.MG_CODEC_DB
+        # the hot path (n_fft 512, arcsinh / raw) runs the fused kernels K1 / K2; any other geometry or codec runs the
+        # generic kernels of csrc/codec_generic.hip (transform as a dense GEMM + elementwise codec)
+        self.geom512 = _check_geometry(self.n_fft, self.hop_length, self.win_length)
+        self.fused = self.geom512 and self.codec in (_lib.MG_CODEC_ARCSINH, _lib.MG_CODEC_RANGE)
         self.return_stats = True      # mean / std of norm_param (returned only; costs two atomics per wave)
         self.return_frames = False    # norm_param['frames'] (dead on the hot path; [B, F, 512] of extra traffic)
         self.return_pha = False       # pha = sign(X) * noise is dead on the arcsinh / raw paths
@@ -55,14 +64,35 @@ class Audio2MDCT(torch.nn.Module):
     def _ranges(self):
         return (float(self.norm_range[0]), float(self.norm_range[1])), (float(self.src_range[0]), float(self.src_range[1]))
 
+    def _raw(self, audio, want_frames=False):
+        """Raw MDCT coefficients [B, F, M] (+ windowed frames) by the kernel that fits the geometry."""
+        if self.geom512:
+            window, d4 = self._tables(audio.device)
+            r = mdct4_codec(audio, window, d4, self.n_fft, codec=_lib.MG_CODEC_RAW, want_frames=want_frames)
+            return r["spec"], r["frames"]
+        if self.window.device != audio.device:
+            self.window = self.window.to(audio.device)
+        return mdct4_generic(audio, self.window, self.n_fft, self.hop_length, True, want_frames)
+
     def encode(self, audio, want_pair=False, want_stats=None, want_frames=None):
-        """Fused K1 launch.  Returns the launcher dict (spec [B,F,W], pair [B,F,W,2] NHWC, min/max, stats)."""
-        window, d4 = self._tables(audio.device)
+        """K1 (fused) or the generic transform + codec.  Returns the launcher dict (spec [B,F,W] / spec4 [B,C,F,W], pair
+        [B,F,W,2] NHWC, min/max, stats)."""
         nr, sr = self._ranges()
-        return mdct4_codec(audio, window, d4, self.n_fft, codec=self.codec, gain=float(self.arcsinh_gain),
-                           norm_range=nr, src_range=sr, per_sample=not self.abs_norm, want_pair=want_pair,
-                           want_stats=self.return_stats if want_stats is None else want_stats,
-                           want_frames=self.return_frames if want_frames is None else want_frames)
+        want_stats = self.return_stats if want_stats is None else want_stats
+        want_frames = self.return_frames if want_frames is None else want_frames
+        if self.fused:
+            window, d4 = self._tables(audio.device)
+            r = mdct4_codec(audio, window, d4, self.n_fft, codec=self.codec, gain=float(self.arcsinh_gain),
+                            norm_range=nr, src_range=sr, per_sample=not self.abs_norm, want_pair=want_pair,
+                            want_stats=want_stats, want_frames=want_frames)
+            r["spec4"], r["raw"] = r["spec"][:, None], None
+            return r
+        raw, frames = self._raw(_lib.f32c(audio.reshape(-1, audio.shape[-1])), want_frames)
+        r = codec_forward(raw, codec=self.codec, gain=float(self.arcsinh_gain), alpha=float(self.alpha),
+                          min_value=float(self.min_value), norm_range=nr, src_range=sr, per_sample=not self.abs_norm,
+                          want_pair=want_pair, want_stats=want_stats)
+        r["frames"], r["raw"] = frames, raw
+        return r
 
     def _norm_param(self, r, dev):
         if self.abs_norm:
@@ -72,10 +102,10 @@ class Audio2MDCT(torch.nn.Module):
                                    torch.tensor([self.src_range[1]], device=dev)[None, None, None, :])
             a_min, a_max = cache[str(dev)]
         else:
-            a_min, a_max = r["min"][:, None, None, None], r["max"][:, None, None, None]
+            a_min, a_max = r["min"].reshape(r["min"].shape[0], -1)[:, :, None, None], r["max"].reshape(r["max"].shape[0], -1)[:, :, None, None]
         mean = std = None
         if r["stats"] is not None:
-            n = r["spec"].numel()
+            n = r["spec4"].numel()
             s = r["stats"]
             mean = (s[0] / n).float()
             std = ((s[1] - s[0] * s[0] / n) / (n - 1)).clamp_min(0).sqrt().float()
@@ -84,9 +114,16 @@ class Audio2MDCT(torch.nn.Module):
     # -- reference API --------------------------------------------------------------------------
     def to_spectro(self, audio: torch.Tensor, mask: bool = False, mask_size: int = -1):
         r = self.encode(audio)
-        log_spectro = r["spec"][:, None]                      # [B, 1, F, W] float32
+        log_spectro = r["spec4"]                              # [B, C, F, W] float32 (C = 2 for --explicit_encoding)
         pha = None
-        if self.return_pha:
+        if self.codec in (_lib.MG_CODEC_DB, _lib.MG_CODEC_EXPLICIT):
+            # pix2pixHD_model.py:36, 50-55: the sign of the coefficients, times uniform-rescaled noise unless explicit
+            # (to_audio multiplies the dB magnitudes by it).  Random numbers come from torch's generator.
+            pha = torch.sign(r["raw"])[:, None]
+            if self.codec == _lib.MG_CODEC_DB:
+                noise = torch.randn(pha.size(), device=pha.device)
+                pha = pha * ((noise - noise.min()) / (noise.max() - noise.min()))
+        elif self.return_pha:
             zero = (0.0 - self.src_range[0]) / (self.src_range[1] - self.src_range[0]) * \
                 (self.norm_range[1] - self.norm_range[0]) + self.norm_range[0] if self.abs_norm else None
             if zero is None:
@@ -134,16 +171,37 @@ class Audio2MDCT(torch.nn.Module):
         return x
 
     def to_audio(self, log_spectro: torch.Tensor, norm_param: Dict[str, torch.Tensor], pha: torch.Tensor = None):
-        window, d4 = self._tables(log_spectro.device)
         nr, sr = self._ranges()
         mn, mx = norm_param["min"], norm_param["max"]
         per_sample = mn.numel() > 1
         if not per_sample:
             sr = (float(mn.reshape(-1)[0]), float(mx.reshape(-1)[0])) if not self.abs_norm else sr
-        spec = log_spectro.squeeze(1) if log_spectro.dim() == 4 else log_spectro
-        audio, _ = imdct4_codec(spec, window, d4, self.n_fft, codec=self.codec, gain=float(self.arcsinh_gain),
-                                norm_range=nr, src_range=sr, min_b=mn if per_sample else None,
-                                max_b=mx if per_sample else None)
+        if self.fused:
+            window, d4 = self._tables(log_spectro.device)
+            spec = log_spectro.squeeze(1) if log_spectro.dim() == 4 else log_spectro
+            audio, _ = imdct4_codec(spec, window, d4, self.n_fft, codec=self.codec, gain=float(self.arcsinh_gain),
+                                    norm_range=nr, src_range=sr, min_b=mn if per_sample else None,
+                                    max_b=mx if per_sample else None)
+            return audio[:, None, None, :]
+        spec4 = log_spectro if log_spectro.dim() == 4 else log_spectro[:, None]
+        raw = codec_inverse(spec4, codec=self.codec, gain=float(self.arcsinh_gain), alpha=float(self.alpha),
+                            min_value=float(self.min_value), norm_range=nr, src_range=sr,
+                            min_b=mn if per_sample else None, max_b=mx if per_sample else None)
+        if self.codec == _lib.MG_CODEC_DB and pha is not None:       # pix2pixHD_model.py:147-157
+            ph = pha.reshape(raw.shape).to(raw.device)
+            if self.up_ratio > 1:
+                size = ph.size(-2)
+                keep = int(size * (1 / self.up_ratio))
+                pseudo = (2 * torch.randint(low=0, high=2, size=ph.size(), device=raw.device) - 1).to(ph.dtype)
+                ph = torch.cat((ph[..., :keep, :], pseudo[..., keep:, :]), dim=-2)
+            raw = raw * ph
+        if self.geom512:
+            window, d4 = self._tables(raw.device)
+            audio, _ = imdct4_codec(raw, window, d4, self.n_fft, codec=_lib.MG_CODEC_RAW)
+        else:
+            if self.window.device != raw.device:
+                self.window = self.window.to(raw.device)
+            audio, _ = imdct4_generic(raw, self.window, self.n_fft, self.hop_length, True)
         return audio[:, None, None, :]
 
     def forward(self, lr_audio: torch.Tensor):

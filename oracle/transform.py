@@ -6,7 +6,9 @@ Follows the reference's arithmetic, not its FFT mechanics:
 * ``kbd_window``      <- util/util.py:179-186 (kbdwin)
 * ``mdct4``           <- models/mdct.py:392-425 (MDCT4.forward)
 * ``imdct4``          <- models/mdct.py:457-489 (IMDCT4.forward)
-* ``normalize``       <- models/pix2pixHD_model.py:83-125 (Audio2MDCT.normalize)
+* ``normalize``       <- models/pix2pixHD_model.py:83-125 (Audio2MDCT.normalize; the dB / explicit-encoding branches call
+                         torchaudio's amplitude_to_DB / DB_to_amplitude, which are not installed here: restated from
+                         their published formulas, parity of those two functions UNPINNED)
 * ``denormalize``     <- models/pix2pixHD_model.py:127-137
 * ``to_spectro``      <- models/pix2pixHD_model.py:32-81 (arcsinh / raw branches)
 * ``to_audio``        <- models/pix2pixHD_model.py:139-163
@@ -168,19 +170,35 @@ def imdct4(spec: np.ndarray, window: np.ndarray, n_fft: int, hop: int, center: b
 # --------------------------------------------------------------------------
 # codec
 # --------------------------------------------------------------------------
-def normalize(spec, *, arcsinh_transform=True, raw_mdct=False, arcsinh_gain=1000.0,
-              abs_norm=True, src_range=(-5.0, 5.0), norm_range=(-1.0, 1.0)):
-    """Audio2MDCT.normalize (arcsinh and raw branches).  spec float64 [B, C, F, W].
+def amplitude_to_db(x, multiplier, amin, db_multiplier):
+    """torchaudio.functional.amplitude_to_DB (top_db=None): multiplier * log10(clamp(x, min=amin)) - multiplier * db_multiplier."""
+    return multiplier * np.log10(np.clip(x, amin, None)) - multiplier * db_multiplier
 
-    Returns (normalised float64, max, min, mean, std) like pix2pixHD_model.py:125.
+
+def db_to_amplitude(x, ref, power):
+    """torchaudio.functional.DB_to_amplitude: ref * (10 ** (0.1 x)) ** power."""
+    return ref * np.power(np.power(10.0, 0.1 * x), power)
+
+
+def normalize(spec, *, arcsinh_transform=True, raw_mdct=False, arcsinh_gain=1000.0,
+              abs_norm=True, src_range=(-5.0, 5.0), norm_range=(-1.0, 1.0), explicit_encoding=False, alpha=0.6,
+              min_value=1e-7):
+    """Audio2MDCT.normalize, every branch (pix2pixHD_model.py:84-106).  spec float64 [B, 1, F, W].
+
+    Returns (normalised float64 [B, C, F, W], max, min, mean, std) like pix2pixHD_model.py:125.
     """
     spec = np.asarray(spec, dtype=np.float64)
-    if arcsinh_transform:
+    if explicit_encoding:
+        neg = 0.5 * (np.abs(spec) - spec)
+        pos = spec + neg
+        log_spec = np.concatenate((amplitude_to_db(alpha * pos + (1 - alpha) * neg, 20.0, min_value, 1.0),
+                                   amplitude_to_db((1 - alpha) * pos + alpha * neg, 20.0, min_value, 1.0)), axis=1)
+    elif arcsinh_transform:
         log_spec = np.arcsinh(arcsinh_gain * spec) / np.float64(np.float32(LN10))  # torch.log(tensor(10.)) is fp32
     elif raw_mdct:
         log_spec = spec
     else:
-        raise NotImplementedError("dB / explicit-encoding branches are out of the hot-path scope")
+        log_spec = amplitude_to_db(np.abs(spec) + min_value, 20.0, min_value, 1.0)
     mean = np.float32(log_spec.mean())
     std = np.float32(np.sqrt(log_spec.var(ddof=1)))
     if not abs_norm:
@@ -196,15 +214,16 @@ def normalize(spec, *, arcsinh_transform=True, raw_mdct=False, arcsinh_gain=1000
 
 
 def denormalize(log_spec, a_min, a_max, *, arcsinh_transform=True, raw_mdct=False,
-                arcsinh_gain=1000.0, norm_range=(-1.0, 1.0)):
-    """Audio2MDCT.denormalize.  pix2pixHD_model.py:127-137."""
+                arcsinh_gain=1000.0, norm_range=(-1.0, 1.0), explicit_encoding=False, min_value=1e-7):
+    """Audio2MDCT.denormalize.  pix2pixHD_model.py:127-137 (note the branch order there: arcsinh, raw, else dB -- the
+    explicit encoding reaches the dB branch only with arcsinh / raw off, as in normalize's precedence)."""
     x = (np.asarray(log_spec).astype(np.float64) - norm_range[0]) / (norm_range[1] - norm_range[0])
     x = x * (np.asarray(a_max, dtype=np.float64) - np.asarray(a_min, dtype=np.float64)) + np.asarray(a_min, dtype=np.float64)
-    if arcsinh_transform:
+    if arcsinh_transform and not explicit_encoding:
         return np.sinh(x * np.float64(np.float32(LN10))) / arcsinh_gain
-    if raw_mdct:
+    if raw_mdct and not explicit_encoding:
         return x
-    raise NotImplementedError
+    return db_to_amplitude(x, 10.0, 0.5) - min_value
 
 
 def to_spectro(audio, window, n_fft, hop, **codec):
@@ -218,10 +237,18 @@ def to_spectro(audio, window, n_fft, hop, **codec):
     return out.astype(np.float32), {"max": a_max, "min": a_min, "mean": mean, "std": std, "frames": frames}
 
 
-def to_audio(log_spec, norm_param, window, n_fft, hop, **codec):
-    """Audio2MDCT.to_audio (arcsinh / raw branches).  pix2pixHD_model.py:139-163."""
-    codec = {k: v for k, v in codec.items() if k in ("arcsinh_transform", "raw_mdct", "arcsinh_gain", "norm_range")}
-    spec = denormalize(log_spec, norm_param["min"], norm_param["max"], **codec)
+def to_audio(log_spec, norm_param, window, n_fft, hop, pha=None, **codec):
+    """Audio2MDCT.to_audio.  pix2pixHD_model.py:139-163 (the dB branch multiplies the magnitudes by ``pha``; its random
+    pseudo-phase for up_ratio > 1 is the caller's business)."""
+    alpha = codec.get("alpha", 0.6)
+    explicit = codec.get("explicit_encoding", False)
+    db = not explicit and not codec.get("arcsinh_transform", True) and not codec.get("raw_mdct", False)
+    keys = ("arcsinh_transform", "raw_mdct", "arcsinh_gain", "norm_range", "explicit_encoding", "min_value")
+    spec = denormalize(log_spec, norm_param["min"], norm_param["max"], **{k: v for k, v in codec.items() if k in keys})
+    if explicit:
+        spec = ((spec[:, 0] - spec[:, 1]) / (2 * alpha - 1))[:, None]
+    elif db and pha is not None:
+        spec = spec * np.asarray(pha, dtype=np.float64)
     audio, _ = imdct4(spec[:, 0], window, n_fft, hop, center=True)
     return audio
 

@@ -58,8 +58,11 @@ def test_host_tensors_are_refused():
 
 def test_unsupported_geometry_raises():
     from mdctgan_amd.mdct import IMDCT4, MDCT4, kbdwin
+    MDCT4(2048, 512, 2048, kbdwin, device="cpu")           # legal geometry: the generic path (csrc/codec_generic.hip)
     with pytest.raises(NotImplementedError):
-        MDCT4(2048, 512, 2048, kbdwin, device="cpu")
+        MDCT4(511, 128, 511, None, device="cpu")            # odd n_fft
+    with pytest.raises(AssertionError):
+        MDCT4(512, 600, 512, kbdwin, device="cpu")          # hop longer than the window (mdct.py:384)
     with pytest.raises(AssertionError):
         MDCT4(512, 256, 1024, kbdwin, device="cpu")        # window longer than n_fft (mdct.py:383)
     im = IMDCT4(512, 256, 512, kbdwin, device="cpu")
