@@ -53,22 +53,26 @@ class ArenaReducer:
         # (tail_bytes, default a quarter of a bucket) and never let a large late-arena tensor ride in it.
         tail = max(1, (bucket_bytes // 4 if tail_bytes is None else tail_bytes) // 4)
         per_bucket = max(1, bucket_bytes // 4)
-        lo, count, cur = 0, 0, 0
+        lo, count, cur, writes = 0, 0, 0, 0
+        self._bucket_writes = []           # wgrad launches a bucket waits for (a module applied k times writes k times)
         for p, off, n in slices:
             cap = tail if not self.buckets else per_bucket
             if count and off + n - lo > cap:                   # close before a tensor that would overflow the cap
                 self.buckets.append([lo, off, count])
-                lo, count = off, 0
+                self._bucket_writes.append(writes)
+                lo, count, writes = off, 0, 0
             self.param_bucket[id(p)] = len(self.buckets)
             count += 1
+            writes += int(getattr(p, "_mg_writes", 1)) * writes_per_step
             cur = off + n
         if count:
             self.buckets.append([lo, cur, count])
+            self._bucket_writes.append(writes)
         self._reset()
         self._hook = Fh.register_grad_ready_hook(self._on_ready)
 
     def _reset(self):
-        self.pending = [b[2] * self.writes_per_step for b in self.buckets]
+        self.pending = list(self._bucket_writes)
         self.works = []
 
     def close(self):
@@ -76,7 +80,7 @@ class ArenaReducer:
 
     def _launch(self, i):
         lo, hi, _ = self.buckets[i]
-        if not (self.world > 1 or self.force):
+        if not (self.world > 1 or self.force) or not dist.is_initialized():     # (a reducer that outlived its group)
             return
         n = hi - lo
         if self.mode == "rs_ag" and n % self.world == 0:

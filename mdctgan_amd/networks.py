@@ -396,8 +396,8 @@ class LocalEnhancer(FusedModule):
                  upsample_type="transconv", n_attn_g=0, n_attn_l=0, input_size=(128, 256), proj_factor_g=4,
                  heads_g=4, dim_head_g=128, proj_factor_l=4, heads_l=4, dim_head_l=128):
         super().__init__()
-        if n_local_enhancers != 1 or n_attn_l > 0:
-            raise NotImplementedError("HIP LocalEnhancer: n_local_enhancers == 1 and n_blocks_attn_l == 0")
+        if n_local_enhancers != 1:
+            raise NotImplementedError("HIP LocalEnhancer: n_local_enhancers == 1")
         norm_layer = norm_layer or get_norm_layer("instance")
         self.n_local_enhancers = n_local_enhancers
         ngf_global = ngf * (2 ** n_local_enhancers)
@@ -415,6 +415,27 @@ class LocalEnhancer(FusedModule):
                             norm_layer(ngf_global * 2), nn.ReLU(True)]
         model_upsample = [ResnetBlock(ngf_global * 2, padding_type=padding_type, norm_layer=norm_layer)
                           for _ in range(n_blocks_local)]
+        if n_attn_l > 0:
+            # networks.py:218-237.  The reference multiplies Python lists: the second [conv, norm, ReLU] triple of the 8x
+            # down-sampler is the SAME three modules applied twice, and ONE 2 ngf -> 2 ngf up-sampler (+ norm, ReLU) is
+            # applied three times behind the remaining blocks -- mirrored object for object, so state-dict keys (every alias
+            # is listed) and weight sharing are the reference's.
+            middle = n_blocks_local // 2
+            d = [down(ngf_global * 2, ngf_global, kernel_size=3, stride=2, padding=1), norm_layer(ngf_global), nn.ReLU(True)]
+            d += [down(ngf_global, ngf_global, kernel_size=3, stride=2, padding=1), norm_layer(ngf_global), nn.ReLU(True)] * 2
+            model_upsample.insert(middle, nn.Sequential(*d))
+            fmap = tuple(map(lambda x: x // 16, input_size))
+            model_upsample.insert(middle + 1, BottleStack(
+                dim=ngf_global, fmap_size=fmap, dim_out=ngf_global * 2, num_layers=n_attn_l, proj_factor=proj_factor_l,
+                downsample=False, heads=heads_l, dim_head=dim_head_l, activation=nn.ReLU(True), rel_pos_emb=False))
+            shared_up = [up(in_channels=ngf_global * 2, out_channels=ngf_global * 2, kernel_size=3, stride=2, padding=1,
+                            output_padding=1), norm_layer(ngf_global), nn.ReLU(True)]
+            model_upsample += shared_up * 3
+            # a shared module's weight gradient is written once per application: the data-parallel reducer must wait for
+            # all of them before it launches the bucket (mdctgan_amd/ddp.py reads _mg_writes)
+            for m, times in ((d[3], 2), (shared_up[0], 3)):
+                for prm in m.parameters():
+                    prm._mg_writes = times
         model_upsample += [up(in_channels=ngf_global * 2, out_channels=ngf_global, kernel_size=3, stride=2,
                               padding=1, output_padding=1), norm_layer(ngf_global), nn.ReLU(True)]
         model_upsample += [nn.ReflectionPad2d(3), Conv2d(ngf, output_nc, kernel_size=7, padding=0), nn.Tanh()]

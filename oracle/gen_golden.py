@@ -266,6 +266,19 @@ def main():
         arrs["gD/" + k] = v.numpy()
     save("g9_step_global_fp16", **arrs)
 
+    # ---- G10 LocalEnhancer with the local attention sandwich (networks.py:218-237: the shared-module lists) ----------
+    # The reference's own module tree and forward; the bottleneck-transformer arithmetic inside is the stand-in above
+    # (third party, unpinned) -- what this pins is the wiring: which modules are shared, applied how often, on which maps.
+    net = quiet(rnet.define_G, 2, 1, 4, "local", 2, 1, 1, 3, "instance", gpu_ids=[], input_size=(64, 256),
+                n_attn_g=0, n_attn_l=1, proj_factor_l=4, heads_l=2, dim_head_l=8)
+    onets.fill_deterministic(net)
+    net.eval()
+    gin = torch.rand(1, 2, 64, 256, generator=g) * 2 - 1
+    with torch.no_grad():
+        out = net(gin)
+    save("g10_netG_local_attn_l", x=gin.numpy(), y=out.numpy(), keys=np.array(list(net.state_dict().keys())),
+         shapes=np.array([str(tuple(p.shape)) for p in net.state_dict().values()]))
+
 
 if __name__ == "__main__":
     main()

@@ -187,11 +187,14 @@ class GlobalGeneratorRef(nn.Module):
 
 
 class LocalEnhancerRef(nn.Module):
-    """networks.py:173-267 with n_local_enhancers == 1 and n_attn_l == 0 (all BASELINE configs)."""
+    """networks.py:173-267 with n_local_enhancers == 1.  n_attn_l > 0 (networks.py:218-237): after the first
+    n_blocks_local // 2 local blocks an 8x down-sampling Sequential whose second [conv, norm, ReLU] triple is the SAME
+    three modules applied twice (a Python list multiplied by 2), a BottleStack on the /16 map, and -- appended after the
+    remaining blocks -- ONE transposed convolution (2 ngf -> 2 ngf) with its norm and ReLU applied three times."""
 
     def __init__(self, input_nc, output_nc, ngf=32, n_down_global=3, n_blocks_global=9, n_blocks_local=3,
                  up="transconv", down="conv", n_attn_g=0, input_size=(128, 256), proj_factor_g=4, heads_g=4,
-                 dim_head_g=128):
+                 dim_head_g=128, n_attn_l=0, proj_factor_l=4, heads_l=4, dim_head_l=128):
         super().__init__()
         g = global_generator_layers(input_nc, output_nc, ngf * 2, n_down_global, n_blocks_global, up, down,
                                     n_attn_g, tuple(s // 2 for s in input_size), proj_factor_g, heads_g, dim_head_g)
@@ -199,6 +202,14 @@ class LocalEnhancerRef(nn.Module):
         self.model1_1 = nn.Sequential(nn.ReflectionPad2d(3), nn.Conv2d(input_nc, ngf, 7), _inorm(ngf), nn.ReLU(),
                                       _down(down, ngf, 2 * ngf), _inorm(2 * ngf), nn.ReLU())
         tail = [ResBlockRef(2 * ngf) for _ in range(n_blocks_local)]
+        if n_attn_l > 0:
+            middle = n_blocks_local // 2
+            d = [_down(down, 2 * ngf, ngf), _inorm(ngf), nn.ReLU()]
+            d += [_down(down, ngf, ngf), _inorm(ngf), nn.ReLU()] * 2
+            tail.insert(middle, nn.Sequential(*d))
+            fmap = tuple(x // 16 for x in input_size)
+            tail.insert(middle + 1, BotStackRef(ngf, fmap, 2 * ngf, n_attn_l, proj_factor_l, heads_l, dim_head_l))
+            tail += [_up(up, 2 * ngf, 2 * ngf), _inorm(ngf), nn.ReLU()] * 3
         tail += [_up(up, 2 * ngf, ngf), _inorm(ngf), nn.ReLU(),
                  nn.ReflectionPad2d(3), nn.Conv2d(ngf, output_nc, 7), nn.Tanh()]
         self.model1_2 = nn.Sequential(*tail)
@@ -243,14 +254,15 @@ class MultiscaleDRef(nn.Module):
 
 def build_generator(netG, input_nc, output_nc, ngf, n_down_global, n_blocks_global, n_blocks_local=3,
                     up="transconv", down="conv", input_size=(128, 256), n_attn_g=0, proj_factor_g=4, heads_g=4,
-                    dim_head_g=128):
+                    dim_head_g=128, n_attn_l=0, proj_factor_l=4, heads_l=4, dim_head_l=128):
     """define_G for netG in {global, local} (networks.py:33-56), without weights_init."""
     if netG == "global":
         return GlobalGeneratorRef(input_nc, output_nc, ngf, n_down_global, n_blocks_global, up, down, n_attn_g,
                                   input_size, proj_factor_g, heads_g, dim_head_g)
     if netG == "local":
         return LocalEnhancerRef(input_nc, output_nc, ngf, n_down_global, n_blocks_global, n_blocks_local, up, down,
-                                n_attn_g, input_size, proj_factor_g, heads_g, dim_head_g)
+                                n_attn_g, input_size, proj_factor_g, heads_g, dim_head_g, n_attn_l, proj_factor_l, heads_l,
+                                dim_head_l)
     raise NotImplementedError("generator not implemented!")
 
 

@@ -110,3 +110,17 @@ def test_bucket_layout_single_process():
     assert first[1] - first[0] <= 4096 // 4 // 4 or first[2] == 1
     assert all(b[1] - b[0] <= 4096 // 4 or b[2] == 1 for b in red.buckets)
     red.close()
+    # a module applied k times in one forward (the shared samplers of LocalEnhancer's attention sandwich) writes its
+    # gradient k times per backward: its bucket waits for all of them
+    params[1]._mg_writes = 3
+    red = ddp.ArenaReducer(flat, slices, writes_per_step=1, bucket_bytes=1 << 20)
+    assert sum(red.pending) == len(params) + 2
+    from mdctgan_amd import functional as Fh
+    red.force = False
+    for p in params:
+        for _ in range(int(getattr(p, "_mg_writes", 1))):
+            Fh._notify(p)
+    assert all(v == 0 for v in red.pending)
+    red.finish()
+    assert sum(red.pending) == len(params) + 2
+    red.close()

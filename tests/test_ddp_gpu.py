@@ -111,6 +111,8 @@ def test_update_fixed_params_under_fp16_and_ddp(golden, one_rank_group):
     # blew up and that, if steps were taken, global-branch parameters (not optimised before the swap) moved too
     if moved:
         assert any(k.startswith("model.") for k in moved)
+    for r in m.reducers.values():
+        r.close()
 
 
 def test_graphed_step_follows_learning_rate_schedule(golden):

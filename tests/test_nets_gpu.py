@@ -114,6 +114,48 @@ def test_generator_backward(tag):
     assert live >= len(grads["f64"]) // 2
 
 
+def test_local_attention_sandwich(golden):
+    """LocalEnhancer with n_blocks_attn_l = 1 (networks.py:218-237): state-dict keys and the eval-mode forward against
+    fixture G10 (the reference's module tree, shared modules included), and every parameter gradient in training mode --
+    the shared down- / up-samplers accumulate two / three weight-gradient contributions per step -- against the oracle's
+    float64 autograd."""
+    from mdctgan_amd import networks
+    g = golden("g10_netG_local_attn_l")
+    kw = dict(input_size=(64, 256), n_attn_l=1, proj_factor_l=4, heads_l=2, dim_head_l=8)
+    net = networks.define_G(2, 1, 4, "local", 2, 1, 1, 3, n_attn_g=0, **kw)
+    assert list(net.state_dict().keys()) == list(g["keys"])
+    onets.fill_deterministic(net)
+    net = net.to(DEV).eval()
+    x = torch.from_numpy(g["x"])
+    o64 = onets.fill_deterministic(onets.build_generator("local", 2, 1, 4, 2, 1, 3, **kw)).double()
+    o32 = onets.fill_deterministic(onets.build_generator("local", 2, 1, 4, 2, 1, 3, **kw))
+    with torch.no_grad():
+        y = net(x.to(DEV)).cpu().numpy()
+        y64 = o64.eval()(x.double()).numpy()
+    judged(y, g["y"], y64, "local + attn_l forward vs reference golden")
+    # gradients (training mode: BatchNorm batch statistics)
+    gen = torch.Generator().manual_seed(9)
+    xb = torch.rand(2, 2, 64, 256, generator=gen) * 2 - 1
+    gy = torch.randn(2, 1, 64, 256, generator=gen)
+    grads = {}
+    for name, o in (("f64", o64), ("f32", o32)):
+        o.train()
+        o.zero_grad()
+        dt = torch.float64 if name == "f64" else torch.float32
+        (o(xb.to(dt)) * gy.to(dt)).sum().backward()
+        grads[name] = {k: p.grad.numpy().copy() for k, p in o.named_parameters()}
+    net.train()
+    (net(xb.to(DEV)) * gy.to(DEV)).sum().backward()
+    checked = 0
+    for k, p in net.named_parameters():
+        if _dead_bias(k, grads["f64"][k], grads["f64"]):
+            continue
+        assert p.grad is not None, k
+        judged(p.grad.cpu().numpy(), grads["f32"][k], grads["f64"][k], "attn_l grad " + k, k=6.0)
+        checked += 1
+    assert checked >= 20
+
+
 def test_discriminator_forward_backward(golden):
     from mdctgan_amd import networks
     g = golden("g6_netD")

@@ -144,6 +144,23 @@ def test_bot_keys_and_shapes(golden):
     assert y.shape == (1, 1, 64, 256)
 
 
+def test_local_attention_sandwich_matches_reference(golden):
+    """networks.py:218-237 (n_blocks_attn_l > 0): fixture G10 = the reference's own LocalEnhancer module tree (shared
+    down- / up-sampling modules through Python list multiplication) around the stand-in bottleneck-transformer block, eval
+    mode.  The oracle must list the same state-dict keys (every alias of a shared module) and produce the same output."""
+    g = golden("g10_netG_local_attn_l")
+    net = nets.build_generator("local", 2, 1, 4, 2, 1, 3, input_size=(64, 256), n_attn_l=1, proj_factor_l=4, heads_l=2,
+                               dim_head_l=8)
+    assert list(net.state_dict().keys()) == list(g["keys"])
+    assert [str(tuple(p.shape)) for p in net.state_dict().values()] == list(g["shapes"])
+    # shared modules: fewer distinct parameters than state-dict entries
+    assert len(list(net.parameters())) < sum(1 for k in g["keys"] if "running" not in k and "num_batches" not in k)
+    nets.fill_deterministic(net).eval()
+    with torch.no_grad():
+        y = net(torch.from_numpy(g["x"]))
+    np.testing.assert_allclose(y.numpy(), g["y"], atol=2e-5, rtol=1e-4)
+
+
 def test_step_matches_reference(golden):
     g = golden("g6_step_global")
     netG = nets.fill_deterministic(nets.build_generator("global", 2, 1, 4, 4, 2, input_size=(32, 256)))
