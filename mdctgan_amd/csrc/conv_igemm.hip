@@ -1302,6 +1302,7 @@ inline size_t slab_count(int old_splits, int dense) {      // split-K slabs a wo
 
 #include "dense_gemm_h.h"
 #include "conv_h16.h"
+#include "conv_dma.h"
 
 
 // The 32-deep forward kernel needs dynamic LDS above the 64 KB static limit for its 128x128 tile.
@@ -2383,6 +2384,12 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
         snprintf(out, out_len, "conv_rowdot_fwd_kernel<%d>", kq);
     } else if (kq && pass == 2) {
         snprintf(out, out_len, "conv_rowdot_wgrad_kernel<%d>", kq);
+    } else if (pass == 0 && conv_dma_fwd_ok(g)) {
+        const CdPlan cp = conv_dma_fwd_plan(g);
+        snprintf(out, out_len, "conv_fwd_dma_kernel<%d, %d>", cp.bm, cp.bn);
+    } else if (pass == 2 && conv_dma_wgrad_ok(g)) {
+        const CdPlan cp = conv_dma_wgrad_plan(g);
+        snprintf(out, out_len, "conv_wgrad_dma_kernel<%d, %d>", cp.bm, cp.bn);
     } else if (pass == 0) {
         const TilePlan tp = fwd_plan(g);
         const bool vec16 = g->Ci % BK == 0;
@@ -2415,7 +2422,9 @@ size_t mg_conv_fwd_workspace(const mg_conv_geom* g) {
     if (wino4_ok(g) && !mg_conv_rowdot_kq(g)) return wino4_fwd_ws(g);
     if (wino42_ok(g)) return wino42_fwd_ws(g);
     const TilePlan tp = fwd_plan(g);
-    return tp.splits > 1 ? (size_t)tp.splits * g->B * g->OH * g->OW * g->Co * sizeof(float) + 256 : 256;
+    int sp = tp.splits;
+    if (conv_dma_fwd_ok(g) && conv_dma_fwd_plan(g).splits > sp) sp = conv_dma_fwd_plan(g).splits;
+    return sp > 1 ? (size_t)sp * g->B * g->OH * g->OW * g->Co * sizeof(float) + 256 : 256;
 }
 size_t mg_conv_dgrad_workspace(const mg_conv_geom* g) {
     if (!geom_ok(g)) return 0;
@@ -2517,6 +2526,25 @@ int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const f
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)g->B * g->OH * g->OW;
     const int N = g->Co;
+    if (conv_dma_fwd_ok(g) && aligned16(x) && aligned16(w) && aligned16(y) && (!bias || aligned16(bias))) {
+        CdPlan cp = conv_dma_fwd_plan(g);
+        if (cp.splits > 1 && (!workspace || workspace_bytes < mg_conv_fwd_workspace(g) || !aligned16(workspace))) {
+            cp.splits = 1;
+            cp.cps = 1 << 28;
+        }
+        probe_begin(st);
+        conv_dma_fwd_launch(g, cp, x, w, bias, y, act, (float*)workspace, st);
+        probe_end(st);
+        MG_CHECK_LAUNCH();
+        if (cp.splits > 1) {
+            const size_t n = (size_t)M * N;
+            const unsigned blocks = (unsigned)((n / 4 + 255) / 256 > 4096 ? 4096 : (n / 4 + 255) / 256);
+            hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, cp.splits, n, N,
+                               bias, act, y, 0);
+            MG_CHECK_LAUNCH();
+        }
+        return MG_OK;
+    }
     const bool vec = (g->Ci % BK == 0) && aligned16(x) && aligned16(w);
     TilePlan tp = fwd_plan(g);
     if (tp.splits > 1 && (!workspace || workspace_bytes < mg_conv_fwd_workspace(g) || !aligned16(y) ||
@@ -2661,7 +2689,9 @@ size_t mg_conv_wgrad_workspace(const mg_conv_geom* g) {
     if (wino42_ok(g)) return wino42_wgrad_ws(g);
     if (smallc_wgrad_kind(g)) return smallc_wgrad_ws(g);
     const WgradPlan p = wgrad_plan(g);
-    const size_t wg = p.splits > 1 ? (size_t)p.splits * g->Co * g->KH * g->KW * g->Ci * sizeof(float) : 0;
+    int sp = p.splits;
+    if (conv_dma_wgrad_ok(g) && conv_dma_wgrad_plan(g).splits > sp) sp = conv_dma_wgrad_plan(g).splits;
+    const size_t wg = sp > 1 ? (size_t)sp * g->Co * g->KH * g->KW * g->Ci * sizeof(float) : 0;
     const size_t cs = mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co);
     return (wg > cs ? wg : cs) + 256;
 }
@@ -2741,6 +2771,23 @@ int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, floa
     }
     const Geom gg = to_geom(g);
     hipStream_t st = (hipStream_t)stream;
+    if (conv_dma_wgrad_ok(g) && aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace)) {
+        const CdPlan cp = conv_dma_wgrad_plan(g);
+        const size_t n_out = (size_t)g->Co * g->KH * g->KW * g->Ci;
+        probe_begin(st);
+        conv_dma_wgrad_launch(g, cp, x, dy, dw, accumulate, (float*)workspace, st);
+        probe_end(st);
+        MG_CHECK_LAUNCH();
+        if (cp.splits > 1) {
+            const unsigned blocks = (unsigned)((n_out / 4 + 255) / 256 > 4096 ? 4096 : (n_out / 4 + 255) / 256 + 1);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, cp.splits, n_out, dw,
+                               accumulate);
+            MG_CHECK_LAUNCH();
+        }
+        if (dbias)
+            return mg_colsum(dy, (long long)g->B * g->OH * g->OW, g->Co, dbias, accumulate, workspace, workspace_bytes, stream);
+        return MG_OK;
+    }
     const WgradPlan p = wgrad_plan(g);
     const bool veca = (g->Co % 4 == 0) && aligned16(dy);
     const bool vecb = (g->Ci % 4 == 0) && aligned16(x);
