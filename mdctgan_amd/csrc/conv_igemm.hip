@@ -2384,6 +2384,9 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
         snprintf(out, out_len, "conv_rowdot_fwd_kernel<%d>", kq);
     } else if (kq && pass == 2) {
         snprintf(out, out_len, "conv_rowdot_wgrad_kernel<%d>", kq);
+    } else if (pass == 1 && conv_dma_dgrad_ok(g) && !smallc_dgrad_ok(g)) {
+        const CdPlan cp = conv_dma_dgrad_plan(g);
+        snprintf(out, out_len, "conv_dgrad_dma_kernel<%d, %d>", cp.bm, cp.bn);
     } else if (pass == 0 && conv_dma_fwd_ok(g)) {
         const CdPlan cp = conv_dma_fwd_plan(g);
         snprintf(out, out_len, "conv_fwd_dma_kernel<%d, %d>", cp.bm, cp.bn);
@@ -2433,7 +2436,9 @@ size_t mg_conv_dgrad_workspace(const mg_conv_geom* g) {
     if (wino4_ok(g)) return wino4_dgrad_ws(g);
     if (wino42_ok(g)) return wino42_dgrad_ws(g);
     const TilePlan tp = dgrad_plan(g);
-    return tp.splits > 1 ? (size_t)tp.splits * g->B * g->H * g->W * g->Ci * sizeof(float) + 256 : 256;
+    int sp = tp.splits;
+    if (conv_dma_dgrad_ok(g) && conv_dma_dgrad_plan(g).splits > sp) sp = conv_dma_dgrad_plan(g).splits;
+    return sp > 1 ? (size_t)sp * g->B * g->H * g->W * g->Ci * sizeof(float) + 256 : 256;
 }
 
 size_t mg_conv_wino_weights_bytes(const mg_conv_geom* g) {
@@ -2612,6 +2617,22 @@ int mg_conv_dgrad_w(const mg_conv_geom* g, const float* dy, const float* w, cons
     const Geom gg = to_geom(g);
     hipStream_t st = (hipStream_t)stream;
     const int s = g->stride;
+    if (conv_dma_dgrad_ok(g) && aligned16(dy) && aligned16(w) && aligned16(dx) && (!bias || aligned16(bias))) {
+        CdPlan cp = conv_dma_dgrad_plan(g);
+        if (cp.splits > 1 && (!workspace || workspace_bytes < mg_conv_dgrad_workspace(g) || !aligned16(workspace))) cp.splits = 1;
+        probe_begin(st);
+        conv_dma_dgrad_launch(g, cp, dy, w, bias, dx, act, (float*)workspace, st);
+        probe_end(st);
+        MG_CHECK_LAUNCH();
+        if (cp.splits > 1) {
+            const size_t n = (size_t)g->B * g->H * g->W * g->Ci;
+            const unsigned blocks = (unsigned)((n / 4 + 255) / 256 > 4096 ? 4096 : (n / 4 + 255) / 256);
+            hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, cp.splits, n, g->Ci,
+                               bias, act, dx, 0);
+            MG_CHECK_LAUNCH();
+        }
+        return MG_OK;
+    }
     // every input pixel is produced by exactly one class launch; classes cover all of [0,H)x[0,W)
     const long long Mc = (long long)g->B * ((g->H + s - 1) / s) * ((g->W + s - 1) / s);   // largest class
     const int N = g->Ci;
