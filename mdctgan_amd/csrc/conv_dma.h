@@ -15,14 +15,90 @@
 
 constexpr unsigned CD_OOB = 0x80000000u;      // >= any num_records: the DMA lane reads zeros
 
+// HALF instances (autocast, MG_PRECISION_F16): the same kernels over float16 copies of the activations and weights (cast
+// pre-passes, conv_igemm.hip) on v_mfma_f32_32x32x16_f16.  A chunk row is still 128 bytes -- 64 channels -- so the gather,
+// the LDS images of the k-contiguous operands and the pipeline are unchanged; ds_read_b128 yields the 8-half MFMA operand.
+// Row-contiguous operands (the weight gradient's two sides, the data gradient's weights) are k-major LDS images [64][R]
+// halves read with ds_read_b64_tr_b16 (16 lanes fetch a [4 k][16 columns] block, every lane receives the 4 k of its
+// column): two reads are one MFMA operand.  The 16-byte slots of a k row are XOR-swizzled on the DMA source side so that
+// the 8 row segments a 32-lane half reads fall into 8 different 32-byte bank groups.
+template <bool HALF>
+struct CdElem {
+    static constexpr unsigned ES = HALF ? 2u : 4u;      // element bytes
+    static constexpr int CK = HALF ? 64 : 32;           // K depth of one chunk (128-byte rows)
+};
+template <int R>
+__device__ __forceinline__ int cd_rc_swz(int k) { return R == 128 ? ((k & 3) << 2) : (((k >> 1) & 1) << 2); }
+
+typedef __fp16 cd_h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef cd_h4 __attribute__((address_space(3))) * cd_h4_lds;
+
+__device__ __forceinline__ f16x8 cd_frag_kc(const float* S, int row, int s, int kh) {
+    return *reinterpret_cast<const f16x8*>(S + row * 32 + 4 * ((2 * s + kh) ^ ((row >> 1) & 7)));
+}
+// RC image [64][R] halves; col0 = tile-relative first column of the wave's 32-column block
+template <int R>
+__device__ __forceinline__ f16x8 cd_frag_rc(const float* S, int col0, int s, int lane) {
+    static_assert(R == 64 || R == 128, "row-contiguous operand tiles are 64 or 128 columns wide");
+    const int i = lane & 15;
+    const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
+    const int k = 16 * s + 8 * (lane >> 5) + (i >> 2);
+    const char* p = reinterpret_cast<const char*>(S) + k * (2 * R) + 16 * ((col >> 3) ^ cd_rc_swz<R>(k)) + 2 * (col & 7);
+    const cd_h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((cd_h4_lds)(p));
+    const cd_h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((cd_h4_lds)(p + 8 * R));       // k + 4: same swizzle
+    f16x8 v;
+    v[0] = (_Float16)lo[0]; v[1] = (_Float16)lo[1]; v[2] = (_Float16)lo[2]; v[3] = (_Float16)lo[3];
+    v[4] = (_Float16)hi[0]; v[5] = (_Float16)hi[1]; v[6] = (_Float16)hi[2]; v[7] = (_Float16)hi[3];
+    return v;
+}
+template <int MB, int NB, int ALAY, int BLAY, int BM, int BN>
+__device__ __forceinline__ void cd_chunk_h(const float* As, const float* Bs, f32x16 (&acc)[MB][NB], int wm0, int wn0, int lane) {
+    const int r = lane & 31, kh = lane >> 5;
+    f16x8 a[2][MB], b[2][NB];
+    auto fetch = [&](int s, int buf) {
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi)
+            a[buf][mi] = ALAY == DG_KC ? cd_frag_kc(As, wm0 + 32 * mi + r, s, kh) : cd_frag_rc<BM>(As, wm0 + 32 * mi, s, lane);
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni)
+            b[buf][ni] = BLAY == DG_KC ? cd_frag_kc(Bs, wn0 + 32 * ni + r, s, kh) : cd_frag_rc<BN>(Bs, wn0 + 32 * ni, s, lane);
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (s + 1 < 4) fetch(s + 1, (s + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = mfma32x32x16h(a[s & 1][mi], b[s & 1][ni], acc[mi][ni]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <bool HALF, int MB, int NB, int ALAY, int BLAY, int BM, int BN>
+__device__ __forceinline__ void cd_chunk(const float* As, const float* Bs, f32x16 (&acc)[MB][NB], int wm0, int wn0, int lane) {
+    if constexpr (HALF) cd_chunk_h<MB, NB, ALAY, BLAY, BM, BN>(As, Bs, acc, wm0, wn0, lane);
+    else dg_chunk_g<MB, NB, ALAY, BLAY, BM, BN>(As, Bs, acc, wm0, wn0, lane);
+}
+// byte offset of the 16 bytes lane `lane` fetches for piece `piece` of a row-contiguous operand tile ([K][R], ld elements
+// between k rows): k row inside the chunk and source column (swizzled for the float16 transpose reads)
+template <bool HALF, int R>
+__device__ __forceinline__ void cd_rc_lane(int piece, int lane, int& k, int& col) {
+    constexpr int EPL = HALF ? 8 : 4, LPR = R / EPL;        // elements per lane, lanes per k row
+    k = piece * (64 / LPR) + lane / LPR;
+    const int j = lane % LPR;
+    col = EPL * (HALF ? (j ^ cd_rc_swz<R>(k)) : j);
+}
+
 struct CdArgs {
-    const float* x;          // FWD: input [B,H,W,Ci];  WGRAD: input x
-    const float* w;          // FWD: weights [Co][KH*KW*Ci];  WGRAD: dy [B,OH,OW,Co]
+    const void* x;           // FWD: input [B,H,W,Ci];  WGRAD: input x;  DGRAD: dy           (float32, HALF: float16)
+    const void* w;           // FWD: weights [Co][KH*KW*Ci];  WGRAD: dy [B,OH,OW,Co];  DGRAD: weights
     const float* bias;
     float* y;                // FWD: output [M][Co];  WGRAD: dW [Co][KH*KW*Ci]
     float* part;             // split-K slabs
     int B, H, W, Ci, OH, OW, Co, KH, KW, s, p, reflect;
     int act, tiles_m, tiles_n, splits, cps, accumulate;
+    int round_f16;           // HALF: round the direct result through float16 (autocast output)
 };
 
 __device__ __forceinline__ unsigned cd_pixel_off(const CdArgs& g, int pb, int iy, int ix, unsigned cbytes) {
@@ -38,10 +114,12 @@ __device__ __forceinline__ unsigned cd_pixel_off(const CdArgs& g, int pb, int iy
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN>
+template <int BM, int BN, bool HALF = false>
 __global__ __launch_bounds__(256) void conv_fwd_dma_kernel(CdArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using Cfg = DgCfgG<BM, BN, 2, 2, DG_KC, DG_KC, 2>;
+    constexpr unsigned ES = CdElem<HALF>::ES;
+    constexpr int CK = CdElem<HALF>::CK;
     constexpr int MB = Cfg::MB, NB = Cfg::NB, PA = Cfg::PA, PB = Cfg::PB;
     extern __shared__ __attribute__((aligned(1024))) float cd_smem[];
     float* As0 = cd_smem;
@@ -54,18 +132,18 @@ __global__ __launch_bounds__(256) void conv_fwd_dma_kernel(CdArgs g) {
     const int sp = L / tiles, rem = L - sp * tiles;
     const int tn = rem / g.tiles_m, tm = rem - tn * g.tiles_m;      // consecutive tiles share the weight panel
     const int m0 = tm * BM, n0 = tn * BN;
-    const int cpt = g.Ci / DG_BK, total_chunks = KT * cpt;
+    const int cpt = g.Ci / CK, total_chunks = KT * cpt;
     const int c_begin = sp * g.cps, c_end = min(total_chunks, c_begin + g.cps);
 
-    auto make_rsrc = [](const float* p, unsigned bytes) -> dg_v4i {
+    auto make_rsrc = [](const void* p, unsigned bytes) -> dg_v4i {
         const unsigned long long a = (unsigned long long)p;
         dg_v4i r;
         r[0] = (int)(unsigned)a; r[1] = (int)((unsigned)(a >> 32) & 0xffffu); r[2] = (int)bytes; r[3] = 0x00020000;
         return r;
     };
-    const unsigned cbytes = (unsigned)g.Ci * 4u;
+    const unsigned cbytes = (unsigned)g.Ci * ES;
     const dg_v4i ra = make_rsrc(g.x, (unsigned)g.B * (unsigned)g.H * (unsigned)g.W * cbytes);
-    const dg_v4i rb = make_rsrc(g.w, (unsigned)N * (unsigned)K * 4u);
+    const dg_v4i rb = make_rsrc(g.w, (unsigned)N * (unsigned)K * ES);
     // this lane's PA rows of the A tile: output pixel -> top-left input coordinate and sample base
     int iy0[PA], ix0[PA], pb[PA];
     unsigned qa[PA];
@@ -84,7 +162,7 @@ __global__ __launch_bounds__(256) void conv_fwd_dma_kernel(CdArgs g) {
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
         const int row = 8 * (wave * PB + i) + (lane >> 3), q = (lane & 7) ^ ((row >> 1) & 7);
-        vb[i] = ((unsigned)min(n0 + row, N - 1) * (unsigned)K + 4u * q) * 4u;
+        vb[i] = (unsigned)min(n0 + row, N - 1) * (unsigned)K * ES + 16u * q;
     }
     int tap = c_begin / cpt, cc = c_begin - tap * cpt;       // running position of the NEXT chunk to issue
     auto set_tap = [&]() {
@@ -100,7 +178,7 @@ __global__ __launch_bounds__(256) void conv_fwd_dma_kernel(CdArgs g) {
     const unsigned lds_b0 = (unsigned)(size_t)(dg_lds_ptr)Bs0 + (unsigned)(wave * PB) * 1024u;
     auto issue = [&](int c, int buf) {        // chunks are issued in increasing c: (tap, cc) is a running state
         const unsigned la = lds_a0 + (unsigned)buf * (unsigned)(Cfg::ASZ * 4), lb = lds_b0 + (unsigned)buf * (unsigned)(Cfg::BSZ * 4);
-        const unsigned sa_off = (unsigned)cc * (DG_BK * 4u), sb_off = (unsigned)c * (DG_BK * 4u);
+        const unsigned sa_off = (unsigned)cc * 128u, sb_off = (unsigned)c * 128u;
 #pragma unroll
         for (int i = 0; i < PA; ++i) dg_dma16(va[i], ra, la + 1024u * i, sa_off);
 #pragma unroll
@@ -121,7 +199,7 @@ __global__ __launch_bounds__(256) void conv_fwd_dma_kernel(CdArgs g) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < c_end) issue(c + 1, cur ^ 1);
-        dg_chunk_g<MB, NB, DG_KC, DG_KC, BM, BN>(As0 + cur * Cfg::ASZ, Bs0 + cur * Cfg::BSZ, acc, wm0, wn0, lane);
+        cd_chunk<HALF, MB, NB, DG_KC, DG_KC, BM, BN>(As0 + cur * Cfg::ASZ, Bs0 + cur * Cfg::BSZ, acc, wm0, wn0, lane);
     }
 
     float* o = g.part ? g.part + (size_t)sp * ((size_t)M * N) : g.y;
@@ -137,7 +215,8 @@ __global__ __launch_bounds__(256) void conv_fwd_dma_kernel(CdArgs g) {
                 const int row = m0 + wm0 + 32 * mi + mfma32_row(r, lane);
                 if (row < M && col < N) {
                     const float v = acc[mi][ni][r];
-                    o[(size_t)row * N + col] = direct ? apply_act(v + bv, g.act) : v;
+                    const float va2 = apply_act(v + bv, g.act);
+                    o[(size_t)row * N + col] = direct ? ((HALF && g.round_f16) ? round_h(va2) : va2) : v;
                 }
             }
         }
@@ -147,10 +226,12 @@ __global__ __launch_bounds__(256) void conv_fwd_dma_kernel(CdArgs g) {
 // ------------------------------------------------------------------------------------------------------------------
 // weight gradient: rows co, columns (tap, ci), reduction over output pixels (split over workgroups)
 // ------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN>
+template <int BM, int BN, bool HALF = false>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(CdArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using Cfg = DgCfgG<BM, BN, 2, 2, DG_RC, DG_RC, 2>;
+    constexpr unsigned ES = CdElem<HALF>::ES;
+    constexpr int CK = CdElem<HALF>::CK;
     constexpr int MB = Cfg::MB, NB = Cfg::NB, PA = Cfg::PA, PB = Cfg::PB;
     static_assert(BN == 64, "a column tile must lie inside one tap (Ci % 64 == 0)");
     extern __shared__ __attribute__((aligned(1024))) float cd_smem[];
@@ -166,43 +247,47 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(CdArgs g) {
     const int r_0 = tm * BM, n0 = tn * BN;
     const int tap = n0 / g.Ci, ci0 = n0 - tap * g.Ci;
     const int ky = tap / g.KW, kx = tap - ky * g.KW;
-    const int total_chunks = (Mpx + DG_BK - 1) / DG_BK;
+    const int total_chunks = (Mpx + CK - 1) / CK;
     const int c_begin = sp * g.cps, c_end = min(total_chunks, c_begin + g.cps);
 
-    auto make_rsrc = [](const float* p, unsigned bytes) -> dg_v4i {
+    auto make_rsrc = [](const void* p, unsigned bytes) -> dg_v4i {
         const unsigned long long a = (unsigned long long)p;
         dg_v4i r;
         r[0] = (int)(unsigned)a; r[1] = (int)((unsigned)(a >> 32) & 0xffffu); r[2] = (int)bytes; r[3] = 0x00020000;
         return r;
     };
-    const unsigned cbytes = (unsigned)g.Ci * 4u;
+    const unsigned cbytes = (unsigned)g.Ci * ES;
     // A = dy [Mpx][Co]: rows behind Mpx are behind num_records (zeros) -- the K tail is free
-    const dg_v4i ra = make_rsrc(g.w, (unsigned)Mpx * (unsigned)g.Co * 4u);
+    const dg_v4i ra = make_rsrc(g.w, (unsigned)Mpx * (unsigned)g.Co * ES);
     const dg_v4i rb = make_rsrc(g.x, (unsigned)g.B * (unsigned)g.H * (unsigned)g.W * cbytes);
-    constexpr int LPRA = BM / 4, LPRB = BN / 4;          // lanes per k row
+    constexpr int EPL = HALF ? 8 : 4;                    // elements per lane (16 bytes)
     unsigned va[PA];
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-        const int k = (wave * PA + i) * (64 / LPRA) + lane / LPRA, c4 = lane % LPRA;
-        va[i] = ((unsigned)k * (unsigned)g.Co + (unsigned)min(r_0 + 4 * c4, R - 4)) * 4u;
+        int k, col;
+        cd_rc_lane<HALF, BM>(wave * PA + i, lane, k, col);
+        va[i] = ((unsigned)k * (unsigned)g.Co + (unsigned)min(r_0 + col, R - EPL)) * ES;
     }
     // B rows: pixel m = 32 c + krow of this lane, as running (b, oy, ox)
     int pm[PB], pbb[PB], poy[PB], pox[PB];
-    const unsigned qb = (unsigned)(ci0 + 4 * (lane % LPRB)) * 4u;
+    unsigned qb[PB];
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-        pm[i] = c_begin * DG_BK + (wave * PB + i) * (64 / LPRB) + lane / LPRB;
+        int k, col;
+        cd_rc_lane<HALF, BN>(wave * PB + i, lane, k, col);
+        qb[i] = (unsigned)(ci0 + col) * ES;
+        pm[i] = c_begin * CK + k;
         pbb[i] = pm[i] / (g.OH * g.OW);
         const int r2 = pm[i] - pbb[i] * (g.OH * g.OW);
         poy[i] = r2 / g.OW;
         pox[i] = r2 - poy[i] * g.OW;
     }
-    const int adv_oy = DG_BK / g.OW, adv_ox = DG_BK - adv_oy * g.OW;
+    const int adv_oy = CK / g.OW, adv_ox = CK - adv_oy * g.OW;
     const unsigned lds_a0 = (unsigned)(size_t)(dg_lds_ptr)As0 + (unsigned)(wave * PA) * 1024u;
     const unsigned lds_b0 = (unsigned)(size_t)(dg_lds_ptr)Bs0 + (unsigned)(wave * PB) * 1024u;
     auto issue = [&](int c, int buf) {
         const unsigned la = lds_a0 + (unsigned)buf * (unsigned)(Cfg::ASZ * 4), lb = lds_b0 + (unsigned)buf * (unsigned)(Cfg::BSZ * 4);
-        const unsigned sa_off = (unsigned)c * (unsigned)DG_BK * (unsigned)g.Co * 4u;
+        const unsigned sa_off = (unsigned)c * (unsigned)CK * (unsigned)g.Co * ES;
 #pragma unroll
         for (int i = 0; i < PA; ++i) dg_dma16(va[i], ra, la + 1024u * i, sa_off);
 #pragma unroll
@@ -210,10 +295,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(CdArgs g) {
             unsigned o = CD_OOB;
             if (pm[i] < Mpx) {
                 o = cd_pixel_off(g, pbb[i] * g.H * g.W, poy[i] * g.s - g.p + ky, pox[i] * g.s - g.p + kx, cbytes);
-                if (o != CD_OOB) o += qb;
+                if (o != CD_OOB) o += qb[i];
             }
             dg_dma16(o, rb, lb + 1024u * i, 0u);
-            pm[i] += DG_BK;
+            pm[i] += CK;
             pox[i] += adv_ox;
             poy[i] += adv_oy;
             if (pox[i] >= g.OW) { pox[i] -= g.OW; ++poy[i]; }
@@ -234,7 +319,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(CdArgs g) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < c_end) issue(c + 1, cur ^ 1);
-        dg_chunk_g<MB, NB, DG_RC, DG_RC, BM, BN>(As0 + cur * Cfg::ASZ, Bs0 + cur * Cfg::BSZ, acc, wm0, wn0, lane);
+        cd_chunk<HALF, MB, NB, DG_RC, DG_RC, BM, BN>(As0 + cur * Cfg::ASZ, Bs0 + cur * Cfg::BSZ, acc, wm0, wn0, lane);
     }
 
     float* o = g.part ? g.part + (size_t)sp * ((size_t)R * N) : g.y;
@@ -263,10 +348,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(CdArgs g) {
 // A: gathered rows of dY (k-contiguous, range-checked like the forward's), B: the weights viewed [(tap, co)][ci]
 // (row-contiguous: k-major LDS image, ds_read_b32 fragments).  grid = (tiles, classes, splits).
 // ------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN>
+template <int BM, int BN, bool HALF = false>
 __global__ __launch_bounds__(256) void conv_dgrad_dma_kernel(CdArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using Cfg = DgCfgG<BM, BN, 2, 2, DG_KC, DG_RC, 2>;
+    constexpr unsigned ES = CdElem<HALF>::ES;
+    constexpr int CK = CdElem<HALF>::CK;
     constexpr int MB = Cfg::MB, NB = Cfg::NB, PA = Cfg::PA, PB = Cfg::PB;
     extern __shared__ __attribute__((aligned(1024))) float cd_smem[];
     float* As0 = cd_smem;
@@ -294,19 +381,19 @@ __global__ __launch_bounds__(256) void conv_dgrad_dma_kernel(CdArgs g) {
     const int ky0 = (py + g.p) % s, kx0 = (px + g.p) % s;
     const int nky = (g.KH - ky0 + s - 1) / s, nkx = (g.KW - kx0 + s - 1) / s;
     const int oyb = (py + g.p) / s, oxb = (px + g.p) / s;
-    const int cpt = g.Co / DG_BK, total_chunks = nky * nkx * cpt;
+    const int cpt = g.Co / CK, total_chunks = nky * nkx * cpt;
     const int cps = (total_chunks + (int)gridDim.z - 1) / (int)gridDim.z;     // every class splits its own K range evenly
     const int c_begin = blockIdx.z * cps, c_end = min(total_chunks, c_begin + cps);
 
-    auto make_rsrc = [](const float* p, unsigned bytes) -> dg_v4i {
+    auto make_rsrc = [](const void* p, unsigned bytes) -> dg_v4i {
         const unsigned long long a = (unsigned long long)p;
         dg_v4i r;
         r[0] = (int)(unsigned)a; r[1] = (int)((unsigned)(a >> 32) & 0xffffu); r[2] = (int)bytes; r[3] = 0x00020000;
         return r;
     };
-    const unsigned cbytes = (unsigned)g.Co * 4u;
+    const unsigned cbytes = (unsigned)g.Co * ES;
     const dg_v4i ra = make_rsrc(g.x, (unsigned)g.B * (unsigned)g.OH * (unsigned)g.OW * cbytes);          // dy
-    const dg_v4i rb = make_rsrc(g.w, (unsigned)g.Co * (unsigned)KT * (unsigned)g.Ci * 4u);
+    const dg_v4i rb = make_rsrc(g.w, (unsigned)g.Co * (unsigned)KT * (unsigned)g.Ci * ES);
     int yy[PA], xx[PA], pb[PA];
     unsigned qa[PA];
 #pragma unroll
@@ -319,12 +406,12 @@ __global__ __launch_bounds__(256) void conv_dgrad_dma_kernel(CdArgs g) {
         xx[i] = r2 - (r2 / Wc) * Wc + oxb;
         pb[i] = b * g.OH * g.OW;
     }
-    constexpr int LPRB = BN / 4;
     unsigned va[PA], vb[PB];
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-        const int k = (wave * PB + i) * (64 / LPRB) + lane / LPRB, c4 = lane % LPRB;
-        vb[i] = ((unsigned)k * (unsigned)(KT * g.Ci) + (unsigned)(n0 + 4 * c4)) * 4u;
+        int k, col;
+        cd_rc_lane<HALF, BN>(wave * PB + i, lane, k, col);
+        vb[i] = ((unsigned)k * (unsigned)(KT * g.Ci) + (unsigned)(n0 + col)) * ES;
     }
     int tapi = c_begin / cpt, cc = c_begin - tapi * cpt;
     unsigned tap_off_b = 0;
@@ -336,15 +423,15 @@ __global__ __launch_bounds__(256) void conv_dgrad_dma_kernel(CdArgs g) {
             const bool ok = (unsigned)oy < (unsigned)g.OH && (unsigned)ox < (unsigned)g.OW;
             va[i] = ok ? (unsigned)(pb[i] + oy * g.OW + ox) * cbytes + qa[i] : CD_OOB;
         }
-        tap_off_b = (unsigned)(((ky0 + s * tyi) * g.KW + kx0 + s * txi) * g.Ci) * 4u;
+        tap_off_b = (unsigned)(((ky0 + s * tyi) * g.KW + kx0 + s * txi) * g.Ci) * ES;
     };
     set_tap();
     const unsigned lds_a0 = (unsigned)(size_t)(dg_lds_ptr)As0 + (unsigned)(wave * PA) * 1024u;
     const unsigned lds_b0 = (unsigned)(size_t)(dg_lds_ptr)Bs0 + (unsigned)(wave * PB) * 1024u;
-    const unsigned co_stride = (unsigned)(KT * g.Ci) * 4u * (unsigned)DG_BK;      // 32 output channels further
+    const unsigned co_stride = (unsigned)(KT * g.Ci) * ES * (unsigned)CK;      // one chunk of output channels further
     auto issue = [&](int c, int buf) {
         const unsigned la = lds_a0 + (unsigned)buf * (unsigned)(Cfg::ASZ * 4), lb = lds_b0 + (unsigned)buf * (unsigned)(Cfg::BSZ * 4);
-        const unsigned sa_off = (unsigned)cc * (DG_BK * 4u), sb_off = tap_off_b + (unsigned)cc * co_stride;
+        const unsigned sa_off = (unsigned)cc * 128u, sb_off = tap_off_b + (unsigned)cc * co_stride;
 #pragma unroll
         for (int i = 0; i < PA; ++i) dg_dma16(va[i], ra, la + 1024u * i, sa_off);
 #pragma unroll
@@ -365,7 +452,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_dma_kernel(CdArgs g) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < c_end) issue(c + 1, cur ^ 1);
-        dg_chunk_g<MB, NB, DG_KC, DG_RC, BM, BN>(As0 + cur * Cfg::ASZ, Bs0 + cur * Cfg::BSZ, acc, wm0, wn0, lane);
+        cd_chunk<HALF, MB, NB, DG_KC, DG_RC, BM, BN>(As0 + cur * Cfg::ASZ, Bs0 + cur * Cfg::BSZ, acc, wm0, wn0, lane);
     }
 
     // split-K slabs are whole dx images (classes write disjoint pixels of the same slab)
@@ -384,31 +471,50 @@ __global__ __launch_bounds__(256) void conv_dgrad_dma_kernel(CdArgs g) {
             for (int ni = 0; ni < NB; ++ni) {
                 const int col = n0 + wn0 + 32 * ni + (lane & 31);
                 const float v = acc[mi][ni][r];
-                o[off + col] = direct ? apply_act(v + (g.bias ? g.bias[col] : 0.0f), g.act) : v;
+                const float vb2 = apply_act(v + (g.bias ? g.bias[col] : 0.0f), g.act);
+                o[off + col] = direct ? ((HALF && g.round_f16) ? round_h(vb2) : vb2) : v;
             }
         }
 #endif
 }
 
 inline bool conv_dma_enabled() { static const bool off = getenv("MG_NO_CONV_DMA") != nullptr; return !off; }
+inline bool conv_dma_half(const mg_conv_geom* g) { return g->precision == MG_PRECISION_F16; }
+inline bool conv_dma_prec_ok(const mg_conv_geom* g) {
+    static const bool off_h = getenv("MG_NO_CONV_DMA_H") != nullptr;
+    if (!conv_dma_enabled()) return false;
+    return g->precision == MG_PRECISION_F32 || (g->precision == MG_PRECISION_F16 && !off_h);
+}
+inline int conv_dma_ck(const mg_conv_geom* g) { return conv_dma_half(g) ? 64 : 32; }
+inline double conv_dma_es(const mg_conv_geom* g) { return conv_dma_half(g) ? 2.0 : 4.0; }
 inline bool conv_dma_fwd_ok(const mg_conv_geom* g) {
-    return conv_dma_enabled() && g->precision == MG_PRECISION_F32 && g->Ci % DG_BK == 0 && g->Co % 64 == 0 &&
-           (double)g->B * g->H * g->W * g->Ci * 4.0 < 2e9 && (double)g->Co * g->KH * g->KW * g->Ci * 4.0 < 2e9;
+    return conv_dma_prec_ok(g) && g->Ci % conv_dma_ck(g) == 0 && g->Co % 64 == 0 &&
+           (double)g->B * g->H * g->W * g->Ci * conv_dma_es(g) < 2e9 && (double)g->Co * g->KH * g->KW * g->Ci * conv_dma_es(g) < 2e9;
 }
 inline bool conv_dma_wgrad_ok(const mg_conv_geom* g) {
-    return conv_dma_enabled() && g->precision == MG_PRECISION_F32 && g->Ci % 64 == 0 && g->Co % 64 == 0 &&
-           (double)g->B * g->H * g->W * g->Ci * 4.0 < 2e9 && (double)g->B * g->OH * g->OW * g->Co * 4.0 < 2e9;
+    return conv_dma_prec_ok(g) && g->Ci % 64 == 0 && g->Co % 64 == 0 &&
+           (double)g->B * g->H * g->W * g->Ci * conv_dma_es(g) < 2e9 && (double)g->B * g->OH * g->OW * g->Co * conv_dma_es(g) < 2e9;
 }
 inline bool conv_dma_dgrad_ok(const mg_conv_geom* g) {
-    return conv_dma_enabled() && g->precision == MG_PRECISION_F32 && !g->reflect && g->Co % DG_BK == 0 && g->Ci % 64 == 0 &&
-           (double)g->B * g->OH * g->OW * g->Co * 4.0 < 2e9 && (double)g->Co * g->KH * g->KW * g->Ci * 4.0 < 2e9;
+    return conv_dma_prec_ok(g) && !g->reflect && g->Co % conv_dma_ck(g) == 0 && g->Ci % 64 == 0 &&
+           (double)g->B * g->OH * g->OW * g->Co * conv_dma_es(g) < 2e9 && (double)g->Co * g->KH * g->KW * g->Ci * conv_dma_es(g) < 2e9;
 }
+// float16 staging of the HALF instances (bytes, 256-aligned): activations cast by a pre-pass, weights unless a cached copy
+// (mg_wino_tiles.u, mg_conv_wino_prepare) is handed in
+inline size_t cd_al(size_t b) { return (b + 255) & ~(size_t)255; }
+inline size_t conv_dma_h_x_bytes(const mg_conv_geom* g) { return cd_al((size_t)g->B * g->H * g->W * g->Ci * 2); }
+inline size_t conv_dma_h_dy_bytes(const mg_conv_geom* g) { return cd_al((size_t)g->B * g->OH * g->OW * g->Co * 2); }
+inline size_t conv_dma_h_w_bytes(const mg_conv_geom* g) { return cd_al((size_t)g->Co * g->KH * g->KW * g->Ci * 2); }
 struct CdPlan { int bm, bn, splits, cps; };
-// the dense plan's cost model (dense_plan above) on the convolution's GEMM view, DMA instances only
-CdPlan conv_dma_plan(long long M, int N, int chunks, bool wgrad) {
+// the dense plan's cost model (dense_plan above) on the convolution's GEMM view, DMA instances only.  ck = K depth of a chunk
+// (32 float32 / 64 float16); the float16 instances are priced at 4x the float32 MFMA rate (what the staging sustains) with a
+// proportionally larger fixed cost per workgroup.
+CdPlan conv_dma_plan(long long M, int N, int chunks, bool wgrad, int ck) {
     struct Cand { int bm, bn; double eff; };
     static const Cand cands[4] = {{64, 64, 0.83}, {64, 128, 0.885}, {128, 64, 0.855}, {128, 128, 0.91}};
     static const int split_opts[12] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
+    const bool half = ck == 64;
+    const double rate = (half ? 4.0 : 1.0) * 157.3e12 / 256.0, fixed = half ? 4.0 : 1.2;
     CdPlan p{64, 64, 1, 1 << 28};
     int f_bm = 0, f_bn = 0, f_sp = 0;
     if (const char* f = getenv("MG_FORCE_CONV_DMA")) {      // tuning harness: "bm,bn,splits"
@@ -419,14 +525,14 @@ CdPlan conv_dma_plan(long long M, int N, int chunks, bool wgrad) {
         if (N % c.bn != 0 || (wgrad && c.bn != 64)) continue;
         if (f_bm && (c.bm != f_bm || c.bn != f_bn)) continue;
         const long long w = ((M + c.bm - 1) / c.bm) * (long long)(N / c.bn);
-        const double tile_us = 2.0 * c.bm * c.bn * DG_BK / (157.3e12 / 256.0) * 1e6 / c.eff;
+        const double tile_us = 2.0 * c.bm * c.bn * ck / rate * 1e6 / c.eff;
         for (int sp : split_opts) {
             if (sp > 1 && chunks / sp < 8) break;
             if (f_sp && sp != f_sp) continue;
             const int cps = (chunks + sp - 1) / sp;
             const int spl = (chunks + cps - 1) / cps;
             const long long wg = w * spl;
-            double t = (double)((wg + 255) / 256) * tile_us * (cps + 1.2);
+            double t = (double)((wg + 255) / 256) * tile_us * (cps + fixed);
             if (wg < 512) t /= 0.85;
             if (spl > 1) t += (double)(spl + 1) * (double)M * N * 4.0 / 4e12 * 1e6 + 3.0;
             if (t < best) { best = t; p = {c.bm, c.bn, spl, cps}; }
@@ -436,50 +542,67 @@ CdPlan conv_dma_plan(long long M, int N, int chunks, bool wgrad) {
     return p;
 }
 inline CdPlan conv_dma_fwd_plan(const mg_conv_geom* g) {
-    return conv_dma_plan((long long)g->B * g->OH * g->OW, g->Co, g->KH * g->KW * (g->Ci / DG_BK), false);
+    const int ck = conv_dma_ck(g);
+    return conv_dma_plan((long long)g->B * g->OH * g->OW, g->Co, g->KH * g->KW * (g->Ci / ck), false, ck);
 }
 inline CdPlan conv_dma_wgrad_plan(const mg_conv_geom* g) {
     const long long Mpx = (long long)g->B * g->OH * g->OW;
-    return conv_dma_plan(g->Co, g->KH * g->KW * g->Ci, (int)((Mpx + DG_BK - 1) / DG_BK), true);
+    const int ck = conv_dma_ck(g);
+    return conv_dma_plan(g->Co, g->KH * g->KW * g->Ci, (int)((Mpx + ck - 1) / ck), true, ck);
 }
 template <typename KernelT>
-inline void cd_launch(KernelT kern, size_t lds, unsigned grid, const CdArgs& a, hipStream_t st) {
+inline void cd_launch(KernelT kern, size_t lds, dim3 grid, const CdArgs& a, hipStream_t st) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
 }
 inline CdArgs cd_args(const mg_conv_geom* g) {
     CdArgs a{};
     a.B = g->B; a.H = g->H; a.W = g->W; a.Ci = g->Ci; a.OH = g->OH; a.OW = g->OW; a.Co = g->Co; a.KH = g->KH; a.KW = g->KW;
     a.s = g->stride; a.p = g->pad; a.reflect = g->reflect;
+    a.round_f16 = conv_dma_half(g) ? 1 : 0;
     return a;
 }
-void conv_dma_fwd_launch(const mg_conv_geom* g, const CdPlan& p, const float* x, const float* w, const float* bias, float* y,
+// x, w: float32 tensors, or (conv_dma_half(g)) their float16 copies
+template <bool HALF>
+void conv_dma_fwd_launch_t(const CdArgs& a, const CdPlan& p, dim3 grid, hipStream_t st) {
+    if (p.bm == 128 && p.bn == 128) cd_launch(conv_fwd_dma_kernel<128, 128, HALF>, DgCfgG<128, 128, 2, 2, 0, 0, 2>::LDS_BYTES, grid, a, st);
+    else if (p.bm == 64 && p.bn == 128) cd_launch(conv_fwd_dma_kernel<64, 128, HALF>, DgCfgG<64, 128, 2, 2, 0, 0, 2>::LDS_BYTES, grid, a, st);
+    else if (p.bm == 128 && p.bn == 64) cd_launch(conv_fwd_dma_kernel<128, 64, HALF>, DgCfgG<128, 64, 2, 2, 0, 0, 2>::LDS_BYTES, grid, a, st);
+    else cd_launch(conv_fwd_dma_kernel<64, 64, HALF>, DgCfgG<64, 64, 2, 2, 0, 0, 2>::LDS_BYTES, grid, a, st);
+}
+void conv_dma_fwd_launch(const mg_conv_geom* g, const CdPlan& p, const void* x, const void* w, const float* bias, float* y,
                          int act, float* part, hipStream_t st) {
     CdArgs a = cd_args(g);
     a.x = x; a.w = w; a.bias = bias; a.y = y; a.part = p.splits > 1 ? part : nullptr; a.act = act;
     const long long M = (long long)g->B * g->OH * g->OW;
     a.tiles_m = (int)((M + p.bm - 1) / p.bm); a.tiles_n = g->Co / p.bn; a.splits = p.splits; a.cps = p.cps;
-    const unsigned grid = (unsigned)((long long)a.tiles_m * a.tiles_n * a.splits);
-    if (p.bm == 128 && p.bn == 128) cd_launch(conv_fwd_dma_kernel<128, 128>, DgCfgG<128, 128, 2, 2, 0, 0, 2>::LDS_BYTES, grid, a, st);
-    else if (p.bm == 64 && p.bn == 128) cd_launch(conv_fwd_dma_kernel<64, 128>, DgCfgG<64, 128, 2, 2, 0, 0, 2>::LDS_BYTES, grid, a, st);
-    else if (p.bm == 128 && p.bn == 64) cd_launch(conv_fwd_dma_kernel<128, 64>, DgCfgG<128, 64, 2, 2, 0, 0, 2>::LDS_BYTES, grid, a, st);
-    else cd_launch(conv_fwd_dma_kernel<64, 64>, DgCfgG<64, 64, 2, 2, 0, 0, 2>::LDS_BYTES, grid, a, st);
+    const dim3 grid((unsigned)((long long)a.tiles_m * a.tiles_n * a.splits));
+    if (conv_dma_half(g)) conv_dma_fwd_launch_t<true>(a, p, grid, st);
+    else conv_dma_fwd_launch_t<false>(a, p, grid, st);
 }
-void conv_dma_wgrad_launch(const mg_conv_geom* g, const CdPlan& p, const float* x, const float* dy, float* dw, int accumulate,
+void conv_dma_wgrad_launch(const mg_conv_geom* g, const CdPlan& p, const void* x, const void* dy, float* dw, int accumulate,
                            float* part, hipStream_t st) {
     CdArgs a = cd_args(g);
     a.x = x; a.w = dy; a.y = dw; a.part = p.splits > 1 ? part : nullptr; a.accumulate = accumulate;
     a.tiles_m = (g->Co + p.bm - 1) / p.bm; a.tiles_n = g->KH * g->KW * g->Ci / p.bn; a.splits = p.splits; a.cps = p.cps;
-    const unsigned grid = (unsigned)((long long)a.tiles_m * a.tiles_n * a.splits);
-    if (p.bm == 128) cd_launch(conv_wgrad_dma_kernel<128, 64>, DgCfgG<128, 64, 2, 2, 1, 1, 2>::LDS_BYTES, grid, a, st);
-    else cd_launch(conv_wgrad_dma_kernel<64, 64>, DgCfgG<64, 64, 2, 2, 1, 1, 2>::LDS_BYTES, grid, a, st);
+    const dim3 grid((unsigned)((long long)a.tiles_m * a.tiles_n * a.splits));
+    const bool half = conv_dma_half(g);
+    if (p.bm == 128) {
+        if (half) cd_launch(conv_wgrad_dma_kernel<128, 64, true>, DgCfgG<128, 64, 2, 2, 1, 1, 2>::LDS_BYTES, grid, a, st);
+        else cd_launch(conv_wgrad_dma_kernel<128, 64, false>, DgCfgG<128, 64, 2, 2, 1, 1, 2>::LDS_BYTES, grid, a, st);
+    } else {
+        if (half) cd_launch(conv_wgrad_dma_kernel<64, 64, true>, DgCfgG<64, 64, 2, 2, 1, 1, 2>::LDS_BYTES, grid, a, st);
+        else cd_launch(conv_wgrad_dma_kernel<64, 64, false>, DgCfgG<64, 64, 2, 2, 1, 1, 2>::LDS_BYTES, grid, a, st);
+    }
 }
 
 // data gradient: the plan is made for the heaviest parity class (M = pixels of one class, all taps / stride^2 of the chunks)
 inline CdPlan conv_dma_dgrad_plan(const mg_conv_geom* g) {
-    const int s = g->stride;
+    const int s = g->stride, ck = conv_dma_ck(g);
+    const bool half = conv_dma_half(g);
+    const double rate = (half ? 4.0 : 1.0) * 157.3e12 / 256.0, fixed = half ? 4.0 : 1.2;
     const long long Mc = (long long)g->B * ((g->H + s - 1) / s) * ((g->W + s - 1) / s);
-    const int chunks = ((g->KH + s - 1) / s) * ((g->KW + s - 1) / s) * (g->Co / DG_BK);
+    const int chunks = ((g->KH + s - 1) / s) * ((g->KW + s - 1) / s) * (g->Co / ck);
     // the classes run side by side: count their workgroups when judging how full the chip is
     CdPlan best{64, 64, 1, 1 << 28};
     double best_t = 1e300;
@@ -490,17 +613,17 @@ inline CdPlan conv_dma_dgrad_plan(const mg_conv_geom* g) {
     if (const char* f = getenv("MG_FORCE_CONV_DMA")) {
         if (sscanf(f, "%d,%d,%d", &f_bm, &f_bn, &f_sp) != 3) f_bm = f_bn = f_sp = 0;
     }
-    const int total_k = g->KH * g->KW * (g->Co / DG_BK);          // chunks summed over the classes
+    const int total_k = g->KH * g->KW * (g->Co / ck);          // chunks summed over the classes
     for (const Cand& c : cands) {
         if (g->Ci % c.bn != 0) continue;
         if (f_bm && (c.bm != f_bm || c.bn != f_bn)) continue;
         const long long w = ((Mc + c.bm - 1) / c.bm) * (long long)(g->Ci / c.bn);
-        const double tile_us = 2.0 * c.bm * c.bn * DG_BK / (157.3e12 / 256.0) * 1e6 / c.eff;
+        const double tile_us = 2.0 * c.bm * c.bn * ck / rate * 1e6 / c.eff;
         for (int sp : split_opts) {
             if (sp > 1 && chunks / sp < 8) break;
             if (f_sp && sp != f_sp) continue;
             const long long wg = w * s * s * sp;
-            double t = (double)((wg + 255) / 256) * tile_us * ((double)total_k / (s * s) / sp + 1.2);
+            double t = (double)((wg + 255) / 256) * tile_us * ((double)total_k / (s * s) / sp + fixed);
             if (wg < 512) t /= 0.85;
             if (sp > 1) t += (double)(sp + 1) * (double)g->B * g->H * g->W * g->Ci * 4.0 / 4e12 * 1e6 + 3.0;
             if (t < best_t) { best_t = t; best = {c.bm, c.bn, sp, 0}; }
@@ -508,19 +631,20 @@ inline CdPlan conv_dma_dgrad_plan(const mg_conv_geom* g) {
     }
     return best;
 }
-void conv_dma_dgrad_launch(const mg_conv_geom* g, const CdPlan& p, const float* dy, const float* w, const float* bias, float* dx,
+template <bool HALF>
+void conv_dma_dgrad_launch_t(const CdArgs& a, const CdPlan& p, dim3 grid, hipStream_t st) {
+    if (p.bm == 128 && p.bn == 128) cd_launch(conv_dgrad_dma_kernel<128, 128, HALF>, DgCfgG<128, 128, 2, 2, 0, 1, 2>::LDS_BYTES, grid, a, st);
+    else if (p.bm == 64 && p.bn == 128) cd_launch(conv_dgrad_dma_kernel<64, 128, HALF>, DgCfgG<64, 128, 2, 2, 0, 1, 2>::LDS_BYTES, grid, a, st);
+    else if (p.bm == 128 && p.bn == 64) cd_launch(conv_dgrad_dma_kernel<128, 64, HALF>, DgCfgG<128, 64, 2, 2, 0, 1, 2>::LDS_BYTES, grid, a, st);
+    else cd_launch(conv_dgrad_dma_kernel<64, 64, HALF>, DgCfgG<64, 64, 2, 2, 0, 1, 2>::LDS_BYTES, grid, a, st);
+}
+void conv_dma_dgrad_launch(const mg_conv_geom* g, const CdPlan& p, const void* dy, const void* w, const float* bias, float* dx,
                            int act, float* part, hipStream_t st) {
     CdArgs a = cd_args(g);
     a.x = dy; a.w = w; a.bias = bias; a.y = dx; a.part = p.splits > 1 ? part : nullptr; a.act = act;
     const int s = g->stride;
     const long long Mc = (long long)g->B * ((g->H + s - 1) / s) * ((g->W + s - 1) / s);
     const dim3 grid((unsigned)(((Mc + p.bm - 1) / p.bm) * (g->Ci / p.bn)), (unsigned)(s * s), (unsigned)p.splits);
-    auto go = [&](auto kern, size_t lds) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
-    };
-    if (p.bm == 128 && p.bn == 128) go(conv_dgrad_dma_kernel<128, 128>, DgCfgG<128, 128, 2, 2, 0, 1, 2>::LDS_BYTES);
-    else if (p.bm == 64 && p.bn == 128) go(conv_dgrad_dma_kernel<64, 128>, DgCfgG<64, 128, 2, 2, 0, 1, 2>::LDS_BYTES);
-    else if (p.bm == 128 && p.bn == 64) go(conv_dgrad_dma_kernel<128, 64>, DgCfgG<128, 64, 2, 2, 0, 1, 2>::LDS_BYTES);
-    else go(conv_dgrad_dma_kernel<64, 64>, DgCfgG<64, 64, 2, 2, 0, 1, 2>::LDS_BYTES);
+    if (conv_dma_half(g)) conv_dma_dgrad_launch_t<true>(a, p, grid, st);
+    else conv_dma_dgrad_launch_t<false>(a, p, grid, st);
 }

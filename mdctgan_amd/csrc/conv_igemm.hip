@@ -1142,6 +1142,8 @@ __global__ void colsum_partial_kernel(const float* __restrict__ a, long long M, 
 }
 
 }  // namespace
+
+extern "C" int mg_conv_rowdot_kq(const mg_conv_geom* g);       // conv_rowdot.hip
 #include "wino.h"
 #include "wino4.h"
 #include "wino42.h"
@@ -1303,6 +1305,14 @@ inline size_t slab_count(int old_splits, int dense) {      // split-K slabs a wo
 #include "dense_gemm_h.h"
 #include "conv_h16.h"
 #include "conv_dma.h"
+// float32 -> float16 staging copy of n elements (n % 8 == 0 for every eligible layer: Ci, Co % 64 == 0)
+inline void cd_cast16(const float* src, void* dst, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(h16_cast_kernel, dim3(h16_grid(n / 8)), dim3(256), 0, st, src, (_Float16*)dst, n / 8);
+}
+// a layer any of whose passes runs on the float16 implicit GEMMs keeps a cached float16 copy of its weights
+inline bool conv_dma_h_any(const mg_conv_geom* g) {
+    return conv_dma_half(g) && !h16_ok(g) && !mg_conv_rowdot_kq(g) && (conv_dma_fwd_ok(g) || conv_dma_dgrad_ok(g));
+}
 
 
 // The 32-deep forward kernel needs dynamic LDS above the 64 KB static limit for its 128x128 tile.
@@ -2386,13 +2396,13 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
         snprintf(out, out_len, "conv_rowdot_wgrad_kernel<%d>", kq);
     } else if (pass == 1 && conv_dma_dgrad_ok(g) && !smallc_dgrad_ok(g)) {
         const CdPlan cp = conv_dma_dgrad_plan(g);
-        snprintf(out, out_len, "conv_dgrad_dma_kernel<%d, %d>", cp.bm, cp.bn);
+        snprintf(out, out_len, "conv_dgrad_dma_kernel<%d, %d, %s>", cp.bm, cp.bn, prec_h(g) ? "true" : "false");
     } else if (pass == 0 && conv_dma_fwd_ok(g)) {
         const CdPlan cp = conv_dma_fwd_plan(g);
-        snprintf(out, out_len, "conv_fwd_dma_kernel<%d, %d>", cp.bm, cp.bn);
+        snprintf(out, out_len, "conv_fwd_dma_kernel<%d, %d, %s>", cp.bm, cp.bn, prec_h(g) ? "true" : "false");
     } else if (pass == 2 && conv_dma_wgrad_ok(g)) {
         const CdPlan cp = conv_dma_wgrad_plan(g);
-        snprintf(out, out_len, "conv_wgrad_dma_kernel<%d, %d>", cp.bm, cp.bn);
+        snprintf(out, out_len, "conv_wgrad_dma_kernel<%d, %d, %s>", cp.bm, cp.bn, prec_h(g) ? "true" : "false");
     } else if (pass == 0) {
         const TilePlan tp = fwd_plan(g);
         const bool vec16 = g->Ci % BK == 0;
@@ -2427,7 +2437,8 @@ size_t mg_conv_fwd_workspace(const mg_conv_geom* g) {
     const TilePlan tp = fwd_plan(g);
     int sp = tp.splits;
     if (conv_dma_fwd_ok(g) && conv_dma_fwd_plan(g).splits > sp) sp = conv_dma_fwd_plan(g).splits;
-    return sp > 1 ? (size_t)sp * g->B * g->OH * g->OW * g->Co * sizeof(float) + 256 : 256;
+    const size_t stage = (conv_dma_fwd_ok(g) && conv_dma_half(g)) ? conv_dma_h_x_bytes(g) + conv_dma_h_w_bytes(g) : 0;
+    return stage + (sp > 1 ? (size_t)sp * g->B * g->OH * g->OW * g->Co * sizeof(float) + 256 : 256);
 }
 size_t mg_conv_dgrad_workspace(const mg_conv_geom* g) {
     if (!geom_ok(g)) return 0;
@@ -2438,12 +2449,14 @@ size_t mg_conv_dgrad_workspace(const mg_conv_geom* g) {
     const TilePlan tp = dgrad_plan(g);
     int sp = tp.splits;
     if (conv_dma_dgrad_ok(g) && conv_dma_dgrad_plan(g).splits > sp) sp = conv_dma_dgrad_plan(g).splits;
-    return sp > 1 ? (size_t)sp * g->B * g->H * g->W * g->Ci * sizeof(float) + 256 : 256;
+    const size_t stage = (conv_dma_dgrad_ok(g) && conv_dma_half(g)) ? conv_dma_h_dy_bytes(g) + conv_dma_h_w_bytes(g) : 0;
+    return stage + (sp > 1 ? (size_t)sp * g->B * g->H * g->W * g->Ci * sizeof(float) + 256 : 256);
 }
 
 size_t mg_conv_wino_weights_bytes(const mg_conv_geom* g) {
     if (!geom_ok(g) || mg_conv_rowdot_kq(g)) return 0;
     if (h16_ok(g)) return h16_weights_bytes(g);         // the float16 weight copy of the autocast GEMM path (conv_h16.h)
+    if (conv_dma_h_any(g)) return h16_weights_bytes(g); // ... and of the float16 implicit GEMMs (conv_dma.h)
     if (wino4_ok(g)) return (size_t)25 * g->Co * g->Ci * sizeof(float);
     if (wino42_ok(g)) return (size_t)25 * g->Co * 4 * g->Ci * sizeof(float);
     if (!wino_ok(g)) return 0;
@@ -2451,7 +2464,7 @@ size_t mg_conv_wino_weights_bytes(const mg_conv_geom* g) {
 }
 int mg_conv_wino_prepare(const mg_conv_geom* g, const float* w, float* u, void* stream) {
     if (!mg_conv_wino_weights_bytes(g) || !w || !u || !aligned16(w) || !aligned16(u)) return MG_ERR_ARG;
-    if (h16_ok(g)) return h16_prepare(g, w, u, (hipStream_t)stream);
+    if (h16_ok(g) || conv_dma_h_any(g)) return h16_prepare(g, w, u, (hipStream_t)stream);
     if (wino4_ok(g)) {
         hipLaunchKernelGGL(wino4_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 2)), dim3(256), 0,
                            (hipStream_t)stream, w, g->Co, g->Ci, u);
@@ -2471,7 +2484,7 @@ int mg_conv_wino_prepare(const mg_conv_geom* g, const float* w, float* u, void* 
 }
 
 size_t mg_conv_wino_tiles_bytes(const mg_conv_geom* g, int which) {
-    if (!mg_conv_wino_weights_bytes(g) || h16_ok(g)) return 0;
+    if (!mg_conv_wino_weights_bytes(g) || h16_ok(g) || conv_dma_h_any(g)) return 0;
     if (wino4_ok(g)) {
         const Wino4Dims d4 = wino4_dims(g);
         return which == 0 ? (size_t)25 * d4.T * g->Ci * sizeof(float) : which == 1 ? (size_t)25 * d4.T * g->Co * sizeof(float) : 0;
@@ -2531,21 +2544,39 @@ int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const f
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)g->B * g->OH * g->OW;
     const int N = g->Co;
-    if (conv_dma_fwd_ok(g) && aligned16(x) && aligned16(w) && aligned16(y) && (!bias || aligned16(bias))) {
+    const bool cd_half = conv_dma_half(g);
+    if (conv_dma_fwd_ok(g) && aligned16(x) && aligned16(w) && aligned16(y) && (!bias || aligned16(bias)) &&
+        (!cd_half || (workspace && aligned16(workspace) && workspace_bytes >= mg_conv_fwd_workspace(g)))) {
         CdPlan cp = conv_dma_fwd_plan(g);
         if (cp.splits > 1 && (!workspace || workspace_bytes < mg_conv_fwd_workspace(g) || !aligned16(workspace))) {
             cp.splits = 1;
             cp.cps = 1 << 28;
         }
+        const void* xin = x;
+        const void* win = w;
+        char* wsp = (char*)workspace;
+        if (cd_half) {          // float16 copies: the activation by a cast pass, the weights from the cache when there is one
+            cd_cast16(x, wsp, (size_t)g->B * g->H * g->W * g->Ci, st);
+            xin = wsp;
+            wsp += conv_dma_h_x_bytes(g);
+            if (u) {
+                win = u;
+            } else {
+                cd_cast16(w, wsp, (size_t)g->Co * g->KH * g->KW * g->Ci, st);
+                win = wsp;
+            }
+            wsp += conv_dma_h_w_bytes(g);
+            MG_CHECK_LAUNCH();
+        }
         probe_begin(st);
-        conv_dma_fwd_launch(g, cp, x, w, bias, y, act, (float*)workspace, st);
+        conv_dma_fwd_launch(g, cp, xin, win, bias, y, act, (float*)wsp, st);
         probe_end(st);
         MG_CHECK_LAUNCH();
         if (cp.splits > 1) {
             const size_t n = (size_t)M * N;
             const unsigned blocks = (unsigned)((n / 4 + 255) / 256 > 4096 ? 4096 : (n / 4 + 255) / 256);
-            hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, cp.splits, n, N,
-                               bias, act, y, 0);
+            hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, (const float*)wsp, cp.splits, n, N,
+                               bias, act, y, cd_half ? 1 : 0);
             MG_CHECK_LAUNCH();
         }
         return MG_OK;
@@ -2617,18 +2648,36 @@ int mg_conv_dgrad_w(const mg_conv_geom* g, const float* dy, const float* w, cons
     const Geom gg = to_geom(g);
     hipStream_t st = (hipStream_t)stream;
     const int s = g->stride;
-    if (conv_dma_dgrad_ok(g) && aligned16(dy) && aligned16(w) && aligned16(dx) && (!bias || aligned16(bias))) {
+    const bool cd_half = conv_dma_half(g);
+    if (conv_dma_dgrad_ok(g) && aligned16(dy) && aligned16(w) && aligned16(dx) && (!bias || aligned16(bias)) &&
+        (!cd_half || (workspace && aligned16(workspace) && workspace_bytes >= mg_conv_dgrad_workspace(g)))) {
         CdPlan cp = conv_dma_dgrad_plan(g);
         if (cp.splits > 1 && (!workspace || workspace_bytes < mg_conv_dgrad_workspace(g) || !aligned16(workspace))) cp.splits = 1;
+        const void* dyin = dy;
+        const void* win = w;
+        char* wsp = (char*)workspace;
+        if (cd_half) {
+            cd_cast16(dy, wsp, (size_t)g->B * g->OH * g->OW * g->Co, st);
+            dyin = wsp;
+            wsp += conv_dma_h_dy_bytes(g);
+            if (u) {
+                win = u;
+            } else {
+                cd_cast16(w, wsp, (size_t)g->Co * g->KH * g->KW * g->Ci, st);
+                win = wsp;
+            }
+            wsp += conv_dma_h_w_bytes(g);
+            MG_CHECK_LAUNCH();
+        }
         probe_begin(st);
-        conv_dma_dgrad_launch(g, cp, dy, w, bias, dx, act, (float*)workspace, st);
+        conv_dma_dgrad_launch(g, cp, dyin, win, bias, dx, act, (float*)wsp, st);
         probe_end(st);
         MG_CHECK_LAUNCH();
         if (cp.splits > 1) {
             const size_t n = (size_t)g->B * g->H * g->W * g->Ci;
             const unsigned blocks = (unsigned)((n / 4 + 255) / 256 > 4096 ? 4096 : (n / 4 + 255) / 256);
-            hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, cp.splits, n, g->Ci,
-                               bias, act, dx, 0);
+            hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, (const float*)wsp, cp.splits, n, g->Ci,
+                               bias, act, dx, cd_half ? 1 : 0);
             MG_CHECK_LAUNCH();
         }
         return MG_OK;
@@ -2712,7 +2761,8 @@ size_t mg_conv_wgrad_workspace(const mg_conv_geom* g) {
     const WgradPlan p = wgrad_plan(g);
     int sp = p.splits;
     if (conv_dma_wgrad_ok(g) && conv_dma_wgrad_plan(g).splits > sp) sp = conv_dma_wgrad_plan(g).splits;
-    const size_t wg = sp > 1 ? (size_t)sp * g->Co * g->KH * g->KW * g->Ci * sizeof(float) : 0;
+    size_t wg = sp > 1 ? (size_t)sp * g->Co * g->KH * g->KW * g->Ci * sizeof(float) : 0;
+    if (conv_dma_wgrad_ok(g) && conv_dma_half(g)) wg += conv_dma_h_x_bytes(g) + conv_dma_h_dy_bytes(g);
     const size_t cs = mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co);
     return (wg > cs ? wg : cs) + 256;
 }
@@ -2795,13 +2845,25 @@ int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, floa
     if (conv_dma_wgrad_ok(g) && aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace)) {
         const CdPlan cp = conv_dma_wgrad_plan(g);
         const size_t n_out = (size_t)g->Co * g->KH * g->KW * g->Ci;
+        const void* xin = x;
+        const void* dyin = dy;
+        char* wsp = (char*)workspace;
+        if (conv_dma_half(g)) {
+            cd_cast16(x, wsp, (size_t)g->B * g->H * g->W * g->Ci, st);
+            xin = wsp;
+            wsp += conv_dma_h_x_bytes(g);
+            cd_cast16(dy, wsp, (size_t)g->B * g->OH * g->OW * g->Co, st);
+            dyin = wsp;
+            wsp += conv_dma_h_dy_bytes(g);
+            MG_CHECK_LAUNCH();
+        }
         probe_begin(st);
-        conv_dma_wgrad_launch(g, cp, x, dy, dw, accumulate, (float*)workspace, st);
+        conv_dma_wgrad_launch(g, cp, xin, dyin, dw, accumulate, (float*)wsp, st);
         probe_end(st);
         MG_CHECK_LAUNCH();
         if (cp.splits > 1) {
             const unsigned blocks = (unsigned)((n_out / 4 + 255) / 256 > 4096 ? 4096 : (n_out / 4 + 255) / 256 + 1);
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, cp.splits, n_out, dw,
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)wsp, cp.splits, n_out, dw,
                                accumulate);
             MG_CHECK_LAUNCH();
         }

@@ -29,13 +29,14 @@ struct HgArgs {
     int b_cpt, b_tap_stride;
 };
 
-template <int BM, int BN, int WGM, int WGN, bool BRC = false>
+template <int BM, int BN, int WGM, int WGN, bool BRC = false, int NBUF = 2>
 struct HgCfg {
     static constexpr int NT = 64 * WGM * WGN, NW = WGM * WGN;
     static constexpr int MB = BM / WGM / 32, NB = BN / WGN / 32;
     static constexpr int ASZ = BM * 32, BSZ = BN * 32;                // 32-bit words per buffer (64 halves per row)
     static constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;          // 1 KiB pieces per wave and chunk
-    static constexpr size_t LDS_BYTES = (size_t)2 * (ASZ + BSZ) * 4;
+    static constexpr size_t LDS_BYTES = (size_t)NBUF * (ASZ + BSZ) * 4;
+    static_assert(NBUF >= 2 && NBUF <= 4, "pipeline depth");
     static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "pieces must divide evenly over the waves");
     static_assert(!BRC || (BN == 64 || BN == 128), "row-contiguous B: a 1 KiB piece is 8 or 4 whole k rows");
 };
@@ -44,14 +45,16 @@ struct HgCfg {
 // pieces of 1024 / (2 BN) whole k rows); a lane gathers the 8 k of its column with eight 16-bit LDS reads -- 8x the LDS
 // instructions of the k-contiguous form, affordable where the kernel is bound by streaming the weights (the 4x8 trunk) and
 // it saves keeping a second, transposed float16 copy of every weight tensor.
-template <int BM, int BN, int WGM, int WGN, bool BRC = false>
+// NBUF LDS buffers keep NBUF - 1 chunks in flight: with one workgroup per CU (grid == 256 on the weight-streaming trunk
+// shapes) a two-buffer loop has one 32 KiB chunk outstanding per CU -- a quarter of what the HBM latency needs.
+template <int BM, int BN, int WGM, int WGN, bool BRC = false, int NBUF = 2>
 __global__ __launch_bounds__(64 * WGM * WGN) void hgemm_kernel(HgArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using Cfg = HgCfg<BM, BN, WGM, WGN, BRC>;
+    using Cfg = HgCfg<BM, BN, WGM, WGN, BRC, NBUF>;
     constexpr int MB = Cfg::MB, NB = Cfg::NB, PA = Cfg::PA, PB = Cfg::PB;
     extern __shared__ __attribute__((aligned(1024))) float hg_smem[];
     float* As0 = hg_smem;
-    float* Bs0 = hg_smem + 2 * Cfg::ASZ;
+    float* Bs0 = hg_smem + NBUF * Cfg::ASZ;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -117,18 +120,35 @@ __global__ __launch_bounds__(64 * WGM * WGN) void hgemm_kernel(HgArgs g) {
         for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = f32x16{0};
     const int wm0 = (wave / WGN) * (BM / WGM), wn0 = (wave % WGN) * (BN / WGN);
     const int r = lane & 31, kh = lane >> 5;
+#if defined(HG_DEBUG_NO_LDS)
+    f16x8 a[2][MB], b[2][NB];
+#endif
 
-    if (c_begin < c_end) issue(c_begin, 0);
+    constexpr int AHEAD = NBUF - 1, PER = PA + PB;         // chunks in flight, DMA instructions per chunk and lane
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i)
+        if (c_begin + i < c_end) issue(c_begin + i, i);
+    int cur = 0, nxt = AHEAD % NBUF;
     for (int c = c_begin; c < c_end; ++c) {
-        const int cur = (c - c_begin) & 1;
-        dg_wait_vmcnt<0>();
+        // chunk c has landed when at most the younger chunks' instructions are outstanding (fewer near the tail: wait for all)
+        if (NBUF == 2 || c + AHEAD > c_end) dg_wait_vmcnt<0>();
+        else dg_wait_vmcnt<(AHEAD - 1) * PER>();
+#if !defined(HG_DEBUG_NO_BARRIER)
         __builtin_amdgcn_s_barrier();
+#endif
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < c_end) issue(c + 1, cur ^ 1);
+#if !defined(HG_DEBUG_NO_DMA)
+        if (c + AHEAD < c_end) issue(c + AHEAD, nxt);
+#endif
         const float* As = As0 + cur * Cfg::ASZ;
         const float* Bs = Bs0 + cur * Cfg::BSZ;
+#if !defined(HG_DEBUG_NO_LDS)
         f16x8 a[2][MB], b[2][NB];
+#endif
         auto fetch = [&](int s, int buf) {
+#if defined(HG_DEBUG_NO_LDS)
+            if (c > c_begin) return;
+#endif
 #pragma unroll
             for (int mi = 0; mi < MB; ++mi) {
                 const int row = wm0 + 32 * mi + r;
@@ -148,6 +168,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void hgemm_kernel(HgArgs g) {
                 }
             }
         };
+#if defined(HG_DEBUG_NO_COMPUTE)
+        if (g.K < 0)
+#endif
+        {
         fetch(0, 0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -159,6 +183,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void hgemm_kernel(HgArgs g) {
                 for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = mfma32x32x16h(a[s & 1][mi], b[s & 1][ni], acc[mi][ni]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        }
+        cur = cur + 1 == NBUF ? 0 : cur + 1;
+        nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
     }
 
     float* o = g.part ? g.part + (size_t)sp * ((size_t)g.M * g.N) : g.C;
@@ -186,18 +213,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void hgemm_kernel(HgArgs g) {
 #endif
 }
 
-template <int BM, int BN, int WGM, int WGN, bool BRC = false>
+template <int BM, int BN, int WGM, int WGN, bool BRC = false, int NBUF = 2>
 inline void hgemm_launch(const HgArgs& a0, hipStream_t st) {
-    using Cfg = HgCfg<BM, BN, WGM, WGN, BRC>;
+    using Cfg = HgCfg<BM, BN, WGM, WGN, BRC, NBUF>;
     HgArgs a = a0;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
     static bool once = false;
     if (!once) {
-        hipFuncSetAttribute((const void*)hgemm_kernel<BM, BN, WGM, WGN, BRC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void*)hgemm_kernel<BM, BN, WGM, WGN, BRC, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)Cfg::LDS_BYTES);
         once = true;
     }
     const unsigned grid = (unsigned)((long long)a.tiles_m * a.tiles_n * a.splits);
-    hipLaunchKernelGGL((hgemm_kernel<BM, BN, WGM, WGN, BRC>), dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((hgemm_kernel<BM, BN, WGM, WGN, BRC, NBUF>), dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, a);
 }

@@ -3,6 +3,7 @@
 #include "common.h"
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 namespace {
@@ -50,11 +51,15 @@ __global__ void ref_rc_kernel(const _Float16* A, const _Float16* B, float* out, 
     out[idx] = (float)s;
 }
 #define VR(BM, BN, WM, WN) {#BM "x" #BN "/" #WM "x" #WN " rc", BM, BN, hgemm_launch<BM, BN, WM, WN, true>}
-const Variant vrc[] = {VR(64, 64, 2, 2), VR(128, 64, 2, 2), VR(64, 128, 2, 2), VR(128, 128, 2, 2), VR(128, 128, 4, 2), VR(128, 128, 2, 4),
-                       VR(256, 64, 4, 2), VR(256, 128, 4, 2), VR(256, 64, 4, 1)};
+#define VRN(BM, BN, WM, WN, NB) {#BM "x" #BN "/" #WM "x" #WN " rc n" #NB, BM, BN, hgemm_launch<BM, BN, WM, WN, true, NB>}
+const Variant vrc[] = {VR(128, 64, 2, 2), VR(128, 128, 4, 2), VR(256, 64, 4, 2), VR(256, 128, 4, 2),
+                       VRN(128, 64, 2, 2, 3), VRN(128, 64, 2, 2, 4), VRN(128, 128, 4, 2, 3), VRN(128, 128, 4, 2, 4), VRN(256, 64, 4, 2, 3), VRN(256, 64, 4, 2, 4),
+                       VRN(256, 128, 4, 2, 3)};
 #define V(BM, BN, WM, WN) {#BM "x" #BN "/" #WM "x" #WN, BM, BN, hgemm_launch<BM, BN, WM, WN>}
-const Variant vs[] = {V(64, 64, 2, 2), V(128, 64, 2, 2), V(64, 128, 2, 2), V(128, 128, 2, 2), V(128, 128, 4, 2), V(128, 128, 2, 4),
-                      V(256, 64, 4, 2), V(256, 128, 4, 2), V(128, 256, 2, 4), V(256, 256, 4, 2), V(256, 256, 2, 4), V(256, 64, 4, 1), V(256, 128, 4, 1)};
+#define VN(BM, BN, WM, WN, NB) {#BM "x" #BN "/" #WM "x" #WN " n" #NB, BM, BN, hgemm_launch<BM, BN, WM, WN, false, NB>}
+const Variant vs[] = {V(128, 64, 2, 2), V(128, 128, 2, 2), V(128, 128, 4, 2), V(256, 64, 4, 2), V(256, 128, 4, 2), V(256, 256, 4, 2),
+                      VN(128, 64, 2, 2, 3), VN(128, 64, 2, 2, 4), VN(128, 128, 2, 2, 3), VN(128, 128, 2, 2, 4), VN(128, 128, 4, 2, 3), VN(128, 128, 4, 2, 4),
+                      VN(256, 64, 4, 2, 3), VN(256, 64, 4, 2, 4), VN(256, 128, 4, 2, 3), VN(256, 256, 4, 2, 3) };
 struct Problem { const char* name; int M, N, K; };
 }  // namespace
 
@@ -75,11 +80,12 @@ int main(int argc, char** argv) {
         if (only[0] && !strstr(pr.name, only)) continue;
         const size_t na = (size_t)pr.M * pr.K, nb = (size_t)pr.N * pr.K, nc = (size_t)pr.M * pr.N;
         _Float16 *A, *B; float *C, *R, *part;
-        hipMalloc(&A, na * 2); hipMalloc(&B, nb * 2); hipMalloc(&C, nc * 4); hipMalloc(&R, nc * 4);
+        const int nrot = getenv("HG_ROT") ? atoi(getenv("HG_ROT")) : 1;     // > 1: cycle through copies of B (defeats the 256 MiB Infinity Cache)
+        hipMalloc(&A, na * 2); hipMalloc(&B, nb * 2 * nrot); hipMalloc(&C, nc * 4); hipMalloc(&R, nc * 4);
         const int max_splits = 32;
         hipMalloc(&part, nc * 4 * (pr.M * (size_t)pr.N > (64u << 20) ? 1 : max_splits));
         fill_h<<<1024, 256, 0, st>>>(A, na, 1u);
-        fill_h<<<1024, 256, 0, st>>>(B, nb, 7u);
+        for (int i = 0; i < nrot; ++i) fill_h<<<1024, 256, 0, st>>>(B + (size_t)i * nb, nb, 7u);
         ref_kernel<<<(unsigned)((nc + 255) / 256), 256, 0, st>>>(A, B, R, pr.M, pr.N, pr.K, pr.K, pr.K);
         hipStreamSynchronize(st);
         const double flops = 2.0 * pr.M * (double)pr.N * pr.K;
@@ -97,7 +103,10 @@ int main(int argc, char** argv) {
                 g.A = A; g.B = B; g.C = C; g.part = sp > 1 ? part : nullptr; g.bias = nullptr;
                 g.M = pr.M; g.N = pr.N; g.K = pr.K; g.lda = pr.K; g.ldb = pr.K;
                 g.cps = (chunks + sp - 1) / sp; g.splits = (chunks + g.cps - 1) / g.cps; g.round_f16 = 0; g.accumulate = 0; g.b_cpt = 1 << 30; g.b_tap_stride = 0;
+                int rot = 0;
                 auto run = [&]() {
+                    g.B = B + (size_t)rot * nb;
+                    rot = rot + 1 == nrot ? 0 : rot + 1;
                     v.launch(g, st);
                     if (g.splits > 1) reduce_kernel<<<1024, 256, 0, st>>>(part, g.splits, nc, C);
                 };
@@ -121,7 +130,7 @@ int main(int argc, char** argv) {
                 }
                 std::sort(ts.begin(), ts.end());
                 const float err = h[0] / (h[1] > 0 ? h[1] : 1.f);
-                printf("   %-12s splits %2d wgs %5lld  med %8.1f us  %7.1f TF  %6.2f TB/s  relerr %.1e%s\n", v.name, g.splits, wgs, ts[1],
+                printf("   %-18s splits %2d wgs %5lld  med %8.1f us  %7.1f TF  %6.2f TB/s  relerr %.1e%s\n", v.name, g.splits, wgs, ts[1],
                        flops / ts[1] / 1e6, bytes / ts[1] / 1e6, err, err > 1e-4f ? "  <-- WRONG" : "");
             }
         }
@@ -169,7 +178,7 @@ int main(int argc, char** argv) {
                 }
                 std::sort(ts.begin(), ts.end());
                 const float err = h[0] / (h[1] > 0 ? h[1] : 1.f);
-                printf("   %-16s splits %2d wgs %5lld  med %8.1f us  %7.1f TF  relerr %.1e%s\n", v.name, g.splits, wgs, ts[1], flops / ts[1] / 1e6, err,
+                printf("   %-22s splits %2d wgs %5lld  med %8.1f us  %7.1f TF  relerr %.1e%s\n", v.name, g.splits, wgs, ts[1], flops / ts[1] / 1e6, err,
                        err > 1e-4f ? "  <-- WRONG" : "");
             }
         }

@@ -36,6 +36,14 @@ CASES = [
     ("h16_1x1", 4, 128, 4, 8, 192, 1, 1, 0, False),
     ("h16_5x5_zero_pad_ragged", 1, 64, 6, 10, 64, 5, 1, 2, False),       # 60 pixels: the K padding of the weight gradient
     ("h16_4x4_pad2", 1, 64, 5, 9, 128, 4, 1, 2, False),                   # output larger than the input (6 x 10)
+    # activation-dominated layers with channels % 64 == 0: float16 implicit GEMMs with LDS-DMA staging and transpose reads
+    # (csrc/conv_dma.h, HALF instances) over float16 copies of the activations
+    ("cdh_down3x3_s2", 2, 64, 32, 64, 128, 3, 2, 1, False),
+    ("cdh_d4x4_s2_odd", 2, 64, 33, 65, 128, 4, 2, 2, False),              # 17 x 33 outputs: pixel tails everywhere
+    ("cdh_3x3_zero_pad", 4, 128, 12, 20, 64, 3, 1, 1, False),
+    ("cdh_5x5_ragged", 3, 64, 9, 13, 64, 5, 1, 2, False),                 # 351 pixels: the weight gradient's K tail
+    ("cdh_res3x3_reflect_64", 2, 64, 24, 40, 64, 3, 1, 1, True),         # local-enhancer residual block
+    ("cdh_up_twin_256_128", 2, 256, 16, 24, 128, 3, 2, 1, False),        # the ladder's 256 -> 128 pair
 ]
 
 
@@ -82,11 +90,16 @@ def test_conv_f16_precision(case):
     # reference): the rounding error of 16 transformed products folds into each output -> a few float16 ulps.
     h16 = ops.plan_name(0, g).startswith("hgemm")
     assert h16 == name.startswith("h16_"), ops.plan_name(0, g)
-    wino = bool(_lib.load().mg_conv_wino_weights_bytes(g)) and not h16
+    cdh = "dma_kernel" in ops.plan_name(0, g)
+    if name.startswith("cdh_"):
+        assert ops.plan_name(0, g).startswith("conv_fwd_dma_kernel") and ops.plan_name(0, g).endswith("true>")
+        assert ops.plan_name(2, g).startswith("conv_wgrad_dma_kernel") and ops.plan_name(2, g).endswith("true>")
+        assert reflect or ops.plan_name(1, g).startswith("conv_dgrad_dma_kernel"), ops.plan_name(1, g)
+    wino = bool(_lib.load().mg_conv_wino_weights_bytes(g)) and not h16 and not cdh
     tol = dict(ulps=4.0, floor=2.0 ** -9) if wino else {}
     close_f16(ops.conv_fwd(g, xd, wd, bd), nhwc(y.detach()), **tol)
     close_f16(ops.conv_dgrad(g, gyd, wd), nhwc(xh.grad), **tol)
-    if h16:      # the caller-held float16 weight copy (one cast per step, shared by forward and data gradient): same bits
+    if h16 or cdh:      # the caller-held float16 weight copy (one cast per step, shared by forward and data gradient): same bits
         u = ops.wino_weights(g, wd)
         assert u is not None and u.numel() * 4 == Co * k * k * Ci * 2
         assert torch.equal(ops.conv_fwd(g, xd, wd, bd, u=u), ops.conv_fwd(g, xd, wd, bd))
