@@ -639,8 +639,9 @@ void conv_dma_dgrad_launch_t(const CdArgs& a, const CdPlan& p, dim3 grid, hipStr
     else cd_launch(conv_dgrad_dma_kernel<64, 64, HALF>, DgCfgG<64, 64, 2, 2, 0, 1, 2>::LDS_BYTES, grid, a, st);
 }
 void conv_dma_dgrad_launch(const mg_conv_geom* g, const CdPlan& p, const void* dy, const void* w, const float* bias, float* dx,
-                           int act, float* part, hipStream_t st) {
+                           int act, float* part, hipStream_t st, int round_f16) {
     CdArgs a = cd_args(g);
+    a.round_f16 = round_f16;
     a.x = dy; a.w = w; a.bias = bias; a.y = dx; a.part = p.splits > 1 ? part : nullptr; a.act = act;
     const int s = g->stride;
     const long long Mc = (long long)g->B * ((g->H + s - 1) / s) * ((g->W + s - 1) / s);

@@ -197,8 +197,11 @@ int h16_prepare(const mg_conv_geom* g, const float* w, void* w16, hipStream_t st
     return MG_OK;
 }
 inline void h16_launch(const H16Plan& p, bool brc, const HgArgs& a, hipStream_t st) {
-    if (brc) hgemm_launch<128, 64, 2, 2, true>(a, st);
-    else hgemm_launch<128, 128, 4, 2, false>(a, st);
+    // three LDS buffers: two chunks in flight per workgroup -- the weights come cold from HBM every step (1.4 GB of float16
+    // copies per configs[2] iteration, nothing stays in the 256 MiB Infinity Cache) and one chunk per CU does not cover that
+    // latency (scripts/ubench/hgemm_bench with HG_ROT=6: 43.5 -> 36.7 us on the 2048-channel trunk shape)
+    if (brc) hgemm_launch<128, 64, 2, 2, true, 3>(a, st);
+    else hgemm_launch<128, 128, 4, 2, false, 3>(a, st);
     (void)p;
 }
 

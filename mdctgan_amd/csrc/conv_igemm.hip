@@ -1309,9 +1309,67 @@ inline size_t slab_count(int old_splits, int dense) {      // split-K slabs a wo
 inline void cd_cast16(const float* src, void* dst, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(h16_cast_kernel, dim3(h16_grid(n / 8)), dim3(256), 0, st, src, (_Float16*)dst, n / 8);
 }
+// ReflectionPad2d(1) + 3x3 stride-1 data gradient on the DMA kernel: the zero-padded "full" data gradient over the padded
+// (H+2) x (W+2) domain (geometry gp: pad 0, same OH x OW), folded back onto H x W by wino_fold_reflect_kernel
+inline bool cd_reflect_dgrad_geom(const mg_conv_geom* g, mg_conv_geom* gp) {
+    if (!g->reflect || g->stride != 1 || g->pad != 1 || g->KH != 3 || g->KW != 3 || g->Ci % 4) return false;
+    *gp = *g;
+    gp->H += 2; gp->W += 2; gp->pad = 0; gp->reflect = 0;
+    return conv_dma_dgrad_ok(gp);
+}
+// staging + split-K slabs of the DMA data gradient
+inline size_t cd_dgrad_ws(const mg_conv_geom* g) {
+    const CdPlan cp = conv_dma_dgrad_plan(g);
+    const size_t stage = conv_dma_half(g) ? conv_dma_h_dy_bytes(g) + conv_dma_h_w_bytes(g) : 0;
+    return stage + (cp.splits > 1 ? (size_t)cp.splits * g->B * g->H * g->W * g->Ci * sizeof(float) : 0) + 256;
+}
+inline size_t cd_reflect_dxp_bytes(const mg_conv_geom* gp) { return cd_al((size_t)gp->B * gp->H * gp->W * gp->Ci * sizeof(float)); }
+// the DMA data gradient proper.  wsp: cd_dgrad_ws(g) bytes (may be null when nothing is needed); round_f16: autocast output
+// rounding of the direct result (the reflect wrapper rounds after its fold instead)
+int cd_dgrad_run(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act, char* wsp,
+                 hipStream_t st, const float* u, float* md, int round_f16);
 // a layer any of whose passes runs on the float16 implicit GEMMs keeps a cached float16 copy of its weights
 inline bool conv_dma_h_any(const mg_conv_geom* g) {
-    return conv_dma_half(g) && !h16_ok(g) && !mg_conv_rowdot_kq(g) && (conv_dma_fwd_ok(g) || conv_dma_dgrad_ok(g));
+    mg_conv_geom gp;
+    return conv_dma_half(g) && !h16_ok(g) && !mg_conv_rowdot_kq(g) &&
+           (conv_dma_fwd_ok(g) || conv_dma_dgrad_ok(g) || cd_reflect_dgrad_geom(g, &gp));
+}
+inline bool cd_dgrad_any(const mg_conv_geom* g) {
+    mg_conv_geom gp;
+    return conv_dma_dgrad_ok(g) || cd_reflect_dgrad_geom(g, &gp);
+}
+int cd_dgrad_run(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act, char* wsp,
+                 hipStream_t st, const float* u, float* md, int round_f16) {
+    CdPlan cp = conv_dma_dgrad_plan(g);
+    const bool half = conv_dma_half(g);
+    const void* dyin = dy;
+    const void* win = w;
+    if (half) {
+        void* dy16 = md ? (void*)md : (void*)wsp;      // shared with the weight gradient
+        cd_cast16(dy, dy16, (size_t)g->B * g->OH * g->OW * g->Co, st);
+        dyin = dy16;
+        wsp += conv_dma_h_dy_bytes(g);
+        if (u) {
+            win = u;
+        } else {
+            cd_cast16(w, wsp, (size_t)g->Co * g->KH * g->KW * g->Ci, st);
+            win = wsp;
+        }
+        wsp += conv_dma_h_w_bytes(g);
+        MG_CHECK_LAUNCH();
+    }
+    probe_begin(st);
+    conv_dma_dgrad_launch(g, cp, dyin, win, bias, dx, act, (float*)wsp, st, round_f16);
+    probe_end(st);
+    MG_CHECK_LAUNCH();
+    if (cp.splits > 1) {
+        const size_t n = (size_t)g->B * g->H * g->W * g->Ci;
+        const unsigned blocks = (unsigned)((n / 4 + 255) / 256 > 4096 ? 4096 : (n / 4 + 255) / 256);
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, (const float*)wsp, cp.splits, n, g->Ci,
+                           bias, act, dx, round_f16);
+        MG_CHECK_LAUNCH();
+    }
+    return MG_OK;
 }
 
 
@@ -2318,7 +2376,7 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
     if (!geom_ok(g) || !out || out_len < 64) return MG_ERR_ARG;
     const int kq = mg_conv_rowdot_kq(g);
     if (h16_ok(g) && !kq) {
-        snprintf(out, out_len, pass == 1 ? "hgemm_kernel<128, 64, 2, 2, true>" : "hgemm_kernel<128, 128, 4, 2, false>");
+        snprintf(out, out_len, pass == 1 ? "hgemm_kernel<128, 64, 2, 2, true, 3>" : "hgemm_kernel<128, 128, 4, 2, false, 3>");
     } else if (wino_ok(g) && !kq && !(pass == 1 && wino_dgrad_padded()) &&
         dense_plan(pass, 16, wino_dims(g).T, g->Co, g->Ci, prec_h(g)).ok) {
         dense_name(pass, dense_plan(pass, 16, wino_dims(g).T, g->Co, g->Ci, prec_h(g)), out, out_len);
@@ -2394,8 +2452,9 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
         snprintf(out, out_len, "conv_rowdot_fwd_kernel<%d>", kq);
     } else if (kq && pass == 2) {
         snprintf(out, out_len, "conv_rowdot_wgrad_kernel<%d>", kq);
-    } else if (pass == 1 && conv_dma_dgrad_ok(g) && !smallc_dgrad_ok(g)) {
-        const CdPlan cp = conv_dma_dgrad_plan(g);
+    } else if (pass == 1 && cd_dgrad_any(g) && !smallc_dgrad_ok(g)) {
+        mg_conv_geom gp;
+        const CdPlan cp = conv_dma_dgrad_ok(g) ? conv_dma_dgrad_plan(g) : (cd_reflect_dgrad_geom(g, &gp), conv_dma_dgrad_plan(&gp));
         snprintf(out, out_len, "conv_dgrad_dma_kernel<%d, %d, %s>", cp.bm, cp.bn, prec_h(g) ? "true" : "false");
     } else if (pass == 0 && conv_dma_fwd_ok(g)) {
         const CdPlan cp = conv_dma_fwd_plan(g);
@@ -2448,9 +2507,15 @@ size_t mg_conv_dgrad_workspace(const mg_conv_geom* g) {
     if (wino42_ok(g)) return wino42_dgrad_ws(g);
     const TilePlan tp = dgrad_plan(g);
     int sp = tp.splits;
-    if (conv_dma_dgrad_ok(g) && conv_dma_dgrad_plan(g).splits > sp) sp = conv_dma_dgrad_plan(g).splits;
-    const size_t stage = (conv_dma_dgrad_ok(g) && conv_dma_half(g)) ? conv_dma_h_dy_bytes(g) + conv_dma_h_w_bytes(g) : 0;
-    return stage + (sp > 1 ? (size_t)sp * g->B * g->H * g->W * g->Ci * sizeof(float) + 256 : 256);
+    size_t base = sp > 1 ? (size_t)sp * g->B * g->H * g->W * g->Ci * sizeof(float) + 256 : 256;
+    mg_conv_geom gp;
+    if (conv_dma_dgrad_ok(g)) {
+        if (cd_dgrad_ws(g) > base) base = cd_dgrad_ws(g);
+    } else if (cd_reflect_dgrad_geom(g, &gp)) {
+        const size_t need = cd_reflect_dxp_bytes(&gp) + cd_dgrad_ws(&gp);
+        if (need > base) base = need;
+    }
+    return base;
 }
 
 size_t mg_conv_wino_weights_bytes(const mg_conv_geom* g) {
@@ -2484,7 +2549,15 @@ int mg_conv_wino_prepare(const mg_conv_geom* g, const float* w, float* u, void* 
 }
 
 size_t mg_conv_wino_tiles_bytes(const mg_conv_geom* g, int which) {
-    if (!mg_conv_wino_weights_bytes(g) || h16_ok(g) || conv_dma_h_any(g)) return 0;
+    if (!mg_conv_wino_weights_bytes(g) || h16_ok(g)) return 0;
+    if (conv_dma_h_any(g)) {
+        // float16 implicit GEMMs: the "tiles" are the float16 copies of x (forward -> weight gradient) and of dy (data
+        // gradient -> weight gradient), so that each tensor is cast once per step
+        if (!conv_dma_wgrad_ok(g)) return 0;
+        if (which == 0) return conv_dma_fwd_ok(g) ? conv_dma_h_x_bytes(g) : 0;
+        if (which == 1) return cd_dgrad_any(g) ? conv_dma_h_dy_bytes(g) : 0;
+        return 0;
+    }
     if (wino4_ok(g)) {
         const Wino4Dims d4 = wino4_dims(g);
         return which == 0 ? (size_t)25 * d4.T * g->Ci * sizeof(float) : which == 1 ? (size_t)25 * d4.T * g->Co * sizeof(float) : 0;
@@ -2556,8 +2629,9 @@ int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const f
         const void* win = w;
         char* wsp = (char*)workspace;
         if (cd_half) {          // float16 copies: the activation by a cast pass, the weights from the cache when there is one
-            cd_cast16(x, wsp, (size_t)g->B * g->H * g->W * g->Ci, st);
-            xin = wsp;
+            void* x16 = (wt && wt->v) ? (void*)wt->v : (void*)wsp;         // kept by the caller for the weight gradient
+            cd_cast16(x, x16, (size_t)g->B * g->H * g->W * g->Ci, st);
+            xin = x16;
             wsp += conv_dma_h_x_bytes(g);
             if (u) {
                 win = u;
@@ -2648,39 +2722,22 @@ int mg_conv_dgrad_w(const mg_conv_geom* g, const float* dy, const float* w, cons
     const Geom gg = to_geom(g);
     hipStream_t st = (hipStream_t)stream;
     const int s = g->stride;
-    const bool cd_half = conv_dma_half(g);
-    if (conv_dma_dgrad_ok(g) && aligned16(dy) && aligned16(w) && aligned16(dx) && (!bias || aligned16(bias)) &&
-        (!cd_half || (workspace && aligned16(workspace) && workspace_bytes >= mg_conv_dgrad_workspace(g)))) {
-        CdPlan cp = conv_dma_dgrad_plan(g);
-        if (cp.splits > 1 && (!workspace || workspace_bytes < mg_conv_dgrad_workspace(g) || !aligned16(workspace))) cp.splits = 1;
-        const void* dyin = dy;
-        const void* win = w;
-        char* wsp = (char*)workspace;
-        if (cd_half) {
-            cd_cast16(dy, wsp, (size_t)g->B * g->OH * g->OW * g->Co, st);
-            dyin = wsp;
-            wsp += conv_dma_h_dy_bytes(g);
-            if (u) {
-                win = u;
-            } else {
-                cd_cast16(w, wsp, (size_t)g->Co * g->KH * g->KW * g->Ci, st);
-                win = wsp;
-            }
-            wsp += conv_dma_h_w_bytes(g);
+    if (aligned16(dy) && aligned16(w) && aligned16(dx) && (!bias || aligned16(bias)) && workspace && aligned16(workspace) &&
+        workspace_bytes >= mg_conv_dgrad_workspace(g)) {
+        float* md = wt ? wt->md : nullptr;
+        if (conv_dma_dgrad_ok(g))
+            return cd_dgrad_run(g, dy, w, bias, dx, act, (char*)workspace, st, u, md, conv_dma_half(g) ? 1 : 0);
+        mg_conv_geom gp;
+        if (!bias && act == MG_ACT_NONE && cd_reflect_dgrad_geom(g, &gp)) {
+            float* dxp = (float*)workspace;
+            const int rc = cd_dgrad_run(&gp, dy, w, nullptr, dxp, MG_ACT_NONE, (char*)workspace + cd_reflect_dxp_bytes(&gp), st, u,
+                                        md, 0);
+            if (rc != MG_OK) return rc;
+            hipLaunchKernelGGL(wino_fold_reflect_kernel, dim3(wino_grid((size_t)g->B * g->H * g->W * g->Ci / 4)), dim3(256), 0,
+                               st, (const float*)dxp, g->B, g->H, g->W, g->Ci, dx, (int)prec_h(g));
             MG_CHECK_LAUNCH();
+            return MG_OK;
         }
-        probe_begin(st);
-        conv_dma_dgrad_launch(g, cp, dyin, win, bias, dx, act, (float*)wsp, st);
-        probe_end(st);
-        MG_CHECK_LAUNCH();
-        if (cp.splits > 1) {
-            const size_t n = (size_t)g->B * g->H * g->W * g->Ci;
-            const unsigned blocks = (unsigned)((n / 4 + 255) / 256 > 4096 ? 4096 : (n / 4 + 255) / 256);
-            hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, (const float*)wsp, cp.splits, n, g->Ci,
-                               bias, act, dx, cd_half ? 1 : 0);
-            MG_CHECK_LAUNCH();
-        }
-        return MG_OK;
     }
     // every input pixel is produced by exactly one class launch; classes cover all of [0,H)x[0,W)
     const long long Mc = (long long)g->B * ((g->H + s - 1) / s) * ((g->W + s - 1) / s);   // largest class
@@ -2848,12 +2905,20 @@ int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, floa
         const void* xin = x;
         const void* dyin = dy;
         char* wsp = (char*)workspace;
-        if (conv_dma_half(g)) {
-            cd_cast16(x, wsp, (size_t)g->B * g->H * g->W * g->Ci, st);
-            xin = wsp;
+        if (conv_dma_half(g)) {          // float16 copies: the caller's (made by the forward / data-gradient call) or cast here
+            if (wt && wt->v) {
+                xin = wt->v;
+            } else {
+                cd_cast16(x, wsp, (size_t)g->B * g->H * g->W * g->Ci, st);
+                xin = wsp;
+            }
             wsp += conv_dma_h_x_bytes(g);
-            cd_cast16(dy, wsp, (size_t)g->B * g->OH * g->OW * g->Co, st);
-            dyin = wsp;
+            if (wt && wt->md) {
+                dyin = wt->md;
+            } else {
+                cd_cast16(dy, wsp, (size_t)g->B * g->OH * g->OW * g->Co, st);
+                dyin = wsp;
+            }
             wsp += conv_dma_h_dy_bytes(g);
             MG_CHECK_LAUNCH();
         }

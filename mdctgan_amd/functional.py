@@ -207,7 +207,10 @@ class _ConvFn(torch.autograd.Function):
             g = ops.conv_geom(B, stride * H, stride * W, cout_t, cin_t, KH, KW, stride, pad, False,
                               amp.current_precision())
             assert (g.OH, g.OW) == (H, W), "unsupported ConvTranspose2d geometry"
-            y = ops.conv_dgrad(g, nhwc_view(x), w, b, act)
+            # the weight image (Winograd U / float16 copy) serves this call and the backward's data gradient
+            u = ops.wino_weights(g, w) if (ctx.needs_input_grad[0] and x.is_cuda) else None
+            y = ops.conv_dgrad(g, nhwc_view(x), w, b, act, u=u)
+            ctx.u, ctx.v = u, None
         y = nchw_view(y)
         ctx.g, ctx.cfg = g, cfg
         ctx.weight, ctx.bias = weight, bias
@@ -240,7 +243,7 @@ class _ConvFn(torch.autograd.Function):
         if want_dx:
             if not transposed:
                 u = getattr(ctx, "u", None)
-                if u is not None and getattr(ctx, "v", None) is not None and want_dw:
+                if u is not None and want_dw and (getattr(ctx, "v", None) is not None or ops.tiles_are_casts(g)):
                     _, md = ops.wino_tile_buffers(g, gy.device, want_v=False)
                 if rows is not None:
                     dx = torch.empty_like(x_full)
@@ -250,7 +253,9 @@ class _ConvFn(torch.autograd.Function):
                 if last_use:
                     ctx.u = None
             else:
-                dx = nchw_view(ops.conv_fwd(g, nhwc_view(gy), w))
+                dx = nchw_view(ops.conv_fwd(g, nhwc_view(gy), w, u=getattr(ctx, "u", None)))
+                if last_use:
+                    ctx.u = None
         if want_dw:
             wbuf, wacc = grad_buffer(weight)
             bbuf = bacc = None
@@ -263,7 +268,8 @@ class _ConvFn(torch.autograd.Function):
                 if bbuf is not None and bacc != wacc:      # keep one accumulate flag per launch
                     ops.colsum(nhwc_view(gy).reshape(-1, g.Co), bbuf, bacc)
                     bbuf = None
-                v = getattr(ctx, "v", None) if md is not None else None
+                # Winograd images come as a pair; the float16 copies of the implicit-GEMM layers are independent
+                v = getattr(ctx, "v", None) if (md is not None or ops.tiles_are_casts(g)) else None
                 ops.conv_wgrad(g, nhwc_view(x), nhwc_view(gy), wbuf, bbuf, wacc, v=v, md=md)
                 ctx.v = None
             else:

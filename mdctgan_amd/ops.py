@@ -69,6 +69,22 @@ def wino_tile_buffers(g: ConvGeom, device, want_v=True, want_md=True):
     return v, md
 
 
+def tiles_are_casts(g: ConvGeom) -> bool:
+    """True for the autocast layers on the float16 implicit GEMMs (csrc/conv_dma.h): their v / md "tiles" are plain float16
+    copies of x / dy, each usable on its own (Winograd images only work as a pair)."""
+    if g.precision != _lib.PRECISION_F16:
+        return False
+    key = (g.B, g.H, g.W, g.Ci, g.Co, g.KH, g.KW, g.stride, g.pad, g.reflect)
+    hit = _CASTS.get(key)
+    if hit is None:
+        name = plan_name(2, g)
+        hit = _CASTS[key] = name.startswith("conv_wgrad_dma_kernel") and name.endswith("true>")
+    return hit
+
+
+_CASTS = {}
+
+
 def _tiles(u=None, v=None, md=None):
     if u is None and v is None and md is None:
         return None

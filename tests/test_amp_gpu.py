@@ -94,7 +94,7 @@ def test_conv_f16_precision(case):
     if name.startswith("cdh_"):
         assert ops.plan_name(0, g).startswith("conv_fwd_dma_kernel") and ops.plan_name(0, g).endswith("true>")
         assert ops.plan_name(2, g).startswith("conv_wgrad_dma_kernel") and ops.plan_name(2, g).endswith("true>")
-        assert reflect or ops.plan_name(1, g).startswith("conv_dgrad_dma_kernel"), ops.plan_name(1, g)
+        assert ops.plan_name(1, g).startswith("conv_dgrad_dma_kernel"), ops.plan_name(1, g)      # reflect: padded domain + fold
     wino = bool(_lib.load().mg_conv_wino_weights_bytes(g)) and not h16 and not cdh
     tol = dict(ulps=4.0, floor=2.0 ** -9) if wino else {}
     close_f16(ops.conv_fwd(g, xd, wd, bd), nhwc(y.detach()), **tol)
@@ -112,6 +112,17 @@ def test_conv_f16_precision(case):
     assert (dw.double().cpu() - want).abs().max().item() <= wtol * want.abs().max().item()
     ops.conv_wgrad(g, xd, gyd, dw, None, accumulate=True)
     assert (dw.double().cpu() - 2 * want).abs().max().item() <= 2 * wtol * want.abs().max().item()
+    if cdh:      # float16 copies of x / dy handed from the forward / data-gradient call to the weight gradient: same bits
+        u = ops.wino_weights(g, wd)
+        v, md = ops.wino_tile_buffers(g, xd.device)
+        assert v is not None and md is not None
+        assert torch.equal(ops.conv_fwd(g, xd, wd, bd, u=u, v_out=v), ops.conv_fwd(g, xd, wd, bd))
+        if md is not None:
+            assert torch.equal(ops.conv_dgrad(g, gyd, wd, u=u, md_out=md), ops.conv_dgrad(g, gyd, wd))
+        dw1, dw2 = torch.empty_like(dw), torch.empty_like(dw)
+        ops.conv_wgrad(g, xd, gyd, dw1, None)
+        ops.conv_wgrad(g, xd, gyd, dw2, None, v=v, md=md)
+        assert torch.equal(dw1, dw2)
 
 
 def test_conv_f16_overflow_becomes_inf():
