@@ -307,6 +307,12 @@ int mg_scaler_update(float* scaler, float growth_factor, float backoff_factor, i
 int mg_adam_tick_amp(double* state, float beta1, float beta2, const float* scaler, int slot, void* stream);
 int mg_adam_step_amp(float* p, const float* g, float* m, float* v, long long n, const double* state, float beta1,
                      float beta2, float eps, float grad_scale, const float* scaler, int slot, void* stream);
+/* mg_adam_step_amp (scaler != NULL) or mg_adam_step_dev (scaler == NULL) that also writes p16[i] = (float16) p[i] for the
+ * updated parameters: the float16 weight operand of the autocast convolutions (train.py --fp16; autocast casts every
+ * weight per call, pix2pixHD_model.py:285-301) is refreshed by the optimiser pass that already streams the parameters
+ * instead of by one cast launch per layer.  A skipped step (found_inf) leaves p and p16 untouched. */
+int mg_adam_step_h(float* p, const float* g, float* m, float* v, void* p16, long long n, const double* state, float beta1,
+                   float beta2, float eps, float grad_scale, const float* scaler, int slot, void* stream);
 
 #ifdef __cplusplus
 }

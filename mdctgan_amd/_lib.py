@@ -105,6 +105,7 @@ SIGNATURES = {
     "mg_scaler_update": (_i, [_p, _f, _f, _i, _p]),
     "mg_adam_tick_amp": (_i, [_p, _f, _f, _p, _i, _p]),
     "mg_adam_step_amp": (_i, [_p, _p, _p, _p, _ll, _p, _f, _f, _f, _f, _p, _i, _p]),
+    "mg_adam_step_h": (_i, [_p, _p, _p, _p, _p, _ll, _p, _f, _f, _f, _f, _p, _i, _p]),
 }
 
 _lib = None

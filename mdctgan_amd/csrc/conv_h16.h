@@ -196,13 +196,23 @@ int h16_prepare(const mg_conv_geom* g, const float* w, void* w16, hipStream_t st
     MG_CHECK_LAUNCH();
     return MG_OK;
 }
+inline bool h16_deep(long long M, int N, int splits, bool brc) {
+    return ((M + 127) / 128) * ((N + (brc ? 63 : 127)) / (brc ? 64 : 128)) * splits <= 512;
+}
 inline void h16_launch(const H16Plan& p, bool brc, const HgArgs& a, hipStream_t st) {
     // three LDS buffers: two chunks in flight per workgroup -- the weights come cold from HBM every step (1.4 GB of float16
     // copies per configs[2] iteration, nothing stays in the 256 MiB Infinity Cache) and one chunk per CU does not cover that
     // latency (scripts/ubench/hgemm_bench with HG_ROT=6: 43.5 -> 36.7 us on the 2048-channel trunk shape)
-    if (brc) hgemm_launch<128, 64, 2, 2, true, 3>(a, st);
-    else hgemm_launch<128, 128, 4, 2, false, 3>(a, st);
-    (void)p;
+    // Only when the grid is a single round (<= 2 workgroups per CU would fit anyway): the weight gradient's thousands of
+    // short workgroups want two 64 KiB workgroups per CU instead (same harness: 56 vs 78 us).
+    const bool deep = h16_deep(a.M, a.N, p.splits, brc);
+    if (brc) {
+        if (deep) hgemm_launch<128, 64, 2, 2, true, 3>(a, st);
+        else hgemm_launch<128, 64, 2, 2, true, 2>(a, st);
+    } else {
+        if (deep) hgemm_launch<128, 128, 4, 2, false, 3>(a, st);
+        else hgemm_launch<128, 128, 4, 2, false, 2>(a, st);
+    }
 }
 
 int h16_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act, char* ws,

@@ -560,7 +560,7 @@ __global__ void adam_tick_amp_kernel(double* __restrict__ state, double b1, doub
 __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                 float* __restrict__ v, size_t n, const double* __restrict__ state, float b1, float b2,
                                 float eps, float gscale, const float* __restrict__ loss_scale,
-                                const float* __restrict__ found_inf) {
+                                const float* __restrict__ found_inf, _Float16* __restrict__ p16 = nullptr) {
     if (found_inf && *found_inf != 0.0f) return;          // GradScaler.step: skip the update on inf / nan gradients
     if (loss_scale) gscale = gscale / *loss_scale;        // unscale
     const float step_size = (float)state[2], bc2_sqrt = (float)state[3];
@@ -582,6 +582,11 @@ __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__
         *reinterpret_cast<float4*>(p + 4 * i) = pv;
         *reinterpret_cast<float4*>(m + 4 * i) = mv;
         *reinterpret_cast<float4*>(v + 4 * i) = vv;
+        if (p16) {          // float16 shadow of the parameters (the autocast convolutions' weight operand): 2 more bytes written
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            const h4 hv = {(_Float16)pp[0], (_Float16)pp[1], (_Float16)pp[2], (_Float16)pp[3]};
+            *reinterpret_cast<h4*>(p16 + 4 * i) = hv;
+        }
     }
     if (blockIdx.x == 0)
         for (size_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
@@ -590,6 +595,7 @@ __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__
             const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
             m[i] = mi; v[i] = vi;
             p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+            if (p16) p16[i] = (_Float16)p[i];
         }
 }
 
@@ -853,6 +859,18 @@ int mg_adam_step_amp(float* p, const float* g, float* m, float* v, long long n, 
     if (!al16(p) || !al16(g) || !al16(m) || !al16(v)) return MG_ERR_ARG;
     hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for((size_t)n, 8)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
                        (size_t)n, state, beta1, beta2, eps, grad_scale, scaler, scaler + 2 + slot);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+int mg_adam_step_h(float* p, const float* g, float* m, float* v, void* p16, long long n, const double* state, float beta1,
+                   float beta2, float eps, float grad_scale, const float* scaler, int slot, void* stream) {
+    if (!p || !g || !m || !v || !p16 || !state || n <= 0) return MG_ERR_ARG;
+    if (scaler && (slot < 0 || slot >= MG_SCALER_SLOTS)) return MG_ERR_ARG;
+    if (!al16(p) || !al16(g) || !al16(m) || !al16(v) || (reinterpret_cast<uintptr_t>(p16) & 7)) return MG_ERR_ARG;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for((size_t)n, 8)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                       (size_t)n, state, beta1, beta2, eps, grad_scale, scaler, scaler ? scaler + 2 + slot : (const float*)nullptr,
+                       (_Float16*)p16);
     MG_CHECK_LAUNCH();
     return MG_OK;
 }

@@ -125,6 +125,21 @@ def _cached_wino_weights(g, weight, fill=True):
     return u
 
 
+def _weight_image(g, weight):
+    """Weight operand image of a training-step convolution: the Winograd transform / float16 copy made by
+    ops.wino_weights, or -- for layers whose image is the plain float16 copy -- the slice of the optimiser's float16
+    shadow arena (FusedAdam(half_shadow=True)), which the Adam kernel keeps current."""
+    h = getattr(weight, "_mg_h", None)
+    if h is not None and ops.weights_are_casts(g):
+        if weight._version == weight._mg_h_version:
+            return h
+        if not torch.cuda.is_current_stream_capturing():       # the parameter was rewritten by a torch op: re-sync
+            h.copy_(weight._mg_flat)
+            weight._mg_h_version = weight._version
+            return h
+    return ops.wino_weights(g, weight.detach())
+
+
 # ------------------------------------------------------------------------------------------------
 # one discriminator forward, two backward passes
 # ------------------------------------------------------------------------------------------------
@@ -187,7 +202,7 @@ class _ConvFn(torch.autograd.Function):
             g = ops.conv_geom(B, H, W, Ci, Co, KH, KW, stride, pad, reflect, amp.current_precision())
             # Winograd layers: transform the weights once, reuse the image for the data gradient of this step
             if ctx.needs_input_grad[0]:
-                u = ops.wino_weights(g, w)
+                u = _weight_image(g, weight)
             elif x.is_cuda and not torch.is_grad_enabled():
                 # inference: once per weight version (a captured inference graph reads the images its warm-up made)
                 u = _cached_wino_weights(g, weight, fill=not torch.cuda.is_current_stream_capturing())
@@ -208,7 +223,7 @@ class _ConvFn(torch.autograd.Function):
                               amp.current_precision())
             assert (g.OH, g.OW) == (H, W), "unsupported ConvTranspose2d geometry"
             # the weight image (Winograd U / float16 copy) serves this call and the backward's data gradient
-            u = ops.wino_weights(g, w) if (ctx.needs_input_grad[0] and x.is_cuda) else None
+            u = _weight_image(g, weight) if (ctx.needs_input_grad[0] and x.is_cuda) else None
             y = ops.conv_dgrad(g, nhwc_view(x), w, b, act, u=u)
             ctx.u, ctx.v = u, None
         y = nchw_view(y)

@@ -307,6 +307,25 @@ def adam_step_amp(p, g, m, v, state, beta1, beta2, eps, grad_scale, scaler, slot
                "mg_adam_step_amp")
 
 
+def adam_step_h(p, g, m, v, p16, state, beta1, beta2, eps, grad_scale, scaler=None, slot=0):
+    """Adam update that also refreshes the float16 shadow p16 of the parameters (scaler: GradScaler state or None)."""
+    lib = _lib.load()
+    _lib.check(lib.mg_adam_step_h(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), _lib.ptr(p16), p.numel(),
+                                  _lib.ptr(state), beta1, beta2, eps, grad_scale, _lib.ptr(scaler), slot, _lib.stream()),
+               "mg_adam_step_h")
+
+
+def weights_are_casts(g: ConvGeom) -> bool:
+    """True when the layer's cached weight image (mg_conv_wino_prepare) is the plain float16 copy of its OHWI weights."""
+    if g.precision != _lib.PRECISION_F16:
+        return False
+    key = ("w", g.B, g.H, g.W, g.Ci, g.Co, g.KH, g.KW, g.stride, g.pad, g.reflect)
+    hit = _CASTS.get(key)
+    if hit is None:
+        hit = _CASTS[key] = wino_weights_bytes(g) == g.Co * g.KH * g.KW * g.Ci * 2
+    return hit
+
+
 def batchnorm_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, training, residual=None, act=ACT_NONE):
     """x [B, H, W, C] NHWC -> (y, save_mean [C], save_rstd [C])."""
     lib = _lib.load()

@@ -15,6 +15,11 @@ from . import functional as Fh
 from . import ops
 
 
+def _padded(n):
+    """Arena slice length: every float32 slice AND its float16 shadow slice start 16-byte aligned."""
+    return (n + 7) // 8 * 8
+
+
 def _arena_view(flat, off, p):
     n = p.numel()
     if p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) and not p.is_contiguous():
@@ -24,7 +29,9 @@ def _arena_view(flat, off, p):
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-8):
+    def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-8, half_shadow=False):
+        """half_shadow (--fp16): keep a float16 copy of the whole parameter arena, rewritten by the Adam kernel itself; the
+        autocast convolutions read their weight operand from it (functional._weight_image) instead of casting per layer."""
         params = [p for p in params]
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._params = [p for g in self.param_groups for p in g["params"]]
@@ -32,6 +39,8 @@ class FusedAdam(torch.optim.Optimizer):
         self._built = False
         self.grad_scale = 1.0          # 1/world_size under data parallelism (gradients arrive summed)
         self.pre_step_hook = None      # reducer.finish() under data parallelism
+        self.half_shadow = bool(half_shadow)
+        self.flat_h = None
 
     # -- arena ---------------------------------------------------------------------------------
     def _build(self):
@@ -45,7 +54,7 @@ class FusedAdam(torch.optim.Optimizer):
         offs, total = [], 0
         for p in ps:
             offs.append(total)
-            total += (p.numel() + 3) // 4 * 4                  # keep every slice 16-byte aligned
+            total += _padded(p.numel())
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -67,13 +76,20 @@ class FusedAdam(torch.optim.Optimizer):
                     fresh = True
                 p.grad = gview
                 p._mg_fresh = fresh
+            if self.half_shadow:
+                self.flat_h = self.flat_p.to(torch.float16)
+                for p, off in zip(ps, offs):
+                    n = p.numel()
+                    # flat views in arena (= OHWI memory) order; valid while the parameter's version counter stands still
+                    # (the Adam kernel writes both through raw pointers, which does not move it)
+                    p._mg_h, p._mg_flat, p._mg_h_version = self.flat_h[off:off + n], self.flat_p[off:off + n], p._version
         self._built = True
 
     def arena_slices(self):
         """[(param, offset, padded_numel)] in arena order (used by the data-parallel reducer)."""
         if not self._built:
             self._build()
-        return [(p, o, (p.numel() + 3) // 4 * 4) for p, o in zip(self._params, self.offsets)]
+        return [(p, o, _padded(p.numel())) for p, o in zip(self._params, self.offsets)]
 
     # -- torch.optim API -----------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = False):
@@ -130,14 +146,16 @@ class FusedAdam(torch.optim.Optimizer):
             spans.append((lo, hi))
         if scaler_state is None:
             ops.adam_tick(self.state, b1, b2)
-            for lo, hi in spans:
-                ops.adam_step_dev(self.flat_p[lo:hi], self.flat_g[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi],
-                                  self.state, b1, b2, eps, self.grad_scale)
         else:
             for lo, hi in spans:
                 ops.scaler_check(self.flat_g[lo:hi], scaler_state, scaler_slot)
             ops.adam_tick_amp(self.state, b1, b2, scaler_state, scaler_slot)
-            for lo, hi in spans:
-                ops.adam_step_amp(self.flat_p[lo:hi], self.flat_g[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi],
-                                  self.state, b1, b2, eps, self.grad_scale, scaler_state, scaler_slot)
+        for lo, hi in spans:
+            args = (self.flat_p[lo:hi], self.flat_g[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi])
+            if self.flat_h is not None:
+                ops.adam_step_h(*args, self.flat_h[lo:hi], self.state, b1, b2, eps, self.grad_scale, scaler_state, scaler_slot)
+            elif scaler_state is None:
+                ops.adam_step_dev(*args, self.state, b1, b2, eps, self.grad_scale)
+            else:
+                ops.adam_step_amp(*args, self.state, b1, b2, eps, self.grad_scale, scaler_state, scaler_slot)
         return None

@@ -309,8 +309,11 @@ class Pix2PixHDModel(BaseModel):
                           if k.startswith("model" + str(opt.n_local_enhancers))]
             else:
                 params = list(self.netG.parameters())
-            self.optimizer_G = FusedAdam([p for p in params if p.requires_grad], lr=opt.lr, betas=(opt.beta1, 0.999))
-            self.optimizer_D = FusedAdam(list(self.netD.parameters()), lr=opt.lr, betas=(opt.beta1, 0.999))
+            shadow = bool(getattr(opt, "fp16", False))      # autocast: Adam keeps the float16 weight operands current
+            self.optimizer_G = FusedAdam([p for p in params if p.requires_grad], lr=opt.lr, betas=(opt.beta1, 0.999),
+                                         half_shadow=shadow)
+            self.optimizer_D = FusedAdam(list(self.netD.parameters()), lr=opt.lr, betas=(opt.beta1, 0.999),
+                                         half_shadow=shadow)
         # A D pass whose weight gradients train.py discards (the G-loss pass) skips its wgrad launches; set False
         # to reproduce the reference's wasted work bit for bit.
         self.skip_discarded_d_grads = True
@@ -511,7 +514,7 @@ class Pix2PixHDModel(BaseModel):
         params = [p for p in self.netG.parameters() if p.requires_grad]
         for p in params:                       # the new arena copies the current values; gradients start fresh
             p.grad = None
-        self.optimizer_G = FusedAdam(params, lr=self.lr, betas=(self.beta1, 0.999))
+        self.optimizer_G = FusedAdam(params, lr=self.lr, betas=(self.beta1, 0.999), half_shadow=old.half_shadow)
         if self.scaler is not None:
             self.scaler.release(old)
         red = getattr(self, "reducers", None)

@@ -226,6 +226,18 @@ def test_fp16_step_against_reference_and_oracle(golden):
             assert abs(lh[k].item() - lo[k]) <= rtol * abs(lo[k]) + 2e-3, (it, k, lh[k].item(), lo[k])
     assert model3.scaler.get_scale() == rs.get_scale() == 256.0
     assert model3.optimizer_G.state[0].item() == 3 and model3.optimizer_D.state[0].item() == 3
+    # the float16 shadow of the parameters is what the Adam kernel wrote: bit-equal to a fresh cast after real updates,
+    # and untouched by the skipped ones of model2
+    for m_ in (model3, model2):
+        for opt_ in (m_.optimizer_G, m_.optimizer_D):
+            assert opt_.flat_h is not None and torch.equal(opt_.flat_h, opt_.flat_p.to(torch.float16))
+    # a parameter rewritten by a torch op (checkpoint load, re-initialisation): the next step re-syncs its slice
+    w0 = next(p_ for p_ in model3.netG.parameters() if p_.dim() == 4)
+    with torch.no_grad():
+        w0.mul_(0.5)
+    assert not torch.equal(w0._mg_h, w0._mg_flat.to(torch.float16))
+    model3.optimize_parameters(lr, hr)
+    assert torch.equal(model3.optimizer_G.flat_h, model3.optimizer_G.flat_p.to(torch.float16))
     # inference is float32 (generate_audio.py has no autocast)
     sr_spectro, sr_audio, *_ = model3.inference(lr)
     assert torch.isfinite(sr_audio).all() and sr_spectro.dtype == torch.float32
