@@ -42,8 +42,10 @@ def synth_batch(batch, seed, device, lr_rate=12000, hr_rate=48000):
 
 
 class HipEvents:
-    """Raw HIP events (ctypes on libamdhip64): the library records them on its launch stream right around the main
-    GEMM kernel of a conv call (mg_probe_arm), so the duration is the kernel's own, comparable with rocprofv3."""
+    """Raw HIP events (ctypes on libamdhip64) handed to the library (mg_probe_arm): its launcher passes them to
+    hipExtLaunchKernelGGL for the main GEMM kernel of the conv call, which stamps them with that dispatch's own begin /
+    end times on the launch stream -- the duration rocprofv3 reports for the kernel (the older non-DMA launch sites record
+    them immediately around their launch instead)."""
 
     def __init__(self):
         import ctypes
@@ -345,21 +347,24 @@ def main():
     if timer is not None and timer.records:
         n, flops, secs, conv_flops = timer.summary()[dominant]
         achieved = flops / secs / 1e12
-        f16_kernel = dominant.startswith("hgemm") or (     # float16 GEMMs (conv_h16.h) / TAG bit 1 convolution instances
-            dominant.startswith("conv_") and dominant.rstrip().endswith((", 2>", ", 3>")))
+        f16_kernel = dominant.startswith("hgemm") or (     # float16 GEMMs (conv_h16.h), HALF / TAG bit 1 convolution instances
+            dominant.startswith("conv_") and dominant.rstrip().endswith((", 2>", ", 3>", ", true>")))
         peak = PEAK_F16_MFMA_TFLOPS if f16_kernel else PEAK_F32_MFMA_TFLOPS
         roofline = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                     "launches": n, "avg_launch_us": round(secs / n * 1e6, 2),
                     "flops_per_launch": flops / n,
                     "flops_definition": "FLOPs the kernel itself issues (2*M*N*K of its GEMM, summed over the launches of this "
-                                        "symbol).  dgemm32g_kernel<BM, BN, 2, 2, A, B, 2> (csrc/dense_gemm.h) are the batched "
-                                        "Winograd-domain GEMMs: layouts (0, 0) forward, (0, 1) data gradient, (1, 1) weight gradient "
-                                        "of the F(2x2,3x3) / F(2x2,4x4) / F(4x4,2x2) layers; the direct-convolution cost of the same "
+                                        "symbol).  dgemm32g_kernel<BM, BN, 2, 2, A, B, 2, P> (csrc/dense_gemm.h) are the batched "
+                                        "Winograd-domain GEMMs: layouts (A, B) = (0, 0) forward, (0, 1) data gradient, (1, 1) weight "
+                                        "gradient; P = 16 the F(2x2,3x3) layers (the 1024-channel residual trunk), P = 25 the "
+                                        "F(2x2,4x4) / F(4x4,2x2) layers; the direct-convolution cost of the same "
                                         "layers (SURVEY 8d, 2*MACs) averages %.3g FLOP per launch" % (conv_flops / n),
-                    "timed": ("HIP events recorded by the library on its launch stream right around this kernel, "
-                              "every launch of %d eager iterations run right after the graph-replayed timed region" % args.steps) if use_graph else
-                             "HIP events around every launch of this kernel inside the timed region"}
+                    "timed": ("HIP events stamped with the dispatch's own begin / end times (hipExtLaunchKernelGGL start / stop "
+                              "events on the library's launch stream), every launch of this kernel in %d eager iterations run "
+                              "right after the graph-replayed timed region" % args.steps) if use_graph else
+                             "HIP events stamped with the dispatch's own begin / end times (hipExtLaunchKernelGGL), every launch "
+                             "of this kernel inside the timed region"}
         tr = os.path.join(REPO, "profiles", "traffic.json")     # HBM bytes/launch from rocprofv3 --pmc passes
         if os.path.exists(tr):
             try:

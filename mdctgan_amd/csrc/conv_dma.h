@@ -553,7 +553,7 @@ inline CdPlan conv_dma_wgrad_plan(const mg_conv_geom* g) {
 template <typename KernelT>
 inline void cd_launch(KernelT kern, size_t lds, dim3 grid, const CdArgs& a, hipStream_t st) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+    mg_launch(kern, grid, dim3(256), lds, st, a);
 }
 inline CdArgs cd_args(const mg_conv_geom* g) {
     CdArgs a{};

@@ -24,6 +24,7 @@
 #include <stdlib.h>
 #include <cstring>
 #include <type_traits>
+#include <hip/hip_ext.h>
 
 namespace {
 
@@ -1149,6 +1150,30 @@ extern "C" int mg_conv_rowdot_kq(const mg_conv_geom* g);       // conv_rowdot.hi
 #include "wino42.h"
 #include "conv_smallc.h"
 namespace {
+// One-shot event probe: bench.py arms it right before a call whose main GEMM kernel it wants timed on the launch
+// stream.  The LDS-DMA launchers (mg_launch below) hand the two events to hipExtLaunchKernelGGL, which stamps them with
+// the dispatch's own begin / end times -- the duration rocprofv3 reports for that kernel; the older launch sites record the
+// events immediately around their launch (a few microseconds of queue latency included).
+hipEvent_t g_probe_e0 = nullptr, g_probe_e1 = nullptr;
+bool g_probe_exact = false;
+inline void probe_begin(hipStream_t st) {
+    g_probe_exact = false;
+    if (g_probe_e0) hipEventRecord(g_probe_e0, st);
+}
+inline void probe_end(hipStream_t st) {
+    if (g_probe_e1 && !g_probe_exact) hipEventRecord(g_probe_e1, st);
+    g_probe_e0 = g_probe_e1 = nullptr;
+    g_probe_exact = false;
+}
+template <typename KernelT, typename ArgT>
+inline void mg_launch(KernelT kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, const ArgT& a) {
+    if (g_probe_e0 && g_probe_e1 && !g_probe_exact) {
+        hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds, st, g_probe_e0, g_probe_e1, 0, a);
+        g_probe_exact = true;
+    } else {
+        hipLaunchKernelGGL(kern, grid, block, lds, st, a);
+    }
+}
 #include "dense_gemm.h"
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1216,19 +1241,24 @@ inline int dense_splits(int pass, int P, long long T, int Co, int Kc, bool hp) {
 }
 template <int AL, int BL>
 void dense_launch(const DensePlan& p, const DgArgs& a, hipStream_t st) {
-    if (p.dma) {
-        if (p.bm == 128 && p.bn == 128) dgemm32g_launch<128, 128, 2, 2, AL, BL>(a, st);
-        else if (p.bm == 64 && p.bn == 128) dgemm32g_launch<64, 128, 2, 2, AL, BL>(a, st);
-        else if (p.bm == 128 && p.bn == 64) dgemm32g_launch<128, 64, 2, 2, AL, BL>(a, st);
-        else dgemm32g_launch<64, 64, 2, 2, AL, BL>(a, st);
+    if (p.dma && a.P == 16) {
+        if (p.bm == 128 && p.bn == 128) dgemm32g_launch<128, 128, 2, 2, AL, BL, 2, 16>(a, st);
+        else if (p.bm == 64 && p.bn == 128) dgemm32g_launch<64, 128, 2, 2, AL, BL, 2, 16>(a, st);
+        else if (p.bm == 128 && p.bn == 64) dgemm32g_launch<128, 64, 2, 2, AL, BL, 2, 16>(a, st);
+        else dgemm32g_launch<64, 64, 2, 2, AL, BL, 2, 16>(a, st);
+    } else if (p.dma) {
+        if (p.bm == 128 && p.bn == 128) dgemm32g_launch<128, 128, 2, 2, AL, BL, 2, 25>(a, st);
+        else if (p.bm == 64 && p.bn == 128) dgemm32g_launch<64, 128, 2, 2, AL, BL, 2, 25>(a, st);
+        else if (p.bm == 128 && p.bn == 64) dgemm32g_launch<128, 64, 2, 2, AL, BL, 2, 25>(a, st);
+        else dgemm32g_launch<64, 64, 2, 2, AL, BL, 2, 25>(a, st);
     } else {
         if (p.bm == 128) dgemm32_launch<128, 128, 4, 2, AL, BL>(a, st);
         else dgemm32_launch<64, 64, 2, 2, AL, BL>(a, st);
     }
 }
-void dense_name(int pass, const DensePlan& p, char* out, int out_len) {
+void dense_name(int pass, int P, const DensePlan& p, char* out, int out_len) {
     const int al = pass == 2 ? DG_RC : DG_KC, bl = pass == 0 ? DG_KC : DG_RC;
-    if (p.dma) snprintf(out, out_len, "dgemm32g_kernel<%d, %d, 2, 2, %d, %d, 2>", p.bm, p.bn, al, bl);
+    if (p.dma) snprintf(out, out_len, "dgemm32g_kernel<%d, %d, 2, 2, %d, %d, 2, %d>", p.bm, p.bn, al, bl, P);
     else snprintf(out, out_len, "dgemm32_kernel<%d, %d, %d, 2, %d, %d, 0>", p.bm, p.bn, p.bm == 128 ? 4 : 2, al, bl);
 }
 
@@ -1254,14 +1284,6 @@ bool geom_ok(const mg_conv_geom* g) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// One-shot event probe: bench.py arms it right before a call whose main GEMM kernel it wants timed on the launch
-// stream; the launcher records the two events immediately around that kernel launch and disarms.
-hipEvent_t g_probe_e0 = nullptr, g_probe_e1 = nullptr;
-inline void probe_begin(hipStream_t st) { if (g_probe_e0) hipEventRecord(g_probe_e0, st); }
-inline void probe_end(hipStream_t st) {
-    if (g_probe_e1) hipEventRecord(g_probe_e1, st);
-    g_probe_e0 = g_probe_e1 = nullptr;
-}
 
 inline unsigned dense_grid(size_t n) {
     size_t b = (n + 255) / 256;
@@ -2385,11 +2407,11 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
         snprintf(out, out_len, pass == 1 ? "hgemm_kernel<128, 64, 2, 2, true, %d>" : "hgemm_kernel<128, 128, 4, 2, false, %d>", deep ? 3 : 2);
     } else if (wino_ok(g) && !kq && !(pass == 1 && wino_dgrad_padded()) &&
         dense_plan(pass, 16, wino_dims(g).T, g->Co, g->Ci, prec_h(g)).ok) {
-        dense_name(pass, dense_plan(pass, 16, wino_dims(g).T, g->Co, g->Ci, prec_h(g)), out, out_len);
+        dense_name(pass, 16, dense_plan(pass, 16, wino_dims(g).T, g->Co, g->Ci, prec_h(g)), out, out_len);
     } else if (wino4_ok(g) && !kq && dense_plan(pass, 25, wino4_dims(g).T, g->Co, g->Ci, false).ok) {
-        dense_name(pass, dense_plan(pass, 25, wino4_dims(g).T, g->Co, g->Ci, false), out, out_len);
+        dense_name(pass, 25, dense_plan(pass, 25, wino4_dims(g).T, g->Co, g->Ci, false), out, out_len);
     } else if (wino42_ok(g) && !kq && dense_plan(pass, 25, wino42_dims(g).T, g->Co, wino42_dims(g).K4, false).ok) {
-        dense_name(pass, dense_plan(pass, 25, wino42_dims(g).T, g->Co, wino42_dims(g).K4, false), out, out_len);
+        dense_name(pass, 25, dense_plan(pass, 25, wino42_dims(g).T, g->Co, wino42_dims(g).K4, false), out, out_len);
     } else if (wino_ok(g) && !kq) {
         const WinoDims d = wino_dims(g);
         if (pass == 0) {

@@ -251,7 +251,7 @@ inline void dgemm32_launch(const DgArgs& a0, hipStream_t st) {
         once = true;
     }
     const unsigned grid = (unsigned)((long long)a.tiles_m * a.tiles_n * a.splits * a.P);
-    hipLaunchKernelGGL((dgemm32_kernel<BM, BN, WGM, WGN, ALAY, BLAY, ABL>), dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, a);
+    mg_launch(dgemm32_kernel<BM, BN, WGM, WGN, ALAY, BLAY, ABL>, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, a);
 }
 
 
@@ -357,7 +357,9 @@ __device__ __forceinline__ void dg_dma16(unsigned voff, dg_v4i rsrc, unsigned ld
 template <int N>
 __device__ __forceinline__ void dg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int WGM, int WGN, int ALAY, int BLAY, int NBUF = 2>
+// PZ: the batch count as a compile-time constant (16: F(2x2,3x3); 25: F(2x2,4x4) / F(4x4,2x2); 0: read g.P) -- one symbol per
+// transform family, so a profile separates the 1024-channel residual trunk from the ladder's 5x5-tile layers.
+template <int BM, int BN, int WGM, int WGN, int ALAY, int BLAY, int NBUF = 2, int PZ = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void dgemm32g_kernel(DgArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)     // the buffer-resource type does not exist in the host pass (which only needs the stub)
     using Cfg = DgCfgG<BM, BN, WGM, WGN, ALAY, BLAY, NBUF>;
@@ -368,8 +370,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void dgemm32g_kernel(DgArgs g) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nz = PZ ? PZ : g.P;
     const int tiles = g.tiles_m * g.tiles_n, per_z = tiles * g.splits;
-    const int L = xcd_remap(blockIdx.x, per_z * g.P);
+    const int L = xcd_remap(blockIdx.x, per_z * nz);
     const int z = L / per_z;
     int rem = L - z * per_z;
     const int sp = rem / tiles;
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void dgemm32g_kernel(DgArgs g) {
         }
     }
 
-    float* o = g.part ? g.part + ((size_t)sp * g.P + z) * ((size_t)g.M * g.N) : g.C + (size_t)z * g.sc;
+    float* o = g.part ? g.part + ((size_t)sp * nz + z) * ((size_t)g.M * g.N) : g.C + (size_t)z * g.sc;
     if (m0 + BM <= g.M && n0 + BN <= g.N) {        // interior tile (wave-uniform): no per-element predicates
         float* ow = o + (size_t)(m0 + wm0 + 4 * (lane >> 5)) * g.N + n0 + wn0 + (lane & 31);
 #pragma unroll
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void dgemm32g_kernel(DgArgs g) {
 #endif
 }
 
-template <int BM, int BN, int WGM, int WGN, int ALAY, int BLAY, int NBUF = 2>
+template <int BM, int BN, int WGM, int WGN, int ALAY, int BLAY, int NBUF = 2, int PZ = 0>
 inline void dgemm32g_launch(const DgArgs& a0, hipStream_t st) {
     using Cfg = DgCfgG<BM, BN, WGM, WGN, ALAY, BLAY, NBUF>;
     DgArgs a = a0;
@@ -483,10 +486,10 @@ inline void dgemm32g_launch(const DgArgs& a0, hipStream_t st) {
     a.tiles_n = (a.N + BN - 1) / BN;
     static bool once = false;
     if (!once) {
-        hipFuncSetAttribute((const void*)dgemm32g_kernel<BM, BN, WGM, WGN, ALAY, BLAY, NBUF>,
+        hipFuncSetAttribute((const void*)dgemm32g_kernel<BM, BN, WGM, WGN, ALAY, BLAY, NBUF, PZ>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
         once = true;
     }
     const unsigned grid = (unsigned)((long long)a.tiles_m * a.tiles_n * a.splits * a.P);
-    hipLaunchKernelGGL((dgemm32g_kernel<BM, BN, WGM, WGN, ALAY, BLAY, NBUF>), dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, a);
+    mg_launch(dgemm32g_kernel<BM, BN, WGM, WGN, ALAY, BLAY, NBUF, PZ>, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, a);
 }

@@ -226,5 +226,5 @@ inline void hgemm_launch(const HgArgs& a0, hipStream_t st) {
         once = true;
     }
     const unsigned grid = (unsigned)((long long)a.tiles_m * a.tiles_n * a.splits);
-    hipLaunchKernelGGL((hgemm_kernel<BM, BN, WGM, WGN, BRC, NBUF>), dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, a);
+    mg_launch(hgemm_kernel<BM, BN, WGM, WGN, BRC, NBUF>, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, a);
 }

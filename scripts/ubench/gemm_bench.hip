@@ -8,6 +8,10 @@
 #include <cstring>
 #include <vector>
 namespace {
+template <typename KernelT, typename ArgT>
+inline void mg_launch(KernelT kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, const ArgT& a) {
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a);
+}
 #include "dense_gemm.h"
 
 __global__ void ref_gemm_kernel(DgArgs g, int alay, int blay, float* out) {
