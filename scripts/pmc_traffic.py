@@ -1,7 +1,9 @@
 """Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, see profiles/README.md) over
 scripts/bench_conv.py into per-kernel HBM bytes per launch: (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 correction
 of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE reports half the bytes of wide coalesced reads).
-    python scripts/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.csv> <traffic.json>"""
+    python scripts/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.csv> <traffic.json>
+traffic.json also gets "_source": the csv the numbers came from (bench.py copies traffic.json[dominant kernel] into
+roofline.traffic)."""
 import csv, json, re, sys
 from collections import defaultdict
 
@@ -27,7 +29,7 @@ f, fn = collect(sys.argv[1], "FETCH_SIZE")
 w, wn = collect(sys.argv[2], "WRITE_SIZE")
 rows, out = [], {}
 for k in f:
-    if k not in w or not (k.startswith(("conv_", "dense_", "wino"))):
+    if k not in w or not (k.startswith(("conv_", "dense_", "wino", "dgemm32", "hgemm", "h16_", "splitk", "norm_", "adam"))):
         continue
     fk, wk = f[k] / fn[k], w[k] / wn[k]
     b = int((2 * fk + wk) * 1024)
@@ -37,5 +39,7 @@ with open(sys.argv[3], "w") as fh:
     fh.write("kernel,dispatches,FETCH_SIZE_KB_raw,WRITE_SIZE_KB_raw,hbm_bytes_per_launch_corrected\n")
     for r in rows:
         fh.write('"%s",%d,%s,%s,%d\n' % r)
+import os
+out["_source"] = "profiles/" + os.path.basename(sys.argv[3])
 json.dump(out, open(sys.argv[4], "w"), indent=1)
 print(json.dumps(out, indent=1))
