@@ -159,9 +159,11 @@ def sync_buffers(model, group=None):
                 b.div_(world)
 
 
-def attach(model, bucket_bytes=128 << 20, group=None):
+def attach(model, bucket_bytes=None, group=None):
     """Wire a Pix2PixHDModel for data parallelism: broadcast both parameter arenas, every parameter outside them and
     every floating-point buffer from rank 0, create the G and D reducers and fold 1/world into the Adam kernels."""
+    if bucket_bytes is None:       # MDCTGAN_DDP_BUCKET_MB: bucket size in MiB (default 128)
+        bucket_bytes = int(os.environ.get("MDCTGAN_DDP_BUCKET_MB", "128")) << 20
     reducers = {}
     d_writes = 1 if getattr(model, "stack_d_loss_passes", False) else 2    # wgrad launches per D parameter and step
     arena_params = set()
