@@ -1327,6 +1327,7 @@ inline size_t slab_count(int old_splits, int dense) {      // split-K slabs a wo
 #include "dense_gemm_h.h"
 #include "conv_h16.h"
 #include "conv_dma.h"
+#include "conv_co1.h"
 // float32 -> float16 staging copy of n elements (n % 8 == 0 for every eligible layer: Ci, Co % 64 == 0)
 inline void cd_cast16(const float* src, void* dst, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(h16_cast_kernel, dim3(h16_grid(n / 8)), dim3(256), 0, st, src, (_Float16*)dst, n / 8);
@@ -2382,6 +2383,7 @@ void mg_probe_arm(void* e0, void* e1) {
 double mg_conv_plan_flops(int pass, const mg_conv_geom* g) {
     if (!geom_ok(g)) return 0.0;
     const double direct = 2.0 * g->B * g->OH * g->OW * (double)g->Co * g->KH * g->KW * g->Ci;
+    if (co1_gemm_ok(g)) return 2.0 * CO1_TAPS * (double)g->B * g->H * g->W * g->Ci;      // the 64-tap GEMM (conv_co1.h)
     if (wino_ok(g) && !mg_conv_rowdot_kq(g)) {
         const WinoDims d = wino_dims(g);
         const double T = (pass == 1 && g->reflect && wino_dgrad_padded()) ? (double)d.Tp : (double)d.T;
@@ -2397,6 +2399,11 @@ double mg_conv_plan_flops(int pass, const mg_conv_geom* g) {
 int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
     if (!geom_ok(g) || !out || out_len < 64) return MG_ERR_ARG;
     const int kq = mg_conv_rowdot_kq(g);
+    if (co1_gemm_ok(g)) {          // single-output-channel layers as tap GEMMs (conv_co1.h)
+        snprintf(out, out_len, pass == 0 ? "dgemm32g_kernel<64, 128, 2, 2, 0, 0, 2, 0, 0>"
+                               : pass == 1 ? "dgemm32g_kernel<128, 64, 2, 2, 1, 1, 2, 0, 0>" : "dgemm32g_kernel<64, 64, 2, 2, 0, 1, 2, 0, 0>");
+        return MG_OK;
+    }
     if (h16_ok(g) && !kq) {
         const long long px = (long long)g->B * g->OH * g->OW;
         const int Kw = g->KH * g->KW * g->Ci;
@@ -2517,6 +2524,7 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
 
 size_t mg_conv_fwd_workspace(const mg_conv_geom* g) {
     if (!geom_ok(g)) return 0;
+    if (co1_gemm_ok(g)) return co1_fwd_ws(g);
     if (h16_ok(g)) return h16_fwd_ws(g);
     if (wino_ok(g)) return wino_fwd_ws(g);
     if (wino4_ok(g) && !mg_conv_rowdot_kq(g)) return wino4_fwd_ws(g);
@@ -2529,6 +2537,7 @@ size_t mg_conv_fwd_workspace(const mg_conv_geom* g) {
 }
 size_t mg_conv_dgrad_workspace(const mg_conv_geom* g) {
     if (!geom_ok(g)) return 0;
+    if (co1_gemm_ok(g)) return co1_dgrad_ws(g);
     if (h16_ok(g)) return h16_dgrad_ws(g);
     if (wino_ok(g)) return wino_dgrad_ws(g);
     if (wino4_ok(g)) return wino4_dgrad_ws(g);
@@ -2547,7 +2556,9 @@ size_t mg_conv_dgrad_workspace(const mg_conv_geom* g) {
 }
 
 size_t mg_conv_wino_weights_bytes(const mg_conv_geom* g) {
-    if (!geom_ok(g) || mg_conv_rowdot_kq(g)) return 0;
+    if (!geom_ok(g)) return 0;
+    if (co1_gemm_ok(g)) return (size_t)CO1_TAPS * g->Ci * sizeof(float);      // tap GEMM: the weights zero-padded to 64 tap rows
+    if (mg_conv_rowdot_kq(g)) return 0;
     if (h16_ok(g)) return h16_weights_bytes(g);         // the float16 weight copy of the autocast GEMM path (conv_h16.h)
     if (conv_dma_h_any(g)) return h16_weights_bytes(g); // ... and of the float16 implicit GEMMs (conv_dma.h)
     if (wino4_ok(g)) return (size_t)25 * g->Co * g->Ci * sizeof(float);
@@ -2557,6 +2568,11 @@ size_t mg_conv_wino_weights_bytes(const mg_conv_geom* g) {
 }
 int mg_conv_wino_prepare(const mg_conv_geom* g, const float* w, float* u, void* stream) {
     if (!mg_conv_wino_weights_bytes(g) || !w || !u || !aligned16(w) || !aligned16(u)) return MG_ERR_ARG;
+    if (co1_gemm_ok(g)) {
+        co1_pad_w(g, w, u, (hipStream_t)stream);
+        MG_CHECK_LAUNCH();
+        return MG_OK;
+    }
     if (h16_ok(g) || conv_dma_h_any(g)) return h16_prepare(g, w, u, (hipStream_t)stream);
     if (wino4_ok(g)) {
         hipLaunchKernelGGL(wino4_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 2)), dim3(256), 0,
@@ -2578,6 +2594,7 @@ int mg_conv_wino_prepare(const mg_conv_geom* g, const float* w, float* u, void* 
 
 size_t mg_conv_wino_tiles_bytes(const mg_conv_geom* g, int which) {
     if (!mg_conv_wino_weights_bytes(g) || h16_ok(g)) return 0;
+    if (co1_gemm_ok(g)) return which == 1 ? co1_zt_bytes(g) : 0;       // Gt: made by the data gradient, reused by the weight gradient
     if (conv_dma_h_any(g)) {
         // float16 implicit GEMMs: the "tiles" are the float16 copies of x (forward -> weight gradient) and of dy (data
         // gradient -> weight gradient), so that each tensor is cast once per step
@@ -2626,6 +2643,8 @@ int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const f
     if (h16_ok(g) && workspace && workspace_bytes >= h16_fwd_ws(g) && aligned16(x) && aligned16(w) && aligned16(y) &&
         aligned16(workspace) && (!bias || aligned16(bias)))
         return h16_fwd(g, x, w, bias, y, act, (char*)workspace, (hipStream_t)stream, u);
+    if (co1_gemm_ok(g) && workspace && workspace_bytes >= co1_fwd_ws(g) && aligned16(x) && aligned16(w) && aligned16(workspace))
+        return co1_fwd(g, x, w, bias, y, act, (char*)workspace, (hipStream_t)stream, u);
     if (mg_conv_rowdot_kq(g) && aligned16(x) && aligned16(w)) {
         probe_begin((hipStream_t)stream);
         const int rc = mg_conv_rowdot_fwd(g, x, w, bias, y, act, stream);
@@ -2731,6 +2750,9 @@ int mg_conv_dgrad_w(const mg_conv_geom* g, const float* dy, const float* w, cons
     if (h16_ok(g) && !bias && act == MG_ACT_NONE && workspace && workspace_bytes >= h16_dgrad_ws(g) && aligned16(dy) &&
         aligned16(w) && aligned16(dx) && aligned16(workspace))
         return h16_dgrad(g, dy, w, dx, (char*)workspace, (hipStream_t)stream, u);
+    if (co1_gemm_ok(g) && !bias && act == MG_ACT_NONE && workspace && workspace_bytes >= co1_dgrad_ws(g) && aligned16(w) &&
+        aligned16(dx) && aligned16(workspace))
+        return co1_dgrad(g, dy, w, dx, (char*)workspace, (hipStream_t)stream, u, wt ? wt->md : nullptr);
     if (smallc_dgrad_ok(g) && !bias && act == MG_ACT_NONE && aligned16(dy)) {
         probe_begin((hipStream_t)stream);
         const int rc = smallc_dgrad(g, dy, w, dx, (hipStream_t)stream);
@@ -2837,6 +2859,7 @@ int mg_colsum(const float* a, long long M, int C, float* out, int accumulate, vo
 
 size_t mg_conv_wgrad_workspace(const mg_conv_geom* g) {
     if (!geom_ok(g)) return 0;
+    if (co1_gemm_ok(g)) return co1_wgrad_ws(g);
     if (mg_conv_rowdot_kq(g)) return mg_conv_rowdot_wgrad_workspace(g);
     if (h16_ok(g)) return h16_wgrad_ws(g);
     if (wino_ok(g)) return wino_wgrad_ws(g);
@@ -2857,6 +2880,8 @@ int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, floa
     if (!geom_ok(g) || !x || !dy || !dw) return MG_ERR_ARG;
     if (!wino_tiles_ok(g, wt)) return MG_ERR_ARG;
     if (workspace_bytes < mg_conv_wgrad_workspace(g) || !workspace) return MG_ERR_ARG;
+    if (co1_gemm_ok(g) && aligned16(x) && aligned16(workspace))
+        return co1_wgrad(g, x, dy, dw, dbias, accumulate, (char*)workspace, (hipStream_t)stream, wt ? wt->md : nullptr);
     if (mg_conv_rowdot_kq(g) && aligned16(x) && aligned16(workspace)) {
         probe_begin((hipStream_t)stream);
         const int rc = mg_conv_rowdot_wgrad(g, x, dy, dw, dbias, accumulate, workspace, workspace_bytes, stream);

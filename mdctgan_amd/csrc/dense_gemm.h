@@ -27,6 +27,8 @@ struct DgArgs {
     int lda, ldb;           // DG_KC: elements between consecutive rows; DG_RC: elements between consecutive k
     long long sa, sb, sc;   // elements between consecutive positions
     int P, tiles_m, tiles_n, splits, cps;   // cps: 32-deep chunks per split
+    int ldc;                // dgemm32g: elements between consecutive rows of C (0: N); split-K slabs stay [M][N]
+    int kb;                 // dgemm32g: rows a row-contiguous B really has (0: K) -- k rows behind it read as zeros
 };
 
 __device__ __forceinline__ float4 dg_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -339,6 +341,90 @@ __device__ __forceinline__ void dg_chunk_g(const float* As, const float* Bs, f32
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// float32 GEMM chunk on the bf16 MFMA pipe ("3 x bf16"): v_mfma_f32_32x32x2_f32 runs at 1/16 of the rate of
+// v_mfma_f32_32x32x16_bf16, so a float32 product is formed from bf16 pieces instead.  x = hi + mid + lo with hi =
+// bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (round-to-nearest-even; both subtractions are exact in float32) is an
+// EXACT decomposition of a normal float32: |x - hi| <= 2^-8 ulp_exp, |x - hi - mid| <= 2^-16, and what is left is a
+// multiple of the float32 ulp below 2^7 ulps, i.e. fits bf16's 8-bit significand.  Every bf16 x bf16 product is exact in
+// float32 (16 bits), so a.b = sum of the 9 piece products exactly; the kernel issues 8 of them and drops lo.lo (<= 2^-32
+// of |a||b|, far below the 2^-24 of the float32 accumulation both forms share).  Accumulation is the MFMA's float32
+// accumulator, rounded once per 16 k and product group (9 roundings per 16 k against 8 for the float32 instruction).
+// 8 x 32-cycle MFMAs per 32x32x16 block instead of 8 x 64-cycle ones: twice the float32 pipe's rate at float32 accuracy;
+// the split costs ~5.5 VALU operations per loaded operand element, issued in the MFMAs' shadow.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 dg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned dg_u32x4 __attribute__((ext_vector_type(4)));
+struct DgSplit { dg_u32x4 hi, mid, lo; };
+__device__ __forceinline__ unsigned dg_cvt_pk_bf16(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void dg_split8(const float (&x)[8], DgSplit& o) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float x0 = x[2 * j], x1 = x[2 * j + 1];
+        const unsigned h = dg_cvt_pk_bf16(x0, x1);
+        const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+        const unsigned m = dg_cvt_pk_bf16(r0, r1);
+        const float q0 = r0 - __uint_as_float(m << 16), q1 = r1 - __uint_as_float(m & 0xffff0000u);
+        o.hi[j] = h;
+        o.mid[j] = m;
+        o.lo[j] = dg_cvt_pk_bf16(q0, q1);
+    }
+}
+__device__ __forceinline__ f32x16 dg_mfma_bf16(dg_u32x4 a, dg_u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dg_bf16x8, a), __builtin_bit_cast(dg_bf16x8, b), c, 0, 0, 0);
+}
+template <int MB, int NB, int ALAY, int BLAY, int BM, int BN>
+__device__ __forceinline__ void dg_chunk_b8(const float* As, const float* Bs, f32x16 (&acc)[MB][NB], int wm0, int wn0, int lane) {
+    const int r = lane & 31, kh = lane >> 5;
+    auto load8 = [&](const float* S, int lay, int R, int row, int s2, float (&x)[8]) {
+        if (lay == DG_KC) {
+            const int sw = (row >> 1) & 7;
+            const float4 t0 = dg_ld4(S + row * DG_BK + 4 * ((4 * s2 + 2 * kh) ^ sw));
+            const float4 t1 = dg_ld4(S + row * DG_BK + 4 * ((4 * s2 + 2 * kh + 1) ^ sw));
+            x[0] = t0.x; x[1] = t0.y; x[2] = t0.z; x[3] = t0.w; x[4] = t1.x; x[5] = t1.y; x[6] = t1.z; x[7] = t1.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = S[(16 * s2 + 8 * kh + j) * R + row];
+        }
+    };
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        DgSplit a[MB], b[NB];
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) {
+            float x[8];
+            load8(As, ALAY, BM, wm0 + 32 * mi + r, s2, x);
+            dg_split8(x, a[mi]);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni) {
+            float x[8];
+            load8(Bs, BLAY, BN, wn0 + 32 * ni + r, s2, x);
+            dg_split8(x, b[ni]);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NB; ++ni) {
+                f32x16 c = acc[mi][ni];
+                c = dg_mfma_bf16(a[mi].lo, b[ni].mid, c);       // small terms first
+                c = dg_mfma_bf16(a[mi].mid, b[ni].lo, c);
+                c = dg_mfma_bf16(a[mi].lo, b[ni].hi, c);
+                c = dg_mfma_bf16(a[mi].hi, b[ni].lo, c);
+                c = dg_mfma_bf16(a[mi].mid, b[ni].mid, c);
+                c = dg_mfma_bf16(a[mi].mid, b[ni].hi, c);
+                c = dg_mfma_bf16(a[mi].hi, b[ni].mid, c);
+                c = dg_mfma_bf16(a[mi].hi, b[ni].hi, c);
+                acc[mi][ni] = c;
+            }
+    }
+}
+
 typedef int dg_v4i __attribute__((ext_vector_type(4)));
 
 // One LDS-DMA piece: 64 lanes x 16 bytes from buffer `rsrc` at byte offset voff (per lane) + soff (scalar) to LDS byte
@@ -359,7 +445,7 @@ __device__ __forceinline__ void dg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(
 
 // PZ: the batch count as a compile-time constant (16: F(2x2,3x3); 25: F(2x2,4x4) / F(4x4,2x2); 0: read g.P) -- one symbol per
 // transform family, so a profile separates the 1024-channel residual trunk from the ladder's 5x5-tile layers.
-template <int BM, int BN, int WGM, int WGN, int ALAY, int BLAY, int NBUF = 2, int PZ = 0>
+template <int BM, int BN, int WGM, int WGN, int ALAY, int BLAY, int NBUF = 2, int PZ = 0, int EMU = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void dgemm32g_kernel(DgArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)     // the buffer-resource type does not exist in the host pass (which only needs the stub)
     using Cfg = DgCfgG<BM, BN, WGM, WGN, ALAY, BLAY, NBUF>;
@@ -396,7 +482,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void dgemm32g_kernel(DgArgs g) {
         return r;
     };
     const dg_v4i ra = make_rsrc(g.A + (size_t)z * g.sa, (unsigned)((ALAY == DG_KC ? g.M : g.K) * g.lda) * 4u);
-    const dg_v4i rb = make_rsrc(g.B + (size_t)z * g.sb, (unsigned)((BLAY == DG_KC ? g.N : g.K) * g.ldb) * 4u);
+    const dg_v4i rb = make_rsrc(g.B + (size_t)z * g.sb, (unsigned)((BLAY == DG_KC ? g.N : (g.kb ? g.kb : g.K)) * g.ldb) * 4u);
     unsigned va[PA], vb[PB];
 #pragma unroll
     for (int i = 0; i < PA; ++i) va[i] = dg_piece_voffset<BM, ALAY>(wave * PA + i, lane, m0, g.M, g.lda);
@@ -433,7 +519,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void dgemm32g_kernel(DgArgs g) {
             __builtin_amdgcn_s_barrier();      // ... everybody's have, and buffer cur ^ 1 is no longer being read
             __builtin_amdgcn_sched_barrier(0);
             if (c + 1 < c_end) issue(c + 1, cur ^ 1);
-            dg_chunk_g<MB, NB, ALAY, BLAY, BM, BN>(As0 + cur * Cfg::ASZ, Bs0 + cur * Cfg::BSZ, acc, wm0, wn0, lane);
+            if constexpr (EMU) dg_chunk_b8<MB, NB, ALAY, BLAY, BM, BN>(As0 + cur * Cfg::ASZ, Bs0 + cur * Cfg::BSZ, acc, wm0, wn0, lane);
+            else dg_chunk_g<MB, NB, ALAY, BLAY, BM, BN>(As0 + cur * Cfg::ASZ, Bs0 + cur * Cfg::BSZ, acc, wm0, wn0, lane);
         }
     } else {
         // three buffers: two chunks in flight, the DMA of chunk c + 1 stays outstanding across the barrier of chunk c
@@ -447,21 +534,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void dgemm32g_kernel(DgArgs g) {
             __builtin_amdgcn_sched_barrier(0);
             const int nxt2 = cur == 0 ? 2 : cur - 1;
             if (c + 2 < c_end) issue(c + 2, nxt2);
-            dg_chunk_g<MB, NB, ALAY, BLAY, BM, BN>(As0 + cur * Cfg::ASZ, Bs0 + cur * Cfg::BSZ, acc, wm0, wn0, lane);
+            if constexpr (EMU) dg_chunk_b8<MB, NB, ALAY, BLAY, BM, BN>(As0 + cur * Cfg::ASZ, Bs0 + cur * Cfg::BSZ, acc, wm0, wn0, lane);
+            else dg_chunk_g<MB, NB, ALAY, BLAY, BM, BN>(As0 + cur * Cfg::ASZ, Bs0 + cur * Cfg::BSZ, acc, wm0, wn0, lane);
             cur = cur == 2 ? 0 : cur + 1;
         }
     }
 
     float* o = g.part ? g.part + ((size_t)sp * nz + z) * ((size_t)g.M * g.N) : g.C + (size_t)z * g.sc;
+    const size_t ldc = (g.part || !g.ldc) ? (size_t)g.N : (size_t)g.ldc;
     if (m0 + BM <= g.M && n0 + BN <= g.N) {        // interior tile (wave-uniform): no per-element predicates
-        float* ow = o + (size_t)(m0 + wm0 + 4 * (lane >> 5)) * g.N + n0 + wn0 + (lane & 31);
+        float* ow = o + (size_t)(m0 + wm0 + 4 * (lane >> 5)) * ldc + n0 + wn0 + (lane & 31);
 #pragma unroll
         for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NB; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    ow[(size_t)(32 * mi + (r & 3) + 8 * (r >> 2)) * g.N + 32 * ni] = acc[mi][ni][r];
+                    ow[(size_t)(32 * mi + (r & 3) + 8 * (r >> 2)) * ldc + 32 * ni] = acc[mi][ni][r];
     } else {
 #pragma unroll
         for (int mi = 0; mi < MB; ++mi)
@@ -471,14 +560,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void dgemm32g_kernel(DgArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm0 + 32 * mi + mfma32_row(r, lane);
-                    if (row < g.M && col < g.N) o[(size_t)row * g.N + col] = acc[mi][ni][r];
+                    if (row < g.M && col < g.N) o[(size_t)row * ldc + col] = acc[mi][ni][r];
                 }
             }
     }
 #endif
 }
 
-template <int BM, int BN, int WGM, int WGN, int ALAY, int BLAY, int NBUF = 2, int PZ = 0>
+template <int BM, int BN, int WGM, int WGN, int ALAY, int BLAY, int NBUF = 2, int PZ = 0, int EMU = 0>
 inline void dgemm32g_launch(const DgArgs& a0, hipStream_t st) {
     using Cfg = DgCfgG<BM, BN, WGM, WGN, ALAY, BLAY, NBUF>;
     DgArgs a = a0;
@@ -486,10 +575,10 @@ inline void dgemm32g_launch(const DgArgs& a0, hipStream_t st) {
     a.tiles_n = (a.N + BN - 1) / BN;
     static bool once = false;
     if (!once) {
-        hipFuncSetAttribute((const void*)dgemm32g_kernel<BM, BN, WGM, WGN, ALAY, BLAY, NBUF, PZ>,
+        hipFuncSetAttribute((const void*)dgemm32g_kernel<BM, BN, WGM, WGN, ALAY, BLAY, NBUF, PZ, EMU>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
         once = true;
     }
     const unsigned grid = (unsigned)((long long)a.tiles_m * a.tiles_n * a.splits * a.P);
-    mg_launch(dgemm32g_kernel<BM, BN, WGM, WGN, ALAY, BLAY, NBUF, PZ>, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, a);
+    mg_launch(dgemm32g_kernel<BM, BN, WGM, WGN, ALAY, BLAY, NBUF, PZ, EMU>, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, a);
 }

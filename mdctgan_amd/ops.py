@@ -70,15 +70,17 @@ def wino_tile_buffers(g: ConvGeom, device, want_v=True, want_md=True):
 
 
 def tiles_are_casts(g: ConvGeom) -> bool:
-    """True for the autocast layers on the float16 implicit GEMMs (csrc/conv_dma.h): their v / md "tiles" are plain float16
-    copies of x / dy, each usable on its own (Winograd images only work as a pair)."""
-    if g.precision != _lib.PRECISION_F16:
-        return False
-    key = (g.B, g.H, g.W, g.Ci, g.Co, g.KH, g.KW, g.stride, g.pad, g.reflect)
+    """True for layers whose v / md "tiles" are usable on their own (Winograd images only work as a pair): the autocast
+    layers on the float16 implicit GEMMs (csrc/conv_dma.h: plain float16 copies of x / dy) and the single-output-channel
+    tap GEMMs (csrc/conv_co1.h: md = the scattered dy)."""
+    key = (g.B, g.H, g.W, g.Ci, g.Co, g.KH, g.KW, g.stride, g.pad, g.reflect, g.precision)
     hit = _CASTS.get(key)
     if hit is None:
         name = plan_name(2, g)
-        hit = _CASTS[key] = name.startswith("conv_wgrad_dma_kernel") and name.endswith("true>")
+        half = g.precision == _lib.PRECISION_F16 and name.startswith("conv_wgrad_dma_kernel") and name.endswith("true>")
+        # ... and the single-output-channel tap GEMMs (csrc/conv_co1.h): md is the scattered dy, there is no v
+        co1 = g.Co == 1 and wino_weights_bytes(g) == 64 * g.Ci * 4
+        hit = _CASTS[key] = half or co1
     return hit
 
 

@@ -51,6 +51,7 @@ struct Variant { const char* name; int bm, bn; void (*launch)(const DgArgs&, hip
 #define V(BM, BN, WM, WN, AL, BL) {#BM "x" #BN "/" #WM "x" #WN, BM, BN, dgemm32_launch<BM, BN, WM, WN, AL, BL>}
 #define G(BM, BN, WM, WN, AL, BL) {#BM "x" #BN "/" #WM "x" #WN " glds", BM, BN, dgemm32g_launch<BM, BN, WM, WN, AL, BL>}
 #define G3(BM, BN, WM, WN, AL, BL) {#BM "x" #BN "/" #WM "x" #WN " glds3", BM, BN, dgemm32g_launch<BM, BN, WM, WN, AL, BL, 3>}
+#define GE(BM, BN, WM, WN, AL, BL) {#BM "x" #BN "/" #WM "x" #WN " glds b8", BM, BN, dgemm32g_launch<BM, BN, WM, WN, AL, BL, 2, 0, 1>}
 #define VSET(AL, BL) { V(64, 64, 2, 2, AL, BL), V(128, 64, 2, 2, AL, BL), V(64, 128, 2, 2, AL, BL), V(128, 128, 2, 2, AL, BL), \
                        V(128, 128, 4, 2, AL, BL), V(128, 128, 2, 4, AL, BL), V(128, 64, 4, 2, AL, BL), V(64, 128, 2, 4, AL, BL), \
                        V(256, 64, 4, 2, AL, BL), V(64, 256, 2, 4, AL, BL), V(256, 128, 4, 2, AL, BL), V(128, 256, 2, 4, AL, BL), \
@@ -58,7 +59,8 @@ struct Variant { const char* name; int bm, bn; void (*launch)(const DgArgs&, hip
                        G(128, 128, 4, 2, AL, BL), G(128, 128, 2, 4, AL, BL), G(256, 128, 4, 2, AL, BL), G(128, 256, 2, 4, AL, BL), \
                        G(64, 256, 2, 4, AL, BL), G(256, 64, 4, 2, AL, BL), \
                        G3(64, 64, 2, 2, AL, BL), G3(128, 64, 2, 2, AL, BL), G3(64, 128, 2, 2, AL, BL), G3(128, 128, 2, 2, AL, BL), \
-                       G3(128, 128, 4, 2, AL, BL), G3(128, 128, 2, 4, AL, BL), G3(64, 256, 2, 4, AL, BL), G3(256, 64, 4, 2, AL, BL) }
+                       G3(128, 128, 4, 2, AL, BL), G3(128, 128, 2, 4, AL, BL), G3(64, 256, 2, 4, AL, BL), G3(256, 64, 4, 2, AL, BL), \
+                       GE(64, 64, 2, 2, AL, BL), GE(128, 64, 2, 2, AL, BL), GE(64, 128, 2, 2, AL, BL), GE(128, 128, 2, 2, AL, BL), GE(128, 128, 4, 2, AL, BL), GE(256, 128, 4, 2, AL, BL) }
 const Variant v_kk[] = VSET(DG_KC, DG_KC);
 const Variant v_kr[] = VSET(DG_KC, DG_RC);
 const Variant v_rr[] = VSET(DG_RC, DG_RC);
@@ -119,7 +121,7 @@ int main(int argc, char** argv) {
         ref_gemm_kernel<<<(unsigned)((nc + 255) / 256), 256, 0, st>>>(gr, pr.alay, pr.blay, R);
         hipStreamSynchronize(st);
         const Variant* vs = pr.alay == DG_RC ? v_rr : (pr.blay == DG_RC ? v_kr : v_kk);
-        const int nv = 30;
+        const int nv = 36;
         const double flops = 2.0 * pr.P * pr.M * (double)pr.N * pr.K;
         printf("== %s  P=%d M=%d N=%d K=%d  %.2f GFLOP (peak-time %.1f us)\n", pr.name, pr.P, pr.M, pr.N, pr.K, flops / 1e9,
                flops / 157.3e12 * 1e6);

@@ -28,6 +28,10 @@ CONV_CASES = [
     ("d4x4_s2", 2, 16, 17, 33, 32, 4, 2, 2, False),
     ("d4x4_s1", 2, 32, 5, 9, 64, 4, 1, 2, False),
     ("d4x4_s1_co1", 2, 64, 6, 10, 1, 4, 1, 2, False),
+    # single-output-channel layers with Ci % 64 == 0: tap GEMM + gather / scatter (csrc/conv_co1.h)
+    ("co1_head7x7_reflect_64", 2, 64, 20, 36, 1, 7, 1, 3, True),
+    ("co1_4x4_s2_zero", 2, 64, 10, 14, 1, 4, 2, 2, False),
+    ("co1_3x3_reflect_128", 1, 128, 6, 10, 1, 3, 1, 1, True),
     ("conv5x5_p2", 1, 16, 12, 20, 24, 5, 1, 2, False),
     ("conv5x5_p1", 1, 16, 12, 20, 24, 5, 1, 1, False),
     ("conv3x3_p2", 1, 24, 12, 20, 16, 3, 1, 2, False),
@@ -112,6 +116,19 @@ def test_conv_fwd_dgrad_wgrad(case, small_wino42):
     ops.conv_wgrad(g, xd, gyd, dw, db, accumulate=True)
     assert rel_err(dw, 2 * nhwc(w.grad)) < 3e-5
     assert rel_err(db, 2 * b.grad) < 3e-5
+    if name.startswith("co1_") or name == "d4x4_s1_co1":
+        # tap GEMM (csrc/conv_co1.h): the padded weights (u) and the scattered dy (md) may be held by the caller -- same bits
+        assert ops.plan_name(0, g).startswith("dgemm32g_kernel<64, 128") and ops.tiles_are_casts(g)
+        u = ops.wino_weights(g, wd)
+        v, md = ops.wino_tile_buffers(g, xd.device)
+        assert u is not None and u.numel() == 64 * Ci and v is None and md is not None
+        assert torch.equal(ops.conv_fwd(g, xd, wd, bd, u=u), yd)
+        assert torch.equal(ops.conv_dgrad(g, gyd, wd, u=u, md_out=md), dxd)
+        dw1, dw2 = torch.empty_like(dw), torch.empty_like(dw)
+        ops.conv_wgrad(g, xd, gyd, dw1, None)
+        ops.conv_wgrad(g, xd, gyd, dw2, None, md=md)
+        assert torch.equal(dw1, dw2)
+        assert torch.equal(ops.conv_fwd(g, xd, wd, bd, act=ops.ACT_TANH), torch.tanh(yd))
 
 
 def test_conv_fwd_fused_activations():
