@@ -422,9 +422,21 @@ def main():
             out["cpu_baseline"] = cpu_baseline_train(os.cpu_count() or 1)
         if world == 1 and not args.no_cpu_baseline and args.mode == "infer":
             out["cpu_baseline"] = cpu_baseline_infer(os.cpu_count() or 1, lr_rate)
-        print(json.dumps(out), flush=True)
+    # the JSON line must be the LAST thing on stdout: RCCL prints a version banner through C stdio, which a pipe only sees
+    # when the library's buffer is flushed (normally at exit, i.e. after a line printed here)
     if use_ddp:
+        dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if rank == 0:
+        if world > 1:
+            time.sleep(1.0)          # let the other ranks' processes drain their stdio first
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
