@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(CdArgs g) {
     constexpr unsigned ES = CdElem<HALF>::ES;
     constexpr int CK = CdElem<HALF>::CK;
     constexpr int MB = Cfg::MB, NB = Cfg::NB, PA = Cfg::PA, PB = Cfg::PB;
-    static_assert(BN == 64, "a column tile must lie inside one tap (Ci % 64 == 0)");
+    static_assert(BN == 64 || BN == 128, "a column tile must lie inside one tap (Ci % BN == 0; the planner checks it)");
     extern __shared__ __attribute__((aligned(1024))) float cd_smem[];
     float* As0 = cd_smem;
     float* Bs0 = cd_smem + 2 * Cfg::ASZ;
@@ -286,8 +286,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(CdArgs g) {
     const unsigned lds_a0 = (unsigned)(size_t)(dg_lds_ptr)As0 + (unsigned)(wave * PA) * 1024u;
     const unsigned lds_b0 = (unsigned)(size_t)(dg_lds_ptr)Bs0 + (unsigned)(wave * PB) * 1024u;
     auto issue = [&](int c, int buf) {
-        const unsigned la = lds_a0 + (unsigned)buf * (unsigned)(Cfg::ASZ * 4), lb = lds_b0 + (unsigned)buf * (unsigned)(Cfg::BSZ * 4);
-        const unsigned sa_off = (unsigned)c * (unsigned)CK * (unsigned)g.Co * ES;
+        // wave-uniform values; readfirstlane keeps them in SGPRs under the register pressure of the 128-column instances
+        const unsigned la = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_a0 + (unsigned)buf * (unsigned)(Cfg::ASZ * 4)));
+        const unsigned lb = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_b0 + (unsigned)buf * (unsigned)(Cfg::BSZ * 4)));
+        const unsigned sa_off = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)c * (unsigned)CK * (unsigned)g.Co * ES));
 #pragma unroll
         for (int i = 0; i < PA; ++i) dg_dma16(va[i], ra, la + 1024u * i, sa_off);
 #pragma unroll
@@ -509,7 +511,7 @@ struct CdPlan { int bm, bn, splits, cps; };
 // the dense plan's cost model (dense_plan above) on the convolution's GEMM view, DMA instances only.  ck = K depth of a chunk
 // (32 float32 / 64 float16); the float16 instances are priced at 4x the float32 MFMA rate (what the staging sustains) with a
 // proportionally larger fixed cost per workgroup.
-CdPlan conv_dma_plan(long long M, int N, int chunks, bool wgrad, int ck) {
+CdPlan conv_dma_plan(long long M, int N, int chunks, bool wgrad, int ck, int tap_cols = 0) {   // tap_cols: Ci of a weight gradient
     struct Cand { int bm, bn; double eff; };
     static const Cand cands[4] = {{64, 64, 0.83}, {64, 128, 0.885}, {128, 64, 0.855}, {128, 128, 0.91}};
     static const int split_opts[12] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
@@ -522,7 +524,7 @@ CdPlan conv_dma_plan(long long M, int N, int chunks, bool wgrad, int ck) {
     }
     double best = 1e300;
     for (const Cand& c : cands) {
-        if (N % c.bn != 0 || (wgrad && c.bn != 64)) continue;
+        if (N % c.bn != 0 || (wgrad && tap_cols % c.bn != 0)) continue;      // a weight-gradient column tile lies inside one tap
         if (f_bm && (c.bm != f_bm || c.bn != f_bn)) continue;
         const long long w = ((M + c.bm - 1) / c.bm) * (long long)(N / c.bn);
         const double tile_us = 2.0 * c.bm * c.bn * ck / rate * 1e6 / c.eff;
@@ -548,7 +550,7 @@ inline CdPlan conv_dma_fwd_plan(const mg_conv_geom* g) {
 inline CdPlan conv_dma_wgrad_plan(const mg_conv_geom* g) {
     const long long Mpx = (long long)g->B * g->OH * g->OW;
     const int ck = conv_dma_ck(g);
-    return conv_dma_plan(g->Co, g->KH * g->KW * g->Ci, (int)((Mpx + ck - 1) / ck), true, ck);
+    return conv_dma_plan(g->Co, g->KH * g->KW * g->Ci, (int)((Mpx + ck - 1) / ck), true, ck, g->Ci);
 }
 template <typename KernelT>
 inline void cd_launch(KernelT kern, size_t lds, dim3 grid, const CdArgs& a, hipStream_t st) {
@@ -587,13 +589,14 @@ void conv_dma_wgrad_launch(const mg_conv_geom* g, const CdPlan& p, const void* x
     a.tiles_m = (g->Co + p.bm - 1) / p.bm; a.tiles_n = g->KH * g->KW * g->Ci / p.bn; a.splits = p.splits; a.cps = p.cps;
     const dim3 grid((unsigned)((long long)a.tiles_m * a.tiles_n * a.splits));
     const bool half = conv_dma_half(g);
-    if (p.bm == 128) {
-        if (half) cd_launch(conv_wgrad_dma_kernel<128, 64, true>, DgCfgG<128, 64, 2, 2, 1, 1, 2>::LDS_BYTES, grid, a, st);
-        else cd_launch(conv_wgrad_dma_kernel<128, 64, false>, DgCfgG<128, 64, 2, 2, 1, 1, 2>::LDS_BYTES, grid, a, st);
-    } else {
-        if (half) cd_launch(conv_wgrad_dma_kernel<64, 64, true>, DgCfgG<64, 64, 2, 2, 1, 1, 2>::LDS_BYTES, grid, a, st);
-        else cd_launch(conv_wgrad_dma_kernel<64, 64, false>, DgCfgG<64, 64, 2, 2, 1, 1, 2>::LDS_BYTES, grid, a, st);
-    }
+    auto go = [&](auto kh, auto kf, size_t lds) {
+        if (half) cd_launch(kh, lds, grid, a, st);
+        else cd_launch(kf, lds, grid, a, st);
+    };
+    if (p.bm == 128 && p.bn == 128) go(conv_wgrad_dma_kernel<128, 128, true>, conv_wgrad_dma_kernel<128, 128, false>, DgCfgG<128, 128, 2, 2, 1, 1, 2>::LDS_BYTES);
+    else if (p.bm == 64 && p.bn == 128) go(conv_wgrad_dma_kernel<64, 128, true>, conv_wgrad_dma_kernel<64, 128, false>, DgCfgG<64, 128, 2, 2, 1, 1, 2>::LDS_BYTES);
+    else if (p.bm == 128) go(conv_wgrad_dma_kernel<128, 64, true>, conv_wgrad_dma_kernel<128, 64, false>, DgCfgG<128, 64, 2, 2, 1, 1, 2>::LDS_BYTES);
+    else go(conv_wgrad_dma_kernel<64, 64, true>, conv_wgrad_dma_kernel<64, 64, false>, DgCfgG<64, 64, 2, 2, 1, 1, 2>::LDS_BYTES);
 }
 
 // data gradient: the plan is made for the heaviest parity class (M = pixels of one class, all taps / stride^2 of the chunks)
