@@ -1,5 +1,8 @@
 // Single-output-channel convolutions (the generator's 7x7 tanh head, networks.py:244,352; the PatchGAN output layer,
-// networks.py:668-670) as a TAP GEMM on the LDS-DMA kernels (dense_gemm.h) -- float32, Ci % 64 == 0, KH * KW <= 64.
+// networks.py:668-670) as a TAP GEMM on the LDS-DMA kernels (dense_gemm.h) -- Ci % 64 == 0, KH * KW <= 64.
+// MG_PRECISION_F16 (autocast) runs the SAME float32 GEMMs on operands rounded to float16 values first (x by a rounding
+// pass, the weights while they are padded, dy while it is scattered): a product of two float16 values is exact in float32,
+// so this is the arithmetic of the float16 MFMA with float32 accumulation; y and dx are rounded through float16.
 // As a convolution GEMM such a layer has N = 1: 63/64 of an MFMA tile idle, which is why it ran on VALU dot products
 // (conv_rowdot.hip: every input element re-read once per tap).  Contract over the channels FIRST instead:
 //     Zt[tap][p]  = sum_ci W[tap][ci] * X[p][ci]            p = every INPUT pixel   (GEMM 64 x pixels x Ci, W zero-padded to 64 taps)
@@ -18,7 +21,7 @@ constexpr int CO1_TAPS = 64;       // tap rows of the padded weight matrix / Zt 
 inline bool co1_gemm_ok(const mg_conv_geom* g) {
     static const bool off = getenv("MG_NO_CO1_GEMM") != nullptr;
     const long long Mp = (long long)g->B * g->H * g->W;
-    return !off && g->precision == MG_PRECISION_F32 && g->Co == 1 && g->KH * g->KW <= CO1_TAPS && g->Ci % 64 == 0 && Mp % 4 == 0 &&
+    return !off && (g->precision == MG_PRECISION_F32 || g->precision == MG_PRECISION_F16) && g->Co == 1 && g->KH * g->KW <= CO1_TAPS && g->Ci % 64 == 0 && Mp % 4 == 0 &&
            Mp * CO1_TAPS < (1LL << 29) && Mp * g->Ci < (1LL << 29);
 }
 inline long long co1_ldz(const mg_conv_geom* g) { return ((long long)g->B * g->H * g->W + 31) / 32 * 32; }
@@ -31,21 +34,33 @@ inline int co1_wgrad_splits(const mg_conv_geom* g) {
     if (s > chunks / 4) s = chunks / 4;
     return s < 1 ? 1 : s;
 }
-inline size_t co1_fwd_ws(const mg_conv_geom* g) { return co1_wp_bytes(g) + co1_zt_bytes(g) + 256; }
+inline bool co1_half(const mg_conv_geom* g) { return g->precision == MG_PRECISION_F16; }
+// autocast: x rounded to float16 values (float32 storage), made by the forward call and kept for the weight gradient
+inline size_t co1_xr_bytes(const mg_conv_geom* g) { return co1_half(g) ? co1_al((size_t)g->B * g->H * g->W * g->Ci * 4) : 0; }
+inline size_t co1_fwd_ws(const mg_conv_geom* g) { return co1_wp_bytes(g) + co1_zt_bytes(g) + co1_xr_bytes(g) + 256; }
 inline size_t co1_dgrad_ws(const mg_conv_geom* g) { return co1_wp_bytes(g) + co1_zt_bytes(g) + 256; }
 inline size_t co1_wgrad_ws(const mg_conv_geom* g) {
-    return co1_zt_bytes(g) + co1_al((size_t)co1_wgrad_splits(g) * CO1_TAPS * g->Ci * 4) + 1024 + 256;      // + dbias partials
+    return co1_zt_bytes(g) + co1_al((size_t)co1_wgrad_splits(g) * CO1_TAPS * g->Ci * 4) + 1024 + co1_xr_bytes(g) + 256;   // + dbias partials
 }
 
 // wp [64][Ci]: the OHWI weights of the single output channel are already [tap][ci]; rows >= taps are zero
-__global__ void co1_pad_w_kernel(const float* __restrict__ w, int n_real, int n_all, float* __restrict__ wp) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += gridDim.x * blockDim.x) wp[i] = i < n_real ? w[i] : 0.0f;
+__global__ void co1_pad_w_kernel(const float* __restrict__ w, int n_real, int n_all, float* __restrict__ wp, int half) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += gridDim.x * blockDim.x)
+        wp[i] = i < n_real ? (half ? round_h(w[i]) : w[i]) : 0.0f;
+}
+// xr = x rounded through float16 (n4 float4s)
+__global__ void co1_round_kernel(const float* __restrict__ x, size_t n4, float* __restrict__ xr) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = ld4(x + 4 * i);
+        v.x = round_h(v.x); v.y = round_h(v.y); v.z = round_h(v.z); v.w = round_h(v.w);
+        *reinterpret_cast<float4*>(xr + 4 * i) = v;
+    }
 }
 
 // y[o] = act(bias + sum over taps of Zt[tap][source pixel]): one thread per output pixel, consecutive threads = consecutive
 // ox, so every tap's read is a coalesced row segment of Zt
 __global__ void co1_gather_kernel(Geom g, const float* __restrict__ zt, long long ldz, const float* __restrict__ bias, int act,
-                                  float* __restrict__ y) {
+                                  float* __restrict__ y, int half) {
     const long long n = (long long)g.B * g.OH * g.OW;
     for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (long long)gridDim.x * blockDim.x) {
         const int ox = (int)(o % g.OW);
@@ -64,7 +79,8 @@ __global__ void co1_gather_kernel(Geom g, const float* __restrict__ zt, long lon
                 s += zrow[(long long)(ky * g.KW + kx) * ldz + ix];
             }
         }
-        y[o] = apply_act(s, act);
+        s = apply_act(s, act);
+        y[o] = half ? round_h(s) : s;
     }
 }
 
@@ -92,7 +108,8 @@ __device__ __forceinline__ int co1_sources(int i, int k, int n, int on, int s, i
 // border); reflection adds the aliased rows / columns near the border.  Rows [taps, 64) and columns [Mp, ldz) are zeroed by
 // co1_zero_pad_kernel (they meet zero weights / out-of-range x rows in the GEMMs, and 0 * garbage must not be NaN).
 template <int S>
-__global__ __launch_bounds__(256) void co1_scatter_kernel(Geom g, const float* __restrict__ dy, long long ldz, float* __restrict__ gt) {
+__global__ __launch_bounds__(256) void co1_scatter_kernel(Geom g, const float* __restrict__ dy, long long ldz, float* __restrict__ gt,
+                                                          int half) {
     const int tap = blockIdx.y, row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;     // row = b * H + iy
     if (row >= g.B * g.H) return;
     const int b = row / g.H, iy = row - b * g.H;
@@ -108,12 +125,15 @@ __global__ __launch_bounds__(256) void co1_scatter_kernel(Geom g, const float* _
             const bool interior = !g.reflect || (ix > g.p && ix < g.W - 1 - g.p);
             if (ny == 1 && interior) {          // the common case: exactly one source
                 const int t = ix + g.p - kx;
-                if (t >= 0 && t % S == 0 && t / S < g.OW) v = drow[t / S];
+                if (t >= 0 && t % S == 0 && t / S < g.OW) v = half ? round_h(drow[t / S]) : drow[t / S];
             } else {
                 int oxs[3];
                 const int nx = co1_sources(ix, kx, g.W, g.OW, S, g.p, g.reflect, oxs);
                 for (int a = 0; a < ny; ++a)
-                    for (int c = 0; c < nx; ++c) v += dyb[(long long)oys[a] * g.OW + oxs[c]];
+                    for (int c = 0; c < nx; ++c) {
+                        const float d = dyb[(long long)oys[a] * g.OW + oxs[c]];
+                        v += half ? round_h(d) : d;
+                    }
             }
         }
         out[ix] = v;
@@ -204,25 +224,36 @@ inline void co1_gemm_dx(const mg_conv_geom* g, const float* gt, const float* wp,
     a.A = gt; a.B = wp; a.C = dx; a.part = nullptr;
     a.M = (int)((long long)g->B * g->H * g->W); a.N = g->Ci; a.K = CO1_TAPS; a.lda = (int)co1_ldz(g); a.ldb = g->Ci;
     a.P = 1; a.splits = 1; a.cps = 1 << 28;
+    a.round_f16 = co1_half(g) ? 1 : 0;
     dgemm32g_launch<128, 64, 2, 2, DG_RC, DG_RC>(a, st);
 }
 
 inline void co1_pad_w(const mg_conv_geom* g, const float* w, float* wp, hipStream_t st) {
-    hipLaunchKernelGGL(co1_pad_w_kernel, dim3(co1_grid(CO1_TAPS * g->Ci)), dim3(256), 0, st, w, g->KH * g->KW * g->Ci, CO1_TAPS * g->Ci, wp);
+    hipLaunchKernelGGL(co1_pad_w_kernel, dim3(co1_grid(CO1_TAPS * g->Ci)), dim3(256), 0, st, w, g->KH * g->KW * g->Ci, CO1_TAPS * g->Ci, wp,
+                       (int)co1_half(g));
 }
 // u: the caller's padded weights (mg_conv_wino_prepare) or null; md: the caller's Gt buffer (data gradient -> weight gradient)
+inline void co1_round_x(const mg_conv_geom* g, const float* x, float* xr, hipStream_t st) {
+    const size_t n4 = (size_t)g->B * g->H * g->W * g->Ci / 4;
+    hipLaunchKernelGGL(co1_round_kernel, dim3(co1_grid((long long)n4)), dim3(256), 0, st, x, n4, xr);
+}
 int co1_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act, char* ws, hipStream_t st,
-            const float* u) {
+            const float* u, float* v) {
     float* wp = (float*)ws;
     float* zt = (float*)(ws + co1_wp_bytes(g));
     if (u) wp = const_cast<float*>(u);
     else co1_pad_w(g, w, wp, st);
+    if (co1_half(g)) {          // the rounded x: into the caller's buffer (kept for the weight gradient) or the workspace
+        float* xr = v ? v : (float*)(ws + co1_wp_bytes(g) + co1_zt_bytes(g));
+        co1_round_x(g, x, xr, st);
+        x = xr;
+    }
     probe_begin(st);
     co1_gemm_z(g, wp, x, zt, st);
     probe_end(st);
     const Geom gg{g->B, g->H, g->W, g->Ci, g->OH, g->OW, g->Co, g->KH, g->KW, g->stride, g->pad, g->reflect};
     hipLaunchKernelGGL(co1_gather_kernel, dim3(co1_grid((long long)g->B * g->OH * g->OW)), dim3(256), 0, st, gg, (const float*)zt,
-                       co1_ldz(g), bias, act, y);
+                       co1_ldz(g), bias, act, y, (int)co1_half(g));
     MG_CHECK_LAUNCH();
     return MG_OK;
 }
@@ -234,8 +265,8 @@ inline void co1_scatter(const mg_conv_geom* g, const float* dy, float* gt, hipSt
     if (taps < CO1_TAPS || ldz > Mp)
         hipLaunchKernelGGL(co1_zero_pad_kernel, dim3(co1_grid((long long)taps * (ldz - Mp) + (long long)(CO1_TAPS - taps) * ldz)), dim3(256),
                            0, st, gt, taps, Mp, ldz);
-    if (g->stride == 1) hipLaunchKernelGGL(co1_scatter_kernel<1>, grid, dim3(256), 0, st, gg, dy, ldz, gt);
-    else hipLaunchKernelGGL(co1_scatter_kernel<2>, grid, dim3(256), 0, st, gg, dy, ldz, gt);
+    if (g->stride == 1) hipLaunchKernelGGL(co1_scatter_kernel<1>, grid, dim3(256), 0, st, gg, dy, ldz, gt, (int)co1_half(g));
+    else hipLaunchKernelGGL(co1_scatter_kernel<2>, grid, dim3(256), 0, st, gg, dy, ldz, gt, (int)co1_half(g));
 }
 int co1_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* dx, char* ws, hipStream_t st, const float* u, float* md) {
     float* wp = (float*)ws;
@@ -250,8 +281,17 @@ int co1_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* dx,
     return MG_OK;
 }
 int co1_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias, int accumulate, char* ws,
-              hipStream_t st, const float* md) {
+              hipStream_t st, const float* v, const float* md) {
     float* gt = md ? const_cast<float*>(md) : (float*)ws;
+    if (co1_half(g)) {
+        if (v) {
+            x = v;
+        } else {
+            float* xr = (float*)(ws + co1_zt_bytes(g) + co1_al((size_t)co1_wgrad_splits(g) * CO1_TAPS * g->Ci * 4) + 1024);
+            co1_round_x(g, x, xr, st);
+            x = xr;
+        }
+    }
     float* slabs = (float*)(ws + co1_zt_bytes(g));
     if (dbias) {
         float* part = (float*)(ws + co1_zt_bytes(g) + co1_al((size_t)co1_wgrad_splits(g) * CO1_TAPS * g->Ci * 4));

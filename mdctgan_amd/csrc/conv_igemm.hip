@@ -2594,7 +2594,7 @@ int mg_conv_wino_prepare(const mg_conv_geom* g, const float* w, float* u, void* 
 
 size_t mg_conv_wino_tiles_bytes(const mg_conv_geom* g, int which) {
     if (!mg_conv_wino_weights_bytes(g) || h16_ok(g)) return 0;
-    if (co1_gemm_ok(g)) return which == 1 ? co1_zt_bytes(g) : 0;       // Gt: made by the data gradient, reused by the weight gradient
+    if (co1_gemm_ok(g)) return which == 1 ? co1_zt_bytes(g) : (which == 0 ? co1_xr_bytes(g) : 0);   // Gt (data gradient -> weight gradient); autocast: the rounded x
     if (conv_dma_h_any(g)) {
         // float16 implicit GEMMs: the "tiles" are the float16 copies of x (forward -> weight gradient) and of dy (data
         // gradient -> weight gradient), so that each tensor is cast once per step
@@ -2644,7 +2644,7 @@ int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const f
         aligned16(workspace) && (!bias || aligned16(bias)))
         return h16_fwd(g, x, w, bias, y, act, (char*)workspace, (hipStream_t)stream, u);
     if (co1_gemm_ok(g) && workspace && workspace_bytes >= co1_fwd_ws(g) && aligned16(x) && aligned16(w) && aligned16(workspace))
-        return co1_fwd(g, x, w, bias, y, act, (char*)workspace, (hipStream_t)stream, u);
+        return co1_fwd(g, x, w, bias, y, act, (char*)workspace, (hipStream_t)stream, u, wt ? wt->v : nullptr);
     if (mg_conv_rowdot_kq(g) && aligned16(x) && aligned16(w)) {
         probe_begin((hipStream_t)stream);
         const int rc = mg_conv_rowdot_fwd(g, x, w, bias, y, act, stream);
@@ -2881,7 +2881,7 @@ int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, floa
     if (!wino_tiles_ok(g, wt)) return MG_ERR_ARG;
     if (workspace_bytes < mg_conv_wgrad_workspace(g) || !workspace) return MG_ERR_ARG;
     if (co1_gemm_ok(g) && aligned16(x) && aligned16(workspace))
-        return co1_wgrad(g, x, dy, dw, dbias, accumulate, (char*)workspace, (hipStream_t)stream, wt ? wt->md : nullptr);
+        return co1_wgrad(g, x, dy, dw, dbias, accumulate, (char*)workspace, (hipStream_t)stream, wt ? wt->v : nullptr, wt ? wt->md : nullptr);
     if (mg_conv_rowdot_kq(g) && aligned16(x) && aligned16(workspace)) {
         probe_begin((hipStream_t)stream);
         const int rc = mg_conv_rowdot_wgrad(g, x, dy, dw, dbias, accumulate, workspace, workspace_bytes, stream);

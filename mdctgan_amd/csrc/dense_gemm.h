@@ -29,6 +29,7 @@ struct DgArgs {
     int P, tiles_m, tiles_n, splits, cps;   // cps: 32-deep chunks per split
     int ldc;                // dgemm32g: elements between consecutive rows of C (0: N); split-K slabs stay [M][N]
     int kb;                 // dgemm32g: rows a row-contiguous B really has (0: K) -- k rows behind it read as zeros
+    int round_f16;          // dgemm32g: round the direct result through float16 (autocast output of the tap GEMMs)
 };
 
 __device__ __forceinline__ float4 dg_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -542,6 +543,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void dgemm32g_kernel(DgArgs g) {
 
     float* o = g.part ? g.part + ((size_t)sp * nz + z) * ((size_t)g.M * g.N) : g.C + (size_t)z * g.sc;
     const size_t ldc = (g.part || !g.ldc) ? (size_t)g.N : (size_t)g.ldc;
+    const bool rnd = g.round_f16 != 0 && g.part == nullptr;        // wave-uniform
     if (m0 + BM <= g.M && n0 + BN <= g.N) {        // interior tile (wave-uniform): no per-element predicates
         float* ow = o + (size_t)(m0 + wm0 + 4 * (lane >> 5)) * ldc + n0 + wn0 + (lane & 31);
 #pragma unroll
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void dgemm32g_kernel(DgArgs g) {
             for (int ni = 0; ni < NB; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    ow[(size_t)(32 * mi + (r & 3) + 8 * (r >> 2)) * ldc + 32 * ni] = acc[mi][ni][r];
+                    ow[(size_t)(32 * mi + (r & 3) + 8 * (r >> 2)) * ldc + 32 * ni] = rnd ? round_h(acc[mi][ni][r]) : acc[mi][ni][r];
     } else {
 #pragma unroll
         for (int mi = 0; mi < MB; ++mi)
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void dgemm32g_kernel(DgArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm0 + 32 * mi + mfma32_row(r, lane);
-                    if (row < g.M && col < g.N) o[(size_t)row * ldc + col] = acc[mi][ni][r];
+                    if (row < g.M && col < g.N) o[(size_t)row * ldc + col] = rnd ? round_h(acc[mi][ni][r]) : acc[mi][ni][r];
                 }
             }
     }

@@ -19,6 +19,8 @@ SHAPES = {   # name: (B, H, W, Ci, Co, k, stride, pad, reflect)
     "d1_64_128": (8, 33, 65, 64, 128, 4, 2, 2, False),
     "trunk2048": (8, 4, 8, 2048, 2048, 3, 1, 1, True),      # configs[2]: trunk ResNet blocks of the LocalEnhancer
     "local128": (8, 64, 128, 128, 128, 3, 1, 1, True),      #             half-resolution local blocks
+    "down1024": (8, 8, 16, 1024, 2048, 3, 2, 1, False),     #             last rung of its 64 -> 2048 ladder
+    "d256_512_b16": (16, 17, 33, 256, 512, 4, 1, 2, False),  #             stacked [fake, real] discriminator pass
     "d3_64": (8, 128, 256, 3, 64, 4, 2, 2, False),          # first discriminator layers
     "d1_3_64": (8, 64, 128, 3, 64, 4, 2, 2, False),
     "head": (8, 128, 256, 64, 1, 7, 1, 3, True),

@@ -44,6 +44,9 @@ CASES = [
     ("cdh_5x5_ragged", 3, 64, 9, 13, 64, 5, 1, 2, False),                 # 351 pixels: the weight gradient's K tail
     ("cdh_res3x3_reflect_64", 2, 64, 24, 40, 64, 3, 1, 1, True),         # local-enhancer residual block
     ("cdh_up_twin_256_128", 2, 256, 16, 24, 128, 3, 2, 1, False),        # the ladder's 256 -> 128 pair
+    # single-output-channel layers as tap GEMMs on float16-rounded operands (csrc/conv_co1.h)
+    ("co1_head7x7_reflect_64", 2, 64, 20, 36, 1, 7, 1, 3, True),
+    ("co1_dlast_4x4_512", 2, 512, 6, 10, 1, 4, 1, 2, False),
 ]
 
 
@@ -95,7 +98,9 @@ def test_conv_f16_precision(case):
         assert ops.plan_name(0, g).startswith("conv_fwd_dma_kernel") and ops.plan_name(0, g).endswith("true>")
         assert ops.plan_name(2, g).startswith("conv_wgrad_dma_kernel") and ops.plan_name(2, g).endswith("true>")
         assert ops.plan_name(1, g).startswith("conv_dgrad_dma_kernel"), ops.plan_name(1, g)      # reflect: padded domain + fold
-    wino = bool(_lib.load().mg_conv_wino_weights_bytes(g)) and not h16 and not cdh
+    co1 = Co == 1 and ops.plan_name(0, g).startswith("dgemm32g_kernel<64, 128")
+    assert co1 == (name.startswith("co1_") or name == "d4x4_s1_co1"), ops.plan_name(0, g)
+    wino = bool(_lib.load().mg_conv_wino_weights_bytes(g)) and not h16 and not cdh and not co1
     tol = dict(ulps=4.0, floor=2.0 ** -9) if wino else {}
     close_f16(ops.conv_fwd(g, xd, wd, bd), nhwc(y.detach()), **tol)
     close_f16(ops.conv_dgrad(g, gyd, wd), nhwc(xh.grad), **tol)
@@ -112,7 +117,7 @@ def test_conv_f16_precision(case):
     assert (dw.double().cpu() - want).abs().max().item() <= wtol * want.abs().max().item()
     ops.conv_wgrad(g, xd, gyd, dw, None, accumulate=True)
     assert (dw.double().cpu() - 2 * want).abs().max().item() <= 2 * wtol * want.abs().max().item()
-    if cdh:      # float16 copies of x / dy handed from the forward / data-gradient call to the weight gradient: same bits
+    if cdh or co1:   # staged copies of x / dy handed from the forward / data-gradient call to the weight gradient: same bits
         u = ops.wino_weights(g, wd)
         v, md = ops.wino_tile_buffers(g, xd.device)
         assert v is not None and md is not None
