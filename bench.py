@@ -21,6 +21,9 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+# multi-process GPU work on this pool: the host driver only supports dmabuf IPC (RCCL / tensor sharing across processes fails
+# with hipIpcGetMemHandle otherwise); must be in the environment before the HIP runtime loads
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

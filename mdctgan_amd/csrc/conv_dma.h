@@ -508,6 +508,11 @@ inline size_t conv_dma_h_x_bytes(const mg_conv_geom* g) { return cd_al((size_t)g
 inline size_t conv_dma_h_dy_bytes(const mg_conv_geom* g) { return cd_al((size_t)g->B * g->OH * g->OW * g->Co * 2); }
 inline size_t conv_dma_h_w_bytes(const mg_conv_geom* g) { return cd_al((size_t)g->Co * g->KH * g->KW * g->Ci * 2); }
 struct CdPlan { int bm, bn, splits, cps; };
+// cost-model constants of the float16 instances (tuning: MG_HALF_RATE / MG_HALF_FIXED / MG_HALF_FILL)
+inline double cd_env(const char* name, double dflt) { const char* v = getenv(name); return v ? atof(v) : dflt; }
+inline double cd_half_rate() { static const double v = cd_env("MG_HALF_RATE", 4.0); return v; }
+inline double cd_half_fixed() { static const double v = cd_env("MG_HALF_FIXED", 4.0); return v; }
+inline long long cd_half_fill() { static const long long v = (long long)cd_env("MG_HALF_FILL", 512); return v; }
 // the dense plan's cost model (dense_plan above) on the convolution's GEMM view, DMA instances only.  ck = K depth of a chunk
 // (32 float32 / 64 float16); the float16 instances are priced at 4x the float32 MFMA rate (what the staging sustains) with a
 // proportionally larger fixed cost per workgroup.
@@ -516,7 +521,8 @@ CdPlan conv_dma_plan(long long M, int N, int chunks, bool wgrad, int ck, int tap
     static const Cand cands[4] = {{64, 64, 0.83}, {64, 128, 0.885}, {128, 64, 0.855}, {128, 128, 0.91}};
     static const int split_opts[12] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
     const bool half = ck == 64;
-    const double rate = (half ? 4.0 : 1.0) * 157.3e12 / 256.0, fixed = half ? 4.0 : 1.2;
+    const double rate = (half ? cd_half_rate() : 1.0) * 157.3e12 / 256.0, fixed = half ? cd_half_fixed() : 1.2;
+    const long long fill = half ? cd_half_fill() : 512;
     CdPlan p{64, 64, 1, 1 << 28};
     int f_bm = 0, f_bn = 0, f_sp = 0;
     if (const char* f = getenv("MG_FORCE_CONV_DMA")) {      // tuning harness: "bm,bn,splits"
@@ -535,7 +541,7 @@ CdPlan conv_dma_plan(long long M, int N, int chunks, bool wgrad, int ck, int tap
             const int spl = (chunks + cps - 1) / cps;
             const long long wg = w * spl;
             double t = (double)((wg + 255) / 256) * tile_us * (cps + fixed);
-            if (wg < 512) t /= 0.85;
+            if (wg < fill) t /= 0.85;
             if (spl > 1) t += (double)(spl + 1) * (double)M * N * 4.0 / 4e12 * 1e6 + 3.0;
             if (t < best) { best = t; p = {c.bm, c.bn, spl, cps}; }
         }
@@ -603,7 +609,8 @@ void conv_dma_wgrad_launch(const mg_conv_geom* g, const CdPlan& p, const void* x
 inline CdPlan conv_dma_dgrad_plan(const mg_conv_geom* g) {
     const int s = g->stride, ck = conv_dma_ck(g);
     const bool half = conv_dma_half(g);
-    const double rate = (half ? 4.0 : 1.0) * 157.3e12 / 256.0, fixed = half ? 4.0 : 1.2;
+    const double rate = (half ? cd_half_rate() : 1.0) * 157.3e12 / 256.0, fixed = half ? cd_half_fixed() : 1.2;
+    const long long fill = half ? cd_half_fill() : 512;
     const long long Mc = (long long)g->B * ((g->H + s - 1) / s) * ((g->W + s - 1) / s);
     const int chunks = ((g->KH + s - 1) / s) * ((g->KW + s - 1) / s) * (g->Co / ck);
     // the classes run side by side: count their workgroups when judging how full the chip is
@@ -627,7 +634,7 @@ inline CdPlan conv_dma_dgrad_plan(const mg_conv_geom* g) {
             if (f_sp && sp != f_sp) continue;
             const long long wg = w * s * s * sp;
             double t = (double)((wg + 255) / 256) * tile_us * ((double)total_k / (s * s) / sp + fixed);
-            if (wg < 512) t /= 0.85;
+            if (wg < fill) t /= 0.85;
             if (sp > 1) t += (double)(sp + 1) * (double)g->B * g->H * g->W * g->Ci * 4.0 / 4e12 * 1e6 + 3.0;
             if (t < best_t) { best_t = t; best = {c.bm, c.bn, sp, 0}; }
         }
