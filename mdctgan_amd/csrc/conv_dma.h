@@ -27,30 +27,6 @@ struct CdElem {
     static constexpr unsigned ES = HALF ? 2u : 4u;      // element bytes
     static constexpr int CK = HALF ? 64 : 32;           // K depth of one chunk (128-byte rows)
 };
-template <int R>
-__device__ __forceinline__ int cd_rc_swz(int k) { return R == 128 ? ((k & 3) << 2) : (((k >> 1) & 1) << 2); }
-
-typedef __fp16 cd_h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
-typedef cd_h4 __attribute__((address_space(3))) * cd_h4_lds;
-
-__device__ __forceinline__ f16x8 cd_frag_kc(const float* S, int row, int s, int kh) {
-    return *reinterpret_cast<const f16x8*>(S + row * 32 + 4 * ((2 * s + kh) ^ ((row >> 1) & 7)));
-}
-// RC image [64][R] halves; col0 = tile-relative first column of the wave's 32-column block
-template <int R>
-__device__ __forceinline__ f16x8 cd_frag_rc(const float* S, int col0, int s, int lane) {
-    static_assert(R == 64 || R == 128, "row-contiguous operand tiles are 64 or 128 columns wide");
-    const int i = lane & 15;
-    const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
-    const int k = 16 * s + 8 * (lane >> 5) + (i >> 2);
-    const char* p = reinterpret_cast<const char*>(S) + k * (2 * R) + 16 * ((col >> 3) ^ cd_rc_swz<R>(k)) + 2 * (col & 7);
-    const cd_h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((cd_h4_lds)(p));
-    const cd_h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((cd_h4_lds)(p + 8 * R));       // k + 4: same swizzle
-    f16x8 v;
-    v[0] = (_Float16)lo[0]; v[1] = (_Float16)lo[1]; v[2] = (_Float16)lo[2]; v[3] = (_Float16)lo[3];
-    v[4] = (_Float16)hi[0]; v[5] = (_Float16)hi[1]; v[6] = (_Float16)hi[2]; v[7] = (_Float16)hi[3];
-    return v;
-}
 template <int MB, int NB, int ALAY, int BLAY, int BM, int BN>
 __device__ __forceinline__ void cd_chunk_h(const float* As, const float* Bs, f32x16 (&acc)[MB][NB], int wm0, int wn0, int lane) {
     const int r = lane & 31, kh = lane >> 5;

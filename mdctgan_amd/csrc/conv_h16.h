@@ -150,7 +150,8 @@ struct H16Plan { int bm, bn, splits, cps; };
 // K split that gives every CU a workgroup (scripts/ubench/hgemm_bench.hip: the weight stream needs >= 256 workgroups in
 // flight; more splits only add slab traffic)
 H16Plan h16_plan(long long M, int N, int K, bool brc) {
-    H16Plan p{128, brc ? 64 : 128, 1, 1 << 28};
+    H16Plan p{128, 128, 1, 1 << 28};
+    (void)brc;            // both operand forms run 128 x 128 tiles (the row-contiguous one since it reads with ds_read_b64_tr_b16)
     const long long tiles = ((M + p.bm - 1) / p.bm) * ((N + p.bn - 1) / p.bn);
     const int chunks = K / HG_BK;
     int s = 1;
@@ -197,7 +198,8 @@ int h16_prepare(const mg_conv_geom* g, const float* w, void* w16, hipStream_t st
     return MG_OK;
 }
 inline bool h16_deep(long long M, int N, int splits, bool brc) {
-    return ((M + 127) / 128) * ((N + (brc ? 63 : 127)) / (brc ? 64 : 128)) * splits <= 512;
+    (void)brc;
+    return ((M + 127) / 128) * ((N + 127) / 128) * splits <= 512;
 }
 inline void h16_launch(const H16Plan& p, bool brc, const HgArgs& a, hipStream_t st) {
     // three LDS buffers: two chunks in flight per workgroup -- the weights come cold from HBM every step (1.4 GB of float16
@@ -207,8 +209,8 @@ inline void h16_launch(const H16Plan& p, bool brc, const HgArgs& a, hipStream_t 
     // short workgroups want two 64 KiB workgroups per CU instead (same harness: 56 vs 78 us).
     const bool deep = h16_deep(a.M, a.N, p.splits, brc);
     if (brc) {
-        if (deep) hgemm_launch<128, 64, 2, 2, true, 3>(a, st);
-        else hgemm_launch<128, 64, 2, 2, true, 2>(a, st);
+        if (deep) hgemm_launch<128, 128, 4, 2, true, 3>(a, st);
+        else hgemm_launch<128, 128, 4, 2, true, 2>(a, st);
     } else {
         if (deep) hgemm_launch<128, 128, 4, 2, false, 3>(a, st);
         else hgemm_launch<128, 128, 4, 2, false, 2>(a, st);

@@ -2411,7 +2411,7 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
         if (pass == 0) deep = h16_deep(px, g->Co, h16_plan(px, g->Co, Kw, false).splits, false);
         else if (pass == 1) deep = h16_deep((long long)g->B * g->H * g->W, g->Ci, h16_plan((long long)g->B * g->H * g->W, g->Ci, g->KH * g->KW * g->Co, true).splits, true);
         else deep = h16_deep(g->Co, Kw, h16_plan(g->Co, Kw, h16_mp(px), false).splits, false);
-        snprintf(out, out_len, pass == 1 ? "hgemm_kernel<128, 64, 2, 2, true, %d>" : "hgemm_kernel<128, 128, 4, 2, false, %d>", deep ? 3 : 2);
+        snprintf(out, out_len, pass == 1 ? "hgemm_kernel<128, 128, 4, 2, true, %d>" : "hgemm_kernel<128, 128, 4, 2, false, %d>", deep ? 3 : 2);
     } else if (wino_ok(g) && !kq && !(pass == 1 && wino_dgrad_padded()) &&
         dense_plan(pass, 16, wino_dims(g).T, g->Co, g->Ci, prec_h(g)).ok) {
         dense_name(pass, 16, dense_plan(pass, 16, wino_dims(g).T, g->Co, g->Ci, prec_h(g)), out, out_len);

@@ -13,6 +13,37 @@
 
 constexpr int HG_BK = 64;          // halves per chunk row (128 bytes)
 
+// ---- float16 fragment reads shared with the implicit GEMMs (conv_dma.h) ----
+// k-contiguous image: one ds_read_b128 = the 8 halves of an MFMA operand.  Row-contiguous image [64][R] halves: two
+// ds_read_b64_tr_b16 (16 lanes fetch a [4 k][16 columns] block, every lane receives the 4 k of its column); the 16-byte
+// slots of a k row are XOR-swizzled on the DMA source side (cd_rc_swz) so that the 8 row segments a 32-lane half reads fall
+// into 8 different 32-byte bank groups.
+template <int R>
+__device__ __forceinline__ int cd_rc_swz(int k) { return R == 128 ? ((k & 3) << 2) : (((k >> 1) & 1) << 2); }
+
+typedef __fp16 cd_h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef cd_h4 __attribute__((address_space(3))) * cd_h4_lds;
+
+__device__ __forceinline__ f16x8 cd_frag_kc(const float* S, int row, int s, int kh) {
+    return *reinterpret_cast<const f16x8*>(S + row * 32 + 4 * ((2 * s + kh) ^ ((row >> 1) & 7)));
+}
+// RC image [64][R] halves; col0 = tile-relative first column of the wave's 32-column block
+template <int R>
+__device__ __forceinline__ f16x8 cd_frag_rc(const float* S, int col0, int s, int lane) {
+    static_assert(R == 64 || R == 128, "row-contiguous operand tiles are 64 or 128 columns wide");
+    const int i = lane & 15;
+    const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
+    const int k = 16 * s + 8 * (lane >> 5) + (i >> 2);
+    const char* p = reinterpret_cast<const char*>(S) + k * (2 * R) + 16 * ((col >> 3) ^ cd_rc_swz<R>(k)) + 2 * (col & 7);
+    const cd_h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((cd_h4_lds)(p));
+    const cd_h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((cd_h4_lds)(p + 8 * R));       // k + 4: same swizzle
+    f16x8 v;
+    v[0] = (_Float16)lo[0]; v[1] = (_Float16)lo[1]; v[2] = (_Float16)lo[2]; v[3] = (_Float16)lo[3];
+    v[4] = (_Float16)hi[0]; v[5] = (_Float16)hi[1]; v[6] = (_Float16)hi[2]; v[7] = (_Float16)hi[3];
+    return v;
+}
+
+
 struct HgArgs {
     const void* A;           // float16 [M][lda]
     const void* B;           // float16 [N][ldb]
@@ -42,9 +73,8 @@ struct HgCfg {
 };
 
 // BRC: B is row-contiguous ([K][N], see HgArgs).  Its LDS image is k-major ([64][BN] halves, filled by the same DMA in
-// pieces of 1024 / (2 BN) whole k rows); a lane gathers the 8 k of its column with eight 16-bit LDS reads -- 8x the LDS
-// instructions of the k-contiguous form, affordable where the kernel is bound by streaming the weights (the 4x8 trunk) and
-// it saves keeping a second, transposed float16 copy of every weight tensor.
+// pieces of 1024 / (2 BN) whole k rows, slots swizzled); a lane gets the 8 k of its column with two transpose reads
+// (cd_frag_rc) -- no second, transposed float16 copy of every weight tensor.
 // NBUF LDS buffers keep NBUF - 1 chunks in flight: with one workgroup per CU (grid == 256 on the weight-streaming trunk
 // shapes) a two-buffer loop has one 32 KiB chunk outstanding per CU -- a quarter of what the HBM latency needs.
 template <int BM, int BN, int WGM, int WGN, bool BRC = false, int NBUF = 2>
@@ -88,9 +118,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void hgemm_kernel(HgArgs g) {
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-        if (BRC) {
+        if constexpr (BRC) {
             constexpr int LPR = BN / 8;                   // lanes per k row (16 bytes = 8 halves each)
-            const int k = (wave * PB + i) * (64 / LPR) + lane / LPR, c8 = lane % LPR;
+            const int k = (wave * PB + i) * (64 / LPR) + lane / LPR, c8 = (lane % LPR) ^ cd_rc_swz<BN>(k);
             vb[i] = ((unsigned)k * (unsigned)g.ldb + (unsigned)min(n0 + 8 * c8, g.N - 8)) * 2u;
         } else {
             const int row = 8 * (wave * PB + i) + (lane >> 3), q = (lane & 7) ^ ((row >> 1) & 7);
@@ -157,12 +187,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void hgemm_kernel(HgArgs g) {
 #pragma unroll
             for (int ni = 0; ni < NB; ++ni) {
                 const int row = wn0 + 32 * ni + r;
-                if (BRC) {
-                    const _Float16* bh = reinterpret_cast<const _Float16*>(Bs) + (16 * s + 8 * kh) * BN + row;
-                    f16x8 t;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) t[j] = bh[j * BN];
-                    b[buf][ni] = t;
+                if constexpr (BRC) {
+                    b[buf][ni] = cd_frag_rc<BN>(Bs, wn0 + 32 * ni, s, lane);
                 } else {
                     b[buf][ni] = *reinterpret_cast<const f16x8*>(Bs + row * 32 + 4 * ((2 * s + kh) ^ ((row >> 1) & 7)));
                 }
