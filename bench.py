@@ -358,7 +358,7 @@ def main():
                     "launches": n, "avg_launch_us": round(secs / n * 1e6, 2),
                     "flops_per_launch": flops / n,
                     "flops_definition": "FLOPs the kernel itself issues (2*M*N*K of its GEMM, summed over the launches of this "
-                                        "symbol).  dgemm32g_kernel<BM, BN, 2, 2, A, B, 2, P> (csrc/dense_gemm.h) are the batched "
+                                        "symbol).  dgemm32g_kernel<BM, BN, 2, 2, A, B, 2, P, 0> (csrc/dense_gemm.h) are the batched "
                                         "Winograd-domain GEMMs: layouts (A, B) = (0, 0) forward, (0, 1) data gradient, (1, 1) weight "
                                         "gradient; P = 16 the F(2x2,3x3) layers (the 1024-channel residual trunk), P = 25 the "
                                         "F(2x2,4x4) / F(4x4,2x2) layers; the direct-convolution cost of the same "

@@ -1258,7 +1258,7 @@ void dense_launch(const DensePlan& p, const DgArgs& a, hipStream_t st) {
 }
 void dense_name(int pass, int P, const DensePlan& p, char* out, int out_len) {
     const int al = pass == 2 ? DG_RC : DG_KC, bl = pass == 0 ? DG_KC : DG_RC;
-    if (p.dma) snprintf(out, out_len, "dgemm32g_kernel<%d, %d, 2, 2, %d, %d, 2, %d>", p.bm, p.bn, al, bl, P);
+    if (p.dma) snprintf(out, out_len, "dgemm32g_kernel<%d, %d, 2, 2, %d, %d, 2, %d, 0>", p.bm, p.bn, al, bl, P);
     else snprintf(out, out_len, "dgemm32_kernel<%d, %d, %d, 2, %d, %d, 0>", p.bm, p.bn, p.bm == 128 ? 4 : 2, al, bl);
 }
 
