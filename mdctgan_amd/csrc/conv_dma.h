@@ -436,15 +436,23 @@ __global__ __launch_bounds__(256) void conv_dgrad_dma_kernel(CdArgs g) {
     // split-K slabs are whole dx images (classes write disjoint pixels of the same slab)
     float* o = g.part ? g.part + (size_t)blockIdx.z * ((size_t)g.B * g.H * g.W * N) : g.y;
     const bool direct = g.part == nullptr;
+    // a lane's 16 rows per block are m_base + {0..3, 8..11, 16..19, 24..27}: one division for the first, then carries
+    // (three integer divisions per row cost more VALU work than the rows' MFMAs on the light parity classes)
 #pragma unroll
-    for (int mi = 0; mi < MB; ++mi)
+    for (int mi = 0; mi < MB; ++mi) {
+        const int m_base = m0 + wm0 + 32 * mi + 4 * (lane >> 5);
+        int bq = m_base / (Hc * Wc);
+        int y2 = (m_base - bq * (Hc * Wc)) / Wc, x2 = m_base - bq * (Hc * Wc) - y2 * Wc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm0 + 32 * mi + mfma32_row(r, lane);
+            if (r) {
+                x2 += (r & 3) ? 1 : 5;
+                while (x2 >= Wc) { x2 -= Wc; ++y2; }
+                while (y2 >= Hc) { y2 -= Hc; ++bq; }
+            }
+            const int m = m_base + (r & 3) + 8 * (r >> 2);
             if (m >= M) continue;
-            const int b = m / (Hc * Wc), r2 = m - b * (Hc * Wc);
-            const int y2 = r2 / Wc, x2 = r2 - y2 * Wc;
-            const size_t off = ((size_t)(b * g.H + y2 * s + py) * g.W + x2 * s + px) * N;
+            const size_t off = ((size_t)(bq * g.H + y2 * s + py) * g.W + x2 * s + px) * N;
 #pragma unroll
             for (int ni = 0; ni < NB; ++ni) {
                 const int col = n0 + wn0 + 32 * ni + (lane & 31);
@@ -453,6 +461,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_dma_kernel(CdArgs g) {
                 o[off + col] = direct ? ((HALF && g.round_f16) ? round_h(vb2) : vb2) : v;
             }
         }
+    }
 #endif
 }
 
