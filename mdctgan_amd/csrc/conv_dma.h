@@ -245,7 +245,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(CdArgs g) {
         va[i] = ((unsigned)k * (unsigned)g.Co + (unsigned)min(r_0 + col, R - EPL)) * ES;
     }
     // B rows: pixel m = 32 c + krow of this lane, as running (b, oy, ox)
-    int pm[PB], pbb[PB], poy[PB], pox[PB];
+    // Zero padding: the source coordinates (iy, ix) and the linear source pixel are carried along with (oy, ox), so a
+    // chunk's gather address is additions and two range checks, not the multiplications of cd_pixel_off (reflection keeps
+    // those: the reflected index is not linear in the step).
+    int pm[PB], pbb[PB], poy[PB], pox[PB], siy[PB], six[PB], src[PB];
     unsigned qb[PB];
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
@@ -257,8 +260,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(CdArgs g) {
         const int r2 = pm[i] - pbb[i] * (g.OH * g.OW);
         poy[i] = r2 / g.OW;
         pox[i] = r2 - poy[i] * g.OW;
+        siy[i] = poy[i] * g.s - g.p + ky;
+        six[i] = pox[i] * g.s - g.p + kx;
+        src[i] = (pbb[i] * g.H + siy[i]) * g.W + six[i];
     }
     const int adv_oy = CK / g.OW, adv_ox = CK - adv_oy * g.OW;
+    const int d_x = adv_ox * g.s, d_y = adv_oy * g.s, d_src = d_y * g.W + d_x;              // per chunk
+    const int w_x = g.OW * g.s, w_src = g.s * g.W - w_x;                                  // ox wrapped: next output row
+    const int w_y = g.OH * g.s, wb_src = (g.H - w_y) * g.W;                               // oy wrapped: next sample
     const unsigned lds_a0 = (unsigned)(size_t)(dg_lds_ptr)As0 + (unsigned)(wave * PA) * 1024u;
     const unsigned lds_b0 = (unsigned)(size_t)(dg_lds_ptr)Bs0 + (unsigned)(wave * PB) * 1024u;
     auto issue = [&](int c, int buf) {
@@ -271,16 +280,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(CdArgs g) {
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
             unsigned o = CD_OOB;
-            if (pm[i] < Mpx) {
-                o = cd_pixel_off(g, pbb[i] * g.H * g.W, poy[i] * g.s - g.p + ky, pox[i] * g.s - g.p + kx, cbytes);
-                if (o != CD_OOB) o += qb[i];
+            if (g.reflect) {
+                if (pm[i] < Mpx) o = cd_pixel_off(g, pbb[i] * g.H * g.W, siy[i], six[i], cbytes) + qb[i];
+            } else if (pm[i] < Mpx && (unsigned)siy[i] < (unsigned)g.H && (unsigned)six[i] < (unsigned)g.W) {
+                o = (unsigned)src[i] * cbytes + qb[i];
             }
             dg_dma16(o, rb, lb + 1024u * i, 0u);
             pm[i] += CK;
-            pox[i] += adv_ox;
-            poy[i] += adv_oy;
-            if (pox[i] >= g.OW) { pox[i] -= g.OW; ++poy[i]; }
-            while (poy[i] >= g.OH) { poy[i] -= g.OH; ++pbb[i]; }
+            pox[i] += adv_ox; six[i] += d_x;
+            poy[i] += adv_oy; siy[i] += d_y;
+            src[i] += d_src;
+            if (pox[i] >= g.OW) { pox[i] -= g.OW; six[i] -= w_x; ++poy[i]; siy[i] += g.s; src[i] += w_src; }
+            while (poy[i] >= g.OH) { poy[i] -= g.OH; siy[i] -= w_y; ++pbb[i]; src[i] += wb_src; }
         }
     };
 
