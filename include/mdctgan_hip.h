@@ -185,6 +185,16 @@ size_t mg_conv_wino_tiles_bytes(const mg_conv_geom* g, int which);
 int mg_conv_wino_prepare(const mg_conv_geom* g, const float* w, float* u, void* stream);
 int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
                   void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* tiles);
+/* y_raw = conv(x, w) + bias (mg_conv_fwd_w with no activation) followed by mg_instnorm_fwd(y_raw) -> y = act((y_raw - mean)
+ * * rstd) + residual, mean / rstd [B][Co]: the [conv3x3, InstanceNorm2d(affine=False), ReLU] / [conv3x3, InstanceNorm2d, + x]
+ * pairs of ResnetBlock (models/networks.py:440-462).  When the layer runs as Winograd F(2x2,3x3) and a sample's map is
+ * <= 640 pixels, the inverse transform, the statistics and the normalisation are ONE kernel; otherwise the two calls are
+ * made back to back -- same results either way (statistics in double, fixed reduction order).  y_raw is kept because the
+ * InstanceNorm backward recomputes the normalised value from it.  workspace >= mg_conv_fwd_instnorm_workspace(g). */
+size_t mg_conv_fwd_instnorm_workspace(const mg_conv_geom* g);
+int mg_conv_fwd_instnorm_w(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y_raw, float eps,
+                           int act, const float* residual, float* y, float* mean, float* rstd, void* workspace,
+                           size_t workspace_bytes, void* stream, const mg_wino_tiles* wt);
 int mg_conv_dgrad_w(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
                     void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* tiles);
 /* dw [Co, KH, KW, Ci] = sum over pixels; dbias [Co] (nullable) = column sums of dy.

@@ -1713,7 +1713,7 @@ inline void launch_lean_dgrad(const TilePlan& tp, int P, long long T, int Nc, in
 }
 
 int wino_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act, float* ws,
-             hipStream_t st, const float* u_pre, float* v_keep) {
+             hipStream_t st, const float* u_pre, float* v_keep, const WinoNorm* nrm = nullptr) {
     const WinoDims d = wino_dims(g);
     float* U = ws;
     float* V = U + al256((size_t)16 * g->Co * g->Ci);
@@ -1755,6 +1755,15 @@ int wino_fwd(const mg_conv_geom* g, const float* x, const float* w, const float*
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(wino_grid(n / 4)), dim3(256), 0, st, (const float*)pp, tp.splits,
                            n, g->Co, (const float*)nullptr, MG_ACT_NONE, Mx);
     }
+    }
+    if (nrm) {           // output transform + InstanceNorm in one kernel (y = the raw convolution output, nrm->y the normalised one)
+        const dim3 grid(g->Co / 32, g->B);
+        const int nt = (d.TH * d.TW + 31) / 32;
+#define MG_OUT_NORM(NT_) hipLaunchKernelGGL(wino_out_norm_kernel<NT_>, grid, dim3(256), 0, st, (const float*)Mx, g->B, d.TH, d.TW, g->Co, bias, *nrm, y)
+        if (nt == 1) MG_OUT_NORM(1); else if (nt == 2) MG_OUT_NORM(2); else if (nt == 3) MG_OUT_NORM(3); else if (nt == 4) MG_OUT_NORM(4); else MG_OUT_NORM(5);
+#undef MG_OUT_NORM
+        MG_CHECK_LAUNCH();
+        return MG_OK;
     }
     hipLaunchKernelGGL(wino_output_xform_kernel, dim3(wino_grid((size_t)d.T * g->Co / 4)), dim3(256), 0, st,
                        (const float*)Mx, g->B, d.TH, d.TW, g->Co, bias, act, y, (int)prec_h(g));
@@ -2633,6 +2642,29 @@ int mg_conv_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const 
 int mg_conv_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias, int accumulate,
                   void* workspace, size_t workspace_bytes, void* stream) {
     return mg_conv_wgrad_w(g, x, dy, dw, dbias, accumulate, workspace, workspace_bytes, stream, nullptr);
+}
+
+size_t mg_conv_fwd_instnorm_workspace(const mg_conv_geom* g) {
+    if (!geom_ok(g)) return 0;
+    const size_t a = mg_conv_fwd_workspace(g), b = mg_instnorm_workspace(g->B, g->OH * g->OW, g->Co);
+    return a > b ? a : b;
+}
+int mg_conv_fwd_instnorm_w(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y_raw, float eps,
+                           int act, const float* residual, float* y, float* mean, float* rstd, void* workspace,
+                           size_t workspace_bytes, void* stream, const mg_wino_tiles* wt) {
+    if (!geom_ok(g) || !x || !w || !y_raw || !y || !mean || !rstd) return MG_ERR_ARG;
+    if (!wino_tiles_ok(g, wt)) return MG_ERR_ARG;
+    if (!workspace || workspace_bytes < mg_conv_fwd_instnorm_workspace(g)) return MG_ERR_ARG;
+    if (wino_ok(g) && !prec_h(g) && !mg_conv_rowdot_kq(g) && wino_out_norm_ok(g->OH / 2, g->OW / 2, g->Co) && aligned16(x) &&
+        aligned16(w) && aligned16(y_raw) && aligned16(y) && aligned16(mean) && aligned16(rstd) && aligned16(workspace) &&
+        (!bias || aligned16(bias)) && (!residual || aligned16(residual))) {
+        const WinoNorm nrm{eps, act, residual, y, mean, rstd};
+        return wino_fwd(g, x, w, bias, y_raw, MG_ACT_NONE, (float*)workspace, (hipStream_t)stream, wt ? wt->u : nullptr,
+                        wt ? wt->v : nullptr, &nrm);
+    }
+    const int rc = mg_conv_fwd_w(g, x, w, bias, y_raw, MG_ACT_NONE, workspace, workspace_bytes, stream, wt);
+    if (rc != MG_OK) return rc;
+    return mg_instnorm_fwd(y_raw, g->B, g->OH * g->OW, g->Co, eps, act, residual, y, mean, rstd, workspace, workspace_bytes, stream);
 }
 
 int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,

@@ -140,6 +140,131 @@ __global__ void wino_output_xform_kernel(const float* __restrict__ Mx, int B, in
     }
 }
 
+
+// ---- output transform fused with InstanceNorm2d(affine=False) (+ activation, + residual) ---------------------------------
+// The trunk's maps are small (8x16 pixels at configs[1]): a sample's 32-channel slab is 32..160 tiles, so ONE workgroup can
+// inverse-transform it, take the statistics over all its pixels and normalise without a second kernel or a second read --
+// the InstanceNorm statistics live in the epilogue of the kernel that produces the convolution output.  Thread = (channel
+// quad, tile lane): NT tiles of 2x2 pixels each, kept in registers between the statistics and the apply.  Sums in double,
+// fixed-order LDS reduction (deterministic), same arithmetic as wino_output_xform_kernel followed by norm_slab_fwd_kernel.
+struct WinoNorm {
+    float eps;
+    int act;
+    const float* residual;     // [B][2TH][2TW][C] or nullptr
+    float* y;                  // act((y_raw - mean) * rstd) + residual
+    float* mean;               // [B][C]
+    float* rstd;
+};
+template <int NT>
+__global__ __launch_bounds__(256) void wino_out_norm_kernel(const float* __restrict__ Mx, int B, int TH, int TW, int C,
+                                                            const float* __restrict__ bias, WinoNorm nrm,
+                                                            float* __restrict__ y_raw) {
+    __shared__ double red[2][32][32];
+    const int cq = threadIdx.x & 7, tl = threadIdx.x >> 3;
+    const int b = blockIdx.y, c0 = blockIdx.x * 32 + 4 * cq;
+    const int Ts = TH * TW;
+    const size_t T = (size_t)B * Ts;
+    float4 v[NT][4];
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    const float4 bv = bias ? ld4(bias + c0) : zero4();
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int tile = tl + 32 * i;
+        if (tile < Ts) {
+            const size_t t = (size_t)b * Ts + tile;
+            float4 m[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) m[r][c] = ld4(Mx + ((size_t)(r * 4 + c) * T + t) * C + c0);
+            float4 tmp[2][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                tmp[0][c] = f4add(f4add(m[0][c], m[1][c]), m[2][c]);
+                tmp[1][c] = f4sub(f4sub(m[1][c], m[2][c]), m[3][c]);
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                v[i][2 * r] = f4add(f4add(f4add(tmp[r][0], tmp[r][1]), tmp[r][2]), bv);
+                v[i][2 * r + 1] = f4add(f4sub(f4sub(tmp[r][1], tmp[r][2]), tmp[r][3]), bv);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s1[0] += (double)v[i][q].x; s2[0] += (double)v[i][q].x * (double)v[i][q].x;
+                s1[1] += (double)v[i][q].y; s2[1] += (double)v[i][q].y * (double)v[i][q].y;
+                s1[2] += (double)v[i][q].z; s2[2] += (double)v[i][q].z * (double)v[i][q].z;
+                s1[3] += (double)v[i][q].w; s2[3] += (double)v[i][q].w * (double)v[i][q].w;
+            }
+        }
+    }
+    // red[0/1][tile lane][channel] -> 8 partials per channel -> totals in every thread of the channel quad
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[0][tl][4 * cq + j] = s1[j];
+        red[1][tl][4 * cq + j] = s2[j];
+    }
+    __syncthreads();
+    {
+        const int c = threadIdx.x & 31, part = threadIdx.x >> 5;
+        double a = 0.0, bsum = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a += red[0][4 * part + i][c];
+            bsum += red[1][4 * part + i][c];
+        }
+        __syncthreads();
+        red[0][part][c] = a;
+        red[1][part][c] = bsum;
+    }
+    __syncthreads();
+    const int HW = 4 * Ts;
+    float mu[4], rs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double x1 = 0.0, x2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            x1 += red[0][i][4 * cq + j];
+            x2 += red[1][i][4 * cq + j];
+        }
+        const double mval = x1 / HW;
+        double var = x2 / HW - mval * mval;
+        if (var < 0.0) var = 0.0;
+        mu[j] = (float)mval;
+        rs[j] = (float)(1.0 / sqrt(var + (double)nrm.eps));
+    }
+    if (tl == 0) {
+        *reinterpret_cast<float4*>(nrm.mean + (size_t)b * C + c0) = make_float4(mu[0], mu[1], mu[2], mu[3]);
+        *reinterpret_cast<float4*>(nrm.rstd + (size_t)b * C + c0) = make_float4(rs[0], rs[1], rs[2], rs[3]);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int tile = tl + 32 * i;
+        if (tile < Ts) {
+            const int ty = tile / TW, tx = tile - ty * TW;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const size_t off = ((size_t)(b * 2 * TH + 2 * ty + (q >> 1)) * (2 * TW) + 2 * tx + (q & 1)) * C + c0;
+                *reinterpret_cast<float4*>(y_raw + off) = v[i][q];
+                float4 o;
+                o.x = apply_act((v[i][q].x - mu[0]) * rs[0], nrm.act);
+                o.y = apply_act((v[i][q].y - mu[1]) * rs[1], nrm.act);
+                o.z = apply_act((v[i][q].z - mu[2]) * rs[2], nrm.act);
+                o.w = apply_act((v[i][q].w - mu[3]) * rs[3], nrm.act);
+                if (nrm.residual) {
+                    const float4 rr = ld4(nrm.residual + off);
+                    o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+                }
+                *reinterpret_cast<float4*>(nrm.y + off) = o;
+            }
+        }
+    }
+}
+inline bool wino_out_norm_ok(int TH, int TW, int C) {
+    static const bool off = getenv("MG_NO_WINO_NORM_FUSION") != nullptr;
+    return !off && C % 32 == 0 && TH * TW <= 160;
+}
+
 // ReflectionPad2d(1) backward: dX[i][j] = sum of the padded positions aliasing (i, j).  dXp: [B][H+2][W+2][C]
 __global__ void wino_fold_reflect_kernel(const float* __restrict__ dxp, int B, int H, int W, int C,
                                          float* __restrict__ dx, int round_f16 = 0) {

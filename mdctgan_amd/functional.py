@@ -235,66 +235,71 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, y = ctx.saved_tensors
-        stride, pad, reflect, act, transposed, weight_grad = ctx.cfg
-        g, weight, bias = ctx.g, ctx.weight, ctx.bias
-        gy = to_cl(gy)
-        kind = _BackwardPass.kind
-        shared = _is_shared(weight_grad)
-        last_use = not shared or kind != "G"                   # a shared layer is walked again by the D pass
-        want_dx = ctx.needs_input_grad[0] and not (weight_grad == "D0" and kind == "D")
-        want_dw = bool(weight_grad) and weight.requires_grad and not (shared and kind == "G")
-        rows = _live_rows(x) if shared else None
-        x_full = x
-        if rows is not None:                                   # pass "G" over a stacked batch: the fake half only
-            assert not transposed and not want_dw
-            x, gy = x[:rows], gy[:rows]
-            y = y[:rows] if y is not None else None
-            g = ops.conv_geom(rows, g.H, g.W, g.Ci, g.Co, g.KH, g.KW, g.stride, g.pad, g.reflect, g.precision)
-        if act != ACT_NONE:
-            gy = nchw_view(ops.act_bwd(nhwc_view(gy), nhwc_view(y), act))
-        w = weight.detach()
-        dx = None
-        md = None
-        if want_dx:
-            if not transposed:
-                u = getattr(ctx, "u", None)
-                if u is not None and want_dw and (getattr(ctx, "v", None) is not None or ops.tiles_are_casts(g)):
-                    _, md = ops.wino_tile_buffers(g, gy.device, want_v=False)
-                if rows is not None:
-                    dx = torch.empty_like(x_full)
-                    ops.conv_dgrad(g, nhwc_view(gy), w, u=u, out=nhwc_view(dx[:rows]))
-                else:
-                    dx = nchw_view(ops.conv_dgrad(g, nhwc_view(gy), w, u=u, md_out=md))
-                if last_use:
-                    ctx.u = None
+        return _conv_backward(ctx, gy, x, y), None, None, None
+
+
+def _conv_backward(ctx, gy, x, y):
+    """Data and weight gradient of a _ConvFn / _ConvInstNormFn node; returns dx (weight gradients go to the arena)."""
+    stride, pad, reflect, act, transposed, weight_grad = ctx.cfg
+    g, weight, bias = ctx.g, ctx.weight, ctx.bias
+    gy = to_cl(gy)
+    kind = _BackwardPass.kind
+    shared = _is_shared(weight_grad)
+    last_use = not shared or kind != "G"                   # a shared layer is walked again by the D pass
+    want_dx = ctx.needs_input_grad[0] and not (weight_grad == "D0" and kind == "D")
+    want_dw = bool(weight_grad) and weight.requires_grad and not (shared and kind == "G")
+    rows = _live_rows(x) if shared else None
+    x_full = x
+    if rows is not None:                                   # pass "G" over a stacked batch: the fake half only
+        assert not transposed and not want_dw
+        x, gy = x[:rows], gy[:rows]
+        y = y[:rows] if y is not None else None
+        g = ops.conv_geom(rows, g.H, g.W, g.Ci, g.Co, g.KH, g.KW, g.stride, g.pad, g.reflect, g.precision)
+    if act != ACT_NONE:
+        gy = nchw_view(ops.act_bwd(nhwc_view(gy), nhwc_view(y), act))
+    w = weight.detach()
+    dx = None
+    md = None
+    if want_dx:
+        if not transposed:
+            u = getattr(ctx, "u", None)
+            if u is not None and want_dw and (getattr(ctx, "v", None) is not None or ops.tiles_are_casts(g)):
+                _, md = ops.wino_tile_buffers(g, gy.device, want_v=False)
+            if rows is not None:
+                dx = torch.empty_like(x_full)
+                ops.conv_dgrad(g, nhwc_view(gy), w, u=u, out=nhwc_view(dx[:rows]))
             else:
-                dx = nchw_view(ops.conv_fwd(g, nhwc_view(gy), w, u=getattr(ctx, "u", None)))
-                if last_use:
-                    ctx.u = None
-        if want_dw:
-            wbuf, wacc = grad_buffer(weight)
-            bbuf = bacc = None
-            if bias is not None and bias.requires_grad:
-                if getattr(bias, "_mg_zero_grad", False) and not COMPUTE_DEAD_BIAS_GRADS:
-                    _zero_grad_bias(bias)
-                else:
-                    bbuf, bacc = grad_buffer(bias)
-            if not transposed:
-                if bbuf is not None and bacc != wacc:      # keep one accumulate flag per launch
-                    ops.colsum(nhwc_view(gy).reshape(-1, g.Co), bbuf, bacc)
-                    bbuf = None
-                # Winograd images come as a pair; the float16 copies of the implicit-GEMM layers are independent
-                v = getattr(ctx, "v", None) if (md is not None or ops.tiles_are_casts(g)) else None
-                ops.conv_wgrad(g, nhwc_view(x), nhwc_view(gy), wbuf, bbuf, wacc, v=v, md=md)
-                ctx.v = None
+                dx = nchw_view(ops.conv_dgrad(g, nhwc_view(gy), w, u=u, md_out=md))
+            if last_use:
+                ctx.u = None
+        else:
+            dx = nchw_view(ops.conv_fwd(g, nhwc_view(gy), w, u=getattr(ctx, "u", None)))
+            if last_use:
+                ctx.u = None
+    if want_dw:
+        wbuf, wacc = grad_buffer(weight)
+        bbuf = bacc = None
+        if bias is not None and bias.requires_grad:
+            if getattr(bias, "_mg_zero_grad", False) and not COMPUTE_DEAD_BIAS_GRADS:
+                _zero_grad_bias(bias)
             else:
-                ops.conv_wgrad(g, nhwc_view(gy), nhwc_view(x), wbuf, None, wacc)
-                if bbuf is not None:
-                    ops.colsum(nhwc_view(gy).reshape(-1, g.Ci), bbuf, bacc)
-            _notify(weight)
-            if bias is not None and bias.requires_grad:
-                _notify(bias)
-        return dx, None, None, None
+                bbuf, bacc = grad_buffer(bias)
+        if not transposed:
+            if bbuf is not None and bacc != wacc:      # keep one accumulate flag per launch
+                ops.colsum(nhwc_view(gy).reshape(-1, g.Co), bbuf, bacc)
+                bbuf = None
+            # Winograd images come as a pair; the float16 copies of the implicit-GEMM layers are independent
+            v = getattr(ctx, "v", None) if (md is not None or ops.tiles_are_casts(g)) else None
+            ops.conv_wgrad(g, nhwc_view(x), nhwc_view(gy), wbuf, bbuf, wacc, v=v, md=md)
+            ctx.v = None
+        else:
+            ops.conv_wgrad(g, nhwc_view(gy), nhwc_view(x), wbuf, None, wacc)
+            if bbuf is not None:
+                ops.colsum(nhwc_view(gy).reshape(-1, g.Ci), bbuf, bacc)
+        _notify(weight)
+        if bias is not None and bias.requires_grad:
+            _notify(bias)
+    return dx
 
 
 def conv2d(x, weight, bias, stride=1, padding=0, reflect=False, act=ACT_NONE, weight_grad=True):
@@ -308,6 +313,53 @@ def conv_transpose2d(x, weight, bias, stride=2, padding=1, act=ACT_NONE, weight_
 # ------------------------------------------------------------------------------------------------
 # instance norm (+ activation, + residual)
 # ------------------------------------------------------------------------------------------------
+class _ConvInstNormFn(torch.autograd.Function):
+    """y = act(InstanceNorm2d(conv(x, w) + b)) + residual as ONE node (ResnetBlock's two conv / norm pairs,
+    models/networks.py:440-462): forward is ops.conv_fwd_instnorm -- the Winograd inverse transform, the statistics and
+    the normalisation in one kernel on the trunk's small maps -- backward is the InstanceNorm backward followed by the
+    convolution's (_conv_backward), exactly what the two separate nodes do."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, cfg):
+        x = to_cl(x)
+        pad, reflect, weight_grad, act, eps = cfg
+        res = to_cl(residual) if residual is not None else None
+        B, _, H, W = x.shape
+        w = weight.detach()
+        assert w.is_contiguous(memory_format=CL), "conv weights must be channels_last (OHWI) tensors"
+        g = ops.conv_geom(B, H, W, w.shape[1], w.shape[0], w.shape[2], w.shape[3], 1, pad, reflect, amp.current_precision())
+        if ctx.needs_input_grad[0]:
+            u = _weight_image(g, weight)
+        elif x.is_cuda and not torch.is_grad_enabled():
+            u = _cached_wino_weights(g, weight, fill=not torch.cuda.is_current_stream_capturing())
+        else:
+            u = None
+        v = None
+        if u is not None and weight_grad and weight.requires_grad:
+            v, _ = ops.wino_tile_buffers(g, x.device, want_md=False)
+        y, y_raw, mean, rstd = ops.conv_fwd_instnorm(g, nhwc_view(x), w, bias.detach() if bias is not None else None, act,
+                                                     nhwc_view(res) if res is not None else None, eps, u, v)
+        ctx.u, ctx.v = u, v
+        ctx.g, ctx.cfg = g, (1, pad, reflect, ACT_NONE, False, weight_grad)
+        ctx.weight, ctx.bias, ctx.norm_act = weight, bias, act
+        ctx.save_for_backward(x, nchw_view(y_raw), mean, rstd)
+        return nchw_view(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y_raw, mean, rstd = ctx.saved_tensors
+        gy = to_cl(gy)
+        d_raw = nchw_view(ops.instnorm_bwd(nhwc_view(gy), nhwc_view(y_raw), mean, rstd, ctx.norm_act))
+        dx = _conv_backward(ctx, d_raw, x, None)
+        dres = gy if ctx.needs_input_grad[3] else None
+        return dx, None, None, dres, None
+
+
+def conv_instnorm(x, weight, bias, padding=0, reflect=False, act=ACT_NONE, residual=None, eps=1e-5, weight_grad=True):
+    """act(InstanceNorm2d(affine=False)(conv2d(x, weight, bias, stride 1))) + residual."""
+    return _ConvInstNormFn.apply(x, weight, bias, residual, (padding, bool(reflect), weight_grad, act, eps))
+
+
 class _InstNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, act, eps):

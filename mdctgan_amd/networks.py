@@ -283,10 +283,8 @@ class ResnetBlock(nn.Module):
 
     def forward(self, x, weight_grad=True):
         cb = self.conv_block
-        h = cb[1](x, 1, ACT_NONE, weight_grad)
-        h = Fh.instance_norm_act(h, ACT_RELU, None, cb[2].eps)
-        h = cb[5](h, 1, ACT_NONE, weight_grad)
-        return Fh.instance_norm_act(h, ACT_NONE, x, cb[6].eps)
+        h = Fh.conv_instnorm(x, cb[1].weight, cb[1].bias, 1, True, ACT_RELU, None, cb[2].eps, weight_grad)
+        return Fh.conv_instnorm(h, cb[5].weight, cb[5].bias, 1, True, ACT_NONE, x, cb[6].eps, weight_grad)
 
 
 class ConvResBlock(nn.Module):

@@ -106,6 +106,25 @@ def conv_fwd(g: ConvGeom, x, w, bias=None, act=ACT_NONE, u=None, v_out=None):
     return y
 
 
+def conv_fwd_instnorm(g: ConvGeom, x, w, bias=None, act=ACT_NONE, residual=None, eps=1e-5, u=None, v_out=None):
+    """conv + InstanceNorm2d(affine=False) (+ act, + residual) -> (y, y_raw, mean, rstd); one kernel does the Winograd
+    inverse transform and the normalisation when the layer and the map size allow (csrc/wino.h: wino_out_norm_kernel)."""
+    lib = _lib.load()
+    y_raw = torch.empty(g.B, g.OH, g.OW, g.Co, dtype=torch.float32, device=x.device)
+    y = torch.empty_like(y_raw)
+    mean = torch.empty(g.B, g.Co, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(g.B, g.Co, dtype=torch.float32, device=x.device)
+    ws = _ws(lib.mg_conv_fwd_instnorm_workspace(g), x.device)
+    if PROFILER is not None:
+        PROFILER.begin(0, g)
+    _lib.check(lib.mg_conv_fwd_instnorm_w(g, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y_raw), eps, act,
+                                          _lib.ptr(residual), _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(ws),
+                                          ws.numel(), _lib.stream(), _tiles(u, v_out, None)), "mg_conv_fwd_instnorm")
+    if PROFILER is not None:
+        PROFILER.end()
+    return y, y_raw, mean, rstd
+
+
 def conv_dgrad(g: ConvGeom, dy, w, bias=None, act=ACT_NONE, u=None, md_out=None, out=None):
     lib = _lib.load()
     dx = torch.empty(g.B, g.H, g.W, g.Ci, dtype=torch.float32, device=dy.device) if out is None else out

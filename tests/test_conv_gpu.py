@@ -15,6 +15,7 @@ def batched_wino_gemm(name):
     return name.startswith("dgemm32") or "5>" in name
 
 DEV = "cuda"
+ACT_RELU_ = 1          # MG_ACT_RELU (include/mdctgan_hip.h)
 
 # (name, B, Ci, H, W, Co, k, stride, pad, reflect)
 CONV_CASES = [
@@ -263,3 +264,32 @@ def test_winograd4_shared_images():
     ops.conv_wgrad(g, x, dy, dw1, None, v=v, md=md)
     assert torch.equal(dw0, dw1)
     assert batched_wino_gemm(ops.plan_name(1, g))   # the batched 25-position Winograd-domain GEMM
+
+
+@pytest.mark.parametrize("case", [("trunk_like_wino", 8, 128, 8, 16, ACT_RELU_, True), ("trunk_tiny_4x8", 4, 256, 4, 8, 0, True),
+                                  ("bigger_map_16x32", 2, 128, 16, 32, 0, False), ("fallback_direct", 2, 16, 8, 16, ACT_RELU_, True)],
+                         ids=lambda c: c[0])
+def test_conv_fwd_instnorm_matches_separate_calls(case):
+    """mg_conv_fwd_instnorm_w (the Winograd inverse transform, the InstanceNorm statistics and the apply in one kernel on small
+    maps; csrc/wino.h::wino_out_norm_kernel) == mg_conv_fwd_w followed by mg_instnorm_fwd."""
+    from mdctgan_amd import ops
+    name, B, C, H, W, act, with_res = case
+    gen = torch.Generator().manual_seed(len(name))
+    x = torch.randn(B, H, W, C, generator=gen).to(DEV)
+    w = (torch.randn(C, 3, 3, C, generator=gen) / np.sqrt(9 * C)).to(DEV)
+    b = torch.randn(C, generator=gen).to(DEV)
+    res = torch.randn(B, H, W, C, generator=gen).to(DEV) if with_res else None
+    g = ops.conv_geom(B, H, W, C, C, 3, 3, 1, 1, True)
+    y0 = ops.conv_fwd(g, x, w, b)
+    n0, m0, r0 = ops.instnorm_fwd(y0, act, res, 1e-5)
+    y, y_raw, mean, rstd = ops.conv_fwd_instnorm(g, x, w, b, act, res, 1e-5)
+    assert torch.equal(y_raw, y0)                                   # the same inverse transform arithmetic
+    assert (mean - m0).abs().max().item() <= 1e-6 * (m0.abs().max().item() + 1.0)
+    assert (rstd - r0).abs().max().item() <= 2e-6 * r0.abs().max().item()
+    assert (y - n0).abs().max().item() <= 1e-5 * (n0.abs().max().item() + 1.0)
+    # with the caller-held Winograd images (u, v) as the training step passes them
+    u = ops.wino_weights(g, w)
+    if u is not None:
+        v, _ = ops.wino_tile_buffers(g, x.device, want_md=False)
+        y2, yr2, _, _ = ops.conv_fwd_instnorm(g, x, w, b, act, res, 1e-5, u=u, v_out=v)
+        assert torch.equal(yr2, y_raw) and torch.equal(y2, y)
