@@ -195,6 +195,14 @@ size_t mg_conv_fwd_instnorm_workspace(const mg_conv_geom* g);
 int mg_conv_fwd_instnorm_w(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y_raw, float eps,
                            int act, const float* residual, float* y, float* mean, float* rstd, void* workspace,
                            size_t workspace_bytes, void* stream, const mg_wino_tiles* wt);
+/* The backward mirror: for a layer with mg_conv_wino_md_from_norm_ok(g) != 0, mg_instnorm_bwd_wino_md turns the gradient gy at
+ * the InstanceNorm output (y_raw, mean, rstd, act as saved by mg_conv_fwd_instnorm_w) straight into md = A dy A^T, the
+ * Winograd image of the gradient at the convolution output (mg_conv_wino_tiles_bytes(g, 1) bytes) -- InstanceNorm backward
+ * and the data gradient's first transform in one kernel; dy itself is never written.  mg_conv_dgrad_w(g, dy = NULL, ...,
+ * wt->md = md) and mg_conv_wgrad_w(g, x = NULL, dy = NULL, ..., dbias = NULL, wt->v, wt->md) then start from the images. */
+int mg_conv_wino_md_from_norm_ok(const mg_conv_geom* g);
+int mg_instnorm_bwd_wino_md(const mg_conv_geom* g, const float* gy, const float* y_raw, const float* mean, const float* rstd,
+                            int act, float* md, void* stream);
 int mg_conv_dgrad_w(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
                     void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* tiles);
 /* dw [Co, KH, KW, Ci] = sum over pixels; dbias [Co] (nullable) = column sums of dy.

@@ -54,6 +54,8 @@ SIGNATURES = {
     "mg_conv_wino_tiles_bytes": (_sz, [_G, _i]),
     "mg_conv_fwd_w": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p, _W]),
     "mg_conv_fwd_instnorm_workspace": (_sz, [_G]),
+    "mg_conv_wino_md_from_norm_ok": (_i, [_G]),
+    "mg_instnorm_bwd_wino_md": (_i, [_G, _p, _p, _p, _p, _i, _p, _p]),
     "mg_conv_fwd_instnorm_w": (_i, [_G, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _sz, _p, _W]),
     "mg_conv_dgrad_w": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p, _W]),
     "mg_conv_wgrad_w": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p, _W]),

@@ -1785,8 +1785,9 @@ int wino_dgrad_t(const mg_conv_geom* g, const float* dy, const float* w, const f
     else hipLaunchKernelGGL(wino_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 4)), dim3(256), 0, st, w,
                             g->Co, g->Ci, U);
     if (md_keep) Md = md_keep;       // the caller keeps A dy A^T for the weight gradient
-    hipLaunchKernelGGL(wino_dy_xform_kernel, dim3(wino_grid((size_t)T * g->Co / 4)), dim3(256), 0, st, dy, g->B, d.TH,
-                       d.TW, g->Co, Md);
+    if (dy)                          // dy == nullptr: md_keep already holds it (mg_instnorm_bwd_wino_md)
+        hipLaunchKernelGGL(wino_dy_xform_kernel, dim3(wino_grid((size_t)T * g->Co / 4)), dim3(256), 0, st, dy, g->B, d.TH,
+                           d.TW, g->Co, Md);
     if (!dense_wino_gemm(1, 16, T, g->Co, g->Ci, Md, U, dV, part, prec_h(g), st)) {
     const Geom gg{1, 1, (int)T, g->Ci, 1, (int)T, g->Co, 1, 1, 1, 0, 0};
     const TilePlan tp = gemm_plan(T, g->Ci, g->Co / BK, 16, true, 1);
@@ -2644,6 +2645,25 @@ int mg_conv_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float*
     return mg_conv_wgrad_w(g, x, dy, dw, dbias, accumulate, workspace, workspace_bytes, stream, nullptr);
 }
 
+int mg_conv_wino_md_from_norm_ok(const mg_conv_geom* g) {
+    return (geom_ok(g) && wino_ok(g) && !prec_h(g) && !mg_conv_rowdot_kq(g) && !wino_dgrad_padded() &&
+            wino_out_norm_ok(g->OH / 2, g->OW / 2, g->Co)) ? 1 : 0;
+}
+int mg_instnorm_bwd_wino_md(const mg_conv_geom* g, const float* gy, const float* y_raw, const float* mean, const float* rstd,
+                            int act, float* md, void* stream) {
+    if (!gy || !y_raw || !mean || !rstd || !md) return MG_ERR_ARG;
+    if (!mg_conv_wino_md_from_norm_ok(g)) return MG_ERR_UNSUPPORTED;
+    if (!aligned16(gy) || !aligned16(y_raw) || !aligned16(mean) || !aligned16(rstd) || !aligned16(md)) return MG_ERR_ARG;
+    const WinoDims d = wino_dims(g);
+    const dim3 grid(g->Co / 32, g->B);
+    const int nt = (d.TH * d.TW + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+#define MG_NORM_BWD_DY(NT_) hipLaunchKernelGGL(wino_norm_bwd_dy_kernel<NT_>, grid, dim3(256), 0, st, gy, y_raw, mean, rstd, g->B, d.TH, d.TW, g->Co, act, md)
+    if (nt == 1) MG_NORM_BWD_DY(1); else if (nt == 2) MG_NORM_BWD_DY(2); else if (nt == 3) MG_NORM_BWD_DY(3); else if (nt == 4) MG_NORM_BWD_DY(4); else MG_NORM_BWD_DY(5);
+#undef MG_NORM_BWD_DY
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
 size_t mg_conv_fwd_instnorm_workspace(const mg_conv_geom* g) {
     if (!geom_ok(g)) return 0;
     const size_t a = mg_conv_fwd_workspace(g), b = mg_instnorm_workspace(g->B, g->OH * g->OW, g->Co);
@@ -2775,8 +2795,12 @@ int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const f
 
 int mg_conv_dgrad_w(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
                     void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* wt) {
-    if (!geom_ok(g) || !dy || !w || !dx) return MG_ERR_ARG;
+    if (!geom_ok(g) || !w || !dx) return MG_ERR_ARG;
     if (!wino_tiles_ok(g, wt)) return MG_ERR_ARG;
+    // dy == NULL: wt->md already holds A dy A^T (mg_instnorm_bwd_wino_md) -- F(2x2,3x3) layers in the transposed formulation
+    if (!dy && !(wt && wt->md && mg_conv_wino_md_from_norm_ok(g) && !bias && act == MG_ACT_NONE && workspace &&
+                 workspace_bytes >= wino_dgrad_ws(g) && aligned16(w) && aligned16(dx) && aligned16(workspace)))
+        return MG_ERR_ARG;
     const float* u = wt ? wt->u : nullptr;
     if (g->reflect && g->stride != 1) return MG_ERR_UNSUPPORTED;
     if (h16_ok(g) && !bias && act == MG_ACT_NONE && workspace && workspace_bytes >= h16_dgrad_ws(g) && aligned16(dy) &&
@@ -2909,8 +2933,11 @@ size_t mg_conv_wgrad_workspace(const mg_conv_geom* g) {
 
 int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias, int accumulate,
                     void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* wt) {
-    if (!geom_ok(g) || !x || !dy || !dw) return MG_ERR_ARG;
+    if (!geom_ok(g) || !dw) return MG_ERR_ARG;
     if (!wino_tiles_ok(g, wt)) return MG_ERR_ARG;
+    // x / dy may be NULL when the caller hands over both Winograd images of an F(2x2,3x3) layer (no bias gradient then)
+    if ((!x || !dy) && !(wt && wt->v && wt->md && mg_conv_wino_md_from_norm_ok(g) && !dbias && aligned16(dw) && aligned16(workspace)))
+        return MG_ERR_ARG;
     if (workspace_bytes < mg_conv_wgrad_workspace(g) || !workspace) return MG_ERR_ARG;
     if (co1_gemm_ok(g) && aligned16(x) && aligned16(workspace))
         return co1_wgrad(g, x, dy, dw, dbias, accumulate, (char*)workspace, (hipStream_t)stream, wt ? wt->v : nullptr, wt ? wt->md : nullptr);

@@ -260,6 +260,110 @@ __global__ __launch_bounds__(256) void wino_out_norm_kernel(const float* __restr
         }
     }
 }
+
+// ---- InstanceNorm backward fused with the data gradient's A dy A^T transform ------------------------------------------------
+// The mirror of wino_out_norm_kernel: a workgroup owns a (sample, 32-channel) slab, a thread NT tiles of 2x2 pixels.  It
+// reads the gradient at the norm's output and the raw convolution output, reduces the two InstanceNorm backward sums over
+// the slab, forms the gradient at the convolution output in registers and writes its Winograd image Md = A dy A^T
+// directly -- the convolution-output gradient itself never goes to HBM (the data and weight gradients both start from Md).
+// Same arithmetic as norm_slab_bwd_kernel followed by wino_dy_xform_kernel.
+template <int NT>
+__global__ __launch_bounds__(256) void wino_norm_bwd_dy_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               int B, int TH, int TW, int C, int act, float* __restrict__ Md) {
+    __shared__ double red[2][32][32];
+    const int cq = threadIdx.x & 7, tl = threadIdx.x >> 3;
+    const int b = blockIdx.y, c0 = blockIdx.x * 32 + 4 * cq;
+    const int Ts = TH * TW, HW = 4 * Ts;
+    const size_t T = (size_t)B * Ts;
+    const float4 mu4 = ld4(mean + (size_t)b * C + c0), rs4 = ld4(rstd + (size_t)b * C + c0);
+    const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, rs[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
+    float xh[NT][4][4], gq[NT][4][4];          // [tile][pixel q = 2r + c][channel]
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int tile = tl + 32 * i;
+        if (tile < Ts) {
+            const int ty = tile / TW, tx = tile - ty * TW;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const size_t off = ((size_t)(b * 2 * TH + 2 * ty + (q >> 1)) * (2 * TW) + 2 * tx + (q & 1)) * C + c0;
+                float xv[4], gv[4];
+                *reinterpret_cast<float4*>(xv) = ld4(x + off);
+                *reinterpret_cast<float4*>(gv) = ld4(gy + off);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xh[i][q][j] = (xv[j] - mu[j]) * rs[j];
+                    const float d = act == MG_ACT_RELU ? (xh[i][q][j] > 0.0f ? 1.0f : 0.0f)
+                                  : act == MG_ACT_LRELU02 ? (xh[i][q][j] > 0.0f ? 1.0f : 0.2f) : 1.0f;
+                    gq[i][q][j] = gv[j] * d;
+                    s1[j] += (double)gq[i][q][j];
+                    s2[j] += (double)gq[i][q][j] * (double)xh[i][q][j];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xh[i][q][j] = gq[i][q][j] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[0][tl][4 * cq + j] = s1[j];
+        red[1][tl][4 * cq + j] = s2[j];
+    }
+    __syncthreads();
+    {
+        const int c = threadIdx.x & 31, part = threadIdx.x >> 5;
+        double a = 0.0, bsum = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a += red[0][4 * part + i][c];
+            bsum += red[1][4 * part + i][c];
+        }
+        __syncthreads();
+        red[0][part][c] = a;
+        red[1][part][c] = bsum;
+    }
+    __syncthreads();
+    float m1[4], m2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double x1 = 0.0, x2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            x1 += red[0][i][4 * cq + j];
+            x2 += red[1][i][4 * cq + j];
+        }
+        m1[j] = (float)(x1 / HW);
+        m2[j] = (float)(x2 / HW);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int tile = tl + 32 * i;
+        if (tile < Ts) {
+            float4 d[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = rs[j] * (gq[i][q][j] - m1[j] - xh[i][q][j] * m2[j]);
+                d[q] = make_float4(o[0], o[1], o[2], o[3]);
+            }
+            const float4 y00 = d[0], y01 = d[1], y10 = d[2], y11 = d[3];
+            float4 tmp[4][2] = {{y00, y01}, {f4add(y00, y10), f4add(y01, y11)}, {f4sub(y00, y10), f4sub(y01, y11)},
+                                {f4neg(y10), f4neg(y11)}};
+            const size_t t = (size_t)b * Ts + tile;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 o[4] = {tmp[r][0], f4add(tmp[r][0], tmp[r][1]), f4sub(tmp[r][0], tmp[r][1]), f4neg(tmp[r][1])};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) *reinterpret_cast<float4*>(Md + ((size_t)(r * 4 + c) * T + t) * C + c0) = o[c];
+            }
+        }
+    }
+}
 inline bool wino_out_norm_ok(int TH, int TW, int C) {
     static const bool off = getenv("MG_NO_WINO_NORM_FUSION") != nullptr;
     return !off && C % 32 == 0 && TH * TW <= 160;

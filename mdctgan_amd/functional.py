@@ -349,9 +349,29 @@ class _ConvInstNormFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, y_raw, mean, rstd = ctx.saved_tensors
         gy = to_cl(gy)
+        dres = gy if ctx.needs_input_grad[3] else None
+        g, weight, bias = ctx.g, ctx.weight, ctx.bias
+        weight_grad = ctx.cfg[5]
+        dead_bias = bias is None or not bias.requires_grad or (getattr(bias, "_mg_zero_grad", False) and not COMPUTE_DEAD_BIAS_GRADS)
+        u, v = getattr(ctx, "u", None), getattr(ctx, "v", None)
+        if (ctx.needs_input_grad[0] and weight_grad is True and weight.requires_grad and dead_bias and u is not None
+                and v is not None and ops.wino_md_from_norm_ok(g)):
+            # InstanceNorm backward and the A dy A^T transform in one kernel; data and weight gradient start from the images
+            _, md = ops.wino_tile_buffers(g, gy.device, want_v=False)
+            ops.instnorm_bwd_wino_md(g, nhwc_view(gy), nhwc_view(y_raw), mean, rstd, ctx.norm_act, md)
+            w = weight.detach()
+            dx = nchw_view(ops.conv_dgrad(g, None, w, u=u, md_out=md))
+            wbuf, wacc = grad_buffer(weight)
+            if bias is not None and bias.requires_grad:
+                _zero_grad_bias(bias)
+            ops.conv_wgrad(g, None, None, wbuf, None, wacc, v=v, md=md)
+            ctx.u = ctx.v = None
+            _notify(weight)
+            if bias is not None and bias.requires_grad:
+                _notify(bias)
+            return dx, None, None, dres, None
         d_raw = nchw_view(ops.instnorm_bwd(nhwc_view(gy), nhwc_view(y_raw), mean, rstd, ctx.norm_act))
         dx = _conv_backward(ctx, d_raw, x, None)
-        dres = gy if ctx.needs_input_grad[3] else None
         return dx, None, None, dres, None
 
 

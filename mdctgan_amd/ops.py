@@ -125,10 +125,26 @@ def conv_fwd_instnorm(g: ConvGeom, x, w, bias=None, act=ACT_NONE, residual=None,
     return y, y_raw, mean, rstd
 
 
+def wino_md_from_norm_ok(g: ConvGeom) -> bool:
+    """True when instnorm_bwd_wino_md can produce this layer's A dy A^T image (F(2x2,3x3) layer, small map)."""
+    key = ("mdn", g.B, g.H, g.W, g.Ci, g.Co, g.KH, g.KW, g.stride, g.pad, g.reflect, g.precision)
+    hit = _CASTS.get(key)
+    if hit is None:
+        hit = _CASTS[key] = bool(_lib.load().mg_conv_wino_md_from_norm_ok(g))
+    return hit
+
+
+def instnorm_bwd_wino_md(g: ConvGeom, gy, y_raw, mean, rstd, act, md):
+    """InstanceNorm backward + the data gradient's A dy A^T transform in one kernel: fills md, writes no dy."""
+    _lib.check(_lib.load().mg_instnorm_bwd_wino_md(g, _lib.ptr(gy), _lib.ptr(y_raw), _lib.ptr(mean), _lib.ptr(rstd), act,
+                                                   _lib.ptr(md), _lib.stream()), "mg_instnorm_bwd_wino_md")
+
+
 def conv_dgrad(g: ConvGeom, dy, w, bias=None, act=ACT_NONE, u=None, md_out=None, out=None):
+    """dy None: md_out already holds the layer's A dy A^T image (instnorm_bwd_wino_md)."""
     lib = _lib.load()
-    dx = torch.empty(g.B, g.H, g.W, g.Ci, dtype=torch.float32, device=dy.device) if out is None else out
-    ws = _ws(lib.mg_conv_dgrad_workspace(g), dy.device)
+    dx = torch.empty(g.B, g.H, g.W, g.Ci, dtype=torch.float32, device=w.device) if out is None else out
+    ws = _ws(lib.mg_conv_dgrad_workspace(g), w.device)
     if PROFILER is not None:
         PROFILER.begin(1, g)
     _lib.check(lib.mg_conv_dgrad_w(g, _lib.ptr(dy), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(dx), act, _lib.ptr(ws),
@@ -142,7 +158,7 @@ def conv_wgrad(g: ConvGeom, x, dy, dw, dbias=None, accumulate=False, v=None, md=
     """dw: float32 buffer of Co*KH*KW*Ci elements in OHWI order (written / accumulated in place)."""
     lib = _lib.load()
     nbytes = lib.mg_conv_wgrad_workspace(g)
-    ws = _ws(nbytes, x.device)
+    ws = _ws(nbytes, dw.device)
     if PROFILER is not None:
         PROFILER.begin(2, g)
     _lib.check(lib.mg_conv_wgrad_w(g, _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(dbias), int(accumulate),

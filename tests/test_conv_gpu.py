@@ -293,3 +293,34 @@ def test_conv_fwd_instnorm_matches_separate_calls(case):
         v, _ = ops.wino_tile_buffers(g, x.device, want_md=False)
         y2, yr2, _, _ = ops.conv_fwd_instnorm(g, x, w, b, act, res, 1e-5, u=u, v_out=v)
         assert torch.equal(yr2, y_raw) and torch.equal(y2, y)
+
+
+@pytest.mark.parametrize("case", [("trunk_like", 8, 128, 8, 16, ACT_RELU_), ("trunk_tiny_4x8", 4, 256, 4, 8, 0), ("map_16x32", 2, 128, 16, 32, 0)],
+                         ids=lambda c: c[0])
+def test_instnorm_bwd_wino_md_matches_separate_calls(case):
+    """mg_instnorm_bwd_wino_md (InstanceNorm backward + A dy A^T in one kernel, no dy in HBM) followed by the data / weight
+    gradient from the images == mg_instnorm_bwd, then the two gradients from dy."""
+    from mdctgan_amd import ops
+    name, B, C, H, W, act = case
+    gen = torch.Generator().manual_seed(3 + len(name))
+    x = torch.randn(B, H, W, C, generator=gen).to(DEV)
+    w = (torch.randn(C, 3, 3, C, generator=gen) / np.sqrt(9 * C)).to(DEV)
+    gy = torch.randn(B, H, W, C, generator=gen).to(DEV)
+    g = ops.conv_geom(B, H, W, C, C, 3, 3, 1, 1, True)
+    assert ops.wino_md_from_norm_ok(g)
+    u = ops.wino_weights(g, w)
+    v, md1 = ops.wino_tile_buffers(g, x.device)
+    _, md2 = ops.wino_tile_buffers(g, x.device, want_v=False)
+    y, y_raw, mean, rstd = ops.conv_fwd_instnorm(g, x, w, None, act, None, 1e-5, u=u, v_out=v)
+    d_raw = ops.instnorm_bwd(gy, y_raw, mean, rstd, act)
+    dx1 = ops.conv_dgrad(g, d_raw, w, u=u, md_out=md1)
+    dw1 = torch.empty(C, 3, 3, C, device=DEV)
+    ops.conv_wgrad(g, x, d_raw, dw1, None, v=v, md=md1)
+    ops.instnorm_bwd_wino_md(g, gy, y_raw, mean, rstd, act, md2)
+    dx2 = ops.conv_dgrad(g, None, w, u=u, md_out=md2)
+    dw2 = torch.empty_like(dw1)
+    ops.conv_wgrad(g, None, None, dw2, None, v=v, md=md2)
+    scale = md1.abs().max().item()
+    assert (md1 - md2).abs().max().item() <= 2e-6 * scale
+    assert (dx1 - dx2).abs().max().item() <= 1e-5 * dx1.abs().max().item()
+    assert (dw1 - dw2).abs().max().item() <= 1e-5 * dw1.abs().max().item()
