@@ -1814,6 +1814,18 @@ int wino_dgrad_t(const mg_conv_geom* g, const float* dy, const float* w, const f
                            n, g->Ci, (const float*)nullptr, MG_ACT_NONE, dV);
     }
     }
+    if (!prec_h(g) && wino_dd_gather_ok(g->H, g->W, g->Ci)) {      // small maps: patches through LDS, one kernel
+        const int ts = (g->H / 2) * (g->W / 2);
+        const size_t lds = (size_t)ts * 16 * 8 * sizeof(float4);
+        const dim3 grid(g->Ci / 32, g->B);
+        auto go = [&](auto kern) {
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const float*)dV, g->B, g->H, g->W, g->Ci, g->reflect, bias, act, dx);
+        };
+        if (ts <= 32) go(wino_dd_gather_kernel<1>); else go(wino_dd_gather_kernel<2>);
+        MG_CHECK_LAUNCH();
+        return MG_OK;
+    }
     hipLaunchKernelGGL(wino_dd_xform_kernel, dim3(wino_grid((size_t)T * g->Ci / 4)), dim3(256), 0, st, (const float*)dV, T,
                        g->Ci, dd);
     hipLaunchKernelGGL(wino_dx_gather_kernel, dim3(wino_grid((size_t)g->B * g->H * g->W * g->Ci / 4)), dim3(256), 0, st,

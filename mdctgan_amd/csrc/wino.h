@@ -479,6 +479,65 @@ __global__ void wino_dx_gather_kernel(const float* __restrict__ dd, int B, int H
     }
 }
 
+
+// dd transform + gather in one kernel for small maps: a workgroup owns a (sample, 32-channel) slab, computes the B dV B^T
+// patches of all its tiles into LDS ([tile][16][32 channels], 2 KiB per tile) and gathers dx from there -- the same terms
+// in the same order as wino_dd_xform_kernel + wino_dx_gather_kernel (bit-identical), without the dd round trip through HBM.
+template <int NT>
+__global__ __launch_bounds__(256) void wino_dd_gather_kernel(const float* __restrict__ dV, int B, int H, int W, int C, int reflect,
+                                                             const float* __restrict__ bias, int act, float* __restrict__ dx) {
+    extern __shared__ __attribute__((aligned(16))) float4 wdg_lds[];     // [Ts][16][8]
+    const int cq = threadIdx.x & 7, tl = threadIdx.x >> 3;
+    const int b = blockIdx.y, c0 = blockIdx.x * 32 + 4 * cq;
+    const int TH = H / 2, TW = W / 2, Ts = TH * TW;
+    const size_t T = (size_t)B * Ts;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int tile = tl + 32 * i;
+        if (tile < Ts) {
+            const size_t t = (size_t)b * Ts + tile;
+            float4 v[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[r][c] = ld4(dV + ((size_t)(r * 4 + c) * T + t) * C + c0);
+            float4 tmp[4][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float4 o[4];
+                b4(v[0][c], v[1][c], v[2][c], v[3][c], o);
+                tmp[0][c] = o[0]; tmp[1][c] = o[1]; tmp[2][c] = o[2]; tmp[3][c] = o[3];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float4 o[4];
+                b4(tmp[r][0], tmp[r][1], tmp[r][2], tmp[r][3], o);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) wdg_lds[(tile * 16 + r * 4 + c) * 8 + cq] = o[c];
+            }
+        }
+    }
+    __syncthreads();
+    const int HW = H * W;
+    const float4 bv = bias ? ld4(bias + c0) : zero4();
+    for (int p = tl; p < HW; p += 32) {
+        const int iy = p / W, ix = p - iy * W;
+        int ty[3], ry[3], tx[3], rx[3];
+        const int ny = wino_sources(iy, H, TH, reflect, ty, ry), nx = wino_sources(ix, W, TW, reflect, tx, rx);
+        float4 s = bv;
+        float4 acc = zero4();
+        for (int a = 0; a < ny; ++a)
+            for (int c = 0; c < nx; ++c) add4(acc, wdg_lds[((ty[a] * TW + tx[c]) * 16 + ry[a] * 4 + rx[c]) * 8 + cq]);
+        add4(s, acc);
+        s.x = apply_act(s.x, act); s.y = apply_act(s.y, act); s.z = apply_act(s.z, act); s.w = apply_act(s.w, act);
+        *reinterpret_cast<float4*>(dx + ((size_t)b * HW + p) * C + c0) = s;
+    }
+}
+inline bool wino_dd_gather_ok(int H, int W, int C) {
+    static const bool off = getenv("MG_NO_WINO_DD_GATHER_FUSION") != nullptr;
+    return !off && C % 32 == 0 && (H / 2) * (W / 2) <= 64;
+}
+
 // Mdy[16][T][C] = A dy A^T for the 2x2 tiles of dy [B][2TH][2TW][C]
 __global__ void wino_dy_xform_kernel(const float* __restrict__ dy, int B, int TH, int TW, int C, float* __restrict__ Md) {
     const int C4 = C / 4;
