@@ -371,11 +371,15 @@ def main():
         tr = os.path.join(REPO, "profiles", "traffic.json")     # HBM bytes/launch from rocprofv3 --pmc passes
         if os.path.exists(tr):
             try:
-                roofline["traffic"] = json.load(open(tr)).get(dominant)
+                # the same symbol runs on other layer shapes in the other configurations: one section per bench line
+                section = "configs[%d]%s" % (args.config, " --fp16" if args.fp16 else "")
+                doc = json.load(open(tr))
+                table = doc.get(section) or (doc if section == "configs[1]" else {})
+                roofline["traffic"] = table.get(dominant)
                 roofline["traffic_definition"] = ("HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 from separate "
                                                   "rocprofv3 --pmc passes on this kernel at this layer shape (gfx950 reports "
                                                   "half of a wide coalesced read: MI355X_MICROARCH.md, HBM section); "
-                                                  "source file named in profiles/traffic.json[\"_source\"]")
+                                                  "profiles/traffic.json section \"%s\", source file in its \"_source\"" % section)
             except Exception:
                 pass
 

@@ -17,6 +17,7 @@ SHAPES = {   # name: (B, H, W, Ci, Co, k, stride, pad, reflect)
     "d1_256_512": (8, 9, 17, 256, 512, 4, 1, 2, False),     # second discriminator scale (64x128 input)
     "d1_128_256": (8, 17, 33, 128, 256, 4, 2, 2, False),
     "d1_64_128": (8, 33, 65, 64, 128, 4, 2, 2, False),
+    "bottleneck_b64": (64, 8, 16, 1024, 1024, 3, 1, 1, True),   # configs[4]: the same layer at the inference batch
     "trunk2048": (8, 4, 8, 2048, 2048, 3, 1, 1, True),      # configs[2]: trunk ResNet blocks of the LocalEnhancer
     "local128": (8, 64, 128, 128, 128, 3, 1, 1, True),      #             half-resolution local blocks
     "down1024": (8, 8, 16, 1024, 2048, 3, 2, 1, False),     #             last rung of its 64 -> 2048 ladder

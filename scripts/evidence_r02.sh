@@ -15,5 +15,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_cfg4 -o t -- python
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python $R/scripts/bench_conv.py --only bottleneck --iters 2 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python $R/scripts/bench_conv.py --only bottleneck --iters 2 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $O/pmc_sq -o s -- python $R/scripts/bench_conv.py --only bottleneck --iters 2 > /dev/null 2>&1
+# HBM traffic of the dominant kernels of the other bench lines (same symbols, other layer shapes)
+for spec in "c1h:bottleneck:--f16" "c2:trunk2048:" "c2h:trunk2048:--f16" "c4:bottleneck_b64:"; do
+  tag=${spec%%:*}; rest=${spec#*:}; layer=${rest%%:*}; flag=${rest#*:}
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$tag -o f -- python $R/scripts/bench_conv.py --only $layer --iters 2 $flag > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$tag -o w -- python $R/scripts/bench_conv.py --only $layer --iters 2 $flag > /dev/null 2>&1
+done
 find $O -name "*_kernel_trace.csv" -delete
 ls -R $O | head -60

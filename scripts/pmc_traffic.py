@@ -1,9 +1,11 @@
 """Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, see profiles/README.md) over
 scripts/bench_conv.py into per-kernel HBM bytes per launch: (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 correction
 of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE reports half the bytes of wide coalesced reads).
-    python scripts/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.csv> <traffic.json>
-traffic.json also gets "_source": the csv the numbers came from (bench.py copies traffic.json[dominant kernel] into
-roofline.traffic)."""
+    python scripts/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.csv> <traffic.json> [section]
+Without a section the top level of traffic.json is rewritten (the configs[1] float32 trunk layer) together with "_source",
+the csv the numbers came from.  With one ("configs[2] --fp16", "configs[4]", ...: the same kernels are launched on other
+layer shapes there) the numbers go under traffic.json[section], which also names its csv.  bench.py copies
+traffic.json[section of the run][dominant kernel] into roofline.traffic."""
 import csv, json, re, sys
 from collections import defaultdict
 
@@ -41,5 +43,12 @@ with open(sys.argv[3], "w") as fh:
         fh.write('"%s",%d,%s,%s,%d\n' % r)
 import os
 out["_source"] = "profiles/" + os.path.basename(sys.argv[3])
-json.dump(out, open(sys.argv[4], "w"), indent=1)
+if len(sys.argv) > 5:
+    doc = json.load(open(sys.argv[4])) if os.path.exists(sys.argv[4]) else {}
+    doc[sys.argv[5]] = out
+else:
+    old = json.load(open(sys.argv[4])) if os.path.exists(sys.argv[4]) else {}
+    doc = dict(out)
+    doc.update({k: v for k, v in old.items() if isinstance(v, dict)})      # keep the sections
+json.dump(doc, open(sys.argv[4], "w"), indent=1)
 print(json.dumps(out, indent=1))
