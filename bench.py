@@ -353,10 +353,17 @@ def main():
         f16_kernel = dominant.startswith("hgemm") or (     # float16 GEMMs (conv_h16.h), HALF / TAG bit 1 convolution instances
             dominant.startswith("conv_") and dominant.rstrip().endswith((", 2>", ", 3>", ", true>")))
         peak = PEAK_F16_MFMA_TFLOPS if f16_kernel else PEAK_F32_MFMA_TFLOPS
+        split = dominant.startswith("dgemm32g_kernel") and dominant.rstrip().endswith(", 1>")
+        if split:      # MG_F32_SPLIT=1: 8 bf16 piece products per float32 product, issued on the bf16 pipe
+            flops, achieved, peak = 8.0 * flops, 8.0 * achieved, PEAK_F16_MFMA_TFLOPS
         roofline = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                     "launches": n, "avg_launch_us": round(secs / n * 1e6, 2),
                     "flops_per_launch": flops / n,
+                    **({"f32_split": "MG_F32_SPLIT=1: float32 operands as three exact bf16 pieces each, 8 of the 9 piece products "
+                                     "on v_mfma_f32_32x32x16_bf16 with float32 accumulation; achieved / peak count those bf16 "
+                                     "MFMA FLOPs (8 x 2*M*N*K) against the dense bf16 peak; in float32-product terms the kernel "
+                                     "runs at %.1f TFLOP/s" % (achieved / 8.0)} if split else {}),
                     "flops_definition": "FLOPs the kernel itself issues (2*M*N*K of its GEMM, summed over the launches of this "
                                         "symbol).  dgemm32g_kernel<BM, BN, 2, 2, A, B, 2, P, 0> (csrc/dense_gemm.h) are the batched "
                                         "Winograd-domain GEMMs: layouts (A, B) = (0, 0) forward, (0, 1) data gradient, (1, 1) weight "

@@ -9,6 +9,8 @@ python $R/bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench
 python $R/bench.py --config 2 --fp16 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_cfg2_fp16_line.json 2>/dev/null
 python $R/bench.py --config 4 --steps 5 --warmup 2 > $O/bench_infer_cfg4_line.json 2>/dev/null
 python $R/bench.py --mode codec --steps 10 --warmup 2 > $O/bench_codec_line.json 2>/dev/null
+MG_F32_SPLIT=1 python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_train_f32split_line.json 2>/dev/null
+MG_F32_SPLIT=1 python $R/bench.py --config 4 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_infer_cfg4_f32split_line.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_train -o t -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_train_line_profiled.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_cfg2h -o t -- python $R/bench.py --config 2 --fp16 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_cfg2_fp16_line_profiled.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_cfg4 -o t -- python $R/bench.py --config 4 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_infer_cfg4_line_profiled.json 2>/dev/null
