@@ -1239,7 +1239,7 @@ inline int dense_splits(int pass, int P, long long T, int Co, int Kc, bool hp) {
     const DensePlan p = dense_plan(pass, P, T, Co, Kc, hp);
     return p.ok ? p.splits : 0;
 }
-// MG_F32_SPLIT=1 (opt-in, read per call so a test can flip it): the F(2x2,3x3) GEMMs multiply float32 operands as three
+// MG_F32_SPLIT=1 (opt-in, read per call so a test can flip it): the Winograd-domain GEMMs multiply float32 operands as three
 // exact bf16 pieces each on v_mfma_f32_32x32x16_bf16 (dense_gemm.h: dg_chunk_b8; 8 of the 9 piece products, float32
 // accumulation) -- float32-accurate results (error vs float64 1.3e-6 of the output scale against 1.5e-6 for
 // v_mfma_f32_32x32x2_f32) at half the MFMA cycles.  Off by default: the bench's float32 line is the float32 pipe.
@@ -1247,11 +1247,14 @@ inline bool f32_split() {
     const char* e = getenv("MG_F32_SPLIT");
     return e && e[0] == '1';
 }
-inline bool dense_split(const DensePlan& p, int P, int N) { return p.dma && P == 16 && N % 128 == 0 && f32_split(); }
+inline bool dense_split(const DensePlan& p, int P, int N) {
+    return p.dma && (P == 16 || P == 25) && N % 128 == 0 && f32_split();
+}
 template <int AL, int BL>
 void dense_launch(const DensePlan& p, const DgArgs& a, hipStream_t st) {
     if (dense_split(p, a.P, a.N)) {
-        dgemm32g_launch<128, 128, 2, 2, AL, BL, 2, 16, 1>(a, st);
+        if (a.P == 16) dgemm32g_launch<128, 128, 2, 2, AL, BL, 2, 16, 1>(a, st);
+        else dgemm32g_launch<128, 128, 2, 2, AL, BL, 2, 25, 1>(a, st);
     } else if (p.dma && a.P == 16) {
         if (p.bm == 128 && p.bn == 128) dgemm32g_launch<128, 128, 2, 2, AL, BL, 2, 16>(a, st);
         else if (p.bm == 64 && p.bn == 128) dgemm32g_launch<64, 128, 2, 2, AL, BL, 2, 16>(a, st);
@@ -1269,7 +1272,7 @@ void dense_launch(const DensePlan& p, const DgArgs& a, hipStream_t st) {
 }
 void dense_name(int pass, int P, const DensePlan& p, int N, char* out, int out_len) {
     const int al = pass == 2 ? DG_RC : DG_KC, bl = pass == 0 ? DG_KC : DG_RC;
-    if (dense_split(p, P, N)) snprintf(out, out_len, "dgemm32g_kernel<128, 128, 2, 2, %d, %d, 2, 16, 1>", al, bl);
+    if (dense_split(p, P, N)) snprintf(out, out_len, "dgemm32g_kernel<128, 128, 2, 2, %d, %d, 2, %d, 1>", al, bl, P);
     else if (p.dma) snprintf(out, out_len, "dgemm32g_kernel<%d, %d, 2, 2, %d, %d, 2, %d, 0>", p.bm, p.bn, al, bl, P);
     else snprintf(out, out_len, "dgemm32_kernel<%d, %d, %d, 2, %d, %d, 0>", p.bm, p.bn, p.bm == 128 ? 4 : 2, al, bl);
 }
@@ -2450,9 +2453,9 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
         dense_plan(pass, 16, wino_dims(g).T, g->Co, g->Ci, prec_h(g)).ok) {
         dense_name(pass, 16, dense_plan(pass, 16, wino_dims(g).T, g->Co, g->Ci, prec_h(g)), dense_dims(pass, wino_dims(g).T, g->Co, g->Ci).N, out, out_len);
     } else if (wino4_ok(g) && !kq && dense_plan(pass, 25, wino4_dims(g).T, g->Co, g->Ci, false).ok) {
-        dense_name(pass, 25, dense_plan(pass, 25, wino4_dims(g).T, g->Co, g->Ci, false), 0, out, out_len);
+        dense_name(pass, 25, dense_plan(pass, 25, wino4_dims(g).T, g->Co, g->Ci, false), dense_dims(pass, wino4_dims(g).T, g->Co, g->Ci).N, out, out_len);
     } else if (wino42_ok(g) && !kq && dense_plan(pass, 25, wino42_dims(g).T, g->Co, wino42_dims(g).K4, false).ok) {
-        dense_name(pass, 25, dense_plan(pass, 25, wino42_dims(g).T, g->Co, wino42_dims(g).K4, false), 0, out, out_len);
+        dense_name(pass, 25, dense_plan(pass, 25, wino42_dims(g).T, g->Co, wino42_dims(g).K4, false), dense_dims(pass, wino42_dims(g).T, g->Co, wino42_dims(g).K4).N, out, out_len);
     } else if (wino_ok(g) && !kq) {
         const WinoDims d = wino_dims(g);
         if (pass == 0) {
