@@ -75,6 +75,7 @@ struct CdArgs {
     int B, H, W, Ci, OH, OW, Co, KH, KW, s, p, reflect;
     int act, tiles_m, tiles_n, splits, cps, accumulate;
     int round_f16;           // HALF: round the direct result through float16 (autocast output)
+    int cls_order;           // DGRAD, stride 2: 1 = classes in the order (all taps, half, one tap, half), see the kernel
 };
 
 __device__ __forceinline__ unsigned cd_pixel_off(const CdArgs& g, int pb, int iy, int ix, unsigned cbytes) {
@@ -353,7 +354,10 @@ __global__ __launch_bounds__(256) void conv_dgrad_dma_kernel(CdArgs g) {
     // heaviest class first (most taps): workgroups are dispatched in blockIdx order
     int py = 0, px = 0;
     if (s > 1) {
-        const int zi = blockIdx.y / s, zj = blockIdx.y - zi * s;
+        // with fewer workgroups per class than CUs the dispatcher's round robin puts class y and class y + 2 on the same
+        // CUs: (4 taps, 2, 1, 2) pairs the heaviest with the lightest, (4, 2, 2, 1) would pair 4 + 2 against 2 + 1
+        const int zi = blockIdx.y / s;
+        const int zj = (blockIdx.y - zi * s) ^ ((g.cls_order && s == 2) ? zi : 0);
         const int t0y = (g.KH - (g.p % s) + s - 1) / s, t1y = (g.KH - ((1 + g.p) % s) + s - 1) / s;
         const int t0x = (g.KW - (g.p % s) + s - 1) / s, t1x = (g.KW - ((1 + g.p) % s) + s - 1) / s;
         const int hy = t1y > t0y ? 1 : 0, hx = t1x > t0x ? 1 : 0;
@@ -629,7 +633,10 @@ inline CdPlan conv_dma_dgrad_plan(const mg_conv_geom* g) {
             if (sp > 1 && chunks / sp < 8) break;
             if (f_sp && sp != f_sp) continue;
             const long long wg = w * s * s * sp;
-            double t = (double)((wg + 255) / 256) * tile_us * ((double)total_k / (s * s) / sp + fixed);
+            // fewer workgroups per class than CUs: a CU holds workgroups of two classes only (y and y + 2 of the launch
+            // order, see the kernel), the pair (all taps, one tap) sets the time: 2.5 taps against the average 2.25
+            const double k_wg = (double)total_k / (s * s) * ((w * sp >= 256 || total_k == chunks * s * s) ? 1.0 : 1.12);
+            double t = (double)((wg + 255) / 256) * tile_us * (k_wg / sp + fixed);
             if (wg < fill) t /= 0.85;
             if (sp > 1) t += (double)(sp + 1) * (double)g->B * g->H * g->W * g->Ci * 4.0 / 4e12 * 1e6 + 3.0;
             if (t < best_t) { best_t = t; best = {c.bm, c.bn, sp, 0}; }
@@ -652,6 +659,13 @@ void conv_dma_dgrad_launch(const mg_conv_geom* g, const CdPlan& p, const void* d
     const int s = g->stride;
     const long long Mc = (long long)g->B * ((g->H + s - 1) / s) * ((g->W + s - 1) / s);
     const dim3 grid((unsigned)(((Mc + p.bm - 1) / p.bm) * (g->Ci / p.bn)), (unsigned)(s * s), (unsigned)p.splits);
+    // class order (stride 2, odd kernels: 4 / 2 / 2 / 1 taps).  All workgroups resident at once (LDS: 5 / 3 / 2 per CU for
+    // 64x64 / 64x128, 128x64 / 128x128 tiles): the round robin pairs class y with y + 2 on a CU, so (4, 2, 1, 2) balances
+    // (512 -> 1024 channels at 8x16: 107 against 119 us).  More rounds than that: heaviest first is the better list order
+    // (128 -> 256 channels at 64x128: 87 against 100 us).  MG_DGRAD_CLASS_ORDER=0|1 forces one.
+    const long long slots = 256LL * (p.bm == 64 && p.bn == 64 ? 5 : (p.bm == 128 && p.bn == 128 ? 2 : 3));
+    a.cls_order = (long long)grid.x * grid.y * grid.z <= slots ? 1 : 0;
+    if (const char* e = getenv("MG_DGRAD_CLASS_ORDER")) a.cls_order = e[0] == '1' ? 1 : 0;
     if (conv_dma_half(g)) conv_dma_dgrad_launch_t<true>(a, p, grid, st);
     else conv_dma_dgrad_launch_t<false>(a, p, grid, st);
 }
