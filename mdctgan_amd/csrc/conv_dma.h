@@ -356,8 +356,11 @@ __global__ __launch_bounds__(256) void conv_dgrad_dma_kernel(CdArgs g) {
     if (s > 1) {
         // with fewer workgroups per class than CUs the dispatcher's round robin puts class y and class y + 2 on the same
         // CUs: (4 taps, 2, 1, 2) pairs the heaviest with the lightest, (4, 2, 2, 1) would pair 4 + 2 against 2 + 1
-        const int zi = blockIdx.y / s;
-        const int zj = (blockIdx.y - zi * s) ^ ((g.cls_order && s == 2) ? zi : 0);
+        // ... and a K split (blockIdx.z) of a small grid lands on the same CUs as split 0: rotate the classes by two per
+        // split so that a CU's second workgroup is the light partner again, not another slice of the same class
+        const int cy = (g.cls_order && s == 2) ? (int)((blockIdx.y + 2 * blockIdx.z) & 3) : (int)blockIdx.y;
+        const int zi = cy / s;
+        const int zj = (cy - zi * s) ^ ((g.cls_order && s == 2) ? zi : 0);
         const int t0y = (g.KH - (g.p % s) + s - 1) / s, t1y = (g.KH - ((1 + g.p) % s) + s - 1) / s;
         const int t0x = (g.KW - (g.p % s) + s - 1) / s, t1x = (g.KW - ((1 + g.p) % s) + s - 1) / s;
         const int hy = t1y > t0y ? 1 : 0, hx = t1x > t0x ? 1 : 0;
@@ -635,7 +638,9 @@ inline CdPlan conv_dma_dgrad_plan(const mg_conv_geom* g) {
             const long long wg = w * s * s * sp;
             // fewer workgroups per class than CUs: a CU holds workgroups of two classes only (y and y + 2 of the launch
             // order, see the kernel), the pair (all taps, one tap) sets the time: 2.5 taps against the average 2.25
-            const double k_wg = (double)total_k / (s * s) * ((w * sp >= 256 || total_k == chunks * s * s) ? 1.0 : 1.12);
+            // one workgroup per CU or fewer: nothing to pair with, the all-taps class alone sets the time
+            const double k_wg = wg <= 256 ? (double)chunks
+                                          : (double)total_k / (s * s) * ((w * sp >= 256 || total_k == chunks * s * s) ? 1.0 : 1.12);
             double t = (double)((wg + 255) / 256) * tile_us * (k_wg / sp + fixed);
             if (wg < fill) t /= 0.85;
             if (sp > 1) t += (double)(sp + 1) * (double)g->B * g->H * g->W * g->Ci * 4.0 / 4e12 * 1e6 + 3.0;
