@@ -2381,6 +2381,35 @@ int smallc_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* 
     const size_t n = (size_t)g->Co * g->KH * g->KW * g->Ci;
     return mg_colsum(ws, p.wgs, (int)n, dw, accumulate, ws + lay.red, mg_colsum_workspace(p.wgs, (int)n), st);
 }
+// forward on the MFMA pipe (conv_smallc_fwd_kernel): 0 = not eligible, else the template instance
+int smallc_fwd_kind(const mg_conv_geom* g) {
+    static const bool off = getenv("MG_NO_SMALLC_FWD") != nullptr;
+    if (!smallc_enabled() || off || g->Co % 64 != 0 || (long long)g->B * g->OH > 0x7fffffffLL) return 0;
+    if ((size_t)g->KH * (((g->OW - 1) * g->stride + g->KW) * g->Ci + 4) > 256 * 16) return 0;      // staged through 16 registers per thread
+    if (g->KH == 7 && g->KW == 7 && g->Ci == 2 && g->stride == 1) return 1;      // the generator stem: 66 against 93 us
+    // the 3 -> 64 4x4 stride-2 first discriminator layer (K = 48, 129-pixel rows = 5 pixel blocks for 4 waves) measured
+    // SLOWER here than on the generic kernel (44 against 37 us at batch 16): instance kept for MG_SMALLC_FWD_D=1 only
+    static const bool with_d = getenv("MG_SMALLC_FWD_D") != nullptr;
+    if (with_d && g->KH == 4 && g->KW == 4 && g->Ci == 3 && g->stride == 2) return 2;
+    return 0;
+}
+int smallc_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act, hipStream_t st) {
+    const SmallcWgradPlan p = smallc_wgrad_plan(g);     // the same staged rows
+    const Geom gg = to_geom(g);
+    const int rows = g->B * g->OH, cblocks = (g->Co + 63) / 64;
+    int rpw = 1;                                        // rows per workgroup: one workgroup per CU (260 VGPRs: one fits)
+    if (const char* e = getenv("MG_SMALLC_FWD_ROWS")) rpw = atoi(e) > 0 ? atoi(e) : 1;
+    else while ((long long)((rows + rpw - 1) / rpw) * cblocks > 256 && rpw < 8) ++rpw;
+    const dim3 grid((unsigned)((rows + rpw - 1) / rpw), (unsigned)cblocks);
+    const size_t lds = p.lds + (size_t)64 * g->KH * g->KW * g->Ci * sizeof(float);
+    switch (smallc_fwd_kind(g)) {
+    case 1: hipLaunchKernelGGL((conv_smallc_fwd_kernel<7, 7, 2, 1>), grid, dim3(256), lds, st, gg, x, w, bias, y, act, p.rowlen, rpw, (int)prec_h(g)); break;
+    case 2: hipLaunchKernelGGL((conv_smallc_fwd_kernel<4, 4, 3, 2>), grid, dim3(256), lds, st, gg, x, w, bias, y, act, p.rowlen, rpw, (int)prec_h(g)); break;
+    default: return MG_ERR_UNSUPPORTED;
+    }
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
 int smallc_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* dx, hipStream_t st) {
     const Geom gg = to_geom(g);
     const int s = g->stride;
@@ -2516,6 +2545,8 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
             else
             snprintf(out, out_len, "conv_wgrad_kernel<%d, %d, true, true, 5>", p.big ? 128 : 64, p.big ? 128 : 64);
         }
+    } else if (pass == 0 && !kq && smallc_fwd_kind(g)) {
+        snprintf(out, out_len, "conv_smallc_fwd_kernel<%d, %d, %d, %d>", g->KH, g->KW, g->Ci, g->stride);
     } else if (pass == 1 && smallc_dgrad_ok(g)) {
         snprintf(out, out_len, "conv_smallc_dgrad_kernel<%d>", g->Ci);
     } else if (pass == 2 && !kq && smallc_wgrad_kind(g)) {
@@ -2739,6 +2770,12 @@ int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const f
     if (wino42_ok(g) && workspace && workspace_bytes >= wino42_fwd_ws(g) && aligned16(x) && aligned16(w) && aligned16(y) &&
         aligned16(workspace) && (!bias || aligned16(bias)))
         return wino42_fwd(g, x, w, bias, y, act, (float*)workspace, (hipStream_t)stream, u, wt ? wt->v : nullptr);
+    if (smallc_fwd_kind(g)) {
+        probe_begin((hipStream_t)stream);
+        const int rc = smallc_fwd(g, x, w, bias, y, act, (hipStream_t)stream);
+        probe_end((hipStream_t)stream);
+        return rc;
+    }
     const Geom gg = to_geom(g);
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)g->B * g->OH * g->OW;

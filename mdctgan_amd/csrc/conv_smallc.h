@@ -134,4 +134,122 @@ __global__ __launch_bounds__(KH * 64) void conv_smallc_wgrad_kernel(Geom g, cons
     }
 }
 
+// ---- forward of the same layers on the MFMA pipe ----------------------------------------------------------------------------
+// y[b][oy][ox][co] = act(bias[co] + sum_k patch(b, oy, ox)[k] * w[co][k]),  k = (ky, kx, ci) in OHWI order, K = KH*KW*CI even.
+// As a GEMM this is [pixels] x [K <= 98] x [Co]: the implicit-GEMM loaders of conv_igemm.hip gather single floats for it
+// (2-3 channels per pixel: 29 TFLOP/s on the 2 -> 64 stem).  Here one workgroup owns an output row: the KH input rows it touches
+// are staged once into LDS with the padding materialised (as in the weight gradient above), so the A fragment of
+// v_mfma_f32_32x32x2_f32 -- lane (pixel r, k parity h) needs patch(r)[2j + h] -- is ONE ds_read_b32 at
+// ky(k) * rowlen + ox * S * CI + kxci(k), consecutive pixels -> consecutive banks; the B fragments (w[co][2j + h], K / 2 per
+// 32-channel block) come through LDS once and live in registers for all the rows a workgroup does (rows_per_wg consecutive
+// ones, so that their cost is spread).  A wave takes 32-pixel blocks of the row, 64 output channels each.
+template <int KH, int KW, int CI, int S>
+__global__ __launch_bounds__(256) void conv_smallc_fwd_kernel(Geom g, const float* __restrict__ x,
+                                                              const float* __restrict__ w, const float* __restrict__ bias,
+                                                              float* __restrict__ y, int act, int rowlen, int rows_per_wg,
+                                                              int hp) {
+    constexpr int KWC = KW * CI, K = KH * KWC, KP = K / 2;
+    static_assert(K % 2 == 0, "k pairs");
+    extern __shared__ __attribute__((aligned(16))) float xs_smallc[];
+    float* wl = xs_smallc + KH * rowlen;            // [64][K] weights of this channel block
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int co0 = blockIdx.y * 64;
+    const int ncols = (g.OW - 1) * S + KW;
+    const int nrows = g.B * g.OH;
+    {   // 64 x K weights of this block (Co % 64 == 0, K even: whole float2s), all loads of a thread in flight
+        const float2* wsrc = reinterpret_cast<const float2*>(w + (size_t)co0 * K);
+        constexpr int W2 = 64 * K / 2;
+#pragma unroll
+        for (int it = 0; it < (W2 + 255) / 256; ++it) {
+            const int e = threadIdx.x + 256 * it;
+            if (e < W2) {
+                float2 v = wsrc[e];
+                if (hp) { v.x = round_h(v.x); v.y = round_h(v.y); }
+                reinterpret_cast<float2*>(wl)[e] = v;
+            }
+        }
+    }
+    // LDS offset of k = 2 j + h for this lane's k parity
+    int koff[KP];
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+        const int k = 2 * j + h, ky = k / KWC;
+        koff[j] = ky * rowlen + (k - ky * KWC);
+    }
+    __syncthreads();
+    // B fragments: w[co0 + 32 nb + r][2 j + h], in registers for every row this workgroup does
+    float bw[2][KP];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int j = 0; j < KP; ++j) bw[nb][j] = wl[(32 * nb + r) * K + 2 * j + h];
+    const float bv0 = (bias && co0 + r < g.Co) ? bias[co0 + r] : 0.0f;
+    const float bv1 = (bias && co0 + 32 + r < g.Co) ? bias[co0 + 32 + r] : 0.0f;
+    const int nblk = (g.OW + 31) / 32;
+    const int row_end = min(nrows, (int)(blockIdx.x + 1) * rows_per_wg);
+    // the staged rows of the NEXT output row travel through registers while this one is multiplied (NIT loads in flight per
+    // thread instead of one dependent load per loop trip)
+    constexpr int NIT = 16;
+    const int nstage = KH * rowlen;                  // <= 256 * NIT (checked by the launcher)
+    float pre[NIT];
+    auto fetch = [&](int row) {
+        const int b = row / g.OH, oy = row - b * g.OH;
+        int rr = threadIdx.x / rowlen, ee = threadIdx.x - rr * rowlen;       // (staged row, element) of e, carried along
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = threadIdx.x + 256 * it;
+            float xv = 0.0f;
+            if (e < nstage) {
+                const int jx = ee / CI, c = ee - jx * CI;
+                int iy = oy * S - g.p + rr, ix = jx - g.p;
+                bool ok = jx < ncols;
+                if (g.reflect) { iy = reflect_idx(iy, g.H); ix = reflect_idx(ix, g.W); }
+                else ok = ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                if (ok) xv = x[((size_t)(b * g.H + iy) * g.W + ix) * CI + c];
+            }
+            pre[it] = hp ? round_h(xv) : xv;
+            ee += 256;
+            while (ee >= rowlen) { ee -= rowlen; ++rr; }
+        }
+    };
+    if ((int)(blockIdx.x * rows_per_wg) < row_end) fetch(blockIdx.x * rows_per_wg);
+    for (int row = blockIdx.x * rows_per_wg; row < row_end; ++row) {
+        __syncthreads();                             // the previous row's fragments are read
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = threadIdx.x + 256 * it;
+            if (e < nstage) xs_smallc[e] = pre[it];
+        }
+        __syncthreads();
+        if (row + 1 < row_end) fetch(row + 1);
+        float* yr = y + ((size_t)row * g.OW) * g.Co;
+        for (int mb = wave; mb < nblk; mb += 4) {
+            const int ox = min(32 * mb + r, g.OW - 1);
+            const float* ap = xs_smallc + ox * (S * CI);
+            f32x16 acc0 = f32x16{0}, acc1 = f32x16{0};
+#pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                const float a = ap[koff[j]];
+                acc0 = mfma32x32x2(a, bw[0][j], acc0);
+                acc1 = mfma32x32x2(a, bw[1][j], acc1);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int px = 32 * mb + mfma32_row(q, lane);
+                if (px >= g.OW) continue;
+                const int c0 = co0 + r, c1 = co0 + 32 + r;
+                if (c0 < g.Co) {
+                    const float v = apply_act(acc0[q] + bv0, act);
+                    yr[(size_t)px * g.Co + c0] = hp ? round_h(v) : v;
+                }
+                if (c1 < g.Co) {
+                    const float v = apply_act(acc1[q] + bv1, act);
+                    yr[(size_t)px * g.Co + c1] = hp ? round_h(v) : v;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
