@@ -2333,7 +2333,9 @@ bool smallc_enabled() {
     return !off;
 }
 bool smallc_dgrad_ok(const mg_conv_geom* g) {
-    return smallc_enabled() && g->Ci >= 1 && g->Ci <= 4 && !g->reflect && g->Co % 4 == 0 && g->Co >= 16;
+    const int s = g->stride;       // the class's weights sit in LDS: taps x Co float4s
+    return smallc_enabled() && g->Ci >= 1 && g->Ci <= 4 && !g->reflect && g->Co % 4 == 0 && g->Co >= 16 &&
+           (size_t)((g->KH + s - 1) / s) * ((g->KW + s - 1) / s) * g->Co * 16 <= 60 * 1024;
 }
 // 0: not eligible; otherwise the template instance id
 int smallc_wgrad_kind(const mg_conv_geom* g) {
@@ -2415,12 +2417,18 @@ int smallc_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* 
     const int s = g->stride;
     const long long Mc = (long long)g->B * ((g->H + s - 1) / s) * ((g->W + s - 1) / s);
     const dim3 grid((unsigned)((Mc + 255) / 256), (unsigned)(s * s));
+    // the heaviest class's taps x Co float4s of weights in LDS
+    const size_t wl_bytes = (size_t)((g->KH + s - 1) / s) * ((g->KW + s - 1) / s) * g->Co * 16;
+#define MG_SMALLC_DG(CI_) do { \
+        if (prec_h(g)) hipLaunchKernelGGL((conv_smallc_dgrad_kernel<CI_, true>), grid, dim3(256), wl_bytes, st, gg, dy, w, dx); \
+        else hipLaunchKernelGGL((conv_smallc_dgrad_kernel<CI_, false>), grid, dim3(256), wl_bytes, st, gg, dy, w, dx); } while (0)
     switch (g->Ci) {
-    case 1: hipLaunchKernelGGL(conv_smallc_dgrad_kernel<1>, grid, dim3(256), 0, st, gg, dy, w, dx, (int)prec_h(g)); break;
-    case 2: hipLaunchKernelGGL(conv_smallc_dgrad_kernel<2>, grid, dim3(256), 0, st, gg, dy, w, dx, (int)prec_h(g)); break;
-    case 3: hipLaunchKernelGGL(conv_smallc_dgrad_kernel<3>, grid, dim3(256), 0, st, gg, dy, w, dx, (int)prec_h(g)); break;
-    default: hipLaunchKernelGGL(conv_smallc_dgrad_kernel<4>, grid, dim3(256), 0, st, gg, dy, w, dx, (int)prec_h(g)); break;
+    case 1: MG_SMALLC_DG(1); break;
+    case 2: MG_SMALLC_DG(2); break;
+    case 3: MG_SMALLC_DG(3); break;
+    default: MG_SMALLC_DG(4); break;
     }
+#undef MG_SMALLC_DG
     MG_CHECK_LAUNCH();
     return MG_OK;
 }
@@ -2548,7 +2556,7 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
     } else if (pass == 0 && !kq && smallc_fwd_kind(g)) {
         snprintf(out, out_len, "conv_smallc_fwd_kernel<%d, %d, %d, %d>", g->KH, g->KW, g->Ci, g->stride);
     } else if (pass == 1 && smallc_dgrad_ok(g)) {
-        snprintf(out, out_len, "conv_smallc_dgrad_kernel<%d>", g->Ci);
+        snprintf(out, out_len, "conv_smallc_dgrad_kernel<%d, %s>", g->Ci, prec_h(g) ? "true" : "false");
     } else if (pass == 2 && !kq && smallc_wgrad_kind(g)) {
         snprintf(out, out_len, "conv_smallc_wgrad_kernel<%d, %d, %d>", g->KH, g->KW, g->Ci);
     } else if (kq && pass == 0) {

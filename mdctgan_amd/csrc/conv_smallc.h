@@ -13,34 +13,49 @@ namespace {
 // One thread per input pixel of one stride-parity class (blockIdx.y), so the tap set is uniform across the wave and
 // the weights come in through scalar loads; dy rows are read as float4 per lane (each dy pixel serves (K/s)^2 lanes
 // out of L1 / L2).
-template <int CI>
+template <int CI, bool hp>      // hp compile-time: a run-time flag costs two conversions and a select per weight in the FMA loop
 __global__ __launch_bounds__(256) void conv_smallc_dgrad_kernel(Geom g, const float* __restrict__ dy,
-                                                                const float* __restrict__ w, float* __restrict__ dx,
-                                                                int hp) {
+                                                                const float* __restrict__ w, float* __restrict__ dx) {
     // hp (MG_PRECISION_F16): operands rounded to float16 before the multiply, float32 accumulation, float16-valued output
+    // The class's weights go through LDS as [tap][co] float4s (ci padded to 4): one broadcast ds_read_b128 per (tap, co)
+    // instead of two scalar loads whose out-of-order return forces s_waitcnt lgkmcnt(0) in front of every FMA group.
+    extern __shared__ __attribute__((aligned(16))) float4 wl_smallc[];
     const int s = g.s, cls = blockIdx.y, py = cls / s, px = cls - py * s;
     const int Hc = (g.H - py + s - 1) / s, Wc = (g.W - px + s - 1) / s;
     const int Mc = g.B * Hc * Wc;
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (Hc <= 0 || Wc <= 0) return;
+    const int ky0 = (py + g.p) % s, kx0 = (px + g.p) % s;
+    const int nky = (g.KH - ky0 + s - 1) / s, nkx = (g.KW - kx0 + s - 1) / s;
+    const int wstride = g.KH * g.KW * CI;
+    for (int e = threadIdx.x; e < nky * nkx * g.Co; e += 256) {
+        const int t = e / g.Co, co = e - t * g.Co;
+        const int ky = ky0 + (t / nkx) * s, kx = kx0 + (t % nkx) * s;
+        const float* wp = w + (size_t)co * wstride + (size_t)(ky * g.KW + kx) * CI;
+        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < CI; ++c) v[c] = hp ? round_h(wp[c]) : wp[c];
+        wl_smallc[e] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
     const bool live = m < Mc;
     const int mm = live ? m : 0;
     const int b = mm / (Hc * Wc), rem = mm - b * (Hc * Wc);
     const int yy = rem / Wc, xx = rem - yy * Wc;
     const int iy = s * yy + py, ix = s * xx + px;
-    const int ky0 = (py + g.p) % s, kx0 = (px + g.p) % s;
     float acc[CI];
 #pragma unroll
     for (int c = 0; c < CI; ++c) acc[c] = 0.0f;
+    int t = 0;
     for (int ky = ky0; ky < g.KH; ky += s) {
         const int oy = (iy + g.p - ky) / s;          // exact: (iy + p - ky) is a multiple of s in this class
         const bool oky = (iy + g.p - ky) >= 0 && oy < g.OH;
-        for (int kx = kx0; kx < g.KW; kx += s) {
+        for (int kx = kx0; kx < g.KW; kx += s, ++t) {
             const int ox = (ix + g.p - kx) / s;
             const bool ok = live && oky && (ix + g.p - kx) >= 0 && ox < g.OW;
             const float* dp = dy + (size_t)((b * g.OH + (ok ? oy : 0)) * g.OW + (ok ? ox : 0)) * g.Co;
-            const float* wp = w + (size_t)(ky * g.KW + kx) * CI;
-            const int wstride = g.KH * g.KW * CI;
+            const float4* wt = wl_smallc + (size_t)t * g.Co;
+#pragma unroll 2
             for (int co = 0; co < g.Co; co += 4) {
                 float4 d = ld4(dp + co);
                 if (!ok) d = zero4();
@@ -50,13 +65,12 @@ __global__ __launch_bounds__(256) void conv_smallc_dgrad_kernel(Geom g, const fl
                     for (int j = 0; j < 4; ++j) dv[j] = round_h(dv[j]);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j) {
+                    const float4 wv4 = wt[co + j];
+                    const float wv[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
 #pragma unroll
-                    for (int c = 0; c < CI; ++c) {
-                        float wv = wp[(size_t)(co + j) * wstride + c];
-                        if (hp) wv = round_h(wv);
-                        acc[c] = fmaf(dv[j], wv, acc[c]);
-                    }
+                    for (int c = 0; c < CI; ++c) acc[c] = fmaf(dv[j], wv[c], acc[c]);
+                }
             }
         }
     }
