@@ -2348,11 +2348,20 @@ int smallc_wgrad_kind(const mg_conv_geom* g) {
     return 0;
 }
 // even stride * Ci keeps every pixel's patch segment 8-byte aligned in the staged rows
-struct SmallcWgradPlan { int wgs, rowlen; size_t lds; };
+struct SmallcWgradPlan { int wgs, rowlen; size_t lds; int mfma_g; };     // wgs: partial rows; mfma_g: 0 or the MFMA kernel's pixel groups
+// the MFMA form (conv_smallc_wgrad_mfma_kernel): pixel groups per output row (each writes a partial row), 0 = VALU kernel
+int smallc_wgrad_mfma_groups(const mg_conv_geom* g, int rowlen) {
+    static const bool off = getenv("MG_NO_SMALLC_WGRAD_MFMA") != nullptr;
+    if (off || (size_t)g->KH * rowlen > 256 * 16) return 0;
+    if (g->KH == 7 && g->KW == 7 && g->Ci == 2 && g->stride == 1) return 1;     // K = 98: four k blocks, one per wave
+    if (g->KH == 4 && g->KW == 4 && g->Ci == 3 && g->stride == 2) return 2;     // K = 48: two k blocks x two pixel groups
+    return 0;
+}
 SmallcWgradPlan smallc_wgrad_plan(const mg_conv_geom* g) {
     const int ncols = (g->OW - 1) * g->stride + g->KW;
     const int rowlen = (ncols * g->Ci + 3) / 4 * 4;
-    return {g->B * g->OH, rowlen, (size_t)g->KH * rowlen * sizeof(float)};
+    const int mg = smallc_wgrad_mfma_groups(g, rowlen);
+    return {g->B * g->OH * (mg ? mg : 1), rowlen, (size_t)g->KH * rowlen * sizeof(float), mg};
 }
 // workspace: per-row partials | column-sum scratch of their reduction | column-sum scratch of the bias gradient
 struct SmallcWs { size_t part, red, cs, total; };      // float offsets / counts
@@ -2372,7 +2381,12 @@ int smallc_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* 
     const SmallcWgradPlan p = smallc_wgrad_plan(g);
     const SmallcWs lay = smallc_wgrad_layout(g);
     const Geom gg = to_geom(g);
-    const dim3 grid((unsigned)p.wgs, (unsigned)((g->Co + 63) / 64));
+    const dim3 grid((unsigned)(g->B * g->OH), (unsigned)((g->Co + 63) / 64));
+    if (p.mfma_g) {
+        const size_t lds = p.lds + 16;               // + the zeroed slot the k >= K lanes read
+        if (g->KH == 7) hipLaunchKernelGGL((conv_smallc_wgrad_mfma_kernel<7, 7, 2, 1>), grid, dim3(256), lds, st, gg, x, dy, ws, p.rowlen, (int)prec_h(g));
+        else hipLaunchKernelGGL((conv_smallc_wgrad_mfma_kernel<4, 4, 3, 2>), grid, dim3(256), lds, st, gg, x, dy, ws, p.rowlen, (int)prec_h(g));
+    } else
     switch (smallc_wgrad_kind(g)) {
     case 1: hipLaunchKernelGGL((conv_smallc_wgrad_kernel<4, 4, 3>), grid, dim3(256), p.lds, st, gg, x, dy, ws, p.rowlen, (int)prec_h(g)); break;
     case 2: hipLaunchKernelGGL((conv_smallc_wgrad_kernel<7, 7, 2>), grid, dim3(448), p.lds, st, gg, x, dy, ws, p.rowlen, (int)prec_h(g)); break;
@@ -2558,7 +2572,8 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
     } else if (pass == 1 && smallc_dgrad_ok(g)) {
         snprintf(out, out_len, "conv_smallc_dgrad_kernel<%d, %s>", g->Ci, prec_h(g) ? "true" : "false");
     } else if (pass == 2 && !kq && smallc_wgrad_kind(g)) {
-        snprintf(out, out_len, "conv_smallc_wgrad_kernel<%d, %d, %d>", g->KH, g->KW, g->Ci);
+        if (smallc_wgrad_plan(g).mfma_g) snprintf(out, out_len, "conv_smallc_wgrad_mfma_kernel<%d, %d, %d, %d>", g->KH, g->KW, g->Ci, g->stride);
+        else snprintf(out, out_len, "conv_smallc_wgrad_kernel<%d, %d, %d>", g->KH, g->KW, g->Ci);
     } else if (kq && pass == 0) {
         snprintf(out, out_len, "conv_rowdot_fwd_kernel<%d>", kq);
     } else if (kq && pass == 2) {

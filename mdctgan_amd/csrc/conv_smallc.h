@@ -266,4 +266,92 @@ __global__ __launch_bounds__(256) void conv_smallc_fwd_kernel(Geom g, const floa
     }
 }
 
+// ---- weight gradient of the same layers on the MFMA pipe ---------------------------------------------------------------------
+// part[prow][co][k] = sum over the pixels of an output row of dy[px][co] * patch(px)[k]: per row a [64 co] x [K] x [OW pixels]
+// GEMM.  The VALU kernel above spends its time on the broadcast LDS reads of the patch (KW * CI / 2 ds_read_b64 per pixel and
+// wave: 103 us on the stem).  Here the A fragment of v_mfma_f32_32x32x2_f32 is dy read straight from HBM (lane (co r, pixel
+// parity h): 128 contiguous bytes per pixel), the B fragment one ds_read_b32 of the staged rows (lane (k r, h) at
+// ky(k) * rowlen + kxci(k) + pixel * S * CI; k >= K reads a zeroed slot with stride 0).  A wave owns one 32-wide block of k
+// and both 32-channel blocks; with fewer k blocks than waves the spare waves take every G-th pixel pair and write their own
+// partial row (the reduction over rows follows anyway).
+template <int KH, int KW, int CI, int S>
+__global__ __launch_bounds__(256) void conv_smallc_wgrad_mfma_kernel(Geom g, const float* __restrict__ x,
+                                                                     const float* __restrict__ dy, float* __restrict__ part,
+                                                                     int rowlen, int hp) {
+    constexpr int KWC = KW * CI, K = KH * KWC, NBLK = (K + 31) / 32, G = 4 / NBLK, U = 8;
+    static_assert(NBLK == 1 || NBLK == 2 || NBLK == 4, "k blocks per wave layout");
+    extern __shared__ __attribute__((aligned(16))) float xs_smallc[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x / g.OH, oy = blockIdx.x - b * g.OH;
+    const int co0 = blockIdx.y * 64;
+    const int ncols = (g.OW - 1) * S + KW;
+    const int nstage = KH * rowlen;                   // + 4 zeroed floats behind it
+    {
+        constexpr int NIT = 16;                       // nstage <= 256 * NIT (checked by the launcher)
+        float pre[NIT];
+        int rr = threadIdx.x / rowlen, ee = threadIdx.x - rr * rowlen;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = threadIdx.x + 256 * it;
+            float xv = 0.0f;
+            if (e < nstage) {
+                const int jx = ee / CI, c = ee - jx * CI;
+                int iy = oy * S - g.p + rr, ix = jx - g.p;
+                bool ok = jx < ncols;
+                if (g.reflect) { iy = reflect_idx(iy, g.H); ix = reflect_idx(ix, g.W); }
+                else ok = ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                if (ok) xv = x[((size_t)(b * g.H + iy) * g.W + ix) * CI + c];
+            }
+            pre[it] = hp ? round_h(xv) : xv;
+            ee += 256;
+            while (ee >= rowlen) { ee -= rowlen; ++rr; }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = threadIdx.x + 256 * it;
+            if (e < nstage) xs_smallc[e] = pre[it];
+        }
+        if (threadIdx.x < 4) xs_smallc[nstage + threadIdx.x] = 0.0f;
+    }
+    __syncthreads();
+    const int nb = wave % NBLK, grp = wave / NBLK;
+    const int k = 32 * nb + r;
+    const bool kok = k < K;
+    const int ky = kok ? k / KWC : 0;
+    const int bbase = kok ? ky * rowlen + (k - ky * KWC) : nstage;
+    const int bstep = kok ? S * CI : 0;
+    const float* dyr = dy + (size_t)blockIdx.x * g.OW * g.Co + co0 + r;
+    const bool c0ok = co0 + r < g.Co, c1ok = co0 + 32 + r < g.Co;
+    f32x16 acc0 = f32x16{0}, acc1 = f32x16{0};
+    const int npairs = (g.OW + 1) / 2;
+    for (int pp0 = grp; pp0 < npairs; pp0 += G * U) {
+        float a0[U], a1[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int px = 2 * (pp0 + u * G) + h;
+            const bool ok = px < g.OW;
+            const int pc = ok ? px : g.OW - 1;
+            a0[u] = (ok && c0ok) ? dyr[(size_t)pc * g.Co] : 0.0f;
+            a1[u] = (ok && c1ok) ? dyr[(size_t)pc * g.Co + 32] : 0.0f;
+            bv[u] = xs_smallc[bbase + pc * bstep];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (hp) { a0[u] = round_h(a0[u]); a1[u] = round_h(a1[u]); }
+            acc0 = mfma32x32x2(a0[u], bv[u], acc0);
+            acc1 = mfma32x32x2(a1[u], bv[u], acc1);
+        }
+    }
+    if (kok) {
+        float* o = part + ((size_t)(blockIdx.x * G + grp) * g.Co + co0) * K + k;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int cr = mfma32_row(q, lane);
+            if (co0 + cr < g.Co) o[(size_t)cr * K] = acc0[q];
+            if (co0 + 32 + cr < g.Co) o[(size_t)(32 + cr) * K] = acc1[q];
+        }
+    }
+}
+
 }  // namespace
