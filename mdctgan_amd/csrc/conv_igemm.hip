@@ -2352,7 +2352,7 @@ struct SmallcWgradPlan { int wgs, rowlen; size_t lds; int mfma_g; };     // wgs:
 // the MFMA form (conv_smallc_wgrad_mfma_kernel): pixel groups per output row (each writes a partial row), 0 = VALU kernel
 int smallc_wgrad_mfma_groups(const mg_conv_geom* g, int rowlen) {
     static const bool off = getenv("MG_NO_SMALLC_WGRAD_MFMA") != nullptr;
-    if (off || (size_t)g->KH * rowlen > 256 * 16) return 0;
+    if (off || (size_t)g->KH * rowlen > 256 * 16 || g->Co % 64 != 0) return 0;
     if (g->KH == 7 && g->KW == 7 && g->Ci == 2 && g->stride == 1) return 1;     // K = 98: four k blocks, one per wave
     if (g->KH == 4 && g->KW == 4 && g->Ci == 3 && g->stride == 2) return 2;     // K = 48: two k blocks x two pixel groups
     return 0;

@@ -321,8 +321,9 @@ __global__ __launch_bounds__(256) void conv_smallc_wgrad_mfma_kernel(Geom g, con
     const int ky = kok ? k / KWC : 0;
     const int bbase = kok ? ky * rowlen + (k - ky * KWC) : nstage;
     const int bstep = kok ? S * CI : 0;
-    const float* dyr = dy + (size_t)blockIdx.x * g.OW * g.Co + co0 + r;
-    const bool c0ok = co0 + r < g.Co, c1ok = co0 + 32 + r < g.Co;
+    // the two 32-channel blocks are the even and the odd channels of the 64: a lane's A values for both are ONE 8-byte load
+    const float* dyr = dy + (size_t)blockIdx.x * g.OW * g.Co + co0 + 2 * r;
+    const bool c0ok = co0 + 2 * r + 1 < g.Co;       // Co % 64 == 0 at every call site; a ragged block loads nothing
     f32x16 acc0 = f32x16{0}, acc1 = f32x16{0};
     const int npairs = (g.OW + 1) / 2;
     for (int pp0 = grp; pp0 < npairs; pp0 += G * U) {
@@ -332,8 +333,9 @@ __global__ __launch_bounds__(256) void conv_smallc_wgrad_mfma_kernel(Geom g, con
             const int px = 2 * (pp0 + u * G) + h;
             const bool ok = px < g.OW;
             const int pc = ok ? px : g.OW - 1;
-            a0[u] = (ok && c0ok) ? dyr[(size_t)pc * g.Co] : 0.0f;
-            a1[u] = (ok && c1ok) ? dyr[(size_t)pc * g.Co + 32] : 0.0f;
+            const float2 av = (ok && c0ok) ? *reinterpret_cast<const float2*>(dyr + (size_t)pc * g.Co) : make_float2(0.0f, 0.0f);
+            a0[u] = av.x;
+            a1[u] = av.y;
             bv[u] = xs_smallc[bbase + pc * bstep];
         }
 #pragma unroll
@@ -348,8 +350,10 @@ __global__ __launch_bounds__(256) void conv_smallc_wgrad_mfma_kernel(Geom g, con
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int cr = mfma32_row(q, lane);
-            if (co0 + cr < g.Co) o[(size_t)cr * K] = acc0[q];
-            if (co0 + 32 + cr < g.Co) o[(size_t)(32 + cr) * K] = acc1[q];
+            if (co0 + 2 * cr + 1 < g.Co) {
+                o[(size_t)(2 * cr) * K] = acc0[q];
+                o[(size_t)(2 * cr + 1) * K] = acc1[q];
+            }
         }
     }
 }
