@@ -729,6 +729,113 @@ def l1_halves_loss(t, scale: float = 1.0):
     return _L1HalvesFn.apply(t, float(scale))
 
 
+# Sums of such terms over the discriminator scales / layers as ONE autograd node each: the kernels accumulate into the
+# loss scalar (mg_*_fwd's accumulate flag, the same float32 additions in the same order as `loss = loss + term`), so the
+# step launches no at::native add for them.
+def _cl(t):
+    return t.contiguous(memory_format=CL) if t.dim() == 4 else t.contiguous()
+
+
+class _L1HalvesSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scale, *ts):
+        ts = [_cl(t) for t in ts]
+        loss = torch.empty(1, dtype=torch.float32, device=ts[0].device)
+        for i, t in enumerate(ts):
+            B = t.shape[0] // 2
+            ops.l1_fwd(t[:B], t[B:], scale, loss, i > 0)
+        ctx.scale = scale
+        ctx.save_for_backward(*ts)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, go):
+        go = go.reshape(1).float().contiguous()
+        grads = []
+        for t in ctx.saved_tensors:
+            B = t.shape[0] // 2
+            g = torch.empty_like(t)
+            if _BackwardPass.kind != "G":
+                g[B:].zero_()
+            ops.l1_bwd(t[:B], t[B:], ctx.scale, go, out=g[:B])
+            grads.append(g)
+        return (None, *grads)
+
+
+def l1_halves_loss_sum(ts, scale: float = 1.0):
+    """sum_i l1_halves_loss(ts[i], scale), one node."""
+    ts = list(ts)
+    assert ts and all(t.shape[0] % 2 == 0 for t in ts)
+    return _L1HalvesSumFn.apply(float(scale), *ts)
+
+
+class _MseConstFirstHalfSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, target, *preds):
+        preds = [_cl(t) for t in preds]
+        loss = torch.empty(1, dtype=torch.float32, device=preds[0].device)
+        for i, t in enumerate(preds):
+            ops.mse_const_fwd(t[:t.shape[0] // 2], target, 1.0, loss, i > 0)
+        ctx.target = target
+        ctx.save_for_backward(*preds)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, go):
+        go = go.reshape(1).float().contiguous()
+        grads = []
+        for t in ctx.saved_tensors:
+            B = t.shape[0] // 2
+            g = torch.empty_like(t)
+            if _BackwardPass.kind != "G":
+                g[B:].zero_()
+            ops.mse_const_bwd(t[:B], ctx.target, 1.0, go, out=g[:B])
+            grads.append(g)
+        return (None, *grads)
+
+
+def mse_const_first_half_loss_sum(preds, target: float):
+    """sum_i mse_const_first_half_loss(preds[i], target), one node."""
+    preds = list(preds)
+    assert preds and all(t.shape[0] % 2 == 0 for t in preds)
+    return _MseConstFirstHalfSumFn.apply(float(target), *preds)
+
+
+class _MseConstPairSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t0, t1, *preds):
+        preds = [_cl(t) for t in preds]
+        l0 = torch.empty(1, dtype=torch.float32, device=preds[0].device)
+        l1 = torch.empty(1, dtype=torch.float32, device=preds[0].device)
+        for i, t in enumerate(preds):
+            B = t.shape[0] // 2
+            ops.mse_const_fwd(t[:B], t0, 1.0, l0, i > 0)
+            ops.mse_const_fwd(t[B:], t1, 1.0, l1, i > 0)
+        ctx.targets = (t0, t1)
+        ctx.save_for_backward(*preds)
+        return l0.reshape(()), l1.reshape(())
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        g0 = g0.reshape(1).float().contiguous()
+        g1 = g1.reshape(1).float().contiguous()
+        grads = []
+        for t in ctx.saved_tensors:
+            B = t.shape[0] // 2
+            g = torch.empty_like(t)
+            ops.mse_const_bwd(t[:B], ctx.targets[0], 1.0, g0, out=g[:B])
+            ops.mse_const_bwd(t[B:], ctx.targets[1], 1.0, g1, out=g[B:])
+            grads.append(g)
+        return (None, None, *grads)
+
+
+def mse_const_pair_loss_sum(preds, target_first: float, target_second: float):
+    """(sum_i first-half term, sum_i second-half term) of mse_const_pair_loss over preds, one node."""
+    preds = list(preds)
+    assert preds and all(t.shape[0] % 2 == 0 for t in preds)
+    return _MseConstPairSumFn.apply(float(target_first), float(target_second), *preds)
+
+
 def mse_const_loss(pred, target: float, scale: float = 1.0):
     """scale * mean((pred - target)^2)  == nn.MSELoss()(pred, full_like(pred, target)) * scale."""
     return _MseConstFn.apply(pred, float(target), float(scale))

@@ -372,12 +372,9 @@ class Pix2PixHDModel(BaseModel):
             # per-sample (InstanceNorm), so stacking is exact; half the launches, twice the rows per GEMM
             pred_both = self.netD.forward(Fh.d_input_pair(lr_spectro, sr_spectro, hr_spectro,
                                                           float(self.norm_range[0])))
-        if stacked:
-            loss_D_fake = loss_D_real = 0
-            for scale_out in pred_both:
-                l_fake, l_real = Fh.mse_const_pair_loss(scale_out[-1], self.criterionGAN.fake_label,
-                                                        self.criterionGAN.real_label)
-                loss_D_fake, loss_D_real = loss_D_fake + l_fake, loss_D_real + l_real
+        if stacked:       # the sums over the scales are one node each: the kernels accumulate, no elementwise adds
+            loss_D_fake, loss_D_real = Fh.mse_const_pair_loss_sum([scale_out[-1] for scale_out in pred_both],
+                                                                  self.criterionGAN.fake_label, self.criterionGAN.real_label)
         else:
             pred_fake_pool = self.netD.forward(self._d_in(lr_spectro, sr_spectro.detach()))
             loss_D_fake = self.criterionGAN(pred_fake_pool, False)
@@ -387,13 +384,11 @@ class Pix2PixHDModel(BaseModel):
         D_weights = 1.0 / self.num_D
         loss_G_GAN_Feat = 0
         if shared:
-            loss_G_GAN = 0
-            for scale_out in pred_both:
-                loss_G_GAN = loss_G_GAN + Fh.mse_const_first_half_loss(scale_out[-1], self.criterionGAN.real_label)
-                if not self.no_ganFeat_loss:
-                    for t in scale_out[:-1]:
-                        loss_G_GAN_Feat = loss_G_GAN_Feat + Fh.l1_halves_loss(
-                            t, D_weights * feat_weights * self.lambda_feat)
+            loss_G_GAN = Fh.mse_const_first_half_loss_sum([scale_out[-1] for scale_out in pred_both],
+                                                          self.criterionGAN.real_label)
+            if not self.no_ganFeat_loss:
+                loss_G_GAN_Feat = Fh.l1_halves_loss_sum([t for scale_out in pred_both for t in scale_out[:-1]],
+                                                        D_weights * feat_weights * self.lambda_feat)
         else:
             if stacked:
                 pred_real = [[t.detach()[B:] for t in scale_out] for scale_out in pred_both]
