@@ -179,6 +179,9 @@ typedef struct {
     const float* u;
     float* v;
     float* md;
+    const float* add;   /* mg_conv_dgrad_w only, any geometry: dx += add ([B,H,W,Ci]) -- the gradient a skip connection brings to
+                         * the same tensor (ResnetBlock, models/networks.py:462), folded into the call's last kernel where the path
+                         * allows and added by a separate pass otherwise; NULL for every other call */
 } mg_wino_tiles;
 size_t mg_conv_wino_weights_bytes(const mg_conv_geom* g);
 size_t mg_conv_wino_tiles_bytes(const mg_conv_geom* g, int which);

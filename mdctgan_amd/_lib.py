@@ -35,7 +35,7 @@ _G = C.POINTER(ConvGeom)
 
 class WinoTiles(C.Structure):
     """mg_wino_tiles: caller-held Winograd images (u: transformed weights, v: B^T x B, md: A dy A^T)."""
-    _fields_ = [("u", C.c_void_p), ("v", C.c_void_p), ("md", C.c_void_p)]
+    _fields_ = [("u", C.c_void_p), ("v", C.c_void_p), ("md", C.c_void_p), ("add", C.c_void_p)]
 
 
 _W = C.POINTER(WinoTiles)

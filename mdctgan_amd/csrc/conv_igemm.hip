@@ -1786,6 +1786,10 @@ int wino_fwd(const mg_conv_geom* g, const float* x, const float* w, const float*
     return MG_OK;
 }
 
+// mg_wino_tiles.add of the mg_conv_dgrad_w call in flight on this thread: a path that can fold "dx += add" into its last
+// kernel takes it and clears it; whatever is left is added by a separate pass at the end of the call.
+static thread_local const float* g_dgrad_add = nullptr;
+
 // Data gradient as the transpose of the forward pipeline (wino.h): T tiles, no padded domain.
 int wino_dgrad_t(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act, float* ws,
                  hipStream_t st, const float* u_pre, float* md_keep) {
@@ -1835,7 +1839,9 @@ int wino_dgrad_t(const mg_conv_geom* g, const float* dy, const float* w, const f
         const dim3 grid(g->Ci / 32, g->B);
         auto go = [&](auto kern) {
             hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const float*)dV, g->B, g->H, g->W, g->Ci, g->reflect, bias, act, dx);
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const float*)dV, g->B, g->H, g->W, g->Ci, g->reflect, bias, act, dx,
+                               g_dgrad_add);
+            g_dgrad_add = nullptr;                 // consumed: mg_conv_dgrad_w has nothing left to add
         };
         if (ts <= 32) go(wino_dd_gather_kernel<1>); else go(wino_dd_gather_kernel<2>);
         MG_CHECK_LAUNCH();
@@ -2880,8 +2886,20 @@ int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const f
     return MG_OK;
 }
 
+static int dgrad_dispatch(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
+                          void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* wt);
 int mg_conv_dgrad_w(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
                     void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* wt) {
+    if (wt && wt->add && !aligned16(wt->add)) return MG_ERR_ARG;
+    g_dgrad_add = wt ? wt->add : nullptr;
+    int rc = dgrad_dispatch(g, dy, w, bias, dx, act, workspace, workspace_bytes, stream, wt);
+    const float* left = g_dgrad_add;
+    g_dgrad_add = nullptr;
+    if (rc == MG_OK && left) rc = mg_add(dx, left, dx, (long long)g->B * g->H * g->W * g->Ci, stream);
+    return rc;
+}
+static int dgrad_dispatch(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
+                          void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* wt) {
     if (!geom_ok(g) || !w || !dx) return MG_ERR_ARG;
     if (!wino_tiles_ok(g, wt)) return MG_ERR_ARG;
     // dy == NULL: wt->md already holds A dy A^T (mg_instnorm_bwd_wino_md) -- F(2x2,3x3) layers in the transposed formulation

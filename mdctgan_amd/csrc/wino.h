@@ -485,7 +485,8 @@ __global__ void wino_dx_gather_kernel(const float* __restrict__ dd, int B, int H
 // in the same order as wino_dd_xform_kernel + wino_dx_gather_kernel (bit-identical), without the dd round trip through HBM.
 template <int NT>
 __global__ __launch_bounds__(256) void wino_dd_gather_kernel(const float* __restrict__ dV, int B, int H, int W, int C, int reflect,
-                                                             const float* __restrict__ bias, int act, float* __restrict__ dx) {
+                                                             const float* __restrict__ bias, int act, float* __restrict__ dx,
+                                                             const float* __restrict__ addend) {
     extern __shared__ __attribute__((aligned(16))) float4 wdg_lds[];     // [Ts][16][8]
     const int cq = threadIdx.x & 7, tl = threadIdx.x >> 3;
     const int b = blockIdx.y, c0 = blockIdx.x * 32 + 4 * cq;
@@ -530,6 +531,7 @@ __global__ __launch_bounds__(256) void wino_dd_gather_kernel(const float* __rest
             for (int c = 0; c < nx; ++c) add4(acc, wdg_lds[((ty[a] * TW + tx[c]) * 16 + ry[a] * 4 + rx[c]) * 8 + cq]);
         add4(s, acc);
         s.x = apply_act(s.x, act); s.y = apply_act(s.y, act); s.z = apply_act(s.z, act); s.w = apply_act(s.w, act);
+        if (addend) add4(s, ld4(addend + ((size_t)b * HW + p) * C + c0));      // the skip connection's gradient (mg_wino_tiles.add)
         *reinterpret_cast<float4*>(dx + ((size_t)b * HW + p) * C + c0) = s;
     }
 }

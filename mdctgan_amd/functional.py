@@ -322,7 +322,8 @@ class _ConvInstNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, cfg):
         x = to_cl(x)
-        pad, reflect, weight_grad, act, eps = cfg
+        pad, reflect, weight_grad, act, eps = cfg[:5]
+        ctx.skip = cfg[5] if len(cfg) > 5 else None      # ("give" | "take", SkipGrad): see SkipGrad
         res = to_cl(residual) if residual is not None else None
         B, _, H, W = x.shape
         w = weight.detach()
@@ -350,6 +351,13 @@ class _ConvInstNormFn(torch.autograd.Function):
         x, y_raw, mean, rstd = ctx.saved_tensors
         gy = to_cl(gy)
         dres = gy if ctx.needs_input_grad[3] else None
+        skip_g = None
+        if ctx.skip is not None:
+            role, holder = ctx.skip
+            if role == "give" and dres is not None:      # the block's first convolution adds it to its data gradient
+                holder.g, dres = dres, None
+            elif role == "take":
+                skip_g, holder.g = holder.g, None
         g, weight, bias = ctx.g, ctx.weight, ctx.bias
         weight_grad = ctx.cfg[5]
         dead_bias = bias is None or not bias.requires_grad or (getattr(bias, "_mg_zero_grad", False) and not COMPUTE_DEAD_BIAS_GRADS)
@@ -360,7 +368,8 @@ class _ConvInstNormFn(torch.autograd.Function):
             _, md = ops.wino_tile_buffers(g, gy.device, want_v=False)
             ops.instnorm_bwd_wino_md(g, nhwc_view(gy), nhwc_view(y_raw), mean, rstd, ctx.norm_act, md)
             w = weight.detach()
-            dx = nchw_view(ops.conv_dgrad(g, None, w, u=u, md_out=md))
+            dx = nchw_view(ops.conv_dgrad(g, None, w, u=u, md_out=md,
+                                          add=nhwc_view(skip_g) if skip_g is not None else None))
             wbuf, wacc = grad_buffer(weight)
             if bias is not None and bias.requires_grad:
                 _zero_grad_bias(bias)
@@ -372,12 +381,27 @@ class _ConvInstNormFn(torch.autograd.Function):
             return dx, None, None, dres, None
         d_raw = nchw_view(ops.instnorm_bwd(nhwc_view(gy), nhwc_view(y_raw), mean, rstd, ctx.norm_act))
         dx = _conv_backward(ctx, d_raw, x, None)
+        if skip_g is not None:
+            dx = skip_g if dx is None else add(dx, skip_g)
         return dx, None, None, dres, None
 
 
-def conv_instnorm(x, weight, bias, padding=0, reflect=False, act=ACT_NONE, residual=None, eps=1e-5, weight_grad=True):
-    """act(InstanceNorm2d(affine=False)(conv2d(x, weight, bias, stride 1))) + residual."""
-    return _ConvInstNormFn.apply(x, weight, bias, residual, (padding, bool(reflect), weight_grad, act, eps))
+class SkipGrad:
+    """Carries the gradient of a skip connection from the node that receives it (the block's last conv_instnorm, role "give":
+    it hands over d(residual) instead of returning it to autograd) to the node that produced the skipped tensor's other use
+    (the block's first conv_instnorm, role "take": dx += g inside its data gradient's last kernel) -- the engine would add
+    the two with an elementwise kernel.  Valid because both nodes take the SAME tensor and "take" runs after "give" in every
+    backward pass (its output feeds "give")."""
+    __slots__ = ("g",)
+
+    def __init__(self):
+        self.g = None
+
+
+def conv_instnorm(x, weight, bias, padding=0, reflect=False, act=ACT_NONE, residual=None, eps=1e-5, weight_grad=True, skip=None):
+    """act(InstanceNorm2d(affine=False)(conv2d(x, weight, bias, stride 1))) + residual.  skip: ("give" | "take", SkipGrad)."""
+    cfg = (padding, bool(reflect), weight_grad, act, eps) + ((skip,) if skip is not None else ())
+    return _ConvInstNormFn.apply(x, weight, bias, residual, cfg)
 
 
 class _InstNormFn(torch.autograd.Function):

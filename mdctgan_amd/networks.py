@@ -283,8 +283,12 @@ class ResnetBlock(nn.Module):
 
     def forward(self, x, weight_grad=True):
         cb = self.conv_block
-        h = Fh.conv_instnorm(x, cb[1].weight, cb[1].bias, 1, True, ACT_RELU, None, cb[2].eps, weight_grad)
-        return Fh.conv_instnorm(h, cb[5].weight, cb[5].bias, 1, True, ACT_NONE, x, cb[6].eps, weight_grad)
+        # the skip connection's gradient rides into conv 1's data gradient instead of an autograd add (Fh.SkipGrad)
+        skip = Fh.SkipGrad() if (torch.is_grad_enabled() and x.requires_grad) else None
+        h = Fh.conv_instnorm(x, cb[1].weight, cb[1].bias, 1, True, ACT_RELU, None, cb[2].eps, weight_grad,
+                             ("take", skip) if skip else None)
+        return Fh.conv_instnorm(h, cb[5].weight, cb[5].bias, 1, True, ACT_NONE, x, cb[6].eps, weight_grad,
+                                ("give", skip) if skip else None)
 
 
 class ConvResBlock(nn.Module):

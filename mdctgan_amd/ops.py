@@ -87,10 +87,10 @@ def tiles_are_casts(g: ConvGeom) -> bool:
 _CASTS = {}
 
 
-def _tiles(u=None, v=None, md=None):
-    if u is None and v is None and md is None:
+def _tiles(u=None, v=None, md=None, add=None):
+    if u is None and v is None and md is None and add is None:
         return None
-    return _lib.WinoTiles(_lib.ptr(u), _lib.ptr(v), _lib.ptr(md))
+    return _lib.WinoTiles(_lib.ptr(u), _lib.ptr(v), _lib.ptr(md), _lib.ptr(add))
 
 
 def conv_fwd(g: ConvGeom, x, w, bias=None, act=ACT_NONE, u=None, v_out=None):
@@ -140,15 +140,16 @@ def instnorm_bwd_wino_md(g: ConvGeom, gy, y_raw, mean, rstd, act, md):
                                                    _lib.ptr(md), _lib.stream()), "mg_instnorm_bwd_wino_md")
 
 
-def conv_dgrad(g: ConvGeom, dy, w, bias=None, act=ACT_NONE, u=None, md_out=None, out=None):
-    """dy None: md_out already holds the layer's A dy A^T image (instnorm_bwd_wino_md)."""
+def conv_dgrad(g: ConvGeom, dy, w, bias=None, act=ACT_NONE, u=None, md_out=None, out=None, add=None):
+    """dy None: md_out already holds the layer's A dy A^T image (instnorm_bwd_wino_md).  add: dx += add (a skip connection's
+    gradient), inside the last kernel where the layer's path allows."""
     lib = _lib.load()
     dx = torch.empty(g.B, g.H, g.W, g.Ci, dtype=torch.float32, device=w.device) if out is None else out
     ws = _ws(lib.mg_conv_dgrad_workspace(g), w.device)
     if PROFILER is not None:
         PROFILER.begin(1, g)
     _lib.check(lib.mg_conv_dgrad_w(g, _lib.ptr(dy), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(dx), act, _lib.ptr(ws),
-                                   ws.numel(), _lib.stream(), _tiles(u, None, md_out)), "mg_conv_dgrad")
+                                   ws.numel(), _lib.stream(), _tiles(u, None, md_out, add)), "mg_conv_dgrad")
     if PROFILER is not None:
         PROFILER.end()
     return dx

@@ -334,6 +334,23 @@ def test_conv_fwd_instnorm_matches_separate_calls(case):
         assert torch.equal(yr2, y_raw) and torch.equal(y2, y)
 
 
+@pytest.mark.parametrize("case", [("small_map_fused", 4, 128, 8, 16, 3, 1, 1, True), ("big_map_two_kernels", 2, 64, 32, 64, 3, 1, 1, True),
+                                  ("stride2_direct", 2, 64, 16, 32, 3, 2, 1, False)], ids=lambda c: c[0])
+def test_conv_dgrad_add_is_dgrad_plus_tensor(case):
+    """mg_wino_tiles.add: dx += add, folded into the gather kernel on small Winograd maps, a separate pass elsewhere --
+    bit for bit dgrad(dy) + add either way (one float32 addition per element)."""
+    from mdctgan_amd import ops
+    name, B, C, H, W, k, s, p, reflect = case
+    gen = torch.Generator().manual_seed(len(name))
+    g = ops.conv_geom(B, H, W, C, C, k, k, s, p, reflect)
+    dy = torch.randn(B, g.OH, g.OW, C, generator=gen).to(DEV)
+    w = (torch.randn(C, k, k, C, generator=gen) / np.sqrt(k * k * C)).to(DEV)
+    skip = torch.randn(B, H, W, C, generator=gen).to(DEV)
+    dx0 = ops.conv_dgrad(g, dy, w)
+    dx1 = ops.conv_dgrad(g, dy, w, add=skip)
+    assert torch.equal(dx1, dx0 + skip)
+
+
 @pytest.mark.parametrize("case", [("trunk_like", 8, 128, 8, 16, ACT_RELU_), ("trunk_tiny_4x8", 4, 256, 4, 8, 0), ("map_16x32", 2, 128, 16, 32, 0)],
                          ids=lambda c: c[0])
 def test_instnorm_bwd_wino_md_matches_separate_calls(case):
