@@ -444,7 +444,7 @@ class Pix2PixHDModel(BaseModel):
         return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss_dict.items()}
 
     def make_graphed_step(self, lr_audio, hr_audio, warmup=3):
-        """Capture one full optimize_parameters() iteration (~480 launches: forward, both backward passes, both Adam
+        """Capture one full optimize_parameters() iteration (~470 launches: forward, both backward passes, both Adam
         steps) into a hipGraph and return run(lr, hr) -> loss dict, which copies the batch into the captured input
         buffers and replays.  The optimiser clock and learning rate live in HBM, so replays advance Adam exactly
         like eager steps.  The warm-up iterations are real training steps."""
