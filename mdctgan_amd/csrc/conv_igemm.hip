@@ -1226,7 +1226,9 @@ DensePlan dense_plan(int pass, int P, long long T, int Co, int Kc, bool hp) {
             const int spl = (chunks + cps - 1) / cps;
             const long long wg = w * spl;
             double t = (double)((wg + 255) / 256) * tile_us * (cps + 1.2);
-            if (wg < 512) t /= 0.85;
+            // forward / data gradient: 500 workgroups already count as two rounds (17x33 maps on 128x128 tiles: 110 against
+            // 125 us with the penalty); the weight gradient's short K loops keep the wider band (measured both ways)
+            if (wg < (pass == 2 ? 512 : 384)) t /= 0.85;
             if (spl > 1) t += (double)(spl + 1) * P * (double)dd.M * dd.N * 4.0 / 4e12 * 1e6 + 3.0;
             if (t < best) { best = t; p.bm = c.bm; p.bn = c.bn; p.splits = spl; p.cps = cps; }
         }
