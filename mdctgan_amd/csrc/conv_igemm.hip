@@ -1369,9 +1369,12 @@ inline size_t cd_reflect_dxp_bytes(const mg_conv_geom* gp) { return cd_al((size_
 int cd_dgrad_run(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act, char* wsp,
                  hipStream_t st, const float* u, float* md, int round_f16);
 // a layer any of whose passes runs on the float16 implicit GEMMs keeps a cached float16 copy of its weights
+// (mutually exclusive with the Winograd path, which the pass entry points try FIRST: a layer that is wino_ok() keeps
+// float32 U / V / Md images under MG_PRECISION_F16, so it must never be handed the float16-sized buffers of this path)
+bool wino_ok(const mg_conv_geom* g);
 inline bool conv_dma_h_any(const mg_conv_geom* g) {
     mg_conv_geom gp;
-    return conv_dma_half(g) && !h16_ok(g) && !mg_conv_rowdot_kq(g) &&
+    return conv_dma_half(g) && !h16_ok(g) && !mg_conv_rowdot_kq(g) && !wino_ok(g) &&
            (conv_dma_fwd_ok(g) || conv_dma_dgrad_ok(g) || cd_reflect_dgrad_geom(g, &gp));
 }
 inline bool cd_dgrad_any(const mg_conv_geom* g) {
@@ -2742,6 +2745,7 @@ int mg_instnorm_bwd_wino_md(const mg_conv_geom* g, const float* gy, const float*
                             int act, float* md, void* stream) {
     if (!gy || !y_raw || !mean || !rstd || !md) return MG_ERR_ARG;
     if (!mg_conv_wino_md_from_norm_ok(g)) return MG_ERR_UNSUPPORTED;
+    if (act != MG_ACT_NONE && act != MG_ACT_RELU && act != MG_ACT_LRELU02) return MG_ERR_UNSUPPORTED;   // the only derivatives wino_norm_bwd_dy_kernel has
     if (!aligned16(gy) || !aligned16(y_raw) || !aligned16(mean) || !aligned16(rstd) || !aligned16(md)) return MG_ERR_ARG;
     const WinoDims d = wino_dims(g);
     const dim3 grid(g->Co / 32, g->B);

@@ -126,6 +126,7 @@ def attach_optimizer(opt, writes_per_step=1, bucket_bytes=128 << 20, group=None)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     slices = opt.arena_slices()
     broadcast_arena(opt.flat_p, 0, group)
+    opt.resync_shadow()        # --fp16: the float16 shadow was cast from the PRE-broadcast weights
     red = ArenaReducer(opt.flat_g, slices, writes_per_step, bucket_bytes, group)
     red.bucket_bytes = bucket_bytes
     opt.grad_scale = 1.0 / world

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import torch
 
+from . import functional as Fh
 from . import ops
 
 
@@ -64,10 +65,21 @@ def make_graphed_generate(model, lr_segments: torch.Tensor, batch_size: int = 64
     with torch.cuda.graph(graph):
         out = generate(model, static_in, batch_size, gen_overlap)
 
+    # The captured launches hold raw pointers to the transformed-weight images the warm-up cached on the parameters
+    # (weight._mg_u_cache).  Pin those tensors for the graph's lifetime -- an eager inference after an optimiser step
+    # would replace the cache entries and free them -- and refuse to replay once the weights have moved.
+    params = list(model.netG.parameters())
+    pinned = [getattr(p, "_mg_u_cache", None) for p in params]
+    stamp = (Fh.WEIGHT_EPOCH[0], tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+
     def run(lr=None):
+        now = (Fh.WEIGHT_EPOCH[0], tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        if now != stamp:
+            raise RuntimeError("the generator's weights changed after make_graphed_generate() captured them "
+                               "(optimizer step / load_state_dict): capture again")
         if lr is not None:
             static_in.copy_(lr, non_blocking=True)
         graph.replay()
         return out
-    run.graph = graph
+    run.graph, run.pinned = graph, pinned
     return run

@@ -85,6 +85,14 @@ class FusedAdam(torch.optim.Optimizer):
                     p._mg_h, p._mg_flat, p._mg_h_version = self.flat_h[off:off + n], self.flat_p[off:off + n], p._version
         self._built = True
 
+    @torch.no_grad()
+    def resync_shadow(self):
+        """Re-cast the float16 shadow from the parameter arena.  Needed after any raw write into flat_p that does not go
+        through a parameter (dist.broadcast of the arena, an all-gather of updated shards): such writes do not move the
+        parameters' version counters, so functional._weight_image would keep serving the pre-write shadow."""
+        if self.flat_h is not None:
+            self.flat_h.copy_(self.flat_p)
+
     def arena_slices(self):
         """[(param, offset, padded_numel)] in arena order (used by the data-parallel reducer)."""
         if not self._built:

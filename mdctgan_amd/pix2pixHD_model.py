@@ -187,13 +187,14 @@ class Audio2MDCT(torch.nn.Module):
         raw = codec_inverse(spec4, codec=self.codec, gain=float(self.arcsinh_gain), alpha=float(self.alpha),
                             min_value=float(self.min_value), norm_range=nr, src_range=sr,
                             min_b=mn if per_sample else None, max_b=mx if per_sample else None)
-        if self.codec == _lib.MG_CODEC_DB and pha is not None:       # pix2pixHD_model.py:147-157
+        if self.codec == _lib.MG_CODEC_DB and pha is not None and self.up_ratio > 1:
+            # pix2pixHD_model.py:147-157: the sign restore sits INSIDE `if self.up_ratio > 1` in the reference (at
+            # up_ratio == 1 its dB decode stays unsigned) -- mirrored as written
             ph = pha.reshape(raw.shape).to(raw.device)
-            if self.up_ratio > 1:
-                size = ph.size(-2)
-                keep = int(size * (1 / self.up_ratio))
-                pseudo = (2 * torch.randint(low=0, high=2, size=ph.size(), device=raw.device) - 1).to(ph.dtype)
-                ph = torch.cat((ph[..., :keep, :], pseudo[..., keep:, :]), dim=-2)
+            size = ph.size(-2)
+            keep = int(size * (1 / self.up_ratio))
+            pseudo = (2 * torch.randint(low=0, high=2, size=ph.size(), device=raw.device) - 1).to(ph.dtype)
+            ph = torch.cat((ph[..., :keep, :], pseudo[..., keep:, :]), dim=-2)
             raw = raw * ph
         if self.geom512:
             window, d4 = self._tables(raw.device)

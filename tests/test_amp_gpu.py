@@ -117,6 +117,23 @@ def test_conv_f16_precision(case):
     assert (dw.double().cpu() - want).abs().max().item() <= wtol * want.abs().max().item()
     ops.conv_wgrad(g, xd, gyd, dw, None, accumulate=True)
     assert (dw.double().cpu() - 2 * want).abs().max().item() <= 2 * wtol * want.abs().max().item()
+    if wino:
+        # a float16 Winograd layer that ALSO satisfies the float16 implicit-GEMM predicates must be sized
+        # as a Winograd layer (float32 U / V / Md images) by the buffer-size queries, because the pass entry points take
+        # the Winograd branch first.  Caller-held u / v / md through every pass: same bits as the self-contained calls.
+        T = B * (H // 2) * (W // 2)
+        assert ops.wino_weights_bytes(g) == 16 * Co * Ci * 4, ops.wino_weights_bytes(g)
+        u = ops.wino_weights(g, wd)
+        v, md = ops.wino_tile_buffers(g, xd.device)
+        assert v is not None and v.numel() == 16 * T * Ci and md is not None and md.numel() == 16 * T * Co
+        guard = torch.full((4096,), 3.25, device=DEV)      # allocated right behind the images: an overrun would land here
+        assert torch.equal(ops.conv_fwd(g, xd, wd, bd, u=u, v_out=v), ops.conv_fwd(g, xd, wd, bd))
+        assert torch.equal(ops.conv_dgrad(g, gyd, wd, u=u, md_out=md), ops.conv_dgrad(g, gyd, wd))
+        dw1, dw2 = torch.empty_like(dw), torch.empty_like(dw)
+        ops.conv_wgrad(g, xd, gyd, dw1, None)
+        ops.conv_wgrad(g, xd, gyd, dw2, None, v=v, md=md)
+        assert torch.equal(dw1, dw2)
+        assert bool((guard == 3.25).all())
     if cdh or co1:   # staged copies of x / dy handed from the forward / data-gradient call to the weight gradient: same bits
         u = ops.wino_weights(g, wd)
         v, md = ops.wino_tile_buffers(g, xd.device)

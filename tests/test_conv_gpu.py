@@ -306,7 +306,12 @@ def test_f32_split_gemms_are_float32_accurate(case, monkeypatch):
 
 
 @pytest.mark.parametrize("case", [("trunk_like_wino", 8, 128, 8, 16, ACT_RELU_, True), ("trunk_tiny_4x8", 4, 256, 4, 8, 0, True),
-                                  ("bigger_map_16x32", 2, 128, 16, 32, 0, False), ("fallback_direct", 2, 16, 8, 16, ACT_RELU_, True)],
+                                  ("bigger_map_16x32", 2, 128, 16, 32, 0, False), ("fallback_direct", 2, 16, 8, 16, ACT_RELU_, True),
+                                  # the bench's own trunk shapes: configs[1] 1024 ch @ 8x16 and configs[2]
+                                  # 2048 ch @ 4x8 at batch 8, configs[4] 1024 ch @ 8x16 at batch 64 -- other tiles / splits
+                                  ("configs1_trunk_1024_8x16", 8, 1024, 8, 16, ACT_RELU_, True),
+                                  ("configs2_trunk_2048_4x8", 8, 2048, 4, 8, ACT_RELU_, True),
+                                  ("configs4_trunk_1024_8x16_b64", 64, 1024, 8, 16, ACT_RELU_, True)],
                          ids=lambda c: c[0])
 def test_conv_fwd_instnorm_matches_separate_calls(case):
     """mg_conv_fwd_instnorm_w (the Winograd inverse transform, the InstanceNorm statistics and the apply in one kernel on small
@@ -335,7 +340,9 @@ def test_conv_fwd_instnorm_matches_separate_calls(case):
 
 
 @pytest.mark.parametrize("case", [("small_map_fused", 4, 128, 8, 16, 3, 1, 1, True), ("big_map_two_kernels", 2, 64, 32, 64, 3, 1, 1, True),
-                                  ("stride2_direct", 2, 64, 16, 32, 3, 2, 1, False)], ids=lambda c: c[0])
+                                  ("stride2_direct", 2, 64, 16, 32, 3, 2, 1, False),
+                                  ("configs1_trunk_1024_8x16", 8, 1024, 8, 16, 3, 1, 1, True),
+                                  ("configs2_trunk_2048_4x8", 8, 2048, 4, 8, 3, 1, 1, True)], ids=lambda c: c[0])
 def test_conv_dgrad_add_is_dgrad_plus_tensor(case):
     """mg_wino_tiles.add: dx += add, folded into the gather kernel on small Winograd maps, a separate pass elsewhere --
     bit for bit dgrad(dy) + add either way (one float32 addition per element)."""
@@ -351,7 +358,8 @@ def test_conv_dgrad_add_is_dgrad_plus_tensor(case):
     assert torch.equal(dx1, dx0 + skip)
 
 
-@pytest.mark.parametrize("case", [("trunk_like", 8, 128, 8, 16, ACT_RELU_), ("trunk_tiny_4x8", 4, 256, 4, 8, 0), ("map_16x32", 2, 128, 16, 32, 0)],
+@pytest.mark.parametrize("case", [("trunk_like", 8, 128, 8, 16, ACT_RELU_), ("trunk_tiny_4x8", 4, 256, 4, 8, 0), ("map_16x32", 2, 128, 16, 32, 0),
+                                  ("configs1_trunk_1024_8x16", 8, 1024, 8, 16, ACT_RELU_), ("configs2_trunk_2048_4x8", 8, 2048, 4, 8, ACT_RELU_)],
                          ids=lambda c: c[0])
 def test_instnorm_bwd_wino_md_matches_separate_calls(case):
     """mg_instnorm_bwd_wino_md (InstanceNorm backward + A dy A^T in one kernel, no dy in HBM) followed by the data / weight

@@ -160,3 +160,110 @@ def test_batch64_inference_plans(shape):
     if u is not None:
         y2 = ops.conv_fwd(g, xd, wd, bd, u=u)
         assert torch.equal(y, y2), name
+
+
+def sample_reference_dgrad(dy, w, bias, B, H, W, Ci, Co, k, s, p, OH, OW, n=48, seed=1):
+    """float64 data gradient (= ConvTranspose2d forward, models/networks.py:349-352) at n random input pixels (b, iy, ix),
+    all Ci channels: dx[b, iy, ix, :] = bias + sum over (oy, ox, ky, kx) with oy*s - p + ky == iy, ox*s - p + kx == ix of
+    w[:, ky, kx, :]^T dy[b, oy, ox, :].  dy [B,OH,OW,Co], w [Co,k,k,Ci] on the CPU; zero padding."""
+    rng = np.random.default_rng(seed)
+    idx = np.stack([rng.integers(0, B, n), rng.integers(0, H, n), rng.integers(0, W, n)], 1)
+    idx[0] = (0, 0, 0)
+    idx[1] = (B - 1, H - 1, W - 1)
+    idx[2] = (B - 1, H - 2, W - 2)                      # both parities next to the border
+    dyd, wd = dy.double(), w.double()
+    out = torch.zeros(n, Ci, dtype=torch.float64)
+    for j, (b, iy, ix) in enumerate(idx):
+        acc = bias.double().clone() if bias is not None else torch.zeros(Ci, dtype=torch.float64)
+        for ky in range(k):
+            ty = iy + p - ky
+            if ty % s or not (0 <= ty // s < OH):
+                continue
+            for kx in range(k):
+                tx = ix + p - kx
+                if tx % s or not (0 <= tx // s < OW):
+                    continue
+                acc += dyd[b, ty // s, tx // s, :] @ wd[:, ky, kx, :]
+        out[j] = acc
+    return idx, out
+
+
+@pytest.mark.parametrize("shape", [s_ for s_ in SHAPES_CFG4 if s_[7] == 2], ids=[s_[0] + "_up" for s_ in SHAPES_CFG4 if s_[7] == 2])
+def test_batch64_inference_up_ladder(shape):
+    """configs[4]'s other half: the generator's up-ladder at batch 64 is the DATA-GRADIENT kernel run
+    forward (nn.ConvTranspose2d(3, stride 2, pad 1, output_padding 1) + bias, networks.py:349-352) -- 15 % of the
+    inference step on plans (conv_dgrad_dma_kernel<128,128> / <128,64> by parity class) that no training shape uses.
+    48 sampled output pixels (all channels) against float64, and the adjoint identity against the forward kernel."""
+    from mdctgan_amd import _lib, ops
+    name, B, H, W, Ci, Co, k, s, p, reflect = shape
+    g = ops.conv_geom(B, H, W, Ci, Co, k, k, s, p, reflect, _lib.PRECISION_F32)
+    gen = torch.Generator(device=DEV).manual_seed(len(name) + Co)
+    dyd = torch.randn(B, g.OH, g.OW, Co, generator=gen, device=DEV)           # the low-resolution input of the ConvTranspose2d
+    wd = torch.randn(Co * k * k * Ci, generator=gen, device=DEV).reshape(Co, k, k, Ci) / np.sqrt(Co * k * k / 4.0)
+    bd = torch.randn(Ci, generator=gen, device=DEV)
+    dx = ops.conv_dgrad(g, dyd, wd, bd)
+    assert ops.plan_name(1, g).startswith("conv_dgrad_dma_kernel"), ops.plan_name(1, g)
+    idx, want = sample_reference_dgrad(dyd.cpu(), wd.cpu(), bd.cpu(), B, H, W, Ci, Co, k, s, p, g.OH, g.OW)
+    got = dx[idx[:, 0], idx[:, 1], idx[:, 2]].double().cpu()
+    assert (got - want).abs().max().item() <= 3e-5 * want.abs().max().item(), (name, (got - want).abs().max().item())
+    # <conv(x), dy> == <x, dgrad(dy)> with the forward kernel of the same geometry (float64 inner products on the device)
+    xd = torch.randn(B, H, W, Ci, generator=gen, device=DEV)
+    y0 = ops.conv_fwd(g, xd, wd, None)
+    dx0 = ops.conv_dgrad(g, dyd, wd)
+    lhs, rhs = dot64(y0, dyd), dot64(xd, dx0)
+    assert abs(lhs - rhs) <= 2e-5 * np.sqrt(dot64(y0, y0) * dot64(dyd, dyd)), (name, lhs, rhs)
+    # the no-grad path's cached weight image (if this layer keeps one) gives the same bits
+    u = ops.wino_weights(g, wd)
+    if u is not None:
+        assert torch.equal(ops.conv_dgrad(g, dyd, wd, bd, u=u), dx), name
+
+
+def test_batch64_generate_against_oracle():
+    """generate_audio.py:28-53 at BASELINE configs[4]'s size: 64 segments of 32512 samples, 8 kHz content, through
+    generate() (model.inference at batch 64 + segment stitching, the bench's step).  Two of the 64 segments against the CPU
+    oracle (HotPathRef.inference, float32 generator + float64 transform) on the same weights: the generator's spectrogram at
+    1e-3 of its range (float32 yardstick), the decoded waveform against the oracle's decoder ON THE SAME spectrogram at
+    3e-6 (K2 alone), and against the oracle's end-to-end waveform at 1e-3 of its peak."""
+    from mdctgan_amd import options
+    from mdctgan_amd.generate_audio import generate
+    from mdctgan_amd.pix2pixHD_model import create_model
+    from oracle import nets as onets
+    from oracle import step as ostep
+    from oracle import transform
+    T, NSEG = 32512, 64
+    gen = torch.Generator().manual_seed(77)
+    netG = onets.init_weights(onets.build_generator("global", 2, 1, 64, 4, 9, input_size=(128, 256)), gen)
+    hr = 0.05 * torch.randn(NSEG, T, generator=gen)
+    spec = torch.fft.rfft(hr)
+    spec[:, spec.shape[-1] // 6:] = 0                    # 8 kHz content of a 48 kHz clip
+    lr = torch.fft.irfft(spec, n=T)
+    opt = options.make_opt(*options.SPECTRAL_FLAGS, "--lr_sampling_rate", "8000", "--netG", "global", "--ngf", "64",
+                           "--n_downsample_global", "4", "--n_blocks_global", "9", "--n_blocks_attn_g", "0", "--num_D", "2",
+                           "--batchSize", str(NSEG), "--gpu_ids", "0")
+    model = create_model(opt)
+    model.netG.load_state_dict(netG.state_dict())
+    lr_d = lr.to(DEV)
+    wave = generate(model, lr_d, batch_size=NSEG, gen_overlap=0)
+    assert wave.shape == (1, NSEG * T)
+    model.eval()
+    sr_spectro, sr_audio, _, _, _ = model.inference(lr_d)
+    model.train()
+    assert torch.equal(wave[0], sr_audio.reshape(-1)), "gen_overlap 0: stitching is concatenation (generate_audio.py:53)"
+    pick = [3, 63]
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, threads))
+    try:
+        ref = ostep.HotPathRef(netG, None, ostep.CodecCfg(lr_rate=8000), num_D=2)
+        o_spec, o_audio, o_norm, _ = ref.inference(lr[pick].numpy())
+    finally:
+        torch.set_num_threads(threads)
+    got_spec = sr_spectro[pick].cpu().numpy()
+    o_spec = o_spec.numpy()
+    assert np.abs(got_spec - o_spec).max() <= 1e-3 * max(np.abs(o_spec).max(), 1e-3), np.abs(got_spec - o_spec).max()
+    c = ostep.CodecCfg(lr_rate=8000)
+    same = transform.to_audio(got_spec, o_norm, c.window, c.n_fft, c.hop, **c.codec)        # K2 alone
+    got_wave = wave[0].reshape(NSEG, T)[pick].cpu().numpy()
+    same = np.asarray(same).reshape(len(pick), T)
+    assert np.abs(got_wave - same).max() <= 3e-6 * max(np.abs(same).max(), 1e-3) + 1e-7, np.abs(got_wave - same).max()
+    o_audio = np.asarray(o_audio).reshape(len(pick), T)
+    assert np.abs(got_wave - o_audio).max() <= 1e-3 * np.abs(o_audio).max(), np.abs(got_wave - o_audio).max()

@@ -162,3 +162,75 @@ def test_backward_pass_bookkeeping():
     e = Fh.WEIGHT_EPOCH[0]
     Fh.bump_weight_epoch()
     assert Fh.WEIGHT_EPOCH[0] == e + 1
+
+
+def test_load_network_fallbacks(tmp_path):
+    """BaseModel.load_network (models/base_model.py:49-111): (1) a matching checkpoint loads strictly; (2) a checkpoint with
+    EXCESSIVE layers loads the layers that exist (":66-70"); (3) a checkpoint with FEWER / renamed layers keeps the model's own
+    values where nothing matches, copies same-named same-sized tensors, skips size mismatches and follows --param_key_map
+    ("model.3:5" sends model.3.* to model.5.*; ":72-89"); a missing generator file raises, a missing discriminator file
+    returns (":54-57")."""
+    import torch.nn as nn
+    from mdctgan_amd.pix2pixHD_model import BaseModel
+
+    class Net(nn.Module):
+        def __init__(self, widths=(3, 4, 5)):
+            super().__init__()
+            self.model = nn.Sequential(nn.Conv2d(2, widths[0], 3), nn.ReLU(), nn.Conv2d(widths[0], widths[1], 3), nn.ReLU(),
+                                       nn.Conv2d(widths[1], widths[2], 1))
+
+    def fresh(seed, **kw):
+        torch.manual_seed(seed)
+        return Net(**kw)
+
+    opt = options.make_opt("--gpu_ids", "-1", "--checkpoints_dir", str(tmp_path), "--name", "exp",
+                           "--param_key_map", "model.3:4")
+    bm = BaseModel()
+    bm.initialize(opt)
+    assert bm.save_dir == str(tmp_path / "exp")
+    src = fresh(1)
+    bm.save_network(src, "G", "latest")
+    assert (tmp_path / "exp" / "latest_net_G.pth").is_file()             # the reference's file naming
+    # (1) strict
+    dst = fresh(2)
+    bm.load_network(dst, "G", "latest")
+    for k, v in dst.state_dict().items():
+        assert torch.equal(v, src.state_dict()[k]), k
+    # (2) excessive layers in the file
+    sd = dict(src.state_dict())
+    sd["model.9.weight"] = torch.randn(7, 7)
+    sd["extra.bias"] = torch.randn(3)
+    torch.save(sd, tmp_path / "exp" / "big_net_G.pth")
+    dst = fresh(3)
+    bm.load_network(dst, "G", "big")
+    for k, v in dst.state_dict().items():
+        assert torch.equal(v, src.state_dict()[k]), k
+    # (3) fewer layers, one renamed through param_key_map, one with another size
+    old = nn.Sequential(nn.Conv2d(2, 3, 3), nn.ReLU(), nn.Conv2d(3, 9, 3), nn.Conv2d(4, 5, 1))    # keys 0, 2 (9 != 4 outputs), 3
+    torch.manual_seed(4)
+    for p in old.parameters():
+        torch.nn.init.normal_(p)
+    torch.save({"model." + k: v for k, v in old.state_dict().items()}, tmp_path / "exp" / "old_net_G.pth")
+    dst = fresh(5)
+    before = {k: v.clone() for k, v in dst.state_dict().items()}
+    bm.load_network(dst, "G", "old")
+    got = dst.state_dict()
+    assert torch.equal(got["model.0.weight"], old.state_dict()["0.weight"])          # same name, same size: copied
+    assert torch.equal(got["model.2.weight"], before["model.2.weight"])              # size mismatch: kept
+    assert torch.equal(got["model.4.weight"], old.state_dict()["3.weight"])          # model.3.* -> model.4.* by the key map
+    assert torch.equal(got["model.4.bias"], old.state_dict()["3.bias"])
+    # missing files
+    with pytest.raises(FileNotFoundError):
+        bm.load_network(fresh(6), "G", "nope")
+    d = fresh(7)
+    keep = {k: v.clone() for k, v in d.state_dict().items()}
+    bm.load_network(d, "D", "nope")
+    for k, v in d.state_dict().items():
+        assert torch.equal(v, keep[k])
+    # save_dir override (opt.load_pretrain)
+    other = tmp_path / "elsewhere"
+    other.mkdir()
+    torch.save(src.state_dict(), other / "latest_net_G.pth")
+    dst = fresh(8)
+    bm.load_network(dst, "G", "latest", str(other))
+    assert torch.equal(dst.state_dict()["model.4.weight"], src.state_dict()["model.4.weight"])

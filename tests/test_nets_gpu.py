@@ -605,3 +605,53 @@ def test_published_checkpoint_architecture_runs():
             model.load_network(model.netG, "G", "latest")
             for k, v in model.netG.state_dict().items():
                 assert torch.equal(v, before[k]), k
+
+
+def test_published_checkpoint_architecture_against_oracle():
+    """SURVEY F3 / VERDICT r2 item 8: the generator of the published vctk checkpoints (train.sh:11-15 -- netG local, ngf 56
+    (channel counts 56 / 112 in the local branch, 112 ... 896 in the global one: not multiples of 64, several not of 16),
+    resconv / interpolate sampling blocks, 3 bottleneck-attention blocks of 6 x 128 heads on 8 x 16 tokens) at its real size
+    against the CPU oracle on the same N(0, 0.02) weights: forward, input gradient and EVERY parameter gradient, float64
+    truth with the oracle's float32 run as the yardstick.  The attention block inside is the oracle's restatement of the
+    third-party package (parity unpinned)."""
+    from mdctgan_amd import networks
+    kw = dict(input_size=(128, 256), n_attn_g=3, heads_g=6, dim_head_g=128, proj_factor_g=4)
+    gen = torch.Generator().manual_seed(56)
+    torch.manual_seed(56)
+    o = onets.init_weights(onets.build_generator("local", 2, 1, 56, 3, 4, 3, up="interpolate", down="resconv", **kw), gen)
+    sd = {k: v.clone() for k, v in o.state_dict().items()}
+    net = networks.define_G(2, 1, 56, "local", 3, 4, 1, 3, upsample_type="interpolate", downsample_type="resconv", **kw)
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    assert [tuple(v.shape) for v in net.state_dict().values()] == [tuple(v.shape) for v in sd.values()]
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    x = torch.rand(1, 2, 128, 256, generator=gen) * 2 - 1
+    gy = torch.randn(1, 1, 128, 256, generator=gen)
+    res = {}
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, threads))
+    try:
+        for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            o = o.to(dt).train()
+            o.load_state_dict({k: v.to(dt) if v.dtype.is_floating_point else v for k, v in sd.items()})   # reset BN buffers
+            o.zero_grad()
+            xx = x.clone().to(dt).requires_grad_()
+            y = o(xx)
+            (y * gy.to(dt)).sum().backward()
+            res[name] = dict(y=y.detach().numpy(), dx=xx.grad.numpy(),
+                             grads={k: p.grad.numpy().copy() for k, p in o.named_parameters()})
+    finally:
+        torch.set_num_threads(threads)
+    xd = x.to(DEV).requires_grad_()
+    y = net(xd)
+    (y * gy.to(DEV)).sum().backward()
+    judged(y.detach().cpu().numpy(), res["f32"]["y"], res["f64"]["y"], "published arch forward")
+    judged(xd.grad.cpu().numpy(), res["f32"]["dx"], res["f64"]["dx"], "published arch dL/dx", k=6.0)
+    live = 0
+    for k, p in net.named_parameters():
+        if _dead_bias(k, res["f64"]["grads"][k], res["f64"]["grads"]):
+            continue
+        assert p.grad is not None, k
+        judged(p.grad.cpu().numpy(), res["f32"]["grads"][k], res["f64"]["grads"][k], "published arch grad " + k, k=6.0)
+        live += 1
+    assert live >= 60, live
