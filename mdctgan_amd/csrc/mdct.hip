@@ -441,6 +441,8 @@ __global__ void stitch_kernel(const T* __restrict__ seg, int n_seg, int L, int o
 
 }  // namespace
 
+#include "mdct_bs.h"
+
 // frames per workgroup: a whole-clip tile (4 MFMAs per B fetch) once the launch fills the chip, 32 otherwise
 static int frames_per_wg(int B, int F) {
     if (const char* f = getenv("MG_MDCT_FT")) { const int v = atoi(f); return (v == 128 || v == 64) ? v : 32; }
@@ -478,6 +480,27 @@ int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* w
     }
     if (stats) hipMemsetAsync(stats, 0, 2 * sizeof(double), st);
     if (per_sample) hipLaunchKernelGGL(fill_u32_pairs, dim3((B + 255) / 256), dim3(256), 0, st, scratch_u32, B);
+    // round 3: the table-stationary kernel (mdct_bs.h) wherever its fast path applies; MG_MDCT_BS=0, or any of the older
+    // kernels' own switches (MG_MDCT_GEMM, MG_MDCT_FT), selects the round-1 / round-2 kernels below
+    static const bool bs_off = (getenv("MG_MDCT_BS") && atoi(getenv("MG_MDCT_BS")) == 0);
+    const bool legacy_forced = bs_off || getenv("MG_MDCT_GEMM") || getenv("MG_MDCT_FT");
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!legacy_forced && T % 4 == 0 && !per_sample && !frames_out && al16(audio) && al16(window) && al16(dct4) && al16(spec) &&
+        (!in2 || al16(in2))) {
+        const long long n_tiles = ((long long)B * F + BS_ROWS - 1) / BS_ROWS;
+        int nw = n_tiles >= 256 ? 8 : 2;
+        if (const char* e = getenv("MG_MDCT_BS_NW")) nw = atoi(e) == 8 ? 8 : 2;
+        static bool attr_bs = false;
+        if (!attr_bs) { allow_lds(mdct4_bs_kernel<8>, BS_K1_LDS); allow_lds(mdct4_bs_kernel<2>, BS_K1_LDS); attr_bs = true; }
+        if (nw == 8)
+            hipLaunchKernelGGL(mdct4_bs_kernel<8>, dim3((unsigned)(n_tiles < 256 ? n_tiles : 256), 1), dim3(512), BS_K1_LDS, st,
+                               audio, B, T, F, window, dct4, cp, spec, in2, stats);
+        else
+            hipLaunchKernelGGL(mdct4_bs_kernel<2>, dim3((unsigned)(n_tiles < 256 ? n_tiles : 256), 4), dim3(128), BS_K1_LDS, st,
+                               audio, B, T, F, window, dct4, cp, spec, in2, stats);
+        MG_CHECK_LAUNCH();
+        return MG_OK;
+    }
     // large batches: the tiled GEMM kernel (B operand shared through LDS); MG_MDCT_GEMM=0/1 overrides
     const long long row_tiles = ((long long)B * F + 127) / 128;
     bool gemm = row_tiles >= 256;
@@ -533,6 +556,22 @@ int mg_imdct4_forward(const float* spec, int B, int F, int n_fft, const float* w
         allow_lds(imdct4_kernel<float, 64>, (65 * LDA + 2 * M) * sizeof(float));
         allow_lds(imdct4_kernel<double, 64>, (65 * LDA + 2 * M) * sizeof(float));
         attr_done = true;
+    }
+    {
+        static const bool bs_off = (getenv("MG_MDCT_BS") && atoi(getenv("MG_MDCT_BS")) == 0);
+        auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        if (!bs_off && !getenv("MG_MDCT_FT") && !frames_out && al16(spec) && al16(window) && al16(dct4) && al16(audio)) {
+            const long long n_tiles = (long long)B * ((F + BS_ROWS - 1) / BS_ROWS);
+            static bool attr_bs = false;
+            if (!attr_bs) { allow_lds(imdct4_bs_kernel<float>, BS_K2_LDS); allow_lds(imdct4_bs_kernel<double>, BS_K2_LDS); attr_bs = true; }
+            const dim3 grid((unsigned)(n_tiles < 256 ? n_tiles : 256));
+            if (out_f64)
+                hipLaunchKernelGGL(imdct4_bs_kernel<double>, grid, dim3(512), BS_K2_LDS, st, spec, B, F, window, dct4, cp, (double*)audio, out_len);
+            else
+                hipLaunchKernelGGL(imdct4_bs_kernel<float>, grid, dim3(512), BS_K2_LDS, st, spec, B, F, window, dct4, cp, (float*)audio, out_len);
+            MG_CHECK_LAUNCH();
+            return MG_OK;
+        }
     }
 #define MG_IMDCT(T_, FT_)                                                                                            \
     hipLaunchKernelGGL((imdct4_kernel<T_, FT_>), dim3((F + FT_ - 1) / FT_, B), dim3(256),                            \

@@ -85,7 +85,7 @@ def _opt(**kw):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["db_abs", "db_per_sample", "explicit_abs", "explicit_per_sample", "raw_per_sample", "arcsinh_2048"])
-def test_audio2mdct_codec_branches_against_oracle(mode):
+def test_audio2mdct_codec_branches_against_oracle(mode, monkeypatch):
     from mdctgan_amd.pix2pixHD_model import Audio2MDCT
     kw, n_fft, hop = dict(), 512, 256
     ocodec = dict(norm_range=(-1.0, 1.0))
@@ -138,17 +138,34 @@ def test_audio2mdct_codec_branches_against_oracle(mode):
         np.testing.assert_allclose(norm["max"].cpu().numpy().reshape(-1), wnorm["max"].reshape(-1), atol=1e-2)
     np.testing.assert_allclose(float(norm["mean"]), float(wnorm["mean"]), rtol=2e-2 if db else 1e-4, atol=1e-5)
     np.testing.assert_allclose(float(norm["std"]), float(wnorm["std"]), rtol=5e-2 if db else 1e-4)
-    # decoder on the oracle's spectrogram, with the plain sign as phase for the dB codec (up_ratio forced to 1: no
-    # random pseudo-phase), against the oracle's decoder and against the original waveform
+    # decoder on the oracle's spectrogram against the oracle's decoder and the original waveform.  The dB codec's sign
+    # restore mirrors the reference AS WRITTEN (pix2pixHD_model.py:147-157): `spectro * pha` sits inside
+    # `if self.up_ratio > 1`, where the frames beyond int(F / up_ratio) get a random +-1 pseudo-phase (torch.randint,
+    # pinned to +1 here); at up_ratio == 1 the magnitudes are decoded unsigned.
     sign = np.sign(X)[:, None]
-    pre.up_ratio = 1
-    back = pre.to_audio(torch.from_numpy(ws).cuda(), {k: (torch.from_numpy(np.asarray(v)).cuda() if k in ("min", "max") else v)
-                                                     for k, v in wnorm.items()},
-                        torch.from_numpy(sign.astype(np.float32)).cuda() if mode.startswith("db") else None)
-    wback = T.to_audio(ws.astype(np.float64), wnorm, w, n_fft, hop, pha=sign, **ocodec)
-    assert back.shape == wback.shape
-    assert np.abs(back.cpu().numpy() - wback).max() <= 1e-5 * max(np.abs(wback).max(), 1e-3)
-    assert np.abs(back.cpu().numpy()[:, 0, 0] - x).max() <= 3e-5
+    nparam = {k: (torch.from_numpy(np.asarray(v)).cuda() if k in ("min", "max") else v) for k, v in wnorm.items()}
+    if mode.startswith("db"):
+        sg_d = torch.from_numpy(sign.astype(np.float32)).cuda()
+        pre.up_ratio = 1
+        back = pre.to_audio(torch.from_numpy(ws).cuda(), nparam, sg_d)
+        wback = T.to_audio(ws.astype(np.float64), wnorm, w, n_fft, hop, pha=None, **ocodec)
+        assert np.abs(back.cpu().numpy() - wback).max() <= 1e-5 * max(np.abs(wback).max(), 1e-3)
+        pre.up_ratio = 4.0
+        monkeypatch.setattr(torch, "randint", lambda low, high, size, device=None: torch.ones(tuple(size), dtype=torch.int64, device=device))
+        back = pre.to_audio(torch.from_numpy(ws).cuda(), nparam, sg_d)
+        monkeypatch.undo()
+        keep = int(sign.shape[-2] * (1 / 4.0))
+        ph = sign.copy()
+        ph[..., keep:, :] = 1.0
+        wback = T.to_audio(ws.astype(np.float64), wnorm, w, n_fft, hop, pha=ph, **ocodec)
+        assert back.shape == wback.shape
+        assert np.abs(back.cpu().numpy() - wback).max() <= 1e-5 * max(np.abs(wback).max(), 1e-3)
+    else:
+        back = pre.to_audio(torch.from_numpy(ws).cuda(), nparam, None)
+        wback = T.to_audio(ws.astype(np.float64), wnorm, w, n_fft, hop, pha=None, **ocodec)
+        assert back.shape == wback.shape
+        assert np.abs(back.cpu().numpy() - wback).max() <= 1e-5 * max(np.abs(wback).max(), 1e-3)
+        assert np.abs(back.cpu().numpy()[:, 0, 0] - x).max() <= 3e-5
     if mode.startswith("db"):
         sg = torch.from_numpy(sign.astype(np.float32)).cuda()
         assert pha is not None and bool(((torch.sign(pha) == sg) | (pha == 0)).all())     # sign(X) x noise in [0, 1]
