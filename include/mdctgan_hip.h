@@ -59,8 +59,11 @@ int mg_conv_geom_size(void);
  *   frames_out (nullable): windowed frames [B, F, n_fft] (return_frames=True).
  *   stats (nullable): double[2] = sum(L), sum(L^2) over the batch (for the returned mean / std).
  *   scratch_u32: >= 2*B uint32, required when per_sample != 0.
- *   window [n_fft], dct4 [n_fft/2][n_fft/2] (cos(pi/M (n+1/2)(k+1/2))) are device tables.
+ *   window [n_fft] and dct4 are device tables.  dct4 = 2 * (n_fft/2)^2 floats: the [n_fft/2][n_fft/2] table
+ *   cos(pi/M (n+1/2)(k+1/2)) followed by its register image, which mg_dct4_image(dct4, dct4 + (n_fft/2)^2, stream)
+ *   writes once (the table-stationary kernels of csrc/mdct_bs.h load their operand slabs from it, coalesced).
  */
+int mg_dct4_image(const float* dct4, float* image, void* stream);
 int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* window, const float* dct4,
                      int codec, float gain, float nr0, float nr1, float src_min, float src_max, int per_sample,
                      float* spec, float* in2, float* frames_out, float* min_out, float* max_out,

@@ -46,6 +46,7 @@ SIGNATURES = {
     "mg_conv_geom_size": (_i, []),
     "mg_mdct4_forward": (_i, [_p, _i, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "mg_mdct4_num_frames": (_i, [_i, _i]),
+    "mg_dct4_image": (_i, [_p, _p, _p]),
     "mg_imdct4_forward": (_i, [_p, _i, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _p, _p, _p, _i, _i, _p, _p]),
     "mg_conv_fwd": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p]),
     "mg_conv_fwd_workspace": (_sz, [_G]),

@@ -485,19 +485,24 @@ int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* w
     static const bool bs_off = (getenv("MG_MDCT_BS") && atoi(getenv("MG_MDCT_BS")) == 0);
     const bool legacy_forced = bs_off || getenv("MG_MDCT_GEMM") || getenv("MG_MDCT_FT");
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    if (!legacy_forced && T % 4 == 0 && !per_sample && !frames_out && al16(audio) && al16(window) && al16(dct4) && al16(spec) &&
-        (!in2 || al16(in2))) {
-        const long long n_tiles = ((long long)B * F + BS_ROWS - 1) / BS_ROWS;
+    const long long n_rows = (long long)B * F;
+    if (!legacy_forced && T % 4 == 0 && !per_sample && !frames_out && !stats && (codec == CODEC_RAW || codec == CODEC_ARCSINH) &&
+        !(codec == CODEC_RAW && in2) && n_rows * M * 8 < (1ll << 32) - (1ll << 17) && (long long)B * T * 4 < (1ll << 32) &&
+        al16(audio) && al16(window) && al16(dct4) && al16(spec) && (!in2 || al16(in2))) {
+        const long long n_tiles = (n_rows + BS_ROWS - 1) / BS_ROWS;
         int nw = n_tiles >= 256 ? 8 : 2;
         if (const char* e = getenv("MG_MDCT_BS_NW")) nw = atoi(e) == 8 ? 8 : 2;
-        static bool attr_bs = false;
-        if (!attr_bs) { allow_lds(mdct4_bs_kernel<8>, BS_K1_LDS); allow_lds(mdct4_bs_kernel<2>, BS_K1_LDS); attr_bs = true; }
-        if (nw == 8)
-            hipLaunchKernelGGL(mdct4_bs_kernel<8>, dim3((unsigned)(n_tiles < 256 ? n_tiles : 256), 1), dim3(512), BS_K1_LDS, st,
-                               audio, B, T, F, window, dct4, cp, spec, in2, stats);
-        else
-            hipLaunchKernelGGL(mdct4_bs_kernel<2>, dim3((unsigned)(n_tiles < 256 ? n_tiles : 256), 4), dim3(128), BS_K1_LDS, st,
-                               audio, B, T, F, window, dct4, cp, spec, in2, stats);
+        const dim3 grid((unsigned)(n_tiles < 256 ? n_tiles : 256), 8 / nw), block(nw * 64);
+#define MG_K1_BS(NW_, MODE_, PAIR_)                                                                                       \
+    do {                                                                                                                   \
+        static bool attr = false;                                                                                          \
+        if (!attr) { allow_lds(mdct4_bs_kernel<NW_, MODE_, PAIR_>, BS_K1_LDS); attr = true; }                              \
+        hipLaunchKernelGGL((mdct4_bs_kernel<NW_, MODE_, PAIR_>), grid, block, BS_K1_LDS, st, audio, B, T, F, window, dct4, cp, spec, in2); \
+    } while (0)
+        if (codec == CODEC_RAW) { if (nw == 8) MG_K1_BS(8, CODEC_RAW, false); else MG_K1_BS(2, CODEC_RAW, false); }
+        else if (in2) { if (nw == 8) MG_K1_BS(8, CODEC_ARCSINH, true); else MG_K1_BS(2, CODEC_ARCSINH, true); }
+        else { if (nw == 8) MG_K1_BS(8, CODEC_ARCSINH, false); else MG_K1_BS(2, CODEC_ARCSINH, false); }
+#undef MG_K1_BS
         MG_CHECK_LAUNCH();
         return MG_OK;
     }
@@ -531,6 +536,13 @@ int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* w
                            nr1, min_out, max_out);
         MG_CHECK_LAUNCH();
     }
+    return MG_OK;
+}
+
+int mg_dct4_image(const float* dct4, float* image, void* stream) {
+    if (!dct4 || !image || (reinterpret_cast<uintptr_t>(dct4) & 15) || (reinterpret_cast<uintptr_t>(image) & 15)) return MG_ERR_ARG;
+    hipLaunchKernelGGL(dct4_image_kernel, dim3(M * M / 4 / 256), dim3(256), 0, (hipStream_t)stream, dct4, image);
+    MG_CHECK_LAUNCH();
     return MG_OK;
 }
 

@@ -78,112 +78,186 @@ __device__ __forceinline__ float4 bs_rev4(const float4 v) { return make_float4(v
 // ------------------------------------------------------------------------------------------------------------------
 // K1
 // ------------------------------------------------------------------------------------------------------------------
-template <int NW>
+// Register image of the table (mg_dct4_image, stored right behind the [M][M] table): float4 img[slab = bin / 32][jj][lane] =
+// D4[32 slab + (lane & 31)][8 jj + 4 (lane >> 5) + (0..3)] -- a wave's load of step jj is one coalesced 1 KiB read (the
+// same values straight from the [M][M] table are 32 lines x 32 bytes per instruction).
+__global__ void dct4_image_kernel(const float* __restrict__ d4, float* __restrict__ img) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;            // one float4 each: M * M / 4 of them
+    if (i >= M * M / 4) return;
+    const int lane = i & 63, jj = (i >> 6) & 31, slab = i >> 11;
+    reinterpret_cast<float4*>(img)[i] = *reinterpret_cast<const float4*>(d4 + (size_t)(32 * slab + (lane & 31)) * M + 8 * jj + 4 * (lane >> 5));
+}
+
+// One tile of a wave is 128 MFMAs on ONE accumulator (64-cycle dependent issue, 128 with the SIMD's second wave beside it):
+// every gap takes a handful of independent instructions for free, but the wave issues IN ORDER -- work placed behind a run
+// of MFMAs only sees the last gap.  The kernel therefore runs three tiles at once per wave, interleaved per MFMA: the MFMA
+// stream of tile i, the codec + stores of tile i - 1 out of a second accumulator (one frame row per two table steps) and
+// the fold of tile i + 1 into the other LDS buffer (signal loads issued at the top of the iteration, folded in the second
+// half of the stream).  The iteration body is ONE basic block -- masked lanes are out-of-range buffer offsets, the codec and
+// the pair are template parameters, selects instead of branches -- cut by hand into pieces of a few instructions, one piece
+// behind each MFMA, fenced with sched_barrier so that the compiler keeps them there (phases measured before, scripts/ubench/mdct_bs_bench at 4096 clips: 485 us of
+// MFMA + 160 fold + 105 codec + 100..200 stores, nothing overlapping).
+// MODE: CODEC_RAW / CODEC_ARCSINH.  DBG (ubench only): bit 0 no global stores, bit 1 no codec arithmetic, bit 2 no fold.
+typedef unsigned bs_v2u __attribute__((ext_vector_type(2)));
+typedef unsigned bs_v4u __attribute__((ext_vector_type(4)));
+constexpr unsigned BS_OOB = 0xffffffffu;          // buffer offset behind every num_records: the lane's access is dropped
+
+template <int NW, int MODE, bool PAIR, int DBG = 0>
 __global__ __launch_bounds__(NW * 64) void mdct4_bs_kernel(const float* __restrict__ audio, int B, int T, int F,
                                                            const float* __restrict__ window, const float* __restrict__ dct4,
-                                                           CodecParams cp, float* __restrict__ spec, float* __restrict__ in2,
-                                                           double* __restrict__ stats) {
+                                                           CodecParams cp, float* __restrict__ spec, float* __restrict__ in2) {
     constexpr int NT = NW * 64, Q = M / 2;
-    constexpr int GROUPS = BS_ROWS * (M / 4) / NT;        // float4 groups of the folded tile per thread
+    constexpr int GROUPS = BS_ROWS * (M / 4) / NT;        // float4 groups of the folded tile per thread (4 / 16)
+    constexpr int FSTEP = 16 / GROUPS;                    // fold slice g rides behind table step 16 + g * FSTEP
     extern __shared__ __attribute__((aligned(16))) float bs_smem[];
     float* ws = bs_smem;                                  // [2 M] window
     float* abuf = bs_smem + 2 * M;                        // [2][BS_ROWS][BS_LDA]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rows = B * F, n_tiles = (rows + BS_ROWS - 1) / BS_ROWS;
-    const int col = (blockIdx.y * NW + wave) * 32 + (lane & 31), kh = lane >> 5;
-    const BsCodec cd = bs_codec(cp);
+    const int rows = B * F, n_tiles = (rows + BS_ROWS - 1) / BS_ROWS, G = gridDim.x;
+    const int slab = blockIdx.y * NW + wave, col = slab * 32 + (lane & 31), kh = lane >> 5;
+    BsCodec cd = bs_codec(cp);
+    cd.mode = MODE;
+    const __amdgpu_buffer_rsrc_t r_audio = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(audio), 0, (unsigned)B * (unsigned)T * 4u, 0x00020000);
+    // DBG bit 0: an empty range drops every store (the arithmetic stays alive)
+    const __amdgpu_buffer_rsrc_t r_spec = __builtin_amdgcn_make_buffer_rsrc(spec, 0, (DBG & 1) ? 0u : (unsigned)rows * M * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_in2 = __builtin_amdgcn_make_buffer_rsrc(in2, 0, (PAIR && !(DBG & 1)) ? (unsigned)rows * M * 8u : 0u, 0x00020000);
 
-    // the wave's slab of the table: 32 float4 = bins [col] x k = 8 jj + 4 kh + (0..3)
-    float4 bt[32];
-#pragma unroll
-    for (int jj = 0; jj < 32; ++jj) bt[jj] = bs_ld4(dct4 + (size_t)col * M + 8 * jj + 4 * kh);
-    for (int i = tid; i < 2 * M / 4; i += NT) reinterpret_cast<float4*>(ws)[i] = bs_ld4(window + 4 * i);
-
-    // group gi of a thread: row r = (tid + gi * NT) / 64 of the tile, u[n .. n + 3] with n = 4 * ((tid + gi * NT) % 64)
-    float4 x1[GROUPS], x2[GROUPS];
-    auto offsets = [&](int n, int& o1, int& o2) {
-        if (n < Q) { o1 = 3 * Q - 4 - n; o2 = 3 * Q + n; }        // u = -rev(z[o1..]) - z[o2..]
-        else { o1 = n - Q; o2 = 3 * Q - 4 - n; }                   // u =  z[o1..] - rev(z[o2..])
-    };
+    // group gi of a thread: row r = (tid + gi * NT) / 64 of the tile, u[n .. n + 3] with n = 4 * (lane); lanes 0-31 hold the
+    // n < Q half:  u = -rev(z[3Q-4-n ..]) - z[3Q+n ..]   lanes 32-63:  u = z[n-Q ..] - rev(z[3Q-4-n ..])
+    const int n = 4 * lane;
+    const bool lo = n < Q;
+    const int o1 = lo ? 3 * Q - 4 - n : n - Q, o2 = lo ? 3 * Q + n : 3 * Q - 4 - n;
+    bs_v4u x1[GROUPS], x2[GROUPS];
     auto load_tile = [&](int tile) {
 #pragma unroll
         for (int gi = 0; gi < GROUPS; ++gi) {
-            const int i = tid + gi * NT, r = i >> 6, n = 4 * (i & 63);
+            const int r = wave + gi * NW;                 // (tid + gi * NT) >> 6
             const int m = tile * BS_ROWS + r;
-            int o1, o2;
-            offsets(n, o1, o2);
-            x1[gi] = x2[gi] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < rows) {
-                const int b = m / F, f = m - b * F;
-                const float* x = audio + (size_t)b * T;
-                const int t1 = f * M - M + o1, t2 = f * M - M + o2;     // T % 4 == 0: a float4 is inside or outside as a whole
-                if (t1 >= 0 && t1 + 3 < T) x1[gi] = bs_ld4(x + t1);
-                if (t2 >= 0 && t2 + 3 < T) x2[gi] = bs_ld4(x + t2);
-            }
+            const int b = m / F, f = m - b * F;
+            const int t1 = f * M - M + o1, t2 = f * M - M + o2;     // T % 4 == 0: a float4 is inside or outside the clip as a whole
+            const unsigned base = (unsigned)b * (unsigned)T;
+            const unsigned a1 = (m < rows && t1 >= 0 && t1 + 3 < T) ? (base + (unsigned)t1) * 4u : BS_OOB;
+            const unsigned a2 = (m < rows && t2 >= 0 && t2 + 3 < T) ? (base + (unsigned)t2) * 4u : BS_OOB;
+            x1[gi] = __builtin_amdgcn_raw_buffer_load_b128(r_audio, a1, 0, 0);      // out of range reads 0: the zero padding
+            x2[gi] = __builtin_amdgcn_raw_buffer_load_b128(r_audio, a2, 0, 0);
         }
     };
-    auto fold_tile = [&](int buf) {
-#pragma unroll
-        for (int gi = 0; gi < GROUPS; ++gi) {
-            const int i = tid + gi * NT, r = i >> 6, n = 4 * (i & 63);
-            int o1, o2;
-            offsets(n, o1, o2);
-            const float4 w1 = bs_ld4(ws + o1), w2 = bs_ld4(ws + o2);
-            const float4 a = x1[gi], c = x2[gi];
-            // z = fl32(x * w) (mdct.py:410), then the TDAC fold
-            const float4 z1 = make_float4(__fmul_rn(a.x, w1.x), __fmul_rn(a.y, w1.y), __fmul_rn(a.z, w1.z), __fmul_rn(a.w, w1.w));
-            const float4 z2 = make_float4(__fmul_rn(c.x, w2.x), __fmul_rn(c.y, w2.y), __fmul_rn(c.z, w2.z), __fmul_rn(c.w, w2.w));
+    // The fold of one group and the codec + store of one frame row, cut into pieces that ride behind single MFMAs
+    // (fold_piece 0..3, epi_piece 0..7); state between the pieces lives in these registers.
+    float4 fw1, fw2, fz1, fz2;
+    auto fold_piece = [&](int pc, int gi, int buf) {
+        const int r = wave + gi * NW;
+        if (pc == 0) {
+            fw1 = bs_ld4(ws + o1); fw2 = bs_ld4(ws + o2);
+        } else if (pc == 1) {       // z = fl32(x * w) (mdct.py:410)
+            const float4 a = __builtin_bit_cast(float4, x1[gi]), c = __builtin_bit_cast(float4, x2[gi]);
+            fz1 = make_float4(__fmul_rn(a.x, fw1.x), __fmul_rn(a.y, fw1.y), __fmul_rn(a.z, fw1.z), __fmul_rn(a.w, fw1.w));
+            fz2 = make_float4(__fmul_rn(c.x, fw2.x), __fmul_rn(c.y, fw2.y), __fmul_rn(c.z, fw2.z), __fmul_rn(c.w, fw2.w));
+        } else if (pc == 2) {       // the TDAC fold as  u = p - q,  (p, q) = (-rev(z1), z2) | (z1, rev(z2))
             float4 u;
-            if (n < Q) {
-                const float4 r1 = bs_rev4(z1);
-                u = make_float4(-r1.x - z2.x, -r1.y - z2.y, -r1.z - z2.z, -r1.w - z2.w);
-            } else {
-                const float4 r2 = bs_rev4(z2);
-                u = make_float4(z1.x - r2.x, z1.y - r2.y, z1.z - r2.z, z1.w - r2.w);
-            }
-            *reinterpret_cast<float4*>(abuf + (size_t)buf * BS_ROWS * BS_LDA + r * BS_LDA + n) = u;
+            u.x = (lo ? -fz1.w : fz1.x) - (lo ? fz2.x : fz2.w);
+            u.y = (lo ? -fz1.z : fz1.y) - (lo ? fz2.y : fz2.z);
+            u.z = (lo ? -fz1.y : fz1.z) - (lo ? fz2.z : fz2.y);
+            u.w = (lo ? -fz1.x : fz1.w) - (lo ? fz2.w : fz2.x);
+            fz1 = u;
+        } else {
+            *reinterpret_cast<float4*>(abuf + (size_t)buf * BS_ROWS * BS_LDA + r * BS_LDA + n) = fz1;
         }
+    };
+    auto fold_slice = [&](int gi, int buf) {
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) fold_piece(pc, gi, buf);
+    };
+    float ea, ea2, et, ep, esq, esm, el, ev;
+    unsigned eob = BS_OOB, eob2 = BS_OOB;   // byte offset of (first frame row of this lane's 16, bin col) in spec / in the pair
+    auto epi_piece = [&](int pc, float xv, int r) {      // frame row emrow + (r & 3) + 8 (r >> 2), bin col
+        const int dm = (r & 3) + 8 * (r >> 2);
+        if (MODE == CODEC_RAW || (DBG & 2)) {
+            if (pc == 0) ev = xv;
+        } else if (pc == 0) {
+            const float y = cd.gain * xv;
+            ea = fabsf(y); ea2 = ea * ea; et = ea2 + 1.0f; el = y;
+        } else if (pc == 1) {
+            esq = __builtin_amdgcn_sqrtf(et);
+            ep = fmaf(ea2, fmaf(ea2, fmaf(ea2, -0.044642857142857144f, 0.075f), -0.16666666666666666f), 1.0f);
+        } else if (pc == 2) {
+            et = __builtin_amdgcn_logf(ea + esq);
+            esm = ea * ep * INV_LN10F;
+        } else if (pc == 3) {
+            const float big = et * LOG10_2F;
+            el = copysignf(ea < 0.125f ? esm : big, el) - cd.mn;
+        } else if (pc == 4) {
+            ev = div_const(el, cd.d, cd.rd) * cd.span + cd.nr0;
+        }
+        // addressing costs no VALU: the row inside the tile is the instruction's scalar offset, and a row behind the last one
+        // lies behind num_records (the range check covers voffset + soffset), so the hardware drops it
+        if (pc == 6) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ev), r_spec, eob, dm * (M * 4), 0);
+        } else if (pc == 7 && PAIR) {
+            const bs_v2u pr = {__float_as_uint(ev), __float_as_uint(fabsf(ev) * 2.0f + cd.nr0)};
+            __builtin_amdgcn_raw_buffer_store_b64(pr, r_in2, eob2, dm * (M * 8), 0);
+        }
+    };
+    auto epi_row = [&](float xv, int r) {
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) epi_piece(pc, xv, r);
+    };
+    auto epi_begin = [&](int tile) {         // tile == n_tiles: nothing to store
+        const unsigned m0 = (unsigned)tile * BS_ROWS + 4u * kh;
+        eob = (tile < n_tiles) ? (m0 * M + (unsigned)col) * 4u : BS_OOB - 31u * M * 8u;      // (+ soffset stays out of range, no wrap)
+        eob2 = (tile < n_tiles) ? 2u * eob : eob;
     };
 
-    double s1 = 0.0, s2 = 0.0;
+    // prologue: the first tile's signal first (HBM latency), then window and table; the fold runs while the table arrives
     int tile = blockIdx.x;
-    if (tile < n_tiles) load_tile(tile);
+    load_tile(tile < n_tiles ? tile : n_tiles);           // (tile n_tiles: every row out of range)
+    float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 2 * M / 4) wv = bs_ld4(window + 4 * tid);
+    float4 bt[32];          // the wave's slab of the table: bins [col] x k = 8 jj + 4 kh + (0..3)
+    {
+        const float4* img = reinterpret_cast<const float4*>(dct4 + M * M) + (size_t)slab * 32 * 64 + lane;
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) bt[jj] = img[jj * 64];
+    }
+    if (tid < 2 * M / 4) reinterpret_cast<float4*>(ws)[tid] = wv;
     __syncthreads();                              // window in LDS
-    if (tile < n_tiles) fold_tile(0);
+#pragma unroll
+    for (int gi = 0; gi < GROUPS; ++gi) fold_slice(gi, 0);
     __syncthreads();
+
+    f32x16 accp = f32x16{0};
     int buf = 0;
-    for (; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
-        const int next = tile + gridDim.x;
-        if (next < n_tiles) load_tile(next);      // global loads in flight under the MFMA stream
+    epi_begin(n_tiles);                           // no previous tile yet
+    constexpr int PPJ = 4 / FSTEP;                // fold pieces per table step in the second half (1: NW = 8, 4: NW = 2)
+    for (; tile < n_tiles; tile += G, buf ^= 1) {
+        const int next = tile + G;
+        if (!(DBG & 4)) load_tile(next < n_tiles ? next : n_tiles);      // global loads in flight under the first half of the stream
+        // (two alternating accumulator chains measured no better: 550 vs 512 us for the bare MFMA stream at 4096 clips)
         f32x16 acc = f32x16{0};
         const float* ap = abuf + (size_t)buf * BS_ROWS * BS_LDA + (lane & 31) * BS_LDA + 4 * kh;
+        float4 a = bs_ld4(ap), an = a;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int jj = 0; jj < 32; ++jj) {
-            const float4 a = bs_ld4(ap + 8 * jj);
-            acc = mfma32x32x2(a.x, bt[jj].x, acc);
-            acc = mfma32x32x2(a.y, bt[jj].y, acc);
-            acc = mfma32x32x2(a.z, bt[jj].z, acc);
-            acc = mfma32x32x2(a.w, bt[jj].w, acc);
-        }
-        // epilogue: codec + stores (lane: bin col, 16 frames)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = tile * BS_ROWS + mfma32_row(r, lane);
-            if (m >= rows) continue;
-            float l;
-            const float v = bs_encode(acc[r], cd, l);
-            if (stats && cd.mode != CODEC_RAW) { s1 += (double)l; s2 += (double)l * (double)l; }
-            const size_t o = (size_t)m * M + col;
-            spec[o] = v;
-            if (in2) *reinterpret_cast<float2*>(in2 + 2 * o) = make_float2(v, fabsf(v) * 2.0f + cd.nr0);
+            for (int t = 0; t < 4; ++t) {
+                const float av = t == 0 ? a.x : t == 1 ? a.y : t == 2 ? a.z : a.w;
+                const float bv = t == 0 ? bt[jj].x : t == 1 ? bt[jj].y : t == 2 ? bt[jj].z : bt[jj].w;
+                acc = mfma32x32x2(av, bv, acc);
+                if (t == 0 && jj + 1 < 32) an = bs_ld4(ap + 8 * (jj + 1));       // next step's A operand, one step ahead
+                epi_piece(4 * (jj & 1) + t, accp[jj >> 1], jj >> 1);
+                if (!(DBG & 4) && jj >= 16 && t >= 4 - PPJ)
+                    fold_piece(((jj - 16) % FSTEP) * PPJ + (t - (4 - PPJ)), (jj - 16) / FSTEP, buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);      // nothing moves across: each MFMA keeps its piece in its shadow
+            }
+            a = an;
         }
-        if (next < n_tiles) fold_tile(buf ^ 1);
+        accp = acc;
+        epi_begin(tile);
         __syncthreads();
     }
-    if (stats && cd.mode != CODEC_RAW) {
-        s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
-        if (lane == 0) { atomicAdd(stats, s1); atomicAdd(stats + 1, s2); }
-    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) epi_row(accp[r], r);
 }
 
 constexpr size_t BS_K1_LDS = (size_t)(2 * M + 2 * BS_ROWS * BS_LDA) * sizeof(float);
@@ -207,8 +281,11 @@ __global__ __launch_bounds__(512) void imdct4_bs_kernel(const float* __restrict_
     const int col = wave * 32 + (lane & 31), kh = lane >> 5;
 
     float4 bt[32];
+    {
+        const float4* img = reinterpret_cast<const float4*>(dct4 + M * M) + (size_t)wave * 32 * 64 + lane;
 #pragma unroll
-    for (int jj = 0; jj < 32; ++jj) bt[jj] = bs_ld4(dct4 + (size_t)col * M + 8 * jj + 4 * kh);
+        for (int jj = 0; jj < 32; ++jj) bt[jj] = img[jj * 64];
+    }
     for (int i = tid; i < 2 * M / 4; i += NT) reinterpret_cast<float4*>(ws)[i] = bs_ld4(window + 4 * i);
 
     float4 xr[GROUPS];

@@ -37,12 +37,20 @@ _dct4_cache = {}
 
 
 def dct4_table(m: int, device) -> torch.Tensor:
-    """D4[n, k] = cos(pi/M (n + 1/2)(k + 1/2)) evaluated in float64 on the host, rounded once to float32."""
+    """D4[n, k] = cos(pi/M (n + 1/2)(k + 1/2)) evaluated in float64 on the host, rounded once to float32 -- followed, in the
+    same buffer, by the register image of it that the table-stationary kernels load (mg_dct4_image; include/mdctgan_hip.h:
+    the `dct4` argument of mg_mdct4_forward / mg_imdct4_forward is 2 * m * m floats).  Returns the flat [2 * m * m] tensor;
+    ``dct4_table(m, dev)[:m * m].view(m, m)`` is the table itself."""
     key = (m, str(device))
     t = _dct4_cache.get(key)
     if t is None:
         n = torch.arange(m, dtype=torch.float64) + 0.5
-        t = torch.cos((math.pi / m) * torch.outer(n, n)).to(torch.float32).to(device).contiguous()
+        tab = torch.cos((math.pi / m) * torch.outer(n, n)).to(torch.float32)
+        t = torch.zeros(2 * m * m, dtype=torch.float32, device=device)
+        t[:m * m] = tab.reshape(-1).to(device)
+        if m == 256:        # the fused n_fft = 512 kernels are the only users of the image
+            lib = _lib.load()
+            _lib.check(lib.mg_dct4_image(_lib.ptr(t), t.data_ptr() + 4 * m * m, _lib.stream()), "mg_dct4_image")
         _dct4_cache[key] = t
     return t
 

@@ -24,7 +24,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     cnt[k][r["Counter_Name"]] += 1
 rows = []
 for k, c in acc.items():
-    if "GRBM_GUI_ACTIVE" not in c or not k.startswith(("dgemm32", "conv_", "hgemm", "dense_")):
+    if "GRBM_GUI_ACTIVE" not in c or not k.startswith(("dgemm32", "conv_", "hgemm", "dense_", "mdct4_", "imdct4_")):
         continue
     n = cnt[k]["GRBM_GUI_ACTIVE"]
     cyc = c["GRBM_GUI_ACTIVE"] / n / 8.0
@@ -34,11 +34,14 @@ for k, c in acc.items():
     rows.append((k, n, round(cyc), round(mfma), round(mfma / cyc, 3) if cyc else 0, round(waves / 1024.0, 2),
                  round(4.0 * wave_cyc / waves / cyc, 3) if waves and cyc else 0,
                  round(c.get("SQ_WAIT_INST_ANY", 0.0) / n / wave_cyc, 3) if wave_cyc else 0,
-                 round(c.get("SQ_WAIT_INST_LDS", 0.0) / n / wave_cyc, 3) if wave_cyc else 0))
+                 round(c.get("SQ_WAIT_INST_LDS", 0.0) / n / wave_cyc, 3) if wave_cyc else 0,
+                 round(c.get("SQ_WAIT_ANY", 0.0) / n / wave_cyc, 3) if wave_cyc else 0,
+                 round(c.get("SQ_ACTIVE_INST_VALU", 0.0) / n / wave_cyc, 3) if wave_cyc else 0,
+                 round(c.get("SQ_ACTIVE_INST_ANY", 0.0) / n / wave_cyc, 3) if wave_cyc else 0))
 rows.sort(key=lambda r: -r[2] * r[1])
 with open(sys.argv[2], "w") as fh:
     fh.write("kernel,dispatches,kernel_cycles,mfma_busy_cycles_per_simd,mfma_busy_frac,waves_per_simd,wave_residency_frac,"
-             "wait_any_frac_of_wave_cycles,wait_lds_frac_of_wave_cycles\n")
+             "wait_inst_any_frac_of_wave_cycles,wait_lds_frac_of_wave_cycles,wait_any_parked_frac,active_valu_frac,active_any_frac\n")
     for r in rows:
         fh.write('"%s",%s\n' % (r[0], ",".join(str(x) for x in r[1:])))
 for r in rows:

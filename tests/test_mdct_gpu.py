@@ -279,3 +279,32 @@ def test_fast_codec_math(mods):
     dec = np.sinh(((sg.double().cpu().numpy() + 1.0) / 2.0 * 10.0 - 5.0) * np.log(10.0)) / 1000.0
     y2, _ = imdct4_codec(torch.from_numpy(dec).float().to(DEV), win, d4, 512)
     assert (y - y2).abs().max().item() <= 3e-6 * y2.abs().max().item()
+
+
+def test_table_stationary_k1_writes_nothing_outside_its_outputs(mods):
+    """The last row tile of a ragged batch (3 clips x 129 frames = 387 rows, 13 tiles of 32) is masked by the buffer
+    descriptor's range check (voffset + scalar row offset against num_records), not by branches: outputs embedded in
+    guard-filled arenas must come back with the guards intact and the same values as the stand-alone call."""
+    from mdctgan_amd import _lib
+    from mdctgan_amd.mdct import dct4_table, mdct4_codec
+    _, _, w = mods
+    lib = _lib.load()
+    B, T = 3, 32512 + 76
+    F = lib.mg_mdct4_num_frames(T, 512)
+    assert F == 129
+    x = (0.05 * torch.randn(B, T, generator=torch.Generator().manual_seed(1))).to(DEV)
+    win, d4 = torch.from_numpy(w).to(DEV), dct4_table(256, DEV)
+    n = B * F * 256
+    G = 1 << 16
+    arena_s = torch.full((G + n + G,), 7.5, device=DEV)
+    arena_p = torch.full((G + 2 * n + G,), 7.5, device=DEV)
+    spec, pair = arena_s[G:G + n], arena_p[G:G + 2 * n]
+    rc = lib.mg_mdct4_forward(_lib.ptr(x), B, T, 512, _lib.ptr(win), _lib.ptr(d4), _lib.MG_CODEC_ARCSINH, 1000.0, -1.0, 1.0, -5.0, 5.0, 0,
+                              spec.data_ptr(), pair.data_ptr(), None, None, None, None, None, _lib.stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    for arena, m in ((arena_s, n), (arena_p, 2 * n)):
+        assert bool((arena[:G] == 7.5).all()) and bool((arena[G + m:] == 7.5).all())
+    r = mdct4_codec(x, win, d4, 512, codec=_lib.MG_CODEC_ARCSINH, gain=1000.0, norm_range=(-1.0, 1.0), src_range=(-5.0, 5.0), want_pair=True)
+    assert torch.equal(r["spec"].reshape(-1), spec) and torch.equal(r["pair"].reshape(-1), pair)
+    assert bool((spec != 7.5).all())
