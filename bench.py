@@ -142,6 +142,49 @@ def cpu_baseline_train(max_threads):
                       "%d cores)" % (med, ts[0], ts[-1], threads, max_threads)}
 
 
+def cpu_baseline_train_cfg2(max_threads):
+    """configs[2]'s networks (netG=local: 2048-channel trunk + 2 bottleneck-attention blocks, num_D 3) on the CPU oracle:
+    G+D steps at batch 1 in float32 (the reference's --fp16 branch is CUDA autocast; on the host the same networks run in
+    float32), 1 warm-up + 3 timed, median, scaled x1/8 to the batch-8 step rate."""
+    from oracle import nets as onets
+    from oracle import step as ostep
+    gen = torch.Generator().manual_seed(0)
+    netG = onets.init_weights(onets.build_generator("local", 2, 1, 64, 4, 9, 3, input_size=(128, 256), n_attn_g=2, heads_g=8,
+                                                    dim_head_g=64), gen)
+    netD = onets.init_weights(onets.MultiscaleDRef(3, 64, 3, 3), gen)
+    ref = ostep.HotPathRef(netG, netD, ostep.CodecCfg(), num_D=3)
+    lr, hr = synth_batch(1, 1, "cpu")
+    threads = min(CPU_THREADS, max_threads)
+    torch.set_num_threads(threads)
+    lrn, hrn = lr.numpy(), hr.numpy()
+    med, ts = _median_time(lambda: ref.train_step(lrn, hrn), warmups=1, iters=3)
+    return {"value": round((1.0 / med) * (1.0 / BATCH), 5), "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": "G+D steps of configs[2] (float32 on the host) at batch 1: 1 warm-up + 3 timed, median %.2f s (min %.2f, "
+                      "max %.2f), scaled x1/8 to batch 8; %d threads (fixed; host has %d cores)" % (med, ts[0], ts[-1], threads, max_threads)}
+
+
+def also_lines(args):
+    """The other BASELINE configurations as their own bench lines, each from a child process of this script (own model, own
+    hipGraph, own roofline probe and cpu_baseline), embedded in the headline's JSON so that the driver's one command shows
+    them: configs[2] with --fp16 (the reference's configuration for configs[2] / [3]) and configs[4] (inference)."""
+    import subprocess
+    out = []
+    for extra in (["--config", "2", "--fp16"], ["--config", "4"]):
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--no-also"] + extra
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
+            d = json.loads(line)
+            d["wall_s"] = round(time.perf_counter() - t0, 1)
+            d["cmd"] = "python bench.py " + " ".join(cmd[2:])
+        except Exception as e:      # the headline line must survive a failing side line
+            d = {"cmd": "python bench.py " + " ".join(cmd[2:]), "error": repr(e)[:300]}
+        out.append(d)
+    return out
+
+
 def cpu_baseline_infer(max_threads, lr_rate):
     """configs[4]'s path on the CPU oracle: HotPathRef.inference (to_spectro, generator forward, to_audio) on 2 segments
     of 32512 samples, 3 warm-ups + 5 timed, median; audio-s/s = 2 * 32512 / 48000 / median."""
@@ -225,6 +268,7 @@ def main():
                          "codec: K1+K2 only (to_spectro + to_audio) on --codec-batch clips, reported against the HBM roofline")
     ap.add_argument("--codec-batch", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="headline line only (no configs[2] --fp16 / configs[4] side lines)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--config", type=int, default=1, choices=[1, 2, 4],
@@ -434,8 +478,15 @@ def main():
             out["roofline_codec"] = codec_line
         if world == 1 and not args.no_cpu_baseline and args.mode == "train" and args.config == 1:
             out["cpu_baseline"] = cpu_baseline_train(os.cpu_count() or 1)
+        if world == 1 and not args.no_cpu_baseline and args.mode == "train" and args.config == 2:
+            out["cpu_baseline"] = cpu_baseline_train_cfg2(os.cpu_count() or 1)
         if world == 1 and not args.no_cpu_baseline and args.mode == "infer":
             out["cpu_baseline"] = cpu_baseline_infer(os.cpu_count() or 1, lr_rate)
+    if (rank == 0 and world == 1 and not use_ddp and args.mode == "train" and args.config == 1 and not args.fp16
+            and not args.no_also):
+        del model
+        torch.cuda.empty_cache()
+        out["also"] = also_lines(args)
     # the JSON line must be the LAST thing on stdout: RCCL prints a version banner through C stdio, which a pipe only sees
     # when the library's buffer is flushed (normally at exit, i.e. after a line printed here)
     if use_ddp:

@@ -28,11 +28,17 @@ T_SEG = 32512
 # the HIP step sits at 2-5e-6 on the discriminators where the float32 CPU run sits at 2-3e-6 -- and BOTH jump to 3e-4 ... 2e-3
 # on whole groups of layers from one run to the next (the CPU run is multi-threaded): a LeakyReLU / ReLU input within rounding
 # of zero flips its mask, and behind InstanceNorm over 9 x 17 ... 65 x 129 maps that moves a layer's gradient by O(1e-3).  The
-# generator's gradients (60 layers deep) carry 3e-3 (configs[1]) / 1e-2 (configs[2], BatchNorm over 32 tokens at batch 1) in
-# the float32 CPU run itself.  The 25-position Winograd families of the discriminators add 1.5-4e-4 where no mask flips
-# (direct kernels: 3e-6) -- below that noise, and stated here.  FLOOR_F32 is therefore the mask-flip scale, not 1e-4; the
-# tight bars are the losses (1e-4) and the layers no mask sits behind (the PatchGAN output layers: 1e-5).
-FLOOR_F32 = 5e-3
+# generator's gradients (60 layers deep) carry 2-3.5e-3 (configs[1]) / 0.5-1.2e-2 (configs[2]: BatchNorm over 32 tokens at
+# batch 1) in the float32 CPU run itself, the HIP run 3-6e-3 / 0.8-1.2e-2; single cancellation-prone entries (the 64 -> 1
+# head's bias gradient = a signed sum over 32768 pixels) swing between 6e-5 and 4e-3 on the CPU from run to run.  Op for op
+# the 25-position Winograd families of the discriminators are at 2e-6 where the direct kernels are at 4e-7
+# (scripts/diag_wino4_accuracy.py) -- far below that noise.  FLOOR is therefore twice the float32 CPU run's own worst
+# observed error, not 1e-4; the tight bars are the losses (1e-4) and the layers no mask sits behind (the PatchGAN output
+# layers: 1e-5).  Under --fp16 the yardstick is the oracle's CPU-autocast run (the reference's arithmetic): the L1
+# feature-matching loss differentiates to sign(fake - real) of float16-rounded features, so ANY two float16 evaluations
+# -- the reference's included -- are 0.35-0.47 apart from float64 in the generator's gradients (measured: HIP 0.40, CPU
+# autocast 0.47); the --fp16 leg asserts the losses (2e-2), finiteness, and "no worse than 4 x the reference's arithmetic".
+FLOOR_F32 = {"configs1": 8e-3, "configs2": 2.5e-2}
 FLOOR_FP16 = 3e-2
 
 CONFIGS = {
@@ -147,7 +153,7 @@ def test_full_size_step_gradients(tag, fp16):
         e32 = abs(l32[k] - l64[k])
         if not abs(v.item() - l64[k]) <= rtol * abs(l64[k]) + 4 * e32:
             bad.append(("loss " + k, v.item(), l64[k], l32[k]))
-    floor = FLOOR_FP16 if fp16 else FLOOR_F32
+    floor = FLOOR_FP16 if fp16 else FLOOR_F32[tag]
     checked, worst, report = 0, (0.0, None), {}
     for net, g64, g32, pre in ((model.netG, gG64, gG32, "G."), (model.netD, gD64, gD32, "D.")):
         for k, p in net.named_parameters():
