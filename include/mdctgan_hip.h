@@ -251,12 +251,25 @@ size_t mg_instnorm_workspace(int B, int HW, int C);
  *      training: batch statistics (biased var for normalisation, unbiased into running_var, momentum m);
  *      eval: running statistics.  y = act(gamma * xhat + beta + residual)  (act in {NONE, RELU}; residual nullable).
  */
+/*  Round 3: statistics and application are separate launches with per-slice double-precision partial sums
+ *  [mg_batchnorm_slices()][2][C] between them (mg_batchnorm_workspace(C) bytes): sums -> (a data-parallel run may
+ *  all-reduce the partials here: SyncBN, then count = rows of the whole batch) -> apply.
+ *      mg_batchnorm_sums      partials of (sum x, sum x^2)
+ *      mg_batchnorm_fwd       training: statistics from `sums` / `count`;  eval: running statistics (sums may be NULL)
+ *      mg_batchnorm_bwd_sums  partials of (sum g, sum g * xhat), g = dy masked by the ReLU of y
+ *      mg_batchnorm_bwd       dgamma / dbeta from local_sums (this rank's samples), dx from batch_sums / count */
+size_t mg_batchnorm_workspace(int C);
+int mg_batchnorm_slices(void);
+int mg_batchnorm_sums(const float* x, int R, int C, void* sums, void* stream);
 int mg_batchnorm_fwd(const float* x, int R, int C, float eps, float momentum, int training, const float* gamma,
                      const float* beta, float* running_mean, float* running_var, const float* residual, int act,
-                     float* y, float* save_mean, float* save_rstd, void* stream);
+                     float* y, float* save_mean, float* save_rstd, const void* sums, double count, void* stream);
+int mg_batchnorm_bwd_sums(const float* dy, const float* x, const float* y, int R, int C, const float* mean,
+                          const float* rstd, int act, void* sums, void* stream);
 int mg_batchnorm_bwd(const float* dy, const float* x, const float* y, int R, int C, const float* gamma,
                      const float* mean, const float* rstd, int act, int training, float* dx, float* dresidual,
-                     float* dgamma, float* dbeta, int accumulate, void* stream);
+                     float* dgamma, float* dbeta, int accumulate, const void* local_sums, const void* batch_sums,
+                     double count, void* stream);
 /*  Multi-head self attention with absolute position embeddings (rel_pos_emb=False):
  *      qkv [B, fh*fw, 3*heads*d] (channel = which*heads*d + head*d + dd), emb_h [fh, d], emb_w [fw, d];
  *      sim = (q * d^-0.5) (k + emb_h[y] + emb_w[x])^T, out [B, fh*fw, heads*d] = softmax(sim) v.

@@ -84,8 +84,12 @@ SIGNATURES = {
     "mg_instnorm_fwd": (_i, [_p, _i, _i, _i, _f, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "mg_instnorm_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _sz, _p]),
     "mg_instnorm_workspace": (_sz, [_i, _i, _i]),
-    "mg_batchnorm_fwd": (_i, [_p, _i, _i, _f, _f, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
-    "mg_batchnorm_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _p, _i, _p]),
+    "mg_batchnorm_workspace": (_sz, [_i]),
+    "mg_batchnorm_slices": (_i, []),
+    "mg_batchnorm_sums": (_i, [_p, _i, _i, _p, _p]),
+    "mg_batchnorm_fwd": (_i, [_p, _i, _i, _f, _f, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, C.c_double, _p]),
+    "mg_batchnorm_bwd_sums": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _p, _p]),
+    "mg_batchnorm_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _p, _i, _p, _p, C.c_double, _p]),
     "mg_attention_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "mg_attention_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _sz, _p]),
     "mg_attention_bwd_workspace": (_sz, [_i, _i, _i, _i, _i]),

@@ -20,53 +20,92 @@ __device__ __forceinline__ float act_fwd(float v, int act) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// BatchNorm2d over rows = B*H*W of an NHWC tensor [R, C].  One block per 64 channels, 4 row groups.
+// BatchNorm2d over rows = B*H*W of an NHWC tensor [R, C], as sums -> apply (round 3).  The one-launch kernels of rounds
+// 1-2 ran 8 workgroups for the 512-channel layers of configs[2] (40 / 69 us forward / backward, latency-bound); now the rows
+// are cut into BN_RS slices: a sums kernel writes per-slice double-precision partials [BN_RS][2][C] (fixed-order, no atomics)
+// and the apply kernel adds them in slice order.  Between the two launches a data-parallel run may all-reduce the partials
+// (SyncBN, SURVEY 8e opt-in): the apply kernels take the statistics' row count separately from the local R.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ x, int R, int C, float eps,
-                                                     float momentum, int training, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float* __restrict__ run_mean,
-                                                     float* __restrict__ run_var, const float* __restrict__ residual,
-                                                     int act, float* __restrict__ y, float* __restrict__ save_mean,
-                                                     float* __restrict__ save_rstd) {
+constexpr int BN_RS = 8;
+
+// which == 0: (sum x, sum x^2);  which == 1: (sum g, sum g * xhat) with g = dy masked by the ReLU of y
+template <int BWD>
+__global__ __launch_bounds__(256) void bn_sums_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                      const float* __restrict__ y, int R, int C,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd, int act,
+                                                      double* __restrict__ part) {
     __shared__ double red[2][4][64];
-    __shared__ float stat[2][64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
-    if (training) {
-        double s1 = 0.0, s2 = 0.0;
-        if (c < C)
-            for (int r = rg; r < R; r += 4) {
-                const float v = x[(size_t)r * C + c];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl, sl = blockIdx.y;
+    const int r0 = (int)((long long)R * sl / BN_RS), r1 = (int)((long long)R * (sl + 1) / BN_RS);
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        const float mu = BWD ? mean[c] : 0.f, rs = BWD ? rstd[c] : 0.f;
+        for (int r = r0 + rg; r < r1; r += 4) {
+            const size_t i = (size_t)r * C + c;
+            if (BWD) {
+                float g = dy[i];
+                if (act == MG_ACT_RELU && !(y[i] > 0.0f)) g = 0.0f;
+                s1 += (double)g;
+                s2 += (double)g * (double)((x[i] - mu) * rs);
+            } else {
+                const float v = x[i];
                 s1 += (double)v;
                 s2 += (double)v * (double)v;
             }
-        red[0][rg][cl] = s1;
-        red[1][rg][cl] = s2;
-        __syncthreads();
-        if (rg == 0 && c < C) {
-            const double a = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-            const double b = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
-            const double mu = a / R;
-            double var = b / R - mu * mu;
+        }
+    }
+    red[0][rg][cl] = s1;
+    red[1][rg][cl] = s2;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        part[((size_t)sl * 2 + 0) * C + c] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        part[((size_t)sl * 2 + 1) * C + c] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    }
+}
+__device__ __forceinline__ void bn_total(const double* __restrict__ part, int C, int c, double& a, double& b) {
+    a = 0.0; b = 0.0;
+#pragma unroll
+    for (int s = 0; s < BN_RS; ++s) { a += part[((size_t)s * 2 + 0) * C + c]; b += part[((size_t)s * 2 + 1) * C + c]; }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ x, int R, int C, float eps,
+                                                           float momentum, int training, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ run_mean,
+                                                           float* __restrict__ run_var, const float* __restrict__ residual,
+                                                           int act, float* __restrict__ y, float* __restrict__ save_mean,
+                                                           float* __restrict__ save_rstd, const double* __restrict__ part,
+                                                           double count) {
+    __shared__ float stat[2][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl, sl = blockIdx.y;
+    if (rg == 0 && c < C) {
+        if (training) {
+            double a, b;
+            bn_total(part, C, c, a, b);
+            const double mu = a / count;
+            double var = b / count - mu * mu;
             if (var < 0.0) var = 0.0;
             stat[0][cl] = (float)mu;
             stat[1][cl] = (float)(1.0 / sqrt(var + (double)eps));
-            save_mean[c] = stat[0][cl];
-            save_rstd[c] = stat[1][cl];
-            if (run_mean) {   // nn.BatchNorm2d: running = (1-m) running + m batch (unbiased variance)
-                const double unb = (R > 1) ? var * R / (R - 1) : var;
-                run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)mu;
-                run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)unb;
+            if (sl == 0) {
+                save_mean[c] = stat[0][cl];
+                save_rstd[c] = stat[1][cl];
+                if (run_mean) {   // nn.BatchNorm2d: running = (1-m) running + m batch (unbiased variance)
+                    const double unb = (count > 1.0) ? var * count / (count - 1.0) : var;
+                    run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)mu;
+                    run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)unb;
+                }
             }
+        } else {
+            stat[0][cl] = run_mean[c];
+            stat[1][cl] = 1.0f / sqrtf(run_var[c] + eps);
+            if (sl == 0 && save_mean) { save_mean[c] = stat[0][cl]; save_rstd[c] = stat[1][cl]; }
         }
-    } else if (rg == 0 && c < C) {
-        stat[0][cl] = run_mean[c];
-        stat[1][cl] = 1.0f / sqrtf(run_var[c] + eps);
-        if (save_mean) { save_mean[c] = stat[0][cl]; save_rstd[c] = stat[1][cl]; }
     }
     __syncthreads();
     if (c >= C) return;
+    const int r0 = (int)((long long)R * sl / BN_RS), r1 = (int)((long long)R * (sl + 1) / BN_RS);
     const float mu = stat[0][cl], rs = stat[1][cl], ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
-    for (int r = rg; r < R; r += 4) {
+    for (int r = r0 + rg; r < r1; r += 4) {
         const size_t i = (size_t)r * C + c;
         float z = ga * ((x[i] - mu) * rs) + be;
         if (residual) z += residual[i];
@@ -74,42 +113,36 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ x
     }
 }
 
-// dy -> dx, dgamma, dbeta (+ dresidual = masked dy).  y is the forward output (ReLU mask).
-__global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                     const float* __restrict__ y, int R, int C,
-                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, int act, int training,
-                                                     float* __restrict__ dx, float* __restrict__ dres,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     int accumulate) {
-    __shared__ double red[2][4][64];
+// dy -> dx, dgamma, dbeta (+ dresidual = masked dy).  y is the forward output (ReLU mask).  lpart: this rank's sums (the
+// parameter gradients, reduced later with every other gradient); gpart: the sums over the statistics' batch (== lpart
+// unless SyncBN all-reduced them), count = its row count.
+__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ y, int R, int C,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, int act, int training,
+                                                           float* __restrict__ dx, float* __restrict__ dres,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           int accumulate, const double* __restrict__ lpart,
+                                                           const double* __restrict__ gpart, double count) {
     __shared__ float stat[2][64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
-    const float mu = (c < C) ? mean[c] : 0.f, rs = (c < C) ? rstd[c] : 0.f, ga = (c < C && gamma) ? gamma[c] : 1.0f;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int r = rg; r < R; r += 4) {
-            const size_t i = (size_t)r * C + c;
-            float g = dy[i];
-            if (act == MG_ACT_RELU && !(y[i] > 0.0f)) g = 0.0f;
-            s1 += (double)g;
-            s2 += (double)g * (double)((x[i] - mu) * rs);
-        }
-    red[0][rg][cl] = s1;
-    red[1][rg][cl] = s2;
-    __syncthreads();
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl, sl = blockIdx.y;
     if (rg == 0 && c < C) {
-        const double a = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-        const double b = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
-        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
-        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
-        stat[0][cl] = (float)(a / R);
-        stat[1][cl] = (float)(b / R);
+        double a, b;
+        bn_total(gpart, C, c, a, b);
+        stat[0][cl] = (float)(a / count);
+        stat[1][cl] = (float)(b / count);
+        if (sl == 0 && (dbeta || dgamma)) {
+            bn_total(lpart, C, c, a, b);
+            if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
+            if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
+        }
     }
     __syncthreads();
     if (c >= C) return;
+    const int r0 = (int)((long long)R * sl / BN_RS), r1 = (int)((long long)R * (sl + 1) / BN_RS);
+    const float mu = mean[c], rs = rstd[c], ga = gamma ? gamma[c] : 1.0f;
     const float m1 = stat[0][cl], m2 = stat[1][cl];
-    for (int r = rg; r < R; r += 4) {
+    for (int r = r0 + rg; r < r1; r += 4) {
         const size_t i = (size_t)r * C + c;
         float g = dy[i];
         if (act == MG_ACT_RELU && !(y[i] > 0.0f)) g = 0.0f;
@@ -272,22 +305,31 @@ __global__ __launch_bounds__(256) void attn_bwd_b_kernel(const float* __restrict
 }
 
 // d height[y][dd] = sum_{b,h,x} dE[b,h][(y,x)][dd];  d width[x][dd] = sum_{b,h,y} dE[...]
-__global__ void posemb_grad_kernel(const float* __restrict__ dE, int BH, int fh, int fw, int d,
-                                   float* __restrict__ dheight, float* __restrict__ dwidth, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = fh * fw;
-    if (i < fh * d) {
-        const int y = i / d, dd = i % d;
-        float a = 0.0f;
-        for (int bh = 0; bh < BH; ++bh)
-            for (int x = 0; x < fw; ++x) a += dE[((size_t)bh * n + y * fw + x) * d + dd];
-        dheight[i] = accumulate ? dheight[i] + a : a;
-    } else if (i < (fh + fw) * d) {
-        const int k = i - fh * d, x = k / d, dd = k % d;
-        float a = 0.0f;
-        for (int bh = 0; bh < BH; ++bh)
-            for (int y = 0; y < fh; ++y) a += dE[((size_t)bh * n + y * fw + x) * d + dd];
-        dwidth[k] = accumulate ? dwidth[k] + a : a;
+// one workgroup per row of the two tables (fh + fw of them), 1024 threads = (1024 / d) groups x d lanes: a group walks every
+// (1024 / d)-th (b, head) pair in ascending order, the groups meet in LDS in fixed order (deterministic).  (Rounds 1-2: one
+// thread per table element, 512 strided loads each -- 127 us for 24 KB of result.)
+__global__ __launch_bounds__(1024) void posemb_grad_kernel(const float* __restrict__ dE, int BH, int fh, int fw, int d,
+                                                           float* __restrict__ dheight, float* __restrict__ dwidth,
+                                                           int accumulate) {
+    __shared__ float red[1024];
+    const int n = fh * fw, groups = 1024 / d, dd = threadIdx.x % d, g = threadIdx.x / d;
+    const bool is_h = (int)blockIdx.x < fh;
+    const int idx = is_h ? blockIdx.x : blockIdx.x - fh;
+    float a = 0.0f;
+    if (g < groups) {
+        for (int bh = g; bh < BH; bh += groups) {
+            const float* base = dE + (size_t)bh * n * d + dd;
+            if (is_h) for (int x = 0; x < fw; ++x) a += base[(size_t)(idx * fw + x) * d];
+            else for (int y = 0; y < fh; ++y) a += base[(size_t)(y * fw + idx) * d];
+        }
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (g == 0) {
+        float t = 0.0f;
+        for (int q = 0; q < groups; ++q) t += red[q * d + dd];
+        float* out = is_h ? dheight + idx * d + dd : dwidth + idx * d + dd;
+        *out = accumulate ? *out + t : t;
     }
 }
 
@@ -295,24 +337,48 @@ __global__ void posemb_grad_kernel(const float* __restrict__ dE, int BH, int fh,
 
 extern "C" {
 
+size_t mg_batchnorm_workspace(int C) { return C > 0 ? (size_t)BN_RS * 2 * C * sizeof(double) : 0; }
+int mg_batchnorm_slices(void) { return BN_RS; }
+
+int mg_batchnorm_sums(const float* x, int R, int C, void* sums, void* stream) {
+    if (!x || !sums || R <= 0 || C <= 0) return MG_ERR_ARG;
+    hipLaunchKernelGGL(bn_sums_kernel<0>, dim3((C + 63) / 64, BN_RS), dim3(256), 0, (hipStream_t)stream, x, (const float*)nullptr,
+                       (const float*)nullptr, R, C, (const float*)nullptr, (const float*)nullptr, 0, (double*)sums);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
 int mg_batchnorm_fwd(const float* x, int R, int C, float eps, float momentum, int training, const float* gamma,
                      const float* beta, float* running_mean, float* running_var, const float* residual, int act,
-                     float* y, float* save_mean, float* save_rstd, void* stream) {
+                     float* y, float* save_mean, float* save_rstd, const void* sums, double count, void* stream) {
     if (!x || !y || R <= 0 || C <= 0) return MG_ERR_ARG;
-    if (training && (!save_mean || !save_rstd)) return MG_ERR_ARG;
+    if (training && (!save_mean || !save_rstd || !sums || !(count >= 1.0))) return MG_ERR_ARG;
     if (!training && (!running_mean || !running_var)) return MG_ERR_ARG;
-    hipLaunchKernelGGL(bn_fwd_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, R, C, eps, momentum,
-                       training, gamma, beta, running_mean, running_var, residual, act, y, save_mean, save_rstd);
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((C + 63) / 64, BN_RS), dim3(256), 0, (hipStream_t)stream, x, R, C, eps,
+                       momentum, training, gamma, beta, running_mean, running_var, residual, act, y, save_mean, save_rstd,
+                       (const double*)sums, count);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+int mg_batchnorm_bwd_sums(const float* dy, const float* x, const float* y, int R, int C, const float* mean,
+                          const float* rstd, int act, void* sums, void* stream) {
+    if (!dy || !x || !y || !mean || !rstd || !sums || R <= 0 || C <= 0) return MG_ERR_ARG;
+    hipLaunchKernelGGL(bn_sums_kernel<1>, dim3((C + 63) / 64, BN_RS), dim3(256), 0, (hipStream_t)stream, x, dy, y, R, C, mean,
+                       rstd, act, (double*)sums);
     MG_CHECK_LAUNCH();
     return MG_OK;
 }
 
 int mg_batchnorm_bwd(const float* dy, const float* x, const float* y, int R, int C, const float* gamma,
                      const float* mean, const float* rstd, int act, int training, float* dx, float* dresidual,
-                     float* dgamma, float* dbeta, int accumulate, void* stream) {
-    if (!dy || !x || !y || !mean || !rstd || !dx || R <= 0 || C <= 0) return MG_ERR_ARG;
-    hipLaunchKernelGGL(bn_bwd_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, dy, x, y, R, C, gamma,
-                       mean, rstd, act, training, dx, dresidual, dgamma, dbeta, accumulate);
+                     float* dgamma, float* dbeta, int accumulate, const void* local_sums, const void* batch_sums,
+                     double count, void* stream) {
+    if (!dy || !x || !y || !mean || !rstd || !dx || !local_sums || !batch_sums || !(count >= 1.0) || R <= 0 || C <= 0)
+        return MG_ERR_ARG;
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3((C + 63) / 64, BN_RS), dim3(256), 0, (hipStream_t)stream, dy, x, y, R, C,
+                       gamma, mean, rstd, act, training, dx, dresidual, dgamma, dbeta, accumulate, (const double*)local_sums,
+                       (const double*)batch_sums, count);
     MG_CHECK_LAUNCH();
     return MG_OK;
 }
@@ -364,8 +430,8 @@ int mg_attention_bwd(const float* qkv, const float* emb_h, const float* emb_w, c
     hipLaunchKernelGGL(attn_bwd_b_kernel, dim3(B * heads), dim3(256), lds, st, qkv, emb_h, emb_w, (const float*)dS, n, fw,
                        heads, d, 1.0f / sqrtf((float)d), dqkv, dE);
     if (demb_h && demb_w)
-        hipLaunchKernelGGL(posemb_grad_kernel, dim3(((fh + fw) * d + 255) / 256), dim3(256), 0, st, (const float*)dE,
-                           B * heads, fh, fw, d, demb_h, demb_w, accumulate);
+        hipLaunchKernelGGL(posemb_grad_kernel, dim3(fh + fw), dim3(1024), 0, st, (const float*)dE, B * heads, fh, fw, d, demb_h,
+                           demb_w, accumulate);
     MG_CHECK_LAUNCH();
     return MG_OK;
 }

@@ -40,9 +40,13 @@ class ArenaReducer:
         # so each moves (N-1)/N of the bucket over all links at once on a fully connected node and the all-gather of
         # bucket i overlaps the reduce-scatter of bucket i+1 on RCCL's stream.  Needs a backend with
         # reduce_scatter_tensor (RCCL; not gloo), buckets are then padded to a multiple of the world size.
+        # "sharded" (round 3, ZeRO-1 over the arena): reduce-scatter only; each rank owns 1/world of every bucket, runs the
+        # inf / nan check and Adam on its shards alone (FusedAdam.shard), and the updated PARAMETER shards are all-gathered --
+        # the same bytes on the links as one all-reduce, Adam's HBM stream divided by world (configs[3]: 22 GB -> 2.8 GB per
+        # step and rank at world 8), m / v of the other ranks' shards never touched.
         self.mode = mode or os.environ.get("MDCTGAN_DDP_MODE", "allreduce")
-        if self.mode not in ("allreduce", "rs_ag"):
-            raise ValueError("MDCTGAN_DDP_MODE must be allreduce or rs_ag")
+        if self.mode not in ("allreduce", "rs_ag", "sharded"):
+            raise ValueError("MDCTGAN_DDP_MODE must be allreduce, rs_ag or sharded")
         self.writes_per_step = writes_per_step
         self.active = True
         self.force = dist.is_initialized()       # a 1-rank group still goes through RCCL (used to test the code path)
@@ -83,12 +87,15 @@ class ArenaReducer:
         if not (self.world > 1 or self.force) or not dist.is_initialized():     # (a reducer that outlived its group)
             return
         n = hi - lo
-        if self.mode == "rs_ag" and n % self.world == 0:
+        if self.mode in ("rs_ag", "sharded") and n % self.world == 0:
             shard = n // self.world
             rank = dist.get_rank(self.group)
             mine = self.flat_g[lo + rank * shard:lo + (rank + 1) * shard]
-            dist.reduce_scatter_tensor(mine, self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self.works.append(dist.all_gather_into_tensor(self.flat_g[lo:hi], mine, group=self.group, async_op=True))
+            w = dist.reduce_scatter_tensor(mine, self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if self.mode == "sharded":
+                self.works.append(w)
+            else:
+                self.works.append(dist.all_gather_into_tensor(self.flat_g[lo:hi], mine, group=self.group, async_op=True))
         else:
             self.works.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
                                               async_op=True))
@@ -102,6 +109,52 @@ class ArenaReducer:
         self.pending[i] -= 1
         if self.pending[i] == 0:
             self._launch(i)
+
+    # -- sharded optimiser support (mode == "sharded") ---------------------------------------------------------
+    def sharded(self):
+        return self.mode == "sharded" and (self.world > 1 or self.force) and dist.is_initialized()
+
+    def my_spans(self):
+        """Arena ranges [lo, hi) whose reduced gradient this rank holds and whose parameters it updates: its 1/world of every
+        bucket that divides evenly; whole buckets otherwise (those were all-reduced: every rank updates them redundantly)."""
+        rank = dist.get_rank(self.group)
+        out = []
+        for lo, hi, _ in self.buckets:
+            n = hi - lo
+            if n % self.world == 0:
+                out.append((lo + rank * (n // self.world), lo + (rank + 1) * (n // self.world)))
+            else:
+                out.append((lo, hi))
+        return out
+
+    def restrict(self, spans):
+        """Intersect the optimiser's live spans with this rank's shards."""
+        mine, out = self.my_spans(), []
+        for a, b in spans:
+            for lo, hi in mine:
+                x, y = max(a, lo), min(b, hi)
+                if x < y:
+                    out.append((x, y))
+        return out
+
+    def agree(self, flag):
+        """found_inf (0 / 1, one element on the device) of the GradScaler: a rank only sees its own shards, every rank must
+        take the same skip / step decision (train.py:183-199 semantics on the global batch) -> MAX over the ranks."""
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+
+    def gather(self, flat_p):
+        """After the sharded update: every rank receives the other ranks' updated parameter shards.  Returns the pending
+        collectives: the generator's all-gather is left running under the discriminator's backward pass and Adam step and
+        waited for before the next forward (FusedAdam.finish_pending)."""
+        rank = dist.get_rank(self.group)
+        works = []
+        for lo, hi, _ in self.buckets:
+            n = hi - lo
+            if n % self.world == 0:
+                shard = n // self.world
+                works.append(dist.all_gather_into_tensor(flat_p[lo:hi], flat_p[lo + rank * shard:lo + (rank + 1) * shard],
+                                                         group=self.group, async_op=True))
+        return works
 
     def finish(self):
         """Called before the optimiser step: flush buckets that never filled (frozen / unused parameters) and make
@@ -131,6 +184,7 @@ def attach_optimizer(opt, writes_per_step=1, bucket_bytes=128 << 20, group=None)
     red.bucket_bytes = bucket_bytes
     opt.grad_scale = 1.0 / world
     opt.pre_step_hook = red.finish
+    opt.shard = red if red.sharded() else None
     return red
 
 
@@ -160,6 +214,22 @@ def sync_buffers(model, group=None):
                 b.div_(world)
 
 
+def enable_sync_batchnorm(group=None):
+    """SURVEY 8e opt-in: the BatchNorm2d layers of the bottleneck-attention blocks (configs[2] / [3]) normalise with the
+    statistics of the WHOLE data-parallel batch -- N ranks x batch 8 then computes what one rank x batch 8N would -- at the
+    price of two small all-reduces (slices x 2 x C doubles) per layer and pass.  Default off: per-rank statistics, what
+    torch's DistributedDataParallel does with a plain nn.BatchNorm2d.  MDCTGAN_SYNC_BN=1 makes attach() call this."""
+    from . import ops
+    if not dist.is_initialized():
+        raise RuntimeError("enable_sync_batchnorm needs an initialised process group")
+    ops.SYNC_BN_GROUP = (group, dist.get_world_size(group))
+
+
+def disable_sync_batchnorm():
+    from . import ops
+    ops.SYNC_BN_GROUP = None
+
+
 def attach(model, bucket_bytes=None, group=None):
     """Wire a Pix2PixHDModel for data parallelism: broadcast both parameter arenas, every parameter outside them and
     every floating-point buffer from rank 0, create the G and D reducers and fold 1/world into the Adam kernels."""
@@ -176,4 +246,6 @@ def attach(model, bucket_bytes=None, group=None):
             dist.broadcast(t, src=0, group=group)
     reducers["D"].active = False
     model.reducers = reducers
+    if os.environ.get("MDCTGAN_SYNC_BN", "0") == "1" and dist.is_initialized():
+        enable_sync_batchnorm(group)
     return reducers

@@ -364,6 +364,23 @@ def weights_are_casts(g: ConvGeom) -> bool:
     return hit
 
 
+# SyncBN (SURVEY 8e opt-in; ddp.enable_sync_batchnorm): when set, the per-slice partial sums of a training-mode BatchNorm
+# are all-reduced over this process group between the sums kernel and the apply kernel -- two collectives of
+# slices x 2 x C doubles per layer and pass -- and the statistics cover world x R rows.
+SYNC_BN_GROUP = None       # (group, world) or None
+
+
+def _bn_sync(part):
+    """part: double [slices, 2, C] partial sums -> (partials of the whole batch, world)."""
+    if SYNC_BN_GROUP is None:
+        return part, 1
+    import torch.distributed as dist
+    group, world = SYNC_BN_GROUP
+    tot = part.clone()
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+    return tot, world
+
+
 def batchnorm_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, training, residual=None, act=ACT_NONE):
     """x [B, H, W, C] NHWC -> (y, save_mean [C], save_rstd [C])."""
     lib = _lib.load()
@@ -372,9 +389,15 @@ def batchnorm_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, trai
     y = torch.empty_like(x)
     mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
     rstd = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    part, world = None, 1
+    if training:
+        part = torch.empty(lib.mg_batchnorm_slices(), 2, Cc, dtype=torch.float64, device=x.device)
+        _lib.check(lib.mg_batchnorm_sums(_lib.ptr(x), R, Cc, _lib.ptr(part), _lib.stream()), "mg_batchnorm_sums")
+        part, world = _bn_sync(part)
     _lib.check(lib.mg_batchnorm_fwd(_lib.ptr(x), R, Cc, eps, momentum, int(training), _lib.ptr(gamma), _lib.ptr(beta),
                                     _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(residual), act, _lib.ptr(y),
-                                    _lib.ptr(mean), _lib.ptr(rstd), _lib.stream()), "mg_batchnorm_fwd")
+                                    _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(part), float(R * world), _lib.stream()),
+               "mg_batchnorm_fwd")
     return y, mean, rstd
 
 
@@ -384,9 +407,14 @@ def batchnorm_bwd(dy, x, y, gamma, mean, rstd, act, training, dgamma, dbeta, acc
     R = x.numel() // Cc
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
+    part = torch.empty(lib.mg_batchnorm_slices(), 2, Cc, dtype=torch.float64, device=x.device)
+    _lib.check(lib.mg_batchnorm_bwd_sums(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), R, Cc, _lib.ptr(mean), _lib.ptr(rstd), act,
+                                         _lib.ptr(part), _lib.stream()), "mg_batchnorm_bwd_sums")
+    tot, world = _bn_sync(part) if training else (part, 1)
     _lib.check(lib.mg_batchnorm_bwd(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), R, Cc, _lib.ptr(gamma), _lib.ptr(mean),
                                     _lib.ptr(rstd), act, int(training), _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dgamma),
-                                    _lib.ptr(dbeta), int(accumulate), _lib.stream()), "mg_batchnorm_bwd")
+                                    _lib.ptr(dbeta), int(accumulate), _lib.ptr(part), _lib.ptr(tot), float(R * world),
+                                    _lib.stream()), "mg_batchnorm_bwd")
     return dx, dres
 
 

@@ -39,6 +39,8 @@ class FusedAdam(torch.optim.Optimizer):
         self._built = False
         self.grad_scale = 1.0          # 1/world_size under data parallelism (gradients arrive summed)
         self.pre_step_hook = None      # reducer.finish() under data parallelism
+        self.shard = None              # ddp.ArenaReducer in "sharded" mode: this rank updates its shards only
+        self._pending = None           # ... and the all-gather of the updated shards still in flight
         self.half_shadow = bool(half_shadow)
         self.flat_h = None
 
@@ -128,6 +130,7 @@ class FusedAdam(torch.optim.Optimizer):
         when the check fired (GradScaler.step semantics), all on the device."""
         if not self._built:
             self._build()
+        self.finish_pending()
         if self.pre_step_hook is not None:
             self.pre_step_hook()
         from .functional import bump_weight_epoch
@@ -152,11 +155,15 @@ class FusedAdam(torch.optim.Optimizer):
             lo = self.offsets[a]
             hi = self.total if b == len(self._params) else self.offsets[b]
             spans.append((lo, hi))
+        if self.shard is not None:
+            spans = self.shard.restrict(spans)         # reduce-scattered gradients: only this rank's shards are complete
         if scaler_state is None:
             ops.adam_tick(self.state, b1, b2)
         else:
             for lo, hi in spans:
                 ops.scaler_check(self.flat_g[lo:hi], scaler_state, scaler_slot)
+            if self.shard is not None:
+                self.shard.agree(scaler_state[2 + scaler_slot:3 + scaler_slot])
             ops.adam_tick_amp(self.state, b1, b2, scaler_state, scaler_slot)
         for lo, hi in spans:
             args = (self.flat_p[lo:hi], self.flat_g[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi])
@@ -166,4 +173,17 @@ class FusedAdam(torch.optim.Optimizer):
                 ops.adam_step_dev(*args, self.state, b1, b2, eps, self.grad_scale)
             else:
                 ops.adam_step_amp(*args, self.state, b1, b2, eps, self.grad_scale, scaler_state, scaler_slot)
+        if self.shard is not None:
+            self._pending = self.shard.gather(self.flat_p)
         return None
+
+    @torch.no_grad()
+    def finish_pending(self):
+        """Sharded data parallelism: wait for the all-gather of the updated parameter shards (launched by step(), left
+        running under whatever followed) and refresh the float16 shadow of the other ranks' shards.  Every reader of the
+        parameters calls this first (Pix2PixHDModel.optimize_parameters / inference / save)."""
+        works, self._pending = self._pending, None
+        if works:
+            for w in works:
+                w.wait()
+            self.resync_shadow()

@@ -339,6 +339,7 @@ class Pix2PixHDModel(BaseModel):
 
     def forward(self, lr_audio, hr_audio):
         """pix2pixHD_model.py:394-414."""
+        self._finish_pending()
         pre = self.preprocess
         lr_spectro, lr_pha, lr_norm_param = pre.forward(lr_audio)
         hr_spectro, hr_pha, hr_norm_param = pre.hr_forward(hr_audio)
@@ -409,6 +410,7 @@ class Pix2PixHDModel(BaseModel):
     def optimize_parameters(self, lr_audio, hr_audio):
         """One train.py:160-202 iteration (float32 branch): forward, G step, D step.  Returns the loss dict
         (device scalars; call .item() only when you need to print)."""
+        self._finish_pending()
         with amp.autocast(self.fp16):
             losses, _ = self._forward(lr_audio, hr_audio, infer=False, share_d_pass=True)
         loss_dict = dict(zip(self.loss_names, losses))
@@ -443,6 +445,13 @@ class Pix2PixHDModel(BaseModel):
         # detached: the caller only prints / logs these; handing out the graph would keep one generator's worth of
         # saved activations alive until the next iteration overwrites the dict
         return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss_dict.items()}
+
+    def _finish_pending(self):
+        """Sharded data parallelism (ddp "sharded" mode): the all-gather of the last update may still be in flight."""
+        for name in ("optimizer_G", "optimizer_D"):
+            opt_ = getattr(self, name, None)
+            if opt_ is not None:
+                opt_.finish_pending()
 
     def make_graphed_step(self, lr_audio, hr_audio, warmup=3):
         """Capture one full optimize_parameters() iteration (~470 launches: forward, both backward passes, both Adam
@@ -487,6 +496,7 @@ class Pix2PixHDModel(BaseModel):
 
     def inference(self, lr_audio):
         """pix2pixHD_model.py:618-638."""
+        self._finish_pending()
         with torch.no_grad():
             lr_spectro, lr_pha, lr_norm_param = self.preprocess.forward(lr_audio)
             sr_spectro = self.netG.forward(self._two_channel(lr_spectro))
@@ -499,6 +509,7 @@ class Pix2PixHDModel(BaseModel):
 
     # -- bookkeeping ----------------------------------------------------------------------------
     def save(self, which_epoch):
+        self._finish_pending()
         self.save_network(self.netG, "G", which_epoch, self.gpu_ids)
         self.save_network(self.netD, "D", which_epoch, self.gpu_ids)
 

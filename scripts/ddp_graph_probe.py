@@ -8,7 +8,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29533")
-os.environ["MDCTGAN_DDP_GRAPH"] = "1"
+os.environ["MDCTGAN_DDP_GRAPH"] = "1"       # (MDCTGAN_DDP_MODE from the environment: allreduce / rs_ag / sharded)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -124,3 +124,119 @@ def test_bucket_layout_single_process():
     red.finish()
     assert sum(red.pending) == len(params) + 2
     red.close()
+
+
+class _HostAdam:
+    """Stand-in for FusedAdam on the CPU (the product optimiser drives the HIP Adam kernel and refuses host tensors): the
+    SAME step() control flow -- pre-step hook, live spans restricted to this rank's shards, inf check on those spans, flag
+    agreement, update, all-gather of the parameter shards -- with torch elementwise Adam arithmetic in place of the kernel,
+    so that mdctgan_amd.ddp's sharded-mode logic (restrict / agree / gather) is what runs."""
+
+    def __init__(self, flat_p, flat_g, lr=1e-2, b1=0.5, b2=0.999, eps=1e-8):
+        self.flat_p, self.flat_g = flat_p, flat_g
+        self.m, self.v = torch.zeros_like(flat_p), torch.zeros_like(flat_p)
+        self.t, self.lr, self.b1, self.b2, self.eps = 0, lr, b1, b2, eps
+        self.grad_scale, self.pre_step_hook, self.shard, self._pending = 1.0, None, None, None
+        self.skipped = 0
+
+    def finish_pending(self):
+        works, self._pending = self._pending, None
+        for w in works or []:
+            w.wait()
+
+    def step(self, check_inf=False):
+        self.finish_pending()
+        if self.pre_step_hook is not None:
+            self.pre_step_hook()
+        spans = [(0, self.flat_p.numel())]
+        if self.shard is not None:
+            spans = self.shard.restrict(spans)
+        flag = torch.zeros(1)
+        if check_inf:
+            for lo, hi in spans:
+                if not bool(torch.isfinite(self.flat_g[lo:hi]).all()):
+                    flag[0] = 1.0
+            if self.shard is not None:
+                self.shard.agree(flag)
+        if flag.item() != 0.0:
+            self.skipped += 1
+        else:
+            self.t += 1
+            for lo, hi in spans:
+                g = self.flat_g[lo:hi] * self.grad_scale
+                self.m[lo:hi].mul_(self.b1).add_(g, alpha=1 - self.b1)
+                self.v[lo:hi].mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+                mh, vh = self.m[lo:hi] / (1 - self.b1 ** self.t), self.v[lo:hi] / (1 - self.b2 ** self.t)
+                self.flat_p[lo:hi].sub_(self.lr * mh / (vh.sqrt() + self.eps))
+        if self.shard is not None:
+            self._pending = self.shard.gather(self.flat_p)
+        return flag.item() != 0.0
+
+
+def _sharded_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from mdctgan_amd import ddp
+    from mdctgan_amd import functional as Fh
+    n = 6 * 1024 + 8                                         # several buckets, the last one ragged (8 elements)
+    params = [torch.nn.Parameter(torch.zeros(k)) for k in (1024, 2048, 1024, 2048, 8)]
+    gen = torch.Generator().manual_seed(7)
+    p0 = torch.randn(n, generator=gen)
+    grads = [torch.randn(world, n, generator=gen) for _ in range(4)]     # per step: each rank's local gradient
+    flat_p, flat_g = p0.clone() + rank, torch.zeros(n)       # deliberately different start per rank: attach broadcasts
+    offs = [0, 1024, 3072, 4096, 6144]
+    slices = [(p, o, p.numel()) for p, o in zip(params, offs)]
+
+    class Opt(_HostAdam):
+        def arena_slices(self):
+            return slices
+
+        def resync_shadow(self):
+            pass
+    os.environ["MDCTGAN_DDP_MODE"] = "sharded"
+    opt = Opt(flat_p, flat_g)
+    red = ddp.attach_optimizer(opt, 1, bucket_bytes=4096 * 4)
+    assert opt.shard is red and red.sharded() and torch.equal(flat_p, p0)          # broadcast from rank 0
+    assert len(red.buckets) >= 3 and opt.grad_scale == 1.0 / world
+    spans = red.my_spans()
+    assert sum(hi - lo for lo, hi in spans) == n // world                            # every bucket divides: 1/world each
+    ref = _HostAdam(p0.clone(), torch.zeros(n))                                      # single process on the averaged gradient
+    for step in range(4):
+        poison = step == 2
+        local = grads[step][rank].clone()
+        if poison and rank == 1:
+            local[5000] = float("inf")                       # an overflow on ONE rank, in a shard that rank 0 owns or not
+        flat_g.copy_(local)
+        for p, o, k in reversed(slices):
+            Fh._notify(p)
+        skipped = opt.step(check_inf=True)
+        opt.finish_pending()
+        assert skipped == poison, (rank, step)               # both ranks take the same decision (agree: MAX of the flags)
+        if not poison:
+            ref.flat_g.copy_(grads[step].sum(0) / world)
+            ref.step()
+        # every rank holds the same, fully updated parameters -- equal to the single-process update on the averaged gradient
+        assert torch.allclose(flat_p, ref.flat_p, rtol=0, atol=2e-6), (rank, step, float((flat_p - ref.flat_p).abs().max()))
+        both = [torch.zeros(n) for _ in range(world)]
+        dist.all_gather(both, flat_p)
+        assert torch.equal(both[0], both[1])
+    assert opt.skipped == 1 and opt.t == 3
+    # moments exist only for the shards this rank owns
+    owned = torch.zeros(n, dtype=torch.bool)
+    for lo, hi in spans:
+        owned[lo:hi] = True
+    assert bool((opt.m[~owned] == 0).all()) and bool((opt.m[owned] != 0).any())
+    red.close()
+    np.save(os.path.join(out_dir, "sh%d.npy" % rank), np.ones(1))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_optimizer_and_inf_agreement(tmp_path):
+    """MDCTGAN_DDP_MODE=sharded (reduce-scatter -> each rank checks and updates its 1/world of every bucket -> all-gather of
+    the parameter shards): 2 gloo ranks end every step with identical parameters equal to one process stepping on the
+    averaged gradient; an inf in ONE rank's gradient makes BOTH ranks skip the step (GradScaler semantics on the global
+    batch), also when the inf lies in a shard the other rank owns."""
+    port = _free_port()
+    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "sh%d.npy" % r)) for r in range(2))

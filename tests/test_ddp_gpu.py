@@ -60,14 +60,21 @@ def _batch(golden):
     return torch.from_numpy(g["lr"]).to(DEV), torch.from_numpy(g["hr"]).to(DEV)
 
 
-@pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
-def test_one_rank_rccl_step_is_bit_identical(golden, one_rank_group, mode, monkeypatch):
+@pytest.mark.parametrize("mode,fp16", [("allreduce", False), ("rs_ag", False), ("sharded", False), ("sharded", True)],
+                         ids=["allreduce", "rs_ag", "sharded", "sharded_fp16"])
+def test_one_rank_rccl_step_is_bit_identical(golden, one_rank_group, mode, fp16, monkeypatch):
     from mdctgan_amd import ddp
     monkeypatch.setenv("MDCTGAN_DDP_MODE", mode)
     lr, hr = _batch(golden)
-    plain, dp = _model(), _model()
+    extra = ("--fp16",) if fp16 else ()
+    plain, dp = _model(*extra), _model(*extra)
+    if fp16:      # a scale at which this toy net's float16 gradients are finite: real updates, not three skipped steps
+        plain.scaler.state[0] = 256.0
+        dp.scaler.state[0] = 256.0
     red = ddp.attach(dp)
     assert red["G"].force and red["G"].mode == mode and len(red["G"].buckets) >= 1
+    if mode == "sharded":      # reduce-scatter -> check + Adam on this rank's shards -> all-gather (+ found_inf agreement under --fp16)
+        assert dp.optimizer_G.shard is red["G"] and dp.optimizer_D.shard is red["D"]
     for _ in range(3):
         lp = plain.optimize_parameters(lr, hr)
         ld = dp.optimize_parameters(lr, hr)
@@ -77,9 +84,57 @@ def test_one_rank_rccl_step_is_bit_identical(golden, one_rank_group, mode, monke
     for net in ("netG", "netD"):
         for (k, a), (_, b) in zip(getattr(plain, net).state_dict().items(), getattr(dp, net).state_dict().items()):
             assert torch.equal(a, b), (net, k)
+    if fp16:
+        assert plain.scaler.get_scale() == dp.scaler.get_scale() == 256.0 and dp.optimizer_G.state[0].item() == 3
+        for o in (dp.optimizer_G, dp.optimizer_D):
+            o.finish_pending()
+            assert torch.equal(o.flat_h, o.flat_p.to(torch.float16))
     for r in red.values():
         assert r.pending == [b[2] * r.writes_per_step for b in r.buckets]      # every bucket fired and was reset
         r.close()
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "sharded"])
+def test_data_parallel_step_captures_into_a_hipgraph(mode):
+    """scripts/ddp_graph_probe.py as a test (its own process: a failed capture can poison the stream state): the
+    data-parallel step with its RCCL collectives inside captures into a hipGraph and 2 warm-up + 3 replays equal 5 eager
+    data-parallel steps bit for bit.  One rank only -- this pool has no multi-GPU box -- which is why N > 1 still runs eagerly
+    by default (bench.py; MDCTGAN_DDP_GRAPH=1 opts in): a capture that misbehaves with 8 ranks would cost the whole SCALE run."""
+    import subprocess, sys
+    env = dict(os.environ, MDCTGAN_DDP_MODE=mode, MASTER_PORT=str(_free_port()), MDCTGAN_DDP_GRAPH="1")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "scripts", "ddp_graph_probe.py")], env=env, capture_output=True,
+                       text=True, timeout=600)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("DDP_GRAPH_PROBE")]
+    assert line and line[-1] == "DDP_GRAPH_PROBE capture=ok replay_equals_eager=True", (r.stdout[-500:], r.stderr[-500:])
+
+
+def test_sync_batchnorm_one_rank_equals_plain(one_rank_group):
+    """ddp.enable_sync_batchnorm (SURVEY 8e opt-in): with one rank the all-reduced partial sums are the local ones -- the
+    bottleneck-attention stack must give the same outputs, gradients and running statistics bit for bit, through the
+    RCCL path (the two all-reduces per BatchNorm layer and pass are really issued)."""
+    from mdctgan_amd import ddp, networks
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(4, 64, 4, 8, generator=gen).to(DEV)
+    gy = torch.randn(4, 64, 4, 8, generator=gen).to(DEV)
+    outs = []
+    for sync in (False, True):
+        net = onets.fill_deterministic(networks.BottleStack(dim=64, fmap_size=(4, 8), dim_out=64, num_layers=2, proj_factor=4,
+                                                            heads=2, dim_head=16, downsample=False)).to(DEV).train()
+        if sync:
+            ddp.enable_sync_batchnorm()
+        try:
+            xd = x.clone().requires_grad_()
+            y = net(xd)
+            (y * gy).sum().backward()
+        finally:
+            ddp.disable_sync_batchnorm()
+        outs.append((y.detach().clone(), xd.grad.clone(), [p.grad.clone() for p in net.parameters()],
+                     [b.clone() for b in net.buffers()]))
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for u, v in zip(a[2] + a[3], b[2] + b[3]):
+        assert torch.equal(u, v)
 
 
 def test_update_fixed_params_under_fp16_and_ddp(golden, one_rank_group):
@@ -166,3 +221,88 @@ def test_two_rank_rccl_matches_single_process(golden, tmp_path):
     g_dp = torch.load(os.path.join(str(tmp_path), "gG.pt")) / 2.0
     g_1 = single.optimizer_G.flat_g.cpu()
     assert (g_dp - g_1).abs().max().item() <= 1e-4 * g_1.abs().max().item()
+
+
+def _attn_model(batch):
+    from mdctgan_amd import options
+    from mdctgan_amd.pix2pixHD_model import create_model
+    opt = options.make_opt(*options.SPECTRAL_FLAGS, "--lr_sampling_rate", "12000", "--netG", "local", "--ngf", "4",
+                           "--n_downsample_global", "3", "--n_blocks_global", "2", "--n_blocks_local", "1",
+                           "--n_blocks_attn_g", "2", "--heads_g", "2", "--dim_head_g", "8", "--num_D", "2", "--ndf", "8",
+                           "--batchSize", str(batch), "--bins", "64", "--segment_length", "16128", "--gpu_ids", "0")
+    m = create_model(opt)
+    onets.fill_deterministic(m.netG)
+    onets.fill_deterministic(m.netD)
+    return m
+
+
+def _attn_batch():
+    g = torch.Generator().manual_seed(3)
+    return 0.05 * torch.randn(2, 16128, generator=g), 0.05 * torch.randn(2, 16128, generator=g)
+
+
+def _one_gpu_two_rank_worker(rank, world, port, out_dir, mode, sync_bn):
+    """Two processes on ONE GPU, gloo over device tensors (RCCL refuses two ranks on one device; gloo stages through the
+    host): the real HIP step with a real 2-rank exchange on this pool's 1-GPU boxes."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["MDCTGAN_DDP_MODE"] = mode
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mdctgan_amd import ddp
+    lr, hr = _attn_batch()
+    m = _attn_model(1)
+    ddp.attach(m)
+    if sync_bn:
+        ddp.enable_sync_batchnorm()
+    ld = m.optimize_parameters(lr[rank:rank + 1].cuda(), hr[rank:rank + 1].cuda())
+    m._finish_pending()
+    torch.cuda.synchronize()
+    gG = m.optimizer_G.flat_g.clone()
+    if mode == "sharded":          # reduce-scattered: only this rank's shards hold the sums -> assemble them for the comparison
+        own = torch.zeros_like(gG)
+        for lo, hi in m.reducers["G"].my_spans():
+            own[lo:hi] = gG[lo:hi]
+        dist.all_reduce(own)
+        gG = own
+    torch.save({"gG": gG.cpu(), "pG": m.optimizer_G.flat_p.cpu(), "pD": m.optimizer_D.flat_p.cpu(),
+                "losses": {k: v.item() for k, v in ld.items()},
+                "bufs": [b.cpu() for b in m.netG.buffers() if b.dtype.is_floating_point]}, os.path.join(out_dir, "r%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,sync_bn", [("allreduce", True), ("sharded", True), ("allreduce", False)],
+                         ids=["allreduce_syncbn", "sharded_syncbn", "allreduce_per_rank_bn"])
+def test_two_ranks_on_one_gpu_match_single_process(tmp_path, mode, sync_bn):
+    """2 ranks x batch 1 against 1 process x batch 2 on the same weights and clips, netG=local with two bottleneck-attention
+    blocks (the BatchNorm2d layers are the one cross-sample coupling of the path):
+    * with SyncBN the summed per-rank generator gradients / 2 equal the single-process gradient (float32 rounding of another
+      reduction order) and both ranks end the step with the single process's parameters -- for the all-reduce reducer and for
+      the sharded optimiser (reduce-scatter, Adam on 1/2 of each bucket, all-gather);
+    * without it (the default, what DistributedDataParallel does with nn.BatchNorm2d) the discriminator -- all InstanceNorm,
+      per sample -- still matches, the generator does not: that difference is the documented semantics, not noise."""
+    import torch.multiprocessing as mp
+    mp.spawn(_one_gpu_two_rank_worker, args=(2, _free_port(), str(tmp_path), mode, sync_bn), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), "r%d.pt" % r)) for r in range(2))
+    lr, hr = _attn_batch()
+    single = _attn_model(2)
+    ls = single.optimize_parameters(lr.to(DEV), hr.to(DEV))
+    torch.cuda.synchronize()
+    g1 = single.optimizer_G.flat_g.cpu()
+    gdp = r0["gG"] / 2.0
+    rel = ((gdp - g1).norm() / g1.norm()).item()
+    assert torch.equal(r0["pG"], r1["pG"]) and torch.equal(r0["pD"], r1["pD"])         # the ranks stay in lockstep
+    if sync_bn:
+        assert rel <= 2e-4, rel
+        # the mean of the per-rank losses is the single-process loss
+        for k in ls:
+            assert abs(0.5 * (r0["losses"][k] + r1["losses"][k]) - ls[k].item()) <= 2e-4 * abs(ls[k].item()) + 1e-6, k
+        # first Adam step: +-lr wherever the gradient sign is defined
+        d = (r0["pG"] - single.optimizer_G.flat_p.cpu()).abs()
+        assert d.max().item() <= 2 * 2e-4 + 1e-6 and (d > 2e-6).float().mean().item() <= 0.05
+        for a, b in zip(r0["bufs"], [b_.cpu() for b_ in single.netG.buffers() if b_.dtype.is_floating_point]):
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)                            # running statistics of the whole batch
+    else:
+        assert rel > 1e-3, rel
+    dD = (r0["pD"] - single.optimizer_D.flat_p.cpu()).abs()
+    if sync_bn:
+        assert dD.max().item() <= 2 * 2e-4 + 1e-6
