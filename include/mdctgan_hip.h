@@ -296,6 +296,10 @@ int mg_upsample2x_bwd(const float* dy, int B, int H, int W, int C, float* dx, vo
 /* discriminator input assembly (pix2pixHD_model.py:420-424, 439-440):
  *   out [B, HW, 3] = (lr, s, 2|s| + nr0);  backward: ds = g1 + 2*sign(s)*g2 */
 int mg_dinput_fwd(const float* lr, const float* s, long long n, float nr0, float* out, void* stream);
+/* ... and without --abs_spectro --arcsinh_transform (pix2pixHD_model.py:425-427, 440 else branch): the plain
+ *   torch.cat((a, b), dim=1) of NHWC tensors, n pixels of Ca / Cb channels, and its backward (ga / gb nullable) */
+int mg_cat2_fwd(const float* a, int Ca, const float* b, int Cb, long long n, float* out, void* stream);
+int mg_cat2_bwd(const float* g, int Ca, int Cb, long long n, float* ga, float* gb, void* stream);
 int mg_dinput_bwd(const float* dout, const float* s, long long n, float* ds, void* stream);
 /* generator input pair [n, 2] = (s, 2|s| + nr0) from a spectrogram (pix2pixHD_model.py:400-402) */
 int mg_pair_fwd(const float* s, long long n, float nr0, float* out, void* stream);

@@ -100,6 +100,8 @@ SIGNATURES = {
     "mg_upsample2x_fwd": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "mg_upsample2x_bwd": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "mg_dinput_fwd": (_i, [_p, _p, _ll, _f, _p, _p]),
+    "mg_cat2_fwd": (_i, [_p, _i, _p, _i, _ll, _p, _p]),
+    "mg_cat2_bwd": (_i, [_p, _i, _i, _ll, _p, _p, _p]),
     "mg_dinput_bwd": (_i, [_p, _p, _ll, _p, _p]),
     "mg_pair_fwd": (_i, [_p, _ll, _f, _p, _p]),
     "mg_loss_workspace": (_sz, []),

@@ -455,6 +455,28 @@ __global__ void dinput_bwd_kernel(const float* __restrict__ g, const float* __re
         ds[i] = g[3 * i + 1] + 2.0f * sg * g[3 * i + 2];
     }
 }
+// torch.cat((a, b), dim=1) of NHWC tensors: out[p][0..Ca) = a[p], out[p][Ca..Ca+Cb) = b[p]; and its backward (a split)
+__global__ void cat2_fwd_kernel(const float* __restrict__ a, int Ca, const float* __restrict__ b, int Cb, size_t n,
+                                float* __restrict__ out) {
+    const int Cc = Ca + Cb;
+    const size_t total = n * Cc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / Cc;
+        const int c = (int)(i - p * Cc);
+        out[i] = c < Ca ? a[p * Ca + c] : b[p * Cb + (c - Ca)];
+    }
+}
+__global__ void cat2_bwd_kernel(const float* __restrict__ g, int Ca, int Cb, size_t n, float* __restrict__ ga,
+                                float* __restrict__ gb) {
+    const int Cc = Ca + Cb;
+    const size_t total = n * Cc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / Cc;
+        const int c = (int)(i - p * Cc);
+        if (c < Ca) { if (ga) ga[p * Ca + c] = g[i]; }
+        else if (gb) gb[p * Cb + (c - Ca)] = g[i];
+    }
+}
 __global__ void pair_fwd_kernel(const float* __restrict__ s, size_t n, float nr0, float* __restrict__ out) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float v = s[i];
@@ -745,6 +767,20 @@ int mg_dinput_bwd(const float* dout, const float* s, long long n, float* ds, voi
     if (!dout || !s || !ds || n <= 0) return MG_ERR_ARG;
     hipLaunchKernelGGL(dinput_bwd_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, dout, s,
                        (size_t)n, ds);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+int mg_cat2_fwd(const float* a, int Ca, const float* b, int Cb, long long n, float* out, void* stream) {
+    if (!a || !b || !out || n <= 0 || Ca <= 0 || Cb <= 0) return MG_ERR_ARG;
+    hipLaunchKernelGGL(cat2_fwd_kernel, dim3(grid_for((size_t)n * (Ca + Cb))), dim3(256), 0, (hipStream_t)stream, a, Ca, b, Cb,
+                       (size_t)n, out);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+int mg_cat2_bwd(const float* g, int Ca, int Cb, long long n, float* ga, float* gb, void* stream) {
+    if (!g || (!ga && !gb) || n <= 0 || Ca <= 0 || Cb <= 0) return MG_ERR_ARG;
+    hipLaunchKernelGGL(cat2_bwd_kernel, dim3(grid_for((size_t)n * (Ca + Cb))), dim3(256), 0, (hipStream_t)stream, g, Ca, Cb,
+                       (size_t)n, ga, gb);
     MG_CHECK_LAUNCH();
     return MG_OK;
 }

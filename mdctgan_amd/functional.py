@@ -597,6 +597,40 @@ def d_input(lr_spectro, s_spectro, nr0):
     return _DInputFn.apply(lr_spectro, s_spectro, nr0)
 
 
+class _Cat2Fn(torch.autograd.Function):
+    """torch.cat((a, b), dim=1) (the discriminator input without --abs_spectro --arcsinh_transform,
+    pix2pixHD_model.py:425-427, 440) on channels_last tensors."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        from . import _lib
+        a, b = to_cl(a), to_cl(b)
+        B, Ca, H, W = a.shape
+        Cb = b.shape[1]
+        assert b.shape[0] == B and b.shape[2:] == a.shape[2:]
+        out = torch.empty(B, H, W, Ca + Cb, dtype=torch.float32, device=a.device)
+        _lib.check(_lib.load().mg_cat2_fwd(_lib.ptr(nhwc_view(a).contiguous()), Ca, _lib.ptr(nhwc_view(b).contiguous()), Cb,
+                                           B * H * W, _lib.ptr(out), _lib.stream()), "mg_cat2_fwd")
+        ctx.dims = (B, Ca, Cb, H, W)
+        return nchw_view(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        B, Ca, Cb, H, W = ctx.dims
+        g = nhwc_view(to_cl(g)).contiguous()
+        ga = torch.empty(B, H, W, Ca, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[0] else None
+        gb = torch.empty(B, H, W, Cb, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[1] else None
+        if ga is None and gb is None:
+            return None, None
+        _lib.check(_lib.load().mg_cat2_bwd(_lib.ptr(g), Ca, Cb, B * H * W, _lib.ptr(ga), _lib.ptr(gb), _lib.stream()), "mg_cat2_bwd")
+        return (nchw_view(ga) if ga is not None else None), (nchw_view(gb) if gb is not None else None)
+
+
+def cat_channels(a, b):
+    return _Cat2Fn.apply(a, b)
+
+
 def d_input_pair(lr_spectro, a_spectro, b_spectro, nr0):
     """The discriminator inputs of two spectrogram batches stacked along the batch axis, [2B, 3, F, W]: rows [0, B)
     from ``a``, rows [B, 2B) from ``b``.  No gradient path (used for the two passes of the discriminator loss, whose

@@ -124,10 +124,13 @@ class Audio2MDCT(torch.nn.Module):
                 noise = torch.randn(pha.size(), device=pha.device)
                 pha = pha * ((noise - noise.min()) / (noise.max() - noise.min()))
         elif self.return_pha:
-            zero = (0.0 - self.src_range[0]) / (self.src_range[1] - self.src_range[0]) * \
-                (self.norm_range[1] - self.norm_range[0]) + self.norm_range[0] if self.abs_norm else None
-            if zero is None:
-                raise NotImplementedError("pha with per-sample normalisation")
+            # the normalised value of X = 0: a constant under --abs_norm, per sample from the clip's own (min, max) otherwise
+            if self.abs_norm:
+                zero = (0.0 - self.src_range[0]) / (self.src_range[1] - self.src_range[0]) * \
+                    (self.norm_range[1] - self.norm_range[0]) + self.norm_range[0]
+            else:
+                mn_b, mx_b = r["min"].reshape(-1, 1, 1, 1), r["max"].reshape(-1, 1, 1, 1)
+                zero = (0.0 - mn_b) / (mx_b - mn_b) * (self.norm_range[1] - self.norm_range[0]) + self.norm_range[0]
             noise = torch.randn(log_spectro.size(), device=log_spectro.device)
             noise = (noise - noise.min()) / (noise.max() - noise.min())
             pha = torch.sign(log_spectro - zero) * noise
@@ -299,8 +302,8 @@ class Pix2PixHDModel(BaseModel):
             if self.isTrain:
                 self.load_network(self.netD, "D", opt.which_epoch, opt.load_pretrain)
         if self.isTrain:
-            if opt.pool_size > 0:
-                raise NotImplementedError("--pool_size > 0 (image pool) is outside the hot path (default 0)")
+            from .image_pool import ImagePool
+            self.fake_pool = ImagePool(opt.pool_size)          # pix2pixHD_model.py:294-298 (default 0: no history)
             self.old_lr = opt.lr
             self.limit_aux_loss = False
             self.criterionGAN = networks.GANLoss(use_lsgan=True, device=self.device)
@@ -352,14 +355,15 @@ class Pix2PixHDModel(BaseModel):
     def _d_in(self, lr_spectro, x_spectro):
         if self.abs_spectro and self.arcsinh_transform:
             return Fh.d_input(lr_spectro, x_spectro, float(self.norm_range[0]))
-        raise NotImplementedError("discriminator input without --abs_spectro --arcsinh_transform")
+        return Fh.cat_channels(lr_spectro, x_spectro)        # pix2pixHD_model.py:425-427, 440: sr_input = sr_spectro
 
     def _forward(self, lr_audio, hr_audio, infer=False, share_d_pass=False):
         """pix2pixHD_model.py:416-616: the four live losses [G_GAN, G_GAN_Feat, D_real, D_fake].  share_d_pass: the
         caller backpropagates the two losses under Fh.backward_pass (optimize_parameters does); otherwise every loss
         keeps its own discriminator pass and plain loss.backward() calls work as in train.py."""
         sr_spectro, _, hr_spectro, _, hr_norm_param, lr_spectro, _, lr_norm_param = self.forward(lr_audio, hr_audio)
-        stacked = self.stack_d_loss_passes and self.abs_spectro and self.arcsinh_transform
+        pooled = self.isTrain and getattr(self.opt, "pool_size", 0) > 0     # the fake pass of the D loss sees the history
+        stacked = self.stack_d_loss_passes and self.abs_spectro and self.arcsinh_transform and not pooled
         shared = (share_d_pass and stacked and self.share_d_fake_pass and self.skip_discarded_d_grads
                   and torch.is_grad_enabled() and sr_spectro.requires_grad)
         self._shared_rows = 0
@@ -378,7 +382,10 @@ class Pix2PixHDModel(BaseModel):
             loss_D_fake, loss_D_real = Fh.mse_const_pair_loss_sum([scale_out[-1] for scale_out in pred_both],
                                                                   self.criterionGAN.fake_label, self.criterionGAN.real_label)
         else:
-            pred_fake_pool = self.netD.forward(self._d_in(lr_spectro, sr_spectro.detach()))
+            fake_in = self._d_in(lr_spectro, sr_spectro.detach())
+            if pooled:                                # discriminate_F(..., use_pool=True), pix2pixHD_model.py:366-374
+                fake_in = self.fake_pool.query(fake_in).contiguous(memory_format=torch.channels_last)
+            pred_fake_pool = self.netD.forward(fake_in)
             loss_D_fake = self.criterionGAN(pred_fake_pool, False)
             pred_real = self.netD.forward(self._d_in(lr_spectro, hr_spectro))
             loss_D_real = self.criterionGAN(pred_real, True)

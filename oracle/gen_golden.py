@@ -279,6 +279,19 @@ def main():
     save("g10_netG_local_attn_l", x=gin.numpy(), y=out.numpy(), keys=np.array(list(net.state_dict().keys())),
          shapes=np.array([str(tuple(p.shape)) for p in net.state_dict().values()]))
 
+    # ---- G11 ImagePool (util/image_pool.py:4-31, --pool_size > 0): which image a query returns -------------------------
+    # Images are labelled by a running id (their constant value); the fixture holds the ids of the returned batch for 8
+    # queries of 2 images through a pool of 3 under random.seed(7): fill-up, then 50 % swap with a random slot.
+    import random
+    from util.image_pool import ImagePool
+    random.seed(7)
+    pool = ImagePool(3)
+    returned = []
+    for q in range(8):
+        batch = torch.stack([torch.full((2, 3, 4), float(2 * q + i)) for i in range(2)])
+        returned.append(pool.query(batch)[:, 0, 0, 0].numpy().copy())
+    save("g11_image_pool", returned=np.stack(returned), pool_size=np.array(3), seed=np.array(7))
+
 
 if __name__ == "__main__":
     main()

@@ -20,10 +20,13 @@ class CodecCfg:
     """The spectral flags every BASELINE config carries (train.sh:9-10)."""
 
     def __init__(self, n_fft=512, hop=256, win=512, arcsinh_gain=1000.0, norm_range=(-1.0, 1.0),
-                 src_range=(-5.0, 5.0), abs_norm=True, hr_rate=48000, lr_rate=12000, fit_residual=False):
+                 src_range=(-5.0, 5.0), abs_norm=True, hr_rate=48000, lr_rate=12000, fit_residual=False,
+                 arcsinh_transform=True, raw_mdct=False, abs_spectro=True):
         self.n_fft, self.hop, self.win = n_fft, hop, win
-        self.codec = dict(arcsinh_transform=True, raw_mdct=False, arcsinh_gain=arcsinh_gain, abs_norm=abs_norm,
+        self.codec = dict(arcsinh_transform=arcsinh_transform, raw_mdct=raw_mdct, arcsinh_gain=arcsinh_gain, abs_norm=abs_norm,
                           src_range=src_range, norm_range=norm_range)
+        # pix2pixHD_model.py:400-405, 420-427: the (s, 2|s| + nr0) pair only with --abs_spectro AND --arcsinh_transform
+        self.pair = bool(abs_spectro and arcsinh_transform)
         self.norm_range = norm_range
         self.up_ratio = hr_rate / lr_rate
         self.fit_residual = fit_residual
@@ -46,6 +49,8 @@ class HotPathRef:
         return torch.from_numpy(s).to(self.dtype), norm
 
     def two_channel(self, s):
+        if not getattr(self.cfg, "pair", True):
+            return s                                                        # pix2pixHD_model.py:404, 426-427
         return torch.cat((s, s.abs() * 2 + self.cfg.norm_range[0]), dim=1)  # pix2pixHD_model.py:400-402
 
     # -- forward + losses ----------------------------------------------

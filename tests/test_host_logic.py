@@ -234,3 +234,19 @@ def test_load_network_fallbacks(tmp_path):
     dst = fresh(8)
     bm.load_network(dst, "G", "latest", str(other))
     assert torch.equal(dst.state_dict()["model.4.weight"], src.state_dict()["model.4.weight"])
+
+
+def test_image_pool_selects_like_the_reference(golden):
+    """util/image_pool.py:4-31 under random.seed(7): fixture G11 holds which image each of 8 queries (2 images, pool of 3)
+    returned in the reference."""
+    import random
+    from mdctgan_amd.image_pool import ImagePool
+    g = golden("g11_image_pool")
+    random.seed(int(g["seed"]))
+    pool = ImagePool(int(g["pool_size"]))
+    for q, want in enumerate(g["returned"]):
+        batch = torch.stack([torch.full((2, 3, 4), float(2 * q + i)) for i in range(2)])
+        got = pool.query(batch)
+        assert got.shape == batch.shape and got[:, 0, 0, 0].tolist() == want.tolist(), q
+    same = torch.randn(2, 3, 4, 4)
+    assert ImagePool(0).query(same) is same

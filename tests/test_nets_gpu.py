@@ -655,3 +655,80 @@ def test_published_checkpoint_architecture_against_oracle():
         judged(p.grad.cpu().numpy(), res["f32"]["grads"][k], res["f64"]["grads"][k], "published arch grad " + k, k=6.0)
         live += 1
     assert live >= 60, live
+
+
+def test_step_without_abs_spectro_pair(golden):
+    """pix2pixHD_model.py:404, 425-427, 440 (the else branches): without --abs_spectro --arcsinh_transform the generator sees
+    the 1-channel spectrogram and the discriminators cat(lr, sr) -- here with --raw_mdct.  Forward losses against the oracle,
+    one optimisation step (three discriminator passes: the stacked / shared passes are built on the 3-channel input
+    kernel), every parameter of G and D receives a gradient, and the data gradient through the channel concat is checked
+    against float64 directly."""
+    from mdctgan_amd import functional as Fh
+    from mdctgan_amd import options
+    from mdctgan_amd.pix2pixHD_model import create_model
+    g = golden("g6_step_global")
+    opt = options.make_opt("--raw_mdct", "--norm_range", "-1", "1", "--abs_norm", "--src_range", "-60", "60", "--input_nc", "1",
+                           "--lr_sampling_rate", "12000", "--netG", "global", "--ngf", "4", "--n_blocks_global", "2",
+                           "--n_blocks_attn_g", "0", "--num_D", "2", "--ndf", "8", "--batchSize", "2", "--bins", "32",
+                           "--segment_length", "7936", "--gpu_ids", "0")
+    model = create_model(opt)
+    onets.fill_deterministic(model.netG)
+    onets.fill_deterministic(model.netD)
+    assert next(iter(model.netD.parameters())).shape[1] == 2          # D input: lr + sr
+    netG = onets.fill_deterministic(onets.build_generator("global", 1, 1, 4, 4, 2, input_size=(32, 256)))
+    netD = onets.fill_deterministic(onets.MultiscaleDRef(2, ndf=8, n_layers=3, num_D=2))
+    cfg = ostep.CodecCfg(arcsinh_transform=False, raw_mdct=True, src_range=(-60.0, 60.0), abs_spectro=False)
+    ref = ostep.HotPathRef(netG, netD, cfg, num_D=2)
+    lo, _ = ref.forward_losses(g["lr"], g["hr"])
+    lr, hr = torch.from_numpy(g["lr"]).to(DEV), torch.from_numpy(g["hr"]).to(DEV)
+    lh, _ = model._forward(lr, hr)
+    for k, v in zip(model.loss_names, lh):
+        assert abs(v.item() - float(lo[k])) <= 0.05 * abs(float(lo[k])) + 1e-3, (k, v.item(), float(lo[k]))
+    ld = model.optimize_parameters(lr, hr)
+    assert model._shared_rows == 0 and all(np.isfinite(v.item()) for v in ld.values())
+    for net in (model.netG, model.netD):
+        for k, p in net.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    # the concat itself
+    gen = torch.Generator().manual_seed(2)
+    a = torch.randn(2, 1, 5, 7, generator=gen).to(DEV).requires_grad_()
+    b = torch.randn(2, 3, 5, 7, generator=gen).to(DEV).requires_grad_()
+    w = torch.randn(2, 4, 5, 7, generator=gen).to(DEV)
+    y = Fh.cat_channels(a, b)
+    assert torch.equal(y, torch.cat((a, b), dim=1))
+    (y * w).sum().backward()
+    assert torch.equal(a.grad, w[:, :1]) and torch.equal(b.grad, w[:, 1:])
+
+
+def test_image_pool_step():
+    """--pool_size 2 (pix2pixHD_model.py:294-298, 366-374): the D loss's fake pass reads the history pool.  While the pool
+    fills up a query returns the images it was given, so the first iteration equals the pool-less three-pass step bit for bit;
+    later iterations run on stored inputs (finite losses, every parameter still gets its gradient)."""
+    import random
+    from mdctgan_amd import options
+    from mdctgan_amd.pix2pixHD_model import create_model
+
+    def build(*extra):
+        opt = options.make_opt(*options.SPECTRAL_FLAGS, "--lr_sampling_rate", "12000", "--netG", "global", "--ngf", "4",
+                               "--n_blocks_global", "2", "--n_blocks_attn_g", "0", "--num_D", "2", "--ndf", "8", "--batchSize", "2",
+                               "--bins", "32", "--segment_length", "7936", "--gpu_ids", "0", *extra)
+        m = create_model(opt)
+        onets.fill_deterministic(m.netG)
+        onets.fill_deterministic(m.netD)
+        return m
+    random.seed(3)
+    pooled, plain = build("--pool_size", "2"), build()
+    plain.stack_d_loss_passes = False
+    gen = torch.Generator().manual_seed(8)
+    for it in range(4):
+        hr = (0.05 * torch.randn(2, 7936, generator=gen)).to(DEV)
+        lr = (0.05 * torch.randn(2, 7936, generator=gen)).to(DEV)
+        lp = pooled.optimize_parameters(lr, hr)
+        assert pooled._shared_rows == 0 and all(np.isfinite(v.item()) for v in lp.values())
+        if it == 0:
+            lq = plain.optimize_parameters(lr, hr)
+            for k in lp:
+                assert lp[k].item() == lq[k].item(), k
+    assert pooled.fake_pool.num_imgs == 2 and len(pooled.fake_pool.images) == 2
+    for k, p in pooled.netD.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
