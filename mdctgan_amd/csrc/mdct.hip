@@ -486,22 +486,25 @@ int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* w
     const bool legacy_forced = bs_off || getenv("MG_MDCT_GEMM") || getenv("MG_MDCT_FT");
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const long long n_rows = (long long)B * F;
-    if (!legacy_forced && T % 4 == 0 && !per_sample && !frames_out && !stats && (codec == CODEC_RAW || codec == CODEC_ARCSINH) &&
+    if (!legacy_forced && T % 4 == 0 && !per_sample && !frames_out && (codec == CODEC_RAW || codec == CODEC_ARCSINH) &&
         !(codec == CODEC_RAW && in2) && n_rows * M * 8 < (1ll << 32) - (1ll << 17) && (long long)B * T * 4 < (1ll << 32) &&
         al16(audio) && al16(window) && al16(dct4) && al16(spec) && (!in2 || al16(in2))) {
         const long long n_tiles = (n_rows + BS_ROWS - 1) / BS_ROWS;
         int nw = n_tiles >= 256 ? 8 : 2;
         if (const char* e = getenv("MG_MDCT_BS_NW")) nw = atoi(e) == 8 ? 8 : 2;
         const dim3 grid((unsigned)(n_tiles < 256 ? n_tiles : 256), 8 / nw), block(nw * 64);
-#define MG_K1_BS(NW_, MODE_, PAIR_)                                                                                       \
+#define MG_K1_BS(NW_, MODE_, PAIR_, STATS_)                                                                              \
     do {                                                                                                                   \
         static bool attr = false;                                                                                          \
-        if (!attr) { allow_lds(mdct4_bs_kernel<NW_, MODE_, PAIR_>, BS_K1_LDS); attr = true; }                              \
-        hipLaunchKernelGGL((mdct4_bs_kernel<NW_, MODE_, PAIR_>), grid, block, BS_K1_LDS, st, audio, B, T, F, window, dct4, cp, spec, in2); \
+        if (!attr) { allow_lds(mdct4_bs_kernel<NW_, MODE_, PAIR_, STATS_>, BS_K1_LDS); attr = true; }                      \
+        hipLaunchKernelGGL((mdct4_bs_kernel<NW_, MODE_, PAIR_, STATS_>), grid, block, BS_K1_LDS, st, audio, B, T, F, window, dct4, cp, \
+                           spec, in2, stats);                                                                              \
     } while (0)
-        if (codec == CODEC_RAW) { if (nw == 8) MG_K1_BS(8, CODEC_RAW, false); else MG_K1_BS(2, CODEC_RAW, false); }
-        else if (in2) { if (nw == 8) MG_K1_BS(8, CODEC_ARCSINH, true); else MG_K1_BS(2, CODEC_ARCSINH, true); }
-        else { if (nw == 8) MG_K1_BS(8, CODEC_ARCSINH, false); else MG_K1_BS(2, CODEC_ARCSINH, false); }
+#define MG_K1_BS_S(NW_, MODE_, PAIR_) do { if (stats) MG_K1_BS(NW_, MODE_, PAIR_, true); else MG_K1_BS(NW_, MODE_, PAIR_, false); } while (0)
+        if (codec == CODEC_RAW) { if (nw == 8) MG_K1_BS(8, CODEC_RAW, false, false); else MG_K1_BS(2, CODEC_RAW, false, false); }
+        else if (in2) { if (nw == 8) MG_K1_BS_S(8, CODEC_ARCSINH, true); else MG_K1_BS_S(2, CODEC_ARCSINH, true); }
+        else { if (nw == 8) MG_K1_BS_S(8, CODEC_ARCSINH, false); else MG_K1_BS_S(2, CODEC_ARCSINH, false); }
+#undef MG_K1_BS_S
 #undef MG_K1_BS
         MG_CHECK_LAUNCH();
         return MG_OK;

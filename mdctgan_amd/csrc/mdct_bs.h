@@ -102,31 +102,37 @@ typedef unsigned bs_v2u __attribute__((ext_vector_type(2)));
 typedef unsigned bs_v4u __attribute__((ext_vector_type(4)));
 constexpr unsigned BS_OOB = 0xffffffffu;          // buffer offset behind every num_records: the lane's access is dropped
 
-template <int NW, int MODE, bool PAIR, int DBG = 0>
+template <int NW, int MODE, bool PAIR, bool STATS = false, int DBG = 0>
 __global__ __launch_bounds__(NW * 64) void mdct4_bs_kernel(const float* __restrict__ audio, int B, int T, int F,
                                                            const float* __restrict__ window, const float* __restrict__ dct4,
-                                                           CodecParams cp, float* __restrict__ spec, float* __restrict__ in2) {
+                                                           CodecParams cp, float* __restrict__ spec, float* __restrict__ in2,
+                                                           double* __restrict__ stats) {
     constexpr int NT = NW * 64, Q = M / 2;
     constexpr int GROUPS = BS_ROWS * (M / 4) / NT;        // float4 groups of the folded tile per thread (4 / 16)
     constexpr int FSTEP = 16 / GROUPS;                    // fold slice g rides behind table step 16 + g * FSTEP
     extern __shared__ __attribute__((aligned(16))) float bs_smem[];
-    float* ws = bs_smem;                                  // [2 M] window
-    float* abuf = bs_smem + 2 * M;                        // [2][BS_ROWS][BS_LDA]
+    float* ws = bs_smem;                                  // [2 M] window, then [2 M] its negative
+    float* abuf = bs_smem + 4 * M;                        // [2][BS_ROWS][BS_LDA]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rows = B * F, n_tiles = (rows + BS_ROWS - 1) / BS_ROWS, G = gridDim.x;
     const int slab = blockIdx.y * NW + wave, col = slab * 32 + (lane & 31), kh = lane >> 5;
     BsCodec cd = bs_codec(cp);
     cd.mode = MODE;
+    const float k1 = (float)(((double)cp.nr1 - (double)cp.nr0) / ((double)cp.mx - (double)cp.mn));
+    const float k0 = (float)((double)cp.nr0 - (double)cp.mn * (((double)cp.nr1 - (double)cp.nr0) / ((double)cp.mx - (double)cp.mn)));
     const __amdgpu_buffer_rsrc_t r_audio = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(audio), 0, (unsigned)B * (unsigned)T * 4u, 0x00020000);
     // DBG bit 0: an empty range drops every store (the arithmetic stays alive)
     const __amdgpu_buffer_rsrc_t r_spec = __builtin_amdgcn_make_buffer_rsrc(spec, 0, (DBG & 1) ? 0u : (unsigned)rows * M * 4u, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_in2 = __builtin_amdgcn_make_buffer_rsrc(in2, 0, (PAIR && !(DBG & 1)) ? (unsigned)rows * M * 8u : 0u, 0x00020000);
 
-    // group gi of a thread: row r = (tid + gi * NT) / 64 of the tile, u[n .. n + 3] with n = 4 * (lane); lanes 0-31 hold the
-    // n < Q half:  u = -rev(z[3Q-4-n ..]) - z[3Q+n ..]   lanes 32-63:  u = z[n-Q ..] - rev(z[3Q-4-n ..])
+    // group gi of a thread: row r = (tid + gi * NT) / 64 of the tile, u[n .. n + 3] with n = 4 * lane.  With z = fl32(x * w):
+    //   n <  Q:  u = -rev(z[3Q-4-n ..]) - z[3Q+n ..]        n >= Q:  u = z[n-Q ..] - rev(z[3Q-4-n ..])
+    // i.e. for every lane  u = s * z[oS ..] - rev(z[oR ..])  with oR = 3Q-4-n, (oS, s) = (3Q+n, -1) | (n-Q, +1); the sign rides in
+    // the window (the second LDS copy is -w: fl32(x * -w) = -fl32(x * w)), so a half wave needs no selects
     const int n = 4 * lane;
     const bool lo = n < Q;
-    const int o1 = lo ? 3 * Q - 4 - n : n - Q, o2 = lo ? 3 * Q + n : 3 * Q - 4 - n;
+    const int o1 = 3 * Q - 4 - n, o2 = lo ? 3 * Q + n : n - Q;         // (o1: the reversed run, o2: the straight one)
+    const float* wS = ws + (lo ? 2 * M : 0) + o2;
     bs_v4u x1[GROUPS], x2[GROUPS];
     auto load_tile = [&](int tile) {
 #pragma unroll
@@ -148,18 +154,13 @@ __global__ __launch_bounds__(NW * 64) void mdct4_bs_kernel(const float* __restri
     auto fold_piece = [&](int pc, int gi, int buf) {
         const int r = wave + gi * NW;
         if (pc == 0) {
-            fw1 = bs_ld4(ws + o1); fw2 = bs_ld4(ws + o2);
+            fw1 = bs_ld4(ws + o1); fw2 = bs_ld4(wS);
         } else if (pc == 1) {       // z = fl32(x * w) (mdct.py:410)
             const float4 a = __builtin_bit_cast(float4, x1[gi]), c = __builtin_bit_cast(float4, x2[gi]);
             fz1 = make_float4(__fmul_rn(a.x, fw1.x), __fmul_rn(a.y, fw1.y), __fmul_rn(a.z, fw1.z), __fmul_rn(a.w, fw1.w));
             fz2 = make_float4(__fmul_rn(c.x, fw2.x), __fmul_rn(c.y, fw2.y), __fmul_rn(c.z, fw2.z), __fmul_rn(c.w, fw2.w));
-        } else if (pc == 2) {       // the TDAC fold as  u = p - q,  (p, q) = (-rev(z1), z2) | (z1, rev(z2))
-            float4 u;
-            u.x = (lo ? -fz1.w : fz1.x) - (lo ? fz2.x : fz2.w);
-            u.y = (lo ? -fz1.z : fz1.y) - (lo ? fz2.y : fz2.z);
-            u.z = (lo ? -fz1.y : fz1.z) - (lo ? fz2.z : fz2.y);
-            u.w = (lo ? -fz1.x : fz1.w) - (lo ? fz2.w : fz2.x);
-            fz1 = u;
+        } else if (pc == 2) {       // the TDAC fold:  u = (+-z)[straight] - rev(z[reversed])
+            fz1 = make_float4(fz2.x - fz1.w, fz2.y - fz1.z, fz2.z - fz1.y, fz2.w - fz1.x);
         } else {
             *reinterpret_cast<float4*>(abuf + (size_t)buf * BS_ROWS * BS_LDA + r * BS_LDA + n) = fz1;
         }
@@ -168,7 +169,9 @@ __global__ __launch_bounds__(NW * 64) void mdct4_bs_kernel(const float* __restri
 #pragma unroll
         for (int pc = 0; pc < 4; ++pc) fold_piece(pc, gi, buf);
     };
-    float ea, ea2, et, ep, esq, esm, el, ev;
+    float ea, ea2, et, ep, esq, esm, el, ev, elog = 0.0f;
+    double s1 = 0.0, s2 = 0.0;      // STATS: sum / sum of squares of the log-domain values (the returned mean / std)
+    int em0 = 0;                    // STATS: first frame row of this lane in the previous tile (rows: none)
     unsigned eob = BS_OOB, eob2 = BS_OOB;   // byte offset of (first frame row of this lane's 16, bin col) in spec / in the pair
     auto epi_piece = [&](int pc, float xv, int r) {      // frame row emrow + (r & 3) + 8 (r >> 2), bin col
         const int dm = (r & 3) + 8 * (r >> 2);
@@ -185,16 +188,22 @@ __global__ __launch_bounds__(NW * 64) void mdct4_bs_kernel(const float* __restri
             esm = ea * ep * INV_LN10F;
         } else if (pc == 3) {
             const float big = et * LOG10_2F;
-            el = copysignf(ea < 0.125f ? esm : big, el) - cd.mn;
+            elog = copysignf(ea < 0.125f ? esm : big, el);
         } else if (pc == 4) {
-            ev = div_const(el, cd.d, cd.rd) * cd.span + cd.nr0;
+            // (l - min) / (max - min) * (nr1 - nr0) + nr0 as ONE fma with the constants folded in double: within an ulp of the
+            // exact value (the reference's four float32 operations: within two)
+            ev = fmaf(elog, k1, k0);
+        }
+        if (STATS && pc == 5 && MODE != CODEC_RAW) {
+            const double l = (em0 + dm < rows) ? (double)elog : 0.0;
+            s1 += l; s2 += l * l;
         }
         // addressing costs no VALU: the row inside the tile is the instruction's scalar offset, and a row behind the last one
         // lies behind num_records (the range check covers voffset + soffset), so the hardware drops it
         if (pc == 6) {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ev), r_spec, eob, dm * (M * 4), 0);
         } else if (pc == 7 && PAIR) {
-            const bs_v2u pr = {__float_as_uint(ev), __float_as_uint(fabsf(ev) * 2.0f + cd.nr0)};
+            const bs_v2u pr = {__float_as_uint(ev), __float_as_uint(fmaf(fabsf(ev), 2.0f, cd.nr0))};     // (x 2 is exact: == |v| * 2 + nr0)
             __builtin_amdgcn_raw_buffer_store_b64(pr, r_in2, eob2, dm * (M * 8), 0);
         }
     };
@@ -206,6 +215,7 @@ __global__ __launch_bounds__(NW * 64) void mdct4_bs_kernel(const float* __restri
         const unsigned m0 = (unsigned)tile * BS_ROWS + 4u * kh;
         eob = (tile < n_tiles) ? (m0 * M + (unsigned)col) * 4u : BS_OOB - 31u * M * 8u;      // (+ soffset stays out of range, no wrap)
         eob2 = (tile < n_tiles) ? 2u * eob : eob;
+        em0 = (tile < n_tiles) ? (int)m0 : rows;
     };
 
     // prologue: the first tile's signal first (HBM latency), then window and table; the fold runs while the table arrives
@@ -219,7 +229,10 @@ __global__ __launch_bounds__(NW * 64) void mdct4_bs_kernel(const float* __restri
 #pragma unroll
         for (int jj = 0; jj < 32; ++jj) bt[jj] = img[jj * 64];
     }
-    if (tid < 2 * M / 4) reinterpret_cast<float4*>(ws)[tid] = wv;
+    if (tid < 2 * M / 4) {
+        reinterpret_cast<float4*>(ws)[tid] = wv;
+        reinterpret_cast<float4*>(ws + 2 * M)[tid] = make_float4(-wv.x, -wv.y, -wv.z, -wv.w);
+    }
     __syncthreads();                              // window in LDS
 #pragma unroll
     for (int gi = 0; gi < GROUPS; ++gi) fold_slice(gi, 0);
@@ -258,9 +271,13 @@ __global__ __launch_bounds__(NW * 64) void mdct4_bs_kernel(const float* __restri
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) epi_row(accp[r], r);
+    if (STATS && MODE != CODEC_RAW) {
+        s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+        if (lane == 0) { atomicAdd(stats, s1); atomicAdd(stats + 1, s2); }
+    }
 }
 
-constexpr size_t BS_K1_LDS = (size_t)(2 * M + 2 * BS_ROWS * BS_LDA) * sizeof(float);
+constexpr size_t BS_K1_LDS = (size_t)(4 * M + 2 * BS_ROWS * BS_LDA) * sizeof(float);
 
 // ------------------------------------------------------------------------------------------------------------------
 // K2.  grid = workers, block = 512.  Tile = (clip b, frames f0 .. f0 + 31); emits hop blocks h = f0 .. f0 + 31:

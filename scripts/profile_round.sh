@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round evidence in one GPU call: rocprofv3 --kernel-trace --stats summaries of the bench lines (-> gpurun_out/rNN_*), to be
+# copied into profiles/.   usage (GPU box, from the repo root): bash scripts/profile_round.sh r03
+tag=${1:-r03}
+R=$(pwd)
+out=$R/gpurun_out
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+prof() {   # name, bench args...
+    name=$1; shift
+    rm -rf /tmp/prof_$name
+    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o p -- python $R/bench.py "$@" --no-cpu-baseline --no-also \
+        > $out/${tag}_${name}_line_profiled.json 2> /tmp/prof_$name.err
+    f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1)
+    [ -n "$f" ] && cp $f $out/${tag}_${name}_kernel_stats.csv
+    a=$(find /tmp/prof_$name -name "*agent_info.csv" | head -1)
+    [ -n "$a" ] && cp $a $out/${tag}_agent_info.csv
+    tail -c 400 $out/${tag}_${name}_line_profiled.json; echo
+}
+prof bench_train --steps 10 --warmup 2
+prof bench_cfg2_fp16 --config 2 --fp16 --steps 10 --warmup 2
+prof bench_infer_cfg4 --config 4 --steps 10 --warmup 2
+prof bench_codec --mode codec --steps 10 --warmup 2
+cd $R
+python bench.py --mode codec --steps 20 --warmup 5 > $out/${tag}_bench_codec_line.json 2>/dev/null
+python bench.py --config 2 --steps 20 --warmup 5 --no-also > $out/${tag}_bench_cfg2_f32_line.json 2>/dev/null
+python bench.py --fp16 --steps 20 --warmup 5 --no-also > $out/${tag}_bench_train_fp16_line.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 > $out/${tag}_bench_train_line.json 2>/dev/null
+for f in bench_codec bench_cfg2_f32 bench_train_fp16 bench_train; do tail -c 300 $out/${tag}_${f}_line.json; echo; done

@@ -45,10 +45,10 @@ int main(int argc, char** argv) {
     };
 #define K1(NW_, MODE_, PAIR_, DBG_, name)                                                                                  \
     {                                                                                                                       \
-        auto k = mdct4_bs_kernel<NW_, MODE_, PAIR_, DBG_>;                                                                  \
+        auto k = mdct4_bs_kernel<NW_, MODE_, PAIR_, false, DBG_>;                                                                  \
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BS_K1_LDS);                    \
         const dim3 grid(n_tiles < 256 ? n_tiles : 256, 8 / NW_);                                                            \
-        report(name, time_ms([&] { hipLaunchKernelGGL(k, grid, dim3(NW_ * 64), BS_K1_LDS, 0, x, B, T, F, w, d, cp, spec, in2); }, iters)); \
+        report(name, time_ms([&] { hipLaunchKernelGGL(k, grid, dim3(NW_ * 64), BS_K1_LDS, 0, x, B, T, F, w, d, cp, spec, in2, (double*)nullptr); }, iters)); \
     }
     printf("== K1, %d clips (%d row tiles)\n", B, n_tiles);
     K1(8, CODEC_ARCSINH, true, 0, "K1 nw8 (product)");
