@@ -575,15 +575,19 @@ int mg_imdct4_forward(const float* spec, int B, int F, int n_fft, const float* w
     {
         static const bool bs_off = (getenv("MG_MDCT_BS") && atoi(getenv("MG_MDCT_BS")) == 0);
         auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-        if (!bs_off && !getenv("MG_MDCT_FT") && !frames_out && al16(spec) && al16(window) && al16(dct4) && al16(audio)) {
+        if (!bs_off && !getenv("MG_MDCT_FT") && !frames_out && !out_f64 && out_len % 4 == 0 && al16(spec) && al16(window) && al16(dct4) &&
+            al16(audio) && (long long)B * F * M * 4 < (1ll << 32) && (long long)B * out_len * 4 < (1ll << 32) - (1ll << 16) &&
+            codec >= CODEC_RAW && codec <= CODEC_RANGE) {
             const long long n_tiles = (long long)B * ((F + BS_ROWS - 1) / BS_ROWS);
-            static bool attr_bs = false;
-            if (!attr_bs) { allow_lds(imdct4_bs_kernel<float>, BS_K2_LDS); allow_lds(imdct4_bs_kernel<double>, BS_K2_LDS); attr_bs = true; }
             const dim3 grid((unsigned)(n_tiles < 256 ? n_tiles : 256));
-            if (out_f64)
-                hipLaunchKernelGGL(imdct4_bs_kernel<double>, grid, dim3(512), BS_K2_LDS, st, spec, B, F, window, dct4, cp, (double*)audio, out_len);
-            else
-                hipLaunchKernelGGL(imdct4_bs_kernel<float>, grid, dim3(512), BS_K2_LDS, st, spec, B, F, window, dct4, cp, (float*)audio, out_len);
+#define MG_K2_BS(MODE_)                                                                                                   \
+    do {                                                                                                                   \
+        static bool attr = false;                                                                                          \
+        if (!attr) { allow_lds(imdct4_bs_kernel<MODE_>, BS_K2_LDS); attr = true; }                                         \
+        hipLaunchKernelGGL((imdct4_bs_kernel<MODE_>), grid, dim3(512), BS_K2_LDS, st, spec, B, F, window, dct4, cp, (float*)audio, out_len); \
+    } while (0)
+            if (codec == CODEC_RAW) MG_K2_BS(CODEC_RAW); else if (codec == CODEC_ARCSINH) MG_K2_BS(CODEC_ARCSINH); else MG_K2_BS(CODEC_RANGE);
+#undef MG_K2_BS
             MG_CHECK_LAUNCH();
             return MG_OK;
         }

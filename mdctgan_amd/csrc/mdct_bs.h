@@ -24,6 +24,7 @@ namespace {
 
 constexpr int BS_ROWS = 32;             // frames per tile (one 32 x 32 MFMA block per wave)
 constexpr int BS_LDA = M + 4;           // LDS row pitch in floats: 65 16-byte slots -> ds_read_b128 of 16 rows hits 16 bank groups
+constexpr int BS_K2_AROWS = 40;         // K2 operand tile rows in LDS: 32 frames + the halo + padding (every wave stores its 5th group)
 constexpr float LOG10_2F = 0.30102999566398120f;
 constexpr float INV_LN10F = 0.43429448190325176f;
 
@@ -282,144 +283,175 @@ constexpr size_t BS_K1_LDS = (size_t)(4 * M + 2 * BS_ROWS * BS_LDA) * sizeof(flo
 // ------------------------------------------------------------------------------------------------------------------
 // K2.  grid = workers, block = 512.  Tile = (clip b, frames f0 .. f0 + 31); emits hop blocks h = f0 .. f0 + 31:
 //   out[(h - 1) M + n] = 4 / N * (w[n] y_h[n] + w[n + M] y_{h-1}[n + M]),  y = [v2, -v2_r, -v1_r, -v1] of v = DCT-IV(X).
+// Same structure as K1: per wave three tiles in flight, one piece of the side work behind each MFMA -- the DCT stream of
+// tile i (+ the halo frame f0 - 1 as four FMAs per table step), the unfold / window / overlap-add / store of tile i - 1 out
+// of the other v buffer, the decode (denormalise, sinh) of tile i + 1 into the other operand buffer.  One barrier per tile.
 // ------------------------------------------------------------------------------------------------------------------
-template <typename OutT>
+template <int MODE>
 __global__ __launch_bounds__(512) void imdct4_bs_kernel(const float* __restrict__ spec, int B, int F,
                                                         const float* __restrict__ window, const float* __restrict__ dct4,
-                                                        CodecParams cp, OutT* __restrict__ audio, int out_len) {
+                                                        CodecParams cp, float* __restrict__ audio, int out_len) {
     constexpr int NT = 512, Q = M / 2;
-    constexpr int GROUPS = (BS_ROWS + 1) * (M / 4) / NT + 1;     // 33 rows x 64 float4 groups over 512 threads: 4 full + 1 partial
+    constexpr int DG = 5;                                     // decode groups per thread: rows wave + 8 gi (row 32 = halo; 33..39 padding)
+    constexpr int UG = BS_ROWS * (M / 4) / NT;                // unfold groups per thread: 4
+    constexpr int A_F = BS_K2_AROWS * BS_LDA;                 // operand tile: rows 0..31 = frames f0.., row 32 = halo frame f0 - 1
+    constexpr int V_F = (BS_ROWS + 1) * BS_LDA;               // v tile: the same rows
     extern __shared__ __attribute__((aligned(16))) float bs_smem[];
-    float* ws = bs_smem;                                  // [2 M]
-    float* abuf = bs_smem + 2 * M;                        // [2][BS_ROWS + 1][BS_LDA]: row 32 = halo frame f0 - 1
-    constexpr int TILE_F = (BS_ROWS + 1) * BS_LDA;
+    float* abuf = bs_smem;                                // [2][A_F] decoded coefficients (the A operand)
+    float* vbuf = abuf + 2 * A_F;                         // [2][V_F] v = DCT-IV(X) of the tile before
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_per_clip = (F + BS_ROWS - 1) / BS_ROWS, n_tiles = B * tiles_per_clip;
+    const int tiles_per_clip = (F + BS_ROWS - 1) / BS_ROWS, n_tiles = B * tiles_per_clip, G = gridDim.x;
     const int col = wave * 32 + (lane & 31), kh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t r_spec = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(spec), 0, (unsigned)B * (unsigned)F * M * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(audio, 0, (unsigned)B * (unsigned)out_len * 4u, 0x00020000);
 
+    // denormalise + decode folded into  x = v * c1 + c0  (= ln10 * ((v - nr0) / (nr1 - nr0) * (max - min) + min)),
+    // X = sinh(x) / gain -- constants in double once per tile (per-sample ranges change them per clip)
+    float c1 = 1.0f, c0 = 0.0f;
+    const float rgain = 1.0f / cp.gain;
+    auto tile_consts = [&](int tile) {
+        const int b = (tile < n_tiles ? tile : 0) / tiles_per_clip;
+        float mn = cp.mn, mx = cp.mx;
+        if (cp.per_sample) { mn = cp.mn_b[b]; mx = cp.mx_b[b]; }
+        const double k = ((double)mx - (double)mn) / ((double)cp.nr1 - (double)cp.nr0);
+        const double sc = (MODE == CODEC_ARCSINH) ? (double)LN10F : 1.0;
+        c1 = (float)(k * sc);
+        c0 = (float)(((double)mn - (double)cp.nr0 * k) * sc);
+    };
+    bs_v4u xr[DG];
+    float xok[DG];          // 1 / 0: frames outside the clip contribute nothing (decode(0) != 0); a factor, not a branch
+    auto load_tile = [&](int tile, int g0, int g1) {        // groups [g0, g1): issued in two batches to keep fewer registers live
+        const int tl = tile < n_tiles ? tile : 0;
+        const int b = tl / tiles_per_clip, f0 = (tl - b * tiles_per_clip) * BS_ROWS;
+#pragma unroll
+        for (int gi = g0; gi < g1; ++gi) {
+            const int j = wave + 8 * gi;                 // (tid + gi * NT) >> 6
+            const int f = (j == BS_ROWS) ? f0 - 1 : f0 + j;
+            const bool ok = tile < n_tiles && j <= BS_ROWS && f >= 0 && f < F;
+            xok[gi] = ok ? 1.0f : 0.0f;
+            const unsigned o = ok ? (((unsigned)b * F + (unsigned)f) * M + 4u * lane) * 4u : BS_OOB;
+            xr[gi] = __builtin_amdgcn_raw_buffer_load_b128(r_spec, o, 0, 0);
+        }
+    };
+    auto dec1 = [&](float v) -> float {
+        if (MODE == CODEC_RAW) return v;
+        const float x = fmaf(v, c1, c0);
+        if (MODE == CODEC_ARCSINH) return sinh_fast(x) * rgain;
+        return x;
+    };
+    auto decode_piece = [&](int pc, int gi, int buf) {      // pieces 0..3: one coefficient each, straight to LDS (no register tile)
+        const float4 x = __builtin_bit_cast(float4, xr[gi]);
+        float* dst = abuf + (size_t)buf * A_F + (wave + 8 * gi) * BS_LDA + 4 * lane;
+        const float xv = pc == 0 ? x.x : pc == 1 ? x.y : pc == 2 ? x.z : x.w;
+        dst[pc] = dec1(xv) * xok[gi];                       // (an out-of-range load returned 0: dec1 of it is finite)
+    };
+    // unfold of the previous tile, group gi: hop block j = wave + 8 gi, samples n = 4 lane ..+3
+    const float scale = 4.0f / (2 * M);
+    const int n = 4 * lane;
+    const bool lo = n < Q;
+    unsigned pbase = 0;         // element index of (clip b, sample (f0 - 1) M + n) of the previous tile in the output
+    int pf0 = 0;
+    bool pvalid = false;
+    float4 uc, up;
+    const float4 uw0 = bs_ld4(window + n), uw1 = bs_ld4(window + n + M);      // this lane's window values: the same for every hop block
+    auto unfold_piece = [&](int pc, int gi, int vb) {
+        const int j = wave + 8 * gi;
+        const float* vc = vbuf + (size_t)vb * V_F + j * BS_LDA;                                   // frame h
+        const float* vp = vbuf + (size_t)vb * V_F + ((j == 0) ? BS_ROWS : j - 1) * BS_LDA;        // frame h - 1
+        if (pc == 0) {
+            // y_h[n] = v_h[Q + n] | -v_h[3Q - 1 - n];   y_{h-1}[n + M] = -v_{h-1}[Q - 1 - n] | -v_{h-1}[n - Q]
+            uc = bs_ld4(vc + (lo ? Q + n : 3 * Q - 4 - n));
+            up = bs_ld4(vp + (lo ? Q - 4 - n : n - Q));
+        } else if (pc == 1) {
+            const float4 c = uc, q = up;
+            uc = lo ? c : make_float4(-c.w, -c.z, -c.y, -c.x);
+            up = lo ? make_float4(-q.w, -q.z, -q.y, -q.x) : make_float4(-q.x, -q.y, -q.z, -q.w);
+        } else if (pc == 2) {
+            uc = make_float4(scale * (uw0.x * uc.x + uw1.x * up.x), scale * (uw0.y * uc.y + uw1.y * up.y),
+                             scale * (uw0.z * uc.z + uw1.z * up.z), scale * (uw0.w * uc.w + uw1.w * up.w));
+        } else {
+            const int hh = pf0 + j, t0 = (hh - 1) * M + n;       // out_len % 4 == 0: a float4 is inside or outside the crop as a whole
+            const bool ok = pvalid && hh >= 1 && hh <= F - 1 && t0 + 3 < out_len;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bs_v4u, uc), r_out, ok ? (pbase + (unsigned)(j * M)) * 4u : BS_OOB, 0, 0);
+        }
+    };
+
+    // prologue
+    int tile = blockIdx.x;
+    tile_consts(tile);
+    load_tile(tile, 0, DG);
+    // (decode first, one value at a time, THEN fetch the table: 20 interleaved sinh evaluations beside 128 live table registers
+    // spill; the microsecond of table latency this exposes is paid once per workgroup)
+#pragma unroll
+    for (int gi = 0; gi < DG; ++gi)
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+            decode_piece(pc, gi, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     float4 bt[32];
     {
         const float4* img = reinterpret_cast<const float4*>(dct4 + M * M) + (size_t)wave * 32 * 64 + lane;
 #pragma unroll
         for (int jj = 0; jj < 32; ++jj) bt[jj] = img[jj * 64];
     }
-    for (int i = tid; i < 2 * M / 4; i += NT) reinterpret_cast<float4*>(ws)[i] = bs_ld4(window + 4 * i);
-
-    float4 xr[GROUPS];
-    auto load_tile = [&](int tile) {
-        const int b = tile / tiles_per_clip, f0 = (tile - b * tiles_per_clip) * BS_ROWS;
-#pragma unroll
-        for (int gi = 0; gi < GROUPS; ++gi) {
-            const int i = tid + gi * NT, j = i >> 6, k = 4 * (i & 63);
-            xr[gi] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j <= BS_ROWS) {
-                const int f = (j == BS_ROWS) ? f0 - 1 : f0 + j;
-                if (f >= 0 && f < F) xr[gi] = bs_ld4(spec + ((size_t)b * F + f) * M + k);
-            }
-        }
-    };
-    const float span = cp.nr1 - cp.nr0, rspan = 1.0f / span, rgain = 1.0f / cp.gain;
-    auto dec1 = [&](float v, float mn, float d) -> float {      // Audio2MDCT.denormalize, pix2pixHD_model.py:127-137
-        if (cp.mode == CODEC_RAW) return v;
-        const float l = div_const(v - cp.nr0, span, rspan) * d + mn;
-        if (cp.mode == CODEC_ARCSINH) return div_const(sinh_fast(l * LN10F), cp.gain, rgain);
-        return l;
-    };
-    auto decode_tile = [&](int tile, int buf) {
-        const int b = tile / tiles_per_clip, f0 = (tile - b * tiles_per_clip) * BS_ROWS;
-        float mn = cp.mn, mx = cp.mx;
-        if (cp.per_sample) { mn = cp.mn_b[b]; mx = cp.mx_b[b]; }
-        const float d = mx - mn;
-#pragma unroll
-        for (int gi = 0; gi < GROUPS; ++gi) {
-            const int i = tid + gi * NT, j = i >> 6, k = 4 * (i & 63);
-            if (j > BS_ROWS) continue;
-            const int f = (j == BS_ROWS) ? f0 - 1 : f0 + j;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);       // frames outside the clip contribute nothing (decode(0) != 0)
-            if (f >= 0 && f < F) v = make_float4(dec1(xr[gi].x, mn, d), dec1(xr[gi].y, mn, d), dec1(xr[gi].z, mn, d), dec1(xr[gi].w, mn, d));
-            *reinterpret_cast<float4*>(abuf + (size_t)buf * TILE_F + j * BS_LDA + k) = v;
-        }
-    };
-
-    int tile = blockIdx.x;
-    if (tile < n_tiles) load_tile(tile);
     __syncthreads();
-    if (tile < n_tiles) decode_tile(tile, 0);
-    __syncthreads();
-    int buf = 0;
-    const float scale = 4.0f / (2 * M);
-    for (; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
-        const int next = tile + gridDim.x;
-        if (next < n_tiles) load_tile(next);
-        float* at = abuf + (size_t)buf * TILE_F;
+
+    int buf = 0, vb = 0;
+    for (; tile < n_tiles; tile += G, buf ^= 1, vb ^= 1) {
+        tile_consts(tile + G);                      // (scalar work, outside the pinned stream)
+        const float* at = abuf + (size_t)buf * A_F;
         f32x16 acc = f32x16{0};
         float4 h4 = make_float4(0.f, 0.f, 0.f, 0.f);       // halo frame: this lane's half of the k of its bin, four partial sums
         const float* ap = at + (lane & 31) * BS_LDA + 4 * kh;
         const float* hp = at + BS_ROWS * BS_LDA + 4 * kh;
+        float4 a = bs_ld4(ap), an = a, xh = a;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int jj = 0; jj < 32; ++jj) {
-            const float4 a = bs_ld4(ap + 8 * jj);
-            const float4 xh = bs_ld4(hp + 8 * jj);
-            acc = mfma32x32x2(a.x, bt[jj].x, acc);
-            acc = mfma32x32x2(a.y, bt[jj].y, acc);
-            acc = mfma32x32x2(a.z, bt[jj].z, acc);
-            acc = mfma32x32x2(a.w, bt[jj].w, acc);
-            h4.x = fmaf(xh.x, bt[jj].x, h4.x); h4.y = fmaf(xh.y, bt[jj].y, h4.y);
-            h4.z = fmaf(xh.z, bt[jj].z, h4.z); h4.w = fmaf(xh.w, bt[jj].w, h4.w);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float av = t == 0 ? a.x : t == 1 ? a.y : t == 2 ? a.z : a.w;
+                const float bv = t == 0 ? bt[jj].x : t == 1 ? bt[jj].y : t == 2 ? bt[jj].z : bt[jj].w;
+                acc = mfma32x32x2(av, bv, acc);
+                if (t == 0) { xh = bs_ld4(hp + 8 * jj); if (jj + 1 < 32) an = bs_ld4(ap + 8 * (jj + 1)); }
+                if (t == 0 && jj == 7) load_tile(tile + G, 0, 3);      // next tile's coefficients: issued behind the unfold pieces,
+                if (t == 0 && jj == 14) load_tile(tile + G, 3, DG);    // decoded from step 12 / 18 on
+                if (t == 3) {
+                    h4.x = fmaf(xh.x, bt[jj].x, h4.x); h4.y = fmaf(xh.y, bt[jj].y, h4.y);
+                    h4.z = fmaf(xh.z, bt[jj].z, h4.z); h4.w = fmaf(xh.w, bt[jj].w, h4.w);
+                }
+                if (t == 1 || t == 2) {
+                    const int slot = 2 * jj + (t - 1);          // 64 slots: 16 unfold pieces (their data is in LDS), later 20 decode pieces
+                    if (slot < 4 * UG) unfold_piece(slot & 3, slot >> 2, vb ^ 1);
+                    else if (slot >= 24 && slot < 24 + 4 * DG) decode_piece((slot - 24) & 3, (slot - 24) >> 2, buf ^ 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            a = an;
         }
         float h = (h4.x + h4.y) + (h4.z + h4.w);
         h += __shfl_xor(h, 32, 64);
-        __syncthreads();                           // every wave is done reading the tile as the A operand
-        // v = DCT-IV(X) back into the same buffer: rows 0..31 frames, row 32 halo
+        // v = DCT-IV(X) into this tile's v buffer: rows 0..31 frames, row 32 halo (the unfold of the NEXT iteration reads it)
+        float* vt = vbuf + (size_t)vb * V_F;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) at[mfma32_row(r, lane) * BS_LDA + col] = acc[r];
-        if (lane < 32) at[BS_ROWS * BS_LDA + col] = h;
-        __syncthreads();
-        // unfold, window, overlap-add, scale, centre crop: 32 hop blocks x 256 samples, float4 per thread
+        for (int r = 0; r < 16; ++r) vt[mfma32_row(r, lane) * BS_LDA + col] = acc[r];
+        if (lane < 32) vt[BS_ROWS * BS_LDA + col] = h;
         {
-            const int b = tile / tiles_per_clip, f0 = (tile - b * tiles_per_clip) * BS_ROWS;
-#pragma unroll
-            for (int gi = 0; gi < BS_ROWS * (M / 4) / NT; ++gi) {
-                const int i = tid + gi * NT, j = i >> 6, n = 4 * (i & 63);
-                const int hh = f0 + j;
-                if (hh < 1 || hh > F - 1) continue;
-                const float* vc = at + j * BS_LDA;                                   // frame h
-                const float* vp = at + ((j == 0) ? BS_ROWS : j - 1) * BS_LDA;        // frame h - 1
-                float4 yc, yp;
-                if (n < Q) {      // y_h[n] = v_h[Q + n];  y_{h-1}[n + M] = -v_{h-1}[Q - 1 - n]
-                    yc = bs_ld4(vc + Q + n);
-                    const float4 t = bs_rev4(bs_ld4(vp + Q - 4 - n));
-                    yp = make_float4(-t.x, -t.y, -t.z, -t.w);
-                } else {          // y_h[n] = -v_h[3Q - 1 - n];  y_{h-1}[n + M] = -v_{h-1}[n - Q]
-                    const float4 t = bs_rev4(bs_ld4(vc + 3 * Q - 4 - n));
-                    yc = make_float4(-t.x, -t.y, -t.z, -t.w);
-                    const float4 u = bs_ld4(vp + n - Q);
-                    yp = make_float4(-u.x, -u.y, -u.z, -u.w);
-                }
-                const float4 w0 = bs_ld4(ws + n), w1 = bs_ld4(ws + n + M);
-                const float o0 = scale * (w0.x * yc.x + w1.x * yp.x), o1 = scale * (w0.y * yc.y + w1.y * yp.y);
-                const float o2 = scale * (w0.z * yc.z + w1.z * yp.z), o3 = scale * (w0.w * yc.w + w1.w * yp.w);
-                const int t0 = (hh - 1) * M + n;
-                OutT* dst = audio + (size_t)b * out_len + t0;
-                if (t0 + 3 < out_len && (((size_t)b * out_len + t0) & 3) == 0) {
-                    if constexpr (sizeof(OutT) == 4) {
-                        *reinterpret_cast<float4*>(dst) = make_float4(o0, o1, o2, o3);
-                    } else {
-                        dst[0] = (OutT)o0; dst[1] = (OutT)o1; dst[2] = (OutT)o2; dst[3] = (OutT)o3;
-                    }
-                } else {
-                    if (t0 < out_len) dst[0] = (OutT)o0;
-                    if (t0 + 1 < out_len) dst[1] = (OutT)o1;
-                    if (t0 + 2 < out_len) dst[2] = (OutT)o2;
-                    if (t0 + 3 < out_len) dst[3] = (OutT)o3;
-                }
-            }
+            const int pb = tile / tiles_per_clip;
+            pf0 = (tile - pb * tiles_per_clip) * BS_ROWS;
+            pbase = (unsigned)pb * (unsigned)out_len + (unsigned)((pf0 - 1) * M + n);      // (wraps for pf0 == 0: those blocks are masked)
+            pvalid = true;
         }
-        if (next < n_tiles) decode_tile(next, buf ^ 1);
         __syncthreads();
     }
+    // drain: the last tile's unfold
+#pragma unroll
+    for (int gi = 0; gi < UG; ++gi)
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) unfold_piece(pc, gi, vb ^ 1);
 }
 
-constexpr size_t BS_K2_LDS = (size_t)(2 * M + 2 * (BS_ROWS + 1) * BS_LDA) * sizeof(float);
+constexpr size_t BS_K2_LDS = (size_t)(2 * BS_K2_AROWS * BS_LDA + 2 * (BS_ROWS + 1) * BS_LDA) * sizeof(float);
 
 }  // namespace

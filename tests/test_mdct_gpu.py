@@ -88,7 +88,8 @@ def test_round_trip_full_size(mods):
     from mdctgan_amd.mdct import IMDCT4
     im64 = IMDCT4(512, 256, 512, imdct.window, device=DEV, dtype=torch.float64)
     y64, _ = im64(X)
-    assert y64.dtype == torch.float64 and torch.equal(y64.float(), y)
+    # (the float64 store is the round-1 kernel's, the float32 one the table-stationary kernel's: another k order, same bar)
+    assert y64.dtype == torch.float64 and (y64.float() - y).abs().max().item() <= 2e-6 * y.abs().max().item()
 
 
 def _codec_kw(abs_norm):
