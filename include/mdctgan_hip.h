@@ -218,6 +218,25 @@ int mg_conv_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float*
 size_t mg_conv_wgrad_workspace(const mg_conv_geom* g);
 int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias, int accumulate,
                     void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* tiles);
+/* Round 3 (single process, float32): the weight side of a Winograd F(2x2,3x3) layer in one pass.  Instead of writing dw,
+ * the call applies torch.optim.Adam's update (pix2pixHD_model.py:350-351) to (w, m, v) straight from the Winograd-domain
+ * gradient and leaves u = G w G^T of the UPDATED weights (mg_conv_wino_weights_bytes(g) bytes) for the next forward:
+ * the gradient never exists in HBM, the weights make one round trip instead of three.  state: the optimiser's device
+ * clock double[6] = {step, lr, lr / (1 - b1^step), sqrt(1 - b2^step), 1 - b1^(step+1), sqrt(1 - b2^(step+1))} BEFORE this
+ * iteration's mg_adam_tick (the call reads [1], [4], [5]; mg_adam_tick / mg_adam_tick_amp maintain them, mg_adam_prime
+ * initialises [4], [5] for a fresh or restored clock).  Same results as mg_conv_wgrad_w + mg_adam_step_dev +
+ * mg_conv_wino_prepare, bit for bit.  The caller guarantees what the fusion assumes: one optimiser step per backward
+ * pass, no other contribution to this weight's gradient, no gradient reduction across processes, no loss scaling. */
+typedef struct {
+    float* m;
+    float* v;
+    float* u;
+    const double* state;
+    float beta1, beta2, eps, grad_scale;
+} mg_wino_adam;
+int mg_conv_wgrad_adam_ok(const mg_conv_geom* g);
+int mg_conv_wgrad_adam_w(const mg_conv_geom* g, const float* x, const float* dy, float* w, const mg_wino_adam* adam,
+                         void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* tiles);
 /* Name of the kernel instance a pass (0 fwd, 1 dgrad, 2 wgrad) launches for this geometry -- the symbol
  * rocprofv3 reports -- so bench.py can attribute event-timed launches per kernel.  out: host buffer >= 64 B. */
 int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len);
@@ -330,6 +349,9 @@ int mg_adam_step(float* p, const float* g, float* m, float* v, long long n, floa
  * sqrt(1-beta2^step)}; mg_adam_tick advances it on the device (host writes state[1] = lr when the schedule
  * changes), mg_adam_step_dev reads it -- no step-dependent value is baked into a kernel argument. */
 int mg_adam_tick(double* state, float beta1, float beta2, void* stream);
+/* state[4] = 1 - beta1^(step+1), state[5] = sqrt(1 - beta2^(step+1)) for the clock as it stands (a fresh or restored clock; every
+ * tick maintains them afterwards): the terms mg_conv_wgrad_adam_w reads.  The clock is double[6]. */
+int mg_adam_prime(double* state, float beta1, float beta2, void* stream);
 int mg_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const double* state, float beta1,
                      float beta2, float eps, float grad_scale, void* stream);
 

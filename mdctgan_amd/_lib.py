@@ -40,6 +40,15 @@ class WinoTiles(C.Structure):
 
 _W = C.POINTER(WinoTiles)
 
+
+class WinoAdam(C.Structure):
+    """mg_wino_adam: the optimiser side of mg_conv_wgrad_adam_w (moments, the U image to refresh, the device clock)."""
+    _fields_ = [("m", C.c_void_p), ("v", C.c_void_p), ("u", C.c_void_p), ("state", C.c_void_p),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("grad_scale", C.c_float)]
+
+
+_WA = C.POINTER(WinoAdam)
+
 # name -> (restype, argtypes); must list every symbol include/mdctgan_hip.h declares
 SIGNATURES = {
     "mg_abi_version": (_i, []),
@@ -60,6 +69,8 @@ SIGNATURES = {
     "mg_conv_fwd_instnorm_w": (_i, [_G, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _sz, _p, _W]),
     "mg_conv_dgrad_w": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p, _W]),
     "mg_conv_wgrad_w": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p, _W]),
+    "mg_conv_wgrad_adam_ok": (_i, [_G]),
+    "mg_conv_wgrad_adam_w": (_i, [_G, _p, _p, _p, _WA, _p, _sz, _p, _W]),
     "mg_conv_dgrad": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p]),
     "mg_conv_dgrad_workspace": (_sz, [_G]),
     "mg_conv_wgrad": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p]),
@@ -111,6 +122,7 @@ SIGNATURES = {
     "mg_l1_bwd": (_i, [_p, _p, _ll, _f, _p, _p, _p]),
     "mg_adam_step": (_i, [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _f, _p]),
     "mg_adam_tick": (_i, [_p, _f, _f, _p]),
+    "mg_adam_prime": (_i, [_p, _f, _f, _p]),
     "mg_adam_step_dev": (_i, [_p, _p, _p, _p, _ll, _p, _f, _f, _f, _f, _p]),
     "mg_scaler_check": (_i, [_p, _ll, _p, _i, _p]),
     "mg_scaler_update": (_i, [_p, _f, _f, _i, _p]),

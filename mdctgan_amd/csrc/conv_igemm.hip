@@ -1912,7 +1912,7 @@ int wino_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const flo
 }
 
 int wino_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate, float* ws,
-               hipStream_t st, const float* v_in, const float* md_in) {
+               hipStream_t st, const float* v_in, const float* md_in, const mg_wino_adam* ad = nullptr) {
     const WinoDims d = wino_dims(g);
     const WinoWgradPlan p = wino_wgrad_plan(g);
     float* V = ws;
@@ -1953,6 +1953,10 @@ int wino_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw
                            dU, 0);
     }
     }
+    if (ad)     // dw IS the weight tensor here: inverse transform + Adam + next iteration's forward transform in one pass
+        hipLaunchKernelGGL(wino_adam_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 4)), dim3(256), 0, st, (const float*)dU, g->Co,
+                           g->Ci, dw, ad->m, ad->v, ad->u, ad->state, ad->beta1, ad->beta2, ad->eps, ad->grad_scale);
+    else
     hipLaunchKernelGGL(wino_dweight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 4)), dim3(256), 0, st,
                        (const float*)dU, g->Co, g->Ci, dw, accumulate);
     MG_CHECK_LAUNCH();
@@ -3040,6 +3044,21 @@ size_t mg_conv_wgrad_workspace(const mg_conv_geom* g) {
     if (conv_dma_wgrad_ok(g) && conv_dma_half(g)) wg += conv_dma_h_x_bytes(g) + conv_dma_h_dy_bytes(g);
     const size_t cs = mg_colsum_workspace((long long)g->B * g->OH * g->OW, g->Co);
     return (wg > cs ? wg : cs) + 256;
+}
+
+int mg_conv_wgrad_adam_ok(const mg_conv_geom* g) {
+    return (geom_ok(g) && !co1_gemm_ok(g) && !mg_conv_rowdot_kq(g) && !h16_ok(g) && wino_ok(g) && !prec_h(g) && g->Ci % 4 == 0) ? 1 : 0;
+}
+int mg_conv_wgrad_adam_w(const mg_conv_geom* g, const float* x, const float* dy, float* w, const mg_wino_adam* ad,
+                         void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* wt) {
+    if (!mg_conv_wgrad_adam_ok(g)) return MG_ERR_UNSUPPORTED;
+    if (!w || !ad || !ad->m || !ad->v || !ad->u || !ad->state || !wino_tiles_ok(g, wt)) return MG_ERR_ARG;
+    if ((!x || !dy) && !(wt && wt->v && wt->md && mg_conv_wino_md_from_norm_ok(g))) return MG_ERR_ARG;
+    if (!workspace || workspace_bytes < mg_conv_wgrad_workspace(g)) return MG_ERR_ARG;
+    if (!aligned16(w) || !aligned16(ad->m) || !aligned16(ad->v) || !aligned16(ad->u) || !aligned16(workspace) ||
+        (x && !aligned16(x)) || (dy && !aligned16(dy)))
+        return MG_ERR_ARG;
+    return wino_wgrad(g, x, dy, w, 0, (float*)workspace, (hipStream_t)stream, wt ? wt->v : nullptr, wt ? wt->md : nullptr, ad);
 }
 
 int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias, int accumulate,

@@ -543,6 +543,14 @@ __global__ void adam_tick_kernel(double* __restrict__ state, double b1, double b
         state[0] = step;
         state[2] = state[1] / (1.0 - pow(b1, step));
         state[3] = sqrt(1.0 - pow(b2, step));
+        state[4] = 1.0 - pow(b1, step + 1.0);       // the NEXT step's bias-correction terms: kernels that update weights
+        state[5] = sqrt(1.0 - pow(b2, step + 1.0)); // during backward (before this clock ticks) read these (mg_conv_wgrad_adam_w)
+    }
+}
+__global__ void adam_prime_kernel(double* __restrict__ state, double b1, double b2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        state[4] = 1.0 - pow(b1, state[0] + 1.0);
+        state[5] = sqrt(1.0 - pow(b2, state[0] + 1.0));
     }
 }
 // ---- GradScaler on the device (train.py:65-70, 183-199).  scaler = {scale, growth_tracker, found_inf[slot]...} ----
@@ -577,6 +585,8 @@ __global__ void adam_tick_amp_kernel(double* __restrict__ state, double b1, doub
         state[0] = step;
         state[2] = state[1] / (1.0 - pow(b1, step));
         state[3] = sqrt(1.0 - pow(b2, step));
+        state[4] = 1.0 - pow(b1, step + 1.0);
+        state[5] = sqrt(1.0 - pow(b2, step + 1.0));
     }
 }
 __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -851,6 +861,13 @@ int mg_adam_step(float* p, const float* g, float* m, float* v, long long n, floa
 int mg_adam_tick(double* state, float beta1, float beta2, void* stream) {
     if (!state) return MG_ERR_ARG;
     hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, (double)beta1, (double)beta2);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+int mg_adam_prime(double* state, float beta1, float beta2, void* stream) {
+    if (!state) return MG_ERR_ARG;
+    hipLaunchKernelGGL(adam_prime_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, (double)beta1, (double)beta2);
     MG_CHECK_LAUNCH();
     return MG_OK;
 }

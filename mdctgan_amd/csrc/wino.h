@@ -597,6 +597,89 @@ __global__ void wino_dweight_xform_kernel(const float* __restrict__ dU, int Co, 
     }
 }
 
+// Weight side of a trunk layer in ONE pass (round 3; single process, float32): the weight gradient's inverse transform
+// dw = G^T dU G, the Adam update of (w, m, v) and the forward transform U = G w G^T of the UPDATED weights for the next
+// iteration -- what wino_dweight_xform_kernel, adam_dev_kernel and wino_weight_xform_kernel do in three passes with the
+// gradient and the weights making an HBM round trip each (467 MB -> 354 MB per 1024-channel layer).  The arithmetic is theirs,
+// operation for operation (bit-identical: tests/test_conv_gpu.py::test_wgrad_adam_fusion_is_bit_identical).  The Adam clock
+// has not ticked yet when this runs (backward precedes optimizer.step()): the bias corrections come from state[4], state[5],
+// which the last tick left for exactly this purpose.
+__global__ void wino_adam_kernel(const float* __restrict__ dU, int Co, int Ci, float* __restrict__ w, float* __restrict__ m,
+                                 float* __restrict__ v, float* __restrict__ U, const double* __restrict__ state, float b1,
+                                 float b2, float eps, float gscale) {
+    const float step_size = (float)(state[1] / state[4]), bc2_sqrt = (float)state[5];
+    const int C4 = Ci / 4;
+    const size_t total = (size_t)Co * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4), co = (int)(i / C4);
+        float4 g[3][3];
+        {   // wino_dweight_xform_kernel
+            float4 u[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) u[r][c] = ld4(dU + ((size_t)(r * 4 + c) * Co + co) * Ci + 4 * c4);
+            float4 tmp[3][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 h1 = f4scale(u[1][c], 0.5f), h2 = f4scale(u[2][c], 0.5f);
+                tmp[0][c] = f4add(f4add(u[0][c], h1), h2);
+                tmp[1][c] = f4sub(h1, h2);
+                tmp[2][c] = f4add(f4add(h1, h2), u[3][c]);
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float4 h1 = f4scale(tmp[r][1], 0.5f), h2 = f4scale(tmp[r][2], 0.5f);
+                g[r][0] = f4add(f4add(tmp[r][0], h1), h2);
+                g[r][1] = f4sub(h1, h2);
+                g[r][2] = f4add(f4add(h1, h2), tmp[r][3]);
+            }
+        }
+        // adam_dev_kernel on the nine taps
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const size_t o = ((size_t)(co * 3 + r) * 3 + c) * Ci + 4 * c4;
+                float4 pv = ld4(w + o), mv = ld4(m + o), vv = ld4(v + o);
+                float* pp = reinterpret_cast<float*>(&pv); float* mm = reinterpret_cast<float*>(&mv);
+                float* vp = reinterpret_cast<float*>(&vv); const float* gg = reinterpret_cast<const float*>(&g[r][c]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float gi = gg[j] * gscale;
+                    const float mi = mm[j] + (gi - mm[j]) * (1.0f - b1);
+                    const float vi = vp[j] * b2 + (1.0f - b2) * gi * gi;
+                    mm[j] = mi; vp[j] = vi;
+                    pp[j] = pp[j] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+                }
+                *reinterpret_cast<float4*>(w + o) = pv;
+                *reinterpret_cast<float4*>(m + o) = mv;
+                *reinterpret_cast<float4*>(v + o) = vv;
+                g[r][c] = pv;         // the updated weights
+            }
+        // wino_weight_xform_kernel
+        float4 tmp[4][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            tmp[0][c] = g[0][c];
+            tmp[1][c] = f4scale(f4add(f4add(g[0][c], g[1][c]), g[2][c]), 0.5f);
+            tmp[2][c] = f4scale(f4add(f4sub(g[0][c], g[1][c]), g[2][c]), 0.5f);
+            tmp[3][c] = g[2][c];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float4 o[4];
+            o[0] = tmp[r][0];
+            o[1] = f4scale(f4add(f4add(tmp[r][0], tmp[r][1]), tmp[r][2]), 0.5f);
+            o[2] = f4scale(f4add(f4sub(tmp[r][0], tmp[r][1]), tmp[r][2]), 0.5f);
+            o[3] = tmp[r][2];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                *reinterpret_cast<float4*>(U + ((size_t)(r * 4 + c) * Co + co) * Ci + 4 * c4) = o[c];
+        }
+    }
+}
+
 inline unsigned wino_grid(size_t n) {
     size_t b = (n + 255) / 256;
     return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));

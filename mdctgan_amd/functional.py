@@ -125,10 +125,78 @@ def _cached_wino_weights(g, weight, fill=True):
     return u
 
 
-def _weight_image(g, weight):
+# ------------------------------------------------------------------------------------------------
+# weight-side fusion: gradient inverse transform + Adam + next forward transform in the weight-gradient call
+# ------------------------------------------------------------------------------------------------
+# For the Winograd F(2x2,3x3) trunk layers (18 x 9.4 M weights on configs[1]) the weight gradient never goes to HBM: the
+# call that would write it applies Adam to (w, m, v) and refreshes the layer's transformed weights U for the next iteration
+# (include/mdctgan_hip.h: mg_conv_wgrad_adam_w; 467 -> 354 MB of traffic and 3 -> 1 launches per layer).  Valid only where
+# FusedAdam.can_fuse() says so (one process, float32), only inside fused_adam_scope -- Pix2PixHDModel.optimize_parameters
+# opens it around loss_G.backward(), where exactly one optimiser step follows the backward pass -- and only for weights with
+# a single gradient contribution per step.  Everywhere else the three separate kernels run, with the same bits.
+class _FusedAdamScope:
+    opt = None
+
+
+class fused_adam_scope:
+    def __init__(self, opt):
+        self.opt = opt if (opt is not None and opt.can_fuse()) else None
+
+    def __enter__(self):
+        self.prev, _FusedAdamScope.opt = _FusedAdamScope.opt, self.opt
+        return self
+
+    def __exit__(self, *exc):
+        _FusedAdamScope.opt = self.prev
+        return False
+
+
+def _fusable(g, weight, weight_grad):
+    """The layer keeps a persistent transformed-weight image that mg_conv_wgrad_adam_w refreshes."""
+    opt = getattr(weight, "_mg_opt", None)
+    return (opt is not None and weight_grad is True and weight.requires_grad and int(getattr(weight, "_mg_writes", 1)) == 1
+            and opt.can_fuse() and ops.wgrad_adam_ok(g))
+
+
+def _persistent_u(g, weight):
+    """U = G w G^T in a buffer that lives with the parameter: recomputed only when the weights changed behind its back."""
+    u = getattr(weight, "_mg_u_persist", None)
+    nbytes = ops.wino_weights_bytes(g)
+    if u is None or u.numel() * 4 != nbytes or u.device != weight.device:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        u = weight._mg_u_persist = torch.empty(nbytes // 4, dtype=torch.float32, device=weight.device)
+        weight._mg_u_ok = None
+    if weight._mg_u_ok != weight._version:
+        from . import _lib
+        _lib.check(_lib.load().mg_conv_wino_prepare(g, _lib.ptr(weight.detach()), _lib.ptr(u), _lib.stream()), "mg_conv_wino_prepare")
+        weight._mg_u_ok = weight._version
+    return u
+
+
+def _wgrad_fused(ctx_u, g, weight, x, gy, v, md):
+    """The fused call when the scope, the layer and the image allow it; returns False to fall back to the separate kernels."""
+    opt = _FusedAdamScope.opt
+    if opt is None or getattr(weight, "_mg_opt", None) is not opt or not getattr(weight, "_mg_fresh", True):
+        return False
+    u = getattr(weight, "_mg_u_persist", None)
+    if u is None or ctx_u is None or ctx_u.data_ptr() != u.data_ptr() or weight._mg_u_ok != weight._version:
+        return False
+    grp = opt.param_groups[0]
+    (b1, b2), eps = grp["betas"], grp["eps"]
+    opt.sync_lr()
+    ops.conv_wgrad_adam(g, x, gy, weight.detach(), weight._mg_m, weight._mg_v, u, opt.state, b1, b2, eps, opt.grad_scale, v=v, md=md)
+    return True        # (the gradient buffer stays "fresh": optimizer.step() skips this weight; u now matches the new weights)
+
+
+def _weight_image(g, weight, weight_grad=None):
     """Weight operand image of a training-step convolution: the Winograd transform / float16 copy made by
     ops.wino_weights, or -- for layers whose image is the plain float16 copy -- the slice of the optimiser's float16
     shadow arena (FusedAdam(half_shadow=True)), which the Adam kernel keeps current."""
+    if weight_grad is not None and _fusable(g, weight, weight_grad):
+        u = _persistent_u(g, weight)
+        if u is not None:
+            return u
     h = getattr(weight, "_mg_h", None)
     if h is not None and ops.weights_are_casts(g):
         if weight._version == weight._mg_h_version:
@@ -202,7 +270,7 @@ class _ConvFn(torch.autograd.Function):
             g = ops.conv_geom(B, H, W, Ci, Co, KH, KW, stride, pad, reflect, amp.current_precision())
             # Winograd layers: transform the weights once, reuse the image for the data gradient of this step
             if ctx.needs_input_grad[0]:
-                u = _weight_image(g, weight)
+                u = _weight_image(g, weight, weight_grad)
             elif x.is_cuda and not torch.is_grad_enabled():
                 # inference: once per weight version (a captured inference graph reads the images its warm-up made)
                 u = _cached_wino_weights(g, weight, fill=not torch.cuda.is_current_stream_capturing())
@@ -260,6 +328,7 @@ def _conv_backward(ctx, gy, x, y):
     w = weight.detach()
     dx = None
     md = None
+    u_used = getattr(ctx, "u", None)
     if want_dx:
         if not transposed:
             u = getattr(ctx, "u", None)
@@ -276,6 +345,15 @@ def _conv_backward(ctx, gy, x, y):
             dx = nchw_view(ops.conv_fwd(g, nhwc_view(gy), w, u=getattr(ctx, "u", None)))
             if last_use:
                 ctx.u = None
+    if want_dw and not transposed and rows is None and (bias is None or not bias.requires_grad or (
+            getattr(bias, "_mg_zero_grad", False) and not COMPUTE_DEAD_BIAS_GRADS)):
+        vv = getattr(ctx, "v", None) if (md is not None or ops.tiles_are_casts(g)) else None
+        if _wgrad_fused(u_used, g, weight, nhwc_view(x), nhwc_view(gy), vv, md):
+            if bias is not None and bias.requires_grad:
+                _zero_grad_bias(bias)
+                _notify(bias)
+            ctx.v = None
+            want_dw = False
     if want_dw:
         wbuf, wacc = grad_buffer(weight)
         bbuf = bacc = None
@@ -330,7 +408,7 @@ class _ConvInstNormFn(torch.autograd.Function):
         assert w.is_contiguous(memory_format=CL), "conv weights must be channels_last (OHWI) tensors"
         g = ops.conv_geom(B, H, W, w.shape[1], w.shape[0], w.shape[2], w.shape[3], 1, pad, reflect, amp.current_precision())
         if ctx.needs_input_grad[0]:
-            u = _weight_image(g, weight)
+            u = _weight_image(g, weight, weight_grad)
         elif x.is_cuda and not torch.is_grad_enabled():
             u = _cached_wino_weights(g, weight, fill=not torch.cuda.is_current_stream_capturing())
         else:
@@ -370,10 +448,11 @@ class _ConvInstNormFn(torch.autograd.Function):
             w = weight.detach()
             dx = nchw_view(ops.conv_dgrad(g, None, w, u=u, md_out=md,
                                           add=nhwc_view(skip_g) if skip_g is not None else None))
-            wbuf, wacc = grad_buffer(weight)
             if bias is not None and bias.requires_grad:
                 _zero_grad_bias(bias)
-            ops.conv_wgrad(g, None, None, wbuf, None, wacc, v=v, md=md)
+            if not _wgrad_fused(u, g, weight, None, None, v, md):
+                wbuf, wacc = grad_buffer(weight)
+                ops.conv_wgrad(g, None, None, wbuf, None, wacc, v=v, md=md)
             ctx.u = ctx.v = None
             _notify(weight)
             if bias is not None and bias.requires_grad:

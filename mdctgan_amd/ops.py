@@ -168,6 +168,34 @@ def conv_wgrad(g: ConvGeom, x, dy, dw, dbias=None, accumulate=False, v=None, md=
         PROFILER.end()
 
 
+def wgrad_adam_ok(g: ConvGeom) -> bool:
+    """True when the layer's weight gradient can run as mg_conv_wgrad_adam_w (Winograd F(2x2,3x3), float32)."""
+    key = ("wa", g.B, g.H, g.W, g.Ci, g.Co, g.KH, g.KW, g.stride, g.pad, g.reflect, g.precision)
+    hit = _CASTS.get(key)
+    if hit is None:
+        hit = _CASTS[key] = bool(_lib.load().mg_conv_wgrad_adam_ok(g))
+    return hit
+
+
+def conv_wgrad_adam(g: ConvGeom, x, dy, w, m, v_mom, u, state, beta1, beta2, eps, grad_scale, v=None, md=None):
+    """Weight gradient + Adam update of (w, m, v_mom) + refresh of the transformed weights u, in place (include/mdctgan_hip.h:
+    mg_conv_wgrad_adam_w).  x / dy may be None when both Winograd images (v, md) are handed over."""
+    lib = _lib.load()
+    ws = _ws(lib.mg_conv_wgrad_workspace(g), w.device)
+    ad = _lib.WinoAdam(_lib.ptr(m), _lib.ptr(v_mom), _lib.ptr(u), _lib.ptr(state), beta1, beta2, eps, grad_scale)
+    if PROFILER is not None:
+        PROFILER.begin(2, g)
+    _lib.check(lib.mg_conv_wgrad_adam_w(g, _lib.ptr(x), _lib.ptr(dy), _lib.ptr(w), ad, _lib.ptr(ws), ws.numel(), _lib.stream(),
+                                        _tiles(None, v, md)), "mg_conv_wgrad_adam_w")
+    if PROFILER is not None:
+        PROFILER.end()
+
+
+def adam_prime(state, beta1, beta2):
+    lib = _lib.load()
+    _lib.check(lib.mg_adam_prime(_lib.ptr(state), beta1, beta2, _lib.stream()), "mg_adam_prime")
+
+
 def colsum(a2d, out, accumulate=False):
     lib = _lib.load()
     M, Cc = a2d.shape

@@ -63,7 +63,10 @@ class FusedAdam(torch.optim.Optimizer):
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
         self.offsets, self.total = offs, total
         # device-resident clock {step, lr, step_size, sqrt(bias_correction2)}: keeps the step hipGraph-replayable
-        self.state = torch.zeros(4, dtype=torch.float64, device=dev)
+        # {step, lr, lr / (1 - b1^step), sqrt(1 - b2^step), 1 - b1^(step+1), sqrt(1 - b2^(step+1))}: the last two are the NEXT step's
+        # bias-correction terms, read by the kernels that update weights during backward (functional.fused_adam_scope)
+        self.state = torch.zeros(6, dtype=torch.float64, device=dev)
+        ops.adam_prime(self.state, *self.param_groups[0]["betas"])
         self._lr_on_device = None
         with torch.no_grad():
             for p, off in zip(ps, offs):
@@ -78,6 +81,9 @@ class FusedAdam(torch.optim.Optimizer):
                     fresh = True
                 p.grad = gview
                 p._mg_fresh = fresh
+                n = p.numel()
+                # for the layers whose weight gradient, Adam update and weight transform run as one kernel (mg_conv_wgrad_adam_w)
+                p._mg_opt, p._mg_m, p._mg_v, p._mg_u_ok = self, self.flat_m[off:off + n], self.flat_v[off:off + n], None
             if self.half_shadow:
                 self.flat_h = self.flat_p.to(torch.float16)
                 for p, off in zip(ps, offs):
@@ -94,6 +100,14 @@ class FusedAdam(torch.optim.Optimizer):
         parameters' version counters, so functional._weight_image would keep serving the pre-write shadow."""
         if self.flat_h is not None:
             self.flat_h.copy_(self.flat_p)
+
+    def can_fuse(self):
+        """Weight-side fusion (gradient inverse transform + Adam + next forward transform in the weight-gradient call of the
+        Winograd trunk layers) is valid for a single process in float32: no gradient reduction has to see the gradient, no
+        GradScaler has to inspect it.  MG_NO_WINO_ADAM_FUSION=1 turns it off."""
+        import os
+        return (self._built and not self.half_shadow and self.pre_step_hook is None and self.shard is None
+                and os.environ.get("MG_NO_WINO_ADAM_FUSION", "0") != "1")
 
     def arena_slices(self):
         """[(param, offset, padded_numel)] in arena order (used by the data-parallel reducer)."""
@@ -141,8 +155,17 @@ class FusedAdam(torch.optim.Optimizer):
         self.sync_lr()                        # schedule change (update_learning_rate): refresh the device copy
         # contiguous runs of parameters that received a gradient this step (normally a single run = everything)
         runs, start = [], None
+        fuse = self.can_fuse()
         for i, p in enumerate(self._params):
             has = (p.grad is not None) and not getattr(p, "_mg_fresh", False)
+            if has and fuse and getattr(p, "_mg_known_zero", False) and getattr(p, "_mg_never_stepped", True):
+                # a bias whose gradient is identically zero (it feeds an InstanceNorm) and whose moments are still zero: Adam
+                # leaves it where it is (m = v = 0 -> the update is lr * 0 / (0 + eps)), so the launch is skipped -- exactly;
+                # keeps the arena's runs long now that the big weights between such biases are updated during backward
+                has = False
+            elif has:
+                p._mg_never_stepped = False
+                p._mg_u_ok = None          # rewritten through the arena: a transformed-weight image kept for it is stale
             if has and start is None:
                 start = i
             if not has and start is not None:

@@ -431,7 +431,7 @@ class Pix2PixHDModel(BaseModel):
         g_kw = dict(retain_graph=True) if rows else {}
         d_kw = dict(inputs=[p for p in self.netD.parameters() if p.requires_grad]) if rows else {}
         self.optimizer_G.zero_grad()
-        with Fh.backward_pass("G" if rows else None, rows):
+        with Fh.backward_pass("G" if rows else None, rows), Fh.fused_adam_scope(self.optimizer_G if sc is None and not red else None):
             if sc is not None:
                 sc.scale(loss_G).backward(**g_kw)
                 sc.step(self.optimizer_G)

@@ -732,3 +732,64 @@ def test_image_pool_step():
     assert pooled.fake_pool.num_imgs == 2 and len(pooled.fake_pool.images) == 2
     for k, p in pooled.netD.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
+
+
+def test_weight_side_fusion_is_bit_identical(golden, monkeypatch):
+    """mg_conv_wgrad_adam_w (csrc/wino.h::wino_adam_kernel): for the Winograd trunk layers the weight gradient's inverse
+    transform, the Adam update and the next iteration's weight transform are one kernel inside loss_G.backward(); the gradient
+    never reaches the arena.  Five iterations (the persistent U images are used from the second on) must leave G and D bit
+    for bit where the three separate kernels leave them (MG_NO_WINO_ADAM_FUSION=1), eagerly and as a hipGraph replay, and a
+    learning-rate change must reach the fused kernels through the device clock."""
+    g = golden("g6_step_global")
+    lr, hr = torch.from_numpy(g["lr"]).to(DEV), torch.from_numpy(g["hr"]).to(DEV)
+
+    def build():
+        from mdctgan_amd import options
+        from mdctgan_amd.pix2pixHD_model import create_model
+        opt = options.make_opt(*options.SPECTRAL_FLAGS, "--lr_sampling_rate", "12000", "--netG", "global", "--ngf", "8",
+                               "--n_blocks_global", "2", "--n_blocks_attn_g", "0", "--num_D", "2", "--ndf", "8", "--batchSize", "2",
+                               "--bins", "32", "--segment_length", "7936", "--gpu_ids", "0", "--niter_decay", "10")
+        m = create_model(opt)
+        onets.fill_deterministic(m.netG)
+        onets.fill_deterministic(m.netD)
+        return m
+
+    snaps = {}
+
+    def run(m, graphed):
+        step = m.make_graphed_step(lr, hr, warmup=2) if graphed else (lambda: m.optimize_parameters(lr, hr))
+        for it in range(2 if graphed else 0, 5):         # five iterations; the first two of the graphed model are its warm-up
+            if it == 3:
+                m.update_learning_rate()
+                # (the optimiser's arena is built by the first zero_grad(): iteration 0 still ran the separate kernels)
+                snaps[id(m)] = [p.grad.clone() for k, p in m.netG.named_parameters() if "conv_block" in k and k.endswith("weight")]
+            step()
+        torch.cuda.synchronize()
+        return m
+
+    monkeypatch.setenv("MG_NO_WINO_ADAM_FUSION", "1")
+    plain = run(build(), False)
+    trunk = [p for k, p in plain.netG.named_parameters() if "conv_block" in k and k.endswith("weight")]
+    assert trunk and all(getattr(p, "_mg_u_persist", None) is None for p in trunk)
+    monkeypatch.delenv("MG_NO_WINO_ADAM_FUSION")
+    fused = run(build(), False)
+    ftrunk = [p for k, p in fused.netG.named_parameters() if "conv_block" in k and k.endswith("weight")]
+    assert all(getattr(p, "_mg_u_persist", None) is not None for p in ftrunk), "the trunk layers did not take the fused path"
+    # a fused layer's gradient never reaches the arena: its buffer still holds iteration 0's values; the separate kernels rewrote it
+    assert all(torch.equal(p.grad, s0) for p, s0 in zip(ftrunk, snaps[id(fused)]))
+    assert not any(torch.equal(p.grad, s0) for p, s0 in zip(trunk, snaps[id(plain)]))
+    for (k, a), (_, b) in zip(plain.netG.state_dict().items(), fused.netG.state_dict().items()):
+        assert torch.equal(a, b), k
+    for (k, a), (_, b) in zip(plain.netD.state_dict().items(), fused.netD.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert torch.equal(plain.optimizer_G.flat_m, fused.optimizer_G.flat_m) and torch.equal(plain.optimizer_G.flat_v, fused.optimizer_G.flat_v)
+    # the refreshed image is the transform of the updated weights
+    from mdctgan_amd import ops
+    p0 = ftrunk[0]
+    gq = ops.conv_geom(2, 2, 16, p0.shape[1], p0.shape[0], 3, 3, 1, 1, True)
+    assert torch.equal(p0._mg_u_persist, ops.wino_weights(gq, p0.detach()))
+    # ... and the captured step carries the fused kernels
+    graphed = run(build(), True)
+    for (k, a), (_, b) in zip(plain.netG.state_dict().items(), graphed.netG.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert torch.equal(fused.inference(lr)[0], plain.inference(lr)[0])
