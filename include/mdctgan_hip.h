@@ -334,6 +334,14 @@ int mg_mse_const_fwd(const float* pred, long long n, float target, float scale, 
                      void* workspace, void* stream);
 int mg_mse_const_bwd(const float* pred, long long n, float target, float scale, const float* grad_out, float* grad,
                      void* stream);
+/* --no_lsgan (networks.py:106-109, 676-677): nn.BCELoss against a constant label on probabilities (log terms clamped at -100,
+ * gradient (p - t) / max((1 - p) p, 1e-12) -- torch's rules), and the nn.Sigmoid that produces them. */
+int mg_bce_const_fwd(const float* pred, long long n, float target, float scale, float* loss, int accumulate,
+                     void* workspace, void* stream);
+int mg_bce_const_bwd(const float* pred, long long n, float target, float scale, const float* grad_out, float* grad,
+                     void* stream);
+int mg_sigmoid_fwd(const float* x, float* y, long long n, void* stream);
+int mg_sigmoid_bwd(const float* dy, const float* y, float* dx, long long n, void* stream);
 int mg_l1_fwd(const float* a, const float* b, long long n, float scale, float* loss, int accumulate, void* workspace,
               void* stream);
 int mg_l1_bwd(const float* a, const float* b, long long n, float scale, const float* grad_out, float* grad_a,
@@ -345,8 +353,8 @@ int mg_l1_bwd(const float* a, const float* b, long long n, float scale, const fl
 int mg_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                  float eps, int step, float grad_scale, void* stream);
 
-/* hipGraph-replayable variant: the optimiser clock lives in HBM.  state = double[4] {step, lr, lr/(1-beta1^step),
- * sqrt(1-beta2^step)}; mg_adam_tick advances it on the device (host writes state[1] = lr when the schedule
+/* hipGraph-replayable variant: the optimiser clock lives in HBM.  state = double[6] {step, lr, lr/(1-beta1^step),
+ * sqrt(1-beta2^step), 1-beta1^(step+1), sqrt(1-beta2^(step+1))}; mg_adam_tick advances it on the device (host writes state[1] = lr when the schedule
  * changes), mg_adam_step_dev reads it -- no step-dependent value is baked into a kernel argument. */
 int mg_adam_tick(double* state, float beta1, float beta2, void* stream);
 /* state[4] = 1 - beta1^(step+1), state[5] = sqrt(1 - beta2^(step+1)) for the clock as it stands (a fresh or restored clock; every

@@ -118,6 +118,10 @@ SIGNATURES = {
     "mg_loss_workspace": (_sz, []),
     "mg_mse_const_fwd": (_i, [_p, _ll, _f, _f, _p, _i, _p, _p]),
     "mg_mse_const_bwd": (_i, [_p, _ll, _f, _f, _p, _p, _p]),
+    "mg_bce_const_fwd": (_i, [_p, _ll, _f, _f, _p, _i, _p, _p]),
+    "mg_bce_const_bwd": (_i, [_p, _ll, _f, _f, _p, _p, _p]),
+    "mg_sigmoid_fwd": (_i, [_p, _p, _ll, _p]),
+    "mg_sigmoid_bwd": (_i, [_p, _p, _p, _ll, _p]),
     "mg_l1_fwd": (_i, [_p, _p, _ll, _f, _p, _i, _p, _p]),
     "mg_l1_bwd": (_i, [_p, _p, _ll, _f, _p, _p, _p]),
     "mg_adam_step": (_i, [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _f, _p]),

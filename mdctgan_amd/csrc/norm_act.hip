@@ -368,6 +368,15 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         dx[i] = dy[i] * act_grad_post(y[i], act);
 }
+// nn.Sigmoid (the PatchGAN output under --no_lsgan, networks.py:676-677): y = 1 / (1 + exp(-x)); backward dx = dy y (1 - y)
+__global__ void sigmoid_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = 1.0f / (1.0f + expf(-x[i]));
+}
+__global__ void sigmoid_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dx[i] = dy[i] * (y[i] * (1.0f - y[i]));
+}
 __global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         o[i] = a[i] + b[i];
@@ -491,6 +500,11 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restri
     __shared__ double red[4];
     double s = 0.0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (KIND == 2) {      // nn.BCELoss against a constant label: log terms clamped at -100 like torch's
+            const float pv = a[i];
+            s += (double)((target - 1.0f) * fmaxf(logf(1.0f - pv), -100.0f) - target * fmaxf(logf(pv), -100.0f));
+            continue;
+        }
         const float d = a[i] - (KIND == 0 ? target : b[i]);
         s += (KIND == 0) ? (double)d * (double)d : (double)fabsf(d);
     }
@@ -515,6 +529,11 @@ __global__ void loss_grad_kernel(const float* __restrict__ a, const float* __res
                                  float coef, const float* __restrict__ go, float* __restrict__ grad) {
     const float gsc = coef * (go ? go[0] : 1.0f);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (KIND == 2) {      // binary_cross_entropy_backward: (p - t) / max((1 - p) p, 1e-12)
+            const float pv = a[i];
+            grad[i] = (pv - target) / fmaxf((1.0f - pv) * pv, 1e-12f) * gsc;
+            continue;
+        }
         const float d = a[i] - (KIND == 0 ? target : b[i]);
         if (KIND == 0) grad[i] = 2.0f * d * gsc;
         else grad[i] = (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * gsc;
@@ -822,6 +841,39 @@ int mg_mse_const_bwd(const float* pred, long long n, float target, float scale, 
     if (!pred || !grad || n <= 0) return MG_ERR_ARG;
     hipLaunchKernelGGL(loss_grad_kernel<0>, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, pred, nullptr,
                        target, (size_t)n, scale / (float)n, grad_out, grad);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+int mg_bce_const_fwd(const float* pred, long long n, float target, float scale, float* loss, int accumulate,
+                     void* workspace, void* stream) {
+    if (!pred || !loss || !workspace || n <= 0) return MG_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    size_t nb = ((size_t)n + 1023) / 1024;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(loss_partial_kernel<2>, dim3((unsigned)nb), dim3(256), 0, st, pred, nullptr, target, (size_t)n,
+                       (double*)workspace);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, (int)nb, 1.0 / (double)n,
+                       scale, loss, accumulate);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+int mg_bce_const_bwd(const float* pred, long long n, float target, float scale, const float* grad_out, float* grad,
+                     void* stream) {
+    if (!pred || !grad || n <= 0) return MG_ERR_ARG;
+    hipLaunchKernelGGL(loss_grad_kernel<2>, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, pred, nullptr,
+                       target, (size_t)n, scale / (float)n, grad_out, grad);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+int mg_sigmoid_fwd(const float* x, float* y, long long n, void* stream) {
+    if (!x || !y || n <= 0) return MG_ERR_ARG;
+    hipLaunchKernelGGL(sigmoid_fwd_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, x, y, (size_t)n);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+int mg_sigmoid_bwd(const float* dy, const float* y, float* dx, long long n, void* stream) {
+    if (!dy || !y || !dx || n <= 0) return MG_ERR_ARG;
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, (size_t)n);
     MG_CHECK_LAUNCH();
     return MG_OK;
 }

@@ -973,6 +973,61 @@ def mse_const_pair_loss_sum(preds, target_first: float, target_second: float):
     return _MseConstPairSumFn.apply(float(target_first), float(target_second), *preds)
 
 
+class _BceConstFn(torch.autograd.Function):
+    """scale * nn.BCELoss()(pred, full_like(pred, target)) (networks.py:106-109 with use_lsgan=False)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, scale):
+        from . import _lib
+        pred = pred.contiguous(memory_format=CL) if pred.dim() == 4 else pred.contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        lib = _lib.load()
+        ws = _lib.workspace(lib.mg_loss_workspace(), pred.device)
+        _lib.check(lib.mg_bce_const_fwd(_lib.ptr(pred), pred.numel(), target, scale, _lib.ptr(loss), 0, _lib.ptr(ws), _lib.stream()),
+                   "mg_bce_const_fwd")
+        ctx.target, ctx.scale = target, scale
+        ctx.save_for_backward(pred)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, go):
+        from . import _lib
+        (pred,) = ctx.saved_tensors
+        go = go.reshape(1).float().contiguous()
+        g = torch.empty_like(pred)
+        _lib.check(_lib.load().mg_bce_const_bwd(_lib.ptr(pred), pred.numel(), ctx.target, ctx.scale, _lib.ptr(go), _lib.ptr(g),
+                                                _lib.stream()), "mg_bce_const_bwd")
+        return g, None, None
+
+
+def bce_const_loss(pred, target: float, scale: float = 1.0):
+    return _BceConstFn.apply(pred, float(target), float(scale))
+
+
+class _SigmoidFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        from . import _lib
+        x = to_cl(x) if x.dim() == 4 else x.contiguous()
+        y = torch.empty_like(x)
+        _lib.check(_lib.load().mg_sigmoid_fwd(_lib.ptr(x), _lib.ptr(y), x.numel(), _lib.stream()), "mg_sigmoid_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import _lib
+        (y,) = ctx.saved_tensors
+        gy = gy.contiguous(memory_format=CL) if gy.dim() == 4 else gy.contiguous()
+        dx = torch.empty_like(y)
+        _lib.check(_lib.load().mg_sigmoid_bwd(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(dx), y.numel(), _lib.stream()), "mg_sigmoid_bwd")
+        return dx
+
+
+def sigmoid(x):
+    return _SigmoidFn.apply(x)
+
+
 def mse_const_loss(pred, target: float, scale: float = 1.0):
     """scale * mean((pred - target)^2)  == nn.MSELoss()(pred, full_like(pred, target)) * scale."""
     return _MseConstFn.apply(pred, float(target), float(scale))

@@ -131,6 +131,8 @@ class FusedSequence:
                 self.steps.append(("module", m))
             elif isinstance(m, nn.Sequential):
                 self.steps.append(("seq", FusedSequence(m)))
+            elif isinstance(m, nn.Sigmoid):
+                self.steps.append(("sigmoid",))
             else:
                 raise NotImplementedError("no HIP lowering for layer %s in this position" % m.__class__.__name__)
 
@@ -155,6 +157,8 @@ class FusedSequence:
                     raise NotImplementedError("activation directly after %s" % m.__class__.__name__)
             if norm:
                 x = Fh.instance_norm_act(x, act, None, eps)
+        elif st[0] == "sigmoid":
+            x = Fh.sigmoid(x)
         elif st[0] == "module":
             x = st[1](x, weight_grad=weight_grad)
         else:
@@ -500,8 +504,6 @@ class NLayerDiscriminator(nn.Module):
 
     def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=None, use_sigmoid=False, getIntermFeat=False):
         super().__init__()
-        if use_sigmoid:
-            raise NotImplementedError("--no_lsgan (sigmoid + BCE) is outside the hot path")
         norm_layer = norm_layer or get_norm_layer("instance")
         self.getIntermFeat, self.n_layers = getIntermFeat, n_layers
         kw, padw = 4, int(np.ceil((4 - 1.0) / 2))
@@ -515,6 +517,10 @@ class NLayerDiscriminator(nn.Module):
         sequence += [[Conv2d(nf_prev, nf, kernel_size=kw, stride=1, padding=padw), norm_layer(nf),
                       nn.LeakyReLU(0.2, True)]]
         sequence += [[Conv2d(nf, 1, kernel_size=kw, stride=1, padding=padw)]]
+        if use_sigmoid:
+            # networks.py:676-677.  With getIntermFeat the reference's forward walks model0 .. model{n_layers + 1} only
+            # (:684-689): the Sigmoid module exists but is never applied -- mirrored as written.
+            sequence += [[nn.Sigmoid()]]
         if getIntermFeat:
             for n in range(len(sequence)):
                 setattr(self, "model" + str(n), nn.Sequential(*sequence[n]))
@@ -592,19 +598,19 @@ def define_D(input_nc, ndf, n_layers_D, norm="instance", use_sigmoid=False, num_
 # Losses
 ###############################################################################
 class GANLoss(nn.Module):
-    """networks.py:97-137 with use_lsgan=True: sum over scales of mean((pred[-1] - label)^2)."""
+    """networks.py:97-137: sum over scales of mean((pred[-1] - label)^2) (LSGAN) or of BCE(pred[-1], label) (--no_lsgan)."""
 
     def __init__(self, use_lsgan=True, target_real_label=1.0, target_fake_label=0.0, device="cuda"):
         super().__init__()
-        if not use_lsgan:
-            raise NotImplementedError("--no_lsgan (BCE) is outside the hot path")
+        self.use_lsgan = bool(use_lsgan)
         self.real_label, self.fake_label, self.device = target_real_label, target_fake_label, device
 
     def __call__(self, input, target_is_real):
         label = self.real_label if target_is_real else self.fake_label
+        one = Fh.mse_const_loss if self.use_lsgan else Fh.bce_const_loss       # nn.MSELoss / nn.BCELoss (networks.py:106-109)
         if isinstance(input[0], list):
             loss = 0
             for input_i in input:
-                loss = loss + Fh.mse_const_loss(input_i[-1], label)
+                loss = loss + one(input_i[-1], label)
             return loss
-        return Fh.mse_const_loss(input[-1], label)
+        return one(input[-1], label)

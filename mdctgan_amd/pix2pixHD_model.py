@@ -293,9 +293,11 @@ class Pix2PixHDModel(BaseModel):
             proj_factor_l=opt.proj_factor_l, heads_l=opt.heads_l, dim_head_l=opt.dim_head_l)
         self.netG.set_freeze(opt.freeze_g_d, opt.freeze_g_u, opt.freeze_l_d, opt.freeze_l_u)
         if self.isTrain:
-            if opt.no_lsgan:
-                raise NotImplementedError("--no_lsgan is outside the HIP hot path")
-            self.netD = networks.define_D(input_nc + opt.output_nc, opt.ndf, opt.n_layers_D, opt.norm, False,
+            if opt.no_lsgan and not opt.no_ganFeat_loss:
+                # with feature matching on, NLayerDiscriminator.forward never applies its Sigmoid (networks.py:684-689) and
+                # nn.BCELoss rejects the logits ("all elements of input should be between 0 and 1"): the reference stops here too
+                raise NotImplementedError("--no_lsgan needs --no_ganFeat_loss (the reference's BCELoss would be fed logits)")
+            self.netD = networks.define_D(input_nc + opt.output_nc, opt.ndf, opt.n_layers_D, opt.norm, bool(opt.no_lsgan),
                                           opt.num_D, not opt.no_ganFeat_loss, gpu_ids=self.gpu_ids)
         if not self.isTrain or opt.continue_train or opt.load_pretrain:
             self.load_network(self.netG, "G", opt.which_epoch, opt.load_pretrain)
@@ -306,7 +308,7 @@ class Pix2PixHDModel(BaseModel):
             self.fake_pool = ImagePool(opt.pool_size)          # pix2pixHD_model.py:294-298 (default 0: no history)
             self.old_lr = opt.lr
             self.limit_aux_loss = False
-            self.criterionGAN = networks.GANLoss(use_lsgan=True, device=self.device)
+            self.criterionGAN = networks.GANLoss(use_lsgan=not opt.no_lsgan, device=self.device)
             self.loss_names = ["G_GAN"] + ([] if opt.no_ganFeat_loss else ["G_GAN_Feat"]) + ["D_real", "D_fake"]
             if opt.niter_fix_global > 0:
                 params = [v for k, v in self.netG.named_parameters()
@@ -363,7 +365,8 @@ class Pix2PixHDModel(BaseModel):
         keeps its own discriminator pass and plain loss.backward() calls work as in train.py."""
         sr_spectro, _, hr_spectro, _, hr_norm_param, lr_spectro, _, lr_norm_param = self.forward(lr_audio, hr_audio)
         pooled = self.isTrain and getattr(self.opt, "pool_size", 0) > 0     # the fake pass of the D loss sees the history
-        stacked = self.stack_d_loss_passes and self.abs_spectro and self.arcsinh_transform and not pooled
+        stacked = (self.stack_d_loss_passes and self.abs_spectro and self.arcsinh_transform and not pooled
+                   and not self.no_lsgan and not self.no_ganFeat_loss)      # the stacked-pass loss kernels are the LSGAN + feature ones
         shared = (share_d_pass and stacked and self.share_d_fake_pass and self.skip_discarded_d_grads
                   and torch.is_grad_enabled() and sr_spectro.requires_grad)
         self._shared_rows = 0

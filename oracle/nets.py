@@ -223,9 +223,11 @@ class LocalEnhancerRef(nn.Module):
 class MultiscaleDRef(nn.Module):
     """num_D PatchGANs with getIntermFeat=True (networks.py:507-550, 641-692)."""
 
-    def __init__(self, input_nc, ndf=64, n_layers=3, num_D=3):
+    def __init__(self, input_nc, ndf=64, n_layers=3, num_D=3, use_sigmoid=False, interm=True):
+        """interm=False (--no_ganFeat_loss): one nn.Sequential per scale, `layer{i}`, Sigmoid included when use_sigmoid
+        (--no_lsgan); with interm=True the reference never applies the Sigmoid (networks.py:684-689) -- neither does this."""
         super().__init__()
-        self.num_D, self.n_layers = num_D, n_layers
+        self.num_D, self.n_layers, self.interm = num_D, n_layers, interm
         for i in range(num_D):
             stages = [nn.Sequential(nn.Conv2d(input_nc, ndf, 4, 2, 2), nn.LeakyReLU(0.2))]
             nf = ndf
@@ -235,6 +237,10 @@ class MultiscaleDRef(nn.Module):
             prev, nf = nf, min(nf * 2, 512)
             stages.append(nn.Sequential(nn.Conv2d(prev, nf, 4, 1, 2), _inorm(nf), nn.LeakyReLU(0.2)))
             stages.append(nn.Sequential(nn.Conv2d(nf, 1, 4, 1, 2)))
+            if not interm:
+                flat = [m for st in stages for m in st] + ([nn.Sigmoid()] if use_sigmoid else [])
+                setattr(self, "layer%d" % i, nn.Sequential(*flat))
+                continue
             for j, s in enumerate(stages):
                 setattr(self, "scale%d_layer%d" % (i, j), s)
         self.downsample = nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False)
@@ -242,6 +248,11 @@ class MultiscaleDRef(nn.Module):
     def forward(self, x):
         result = []
         for i in range(self.num_D):
+            if not self.interm:
+                result.append([getattr(self, "layer%d" % (self.num_D - 1 - i))(x)])
+                if i != self.num_D - 1:
+                    x = self.downsample(x)
+                continue
             feats, h = [], x
             for j in range(self.n_layers + 2):
                 h = getattr(self, "scale%d_layer%d" % (self.num_D - 1 - i, j))(h)
@@ -306,6 +317,12 @@ def fill_deterministic(net, scale=0.02):
 
 
 # ---------------------------------------------------------------- losses
+def bce_gan_loss(preds, target_is_real: bool):
+    """GANLoss(use_lsgan=False): sum over scales of BCELoss(pred[-1], const) (networks.py:106-109)."""
+    t = 1.0 if target_is_real else 0.0
+    return sum(F.binary_cross_entropy(p[-1], torch.full_like(p[-1], t)) for p in preds)
+
+
 def lsgan_loss(preds, target_is_real: bool):
     """GANLoss(use_lsgan=True): sum over scales of mse(pred[-1], const)."""
     t = 1.0 if target_is_real else 0.0

@@ -35,7 +35,9 @@ class CodecCfg:
 
 class HotPathRef:
     def __init__(self, netG, netD, cfg: CodecCfg, n_layers_D=3, num_D=2, lambda_feat=10.0, lr=2e-4, beta1=0.5,
-                 dtype=torch.float32):
+                 dtype=torch.float32, use_lsgan=True, feat_loss=True):
+        self.gan_loss = nets.lsgan_loss if use_lsgan else nets.bce_gan_loss       # --no_lsgan
+        self.feat_loss = feat_loss                                                # --no_ganFeat_loss
         self.netG, self.netD, self.cfg = netG.to(dtype), (netD.to(dtype) if netD is not None else None), cfg
         self.n_layers_D, self.num_D, self.lambda_feat, self.dtype = n_layers_D, num_D, lambda_feat, dtype
         if netD is not None:
@@ -62,13 +64,14 @@ class HotPathRef:
             sr_s = sr_s + lr_s
         sr_in, hr_in = self.two_channel(sr_s), self.two_channel(hr_s)
         pred_fake_pool = self.netD(torch.cat((lr_s, sr_in.detach()), dim=1))
-        loss_D_fake = nets.lsgan_loss(pred_fake_pool, False)
+        loss_D_fake = self.gan_loss(pred_fake_pool, False)
         pred_real = self.netD(torch.cat((lr_s, hr_in), dim=1))
-        loss_D_real = nets.lsgan_loss(pred_real, True)
+        loss_D_real = self.gan_loss(pred_real, True)
         pred_fake = self.netD(torch.cat((lr_s, sr_in), dim=1))
-        loss_G_GAN = nets.lsgan_loss(pred_fake, True)
-        loss_G_feat = nets.feature_matching_loss(pred_fake, pred_real, self.n_layers_D, self.num_D, self.lambda_feat)
-        losses = {"G_GAN": loss_G_GAN, "G_GAN_Feat": loss_G_feat, "D_real": loss_D_real, "D_fake": loss_D_fake}
+        loss_G_GAN = self.gan_loss(pred_fake, True)
+        losses = {"G_GAN": loss_G_GAN, "D_real": loss_D_real, "D_fake": loss_D_fake}
+        if self.feat_loss:
+            losses["G_GAN_Feat"] = nets.feature_matching_loss(pred_fake, pred_real, self.n_layers_D, self.num_D, self.lambda_feat)
         return losses, sr_s
 
     def train_step(self, lr_audio, hr_audio, amp=False, scaler=None):
@@ -82,7 +85,7 @@ class HotPathRef:
         else:
             losses, _ = self.forward_losses(lr_audio, hr_audio)
         loss_D = (losses["D_fake"] + losses["D_real"]) * 0.5
-        loss_G = losses["G_GAN"] + losses["G_GAN_Feat"]
+        loss_G = losses["G_GAN"] + losses.get("G_GAN_Feat", 0)
         self.opt_G.zero_grad()
         if amp:
             scaler.scale(loss_G).backward()

@@ -79,8 +79,9 @@ def test_unsupported_configs_fail_loudly():
         networks.define_G(2, 1, 8, "global", 1, 2, n_attn_g=1, input_size=(32, 64))
     with pytest.raises(NotImplementedError):
         networks.get_norm_layer("batch")
-    with pytest.raises(NotImplementedError):
-        networks.GANLoss(use_lsgan=False)
+    assert networks.GANLoss(use_lsgan=False).use_lsgan is False        # (BCE is built since round 3; needs --no_ganFeat_loss, see
+    with pytest.raises(NotImplementedError):                            #  tests/test_nets_gpu.py::test_no_lsgan_step_against_oracle)
+        networks.define_G(2, 1, 8, "local", 3, 2, 2, 1, input_size=(64, 256), n_attn_g=0)      # n_local_enhancers = 2: a shape error in the reference
     net = build_g("global")
     from mdctgan_amd import _lib
     with pytest.raises(_lib.HipLibraryError):

@@ -55,10 +55,10 @@ def judged(got, f32, f64, what, k=4.0):
     # floor 5e-4: one mask flip in either float32 run already costs ~1e-4 (the op-level tests in test_conv_gpu /
     # test_elementwise_gpu hold the tight 3e-5 bars; this test guards the wiring, where a bug costs O(1))
     assert e_hip <= max(k * e_32, 5e-4) + 2e-6, "%s: HIP rel-L2 err %.3e vs fp32-CPU %.3e" % (what, e_hip, e_32)
-    # localised-garbage guard: 2 % of the tensor's scale, or 4x float32-CPU's own worst element where that is larger (a
+    # localised-garbage guard: 2 % of the tensor's scale, or 1.5 k x float32-CPU's own worst element where that is larger (a
     # ReLU-mask flip behind a 2048-channel reduction moves single elements by more than 2 % in ANY float32 run)
     worst, worst32 = np.abs(got - f64).max(), np.abs(f32 - f64).max()
-    assert worst <= max(2e-2 * max(np.abs(f64).max(), 1e-30), 4.0 * worst32), "%s: max-abs %.3e (fp32-CPU %.3e)" % (what, worst, worst32)
+    assert worst <= max(2e-2 * max(np.abs(f64).max(), 1e-30), 1.5 * k * worst32), "%s: max-abs %.3e (fp32-CPU %.3e)" % (what, worst, worst32)
 
 
 @pytest.mark.parametrize("tag", list(CFGS))
@@ -793,3 +793,51 @@ def test_weight_side_fusion_is_bit_identical(golden, monkeypatch):
     for (k, a), (_, b) in zip(plain.netG.state_dict().items(), graphed.netG.state_dict().items()):
         assert torch.equal(a, b), k
     assert torch.equal(fused.inference(lr)[0], plain.inference(lr)[0])
+
+
+def test_no_lsgan_step_against_oracle():
+    """--no_lsgan --no_ganFeat_loss (networks.py:106-109 BCELoss, :676-677 Sigmoid; the only form in which the reference's
+    BCE branch runs -- with feature matching on, its discriminator forward never applies the Sigmoid and BCELoss rejects the
+    logits, which create_model reports as NotImplementedError): the sigmoid / BCE kernels op by op against float64, then the
+    three losses of one iteration against the oracle and a finite optimisation step with every gradient in place."""
+    from mdctgan_amd import functional as Fh
+    from mdctgan_amd import options
+    from mdctgan_amd.pix2pixHD_model import create_model
+    gen = torch.Generator().manual_seed(12)
+    z = (3.0 * torch.randn(2, 1, 9, 17, generator=gen)).to(DEV).requires_grad_()
+    for label in (0.0, 1.0):
+        z.grad = None
+        loss = Fh.bce_const_loss(Fh.sigmoid(z), label)
+        loss.backward()
+        z64 = z.detach().double().cpu().requires_grad_()
+        l64 = torch.nn.functional.binary_cross_entropy(torch.sigmoid(z64), torch.full_like(z64, label))
+        l64.backward()
+        assert abs(loss.item() - l64.item()) <= 1e-6 * abs(l64.item())
+        assert (z.grad.double().cpu() - z64.grad).abs().max().item() <= 1e-6 * z64.grad.abs().max().item()
+    sat = torch.tensor([[[[40.0, -40.0, 120.0]]]], device=DEV)          # saturated probabilities: the -100 clamp of BCELoss
+    want = torch.nn.functional.binary_cross_entropy(torch.sigmoid(sat.cpu()), torch.zeros(1, 1, 1, 3))
+    assert abs(Fh.bce_const_loss(Fh.sigmoid(sat), 0.0).item() - want.item()) <= 1e-5 * want.item()
+    flags = [*options.SPECTRAL_FLAGS, "--lr_sampling_rate", "12000", "--netG", "global", "--ngf", "4", "--n_blocks_global", "2",
+             "--n_blocks_attn_g", "0", "--num_D", "2", "--ndf", "8", "--batchSize", "2", "--bins", "32", "--segment_length", "7936",
+             "--gpu_ids", "0", "--no_lsgan"]
+    with pytest.raises(NotImplementedError):
+        create_model(options.make_opt(*flags))
+    model = create_model(options.make_opt(*flags, "--no_ganFeat_loss"))
+    onets.fill_deterministic(model.netG)
+    onets.fill_deterministic(model.netD)
+    assert model.loss_names == ["G_GAN", "D_real", "D_fake"]
+    netG = onets.fill_deterministic(onets.build_generator("global", 2, 1, 4, 4, 2, input_size=(32, 256)))
+    netD = onets.fill_deterministic(onets.MultiscaleDRef(3, ndf=8, n_layers=3, num_D=2, use_sigmoid=True, interm=False))
+    assert list(netD.state_dict().keys()) == list(model.netD.state_dict().keys())
+    ref = ostep.HotPathRef(netG, netD, ostep.CodecCfg(), num_D=2, use_lsgan=False, feat_loss=False)
+    g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "g6_step_global.npz"))
+    lo, _ = ref.forward_losses(g["lr"], g["hr"])
+    lr, hr = torch.from_numpy(g["lr"]).to(DEV), torch.from_numpy(g["hr"]).to(DEV)
+    lh, _ = model._forward(lr, hr)
+    for k, v in zip(model.loss_names, lh):
+        assert abs(v.item() - float(lo[k])) <= 0.02 * abs(float(lo[k])) + 1e-4, (k, v.item(), float(lo[k]))
+    ld = model.optimize_parameters(lr, hr)
+    assert model._shared_rows == 0 and all(np.isfinite(v.item()) for v in ld.values())
+    for net in (model.netG, model.netD):
+        for k, p in net.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
