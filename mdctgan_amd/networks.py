@@ -403,7 +403,9 @@ class LocalEnhancer(FusedModule):
                  heads_g=4, dim_head_g=128, proj_factor_l=4, heads_l=4, dim_head_l=128):
         super().__init__()
         if n_local_enhancers != 1:
-            raise NotImplementedError("HIP LocalEnhancer: n_local_enhancers == 1")
+            # the reference builds ONE enhancer whatever the count, pools the global branch's input 2^n-fold and then adds an
+            # H/2 map to an H/2^n map (networks.py:177-211, 256-266): a shape error at n = 2 -- nothing to mirror
+            raise NotImplementedError("n_local_enhancers != 1 does not run in the reference either (networks.py:256-266)")
         norm_layer = norm_layer or get_norm_layer("instance")
         self.n_local_enhancers = n_local_enhancers
         ngf_global = ngf * (2 ** n_local_enhancers)

@@ -27,3 +27,18 @@ python bench.py --config 2 --steps 20 --warmup 5 --no-also > $out/${tag}_bench_c
 python bench.py --fp16 --steps 20 --warmup 5 --no-also > $out/${tag}_bench_train_fp16_line.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 > $out/${tag}_bench_train_line.json 2>/dev/null
 for f in bench_codec bench_cfg2_f32 bench_train_fp16 bench_train; do tail -c 300 $out/${tag}_${f}_line.json; echo; done
+
+# K1 / K2 micro-benchmark (product kernels + variants with parts switched off) and their SQ counters
+hipcc --version > /dev/null 2>&1
+for b in 4096 64 8; do scripts/ubench/mdct_bs_bench $b; done > $out/${tag}_mdct_bs_ubench.log 2>&1
+cd /tmp
+rm -rf /tmp/pmc_bs
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY \
+    -d /tmp/pmc_bs --output-format csv -- $R/scripts/ubench/mdct_bs_bench 4096 > /dev/null 2>&1
+f=$(find /tmp/pmc_bs -name "*counter_collection.csv" | head -1)
+[ -n "$f" ] && python $R/scripts/pmc_sq.py $f $out/${tag}_pmc_sq_mdct_bs.csv > /dev/null
+cd $R
+# full-size step parity by kernel family + op-level accuracy of the 25-position Winograd families
+bash scripts/diag_fullsize_step.sh $out/${tag}_step_report.jsonl > $out/${tag}_fullsize_step_parity.txt 2>&1
+python scripts/diag_wino4_accuracy.py >> $out/${tag}_fullsize_step_parity.txt 2>&1
+tail -5 $out/${tag}_mdct_bs_ubench.log
