@@ -166,21 +166,27 @@ def cpu_baseline_train_cfg2(max_threads):
 def also_lines(args):
     """The other BASELINE configurations as their own bench lines, each from a child process of this script (own model, own
     hipGraph, own roofline probe and cpu_baseline), embedded in the headline's JSON so that the driver's one command shows
-    them: configs[2] with --fp16 (the reference's configuration for configs[2] / [3]) and configs[4] (inference)."""
+    them: configs[2] with --fp16 (the reference's configuration for configs[2] / [3]), configs[4] (inference) and the
+    headline configuration under the MG_F32_SPLIT=1 opt-in."""
     import subprocess
     out = []
-    for extra in (["--config", "2", "--fp16"], ["--config", "4"]):
+    # third line: the headline configuration with MG_F32_SPLIT=1 (float32 products of the Winograd-domain GEMMs formed from three
+    # bf16 pieces on the bf16 MFMA pipe, float32-accurate: DESIGN section 3).  An opt-in, shown beside the headline, never in it.
+    for extra, env in ((["--config", "2", "--fp16"], None), (["--config", "4"], None),
+                       (["--config", "1", "--no-cpu-baseline"], {"MG_F32_SPLIT": "1"})):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
                "--no-also"] + extra
         t0 = time.perf_counter()
+        label = " ".join("%s=%s" % kv for kv in (env or {}).items())
+        label = (label + " " if label else "") + "python bench.py " + " ".join(cmd[2:])
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
             line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
             d = json.loads(line)
             d["wall_s"] = round(time.perf_counter() - t0, 1)
-            d["cmd"] = "python bench.py " + " ".join(cmd[2:])
+            d["cmd"] = label
         except Exception as e:      # the headline line must survive a failing side line
-            d = {"cmd": "python bench.py " + " ".join(cmd[2:]), "error": repr(e)[:300]}
+            d = {"cmd": label, "error": repr(e)[:300]}
         out.append(d)
     return out
 
@@ -261,6 +267,18 @@ def bench_codec(args, dev, rank, world):
                                 "here includes the pair (393 216 B per clip really move) and the mean / std statistics",
                         "timed": "torch events on the launch stream around to_spectro / to_audio (each is one kernel "
                                  "launch plus the output allocation)"}}
+    tr = os.path.join(REPO, "profiles", "traffic.json")      # HBM bytes per launch from the rocprofv3 --pmc passes (4096 clips)
+    if os.path.exists(tr):
+        table = json.load(open(tr)).get("codec", {})
+        t1, t2 = table.get("mdct4_bs_kernel<8, 1, true, false, 0>"), table.get("imdct4_bs_kernel<1>")
+        if t1 and t2:
+            out["roofline"]["traffic"] = int(t1 * B / 4096)
+            out["roofline"]["k2_traffic"] = int(t2 * B / 4096)
+            out["roofline"]["traffic_definition"] = (
+                "HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 from separate rocprofv3 --pmc passes over "
+                "scripts/ubench/mdct_bs_bench at 4096 clips (%s), scaled by clips / 4096; K1 = the pair variant without the "
+                "statistics (526.9 KB per clip: 130 048 read, spectrogram + 2-channel network input written), K2 = 267.5 KB per clip"
+                % table.get("_source"))
     if rank == 0:
         print(json.dumps(out), flush=True)
 

@@ -254,3 +254,174 @@ inline void hgemm_launch(const HgArgs& a0, hipStream_t st) {
     const unsigned grid = (unsigned)((long long)a.tiles_m * a.tiles_n * a.splits);
     mg_launch(hgemm_kernel<BM, BN, WGM, WGN, BRC, NBUF>, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, a);
 }
+
+// ---- A-stationary form for a SHORT reduction (the weight gradient of the small-spatial trunk: K = padded pixel count = 256 on
+// the 2048-channel 4x8 layers, M = Co = 2048, N = 9 Ci = 18432) ----
+// hgemm_kernel spends that shape waiting: a workgroup's four 64-deep chunks arrive one latency after the other with 32 KiB in
+// flight, and every 128 x 128 tile re-fetches its A rows (measured 57 us for 151 MB of output, 2.6 TB/s).  Here a workgroup owns
+// one 128-row A panel for a GROUP of column tiles: the panel lives in VGPRs for the whole kernel (a wave's 32 rows x K halves =
+// 16 K/64 registers), only B is streamed, as one continuous ring of [128][64] chunks that runs across tile boundaries, filled by
+// LW dedicated loader waves.  The loaders are the only waves that count vmcnt -- the eight MFMA waves' global stores (32 per tile
+// and lane) would otherwise sit in the same counter and every "chunk landed" wait would also drain the stores of the tile before.
+// NBUF buffers of 16 KiB: NBUF - 1 chunks (112 KiB at 8) in flight per CU, one workgroup per CU.
+// `flag` (optional): set to 1.0f when a result is not finite -- the GradScaler's inf / nan check (scaler_check_kernel) done on
+// the accumulators, which saves a second pass over the largest gradients of the model.
+struct HgAsArgs {
+    const void* A;           // float16 [M][K]   (lda = K)
+    const void* B;           // float16 [N][K]   (ldb = K)
+    float* C;                // float32 [M][N]
+    float* flag;
+    int M, N, groups, accumulate;
+};
+constexpr int HG_AS_NBUF = 8, HG_AS_LW = 2;
+
+template <int KC, bool ACC>  // K = 64 KC; ACC: C += result
+__global__ __launch_bounds__(64 * (8 + HG_AS_LW)) void hgemm_as_kernel(HgAsArgs g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NBUF = HG_AS_NBUF, LW = HG_AS_LW, AHEAD = NBUF - 1, BSZ = 128 * 32, K = 64 * KC;
+    constexpr int PPW = 16 / LW;                            // 1 KiB pieces per loader wave and chunk
+    static_assert((AHEAD - 1) * PPW <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(1024))) float hg_as_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_m = g.M / 128, tiles_n = g.N / 128;
+    const int L = xcd_remap(blockIdx.x, tiles_m * g.groups);
+    // consecutive L = the m panels of one column group: an XCD streams that group's B rows through its L2 once for all of them
+    const int grp = L / tiles_m, tm = L - grp * tiles_m;
+    const int t0 = (int)((long long)grp * tiles_n / g.groups), t1 = (int)((long long)(grp + 1) * tiles_n / g.groups);
+    const int Q = (t1 - t0) * KC;                           // chunks of this workgroup's stream
+    const int m0 = tm * 128;
+
+    if (wave >= 8) {
+        // ---- loader waves ----
+        const int lw = wave - 8;
+        const unsigned long long a = (unsigned long long)g.B;
+        dg_v4i rb;
+        rb[0] = (int)(unsigned)a;
+        rb[1] = (int)((unsigned)(a >> 32) & 0xffffu);
+        rb[2] = (int)((unsigned)g.N * (unsigned)K * 2u);
+        rb[3] = 0x00020000;
+        unsigned vb[PPW];
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int row = 8 * (lw * PPW + i) + (lane >> 3), q = (lane & 7) ^ ((row >> 1) & 7);
+            vb[i] = (unsigned)row * (unsigned)(K * 2) + 16u * q;
+        }
+        const unsigned lds0 = (unsigned)(size_t)(dg_lds_ptr)hg_as_smem + (unsigned)(lw * PPW) * 1024u;
+        auto issue = [&](int q, int buf) {
+            const int t = q / KC, c = q - t * KC;
+            const unsigned soff = ((unsigned)(t0 + t) * 128u * (unsigned)K + (unsigned)c * 64u) * 2u;
+            const unsigned lb = lds0 + (unsigned)buf * (unsigned)(BSZ * 4);
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) dg_dma16(vb[i], rb, lb + 1024u * i, soff);
+        };
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i)
+            if (i < Q) issue(i, i);
+        int nxt = AHEAD % NBUF;
+        for (int q = 0; q < Q; ++q) {
+            if (q + AHEAD > Q) dg_wait_vmcnt<0>();
+            else dg_wait_vmcnt<(AHEAD - 1) * PPW>();
+            __builtin_amdgcn_s_barrier();                   // chunk q is in LDS; everybody is done with chunk q - 1
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + AHEAD < Q) issue(q + AHEAD, nxt);
+            nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
+        }
+        return;
+    }
+
+    // ---- MFMA waves: 4 (rows) x 2 (columns), 32 x 64 results each ----
+    const int wm = wave >> 1, wn0 = (wave & 1) * 64;
+    const int r = lane & 31, kh = lane >> 5;
+    f16x8 a[4 * KC];
+    {
+        const _Float16* ap = (const _Float16*)g.A + (size_t)(m0 + 32 * wm + r) * K + 8 * kh;
+#pragma unroll
+        for (int s = 0; s < 4 * KC; ++s) a[s] = *reinterpret_cast<const f16x8*>(ap + 16 * s);
+        // the panel has landed before the loop starts: otherwise the compiler waits for it at its first use INSIDE the loop, with a
+        // count that also drains the stores of the tile before on every later trip
+        __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
+    }
+    f32x16 acc[2] = {f32x16{0}, f32x16{0}};
+    bool bad = false;
+    int cur = 0, c = 0, t = t0;
+    for (int q = 0; q < Q; ++q) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const float* Bs = hg_as_smem + cur * BSZ;
+        f16x8 b[2][2];
+        auto fetch = [&](int s, int buf) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) b[buf][ni] = cd_frag_kc(Bs, wn0 + 32 * ni + r, s, kh);
+        };
+        fetch(0, 0);
+        // the A fragment index depends on the chunk within the tile: a switch over c keeps `a` in registers
+#pragma unroll
+        for (int cc = 0; cc < KC; ++cc) {
+            if (c == cc) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if (s + 1 < 4) fetch(s + 1, (s + 1) & 1);
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) acc[ni] = mfma32x32x16h(a[4 * cc + s], b[s & 1][ni], acc[ni]);
+                }
+            }
+        }
+        cur = cur + 1 == NBUF ? 0 : cur + 1;
+        if (++c == KC) {
+            // tile finished: store it (plain dword stores, 2 x 128 bytes per instruction) and start the next one
+            c = 0;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                float* o = g.C + (size_t)(m0 + 32 * wm) * g.N + (size_t)t * 128 + wn0 + 32 * ni + r;
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    float v = acc[ni][rr];
+                    float* p = o + (size_t)mfma32_row(rr, lane) * g.N;
+                    if constexpr (ACC) v += *p;
+                    bad |= !(fabsf(v) <= 3.4028234663852886e38f);
+                    *p = v;
+                }
+                acc[ni] = f32x16{0};
+            }
+            ++t;
+        }
+    }
+    if (g.flag && __any(bad) && lane == 0) *g.flag = 1.0f;
+#endif
+}
+
+inline bool hgemm_as_ok(long long M, int N, int K) {
+    return M % 128 == 0 && N % 128 == 0 && (K == 64 || K == 128 || K == 192 || K == 256) && M / 128 <= 256 &&
+           (long long)N * K * 2 < (1ll << 32);
+}
+template <int KC, bool ACC>
+inline void hgemm_as_go2(const HgAsArgs& a, int grid, hipStream_t st) {
+    constexpr size_t lds = (size_t)HG_AS_NBUF * 128 * 32 * 4;
+    static bool once = false;
+    if (!once) {
+        hipFuncSetAttribute((const void*)hgemm_as_kernel<KC, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        once = true;
+    }
+    mg_launch(hgemm_as_kernel<KC, ACC>, dim3((unsigned)grid), dim3(64 * (8 + HG_AS_LW)), lds, st, a);
+}
+template <int KC>
+inline void hgemm_as_go(const HgAsArgs& a, int grid, hipStream_t st) {
+    if (a.accumulate) hgemm_as_go2<KC, true>(a, grid, st);
+    else hgemm_as_go2<KC, false>(a, grid, st);
+}
+inline void hgemm_as_launch(const void* A, const void* B, float* C, long long M, int N, int K, int accumulate, float* flag, hipStream_t st) {
+    HgAsArgs a{A, B, C, flag, (int)M, N, 1, accumulate};
+    const int tiles_m = (int)(M / 128), tiles_n = N / 128;
+    int groups = 256 / tiles_m;                              // one workgroup per CU ...
+    if (groups > tiles_n) groups = tiles_n;
+    while (groups > 1 && tiles_n / groups < 3) --groups;     // ... of at least three tiles: the panel load and the ring's fill are paid once per workgroup
+    if (const char* f = getenv("MG_HGEMM_AS_GROUPS")) { const int v = atoi(f); if (v >= 1 && v <= tiles_n) groups = v; }
+    a.groups = groups;
+    switch (K / 64) {
+        case 1: hgemm_as_go<1>(a, tiles_m * groups, st); break;
+        case 2: hgemm_as_go<2>(a, tiles_m * groups, st); break;
+        case 3: hgemm_as_go<3>(a, tiles_m * groups, st); break;
+        default: hgemm_as_go<4>(a, tiles_m * groups, st); break;
+    }
+}

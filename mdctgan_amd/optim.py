@@ -154,25 +154,33 @@ class FusedAdam(torch.optim.Optimizer):
         (b1, b2), eps = g["betas"], g["eps"]
         self.sync_lr()                        # schedule change (update_learning_rate): refresh the device copy
         # contiguous runs of parameters that received a gradient this step (normally a single run = everything)
-        runs, start = [], None
         fuse = self.can_fuse()
-        for i, p in enumerate(self._params):
+        kinds = []                            # per parameter: 1 = step it, 0 = nothing to do, 2 = may ride along
+        for p in self._params:
             has = (p.grad is not None) and not getattr(p, "_mg_fresh", False)
             if has and fuse and getattr(p, "_mg_known_zero", False) and getattr(p, "_mg_never_stepped", True):
                 # a bias whose gradient is identically zero (it feeds an InstanceNorm) and whose moments are still zero: Adam
-                # leaves it where it is (m = v = 0 -> the update is lr * 0 / (0 + eps)), so the launch is skipped -- exactly;
-                # keeps the arena's runs long now that the big weights between such biases are updated during backward
-                has = False
+                # leaves it where it is (m = v = 0 -> the update is lr * 0 / (0 + eps)), exactly.  Between two parameters that
+                # are stepped it rides along (one launch over the run instead of one per weight); next to the big weights that
+                # were already updated during backward it is left out, which keeps those out of the spans.
+                kinds.append(2)
             elif has:
                 p._mg_never_stepped = False
                 p._mg_u_ok = None          # rewritten through the arena: a transformed-weight image kept for it is stale
-            if has and start is None:
-                start = i
-            if not has and start is not None:
-                runs.append((start, i))
+                kinds.append(1)
+            else:
+                kinds.append(0)
+        runs, start, last = [], None, None    # [start, last] = first / last stepped parameter of the current run
+        for i, k in enumerate(kinds):
+            if k == 1:
+                if start is None:
+                    start = i
+                last = i
+            elif k == 0 and start is not None:
+                runs.append((start, last + 1))
                 start = None
         if start is not None:
-            runs.append((start, len(self._params)))
+            runs.append((start, last + 1))
         spans = []
         for a, b in runs:
             lo = self.offsets[a]

@@ -31,7 +31,7 @@ f, fn = collect(sys.argv[1], "FETCH_SIZE")
 w, wn = collect(sys.argv[2], "WRITE_SIZE")
 rows, out = [], {}
 for k in f:
-    if k not in w or not (k.startswith(("conv_", "dense_", "wino", "dgemm32", "hgemm", "h16_", "splitk", "norm_", "adam"))):
+    if k not in w or not (k.startswith(("conv_", "dense_", "wino", "dgemm32", "hgemm", "h16_", "splitk", "norm_", "adam", "mdct4_", "imdct4_"))):
         continue
     fk, wk = f[k] / fn[k], w[k] / wn[k]
     b = int((2 * fk + wk) * 1024)

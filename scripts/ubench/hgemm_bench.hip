@@ -138,6 +138,40 @@ int main(int argc, char** argv) {
                        flops / ts[1] / 1e6, bytes / ts[1] / 1e6, err, err > 1e-4f ? "  <-- WRONG" : "");
             }
         }
+        if (hgemm_as_ok(pr.M, pr.N, pr.K)) {
+            const int tn = pr.N / 128, tmm = pr.M / 128;
+            for (int groups : {0, 256 / tmm / 2, 2 * 256 / tmm, 3 * 256 / tmm}) {
+                if (groups > tn) continue;
+                char buf[16]; snprintf(buf, sizeof buf, "%d", groups);
+                if (groups) setenv("MG_HGEMM_AS_GROUPS", buf, 1); else unsetenv("MG_HGEMM_AS_GROUPS");
+                float* flag = dstat + 1;
+                auto run = [&]() { hgemm_as_launch(A, B, C, pr.M, pr.N, pr.K, 0, nullptr, st); };
+                hipMemsetAsync(C, 0, nc * 4, st);
+                hipMemsetAsync(dstat, 0, 8, st);
+                run();
+                maxdiff_kernel<<<512, 256, 0, st>>>(C, R, nc, dstat);
+                float h[2];
+                hipMemcpyAsync(h, dstat, 8, hipMemcpyDeviceToHost, st);
+                hipStreamSynchronize(st);
+                if (hipGetLastError() != hipSuccess) { printf("   A-stationary launch failed\n"); continue; }
+                std::vector<float> ts;
+                for (int rd = 0; rd < 3; ++rd) {
+                    run();
+                    hipEventRecord(e0, st);
+                    for (int it = 0; it < 10; ++it) run();
+                    hipEventRecord(e1, st);
+                    hipEventSynchronize(e1);
+                    float ms; hipEventElapsedTime(&ms, e0, e1);
+                    ts.push_back(ms * 1e2f);
+                }
+                std::sort(ts.begin(), ts.end());
+                const float err = h[0] / (h[1] > 0 ? h[1] : 1.f);
+                printf("   A-stationary       groups %3d           med %8.1f us  %7.1f TF  %6.2f TB/s  relerr %.1e%s\n", groups, ts[1],
+                       flops / ts[1] / 1e6, bytes / ts[1] / 1e6, err, err > 1e-4f ? "  <-- WRONG" : "");
+                (void)flag;
+            }
+            unsetenv("MG_HGEMM_AS_GROUPS");
+        }
         fflush(stdout);
         hipFree(A); hipFree(B); hipFree(C); hipFree(R); hipFree(part);
     }
