@@ -218,6 +218,14 @@ int mg_conv_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float*
 size_t mg_conv_wgrad_workspace(const mg_conv_geom* g);
 int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias, int accumulate,
                     void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* tiles);
+/* --fp16 (train.py:183-199, torch.cuda.amp.GradScaler.unscale_'s inf / nan check): where mg_conv_wgrad_checks_finite(g) != 0 the
+ * weight-gradient kernel inspects its own results -- mg_conv_wgrad_chk stores 1.0f to *found_inf (device memory; left alone
+ * otherwise) when an element of dw, after accumulation, is inf or nan, so the caller can leave dw out of its mg_scaler_check
+ * pass (the 2048-channel trunk layers of configs[2] / [3]: 151 MB each).  found_inf = NULL: same as mg_conv_wgrad_w.
+ * found_inf != NULL on a geometry without the check: MG_ERR_UNSUPPORTED. */
+int mg_conv_wgrad_checks_finite(const mg_conv_geom* g);
+int mg_conv_wgrad_chk(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias, int accumulate,
+                      void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* tiles, float* found_inf);
 /* Round 3 (single process, float32): the weight side of a Winograd F(2x2,3x3) layer in one pass.  Instead of writing dw,
  * the call applies torch.optim.Adam's update (pix2pixHD_model.py:350-351) to (w, m, v) straight from the Winograd-domain
  * gradient and leaves u = G w G^T of the UPDATED weights (mg_conv_wino_weights_bytes(g) bytes) for the next forward:

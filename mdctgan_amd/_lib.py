@@ -69,6 +69,8 @@ SIGNATURES = {
     "mg_conv_fwd_instnorm_w": (_i, [_G, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _sz, _p, _W]),
     "mg_conv_dgrad_w": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p, _W]),
     "mg_conv_wgrad_w": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p, _W]),
+    "mg_conv_wgrad_chk": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p, _W, _p]),
+    "mg_conv_wgrad_checks_finite": (_i, [_G]),
     "mg_conv_wgrad_adam_ok": (_i, [_G]),
     "mg_conv_wgrad_adam_w": (_i, [_G, _p, _p, _p, _WA, _p, _sz, _p, _W]),
     "mg_conv_dgrad": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p]),

@@ -274,7 +274,15 @@ int h16_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* dx,
     return MG_OK;
 }
 
-int h16_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate, char* ws, hipStream_t st) {
+// Short reductions (the padded pixel count is the K of this GEMM: 256 on the 2048-channel 4x8 trunk) run A-stationary
+// (hgemm_as_kernel); MG_HGEMM_AS=0 keeps them on hgemm_kernel.
+inline bool h16_wgrad_as(const mg_conv_geom* g) {
+    static const bool on = !(getenv("MG_HGEMM_AS") && atoi(getenv("MG_HGEMM_AS")) == 0);
+    const long long M = (long long)g->B * g->OH * g->OW;
+    return on && hgemm_as_ok(g->Co, g->KH * g->KW * g->Ci, h16_mp(M));
+}
+int h16_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate, char* ws, hipStream_t st,
+              float* found_inf) {
     const long long M = (long long)g->B * g->OH * g->OW;
     const int Mp = h16_mp(M), N = g->KH * g->KW * g->Ci;
     const H16Plan p = h16_plan(g->Co, N, Mp, false);
@@ -284,6 +292,13 @@ int h16_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw,
     const Geom gg = to_geom(g);
     hipLaunchKernelGGL(h16_colT_kernel, dim3(Mp / 64, g->Co / 64, 1), dim3(256), 0, st, gg, dy, g->Co, (int)M, Mp, 1, dyt);
     hipLaunchKernelGGL(h16_colT_kernel, dim3(Mp / 64, g->Ci / 64, g->KH * g->KW), dim3(256), 0, st, gg, x, g->Ci, (int)M, Mp, 0, xct);
+    if (h16_wgrad_as(g)) {
+        probe_begin(st);
+        hgemm_as_launch(dyt, xct, dw, g->Co, N, Mp, accumulate, found_inf, st);
+        probe_end(st);
+        MG_CHECK_LAUNCH();
+        return MG_OK;
+    }
     HgArgs a{};
     a.A = dyt; a.B = xct; a.C = dw; a.part = p.splits > 1 ? part : nullptr;
     a.M = g->Co; a.N = N; a.K = Mp; a.lda = Mp; a.ldb = Mp; a.splits = p.splits; a.cps = p.cps;

@@ -3063,7 +3063,16 @@ int mg_conv_wgrad_adam_w(const mg_conv_geom* g, const float* x, const float* dy,
 
 int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias, int accumulate,
                     void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* wt) {
+    return mg_conv_wgrad_chk(g, x, dy, dw, dbias, accumulate, workspace, workspace_bytes, stream, wt, nullptr);
+}
+int mg_conv_wgrad_checks_finite(const mg_conv_geom* g) {
+    return (geom_ok(g) && !co1_gemm_ok(g) && !mg_conv_rowdot_kq(g) && h16_ok(g) && h16_wgrad_as(g)) ? 1 : 0;
+}
+int mg_conv_wgrad_chk(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias, int accumulate,
+                      void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* wt, float* found_inf) {
     if (!geom_ok(g) || !dw) return MG_ERR_ARG;
+    if (found_inf && !mg_conv_wgrad_checks_finite(g)) return MG_ERR_UNSUPPORTED;   // nobody would look at dw: refuse instead of skipping silently
+    if (found_inf && !(x && dy && aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace))) return MG_ERR_ARG;
     if (!wino_tiles_ok(g, wt)) return MG_ERR_ARG;
     // x / dy may be NULL when the caller hands over both Winograd images of an F(2x2,3x3) layer (no bias gradient then)
     if ((!x || !dy) && !(wt && wt->v && wt->md && mg_conv_wino_md_from_norm_ok(g) && !dbias && aligned16(dw) && aligned16(workspace)))
@@ -3078,7 +3087,7 @@ int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, floa
         return rc;
     }
     if (h16_ok(g) && aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace)) {
-        const int rc = h16_wgrad(g, x, dy, dw, accumulate, (char*)workspace, (hipStream_t)stream);
+        const int rc = h16_wgrad(g, x, dy, dw, accumulate, (char*)workspace, (hipStream_t)stream, found_inf);
         if (rc != MG_OK) return rc;
         if (dbias)
             return mg_colsum(dy, (long long)g->B * g->OH * g->OW, g->Co, dbias, accumulate, (char*)workspace + h16_wgrad_cs_offset(g),

@@ -45,6 +45,7 @@ def grad_buffer(p: torch.nn.Parameter):
         p.grad = torch.empty_like(p)          # preserve_format: same (channels_last) strides as the parameter
         fresh = True
     p._mg_fresh = False
+    p._mg_inf_checked = False             # whoever writes next has to say so again (see _producer_flag)
     return p.grad, (not fresh)
 
 
@@ -52,6 +53,7 @@ def mark_fresh(params):
     """zero_grad without a memset: the next wgrad kernel overwrites instead of accumulating."""
     for p in params:
         p._mg_fresh = True
+        p._mg_inf_checked = False
 
 
 # A bias added right before InstanceNorm2d(affine=False) is removed again by the mean subtraction: its gradient is
@@ -73,6 +75,20 @@ def _zero_grad_bias(bias):
         bias.grad.zero_()                 # a buffer someone else may have written: clear it once
     bias._mg_known_zero = True
     bias._mg_fresh = False
+
+
+def _producer_flag(weight, g):
+    """--fp16: the GradScaler's found_inf slot of the optimiser that owns `weight`, when this layer's weight-gradient kernel
+    checks its own results (ops.wgrad_checks_finite) -- FusedAdam.step then leaves the gradient out of its check pass.  The
+    kernel looks at the gradient AFTER accumulation, so the last writer's check covers the whole buffer; every writer of a
+    weight gradient passes through here and restates `_mg_inf_checked`."""
+    opt = getattr(weight, "_mg_opt", None)
+    if opt is None:
+        return None
+    flag = opt.producer_flag()
+    if flag is None or not ops.wgrad_checks_finite(g):
+        return None
+    return flag
 
 
 _grad_hooks = []
@@ -368,10 +384,14 @@ def _conv_backward(ctx, gy, x, y):
                 bbuf = None
             # Winograd images come as a pair; the float16 copies of the implicit-GEMM layers are independent
             v = getattr(ctx, "v", None) if (md is not None or ops.tiles_are_casts(g)) else None
-            ops.conv_wgrad(g, nhwc_view(x), nhwc_view(gy), wbuf, bbuf, wacc, v=v, md=md)
+            flag = _producer_flag(weight, g)
+            ops.conv_wgrad(g, nhwc_view(x), nhwc_view(gy), wbuf, bbuf, wacc, v=v, md=md, found_inf=flag)
+            weight._mg_inf_checked = flag is not None
             ctx.v = None
         else:
-            ops.conv_wgrad(g, nhwc_view(gy), nhwc_view(x), wbuf, None, wacc)
+            flag = _producer_flag(weight, g)
+            ops.conv_wgrad(g, nhwc_view(gy), nhwc_view(x), wbuf, None, wacc, found_inf=flag)
+            weight._mg_inf_checked = flag is not None
             if bbuf is not None:
                 ops.colsum(nhwc_view(gy).reshape(-1, g.Ci), bbuf, bacc)
         _notify(weight)

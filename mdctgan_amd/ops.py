@@ -155,17 +155,29 @@ def conv_dgrad(g: ConvGeom, dy, w, bias=None, act=ACT_NONE, u=None, md_out=None,
     return dx
 
 
-def conv_wgrad(g: ConvGeom, x, dy, dw, dbias=None, accumulate=False, v=None, md=None):
-    """dw: float32 buffer of Co*KH*KW*Ci elements in OHWI order (written / accumulated in place)."""
+def conv_wgrad(g: ConvGeom, x, dy, dw, dbias=None, accumulate=False, v=None, md=None, found_inf=None):
+    """dw: float32 buffer of Co*KH*KW*Ci elements in OHWI order (written / accumulated in place).
+    found_inf (a float32 device scalar, only where wgrad_checks_finite(g)): set to 1 by the kernel when dw is not finite."""
     lib = _lib.load()
     nbytes = lib.mg_conv_wgrad_workspace(g)
     ws = _ws(nbytes, dw.device)
     if PROFILER is not None:
         PROFILER.begin(2, g)
-    _lib.check(lib.mg_conv_wgrad_w(g, _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(dbias), int(accumulate),
-                                   _lib.ptr(ws), ws.numel(), _lib.stream(), _tiles(None, v, md)), "mg_conv_wgrad")
+    _lib.check(lib.mg_conv_wgrad_chk(g, _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(dbias), int(accumulate),
+                                     _lib.ptr(ws), ws.numel(), _lib.stream(), _tiles(None, v, md), _lib.ptr(found_inf)),
+               "mg_conv_wgrad")
     if PROFILER is not None:
         PROFILER.end()
+
+
+def wgrad_checks_finite(g: ConvGeom) -> bool:
+    """True when the layer's weight-gradient kernel can do the GradScaler's inf / nan check on its own results
+    (mg_conv_wgrad_chk: the float16 A-stationary GEMM of the small-spatial trunk layers)."""
+    key = ("wf", g.B, g.H, g.W, g.Ci, g.Co, g.KH, g.KW, g.stride, g.pad, g.reflect, g.precision)
+    hit = _CASTS.get(key)
+    if hit is None:
+        hit = _CASTS[key] = bool(_lib.load().mg_conv_wgrad_checks_finite(g))
+    return hit
 
 
 def wgrad_adam_ok(g: ConvGeom) -> bool:

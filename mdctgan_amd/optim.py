@@ -43,6 +43,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._pending = None           # ... and the all-gather of the updated shards still in flight
         self.half_shadow = bool(half_shadow)
         self.flat_h = None
+        self._scaler_flag = None       # GradScaler.state[2 + slot : 3 + slot] once a scaler has stepped this optimiser
 
     # -- arena ---------------------------------------------------------------------------------
     def _build(self):
@@ -108,6 +109,17 @@ class FusedAdam(torch.optim.Optimizer):
         import os
         return (self._built and not self.half_shadow and self.pre_step_hook is None and self.shard is None
                 and os.environ.get("MG_NO_WINO_ADAM_FUSION", "0") != "1")
+
+    def producer_flag(self):
+        """The found_inf slot the weight-gradient kernels may set themselves (functional._producer_flag), or None.  Known from
+        the first GradScaler.step on; single process only -- a reduced gradient can be non-finite on a rank whose own
+        contribution was finite, so under data parallelism every rank checks the reduced arena.  MG_NO_PRODUCER_INF_CHECK=1
+        turns it off."""
+        import os
+        if (self._scaler_flag is None or self.pre_step_hook is not None or self.shard is not None
+                or os.environ.get("MG_NO_PRODUCER_INF_CHECK", "0") == "1"):
+            return None
+        return self._scaler_flag
 
     def arena_slices(self):
         """[(param, offset, padded_numel)] in arena order (used by the data-parallel reducer)."""
@@ -191,8 +203,9 @@ class FusedAdam(torch.optim.Optimizer):
         if scaler_state is None:
             ops.adam_tick(self.state, b1, b2)
         else:
-            for lo, hi in spans:
+            for lo, hi in self._check_spans(spans, kinds):
                 ops.scaler_check(self.flat_g[lo:hi], scaler_state, scaler_slot)
+            self._scaler_flag = scaler_state[2 + scaler_slot:3 + scaler_slot]
             if self.shard is not None:
                 self.shard.agree(scaler_state[2 + scaler_slot:3 + scaler_slot])
             ops.adam_tick_amp(self.state, b1, b2, scaler_state, scaler_slot)
@@ -207,6 +220,28 @@ class FusedAdam(torch.optim.Optimizer):
         if self.shard is not None:
             self._pending = self.shard.gather(self.flat_p)
         return None
+
+    def _check_spans(self, spans, kinds):
+        """The part of `spans` the GradScaler's inf / nan pass has to read: everything except gradients their own kernel
+        already checked (`_mg_inf_checked`).  Exactly-zero bias gradients need no look either, but may sit inside a span."""
+        if self.shard is not None or not any(getattr(p, "_mg_inf_checked", False) for p in self._params):
+            return spans
+        out, start, last = [], None, None
+        n = len(self._params)
+        for i, p in enumerate(self._params):
+            stepped = kinds[i] != 0
+            need = stepped and not getattr(p, "_mg_inf_checked", False) and not getattr(p, "_mg_known_zero", False)
+            ride = stepped and getattr(p, "_mg_known_zero", False) and not getattr(p, "_mg_inf_checked", False)
+            if need:
+                if start is None:
+                    start = i
+                last = i
+            elif not ride and start is not None:
+                out.append((start, last + 1))
+                start = None
+        if start is not None:
+            out.append((start, last + 1))
+        return [(self.offsets[a], self.total if b == n else self.offsets[b]) for a, b in out]
 
     @torch.no_grad()
     def finish_pending(self):

@@ -263,3 +263,84 @@ def test_fp16_step_against_reference_and_oracle(golden):
     # inference is float32 (generate_audio.py has no autocast)
     sr_spectro, sr_audio, *_ = model3.inference(lr)
     assert torch.isfinite(sr_audio).all() and sr_spectro.dtype == torch.float32
+
+
+def test_short_reduction_wgrad_checks_its_own_results():
+    """The weight gradient of a small-spatial layer (256 pixels = the K of its GEMM) runs A-stationary (hgemm_as_kernel,
+    csrc/dense_gemm_h.h) and does the GradScaler's inf / nan check on its accumulators (mg_conv_wgrad_chk)."""
+    from mdctgan_amd import _lib, ops
+    B, H, W, C = 8, 4, 8, 256
+    g = ops.conv_geom(B, H, W, C, C, 3, 3, 1, 1, True, _lib.PRECISION_F16)
+    assert ops.wgrad_checks_finite(g)
+    assert not ops.wgrad_checks_finite(ops.conv_geom(B, H, W, C, C, 3, 3, 1, 1, True, _lib.PRECISION_F32))
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(B, C, H, W, generator=gen)
+    dy = torch.randn(B, C, H, W, generator=gen)
+    xp = F.pad(h(x), (1, 1, 1, 1), mode="reflect")
+    want = torch.nn.grad.conv2d_weight(xp, (C, C, 3, 3), h(dy))                 # float64, float16-rounded operands
+    want = want.permute(0, 2, 3, 1).contiguous()                                # OHWI
+    xd, dyd = nhwc(x).to(DEV), nhwc(dy).to(DEV)
+    dw = torch.full((C, 3, 3, C), float("nan"), device=DEV)
+    flag = torch.zeros(1, device=DEV)
+    ops.conv_wgrad(g, xd, dyd, dw, None, found_inf=flag)
+    assert flag.item() == 0.0
+    err = (dw.double().cpu() - want).abs().max().item()
+    assert err <= 3e-5 * want.abs().max().item(), err
+    first = dw.clone()
+    ops.conv_wgrad(g, xd, dyd, dw, None, accumulate=True, found_inf=flag)       # C += result, checked after the addition
+    assert torch.equal(dw, first + first) and flag.item() == 0.0
+    bad = dyd.clone()
+    bad[3, 2, 5, 77] = float("inf")
+    ops.conv_wgrad(g, xd, bad, dw, None, found_inf=flag)
+    assert flag.item() == 1.0 and not torch.isfinite(dw).all()
+    flag.zero_()
+    dw.copy_(first)
+    dw[200, 1, 1, 9] = float("nan")                                            # a non-finite value already in the buffer
+    ops.conv_wgrad(g, xd, dyd, dw, None, accumulate=True, found_inf=flag)
+    assert flag.item() == 1.0
+    # no flag: plain mg_conv_wgrad_w
+    ops.conv_wgrad(g, xd, dyd, dw, None)
+    assert torch.equal(dw, first)
+    # a geometry whose kernel has no check refuses a flag instead of ignoring it
+    g2 = ops.conv_geom(2, 32, 64, 16, 32, 3, 3, 2, 1, False, _lib.PRECISION_F16)
+    with pytest.raises(RuntimeError):
+        ops.conv_wgrad(g2, torch.zeros(2, 32, 64, 16, device=DEV), torch.zeros(2, 16, 32, 32, device=DEV),
+                       torch.zeros(32, 3, 3, 16, device=DEV), None, found_inf=flag)
+
+
+def test_producer_side_inf_check_changes_nothing(monkeypatch):
+    """FusedAdam leaves gradients whose own kernel checked them out of its mg_scaler_check pass: same weights, same scale and
+    same skipped steps as with MG_NO_PRODUCER_INF_CHECK=1 (everything through the arena pass), overflow iteration included."""
+    from mdctgan_amd import options
+    from mdctgan_amd.pix2pixHD_model import create_model
+
+    def run(off):
+        monkeypatch.setenv("MG_NO_PRODUCER_INF_CHECK", "1" if off else "0")
+        torch.manual_seed(5)
+        opt = options.make_opt(*options.SPECTRAL_FLAGS, "--lr_sampling_rate", "12000", "--netG", "global", "--ngf", "16",
+                               "--n_blocks_global", "2", "--n_blocks_attn_g", "0", "--num_D", "2", "--ndf", "8",
+                               "--batchSize", "2", "--bins", "32", "--segment_length", "7936", "--gpu_ids", "0", "--fp16")
+        model = create_model(opt)
+        onets.fill_deterministic(model.netG)
+        onets.fill_deterministic(model.netD)
+        gen = torch.Generator().manual_seed(11)
+        hr = (0.1 * torch.randn(2, 7936, generator=gen)).to(DEV)
+        lr = (0.1 * torch.randn(2, 7936, generator=gen)).to(DEV)
+        model.scaler.state[0] = 64.0
+        checked, scales = 0, []
+        for it in range(4):
+            if it == 2:
+                model.scaler.state[0] = 2.0 ** 40          # this iteration overflows: both optimisers skip, the scale halves
+            model.optimize_parameters(lr, hr)
+            checked = max(checked, sum(bool(getattr(p, "_mg_inf_checked", False)) for p in model.netG.parameters()))
+            scales.append(model.scaler.get_scale())
+            if it == 2:
+                model.scaler.state[0] = 64.0
+        return ({k: v.detach().clone() for k, v in model.netG.state_dict().items()}, scales, checked,
+                model.optimizer_G.state[0].item())
+    w_on, s_on, n_on, steps_on = run(False)
+    w_off, s_off, n_off, steps_off = run(True)
+    assert n_on > 0 and n_off == 0, (n_on, n_off)           # the trunk's weight gradients took the producer-side check
+    assert s_on == s_off and s_on[2] == 2.0 ** 39 and steps_on == steps_off == 3
+    for k in w_on:
+        assert torch.equal(w_on[k], w_off[k]), k
