@@ -91,16 +91,16 @@ __device__ __forceinline__ unsigned cd_pixel_off(const CdArgs& g, int pb, int iy
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, bool HALF = false>
+template <int BM, int BN, bool HALF = false, int NBUF = 2>
 __global__ __launch_bounds__(256) void conv_fwd_dma_kernel(CdArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using Cfg = DgCfgG<BM, BN, 2, 2, DG_KC, DG_KC, 2>;
+    using Cfg = DgCfgG<BM, BN, 2, 2, DG_KC, DG_KC, NBUF>;
     constexpr unsigned ES = CdElem<HALF>::ES;
     constexpr int CK = CdElem<HALF>::CK;
     constexpr int MB = Cfg::MB, NB = Cfg::NB, PA = Cfg::PA, PB = Cfg::PB;
     extern __shared__ __attribute__((aligned(1024))) float cd_smem[];
     float* As0 = cd_smem;
-    float* Bs0 = cd_smem + 2 * Cfg::ASZ;
+    float* Bs0 = cd_smem + NBUF * Cfg::ASZ;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = g.B * g.OH * g.OW, N = g.Co, KT = g.KH * g.KW, K = KT * g.Ci;
@@ -169,14 +169,21 @@ __global__ __launch_bounds__(256) void conv_fwd_dma_kernel(CdArgs g) {
 #pragma unroll
         for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = f32x16{0};
     const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
-    if (c_begin < c_end) issue(c_begin, 0);
+    // NBUF LDS buffers keep NBUF - 1 chunks in flight (counted vmcnt); see cd_half_nbuf() for why everything runs two
+    constexpr int AHEAD = NBUF - 1, PER = PA + PB;
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i)
+        if (c_begin + i < c_end) issue(c_begin + i, i);
+    int cur = 0, nxt = AHEAD % NBUF;
     for (int c = c_begin; c < c_end; ++c) {
-        const int cur = (c - c_begin) & 1;
-        dg_wait_vmcnt<0>();
+        if (NBUF == 2 || c + AHEAD > c_end) dg_wait_vmcnt<0>();
+        else dg_wait_vmcnt<(AHEAD - 1) * PER>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < c_end) issue(c + 1, cur ^ 1);
+        if (c + AHEAD < c_end) issue(c + AHEAD, nxt);
         cd_chunk<HALF, MB, NB, DG_KC, DG_KC, BM, BN>(As0 + cur * Cfg::ASZ, Bs0 + cur * Cfg::BSZ, acc, wm0, wn0, lane);
+        cur = cur + 1 == NBUF ? 0 : cur + 1;
+        nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
     }
 
     float* o = g.part ? g.part + (size_t)sp * ((size_t)M * N) : g.y;
@@ -203,17 +210,17 @@ __global__ __launch_bounds__(256) void conv_fwd_dma_kernel(CdArgs g) {
 // ------------------------------------------------------------------------------------------------------------------
 // weight gradient: rows co, columns (tap, ci), reduction over output pixels (split over workgroups)
 // ------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, bool HALF = false>
+template <int BM, int BN, bool HALF = false, int NBUF = 2>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(CdArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using Cfg = DgCfgG<BM, BN, 2, 2, DG_RC, DG_RC, 2>;
+    using Cfg = DgCfgG<BM, BN, 2, 2, DG_RC, DG_RC, NBUF>;
     constexpr unsigned ES = CdElem<HALF>::ES;
     constexpr int CK = CdElem<HALF>::CK;
     constexpr int MB = Cfg::MB, NB = Cfg::NB, PA = Cfg::PA, PB = Cfg::PB;
     static_assert(BN == 64 || BN == 128, "a column tile must lie inside one tap (Ci % BN == 0; the planner checks it)");
     extern __shared__ __attribute__((aligned(1024))) float cd_smem[];
     float* As0 = cd_smem;
-    float* Bs0 = cd_smem + 2 * Cfg::ASZ;
+    float* Bs0 = cd_smem + NBUF * Cfg::ASZ;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Mpx = g.B * g.OH * g.OW, R = g.Co, N = g.KH * g.KW * g.Ci;
@@ -302,14 +309,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(CdArgs g) {
 #pragma unroll
         for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = f32x16{0};
     const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
-    if (c_begin < c_end) issue(c_begin, 0);
+    // NBUF LDS buffers keep NBUF - 1 chunks in flight (counted vmcnt); see cd_half_nbuf() for why everything runs two
+    constexpr int AHEAD = NBUF - 1, PER = PA + PB;
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i)
+        if (c_begin + i < c_end) issue(c_begin + i, i);
+    int cur = 0, nxt = AHEAD % NBUF;
     for (int c = c_begin; c < c_end; ++c) {
-        const int cur = (c - c_begin) & 1;
-        dg_wait_vmcnt<0>();
+        if (NBUF == 2 || c + AHEAD > c_end) dg_wait_vmcnt<0>();
+        else dg_wait_vmcnt<(AHEAD - 1) * PER>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < c_end) issue(c + 1, cur ^ 1);
+        if (c + AHEAD < c_end) issue(c + AHEAD, nxt);
         cd_chunk<HALF, MB, NB, DG_RC, DG_RC, BM, BN>(As0 + cur * Cfg::ASZ, Bs0 + cur * Cfg::BSZ, acc, wm0, wn0, lane);
+        cur = cur + 1 == NBUF ? 0 : cur + 1;
+        nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
     }
 
     float* o = g.part ? g.part + (size_t)sp * ((size_t)R * N) : g.y;
@@ -338,16 +352,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(CdArgs g) {
 // A: gathered rows of dY (k-contiguous, range-checked like the forward's), B: the weights viewed [(tap, co)][ci]
 // (row-contiguous: k-major LDS image, ds_read_b32 fragments).  grid = (tiles, classes, splits).
 // ------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, bool HALF = false>
+template <int BM, int BN, bool HALF = false, int NBUF = 2>
 __global__ __launch_bounds__(256) void conv_dgrad_dma_kernel(CdArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using Cfg = DgCfgG<BM, BN, 2, 2, DG_KC, DG_RC, 2>;
+    using Cfg = DgCfgG<BM, BN, 2, 2, DG_KC, DG_RC, NBUF>;
     constexpr unsigned ES = CdElem<HALF>::ES;
     constexpr int CK = CdElem<HALF>::CK;
     constexpr int MB = Cfg::MB, NB = Cfg::NB, PA = Cfg::PA, PB = Cfg::PB;
     extern __shared__ __attribute__((aligned(1024))) float cd_smem[];
     float* As0 = cd_smem;
-    float* Bs0 = cd_smem + 2 * Cfg::ASZ;
+    float* Bs0 = cd_smem + NBUF * Cfg::ASZ;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s = g.s, KT = g.KH * g.KW;
@@ -441,14 +455,21 @@ __global__ __launch_bounds__(256) void conv_dgrad_dma_kernel(CdArgs g) {
 #pragma unroll
         for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = f32x16{0};
     const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
-    if (c_begin < c_end) issue(c_begin, 0);
+    // NBUF LDS buffers keep NBUF - 1 chunks in flight (counted vmcnt); see cd_half_nbuf() for why everything runs two
+    constexpr int AHEAD = NBUF - 1, PER = PA + PB;
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i)
+        if (c_begin + i < c_end) issue(c_begin + i, i);
+    int cur = 0, nxt = AHEAD % NBUF;
     for (int c = c_begin; c < c_end; ++c) {
-        const int cur = (c - c_begin) & 1;
-        dg_wait_vmcnt<0>();
+        if (NBUF == 2 || c + AHEAD > c_end) dg_wait_vmcnt<0>();
+        else dg_wait_vmcnt<(AHEAD - 1) * PER>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < c_end) issue(c + 1, cur ^ 1);
+        if (c + AHEAD < c_end) issue(c + AHEAD, nxt);
         cd_chunk<HALF, MB, NB, DG_KC, DG_RC, BM, BN>(As0 + cur * Cfg::ASZ, Bs0 + cur * Cfg::BSZ, acc, wm0, wn0, lane);
+        cur = cur + 1 == NBUF ? 0 : cur + 1;
+        nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
     }
 
     // split-K slabs are whole dx images (classes write disjoint pixels of the same slab)
@@ -574,13 +595,28 @@ inline CdArgs cd_args(const mg_conv_geom* g) {
     return a;
 }
 // x, w: float32 tensors, or (conv_dma_half(g)) their float16 copies
-template <bool HALF>
-void conv_dma_fwd_launch_t(const CdArgs& a, const CdPlan& p, dim3 grid, hipStream_t st) {
-    if (p.bm == 128 && p.bn == 128) cd_launch(conv_fwd_dma_kernel<128, 128, HALF>, DgCfgG<128, 128, 2, 2, 0, 0, 2>::LDS_BYTES, grid, a, st);
-    else if (p.bm == 64 && p.bn == 128) cd_launch(conv_fwd_dma_kernel<64, 128, HALF>, DgCfgG<64, 128, 2, 2, 0, 0, 2>::LDS_BYTES, grid, a, st);
-    else if (p.bm == 128 && p.bn == 64) cd_launch(conv_fwd_dma_kernel<128, 64, HALF>, DgCfgG<128, 64, 2, 2, 0, 0, 2>::LDS_BYTES, grid, a, st);
-    else cd_launch(conv_fwd_dma_kernel<64, 64, HALF>, DgCfgG<64, 64, 2, 2, 0, 0, 2>::LDS_BYTES, grid, a, st);
+// LDS buffers of the float16 instances (MG_HALF_NBUF=2|3|4, default 2).  Deeper rings were measured and lose: the float16 MFMAs of
+// a chunk are 8x shorter than the DMA round trip, but three chunks in flight cost a resident workgroup per CU (128 x 128: 38.7 ->
+// 57 us on the 128-channel 64x128 layers; 64 x 64 tiles: 47 -> 48 us); the kernels' time is the same for every tile shape
+// (scripts/sweep_half_tiles.sh), i.e. neither operand bytes nor the ring depth set it
+inline int cd_half_nbuf() {
+    static const int v = [] { const char* e = getenv("MG_HALF_NBUF"); const int n = e ? atoi(e) : 2; return n < 2 ? 2 : (n > 4 ? 4 : n); }();
+    return v;
 }
+#define CD_TILE_DISPATCH(KERNEL, ALAY, BLAY, HALF_, NB_)                                                                                    \
+    do {                                                                                                                                    \
+        if (p.bm == 128 && p.bn == 128) cd_launch(KERNEL<128, 128, HALF_, NB_>, DgCfgG<128, 128, 2, 2, ALAY, BLAY, NB_>::LDS_BYTES, grid, a, st); \
+        else if (p.bm == 64 && p.bn == 128) cd_launch(KERNEL<64, 128, HALF_, NB_>, DgCfgG<64, 128, 2, 2, ALAY, BLAY, NB_>::LDS_BYTES, grid, a, st); \
+        else if (p.bm == 128 && p.bn == 64) cd_launch(KERNEL<128, 64, HALF_, NB_>, DgCfgG<128, 64, 2, 2, ALAY, BLAY, NB_>::LDS_BYTES, grid, a, st); \
+        else cd_launch(KERNEL<64, 64, HALF_, NB_>, DgCfgG<64, 64, 2, 2, ALAY, BLAY, NB_>::LDS_BYTES, grid, a, st);                            \
+    } while (0)
+#define CD_DISPATCH(KERNEL, ALAY, BLAY, half)                                                  \
+    do {                                                                                       \
+        if (!(half)) CD_TILE_DISPATCH(KERNEL, ALAY, BLAY, false, 2);                           \
+        else if (cd_half_nbuf() == 4) CD_TILE_DISPATCH(KERNEL, ALAY, BLAY, true, 4);           \
+        else if (cd_half_nbuf() == 3) CD_TILE_DISPATCH(KERNEL, ALAY, BLAY, true, 3);           \
+        else CD_TILE_DISPATCH(KERNEL, ALAY, BLAY, true, 2);                                    \
+    } while (0)
 void conv_dma_fwd_launch(const mg_conv_geom* g, const CdPlan& p, const void* x, const void* w, const float* bias, float* y,
                          int act, float* part, hipStream_t st) {
     CdArgs a = cd_args(g);
@@ -588,8 +624,7 @@ void conv_dma_fwd_launch(const mg_conv_geom* g, const CdPlan& p, const void* x, 
     const long long M = (long long)g->B * g->OH * g->OW;
     a.tiles_m = (int)((M + p.bm - 1) / p.bm); a.tiles_n = g->Co / p.bn; a.splits = p.splits; a.cps = p.cps;
     const dim3 grid((unsigned)((long long)a.tiles_m * a.tiles_n * a.splits));
-    if (conv_dma_half(g)) conv_dma_fwd_launch_t<true>(a, p, grid, st);
-    else conv_dma_fwd_launch_t<false>(a, p, grid, st);
+    CD_DISPATCH(conv_fwd_dma_kernel, 0, 0, conv_dma_half(g));
 }
 void conv_dma_wgrad_launch(const mg_conv_geom* g, const CdPlan& p, const void* x, const void* dy, float* dw, int accumulate,
                            float* part, hipStream_t st) {
@@ -597,15 +632,7 @@ void conv_dma_wgrad_launch(const mg_conv_geom* g, const CdPlan& p, const void* x
     a.x = x; a.w = dy; a.y = dw; a.part = p.splits > 1 ? part : nullptr; a.accumulate = accumulate;
     a.tiles_m = (g->Co + p.bm - 1) / p.bm; a.tiles_n = g->KH * g->KW * g->Ci / p.bn; a.splits = p.splits; a.cps = p.cps;
     const dim3 grid((unsigned)((long long)a.tiles_m * a.tiles_n * a.splits));
-    const bool half = conv_dma_half(g);
-    auto go = [&](auto kh, auto kf, size_t lds) {
-        if (half) cd_launch(kh, lds, grid, a, st);
-        else cd_launch(kf, lds, grid, a, st);
-    };
-    if (p.bm == 128 && p.bn == 128) go(conv_wgrad_dma_kernel<128, 128, true>, conv_wgrad_dma_kernel<128, 128, false>, DgCfgG<128, 128, 2, 2, 1, 1, 2>::LDS_BYTES);
-    else if (p.bm == 64 && p.bn == 128) go(conv_wgrad_dma_kernel<64, 128, true>, conv_wgrad_dma_kernel<64, 128, false>, DgCfgG<64, 128, 2, 2, 1, 1, 2>::LDS_BYTES);
-    else if (p.bm == 128) go(conv_wgrad_dma_kernel<128, 64, true>, conv_wgrad_dma_kernel<128, 64, false>, DgCfgG<128, 64, 2, 2, 1, 1, 2>::LDS_BYTES);
-    else go(conv_wgrad_dma_kernel<64, 64, true>, conv_wgrad_dma_kernel<64, 64, false>, DgCfgG<64, 64, 2, 2, 1, 1, 2>::LDS_BYTES);
+    CD_DISPATCH(conv_wgrad_dma_kernel, 1, 1, conv_dma_half(g));
 }
 
 // data gradient: the plan is made for the heaviest parity class (M = pixels of one class, all taps / stride^2 of the chunks)
@@ -649,13 +676,6 @@ inline CdPlan conv_dma_dgrad_plan(const mg_conv_geom* g) {
     }
     return best;
 }
-template <bool HALF>
-void conv_dma_dgrad_launch_t(const CdArgs& a, const CdPlan& p, dim3 grid, hipStream_t st) {
-    if (p.bm == 128 && p.bn == 128) cd_launch(conv_dgrad_dma_kernel<128, 128, HALF>, DgCfgG<128, 128, 2, 2, 0, 1, 2>::LDS_BYTES, grid, a, st);
-    else if (p.bm == 64 && p.bn == 128) cd_launch(conv_dgrad_dma_kernel<64, 128, HALF>, DgCfgG<64, 128, 2, 2, 0, 1, 2>::LDS_BYTES, grid, a, st);
-    else if (p.bm == 128 && p.bn == 64) cd_launch(conv_dgrad_dma_kernel<128, 64, HALF>, DgCfgG<128, 64, 2, 2, 0, 1, 2>::LDS_BYTES, grid, a, st);
-    else cd_launch(conv_dgrad_dma_kernel<64, 64, HALF>, DgCfgG<64, 64, 2, 2, 0, 1, 2>::LDS_BYTES, grid, a, st);
-}
 void conv_dma_dgrad_launch(const mg_conv_geom* g, const CdPlan& p, const void* dy, const void* w, const float* bias, float* dx,
                            int act, float* part, hipStream_t st, int round_f16) {
     CdArgs a = cd_args(g);
@@ -671,6 +691,5 @@ void conv_dma_dgrad_launch(const mg_conv_geom* g, const CdPlan& p, const void* d
     const long long slots = 256LL * (p.bm == 64 && p.bn == 64 ? 5 : (p.bm == 128 && p.bn == 128 ? 2 : 3));
     a.cls_order = (long long)grid.x * grid.y * grid.z <= slots ? 1 : 0;
     if (const char* e = getenv("MG_DGRAD_CLASS_ORDER")) a.cls_order = e[0] == '1' ? 1 : 0;
-    if (conv_dma_half(g)) conv_dma_dgrad_launch_t<true>(a, p, grid, st);
-    else conv_dma_dgrad_launch_t<false>(a, p, grid, st);
+    CD_DISPATCH(conv_dgrad_dma_kernel, 0, 1, conv_dma_half(g));
 }

@@ -2514,6 +2514,8 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
         if (pass == 0) deep = h16_deep(px, g->Co, h16_plan(px, g->Co, Kw, false).splits, false);
         else if (pass == 1) deep = h16_deep((long long)g->B * g->H * g->W, g->Ci, h16_plan((long long)g->B * g->H * g->W, g->Ci, g->KH * g->KW * g->Co, true).splits, true);
         else deep = h16_deep(g->Co, Kw, h16_plan(g->Co, Kw, h16_mp(px), false).splits, false);
+        if (pass == 2 && h16_wgrad_as(g)) snprintf(out, out_len, "hgemm_as_kernel<%d, false>", h16_mp(px) / 64);
+        else
         snprintf(out, out_len, pass == 1 ? "hgemm_kernel<128, 128, 4, 2, true, %d>" : "hgemm_kernel<128, 128, 4, 2, false, %d>", deep ? 3 : 2);
     } else if (wino_ok(g) && !kq && !(pass == 1 && wino_dgrad_padded()) &&
         dense_plan(pass, 16, wino_dims(g).T, g->Co, g->Ci, prec_h(g)).ok) {
@@ -2596,13 +2598,13 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
     } else if (pass == 1 && cd_dgrad_any(g) && !smallc_dgrad_ok(g)) {
         mg_conv_geom gp;
         const CdPlan cp = conv_dma_dgrad_ok(g) ? conv_dma_dgrad_plan(g) : (cd_reflect_dgrad_geom(g, &gp), conv_dma_dgrad_plan(&gp));
-        snprintf(out, out_len, "conv_dgrad_dma_kernel<%d, %d, %s>", cp.bm, cp.bn, prec_h(g) ? "true" : "false");
+        snprintf(out, out_len, "conv_dgrad_dma_kernel<%d, %d, %s, %d>", cp.bm, cp.bn, prec_h(g) ? "true" : "false", prec_h(g) ? cd_half_nbuf() : 2);
     } else if (pass == 0 && conv_dma_fwd_ok(g)) {
         const CdPlan cp = conv_dma_fwd_plan(g);
-        snprintf(out, out_len, "conv_fwd_dma_kernel<%d, %d, %s>", cp.bm, cp.bn, prec_h(g) ? "true" : "false");
+        snprintf(out, out_len, "conv_fwd_dma_kernel<%d, %d, %s, %d>", cp.bm, cp.bn, prec_h(g) ? "true" : "false", prec_h(g) ? cd_half_nbuf() : 2);
     } else if (pass == 2 && conv_dma_wgrad_ok(g)) {
         const CdPlan cp = conv_dma_wgrad_plan(g);
-        snprintf(out, out_len, "conv_wgrad_dma_kernel<%d, %d, %s>", cp.bm, cp.bn, prec_h(g) ? "true" : "false");
+        snprintf(out, out_len, "conv_wgrad_dma_kernel<%d, %d, %s, %d>", cp.bm, cp.bn, prec_h(g) ? "true" : "false", prec_h(g) ? cd_half_nbuf() : 2);
     } else if (pass == 0) {
         const TilePlan tp = fwd_plan(g);
         const bool vec16 = g->Ci % BK == 0;

@@ -280,7 +280,7 @@ struct DgCfgG {
     static constexpr int ASZ = BM * DG_BK, BSZ = BN * DG_BK;          // floats per buffer, unpadded
     static constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;          // 1 KiB pieces per wave and chunk
     static constexpr size_t LDS_BYTES = (size_t)NBUF * (ASZ + BSZ) * sizeof(float);
-    static_assert(NBUF == 2 || NBUF == 3, "two or three LDS buffers");
+    static_assert(NBUF >= 2 && NBUF <= 4, "two to four LDS buffers");
     static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "pieces must divide evenly over the waves");
 };
 

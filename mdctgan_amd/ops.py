@@ -77,7 +77,7 @@ def tiles_are_casts(g: ConvGeom) -> bool:
     hit = _CASTS.get(key)
     if hit is None:
         name = plan_name(2, g)
-        half = g.precision == _lib.PRECISION_F16 and name.startswith("conv_wgrad_dma_kernel") and name.endswith("true>")
+        half = g.precision == _lib.PRECISION_F16 and name.startswith("conv_wgrad_dma_kernel") and ", true" in name
         # ... and the single-output-channel tap GEMMs (csrc/conv_co1.h): md is the scattered dy, there is no v
         co1 = g.Co == 1 and wino_weights_bytes(g) == 64 * g.Ci * 4
         hit = _CASTS[key] = half or co1

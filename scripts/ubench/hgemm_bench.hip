@@ -76,6 +76,7 @@ int main(int argc, char** argv) {
         {"cfg1 1024ch wgrad    px1024", 1024, 9216, 1024},
         {"ladder 1024->2048    px256", 256, 2048, 9216},
         {"square 4096", 4096, 4096, 4096},
+        {"local128 as a dense GEMM (65536 px x 128 co, K = 9 x 128)", 65536, 128, 1152},
     };
     hipStream_t st; hipStreamCreate(&st);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
