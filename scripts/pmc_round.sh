@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 pass() {   # name counter cmd...
     name=$1; ctr=$2; shift 2
     rm -rf /tmp/pmc_$name_$ctr
-    rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmc_${name}_$ctr --output-format csv -- "$@" > /dev/null 2>&1
+    timeout 200 rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmc_${name}_$ctr --output-format csv -- "$@" > /dev/null 2>&1
     find /tmp/pmc_${name}_$ctr -name "*counter_collection.csv" | head -1
 }
 # the 1024-channel trunk layer of configs[1] (the dominant GEMM's layer)
@@ -18,4 +18,11 @@ python $R/scripts/pmc_traffic.py $f $w $out/${tag}_pmc_hbm_traffic.csv $R/profil
 f=$(pass mdct FETCH_SIZE $R/scripts/ubench/mdct_bs_bench 4096)
 w=$(pass mdct WRITE_SIZE $R/scripts/ubench/mdct_bs_bench 4096)
 python $R/scripts/pmc_traffic.py $f $w $out/${tag}_pmc_hbm_traffic_codec.csv $R/profiles/traffic.json "codec"
+# the dominant kernels of the other bench lines (same symbols, other layer shapes): one section each
+for spec in "configs[1] --fp16:c1h:bottleneck:--f16" "configs[2]:c2:trunk2048:" "configs[2] --fp16:c2h:trunk2048:--f16" "configs[4]:c4:bottleneck_b64:"; do
+    section=${spec%%:*}; rest=${spec#*:}; key=${rest%%:*}; rest=${rest#*:}; layer=${rest%%:*}; flag=${rest#*:}
+    f=$(pass $key FETCH_SIZE python $R/scripts/bench_conv.py --only $layer --iters 2 $flag)
+    w=$(pass $key WRITE_SIZE python $R/scripts/bench_conv.py --only $layer --iters 2 $flag)
+    python $R/scripts/pmc_traffic.py $f $w $out/${tag}_pmc_hbm_traffic_$key.csv $R/profiles/traffic.json "$section" > /dev/null
+done
 cp $R/profiles/traffic.json $out/${tag}_traffic.json
