@@ -185,7 +185,12 @@ typedef struct {
     const float* add;   /* mg_conv_dgrad_w only, any geometry: dx += add ([B,H,W,Ci]) -- the gradient a skip connection brings to
                          * the same tensor (ResnetBlock, models/networks.py:462), folded into the call's last kernel where the path
                          * allows and added by a separate pass otherwise; NULL for every other call */
+    unsigned flags;     /* MG_TILES_*_FILLED (MG_PRECISION_F16 layers whose tiles are plain float16 copies): the copy is already in
+                         * the buffer -- written by the kernel that produced x / dy (mg_instnorm_fwd_h, mg_instnorm_bwd_h,
+                         * mg_conv_fwd_instnorm_h) -- so the call skips its own cast pass.  Paths that do not use the copy ignore it. */
 } mg_wino_tiles;
+#define MG_TILES_V_FILLED 1u    /* mg_conv_fwd_w: v holds float16(x) */
+#define MG_TILES_MD_FILLED 2u   /* mg_conv_dgrad_w: md holds float16(dy) */
 size_t mg_conv_wino_weights_bytes(const mg_conv_geom* g);
 size_t mg_conv_wino_tiles_bytes(const mg_conv_geom* g, int which);
 int mg_conv_wino_prepare(const mg_conv_geom* g, const float* w, float* u, void* stream);
@@ -209,6 +214,11 @@ int mg_conv_fwd_instnorm_w(const mg_conv_geom* g, const float* x, const float* w
 int mg_conv_wino_md_from_norm_ok(const mg_conv_geom* g);
 int mg_instnorm_bwd_wino_md(const mg_conv_geom* g, const float* gy, const float* y_raw, const float* mean, const float* rstd,
                             int act, float* md, void* stream);
+/* mg_conv_fwd_instnorm_w that also writes float16(y) (y16: B*OH*OW*Co halves, 8-byte aligned; NULL = none) for the next
+ * MG_PRECISION_F16 layer's MG_TILES_V_FILLED.  MG_PRECISION_F16 geometries only (MG_ERR_UNSUPPORTED otherwise). */
+int mg_conv_fwd_instnorm_h(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y_raw, float eps,
+                           int act, const float* residual, float* y, float* mean, float* rstd, void* workspace,
+                           size_t workspace_bytes, void* stream, const mg_wino_tiles* tiles, void* y16);
 int mg_conv_dgrad_w(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
                     void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* tiles);
 /* dw [Co, KH, KW, Ci] = sum over pixels; dbias [Co] (nullable) = column sums of dy.
@@ -269,6 +279,13 @@ int mg_instnorm_fwd(const float* x, int B, int HW, int C, float eps, int act, co
 int mg_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, int B, int HW, int C,
                     int act, float* dx, void* workspace, size_t workspace_bytes, void* stream);
 size_t mg_instnorm_workspace(int B, int HW, int C);
+/* --fp16 (train.py:161-164): the same two calls, additionally writing the float16 copy of their output (y16 / dx16: B*HW*C
+ * halves, 8-byte aligned, C % 4 == 0; NULL = none) -- the operand staging the next autocast convolution would otherwise do in
+ * a cast pass of its own (hand it over with MG_TILES_V_FILLED / MG_TILES_MD_FILLED).  The float32 results are unchanged. */
+int mg_instnorm_fwd_h(const float* x, int B, int HW, int C, float eps, int act, const float* residual, float* y,
+                      float* mean, float* rstd, void* workspace, size_t workspace_bytes, void* stream, void* y16);
+int mg_instnorm_bwd_h(const float* dy, const float* x, const float* mean, const float* rstd, int B, int HW, int C,
+                      int act, float* dx, void* workspace, size_t workspace_bytes, void* stream, void* dx16);
 
 /* ------------------------------------------------------------------------------------------
  * K10  bottleneck-transformer block pieces (bottleneck_transformer_pytorch==0.1.4 BottleStack, call sites

@@ -35,7 +35,7 @@ _G = C.POINTER(ConvGeom)
 
 class WinoTiles(C.Structure):
     """mg_wino_tiles: caller-held Winograd images (u: transformed weights, v: B^T x B, md: A dy A^T)."""
-    _fields_ = [("u", C.c_void_p), ("v", C.c_void_p), ("md", C.c_void_p), ("add", C.c_void_p)]
+    _fields_ = [("u", C.c_void_p), ("v", C.c_void_p), ("md", C.c_void_p), ("add", C.c_void_p), ("flags", C.c_uint)]
 
 
 _W = C.POINTER(WinoTiles)
@@ -67,6 +67,7 @@ SIGNATURES = {
     "mg_conv_wino_md_from_norm_ok": (_i, [_G]),
     "mg_instnorm_bwd_wino_md": (_i, [_G, _p, _p, _p, _p, _i, _p, _p]),
     "mg_conv_fwd_instnorm_w": (_i, [_G, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _sz, _p, _W]),
+    "mg_conv_fwd_instnorm_h": (_i, [_G, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _sz, _p, _W, _p]),
     "mg_conv_dgrad_w": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p, _W]),
     "mg_conv_wgrad_w": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p, _W]),
     "mg_conv_wgrad_chk": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p, _W, _p]),
@@ -96,6 +97,8 @@ SIGNATURES = {
     "mg_colsum_workspace": (_sz, [_ll, _i]),
     "mg_instnorm_fwd": (_i, [_p, _i, _i, _i, _f, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "mg_instnorm_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _sz, _p]),
+    "mg_instnorm_fwd_h": (_i, [_p, _i, _i, _i, _f, _i, _p, _p, _p, _p, _p, _sz, _p, _p]),
+    "mg_instnorm_bwd_h": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _sz, _p, _p]),
     "mg_instnorm_workspace": (_sz, [_i, _i, _i]),
     "mg_batchnorm_workspace": (_sz, [_i]),
     "mg_batchnorm_slices": (_i, []),

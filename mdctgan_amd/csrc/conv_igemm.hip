@@ -1367,7 +1367,7 @@ inline size_t cd_reflect_dxp_bytes(const mg_conv_geom* gp) { return cd_al((size_
 // the DMA data gradient proper.  wsp: cd_dgrad_ws(g) bytes (may be null when nothing is needed); round_f16: autocast output
 // rounding of the direct result (the reflect wrapper rounds after its fold instead)
 int cd_dgrad_run(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act, char* wsp,
-                 hipStream_t st, const float* u, float* md, int round_f16);
+                 hipStream_t st, const float* u, float* md, int round_f16, int dy16_filled = 0);
 // a layer any of whose passes runs on the float16 implicit GEMMs keeps a cached float16 copy of its weights
 // (mutually exclusive with the Winograd path, which the pass entry points try FIRST: a layer that is wino_ok() keeps
 // float32 U / V / Md images under MG_PRECISION_F16, so it must never be handed the float16-sized buffers of this path)
@@ -1382,14 +1382,15 @@ inline bool cd_dgrad_any(const mg_conv_geom* g) {
     return conv_dma_dgrad_ok(g) || cd_reflect_dgrad_geom(g, &gp);
 }
 int cd_dgrad_run(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act, char* wsp,
-                 hipStream_t st, const float* u, float* md, int round_f16) {
+                 hipStream_t st, const float* u, float* md, int round_f16, int dy16_filled) {
     CdPlan cp = conv_dma_dgrad_plan(g);
     const bool half = conv_dma_half(g);
     const void* dyin = dy;
     const void* win = w;
     if (half) {
         void* dy16 = md ? (void*)md : (void*)wsp;      // shared with the weight gradient
-        cd_cast16(dy, dy16, (size_t)g->B * g->OH * g->OW * g->Co, st);
+        if (!(md && dy16_filled))                      // MG_TILES_MD_FILLED: the producer of dy wrote the copy (mg_instnorm_bwd_h)
+            cd_cast16(dy, dy16, (size_t)g->B * g->OH * g->OW * g->Co, st);
         dyin = dy16;
         wsp += conv_dma_h_dy_bytes(g);
         if (u) {
@@ -2771,6 +2772,12 @@ size_t mg_conv_fwd_instnorm_workspace(const mg_conv_geom* g) {
 int mg_conv_fwd_instnorm_w(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y_raw, float eps,
                            int act, const float* residual, float* y, float* mean, float* rstd, void* workspace,
                            size_t workspace_bytes, void* stream, const mg_wino_tiles* wt) {
+    return mg_conv_fwd_instnorm_h(g, x, w, bias, y_raw, eps, act, residual, y, mean, rstd, workspace, workspace_bytes, stream, wt, nullptr);
+}
+int mg_conv_fwd_instnorm_h(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y_raw, float eps,
+                           int act, const float* residual, float* y, float* mean, float* rstd, void* workspace,
+                           size_t workspace_bytes, void* stream, const mg_wino_tiles* wt, void* y16) {
+    if (y16 && !prec_h(g)) return MG_ERR_UNSUPPORTED;          // the float32 layers' fused inverse transform + norm has no float16 output
     if (!geom_ok(g) || !x || !w || !y_raw || !y || !mean || !rstd) return MG_ERR_ARG;
     if (!wino_tiles_ok(g, wt)) return MG_ERR_ARG;
     if (!workspace || workspace_bytes < mg_conv_fwd_instnorm_workspace(g)) return MG_ERR_ARG;
@@ -2783,7 +2790,7 @@ int mg_conv_fwd_instnorm_w(const mg_conv_geom* g, const float* x, const float* w
     }
     const int rc = mg_conv_fwd_w(g, x, w, bias, y_raw, MG_ACT_NONE, workspace, workspace_bytes, stream, wt);
     if (rc != MG_OK) return rc;
-    return mg_instnorm_fwd(y_raw, g->B, g->OH * g->OW, g->Co, eps, act, residual, y, mean, rstd, workspace, workspace_bytes, stream);
+    return mg_instnorm_fwd_h(y_raw, g->B, g->OH * g->OW, g->Co, eps, act, residual, y, mean, rstd, workspace, workspace_bytes, stream, y16);
 }
 
 int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
@@ -2834,7 +2841,8 @@ int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const f
         char* wsp = (char*)workspace;
         if (cd_half) {          // float16 copies: the activation by a cast pass, the weights from the cache when there is one
             void* x16 = (wt && wt->v) ? (void*)wt->v : (void*)wsp;         // kept by the caller for the weight gradient
-            cd_cast16(x, x16, (size_t)g->B * g->H * g->W * g->Ci, st);
+            if (!(wt && wt->v && (wt->flags & MG_TILES_V_FILLED)))         // ... unless x's producer already wrote it (mg_instnorm_fwd_h)
+                cd_cast16(x, x16, (size_t)g->B * g->H * g->W * g->Ci, st);
             xin = x16;
             wsp += conv_dma_h_x_bytes(g);
             if (u) {
@@ -2949,12 +2957,13 @@ static int dgrad_dispatch(const mg_conv_geom* g, const float* dy, const float* w
         workspace_bytes >= mg_conv_dgrad_workspace(g)) {
         float* md = wt ? wt->md : nullptr;
         if (conv_dma_dgrad_ok(g))
-            return cd_dgrad_run(g, dy, w, bias, dx, act, (char*)workspace, st, u, md, conv_dma_half(g) ? 1 : 0);
+            return cd_dgrad_run(g, dy, w, bias, dx, act, (char*)workspace, st, u, md, conv_dma_half(g) ? 1 : 0,
+                                (wt && (wt->flags & MG_TILES_MD_FILLED)) ? 1 : 0);
         mg_conv_geom gp;
         if (!bias && act == MG_ACT_NONE && cd_reflect_dgrad_geom(g, &gp)) {
             float* dxp = (float*)workspace;
             const int rc = cd_dgrad_run(&gp, dy, w, nullptr, dxp, MG_ACT_NONE, (char*)workspace + cd_reflect_dxp_bytes(&gp), st, u,
-                                        md, 0);
+                                        md, 0, (wt && (wt->flags & MG_TILES_MD_FILLED)) ? 1 : 0);
             if (rc != MG_OK) return rc;
             hipLaunchKernelGGL(wino_fold_reflect_kernel, dim3(wino_grid((size_t)g->B * g->H * g->W * g->Ci / 4)), dim3(256), 0,
                                st, (const float*)dxp, g->B, g->H, g->W, g->Ci, dx, (int)prec_h(g));

@@ -144,10 +144,13 @@ __global__ void norm_finalize_kernel(const double* __restrict__ part, int B, int
     }
 }
 
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+
 template <bool VEC>
 __global__ void norm_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                       const float* __restrict__ rstd, const float* __restrict__ residual, int HW,
-                                      int C, int act, float* __restrict__ y, size_t total) {
+                                      int C, int act, float* __restrict__ y, size_t total, _Float16* __restrict__ y16 = nullptr) {
+    // y16 (optional, autocast): the float16 copy the next convolution's operand staging would otherwise make in a pass of its own
     constexpr int V = VEC ? 4 : 1;
     const size_t per_b = (size_t)HW * C;
     for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < total;
@@ -168,10 +171,12 @@ __global__ void norm_apply_fwd_kernel(const float* __restrict__ x, const float* 
                 o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
             }
             *reinterpret_cast<float4*>(y + i) = o;
+            if (y16) *reinterpret_cast<h16x4*>(y16 + i) = h16x4{(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
         } else {
             float o = act_fwd((x[i] - mean[b * C + c]) * rstd[b * C + c], act);
             if (residual) o += residual[i];
             y[i] = o;
+            if (y16) y16[i] = (_Float16)o;
         }
     }
 }
@@ -180,7 +185,7 @@ template <bool VEC>
 __global__ void norm_apply_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                       const float* __restrict__ m1, const float* __restrict__ m2, int HW, int C,
-                                      int act, float* __restrict__ dx, size_t total) {
+                                      int act, float* __restrict__ dx, size_t total, _Float16* __restrict__ dx16 = nullptr) {
     constexpr int V = VEC ? 4 : 1;
     const size_t per_b = (size_t)HW * C;
     for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < total;
@@ -203,8 +208,13 @@ __global__ void norm_apply_bwd_kernel(const float* __restrict__ dy, const float*
             const float gq = gv[j] * act_grad_pre(xh, act);
             o[j] = rs * (gq - m1[sc] - xh * m2[sc]);
         }
-        if (VEC) *reinterpret_cast<float4*>(dx + i) = *reinterpret_cast<float4*>(o);
-        else dx[i] = o[0];
+        if (VEC) {
+            *reinterpret_cast<float4*>(dx + i) = *reinterpret_cast<float4*>(o);
+            if (dx16) *reinterpret_cast<h16x4*>(dx16 + i) = h16x4{(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+        } else {
+            dx[i] = o[0];
+            if (dx16) dx16[i] = (_Float16)o[0];
+        }
     }
 }
 
@@ -252,7 +262,7 @@ template <int NP>
 __global__ __launch_bounds__(256) void norm_slab_fwd_kernel(const float* __restrict__ x, int HW, int C, float eps,
                                                             int act, const float* __restrict__ residual,
                                                             float* __restrict__ y, float* __restrict__ mean,
-                                                            float* __restrict__ rstd) {
+                                                            float* __restrict__ rstd, _Float16* __restrict__ y16 = nullptr) {
     __shared__ double red[2][32][32];
     const int cq = threadIdx.x & 7, pl = threadIdx.x >> 3;
     const int b = blockIdx.y, c0 = blockIdx.x * 32 + 4 * cq;
@@ -300,6 +310,7 @@ __global__ __launch_bounds__(256) void norm_slab_fwd_kernel(const float* __restr
                 o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
             }
             *reinterpret_cast<float4*>(y + base + (size_t)p * C) = o;
+            if (y16) *reinterpret_cast<h16x4*>(y16 + base + (size_t)p * C) = h16x4{(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
         }
     }
 }
@@ -308,7 +319,7 @@ template <int NP>
 __global__ __launch_bounds__(256) void norm_slab_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, int HW, int C, int act,
-                                                            float* __restrict__ dx) {
+                                                            float* __restrict__ dx, _Float16* __restrict__ dx16 = nullptr) {
     __shared__ double red[2][32][32];
     const int cq = threadIdx.x & 7, pl = threadIdx.x >> 3;
     const int b = blockIdx.y, c0 = blockIdx.x * 32 + 4 * cq;
@@ -353,6 +364,7 @@ __global__ __launch_bounds__(256) void norm_slab_bwd_kernel(const float* __restr
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = rs[j] * (gq[i][j] - m1[j] - xh[i][j] * m2[j]);
             *reinterpret_cast<float4*>(dx + base + (size_t)p * C) = *reinterpret_cast<float4*>(o);
+            if (dx16) *reinterpret_cast<h16x4*>(dx16 + base + (size_t)p * C) = h16x4{(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
         }
     }
 }
@@ -669,12 +681,18 @@ size_t mg_instnorm_workspace(int B, int HW, int C) {
 
 int mg_instnorm_fwd(const float* x, int B, int HW, int C, float eps, int act, const float* residual, float* y,
                     float* mean, float* rstd, void* workspace, size_t workspace_bytes, void* stream) {
+    return mg_instnorm_fwd_h(x, B, HW, C, eps, act, residual, y, mean, rstd, workspace, workspace_bytes, stream, nullptr);
+}
+int mg_instnorm_fwd_h(const float* x, int B, int HW, int C, float eps, int act, const float* residual, float* y,
+                      float* mean, float* rstd, void* workspace, size_t workspace_bytes, void* stream, void* y16v) {
+    _Float16* y16 = (_Float16*)y16v;
+    if (y16 && ((reinterpret_cast<uintptr_t>(y16) & 7) != 0 || C % 4 != 0)) return MG_ERR_ARG;
     if (!x || !y || !mean || !rstd || !workspace || B <= 0 || HW <= 0 || C <= 0) return MG_ERR_ARG;
     if (workspace_bytes < mg_instnorm_workspace(B, HW, C)) return MG_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (const int np = slab_np(HW, C); np && al16(x) && al16(y) && al16(mean) && al16(rstd) && (!residual || al16(residual))) {
         const dim3 grid(C / 32, B);
-#define MG_SLAB_FWD(NP_) hipLaunchKernelGGL(norm_slab_fwd_kernel<NP_>, grid, dim3(256), 0, st, x, HW, C, eps, act, residual, y, mean, rstd)
+#define MG_SLAB_FWD(NP_) hipLaunchKernelGGL(norm_slab_fwd_kernel<NP_>, grid, dim3(256), 0, st, x, HW, C, eps, act, residual, y, mean, rstd, y16)
         if (np == 4) MG_SLAB_FWD(4); else if (np == 8) MG_SLAB_FWD(8); else if (np == 16) MG_SLAB_FWD(16); else MG_SLAB_FWD(20);
 #undef MG_SLAB_FWD
         MG_CHECK_LAUNCH();
@@ -694,22 +712,28 @@ int mg_instnorm_fwd(const float* x, int B, int HW, int C, float eps, int act, co
     const bool vec = (C % 4 == 0) && al16(x) && al16(y) && (!residual || al16(residual));
     if (vec)
         hipLaunchKernelGGL(norm_apply_fwd_kernel<true>, dim3(grid_for(total, 4)), dim3(256), 0, st, x, mean, rstd,
-                           residual, HW, C, act, y, total);
+                           residual, HW, C, act, y, total, y16);
     else
         hipLaunchKernelGGL(norm_apply_fwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, x, mean, rstd,
-                           residual, HW, C, act, y, total);
+                           residual, HW, C, act, y, total, y16);
     MG_CHECK_LAUNCH();
     return MG_OK;
 }
 
 int mg_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, int B, int HW, int C,
                     int act, float* dx, void* workspace, size_t workspace_bytes, void* stream) {
+    return mg_instnorm_bwd_h(dy, x, mean, rstd, B, HW, C, act, dx, workspace, workspace_bytes, stream, nullptr);
+}
+int mg_instnorm_bwd_h(const float* dy, const float* x, const float* mean, const float* rstd, int B, int HW, int C,
+                      int act, float* dx, void* workspace, size_t workspace_bytes, void* stream, void* dx16v) {
+    _Float16* dx16 = (_Float16*)dx16v;
+    if (dx16 && ((reinterpret_cast<uintptr_t>(dx16) & 7) != 0 || C % 4 != 0)) return MG_ERR_ARG;
     if (!dy || !x || !mean || !rstd || !dx || !workspace || B <= 0 || HW <= 0 || C <= 0) return MG_ERR_ARG;
     if (workspace_bytes < mg_instnorm_workspace(B, HW, C)) return MG_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (const int np = slab_np(HW, C); np && al16(x) && al16(dy) && al16(dx) && al16(mean) && al16(rstd)) {
         const dim3 grid(C / 32, B);
-#define MG_SLAB_BWD(NP_) hipLaunchKernelGGL(norm_slab_bwd_kernel<NP_>, grid, dim3(256), 0, st, dy, x, mean, rstd, HW, C, act, dx)
+#define MG_SLAB_BWD(NP_) hipLaunchKernelGGL(norm_slab_bwd_kernel<NP_>, grid, dim3(256), 0, st, dy, x, mean, rstd, HW, C, act, dx, dx16)
         if (np == 4) MG_SLAB_BWD(4); else if (np == 8) MG_SLAB_BWD(8); else if (np == 16) MG_SLAB_BWD(16); else MG_SLAB_BWD(20);
 #undef MG_SLAB_BWD
         MG_CHECK_LAUNCH();
@@ -731,10 +755,10 @@ int mg_instnorm_bwd(const float* dy, const float* x, const float* mean, const fl
     const bool vec = (C % 4 == 0) && al16(x) && al16(dy) && al16(dx);
     if (vec)
         hipLaunchKernelGGL(norm_apply_bwd_kernel<true>, dim3(grid_for(total, 4)), dim3(256), 0, st, dy, x, mean, rstd,
-                           m1, m2, HW, C, act, dx, total);
+                           m1, m2, HW, C, act, dx, total, dx16);
     else
         hipLaunchKernelGGL(norm_apply_bwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, dy, x, mean, rstd,
-                           m1, m2, HW, C, act, dx, total);
+                           m1, m2, HW, C, act, dx, total, dx16);
     MG_CHECK_LAUNCH();
     return MG_OK;
 }

@@ -13,7 +13,7 @@ import os
 
 import torch
 
-from . import amp, ops
+from . import _lib, amp, ops
 from ._lib import ACT_LRELU02, ACT_NONE, ACT_RELU, ACT_TANH  # noqa: F401
 
 CL = torch.channels_last
@@ -37,6 +37,41 @@ def nchw_view(y):
 # ------------------------------------------------------------------------------------------------
 # fused gradient accumulation
 # ------------------------------------------------------------------------------------------------
+# --fp16: a kernel that produces an activation (InstanceNorm forward) or an activation gradient (InstanceNorm backward) can
+# write the float16 copy the next autocast convolution stages its operand from, instead of that convolution running a cast
+# pass of its own (68 launches / 0.47 ms per configs[2] step).  The copy travels as an attribute of the tensor it mirrors and
+# is only trusted while that tensor is the very one it was made from (storage address, version counter, size).
+# MG_NO_H16_PRODUCER=1 turns the mechanism off (same results: the cast rounds the same float32 values).
+H16_STATS = {"made": 0, "used_fwd": 0, "used_bwd": 0}
+
+
+def _want_h16(B, HW, C, half=None):
+    """Worth writing a float16 copy beside a [B, HW, C] float32 tensor?  Autocast only (half: the forward's precision -- the
+    backward pass runs outside the autocast context); channel counts the float16 implicit GEMMs take (C % 64 == 0);
+    activation-dominated sizes (a tensor whose consumer streams weights, pixels <= 2 C, is im2col'ed from float32 by
+    conv_h16.h instead)."""
+    if half is None:
+        half = amp.current_precision() == _lib.PRECISION_F16
+    return bool(half) and C % 64 == 0 and B * HW > 2 * C and os.environ.get("MG_NO_H16_PRODUCER", "0") != "1"
+
+
+def _attach_h16(t, buf):
+    if buf is not None:
+        t._mg_h16 = (buf, t.data_ptr(), t._version, t.numel())
+        H16_STATS["made"] += 1
+    return t
+
+
+def _h16_of(t):
+    rec = getattr(t, "_mg_h16", None)
+    if rec is None:
+        return None
+    buf, ptr, ver, n = rec
+    if t.data_ptr() != ptr or t._version != ver or t.numel() != n or not t.is_contiguous(memory_format=CL):
+        return None
+    return buf
+
+
 def grad_buffer(p: torch.nn.Parameter):
     """(buffer, accumulate?) for a parameter: allocates p.grad with p's own strides on first use; a buffer that
     was handed out fresh (after zero_grad) is overwritten by the first kernel and accumulated into afterwards."""
@@ -293,11 +328,15 @@ class _ConvFn(torch.autograd.Function):
             else:
                 u = None
             # ... and keep B^T x B for the weight gradient (A dy A^T is shared between dgrad and wgrad in backward)
-            v = None
-            if u is not None and weight_grad and weight.requires_grad:
+            v, v_filled = None, False
+            x16 = _h16_of(x) if ops.precast_ok(0, g) else None
+            if x16 is not None:                  # x's producer already wrote float16(x): the call skips its cast pass
+                v, v_filled = x16, True
+                H16_STATS["used_fwd"] += 1
+            elif u is not None and weight_grad and weight.requires_grad:
                 v, _ = ops.wino_tile_buffers(g, x.device, want_md=False)
-            y = ops.conv_fwd(g, nhwc_view(x), w, b, act, u, v)
-            ctx.u, ctx.v = u, v
+            y = ops.conv_fwd(g, nhwc_view(x), w, b, act, u, v, v_filled)
+            ctx.u, ctx.v = u, (v if (weight_grad and weight.requires_grad) else None)
         else:
             # nn.ConvTranspose2d(k, stride, pad, output_padding = stride - 1): the data gradient of the conv
             # high-res [B, sH, sW, Cout_T] -> low-res [B, H, W, Cin_T]
@@ -308,8 +347,11 @@ class _ConvFn(torch.autograd.Function):
             assert (g.OH, g.OW) == (H, W), "unsupported ConvTranspose2d geometry"
             # the weight image (Winograd U / float16 copy) serves this call and the backward's data gradient
             u = _weight_image(g, weight) if (ctx.needs_input_grad[0] and x.is_cuda) else None
-            y = ops.conv_dgrad(g, nhwc_view(x), w, b, act, u=u)
-            ctx.u, ctx.v = u, None
+            x16 = _h16_of(x) if ops.precast_ok(1, g) else None       # x plays dy in this call
+            if x16 is not None:
+                H16_STATS["used_fwd"] += 1
+            y = ops.conv_dgrad(g, nhwc_view(x), w, b, act, u=u, md_out=x16, md_filled=x16 is not None)
+            ctx.u, ctx.v = u, (x16 if (weight_grad and weight.requires_grad) else None)
         y = nchw_view(y)
         ctx.g, ctx.cfg = g, cfg
         ctx.weight, ctx.bias = weight, bias
@@ -339,26 +381,37 @@ def _conv_backward(ctx, gy, x, y):
         x, gy = x[:rows], gy[:rows]
         y = y[:rows] if y is not None else None
         g = ops.conv_geom(rows, g.H, g.W, g.Ci, g.Co, g.KH, g.KW, g.stride, g.pad, g.reflect, g.precision)
+    # float16(gy) written by gy's producer (an InstanceNorm backward): only for the whole, untouched tensor
+    g16 = _h16_of(gy) if (rows is None and act == ACT_NONE) else None
     if act != ACT_NONE:
         gy = nchw_view(ops.act_bwd(nhwc_view(gy), nhwc_view(y), act))
     w = weight.detach()
     dx = None
     md = None
+    md_filled = False
     u_used = getattr(ctx, "u", None)
     if want_dx:
         if not transposed:
             u = getattr(ctx, "u", None)
-            if u is not None and want_dw and (getattr(ctx, "v", None) is not None or ops.tiles_are_casts(g)):
+            if g16 is not None and ops.precast_ok(1, g):
+                md, md_filled = g16, True
+                H16_STATS["used_bwd"] += 1
+            elif u is not None and want_dw and (getattr(ctx, "v", None) is not None or ops.tiles_are_casts(g)):
                 _, md = ops.wino_tile_buffers(g, gy.device, want_v=False)
             if rows is not None:
                 dx = torch.empty_like(x_full)
                 ops.conv_dgrad(g, nhwc_view(gy), w, u=u, out=nhwc_view(dx[:rows]))
             else:
-                dx = nchw_view(ops.conv_dgrad(g, nhwc_view(gy), w, u=u, md_out=md))
+                dx = nchw_view(ops.conv_dgrad(g, nhwc_view(gy), w, u=u, md_out=md, md_filled=md_filled))
             if last_use:
                 ctx.u = None
         else:
-            dx = nchw_view(ops.conv_fwd(g, nhwc_view(gy), w, u=getattr(ctx, "u", None)))
+            if g16 is not None and ops.precast_ok(0, g):             # gy plays x in this call
+                dx = nchw_view(ops.conv_fwd(g, nhwc_view(gy), w, u=getattr(ctx, "u", None), v_out=g16, v_filled=True))
+                H16_STATS["used_bwd"] += 1
+            else:
+                g16 = None
+                dx = nchw_view(ops.conv_fwd(g, nhwc_view(gy), w, u=getattr(ctx, "u", None)))
             if last_use:
                 ctx.u = None
     if want_dw and not transposed and rows is None and (bias is None or not bias.requires_grad or (
@@ -390,7 +443,10 @@ def _conv_backward(ctx, gy, x, y):
             ctx.v = None
         else:
             flag = _producer_flag(weight, g)
-            ops.conv_wgrad(g, nhwc_view(gy), nhwc_view(x), wbuf, None, wacc, found_inf=flag)
+            half = ops.tiles_are_casts(g) and g.precision == _lib.PRECISION_F16 and g.Co != 1
+            ops.conv_wgrad(g, nhwc_view(gy), nhwc_view(x), wbuf, None, wacc, found_inf=flag,
+                           v=g16 if half else None, md=getattr(ctx, "v", None) if half else None)
+            ctx.v = None
             weight._mg_inf_checked = flag is not None
             if bbuf is not None:
                 ops.colsum(nhwc_view(gy).reshape(-1, g.Ci), bbuf, bacc)
@@ -433,16 +489,22 @@ class _ConvInstNormFn(torch.autograd.Function):
             u = _cached_wino_weights(g, weight, fill=not torch.cuda.is_current_stream_capturing())
         else:
             u = None
-        v = None
-        if u is not None and weight_grad and weight.requires_grad:
+        v, v_filled = None, False
+        x16 = _h16_of(x) if ops.precast_ok(0, g) else None
+        if x16 is not None:
+            v, v_filled = x16, True
+            H16_STATS["used_fwd"] += 1
+        elif u is not None and weight_grad and weight.requires_grad:
             v, _ = ops.wino_tile_buffers(g, x.device, want_md=False)
+        y16 = (torch.empty(B * g.OH * g.OW * g.Co, dtype=torch.float16, device=x.device)
+               if _want_h16(B, g.OH * g.OW, g.Co) else None)
         y, y_raw, mean, rstd = ops.conv_fwd_instnorm(g, nhwc_view(x), w, bias.detach() if bias is not None else None, act,
-                                                     nhwc_view(res) if res is not None else None, eps, u, v)
-        ctx.u, ctx.v = u, v
+                                                     nhwc_view(res) if res is not None else None, eps, u, v, v_filled, y16)
+        ctx.u, ctx.v = u, (v if (weight_grad and weight.requires_grad) else None)
         ctx.g, ctx.cfg = g, (1, pad, reflect, ACT_NONE, False, weight_grad)
         ctx.weight, ctx.bias, ctx.norm_act = weight, bias, act
         ctx.save_for_backward(x, nchw_view(y_raw), mean, rstd)
-        return nchw_view(y)
+        return _attach_h16(nchw_view(y), y16)
 
     @staticmethod
     def backward(ctx, gy):
@@ -478,7 +540,9 @@ class _ConvInstNormFn(torch.autograd.Function):
             if bias is not None and bias.requires_grad:
                 _notify(bias)
             return dx, None, None, dres, None
-        d_raw = nchw_view(ops.instnorm_bwd(nhwc_view(gy), nhwc_view(y_raw), mean, rstd, ctx.norm_act))
+        d16 = (torch.empty(gy.numel(), dtype=torch.float16, device=gy.device)
+               if (_want_h16(g.B, g.OH * g.OW, g.Co, g.precision == _lib.PRECISION_F16) and ops.precast_ok(1, g)) else None)
+        d_raw = _attach_h16(nchw_view(ops.instnorm_bwd(nhwc_view(gy), nhwc_view(y_raw), mean, rstd, ctx.norm_act, dx16=d16)), d16)
         dx = _conv_backward(ctx, d_raw, x, None)
         if skip_g is not None:
             dx = skip_g if dx is None else add(dx, skip_g)
@@ -508,10 +572,12 @@ class _InstNormFn(torch.autograd.Function):
     def forward(ctx, x, residual, act, eps):
         x = to_cl(x)
         res = to_cl(residual) if residual is not None else None
-        y, mean, rstd = ops.instnorm_fwd(nhwc_view(x), act, nhwc_view(res) if res is not None else None, eps)
-        ctx.act = act
+        B, C, H, W = x.shape
+        y16 = torch.empty(x.numel(), dtype=torch.float16, device=x.device) if _want_h16(B, H * W, C) else None
+        y, mean, rstd = ops.instnorm_fwd(nhwc_view(x), act, nhwc_view(res) if res is not None else None, eps, y16=y16)
+        ctx.act, ctx.half = act, amp.current_precision() == _lib.PRECISION_F16
         ctx.save_for_backward(x, mean, rstd)
-        return nchw_view(y)
+        return _attach_h16(nchw_view(y), y16)
 
     @staticmethod
     def backward(ctx, gy):
@@ -525,7 +591,9 @@ class _InstNormFn(torch.autograd.Function):
                 ops.instnorm_bwd(nhwc_view(gy[:rows]), nhwc_view(x[:rows]), mean[:rows], rstd[:rows], ctx.act,
                                  out=nhwc_view(dx[:rows]))
             else:
-                dx = nchw_view(ops.instnorm_bwd(nhwc_view(gy), nhwc_view(x), mean, rstd, ctx.act))
+                B, C, H, W = x.shape
+                d16 = torch.empty(x.numel(), dtype=torch.float16, device=x.device) if _want_h16(B, H * W, C, ctx.half) else None
+                dx = _attach_h16(nchw_view(ops.instnorm_bwd(nhwc_view(gy), nhwc_view(x), mean, rstd, ctx.act, dx16=d16)), d16)
         dres = gy if ctx.needs_input_grad[1] else None
         return dx, dres, None, None
 

@@ -87,26 +87,45 @@ def tiles_are_casts(g: ConvGeom) -> bool:
 _CASTS = {}
 
 
-def _tiles(u=None, v=None, md=None, add=None):
+TILES_V_FILLED, TILES_MD_FILLED = 1, 2      # include/mdctgan_hip.h: MG_TILES_*_FILLED
+
+
+def _tiles(u=None, v=None, md=None, add=None, flags=0):
     if u is None and v is None and md is None and add is None:
         return None
-    return _lib.WinoTiles(_lib.ptr(u), _lib.ptr(v), _lib.ptr(md), _lib.ptr(add))
+    return _lib.WinoTiles(_lib.ptr(u), _lib.ptr(v), _lib.ptr(md), _lib.ptr(add), flags)
 
 
-def conv_fwd(g: ConvGeom, x, w, bias=None, act=ACT_NONE, u=None, v_out=None):
+def precast_ok(pass_id: int, g: ConvGeom) -> bool:
+    """True when this pass of the layer reads its activation operand from a plain float16 copy and honours MG_TILES_V_FILLED
+    (pass 0) / MG_TILES_MD_FILLED (pass 1): the HALF instances of the implicit GEMMs (csrc/conv_dma.h)."""
+    if g.precision != _lib.PRECISION_F16:
+        return False
+    key = ("pc", pass_id, g.B, g.H, g.W, g.Ci, g.Co, g.KH, g.KW, g.stride, g.pad, g.reflect, g.precision)
+    hit = _CASTS.get(key)
+    if hit is None:
+        name = plan_name(pass_id, g)
+        hit = _CASTS[key] = name.startswith(("conv_fwd_dma_kernel", "conv_dgrad_dma_kernel")[pass_id]) and ", true" in name
+    return hit
+
+
+def conv_fwd(g: ConvGeom, x, w, bias=None, act=ACT_NONE, u=None, v_out=None, v_filled=False):
+    """v_filled: v_out already holds float16(x) (written by x's producer; only where precast_ok(0, g))."""
     lib = _lib.load()
     y = torch.empty(g.B, g.OH, g.OW, g.Co, dtype=torch.float32, device=x.device)
     ws = _ws(lib.mg_conv_fwd_workspace(g), x.device)
     if PROFILER is not None:
         PROFILER.begin(0, g)
     _lib.check(lib.mg_conv_fwd_w(g, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), act, _lib.ptr(ws),
-                                 ws.numel(), _lib.stream(), _tiles(u, v_out, None)), "mg_conv_fwd")
+                                 ws.numel(), _lib.stream(), _tiles(u, v_out, None, None, TILES_V_FILLED if v_filled else 0)),
+               "mg_conv_fwd")
     if PROFILER is not None:
         PROFILER.end()
     return y
 
 
-def conv_fwd_instnorm(g: ConvGeom, x, w, bias=None, act=ACT_NONE, residual=None, eps=1e-5, u=None, v_out=None):
+def conv_fwd_instnorm(g: ConvGeom, x, w, bias=None, act=ACT_NONE, residual=None, eps=1e-5, u=None, v_out=None, v_filled=False,
+                      y16=None):
     """conv + InstanceNorm2d(affine=False) (+ act, + residual) -> (y, y_raw, mean, rstd); one kernel does the Winograd
     inverse transform and the normalisation when the layer and the map size allow (csrc/wino.h: wino_out_norm_kernel)."""
     lib = _lib.load()
@@ -117,9 +136,11 @@ def conv_fwd_instnorm(g: ConvGeom, x, w, bias=None, act=ACT_NONE, residual=None,
     ws = _ws(lib.mg_conv_fwd_instnorm_workspace(g), x.device)
     if PROFILER is not None:
         PROFILER.begin(0, g)
-    _lib.check(lib.mg_conv_fwd_instnorm_w(g, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y_raw), eps, act,
+    _lib.check(lib.mg_conv_fwd_instnorm_h(g, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y_raw), eps, act,
                                           _lib.ptr(residual), _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(ws),
-                                          ws.numel(), _lib.stream(), _tiles(u, v_out, None)), "mg_conv_fwd_instnorm")
+                                          ws.numel(), _lib.stream(),
+                                          _tiles(u, v_out, None, None, TILES_V_FILLED if v_filled else 0), _lib.ptr(y16)),
+               "mg_conv_fwd_instnorm")
     if PROFILER is not None:
         PROFILER.end()
     return y, y_raw, mean, rstd
@@ -140,16 +161,18 @@ def instnorm_bwd_wino_md(g: ConvGeom, gy, y_raw, mean, rstd, act, md):
                                                    _lib.ptr(md), _lib.stream()), "mg_instnorm_bwd_wino_md")
 
 
-def conv_dgrad(g: ConvGeom, dy, w, bias=None, act=ACT_NONE, u=None, md_out=None, out=None, add=None):
+def conv_dgrad(g: ConvGeom, dy, w, bias=None, act=ACT_NONE, u=None, md_out=None, out=None, add=None, md_filled=False):
     """dy None: md_out already holds the layer's A dy A^T image (instnorm_bwd_wino_md).  add: dx += add (a skip connection's
-    gradient), inside the last kernel where the layer's path allows."""
+    gradient), inside the last kernel where the layer's path allows.  md_filled: md_out already holds float16(dy) (written by
+    dy's producer; only where precast_ok(1, g))."""
     lib = _lib.load()
     dx = torch.empty(g.B, g.H, g.W, g.Ci, dtype=torch.float32, device=w.device) if out is None else out
     ws = _ws(lib.mg_conv_dgrad_workspace(g), w.device)
     if PROFILER is not None:
         PROFILER.begin(1, g)
     _lib.check(lib.mg_conv_dgrad_w(g, _lib.ptr(dy), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(dx), act, _lib.ptr(ws),
-                                   ws.numel(), _lib.stream(), _tiles(u, None, md_out, add)), "mg_conv_dgrad")
+                                   ws.numel(), _lib.stream(), _tiles(u, None, md_out, add, TILES_MD_FILLED if md_filled else 0)),
+               "mg_conv_dgrad")
     if PROFILER is not None:
         PROFILER.end()
     return dx
@@ -216,27 +239,27 @@ def colsum(a2d, out, accumulate=False):
                              _lib.stream()), "mg_colsum")
 
 
-def instnorm_fwd(x, act=ACT_NONE, residual=None, eps=1e-5):
-    """x [B, H, W, C] -> (y, mean [B,C], rstd [B,C])."""
+def instnorm_fwd(x, act=ACT_NONE, residual=None, eps=1e-5, y16=None):
+    """x [B, H, W, C] -> (y, mean [B,C], rstd [B,C]).  y16: a float16 buffer of y's size that also receives float16(y)."""
     lib = _lib.load()
     B, H, W, Cc = x.shape
     y = torch.empty_like(x)
     mean = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
     rstd = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
     ws = _ws(lib.mg_instnorm_workspace(B, H * W, Cc), x.device)
-    _lib.check(lib.mg_instnorm_fwd(_lib.ptr(x), B, H * W, Cc, eps, act, _lib.ptr(residual), _lib.ptr(y),
-                                   _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(ws), ws.numel(), _lib.stream()),
+    _lib.check(lib.mg_instnorm_fwd_h(_lib.ptr(x), B, H * W, Cc, eps, act, _lib.ptr(residual), _lib.ptr(y),
+                                     _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(ws), ws.numel(), _lib.stream(), _lib.ptr(y16)),
                "mg_instnorm_fwd")
     return y, mean, rstd
 
 
-def instnorm_bwd(dy, x, mean, rstd, act=ACT_NONE, out=None):
+def instnorm_bwd(dy, x, mean, rstd, act=ACT_NONE, out=None, dx16=None):
     lib = _lib.load()
     B, H, W, Cc = x.shape
     dx = torch.empty_like(x) if out is None else out
     ws = _ws(lib.mg_instnorm_workspace(B, H * W, Cc), x.device)
-    _lib.check(lib.mg_instnorm_bwd(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), B, H * W, Cc, act,
-                                   _lib.ptr(dx), _lib.ptr(ws), ws.numel(), _lib.stream()), "mg_instnorm_bwd")
+    _lib.check(lib.mg_instnorm_bwd_h(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), B, H * W, Cc, act,
+                                     _lib.ptr(dx), _lib.ptr(ws), ws.numel(), _lib.stream(), _lib.ptr(dx16)), "mg_instnorm_bwd")
     return dx
 
 

@@ -344,3 +344,89 @@ def test_producer_side_inf_check_changes_nothing(monkeypatch):
     assert s_on == s_off and s_on[2] == 2.0 ** 39 and steps_on == steps_off == 3
     for k in w_on:
         assert torch.equal(w_on[k], w_off[k]), k
+
+
+def test_norm_kernels_write_the_float16_copy():
+    """mg_instnorm_fwd_h / mg_instnorm_bwd_h: the float32 results are those of the plain calls, the float16 output is their
+    round-to-nearest cast -- on the slab kernels (small maps) and on the partial / finalize / apply sequence (large maps)."""
+    from mdctgan_amd import _lib, ops
+    gen = torch.Generator().manual_seed(9)
+    for (B, H, W, C), act, with_res in (((2, 8, 16, 64), _lib.ACT_RELU, True), ((2, 40, 72, 128), _lib.ACT_LRELU02, False),
+                                        ((3, 17, 33, 64), _lib.ACT_NONE, True)):
+        x = torch.randn(B, H, W, C, generator=gen).to(DEV)
+        res = torch.randn(B, H, W, C, generator=gen).to(DEV) if with_res else None
+        gy = torch.randn(B, H, W, C, generator=gen).to(DEV)
+        y0, m0, r0 = ops.instnorm_fwd(x, act, res)
+        y16 = torch.full((x.numel(),), float("nan"), dtype=torch.float16, device=DEV)
+        y1, m1, r1 = ops.instnorm_fwd(x, act, res, y16=y16)
+        assert torch.equal(y0, y1) and torch.equal(m0, m1) and torch.equal(r0, r1)
+        assert torch.equal(y16.view_as(y1), y1.half())
+        d0 = ops.instnorm_bwd(gy, x, m0, r0, act)
+        d16 = torch.full((x.numel(),), float("nan"), dtype=torch.float16, device=DEV)
+        d1 = ops.instnorm_bwd(gy, x, m0, r0, act, dx16=d16)
+        assert torch.equal(d0, d1) and torch.equal(d16.view_as(d1), d1.half())
+
+
+def test_filled_tiles_skip_the_cast_and_change_nothing():
+    """MG_TILES_V_FILLED / MG_TILES_MD_FILLED on the float16 implicit GEMMs: forward / data gradient / weight gradient from a
+    caller-made float16 copy == the calls that cast for themselves; a wrong copy shows (i.e. the flag really skips the cast)."""
+    from mdctgan_amd import _lib, ops
+    gen = torch.Generator().manual_seed(4)
+    for (B, Ci, H, W, Co, k, s, p, refl) in ((2, 64, 32, 64, 128, 3, 2, 1, False), (2, 64, 24, 40, 64, 3, 1, 1, True)):
+        g = ops.conv_geom(B, H, W, Ci, Co, k, k, s, p, refl, _lib.PRECISION_F16)
+        assert ops.precast_ok(0, g) and ops.precast_ok(1, g), (ops.plan_name(0, g), ops.plan_name(1, g))
+        x = torch.randn(B, H, W, Ci, generator=gen).to(DEV)
+        w = (0.05 * torch.randn(Co, k, k, Ci, generator=gen)).to(DEV)
+        dy = torch.randn(B, g.OH, g.OW, Co, generator=gen).to(DEV)
+        x16, dy16 = x.half().reshape(-1), dy.half().reshape(-1)
+        assert torch.equal(ops.conv_fwd(g, x, w, None, v_out=x16, v_filled=True), ops.conv_fwd(g, x, w, None))
+        assert torch.equal(ops.conv_dgrad(g, dy, w, md_out=dy16, md_filled=True), ops.conv_dgrad(g, dy, w))
+        dw0, dw1 = torch.empty_like(w), torch.empty_like(w)
+        ops.conv_wgrad(g, x, dy, dw0, None)
+        ops.conv_wgrad(g, x, dy, dw1, None, v=x16, md=dy16)
+        assert torch.equal(dw0, dw1)
+        assert not torch.equal(ops.conv_fwd(g, x, w, None, v_out=torch.zeros_like(x16), v_filled=True), ops.conv_fwd(g, x, w, None))
+    # a float32 geometry has no float16 output on the fused convolution + norm call
+    g32 = ops.conv_geom(2, 8, 16, 64, 64, 3, 3, 1, 1, True, _lib.PRECISION_F32)
+    with pytest.raises(RuntimeError):
+        ops.conv_fwd_instnorm(g32, torch.zeros(2, 8, 16, 64, device=DEV), torch.zeros(64, 3, 3, 64, device=DEV),
+                              y16=torch.zeros(2 * 8 * 16 * 64, dtype=torch.float16, device=DEV))
+
+
+def test_producer_written_float16_copies_change_nothing(monkeypatch):
+    """The AMP step with the norm kernels writing the next convolution's float16 operand (functional._attach_h16 / _h16_of) ==
+    the step with MG_NO_H16_PRODUCER=1, bit for bit, and the hand-over really happens in both directions."""
+    from mdctgan_amd import functional as Fh
+    from mdctgan_amd import options
+    from mdctgan_amd.pix2pixHD_model import create_model
+
+    def run(off):
+        monkeypatch.setenv("MG_NO_H16_PRODUCER", "1" if off else "0")
+        for k in Fh.H16_STATS:
+            Fh.H16_STATS[k] = 0
+        torch.manual_seed(5)
+        opt = options.make_opt(*options.SPECTRAL_FLAGS, "--lr_sampling_rate", "12000", "--netG", "local", "--ngf", "32",
+                               "--n_downsample_global", "2", "--n_blocks_global", "2", "--n_blocks_local", "2",
+                               "--n_blocks_attn_g", "0", "--num_D", "2", "--ndf", "64", "--batchSize", "2", "--bins", "64",
+                               "--segment_length", "16128", "--gpu_ids", "0", "--fp16")
+        model = create_model(opt)
+        onets.fill_deterministic(model.netG)
+        onets.fill_deterministic(model.netD)
+        gen = torch.Generator().manual_seed(11)
+        hr = (0.1 * torch.randn(2, 16128, generator=gen)).to(DEV)
+        lr = (0.1 * torch.randn(2, 16128, generator=gen)).to(DEV)
+        model.scaler.state[0] = 64.0
+        losses = []
+        for it in range(3):
+            ld = model.optimize_parameters(lr, hr)
+            losses.append({k: v.item() for k, v in ld.items()})
+        return ({k: v.detach().clone() for k, v in model.netG.state_dict().items()},
+                {k: v.detach().clone() for k, v in model.netD.state_dict().items()}, losses, dict(Fh.H16_STATS))
+    g_on, d_on, l_on, st_on = run(False)
+    g_off, d_off, l_off, st_off = run(True)
+    assert st_on["made"] > 0 and st_on["used_fwd"] > 0 and st_on["used_bwd"] > 0, st_on
+    assert st_off == {"made": 0, "used_fwd": 0, "used_bwd": 0}, st_off
+    assert l_on == l_off
+    for a, b in ((g_on, g_off), (d_on, d_off)):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
