@@ -371,6 +371,24 @@ int mg_l1_fwd(const float* a, const float* b, long long n, float scale, float* l
               void* stream);
 int mg_l1_bwd(const float* a, const float* b, long long n, float scale, const float* grad_out, float* grad_a,
               void* stream);
+/* The same three losses over a LIST of tensors, one launch per stage (kind 0: mean((a - target)^2), 1: mean(|a - b|), 2: BCE against
+ * the constant label `target`): loss (+)= sum_i scale * loss_i -- the feature-matching sum over the discriminators' intermediate
+ * layers (models/pix2pixHD_model.py:440-449) and the per-scale GAN terms.  Bit-identical to the accumulate-in-place sequence of
+ * the single-tensor calls in list order.  Backward: grad[i][0..n) = d(scale * loss_i)/da_i * grad_out[0]; additionally
+ * grad[i][n .. n + zero_tail) = 0 (the other half of a stacked [fake; real] batch).  items: HOST array, count <= MG_LOSS_MAX_ITEMS. */
+#define MG_LOSS_MAX_ITEMS 16
+typedef struct {
+    const float* a;
+    const float* b;        /* kind 1 only */
+    float* grad;           /* backward only */
+    long long n;
+    long long zero_tail;   /* backward only */
+} mg_loss_item;
+size_t mg_loss_multi_workspace(void);
+int mg_loss_multi_fwd(int kind, const mg_loss_item* items, int count, float target, float scale, float* loss, int accumulate,
+                      void* workspace, size_t workspace_bytes, void* stream);
+int mg_loss_multi_bwd(int kind, const mg_loss_item* items, int count, float target, float scale, const float* grad_out,
+                      void* stream);
 
 /* K12  fused Adam over one flat float32 buffer (torch.optim.Adam semantics, no weight decay / amsgrad):
  *      pix2pixHD_model.py:350-351, 363-364; train.py:186-202.  step is 1-based.

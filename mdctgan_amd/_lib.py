@@ -41,6 +41,11 @@ class WinoTiles(C.Structure):
 _W = C.POINTER(WinoTiles)
 
 
+class LossItem(C.Structure):
+    """mg_loss_item: one tensor of a multi-tensor loss call."""
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("grad", C.c_void_p), ("n", C.c_longlong), ("zero_tail", C.c_longlong)]
+
+
 class WinoAdam(C.Structure):
     """mg_wino_adam: the optimiser side of mg_conv_wgrad_adam_w (moments, the U image to refresh, the device clock)."""
     _fields_ = [("m", C.c_void_p), ("v", C.c_void_p), ("u", C.c_void_p), ("state", C.c_void_p),
@@ -127,6 +132,9 @@ SIGNATURES = {
     "mg_bce_const_bwd": (_i, [_p, _ll, _f, _f, _p, _p, _p]),
     "mg_sigmoid_fwd": (_i, [_p, _p, _ll, _p]),
     "mg_sigmoid_bwd": (_i, [_p, _p, _p, _ll, _p]),
+    "mg_loss_multi_workspace": (_sz, []),
+    "mg_loss_multi_fwd": (_i, [_i, C.POINTER(LossItem), _i, _f, _f, _p, _i, _p, _sz, _p]),
+    "mg_loss_multi_bwd": (_i, [_i, C.POINTER(LossItem), _i, _f, _f, _p, _p]),
     "mg_l1_fwd": (_i, [_p, _p, _ll, _f, _p, _i, _p, _p]),
     "mg_l1_bwd": (_i, [_p, _p, _ll, _f, _p, _p, _p]),
     "mg_adam_step": (_i, [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _f, _p]),

@@ -552,6 +552,86 @@ __global__ void loss_grad_kernel(const float* __restrict__ a, const float* __res
     }
 }
 
+// ---- the same losses over a LIST of tensors in one launch per stage (the feature-matching loss sums an L1 term per
+// discriminator layer: 8-12 tensors -> 3 launches instead of 3 per tensor).  Every tensor keeps the block count and the
+// grid-stride pattern of its stand-alone launch and the terms are added in list order, so the result is bit-identical to the
+// accumulate-in-place sequence of single-tensor calls.
+struct LossList {
+    const float* a[MG_LOSS_MAX_ITEMS];
+    const float* b[MG_LOSS_MAX_ITEMS];
+    float* grad[MG_LOSS_MAX_ITEMS];
+    unsigned long long n[MG_LOSS_MAX_ITEMS];
+    unsigned long long zero_tail[MG_LOSS_MAX_ITEMS];   // backward: elements after grad[i][n) to clear (the stacked batch's other half)
+    unsigned first_block[MG_LOSS_MAX_ITEMS + 1];       // forward: partial blocks of item i are [first_block[i], first_block[i + 1])
+    float coef[MG_LOSS_MAX_ITEMS];                     // backward: scale / n, divided on the host like the single-tensor entry points do
+    int count;
+};
+template <int KIND>
+__global__ __launch_bounds__(256) void loss_partial_multi_kernel(LossList L, float target, double* __restrict__ part) {
+    __shared__ double red[4];
+    int it = 0;
+    while (it + 1 < L.count && blockIdx.x >= L.first_block[it + 1]) ++it;
+    const unsigned blk = blockIdx.x - L.first_block[it], nblk = L.first_block[it + 1] - L.first_block[it];
+    const float* __restrict__ a = L.a[it];
+    const float* __restrict__ b = L.b[it];
+    const size_t n = (size_t)L.n[it];
+    double s = 0.0;
+    for (size_t i = (size_t)blk * blockDim.x + threadIdx.x; i < n; i += (size_t)nblk * blockDim.x) {
+        if (KIND == 2) {
+            const float pv = a[i];
+            s += (double)((target - 1.0f) * fmaxf(logf(1.0f - pv), -100.0f) - target * fmaxf(logf(pv), -100.0f));
+            continue;
+        }
+        const float d = a[i] - (KIND == 0 ? target : b[i]);
+        s += (KIND == 0) ? (double)d * (double)d : (double)fabsf(d);
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// one wave per item (same lane-strided order and butterfly as loss_final_kernel), then thread 0 adds the terms in list order
+__global__ __launch_bounds__(64 * MG_LOSS_MAX_ITEMS) void loss_final_multi_kernel(LossList L, const double* __restrict__ part,
+                                                                                  float scale, float* __restrict__ loss,
+                                                                                  int accumulate) {
+    __shared__ float term[MG_LOSS_MAX_ITEMS];
+    const int it = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (it < L.count) {
+        const int nb = (int)(L.first_block[it + 1] - L.first_block[it]);
+        const double* p = part + L.first_block[it];
+        double s = 0.0;
+        for (int i = lane; i < nb; i += 64) s += p[i];
+        s = wave_sum_d(s);
+        if (lane == 0) term[it] = (float)(s * (1.0 / (double)L.n[it])) * scale;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float acc = accumulate ? loss[0] : 0.0f;
+        for (int i = 0; i < L.count; ++i) acc = (i == 0 && !accumulate) ? term[0] : acc + term[i];
+        loss[0] = acc;
+    }
+}
+template <int KIND>
+__global__ void loss_grad_multi_kernel(LossList L, float target, const float* __restrict__ go) {
+    const int it = blockIdx.y;
+    const float* __restrict__ a = L.a[it];
+    const float* __restrict__ b = L.b[it];
+    float* __restrict__ grad = L.grad[it];
+    const size_t n = (size_t)L.n[it], nz = (size_t)L.zero_tail[it];
+    const float gsc = L.coef[it] * (go ? go[0] : 1.0f);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n + nz; i += (size_t)gridDim.x * blockDim.x) {
+        if (i >= n) { grad[i] = 0.0f; continue; }
+        if (KIND == 2) {
+            const float pv = a[i];
+            grad[i] = (pv - target) / fmaxf((1.0f - pv) * pv, 1e-12f) * gsc;
+            continue;
+        }
+        const float d = a[i] - (KIND == 0 ? target : b[i]);
+        if (KIND == 0) grad[i] = 2.0f * d * gsc;
+        else grad[i] = (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * gsc;
+    }
+}
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, size_t n, float step_size, float b1, float b2, float eps,
                             float bc2_sqrt, float gscale) {
@@ -919,6 +999,60 @@ int mg_l1_bwd(const float* a, const float* b, long long n, float scale, const fl
     if (!a || !b || !grad_a || n <= 0) return MG_ERR_ARG;
     hipLaunchKernelGGL(loss_grad_kernel<1>, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, a, b, 0.0f,
                        (size_t)n, scale / (float)n, grad_out, grad_a);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+size_t mg_loss_multi_workspace(void) { return (size_t)MG_LOSS_MAX_ITEMS * 1024 * sizeof(double); }
+static bool loss_list(const mg_loss_item* items, int count, bool need_b, bool need_grad, LossList* L) {
+    if (!items || count < 1 || count > MG_LOSS_MAX_ITEMS) return false;
+    L->count = count;
+    unsigned fb = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!items[i].a || items[i].n <= 0 || (need_b && !items[i].b) || (need_grad && !items[i].grad) || items[i].zero_tail < 0)
+            return false;
+        L->a[i] = items[i].a; L->b[i] = items[i].b; L->grad[i] = items[i].grad;
+        L->n[i] = (unsigned long long)items[i].n; L->zero_tail[i] = (unsigned long long)items[i].zero_tail;
+        L->first_block[i] = fb;
+        size_t nb = ((size_t)items[i].n + 1023) / 1024;
+        if (nb > 1024) nb = 1024;
+        fb += (unsigned)nb;
+    }
+    L->first_block[count] = fb;
+    return true;
+}
+int mg_loss_multi_fwd(int kind, const mg_loss_item* items, int count, float target, float scale, float* loss, int accumulate,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+    LossList L;
+    if (kind < 0 || kind > 2 || !loss || !workspace || workspace_bytes < mg_loss_multi_workspace()) return MG_ERR_ARG;
+    if (!loss_list(items, count, kind == 1, false, &L)) return MG_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(L.first_block[count]);
+    double* part = (double*)workspace;
+    if (kind == 0) hipLaunchKernelGGL(loss_partial_multi_kernel<0>, grid, dim3(256), 0, st, L, target, part);
+    else if (kind == 1) hipLaunchKernelGGL(loss_partial_multi_kernel<1>, grid, dim3(256), 0, st, L, target, part);
+    else hipLaunchKernelGGL(loss_partial_multi_kernel<2>, grid, dim3(256), 0, st, L, target, part);
+    hipLaunchKernelGGL(loss_final_multi_kernel, dim3(1), dim3(64 * MG_LOSS_MAX_ITEMS), 0, st, L, (const double*)part, scale, loss,
+                       accumulate);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+int mg_loss_multi_bwd(int kind, const mg_loss_item* items, int count, float target, float scale, const float* grad_out,
+                      void* stream) {
+    LossList L;
+    if (kind < 0 || kind > 2) return MG_ERR_ARG;
+    if (!loss_list(items, count, kind == 1, true, &L)) return MG_ERR_ARG;
+    size_t nmax = 0;
+    for (int i = 0; i < count; ++i) {
+        const size_t ni = (size_t)(items[i].n + items[i].zero_tail);
+        if (ni > nmax) nmax = ni;
+        L.coef[i] = scale / (float)items[i].n;
+    }
+    const dim3 grid(grid_for(nmax), count);
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == 0) hipLaunchKernelGGL(loss_grad_multi_kernel<0>, grid, dim3(256), 0, st, L, target, grad_out);
+    else if (kind == 1) hipLaunchKernelGGL(loss_grad_multi_kernel<1>, grid, dim3(256), 0, st, L, target, grad_out);
+    else hipLaunchKernelGGL(loss_grad_multi_kernel<2>, grid, dim3(256), 0, st, L, target, grad_out);
     MG_CHECK_LAUNCH();
     return MG_OK;
 }

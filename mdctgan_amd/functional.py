@@ -966,9 +966,8 @@ class _L1HalvesSumFn(torch.autograd.Function):
     def forward(ctx, scale, *ts):
         ts = [_cl(t) for t in ts]
         loss = torch.empty(1, dtype=torch.float32, device=ts[0].device)
-        for i, t in enumerate(ts):
-            B = t.shape[0] // 2
-            ops.l1_fwd(t[:B], t[B:], scale, loss, i > 0)
+        # all layers in one partial + one final launch (mg_loss_multi_fwd): same blocks, same order of additions
+        ops.loss_multi_fwd(ops.LOSS_L1, [(t[:t.shape[0] // 2], t[t.shape[0] // 2:], None, 0) for t in ts], 0.0, scale, loss)
         ctx.scale = scale
         ctx.save_for_backward(*ts)
         return loss.reshape(())
@@ -976,14 +975,14 @@ class _L1HalvesSumFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, go):
         go = go.reshape(1).float().contiguous()
-        grads = []
+        grads, rows = [], []
         for t in ctx.saved_tensors:
             B = t.shape[0] // 2
             g = torch.empty_like(t)
-            if _BackwardPass.kind != "G":
-                g[B:].zero_()
-            ops.l1_bwd(t[:B], t[B:], ctx.scale, go, out=g[:B])
+            # the real half gets no gradient from this loss: cleared by the same launch (pass "G" never reads it)
+            rows.append((t[:B], t[B:], g, (t.numel() - t[:B].numel()) if _BackwardPass.kind != "G" else 0))
             grads.append(g)
+        ops.loss_multi_bwd(ops.LOSS_L1, rows, 0.0, ctx.scale, go)
         return (None, *grads)
 
 
@@ -999,8 +998,7 @@ class _MseConstFirstHalfSumFn(torch.autograd.Function):
     def forward(ctx, target, *preds):
         preds = [_cl(t) for t in preds]
         loss = torch.empty(1, dtype=torch.float32, device=preds[0].device)
-        for i, t in enumerate(preds):
-            ops.mse_const_fwd(t[:t.shape[0] // 2], target, 1.0, loss, i > 0)
+        ops.loss_multi_fwd(ops.LOSS_MSE_CONST, [(t[:t.shape[0] // 2], None, None, 0) for t in preds], target, 1.0, loss)
         ctx.target = target
         ctx.save_for_backward(*preds)
         return loss.reshape(())
@@ -1008,14 +1006,13 @@ class _MseConstFirstHalfSumFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, go):
         go = go.reshape(1).float().contiguous()
-        grads = []
+        grads, rows = [], []
         for t in ctx.saved_tensors:
             B = t.shape[0] // 2
             g = torch.empty_like(t)
-            if _BackwardPass.kind != "G":
-                g[B:].zero_()
-            ops.mse_const_bwd(t[:B], ctx.target, 1.0, go, out=g[:B])
+            rows.append((t[:B], None, g, (t.numel() - t[:B].numel()) if _BackwardPass.kind != "G" else 0))
             grads.append(g)
+        ops.loss_multi_bwd(ops.LOSS_MSE_CONST, rows, ctx.target, 1.0, go)
         return (None, *grads)
 
 
@@ -1032,10 +1029,8 @@ class _MseConstPairSumFn(torch.autograd.Function):
         preds = [_cl(t) for t in preds]
         l0 = torch.empty(1, dtype=torch.float32, device=preds[0].device)
         l1 = torch.empty(1, dtype=torch.float32, device=preds[0].device)
-        for i, t in enumerate(preds):
-            B = t.shape[0] // 2
-            ops.mse_const_fwd(t[:B], t0, 1.0, l0, i > 0)
-            ops.mse_const_fwd(t[B:], t1, 1.0, l1, i > 0)
+        ops.loss_multi_fwd(ops.LOSS_MSE_CONST, [(t[:t.shape[0] // 2], None, None, 0) for t in preds], t0, 1.0, l0)
+        ops.loss_multi_fwd(ops.LOSS_MSE_CONST, [(t[t.shape[0] // 2:], None, None, 0) for t in preds], t1, 1.0, l1)
         ctx.targets = (t0, t1)
         ctx.save_for_backward(*preds)
         return l0.reshape(()), l1.reshape(())
@@ -1044,13 +1039,15 @@ class _MseConstPairSumFn(torch.autograd.Function):
     def backward(ctx, g0, g1):
         g0 = g0.reshape(1).float().contiguous()
         g1 = g1.reshape(1).float().contiguous()
-        grads = []
+        grads, rows0, rows1 = [], [], []
         for t in ctx.saved_tensors:
             B = t.shape[0] // 2
             g = torch.empty_like(t)
-            ops.mse_const_bwd(t[:B], ctx.targets[0], 1.0, g0, out=g[:B])
-            ops.mse_const_bwd(t[B:], ctx.targets[1], 1.0, g1, out=g[B:])
+            rows0.append((t[:B], None, g[:B], 0))
+            rows1.append((t[B:], None, g[B:], 0))
             grads.append(g)
+        ops.loss_multi_bwd(ops.LOSS_MSE_CONST, rows0, ctx.targets[0], 1.0, g0)
+        ops.loss_multi_bwd(ops.LOSS_MSE_CONST, rows1, ctx.targets[1], 1.0, g1)
         return (None, None, *grads)
 
 

@@ -352,6 +352,38 @@ def mse_const_bwd(pred, target, scale, grad_out, out=None):
     return g
 
 
+LOSS_MSE_CONST, LOSS_L1, LOSS_BCE_CONST = 0, 1, 2
+LOSS_MAX_ITEMS = 16
+
+
+def _loss_items(rows):
+    """rows: [(a, b | None, grad | None, zero_tail)] -> the ctypes mg_loss_item array (a's element count is n)."""
+    arr = (_lib.LossItem * len(rows))()
+    for i, (a, b, grad, tail) in enumerate(rows):
+        arr[i] = _lib.LossItem(_lib.ptr(a), _lib.ptr(b), _lib.ptr(grad), a.numel(), int(tail))
+    return arr
+
+
+def loss_multi_fwd(kind, rows, target, scale, loss, accumulate=False):
+    """loss (+)= sum_i scale * loss_kind(rows[i]) in one partial + one final launch (mg_loss_multi_fwd); bit-identical to the
+    single-tensor calls accumulated in list order."""
+    lib = _lib.load()
+    ws = _ws(lib.mg_loss_multi_workspace(), loss.device)
+    for lo in range(0, len(rows), LOSS_MAX_ITEMS):
+        part = rows[lo:lo + LOSS_MAX_ITEMS]
+        _lib.check(lib.mg_loss_multi_fwd(kind, _loss_items(part), len(part), float(target), float(scale), _lib.ptr(loss),
+                                         int(accumulate or lo > 0), _lib.ptr(ws), ws.numel(), _lib.stream()), "mg_loss_multi_fwd")
+
+
+def loss_multi_bwd(kind, rows, target, scale, grad_out):
+    """rows carry grad buffers (and the number of elements behind each to clear): one launch for all of them."""
+    lib = _lib.load()
+    for lo in range(0, len(rows), LOSS_MAX_ITEMS):
+        part = rows[lo:lo + LOSS_MAX_ITEMS]
+        _lib.check(lib.mg_loss_multi_bwd(kind, _loss_items(part), len(part), float(target), float(scale), _lib.ptr(grad_out),
+                                         _lib.stream()), "mg_loss_multi_bwd")
+
+
 def l1_fwd(a, b, scale, loss, accumulate):
     lib = _lib.load()
     ws = _ws(lib.mg_loss_workspace(), a.device)

@@ -111,3 +111,52 @@ def test_dinput_pair_losses_adam():
         opt.step()
         ops.adam_step(pd, g.to(DEV), m, v, 2e-4, 0.5, 0.999, 1e-8, step)
         assert (pd.cpu() - pt.detach()).abs().max().item() <= 2.4e-7   # 1 ulp at |p| < 4: lr * m/denom rounds once differently
+
+
+def test_multi_tensor_losses_equal_the_single_tensor_calls():
+    """mg_loss_multi_fwd / mg_loss_multi_bwd (the feature-matching sum over the discriminator layers as one launch per stage) ==
+    the accumulate-in-place sequence of single-tensor calls, bit for bit; the backward also clears the requested tail."""
+    from mdctgan_amd import _lib, ops
+    lib = _lib.load()
+
+    def bce_fwd(x, t, sc, loss, acc):
+        ws = _lib.workspace(lib.mg_loss_workspace(), x.device)
+        _lib.check(lib.mg_bce_const_fwd(_lib.ptr(x), x.numel(), t, sc, _lib.ptr(loss), int(acc), _lib.ptr(ws), _lib.stream()), "bce")
+
+    def bce_bwd(x, t, sc, go, out):
+        _lib.check(lib.mg_bce_const_bwd(_lib.ptr(x), x.numel(), t, sc, _lib.ptr(go), _lib.ptr(out), _lib.stream()), "bce")
+    gen = torch.Generator().manual_seed(13)
+    shapes = [(2, 65, 129, 64), (2, 33, 65, 128), (2, 17, 33, 256), (2, 18, 34, 512), (2, 3, 5, 1), (2, 700, 1100, 3)]
+    for kind in (ops.LOSS_MSE_CONST, ops.LOSS_L1, ops.LOSS_BCE_CONST):
+        a = [torch.rand(s, generator=gen).to("cuda") * 0.98 + 0.01 for s in shapes]
+        b = [torch.rand(s, generator=gen).to("cuda") for s in shapes]
+        target, scale = (0.0, 1.0) if kind == ops.LOSS_L1 else (1.0, 0.7)
+        single_fwd = {ops.LOSS_MSE_CONST: lambda x, y, l, acc: ops.mse_const_fwd(x, target, scale, l, acc),
+                      ops.LOSS_L1: lambda x, y, l, acc: ops.l1_fwd(x, y, scale, l, acc),
+                      ops.LOSS_BCE_CONST: lambda x, y, l, acc: bce_fwd(x, target, scale, l, acc)}[kind]
+        single_bwd = {ops.LOSS_MSE_CONST: lambda x, y, go, out: ops.mse_const_bwd(x, target, scale, go, out=out),
+                      ops.LOSS_L1: lambda x, y, go, out: ops.l1_bwd(x, y, scale, go, out=out),
+                      ops.LOSS_BCE_CONST: lambda x, y, go, out: bce_bwd(x, target, scale, go, out)}[kind]
+        want = torch.full((1,), 3.25, device="cuda")
+        got = want.clone()
+        for i, (x, y) in enumerate(zip(a, b)):
+            single_fwd(x, y, want, True)
+        ops.loss_multi_fwd(kind, [(x, y if kind == ops.LOSS_L1 else None, None, 0) for x, y in zip(a, b)], target, scale, got, True)
+        assert torch.equal(got, want), (kind, got.item(), want.item())
+        fresh = torch.full((1,), float("nan"), device="cuda")
+        ops.loss_multi_fwd(kind, [(x, y if kind == ops.LOSS_L1 else None, None, 0) for x, y in zip(a, b)], target, scale, fresh)
+        assert torch.equal(fresh, want - 3.25) or abs(fresh.item() - (want.item() - 3.25)) <= 1e-6 * abs(want.item())
+        go = torch.full((1,), 0.37, device="cuda")
+        rows, wants, bufs = [], [], []
+        for x, y in zip(a, b):
+            tail = x.numel() // 2
+            buf = torch.full((x.numel() + tail,), float("nan"), device="cuda")
+            w_ = torch.empty_like(x)
+            single_bwd(x, y, go, w_)
+            rows.append((x, y if kind == ops.LOSS_L1 else None, buf, tail))
+            wants.append(w_)
+            bufs.append(buf)
+        ops.loss_multi_bwd(kind, rows, target, scale, go)
+        for buf, w_ in zip(bufs, wants):
+            n = w_.numel()
+            assert torch.equal(buf[:n], w_.reshape(-1)) and bool((buf[n:] == 0).all())
