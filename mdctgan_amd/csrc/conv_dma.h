@@ -537,14 +537,29 @@ inline double cd_env(const char* name, double dflt) { const char* v = getenv(nam
 inline double cd_half_rate() { static const double v = cd_env("MG_HALF_RATE", 4.0); return v; }
 inline double cd_half_fixed() { static const double v = cd_env("MG_HALF_FIXED", 4.0); return v; }
 inline long long cd_half_fill() { static const long long v = (long long)cd_env("MG_HALF_FILL", 512); return v; }
+inline double cd_half_wgrad_eff(int i) {
+    static double v[4] = {0.83, 0.80, 1.0, 0.88};
+    static const bool init = [] {
+        if (const char* e = getenv("MG_HALF_WGRAD_EFF")) { double a, b, c, d; if (sscanf(e, "%lf,%lf,%lf,%lf", &a, &b, &c, &d) == 4) { v[0] = a; v[1] = b; v[2] = c; v[3] = d; } }
+        return true;
+    }();
+    (void)init;
+    return v[i];
+}
 // the dense plan's cost model (dense_plan above) on the convolution's GEMM view, DMA instances only.  ck = K depth of a chunk
 // (32 float32 / 64 float16); the float16 instances are priced at 4x the float32 MFMA rate (what the staging sustains) with a
 // proportionally larger fixed cost per workgroup.
 CdPlan conv_dma_plan(long long M, int N, int chunks, bool wgrad, int ck, int tap_cols = 0) {   // tap_cols: Ci of a weight gradient
     struct Cand { int bm, bn; double eff; };
-    static const Cand cands[4] = {{64, 64, 0.83}, {64, 128, 0.885}, {128, 64, 0.855}, {128, 128, 0.91}};
+    static const Cand cands_f[4] = {{64, 64, 0.83}, {64, 128, 0.885}, {128, 64, 0.855}, {128, 128, 0.91}};
+    // float16 weight gradients (both operands row-contiguous, transpose reads): measured with forced tiles and free splits on the
+    // configs[2] layer shapes (scripts/bench_conv.py --f16, MG_FORCE_CONV_DMA=bm,bn,0), 128 x 64 is the fastest or within 3 % of it
+    // on 11 of 13 shapes (down128: 47 vs 67 us for 64 x 64, the batch-16 discriminator layer 79 vs 101) -- MG_HALF_WGRAD_EFF=a,b,c,d
+    static const Cand cands_hw[4] = {{64, 64, cd_half_wgrad_eff(0)}, {64, 128, cd_half_wgrad_eff(1)}, {128, 64, cd_half_wgrad_eff(2)},
+                                     {128, 128, cd_half_wgrad_eff(3)}};
     static const int split_opts[12] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
     const bool half = ck == 64;
+    const Cand* cands = (half && wgrad) ? cands_hw : cands_f;
     const double rate = (half ? cd_half_rate() : 1.0) * 157.3e12 / 256.0, fixed = half ? cd_half_fixed() : 1.2;
     const long long fill = half ? cd_half_fill() : 512;
     CdPlan p{64, 64, 1, 1 << 28};
@@ -553,8 +568,10 @@ CdPlan conv_dma_plan(long long M, int N, int chunks, bool wgrad, int ck, int tap
         if (sscanf(f, "%d,%d,%d", &f_bm, &f_bn, &f_sp) != 3) f_bm = f_bn = f_sp = 0;
     }
     double best = 1e300;
-    for (const Cand& c : cands) {
+    for (int ci = 0; ci < 4; ++ci) {
+        const Cand& c = cands[ci];
         if (N % c.bn != 0 || (wgrad && tap_cols % c.bn != 0)) continue;      // a weight-gradient column tile lies inside one tap
+        if (half && wgrad && c.bm == 128 && M < 256) continue;               // one row of tiles only: 64-row tiles split it better (128 channels: 79 vs 89 us)
         if (f_bm && (c.bm != f_bm || c.bn != f_bn)) continue;
         const long long w = ((M + c.bm - 1) / c.bm) * (long long)(N / c.bn);
         const double tile_us = 2.0 * c.bm * c.bn * ck / rate * 1e6 / c.eff;
