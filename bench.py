@@ -456,6 +456,18 @@ def main():
                                                   "rocprofv3 --pmc passes on this kernel at this layer shape (gfx950 reports "
                                                   "half of a wide coalesced read: MI355X_MICROARCH.md, HBM section); "
                                                   "profiles/traffic.json section \"%s\", source file in its \"_source\"" % section)
+                # a GEMM below the ridge (FLOP per HBM byte < MFMA peak / 8 TB/s) is bounded by its stream, not by the MFMA pipe:
+                # say how fast that stream moves (measured traffic of the trunk-layer launch over the launch time of the same symbol)
+                tb = roofline["traffic"]
+                if tb and roofline.get("flops_per_launch") and roofline.get("avg_launch_us"):
+                    ridge = roofline["peak"] * 1e12 / 8e12
+                    intensity = roofline["flops_per_launch"] / tb
+                    if intensity < ridge:
+                        gbps = tb / (roofline["avg_launch_us"] * 1e-6) / 1e9
+                        roofline["hbm_view"] = {"bound": "hbm", "flop_per_byte": round(intensity, 1), "ridge": round(ridge, 1),
+                                                "traffic_GBps": round(gbps, 1), "peak_GBps": 8000.0, "frac": round(gbps / 8000.0, 4),
+                                                "note": "this symbol's intensity is below the ridge: the HBM stream bounds it; bytes = the "
+                                                        "measured traffic of its trunk-layer launch (PMC), time = its average launch"}
             except Exception:
                 pass
 
