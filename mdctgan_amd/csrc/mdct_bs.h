@@ -172,6 +172,8 @@ __global__ __launch_bounds__(NW * 64) void mdct4_bs_kernel(const float* __restri
     };
     float ea, ea2, et, ep, esq, esm, el, ev, elog = 0.0f;
     double s1 = 0.0, s2 = 0.0;      // STATS: sum / sum of squares of the log-domain values (the returned mean / std)
+    float f1 = 0.0f, f2 = 0.0f;     // ... of this lane's 16 values of the tile in flight: float32 inside a tile (three VALU operations per
+                                    // value in the MFMA's shadow instead of four double-rate ones), double across tiles
     int em0 = 0;                    // STATS: first frame row of this lane in the previous tile (rows: none)
     unsigned eob = BS_OOB, eob2 = BS_OOB;   // byte offset of (first frame row of this lane's 16, bin col) in spec / in the pair
     auto epi_piece = [&](int pc, float xv, int r) {      // frame row emrow + (r & 3) + 8 (r >> 2), bin col
@@ -196,8 +198,8 @@ __global__ __launch_bounds__(NW * 64) void mdct4_bs_kernel(const float* __restri
             ev = fmaf(elog, k1, k0);
         }
         if (STATS && pc == 5 && MODE != CODEC_RAW) {
-            const double l = (em0 + dm < rows) ? (double)elog : 0.0;
-            s1 += l; s2 += l * l;
+            const float l = (em0 + dm < rows) ? elog : 0.0f;
+            f1 += l; f2 = fmaf(l, l, f2);
         }
         // addressing costs no VALU: the row inside the tile is the instruction's scalar offset, and a row behind the last one
         // lies behind num_records (the range check covers voffset + soffset), so the hardware drops it
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(NW * 64) void mdct4_bs_kernel(const float* __restri
         for (int pc = 0; pc < 8; ++pc) epi_piece(pc, xv, r);
     };
     auto epi_begin = [&](int tile) {         // tile == n_tiles: nothing to store
+        if (STATS && MODE != CODEC_RAW) { s1 += (double)f1; s2 += (double)f2; f1 = f2 = 0.0f; }     // the finished tile's sums
         const unsigned m0 = (unsigned)tile * BS_ROWS + 4u * kh;
         eob = (tile < n_tiles) ? (m0 * M + (unsigned)col) * 4u : BS_OOB - 31u * M * 8u;      // (+ soffset stays out of range, no wrap)
         eob2 = (tile < n_tiles) ? 2u * eob : eob;
@@ -273,6 +276,7 @@ __global__ __launch_bounds__(NW * 64) void mdct4_bs_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) epi_row(accp[r], r);
     if (STATS && MODE != CODEC_RAW) {
+        s1 += (double)f1; s2 += (double)f2;
         s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
         if (lane == 0) { atomicAdd(stats, s1); atomicAdd(stats + 1, s2); }
     }
