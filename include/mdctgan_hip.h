@@ -347,6 +347,10 @@ int mg_cat2_bwd(const float* g, int Ca, int Cb, long long n, float* ga, float* g
 int mg_dinput_bwd(const float* dout, const float* s, long long n, float* ds, void* stream);
 /* generator input pair [n, 2] = (s, 2|s| + nr0) from a spectrogram (pix2pixHD_model.py:400-402) */
 int mg_pair_fwd(const float* s, long long n, float nr0, float* out, void* stream);
+/* mean_std[0] = stats[0] / n, mean_std[1] = sqrt(max(0, (stats[1] - stats[0]^2 / n) / (n - 1))) -- the `mean` / `std` entries of
+ * to_spectro's norm_param (models/pix2pixHD_model.py:108-109: log_spectro.mean(), log_spectro.var().sqrt()) from the {sum, sum of
+ * squares} K1 accumulates, in float64 like the torch expression it replaces. */
+int mg_stats_finalize(const double* stats, long long n, float* mean_std, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K11  losses (networks.py:127-137 GANLoss/LSGAN, pix2pixHD_model.py:443-451 feature matching).

@@ -125,6 +125,7 @@ SIGNATURES = {
     "mg_cat2_bwd": (_i, [_p, _i, _i, _ll, _p, _p, _p]),
     "mg_dinput_bwd": (_i, [_p, _p, _ll, _p, _p]),
     "mg_pair_fwd": (_i, [_p, _ll, _f, _p, _p]),
+    "mg_stats_finalize": (_i, [_p, _ll, _p, _p]),
     "mg_loss_workspace": (_sz, []),
     "mg_mse_const_fwd": (_i, [_p, _ll, _f, _f, _p, _i, _p, _p]),
     "mg_mse_const_bwd": (_i, [_p, _ll, _f, _f, _p, _p, _p]),

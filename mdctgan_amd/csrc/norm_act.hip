@@ -505,6 +505,17 @@ __global__ void pair_fwd_kernel(const float* __restrict__ s, size_t n, float nr0
     }
 }
 
+// mean / unbiased std of a tensor from its {sum, sum of squares} (K1's statistics output): the float64 operations of
+// (s0 / n).float(), ((s1 - s0 * s0 / n) / (n - 1)).clamp_min(0).sqrt().float() in one launch
+__global__ void stats_finalize_kernel(const double* __restrict__ st, double n, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double s0 = st[0], s1 = st[1];
+        out[0] = (float)(s0 / n);
+        double var = (s1 - s0 * s0 / n) / (n - 1.0);
+        if (!(var > 0.0)) var = var != var ? var : 0.0;       // clamp_min(0) keeps nan
+        out[1] = (float)sqrt(var);
+    }
+}
 // ---- losses: stage 1 block partials (double), stage 2 fixed-order sum -> deterministic ----
 template <int KIND>   // 0: (p - t)^2   1: |a - b|
 __global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -914,6 +925,12 @@ int mg_cat2_bwd(const float* g, int Ca, int Cb, long long n, float* ga, float* g
     if (!g || (!ga && !gb) || n <= 0 || Ca <= 0 || Cb <= 0) return MG_ERR_ARG;
     hipLaunchKernelGGL(cat2_bwd_kernel, dim3(grid_for((size_t)n * (Ca + Cb))), dim3(256), 0, (hipStream_t)stream, g, Ca, Cb,
                        (size_t)n, ga, gb);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+int mg_stats_finalize(const double* stats, long long n, float* mean_std, void* stream) {
+    if (!stats || !mean_std || n < 2) return MG_ERR_ARG;
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats, (double)n, mean_std);
     MG_CHECK_LAUNCH();
     return MG_OK;
 }

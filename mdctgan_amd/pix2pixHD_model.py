@@ -106,9 +106,9 @@ class Audio2MDCT(torch.nn.Module):
         mean = std = None
         if r["stats"] is not None:
             n = r["spec4"].numel()
-            s = r["stats"]
-            mean = (s[0] / n).float()
-            std = ((s[1] - s[0] * s[0] / n) / (n - 1)).clamp_min(0).sqrt().float()
+            ms = torch.empty(2, dtype=torch.float32, device=dev)
+            _lib.check(_lib.load().mg_stats_finalize(_lib.ptr(r["stats"]), n, _lib.ptr(ms), _lib.stream()), "mg_stats_finalize")
+            mean, std = ms[0], ms[1]
         return {"max": a_max, "min": a_min, "mean": mean, "std": std, "frames": r["frames"]}
 
     # -- reference API --------------------------------------------------------------------------
