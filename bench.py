@@ -283,6 +283,24 @@ def bench_codec(args, dev, rank, world):
         print(json.dumps(out), flush=True)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this script under torch.distributed.run with one rank per GPU
+    (the command the driver uses for N > 1), rendezvous on 127.0.0.1 at a free port.  The ranks inherit stdout: rank 0's
+    JSON line is still the last line printed.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    rc = subprocess.run(cmd).returncode
+    if rc:
+        raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -302,21 +320,38 @@ def main():
                          "4 = inference, 8k->48k, batch 64 (implies --mode infer)")
     ap.add_argument("--fp16", action="store_true", help="train.py --fp16: autocast convolutions (f16 MFMA) + GradScaler")
     ap.add_argument("--force-ddp", action="store_true", help="run the data-parallel code path even with one rank (testing)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the data-parallel run: nccl = RCCL over xGMI (the product path); gloo "
+                         "exists so that the N > 1 launch path can be tested with several ranks sharing one GPU")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)          # plain `python bench.py --gpus N`: start the N ranks ourselves
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    torch.cuda.set_device(local_rank)
-    dev = "cuda:%d" % local_rank
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was started inside a %d-rank launch (WORLD_SIZE): use --gpus %d, or start it "
+                         "without a launcher and it spawns its own ranks" % (args.gpus, world, world))
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.device_count() == 0)")
+    if world > n_dev and args.backend == "nccl":
+        raise SystemExit("--gpus %d with %d visible GPU(s): RCCL needs one device per rank (--backend gloo shares one GPU "
+                         "between ranks for testing the launch path)" % (world, n_dev))
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    dev = "cuda:%d" % dev_index
     use_ddp = world > 1 or args.force_ddp
     if use_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group("gloo")
 
     from mdctgan_amd import ddp, ops, options
     from mdctgan_amd.pix2pixHD_model import create_model
@@ -350,7 +385,7 @@ def main():
     model = create_model(opt)
     if use_ddp:
         ddp.attach(model)
-    lr, hr = synth_batch(batch, 42 + rank, dev, lr_rate=lr_rate)
+    lr, hr = synth_batch(batch, 42 + rank, dev, lr_rate=lr_rate)      # every rank its own minibatch (weak scaling)
     from mdctgan_amd.generate_audio import generate, make_graphed_generate
 
     def eager_step():
@@ -410,10 +445,12 @@ def main():
             eager_step()
         torch.cuda.synchronize()
         ops.PROFILER = None
+    dist_ranks = None
     if use_ddp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        dist_ranks = dist.get_world_size()          # the rank count the process group itself reports
 
     roofline = None
     if timer is not None and timer.records:
@@ -507,6 +544,8 @@ def main():
                "config": {"workload": workload,
                           "global_batch": batch * world, "segment_length": T_SEG,
                           "parallelism": "dp%d" % world, "launch": "hipGraph replay" if use_graph else "eager",
+                          **({"ranks": dist_ranks, "backend": "rccl" if args.backend == "nccl" else args.backend,
+                              "ddp_mode": {k: r.mode for k, r in (getattr(model, "reducers", None) or {}).items()}} if use_ddp else {}),
                           "steps_counted": ("one G+D optimisation step per GPU; value = steps of per-GPU batch 8 completed "
                                             "per second summed over GPUs (weak scaling)") if args.mode == "train" else
                                            "one step = %d segments through inference + stitching per GPU" % batch},

@@ -82,22 +82,31 @@ class ArenaReducer:
     def close(self):
         Fh.remove_grad_ready_hook(self._hook)
 
+    def _split(self, lo, hi):
+        """A bucket [lo, hi) is handed out in shards only over its prefix [lo, mid) whose length is a multiple of 8 * world:
+        every shard then starts 16-byte aligned in the float32 arenas AND in the float16 shadow (the Adam / scaler kernels
+        reject anything else: mg_adam_step_* `al16`), at every world size -- arena slices are padded to 8 elements only, so a
+        plain n / world split is misaligned at world 4 and 8.  The tail [mid, hi) (< 8 * world elements) is
+        all-reduced and updated redundantly by every rank."""
+        q = 8 * self.world
+        return lo + (hi - lo) // q * q
+
     def _launch(self, i):
         lo, hi, _ = self.buckets[i]
         if not (self.world > 1 or self.force) or not dist.is_initialized():     # (a reducer that outlived its group)
             return
-        n = hi - lo
-        if self.mode in ("rs_ag", "sharded") and n % self.world == 0:
-            shard = n // self.world
+        mid = self._split(lo, hi) if self.mode in ("rs_ag", "sharded") else lo
+        if mid > lo:
+            shard = (mid - lo) // self.world
             rank = dist.get_rank(self.group)
             mine = self.flat_g[lo + rank * shard:lo + (rank + 1) * shard]
-            w = dist.reduce_scatter_tensor(mine, self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w = dist.reduce_scatter_tensor(mine, self.flat_g[lo:mid], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             if self.mode == "sharded":
                 self.works.append(w)
             else:
-                self.works.append(dist.all_gather_into_tensor(self.flat_g[lo:hi], mine, group=self.group, async_op=True))
-        else:
-            self.works.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
+                self.works.append(dist.all_gather_into_tensor(self.flat_g[lo:mid], mine, group=self.group, async_op=True))
+        if mid < hi:
+            self.works.append(dist.all_reduce(self.flat_g[mid:hi], op=dist.ReduceOp.SUM, group=self.group,
                                               async_op=True))
 
     def _on_ready(self, p):
@@ -116,15 +125,16 @@ class ArenaReducer:
 
     def my_spans(self):
         """Arena ranges [lo, hi) whose reduced gradient this rank holds and whose parameters it updates: its 1/world of every
-        bucket that divides evenly; whole buckets otherwise (those were all-reduced: every rank updates them redundantly)."""
+        bucket's shardable prefix, plus the bucket's all-reduced tail (every rank updates that redundantly)."""
         rank = dist.get_rank(self.group)
         out = []
         for lo, hi, _ in self.buckets:
-            n = hi - lo
-            if n % self.world == 0:
-                out.append((lo + rank * (n // self.world), lo + (rank + 1) * (n // self.world)))
-            else:
-                out.append((lo, hi))
+            mid = self._split(lo, hi)
+            shard = (mid - lo) // self.world
+            if shard:
+                out.append((lo + rank * shard, lo + (rank + 1) * shard))
+            if mid < hi:
+                out.append((mid, hi))
         return out
 
     def restrict(self, spans):
@@ -149,10 +159,10 @@ class ArenaReducer:
         rank = dist.get_rank(self.group)
         works = []
         for lo, hi, _ in self.buckets:
-            n = hi - lo
-            if n % self.world == 0:
-                shard = n // self.world
-                works.append(dist.all_gather_into_tensor(flat_p[lo:hi], flat_p[lo + rank * shard:lo + (rank + 1) * shard],
+            mid = self._split(lo, hi)
+            shard = (mid - lo) // self.world
+            if shard:
+                works.append(dist.all_gather_into_tensor(flat_p[lo:mid], flat_p[lo + rank * shard:lo + (rank + 1) * shard],
                                                          group=self.group, async_op=True))
         return works
 
@@ -173,6 +183,23 @@ def broadcast_arena(flat_p, src=0, group=None):
         dist.broadcast(flat_p, src=src, group=group)
 
 
+SHARD_MIN_PARAMS = 64 << 20      # elements of one optimiser's arena from which "sharded" becomes the default at world >= 4
+
+
+def default_mode(world, n_params):
+    """The reduction mode when MDCTGAN_DDP_MODE is unset.  Rule: "sharded" (reduce-scatter, Adam on 1/world of the arena,
+    all-gather of the updated parameters) when world >= 4 AND the arena holds >= 64 Mi parameters; "allreduce" otherwise.
+    Why: both move the same bytes over xGMI, but the Adam kernel streams 28 B (float32) / 30 B (--fp16 shadow) per parameter at
+    ~4.9 TB/s and is a serial tail after backward -- configs[3]'s generator (736 M parameters) pays 4.6 ms of it per step and
+    rank, 0.6 ms at world 8 when sharded; the price is one found_inf MAX-agreement (--fp16) and a parameter all-gather that is
+    left running under the discriminator's backward pass.  Below 64 Mi parameters (every discriminator: 5.5 / 8.3 M) the whole
+    Adam launch is < 0.4 ms and not worth a second collective per bucket; at world 2 the saving is at most half of it."""
+    env = os.environ.get("MDCTGAN_DDP_MODE")
+    if env:
+        return env
+    return "sharded" if (world >= 4 and n_params >= SHARD_MIN_PARAMS) else "allreduce"
+
+
 def attach_optimizer(opt, writes_per_step=1, bucket_bytes=128 << 20, group=None):
     """Broadcast one FusedAdam's parameter arena from rank 0, create its gradient reducer and fold 1/world into the Adam
     kernel.  Returns the reducer (also used by Pix2PixHDModel.update_fixed_params when it replaces optimizer_G)."""
@@ -180,7 +207,8 @@ def attach_optimizer(opt, writes_per_step=1, bucket_bytes=128 << 20, group=None)
     slices = opt.arena_slices()
     broadcast_arena(opt.flat_p, 0, group)
     opt.resync_shadow()        # --fp16: the float16 shadow was cast from the PRE-broadcast weights
-    red = ArenaReducer(opt.flat_g, slices, writes_per_step, bucket_bytes, group)
+    n_params = sum(n for _, _, n in slices)
+    red = ArenaReducer(opt.flat_g, slices, writes_per_step, bucket_bytes, group, mode=default_mode(world, n_params))
     red.bucket_bytes = bucket_bytes
     opt.grad_scale = 1.0 / world
     opt.pre_step_hook = red.finish

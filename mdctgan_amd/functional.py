@@ -233,11 +233,21 @@ def _wgrad_fused(ctx_u, g, weight, x, gy, v, md):
     u = getattr(weight, "_mg_u_persist", None)
     if u is None or ctx_u is None or ctx_u.data_ptr() != u.data_ptr() or weight._mg_u_ok != weight._version:
         return False
+    # One Adam update per weight and optimiser step: a module applied twice in one forward whose weight was not annotated
+    # with _mg_writes = 2 would otherwise be stepped twice from the same bias-correction terms, with U rewritten between the
+    # two data gradients.  opt._step is the host's count of optimizer.step() calls.
+    if getattr(weight, "_mg_fused_stamp", None) == opt._step:
+        raise RuntimeError("a weight whose gradient, Adam update and transform are fused received a second gradient "
+                           "contribution in one backward pass: set weight._mg_writes = <uses per forward> on shared modules")
+    weight._mg_fused_stamp = opt._step
     grp = opt.param_groups[0]
     (b1, b2), eps = grp["betas"], grp["eps"]
     opt.sync_lr()
     ops.conv_wgrad_adam(g, x, gy, weight.detach(), weight._mg_m, weight._mg_v, u, opt.state, b1, b2, eps, opt.grad_scale, v=v, md=md)
-    return True        # (the gradient buffer stays "fresh": optimizer.step() skips this weight; u now matches the new weights)
+    # The gradient buffer stays "fresh": optimizer.step() skips this weight; u now matches the new weights.  weight.grad
+    # was NOT written this step -- it holds whatever an earlier unfused step left there; gradient readers (a norm logger)
+    # must run under MG_NO_WINO_ADAM_FUSION=1.
+    return True
 
 
 def _weight_image(g, weight, weight_grad=None):

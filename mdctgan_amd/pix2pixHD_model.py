@@ -472,6 +472,10 @@ class Pix2PixHDModel(BaseModel):
             # RCCL collectives are capturable (ProcessGroupNCCL records them into the graph from its own stream), but
             # that path has only been exercised with a 1-rank group on this hardware pool: opt-in
             raise NotImplementedError("graph capture of the data-parallel step is opt-in: MDCTGAN_DDP_GRAPH=1")
+        if getattr(self.opt, "pool_size", 0) > 0:
+            # ImagePool.query draws random.uniform / randint on the host: a replay would repeat the captured choices, and the
+            # stored history would live in the graph's private pool where replays overwrite it
+            raise NotImplementedError("--pool_size > 0 takes host-side random decisions every step: not capturable")
         static_lr, static_hr = lr_audio.clone(), hr_audio.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -528,6 +532,9 @@ class Pix2PixHDModel(BaseModel):
         owns a new arena, so everything that was wired to the old one follows: the GradScaler's found_inf slot, and under
         data parallelism the gradient reducer, the 1/world gradient scale and the pre-step hook."""
         old = self.optimizer_G
+        # sharded data parallelism: the previous step's all-gather into the OLD parameter arena may still be in flight on
+        # RCCL's stream; the new arena copies from views of the old one, so wait (and re-cast the old float16 shadow) first
+        old.finish_pending()
         params = [p for p in self.netG.parameters() if p.requires_grad]
         for p in params:                       # the new arena copies the current values; gradients start fresh
             p.grad = None

@@ -200,7 +200,11 @@ def _sharded_worker(rank, world, port, out_dir):
     assert opt.shard is red and red.sharded() and torch.equal(flat_p, p0)          # broadcast from rank 0
     assert len(red.buckets) >= 3 and opt.grad_scale == 1.0 / world
     spans = red.my_spans()
-    assert sum(hi - lo for lo, hi in spans) == n // world                            # every bucket divides: 1/world each
+    # 1/world of every bucket's prefix (a multiple of 8 * world elements); the ragged 8-element bucket is nobody's shard:
+    # it is all-reduced and updated by both ranks
+    q = 8 * world
+    want = sum((hi - lo) // q * q // world + (hi - lo) % q for lo, hi, _ in red.buckets)
+    assert sum(hi - lo for lo, hi in spans) == want and want < n // world + 3 * q
     ref = _HostAdam(p0.clone(), torch.zeros(n))                                      # single process on the averaged gradient
     for step in range(4):
         poison = step == 2
@@ -220,7 +224,7 @@ def _sharded_worker(rank, world, port, out_dir):
         assert torch.allclose(flat_p, ref.flat_p, rtol=0, atol=2e-6), (rank, step, float((flat_p - ref.flat_p).abs().max()))
         both = [torch.zeros(n) for _ in range(world)]
         dist.all_gather(both, flat_p)
-        assert torch.equal(both[0], both[1])
+        assert all(torch.equal(both[0], b) for b in both[1:])
     assert opt.skipped == 1 and opt.t == 3
     # moments exist only for the shards this rank owns
     owned = torch.zeros(n, dtype=torch.bool)
@@ -232,11 +236,64 @@ def _sharded_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_optimizer_and_inf_agreement(tmp_path):
+def test_default_mode_rule(monkeypatch):
+    """ddp.default_mode: sharded from 4 ranks and 64 Mi parameters on (configs[1] / configs[3] generators), all-reduce for the
+    discriminators and at world 2; MDCTGAN_DDP_MODE overrides."""
+    from mdctgan_amd import ddp
+    monkeypatch.delenv("MDCTGAN_DDP_MODE", raising=False)
+    assert ddp.default_mode(8, 736491201) == "sharded" and ddp.default_mode(4, 182433857) == "sharded"
+    assert ddp.default_mode(8, 8294232) == "allreduce" and ddp.default_mode(2, 736491201) == "allreduce"
+    assert ddp.default_mode(1, 736491201) == "allreduce"
+    monkeypatch.setenv("MDCTGAN_DDP_MODE", "rs_ag")
+    assert ddp.default_mode(8, 736491201) == "rs_ag"
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_optimizer_and_inf_agreement(tmp_path, world):
     """MDCTGAN_DDP_MODE=sharded (reduce-scatter -> each rank checks and updates its 1/world of every bucket -> all-gather of
     the parameter shards): 2 gloo ranks end every step with identical parameters equal to one process stepping on the
     averaged gradient; an inf in ONE rank's gradient makes BOTH ranks skip the step (GradScaler semantics on the global
     batch), also when the inf lies in a shard the other rank owns."""
     port = _free_port()
-    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    assert all(os.path.exists(os.path.join(str(tmp_path), "sh%d.npy" % r)) for r in range(2))
+    mp.spawn(_sharded_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "sh%d.npy" % r)) for r in range(world))
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_shard_spans_are_aligned_at_every_world_size(world, monkeypatch):
+    """arena slices are padded to 8 elements only, so bucket_length / world is not a multiple of 4 (float32,
+    16 bytes) or 8 (float16 shadow) at world 4 / 8 -- the discriminator arena of configs[2] has 8 294 232 elements: a shard of
+    2 073 558 at world 4, 1 036 779 at world 8 -- and mg_adam_step_* / mg_scaler_check reject such pointers.  Host logic over
+    the REAL discriminator arena layout (define_D num_D 3) and a generator-like layout with odd tensor sizes: every span of
+    every rank starts and ends on a multiple of 8 elements, the ranks' shards tile each bucket's prefix exactly once, and the
+    remainder (< 8 * world elements per bucket) is in every rank's list."""
+    from mdctgan_amd import ddp, networks
+    from mdctgan_amd.optim import _padded
+    netD = networks.define_D(3, 64, 3, "instance", False, 3, True, gpu_ids=[])
+    d_sizes = [p.numel() for p in netD.parameters()]
+    assert sum(_padded(k) for k in d_sizes) == 8294232
+    g_sizes = [2 * 64 * 49, 64, 128 * 64 * 9, 128, 1024 * 1024 * 9, 1024, 1024 * 1024 * 9, 1024, 77, 3, 64 * 49, 1]
+    monkeypatch.setattr(ddp.dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(ddp.dist, "get_world_size", lambda group=None: world)
+    for sizes, bucket_bytes in ((d_sizes, 128 << 20), (d_sizes, 1 << 20), (g_sizes, 16 << 20)):
+        params = [torch.nn.Parameter(torch.zeros(1)) for _ in sizes]
+        slices, off = [], 0
+        for p, k in zip(params, sizes):
+            slices.append((p, off, _padded(k)))
+            off += _padded(k)
+        red = ddp.ArenaReducer(torch.zeros(1), slices, 1, bucket_bytes, mode="sharded")
+        cover = np.zeros(off, dtype=np.int32)
+        for rank in range(world):
+            monkeypatch.setattr(ddp.dist, "get_rank", lambda group=None, r=rank: r)
+            spans = red.my_spans()
+            for lo, hi in spans:
+                assert lo % 8 == 0 and hi % 8 == 0 and lo < hi, (world, rank, lo, hi)
+                cover[lo:hi] += 1
+            # the optimiser's live spans (slice boundaries: multiples of 8) stay aligned after the intersection
+            for lo, hi in red.restrict([(slices[1][1], off)]):
+                assert lo % 8 == 0 and hi % 8 == 0
+        for lo, hi, _ in red.buckets:
+            mid = red._split(lo, hi)
+            assert hi - mid < 8 * world and (mid - lo) % (8 * world) == 0
+            assert (cover[lo:mid] == 1).all() and (cover[mid:hi] == world).all()
+        red.close()

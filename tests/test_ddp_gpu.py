@@ -306,3 +306,42 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path, mode, sync_bn):
     dD = (r0["pD"] - single.optimizer_D.flat_p.cpu()).abs()
     if sync_bn:
         assert dD.max().item() <= 2 * 2e-4 + 1e-6
+
+
+def _run_bench(*argv, env=None, timeout=900):
+    """bench.py as the driver starts it (a subprocess of the repo root); returns the parsed JSON line (the last line)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    full_env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    full_env.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], capture_output=True, text=True, timeout=timeout,
+                       cwd=root, env=full_env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    assert lines and lines[-1].startswith("{"), r.stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_force_ddp_one_rank_line():
+    """bench.py's data-parallel leg with a 1-rank RCCL group (what one MI355X can run): the line carries n_gpus, dpN and the
+    rank count / backend / reduction mode the process group reported."""
+    d = _run_bench("--gpus", "1", "--force-ddp", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-also", "--no-roofline")
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["unit"] == "steps/s"
+    cfg = d["config"]
+    assert cfg["parallelism"] == "dp1" and cfg["ranks"] == 1 and cfg["backend"] == "rccl"
+    assert cfg["ddp_mode"] == {"G": "allreduce", "D": "allreduce"} and cfg["global_batch"] == 8
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    """a plain `python bench.py --gpus 2` (no launcher, no WORLD_SIZE) must start two ranks itself and
+    print ONE line for the whole job.  One MI355X here: the two ranks share it and reduce over gloo (--backend gloo; RCCL
+    needs a device per rank) -- the launch path, rendezvous, per-rank batches, barrier / MAX-over-ranks timing and the
+    aggregate value are the ones the 8-GPU run uses."""
+    d = _run_bench("--gpus", "2", "--backend", "gloo", "--no-graph", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                   "--no-also", "--no-roofline")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    cfg = d["config"]
+    assert cfg["parallelism"] == "dp2" and cfg["ranks"] == 2 and cfg["backend"] == "gloo" and cfg["global_batch"] == 16
+    assert abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) < 1e-2 * d["value"]      # whole-job aggregate: 2 ranks' steps / time

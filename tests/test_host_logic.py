@@ -1,5 +1,7 @@
 """Host-side logic that needs no GPU: option contract, module trees / state-dict keys of the HIP-backed
 networks against the keys captured from the reference, layer-pattern compilation, optimiser arena maths."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -251,3 +253,32 @@ def test_image_pool_selects_like_the_reference(golden):
         assert got.shape == batch.shape and got[:, 0, 0, 0].tolist() == want.tolist(), q
     same = torch.randn(2, 3, 4, 4)
     assert ImagePool(0).query(same) is same
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """bench.py --gpus N outside a launcher re-runs itself under torch.distributed.run, one rank per GPU, rendezvous on
+    127.0.0.1 (the command shape the driver uses for N > 1), passing its own arguments through."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class Done:
+        returncode = 0
+
+    def fake_run(cmd, **kw):
+        seen["cmd"] = cmd
+        return Done()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    bench.main()
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
