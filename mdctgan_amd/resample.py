@@ -71,3 +71,19 @@ def make_training_pair(waveform: torch.Tensor, orig_sample_rate: int, hr_samplin
     hr = resample(waveform, orig_sample_rate, hr_sampling_rate)
     lr = resample(resample(waveform, orig_sample_rate, lr_sampling_rate), lr_sampling_rate, hr_sampling_rate)
     return seg_pad_audio(lr, segment_length), seg_pad_audio(hr, segment_length)
+
+
+def make_test_segments(raw_audio: torch.Tensor, in_sampling_rate: int, hr_sampling_rate: int, lr_sampling_rate: int,
+                       segment_length: int, gen_overlap: int = 0, is_lr_input: bool = False):
+    """AudioTestDataset (data/audio_dataset.py:141-186; add_noise off) for one waveform [1, L] in HBM: the DC shift of
+    read_audio (``raw += 1e-4 - mean(raw)``), then the low-rate input of the model -- a file that already IS low-rate
+    (``--is_lr_input``) is only brought up to hr_rate, anything else goes down to lr_rate and back up -- cut into segments
+    by seg_pad_audio (generate_audio.segment_audio).  -> (lr_audio [1, L'], segments [n_seg, segment_length])."""
+    from .generate_audio import segment_audio
+    raw = raw_audio.to(torch.float32)
+    raw = raw + (1e-4 - raw.mean())
+    if is_lr_input:
+        lr_audio = resample(raw, in_sampling_rate, hr_sampling_rate)
+    else:
+        lr_audio = resample(resample(raw, in_sampling_rate, lr_sampling_rate), lr_sampling_rate, hr_sampling_rate)
+    return lr_audio, segment_audio(lr_audio, segment_length, gen_overlap)

@@ -292,6 +292,105 @@ def main():
         returned.append(pool.query(batch)[:, 0, 0, 0].numpy().copy())
     save("g11_image_pool", returned=np.stack(returned), pool_size=np.array(3), seed=np.array(7))
 
+    # ---- G12 compute_matrics (util/util.py:132-177; train.py:104-134 eval_model, generate_audio.py:60-61) ---------------
+    # The reference's OWN function on two [2, 32512] triples.  Its one third-party call, torchaudio.functional.spectrogram
+    # (util.py:170-171; torchaudio is not installed), is stood in for by the 6-line torch.stft wrapper below -- torchaudio's
+    # published definition of spectrogram(pad=0, power=2, normalized=False): stft(center, pad_mode="reflect", onesided) then
+    # |.|^power.  Everything else -- MSE, the two SNRs, kbdwin(2 * win_length), the 2x STFT geometry, log10(. + 1e-6), the
+    # mean over dim=-2 (FREQUENCY bins) before the sqrt -- is the reference's arithmetic, in float32 as it runs there.
+    def spectrogram_stub(waveform, pad, window, n_fft, hop_length, win_length, power, normalized, center=True,
+                         pad_mode="reflect", onesided=True):
+        assert pad == 0 and power == 2 and normalized is False
+        s = torch.stft(waveform.reshape(-1, waveform.shape[-1]), n_fft=n_fft, hop_length=hop_length, win_length=win_length,
+                       window=window, center=center, pad_mode=pad_mode, normalized=False, onesided=onesided, return_complex=True)
+        return (s.abs() ** power).reshape(waveform.shape[:-1] + s.shape[-2:])
+    sys.modules["torchaudio.functional"].spectrogram = spectrogram_stub
+    mopt = ref_options(SPECTRAL)
+    arrs = dict(n_fft=np.array(mopt.n_fft), hop_length=np.array(mopt.hop_length), win_length=np.array(mopt.win_length),
+                center=np.array(bool(mopt.center)))
+    for case, (sigma, err) in enumerate([(0.05, 0.3), (1.0, 0.02)]):
+        hr_a = sigma * torch.randn(2, 32512, generator=g)
+        spec_ = torch.fft.rfft(hr_a)
+        spec_[:, spec_.shape[-1] // 4:] = 0
+        lr_a = torch.fft.irfft(spec_, n=32512)
+        sr_a = lr_a + err * (hr_a - lr_a) + 0.01 * sigma * torch.randn(2, 32512, generator=g)
+        got = rutil.compute_matrics(hr_a, lr_a, sr_a, mopt)
+        assert got[3:6] == (0, 0, 0)
+        arrs.update({"hr%d" % case: hr_a.numpy(), "lr%d" % case: lr_a.numpy(), "sr%d" % case: sr_a.numpy(),
+                     "metrics%d" % case: np.array(got, dtype=np.float64)})
+    hr_1d = 0.1 * torch.randn(32512, generator=g)                       # generate_audio.py:60 passes [1, T]; 1-D works too
+    arrs.update(hr2=hr_1d.numpy(), metrics2=np.array(rutil.compute_matrics(hr_1d, 0.5 * hr_1d, 0.9 * hr_1d, mopt), dtype=np.float64))
+    save("g12_metrics", **arrs)
+
+    # ---- G13 dataset chain (data/audio_dataset.py:34-110 AudioDataset, :153-186 AudioTestDataset / AudioAppDataset) ------
+    # The reference's dataset classes run as they are; the three torchaudio entry points they touch are stood in for:
+    # aF.resample by oracle/resample.py (the restatement of torchaudio's algorithm: that part stays UNPINNED), torchaudio.info /
+    # torchaudio.load by an in-memory "file" table.  What this pins is everything around the resampler: the random crop window
+    # (max_audio_start scales the segment by fs / hr_rate, the load takes segment_length frames AT THE FILE RATE), the
+    # HR / LR = down-then-up order, crop-or-pad to segment_length, the test set's DC shift (+1e-4 - mean), is_lr_input, and
+    # seg_pad_audio with --gen_overlap (front pad = overlap, unfold stride = segment_length - overlap).
+    from oracle import resample as oresample
+    ta, taf = sys.modules["torchaudio"], sys.modules["torchaudio.functional"]
+    sys.modules.setdefault("torchvision.transforms", types.ModuleType("torchvision.transforms"))
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    ta.set_audio_backend = lambda name: None
+    files = {"a44k.wav": (44100, 0.1 * torch.randn(1, 50000, generator=g)),
+             "b48k_short.wav": (48000, 0.1 * torch.randn(1, 5000, generator=g)),
+             "c16k.wav": (16000, 0.1 * torch.randn(1, 20000, generator=g))}
+    loads = []
+
+    class Meta:
+        pass
+
+    def info(path):
+        m = Meta()
+        m.sample_rate, m.num_frames = files[path][0], files[path][1].shape[-1]
+        return m
+
+    def load(path, frame_offset=0, num_frames=-1):
+        fs_, w_ = files[path]
+        w_ = w_[:, frame_offset:] if num_frames < 0 else w_[:, frame_offset:frame_offset + num_frames]
+        loads.append((path, frame_offset, w_.clone()))
+        return w_.clone(), fs_
+
+    def resample_stub(waveform, orig_freq, new_freq):
+        return torch.from_numpy(oresample.resample(waveform.numpy(), int(orig_freq), int(new_freq))).to(torch.float32)
+    ta.info, ta.load, taf.resample = info, load, resample_stub
+    import data.audio_dataset as rdata
+    seg = 8192
+    ds = rdata.AudioDataset.__new__(rdata.AudioDataset)          # __init__ walks opt.dataroot on disk; set its fields directly
+    ds.lr_sampling_rate, ds.hr_sampling_rate, ds.segment_length = 12000, 48000, seg
+    ds.n_fft, ds.hop_length, ds.win_length, ds.center, ds.add_noise, ds.snr = 512, 256, 512, True, False, 55
+    ds.audio_file = list(files)
+    ds.audio_len = [(0, 0)] * len(files)
+    torch.manual_seed(1234)                                      # AudioDataset.__init__: torch.manual_seed(opt.seed)
+    arrs = dict(segment_length=np.array(seg), hr_rate=np.array(48000), lr_rate=np.array(12000), names=np.array(list(files)))
+    for i, name in enumerate(files):
+        item = ds[i]
+        path, off, loaded = loads[-1]
+        assert path == name
+        arrs.update({"file%d" % i: files[name][1].numpy(), "fs%d" % i: np.array(files[name][0]), "offset%d" % i: np.array(off),
+                     "loaded%d" % i: loaded.numpy(), "HR%d" % i: item["HR_audio"].numpy(), "LR%d" % i: item["LR_audio"].numpy()})
+
+    class TOpt:
+        pass
+    for j, (overlap, is_lr, fs_in, n) in enumerate([(0, False, 48000, 20000), (256, False, 44100, 30000), (128, True, 12000, 6000),
+                                                    (64, False, 48000, 3000)]):
+        to = TOpt()
+        to.lr_sampling_rate, to.hr_sampling_rate, to.segment_length = 12000, 48000, seg
+        to.n_fft, to.hop_length, to.win_length, to.center = 512, 256, 512, True
+        to.is_lr_input, to.gen_overlap, to.add_noise, to.snr = is_lr, overlap, False, 55
+        raw = 0.1 * torch.randn(1, n, generator=g) + 0.01
+        # read_audio() (audio_dataset.py:141-151) is torchaudio.load + the in-place DC shift; AudioAppDataset (:186-204, the
+        # reference's own in-memory variant) skips it, so the shift is applied here with the reference's statement
+        shifted = raw.clone()
+        shifted += 1e-4 - torch.mean(shifted)
+        app = rdata.AudioAppDataset(to, shifted.clone(), fs_in)
+        arrs.update({"t_raw%d" % j: raw.numpy(), "t_fs%d" % j: np.array(fs_in), "t_overlap%d" % j: np.array(overlap),
+                     "t_is_lr%d" % j: np.array(is_lr), "t_lr_audio%d" % j: app.lr_audio.numpy(),
+                     "t_segments%d" % j: app.seg_audio.numpy(), "t_len%d" % j: np.array(len(app))})
+    save("g13_dataset_chain", **arrs)
+
 
 if __name__ == "__main__":
     main()

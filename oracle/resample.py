@@ -7,6 +7,11 @@ its published algorithm (torchaudio/functional/functional.py, ``_get_sinc_resamp
 ``_apply_sinc_resample_kernel``, BSD-2): **parity unpinned** -- there is no torchaudio here to generate vectors from and
 the reference holds no fixture for this path; the tests pin the restatement only through properties (unit DC gain,
 pass-band sines, identity at equal rates) and the HIP kernel against this restatement.
+
+The dataset chain AROUND the resampler is pinned (round 4): tests/golden/g13_dataset_chain.npz was captured from the
+reference's own AudioDataset / AudioAppDataset classes with aF.resample stood in for by ``resample`` below (cast to float32,
+the dtype torchaudio returns for float32 input); ``crop_window`` / ``training_item`` / ``inference_segments`` restate that chain
+and tests/test_oracle_golden.py holds them to the fixture bit for bit.
 """
 from __future__ import annotations
 
@@ -56,3 +61,60 @@ def resample(waveform, orig_freq: int, new_freq: int, lowpass_filter_width: int 
 def lr_from_hr(hr, hr_rate: int, lr_rate: int):
     """data/audio_dataset.py:68-71: down to lr_rate and back up to hr_rate (the low-rate input the model sees)."""
     return resample(resample(hr, hr_rate, lr_rate), lr_rate, hr_rate)
+
+
+def _resample32(x, orig, new):
+    """aF.resample on a float32 tensor returns float32: the chain below rounds between calls as the reference's tensors do."""
+    return resample(np.asarray(x, dtype=np.float32), orig, new).astype(np.float32)
+
+
+def crop_window(audio_length: int, fs: int, segment_length: int, hr_rate: int) -> int:
+    """data/audio_dataset.py:44: the exclusive upper bound of the random start frame.  The segment is scaled to the FILE's
+    rate here, but the load that follows takes ``segment_length`` frames at the file's rate regardless (:48-49): a 16 kHz file
+    yields 3x the duration, which the crop after resampling cuts back.  <= 0: the whole (short) file is loaded."""
+    return int(audio_length - segment_length * fs / hr_rate)
+
+
+def seg_pad_train(waveform, segment_length: int):
+    """AudioDataset.seg_pad_audio (:102-110) followed by __getitem__'s squeeze(0): [1, L] -> [segment_length]."""
+    w = np.asarray(waveform)
+    if w.shape[1] >= segment_length:
+        return w[0][:segment_length]
+    return np.pad(w, ((0, 0), (0, segment_length - w.shape[1])))[0]
+
+
+def training_item(waveform, fs: int, hr_rate: int, lr_rate: int, segment_length: int):
+    """AudioDataset.__getitem__ (:66-82, add_noise off): loaded [1, L] float32 at rate fs -> (HR, LR) [segment_length]."""
+    hr = _resample32(waveform, fs, hr_rate)
+    lr = _resample32(_resample32(waveform, fs, lr_rate), lr_rate, hr_rate)
+    return seg_pad_train(hr, segment_length), seg_pad_train(lr, segment_length)
+
+
+def seg_pad_test(audio, segment_length: int, overlap: int):
+    """AudioTestDataset.seg_pad_audio (:153-167): [1, L] or [L] -> [n_seg, segment_length]."""
+    a = np.asarray(audio).reshape(-1)
+    length = len(a)
+    if length >= segment_length:
+        n = int(math.ceil(length / segment_length))
+        a = np.pad(a, (overlap, segment_length * n - length + overlap))
+        step = segment_length - overlap
+        count = (len(a) - segment_length) // step + 1
+        return np.stack([a[i * step:i * step + segment_length] for i in range(count)])
+    return np.pad(a, (0, segment_length - length))[None]
+
+
+def inference_segments(raw_audio, fs: int, hr_rate: int, lr_rate: int, segment_length: int, overlap: int = 0, is_lr_input: bool = False):
+    """AudioTestDataset.read_audio's DC shift (:147: raw += 1e-4 - mean(raw), float32) + post_processing (:169-186, add_noise
+    off) + seg_pad_audio: raw [1, L] -> (lr_audio [1, L'], segments [n_seg, segment_length])."""
+    raw = np.asarray(raw_audio, dtype=np.float32)
+    import torch
+    t = torch.from_numpy(raw.copy())
+    t += 1e-4 - torch.mean(t)                      # torch's float32 mean (pairwise), as the reference computes it
+    raw = t.numpy()
+    if is_lr_input:
+        lr_audio = _resample32(raw, fs, hr_rate)
+    else:
+        lr_audio = _resample32(_resample32(raw, fs, lr_rate), lr_rate, hr_rate)
+    return lr_audio, seg_pad_test(lr_audio, segment_length, overlap)
+
+

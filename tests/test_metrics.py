@@ -88,3 +88,24 @@ def test_eval_model_loop(tmp_path):
     eval_model(model, batches, opt, path)
     rows = open(path).read().strip().splitlines()
     assert rows[0] == "err,snr,snr_seg,pesq,lsd" and len(rows) == 3
+
+
+@pytest.mark.gpu
+def test_compute_matrics_against_the_reference_fixture(golden):
+    """G12: the reference's own compute_matrics (float32 on the host).  The device path accumulates its sums in double and
+    runs the STFT as an exact-float32 GEMM, so it sits closer to the float64 yardstick than the reference does: MSE / SNR to
+    float32 rounding of the REFERENCE's sums, the LSD within the reference's own float32 error (1.5e-3 on the quiet case)."""
+    from mdctgan_amd.metrics import compute_matrics
+    g = golden("g12_metrics")
+    opt = types.SimpleNamespace(n_fft=int(g["n_fft"]), hop_length=int(g["hop_length"]), win_length=int(g["win_length"]),
+                                center=bool(g["center"]))
+    cases = [(g["hr0"], g["lr0"], g["sr0"], g["metrics0"]), (g["hr1"], g["lr1"], g["sr1"], g["metrics1"]),
+             (g["hr2"], 0.5 * g["hr2"], 0.9 * g["hr2"], g["metrics2"])]
+    for hr, lr, sr, want in cases:
+        got = compute_matrics(torch.from_numpy(hr), torch.from_numpy(lr), torch.from_numpy(sr).to("cuda"), opt)
+        exact = M.compute_matrics(hr, lr, sr, center=opt.center)
+        assert got[3:6] == (0, 0, 0)
+        assert abs(got[0] - want[0]) <= 2e-6 * want[0]
+        assert abs(got[1] - want[1]) <= 2e-5 and abs(got[2] - want[2]) <= 2e-5                # dB
+        assert abs(got[6] - want[6]) <= 1.5e-3 * want[6]
+        assert abs(got[6] - exact[6]) <= 2e-4 * exact[6]

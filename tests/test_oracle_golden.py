@@ -278,3 +278,61 @@ def test_c_oracle(golden):
     lib.oracle_denormalize(P(out, fp), out.size, 1000.0, -5.0, 5.0, -1.0, 1.0, P(back, dp))
     lib.oracle_imdct4(P(back, dp), 2, 32, 512, P(w, fp), P(audio, dp))
     assert np.abs(audio - g4["audio"][:, 0, 0]).max() <= 1e-12
+
+
+def test_metrics_oracle_reproduces_reference_compute_matrics(golden):
+    """G12 = the reference's own util/util.py:132-177 compute_matrics on [2, 32512] and [32512] triples (aF.spectrogram stood
+    in for by torch.stft, oracle/gen_golden.py).  The float32 restatement must reproduce it to float32 rounding -- this is
+    what pins kbdwin(2 * win_length), the doubled STFT geometry, the +1e-6 floor and the mean over dim=-2 (frequency);
+    the float64 yardstick the HIP path is compared with agrees to the float32 error of the reference itself."""
+    from oracle import metrics as M
+    g = golden("g12_metrics")
+    kw = dict(n_fft=int(g["n_fft"]), hop_length=int(g["hop_length"]), win_length=int(g["win_length"]), center=bool(g["center"]))
+    cases = [(g["hr0"], g["lr0"], g["sr0"], g["metrics0"]), (g["hr1"], g["lr1"], g["sr1"], g["metrics1"]),
+             (g["hr2"], 0.5 * g["hr2"], 0.9 * g["hr2"], g["metrics2"])]
+    for hr, lr, sr, want in cases:
+        got32 = M.compute_matrics(hr, lr, sr, precision="float32", **kw)
+        got64 = M.compute_matrics(hr, lr, sr, **kw)
+        assert tuple(got32[3:6]) == (0, 0, 0) and tuple(want[3:6]) == (0, 0, 0)
+        for i in (0, 1, 2, 6):
+            assert abs(got32[i] - want[i]) <= 2e-6 * abs(want[i]), (i, got32[i], want[i])
+        assert abs(got64[0] - want[0]) <= 1e-6 * want[0]
+        assert abs(got64[1] - want[1]) <= 1e-5 and abs(got64[2] - want[2]) <= 1e-5          # dB
+        assert abs(got64[6] - want[6]) <= 1.5e-3 * want[6]
+    # the axis of the mean: reducing over frames (dim=-1) instead of frequency gives a different number on these signals
+    hr, sr = g["hr0"].astype(np.float64), g["sr0"].astype(np.float64)
+    from oracle import transform
+    kws = dict(n_fft=1024, hop_length=512, win_length=1024, window=transform.kbd_window(1024), center=True)
+    d = (np.log10(M.spectrogram_power(hr, **kws) + 1e-6) - np.log10(M.spectrogram_power(sr, **kws) + 1e-6)) ** 2
+    wrong = float(np.sqrt(d.mean(-1)).mean())
+    assert abs(wrong - g["metrics0"][6]) > 1e-2 * g["metrics0"][6]
+
+
+def test_dataset_chain_oracle_reproduces_reference(golden):
+    """G13 = the reference's own AudioDataset.__getitem__ / AudioAppDataset (data/audio_dataset.py:34-110, 153-204) over an
+    in-memory file table with aF.resample stood in for by oracle/resample.py.  The restated chain must be bit-identical:
+    crop window and load length, HR and LR = down-then-up order, crop-or-pad, the test set's DC shift, --is_lr_input and
+    seg_pad_audio with --gen_overlap."""
+    from oracle import resample as R
+    g = golden("g13_dataset_chain")
+    seg, hr_rate, lr_rate = int(g["segment_length"]), int(g["hr_rate"]), int(g["lr_rate"])
+    torch.manual_seed(1234)                                   # AudioDataset.__init__: torch.manual_seed(opt.seed)
+    for i in range(3):
+        wav, fs, off = g["file%d" % i], int(g["fs%d" % i]), int(g["offset%d" % i])
+        hi = R.crop_window(wav.shape[-1], fs, seg, hr_rate)
+        if hi > 0:
+            assert off == torch.randint(low=0, high=hi, size=(1,)).item()
+            loaded = wav[:, off:off + seg]
+        else:
+            assert off == 0
+            loaded = wav
+        assert np.array_equal(loaded, g["loaded%d" % i])
+        hr, lr = R.training_item(loaded, fs, hr_rate, lr_rate, seg)
+        assert hr.shape == lr.shape == (seg,)
+        assert np.array_equal(hr, g["HR%d" % i]) and np.array_equal(lr, g["LR%d" % i]), i
+    assert int(g["offset0"]) > 0 and g["loaded1"].shape[-1] < seg and g["HR1"][5000:].any() == False   # noqa: E712 (padded tail)
+    for j in range(4):
+        lr_audio, segs = R.inference_segments(g["t_raw%d" % j], int(g["t_fs%d" % j]), hr_rate, lr_rate, seg, int(g["t_overlap%d" % j]),
+                                         bool(g["t_is_lr%d" % j]))
+        assert np.array_equal(lr_audio, g["t_lr_audio%d" % j]), j
+        assert segs.shape[0] == int(g["t_len%d" % j]) and np.array_equal(segs, g["t_segments%d" % j]), j

@@ -67,3 +67,32 @@ def test_training_pair_matches_dataset_chain():
     short = 0.1 * torch.randn(1, 1000, generator=gen)
     lr2, hr2 = make_training_pair(short.to("cuda"), 48000, 48000, 12000, 4096)
     assert lr2.shape == (1, 4096) and hr2[0, 1000:].abs().sum().item() == 0.0
+
+
+@pytest.mark.gpu
+def test_dataset_chain_against_the_reference_fixture(golden):
+    """G13: HR / LR of the reference's own AudioDataset.__getitem__ and the segments of its AudioAppDataset (aF.resample stood
+    in for by the oracle's resampler: that arithmetic stays unpinned, the chain around it is the reference's).  The device
+    chain must land on the same samples to the float32 resampler's rounding, with exactly the same shapes, zero padding and
+    segment boundaries."""
+    from mdctgan_amd.resample import make_test_segments, make_training_pair
+    g = golden("g13_dataset_chain")
+    seg, hr_rate, lr_rate = int(g["segment_length"]), int(g["hr_rate"]), int(g["lr_rate"])
+    for i in range(3):
+        loaded, fs = torch.from_numpy(g["loaded%d" % i]).to("cuda"), int(g["fs%d" % i])
+        lr, hr = make_training_pair(loaded, fs, hr_rate, lr_rate, seg)
+        for got, want in ((hr, g["HR%d" % i]), (lr, g["LR%d" % i])):
+            assert tuple(got.shape) == (1, seg)
+            got = got[0].cpu().numpy()
+            assert np.abs(got - want).max() <= 4e-6 * np.abs(want).max(), i
+            assert np.array_equal(got == 0, want == 0) or np.abs(got[want == 0]).max() <= 4e-6 * np.abs(want).max()
+    assert hr_rate == 48000 and float(np.abs(g["HR1"][5000:]).max()) == 0.0
+    for j in range(4):
+        raw = torch.from_numpy(g["t_raw%d" % j]).to("cuda")
+        lr_audio, segs = make_test_segments(raw, int(g["t_fs%d" % j]), hr_rate, lr_rate, seg, int(g["t_overlap%d" % j]),
+                                            bool(g["t_is_lr%d" % j]))
+        want_lr, want_seg = g["t_lr_audio%d" % j], g["t_segments%d" % j]
+        assert tuple(lr_audio.shape) == want_lr.shape and tuple(segs.shape) == want_seg.shape, j
+        scale = np.abs(want_lr).max()
+        assert np.abs(lr_audio.cpu().numpy() - want_lr).max() <= 4e-6 * scale, j
+        assert np.abs(segs.cpu().numpy() - want_seg).max() <= 4e-6 * scale, j
