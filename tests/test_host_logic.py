@@ -282,3 +282,26 @@ def test_bench_self_launch_command(monkeypatch):
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+
+
+def test_fp16_gradient_verdict_rejects_zero_and_flipped_gradients():
+    """The --fp16 generator-gradient bar of tests/test_fullsize_step_gpu.py (the old "4 x the reference's
+    error" bar was > 1 and passed an all-zero gradient).  With a reference (CPU-autocast) gradient 0.4 away from float64 --
+    the measured situation -- a second float16-like evaluation passes; zeros, a sign flip, a 3x scale and pure noise fail."""
+    import importlib.util
+    root = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("fullsize_step_helpers", os.path.join(root, "test_fullsize_step_gpu.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(0)
+    g64 = rng.standard_normal(20000)
+    noise = lambda s: s * rng.standard_normal(20000)      # noqa: E731
+    g16 = g64 + noise(0.4)
+    verdict = mod.fp16_gradient_verdict
+    assert verdict(g64 + noise(0.4), g64, g16)[0]            # another evaluation with the reference's own error level
+    assert verdict(g64 + noise(0.05), g64, g16)[0]           # a better one
+    assert not verdict(np.zeros_like(g64), g64, g16)[0]      # zeros: relative error exactly 1.0 -- passed the round-3 bar
+    assert not verdict(-g16, g64, g16)[0]                    # sign flip
+    assert not verdict(3.0 * g16, g64, g16)[0]               # scale error (a lost 1 / loss-scale)
+    assert not verdict(noise(1.0), g64, g16)[0]              # unrelated values of the right size
+    assert not verdict(g64 + noise(0.8), g64, g16)[0]        # twice the reference's error
