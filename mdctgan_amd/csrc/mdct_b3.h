@@ -1,0 +1,331 @@
+// K1 / K2 with the 256-point DCT-IV on the bf16 MFMA pipe, float32-accurate (round 4).  Included by mdct.hip after
+// mdct_bs.h (needs M, CodecParams, bs_* helpers).
+//
+// Why: the contraction is MFMA-bound (68.7 GFLOP per 4096 clips: 437 us at the f32 MFMA peak against 134..201 us of HBM
+// time), and v_mfma_f32_32x32x2_f32 runs at 1/16 of the rate of v_mfma_f32_32x32x16_bf16.  A float32 value is the EXACT sum
+// of three bf16 pieces (x = h + m + l: h = bf16(x), m = bf16(x - h), l = bf16(x - h - m); both subtractions are exact), a
+// bf16 x bf16 product is exact in the MFMA's float32 accumulator, so
+//     a * b = ah bh + (ah bm + am bh) + (am bm + ah bl + al bh) + O(2^-24 |a b|)
+// -- six bf16 MFMAs per 16 k instead of eight f32 MFMAs of twice the length: 192 cycles instead of 512.  The three dropped
+// terms (am bl, al bm, al bl) are below one float32 ulp of the product; measured against the float64 oracle the spectra are
+// as close as the f32-pipe kernels' (tests/test_mdct_gpu.py, same 2e-6 * max bar; frames stay bit-exact: the window
+// multiply and the TDAC fold are the float32 operations of mdct_bs.h).
+//
+// Table-stationary like mdct_bs.h, but the table is now three bf16 images (3 x 128 KB): a workgroup of FOUR waves, one per
+// SIMD with the whole 512-entry register file (256 VGPR + 256 AGPR) -- wave w keeps bins [64 w, 64 w + 64) for all 256 k
+// and all three pieces in 384 registers (the MFMA reads its B operand straight from AGPRs) and streams 32-frame row tiles
+// past them.  Per tile and wave: 16 k-blocks x (3 ds_read_b128 of the A pieces + 12 MFMAs) = 192 MFMAs = 6144 cycles.
+//
+// K1 (mdct4_b3_kernel) per tile, interleaved behind single MFMAs (one basic block, pieces pinned with sched_barrier):
+//   * the codec + stores of tile i - 1 out of the previous accumulators (32 values per lane);
+//   * 33 LDS-DMA pieces (buffer_load ... lds, 1 KiB each) that bring tile i + 1's hop blocks of raw audio into LDS --
+//     no register holds a load in flight (the budget has none left);
+//   * after a mid-stream barrier the fold of tile i + 1: window (float32 product, mdct.py:410), TDAC fold, split into the
+//     three bf16 pieces, written as MFMA A operands into the other LDS buffer.
+// K2 (imdct4_b3_kernel): a workgroup walks whole clips, tile by tile in frame order, so the frame in front of a tile is the
+// last row of the tile before (kept in a 3-slot LDS ring) -- no halo recomputation.
+#pragma once
+
+namespace {
+
+typedef unsigned b3_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned b3_u2 __attribute__((ext_vector_type(2)));
+typedef __bf16 b3_bf8 __attribute__((ext_vector_type(8)));
+typedef int b3_v4i __attribute__((ext_vector_type(4)));
+
+constexpr int B3_ROWS = 32;                     // frames per tile
+constexpr int B3_NT = 256;                      // 4 waves
+constexpr int B3_BLK = 33 * 16;                 // bytes of one (k-block, k-half) group of the A image: 32 rows x 16 B + 16 B pad
+constexpr int B3_PIECE = 32 * B3_BLK;           // one bf16 piece of a tile: 16 k-blocks x 2 halves
+constexpr int B3_ABUF = 3 * B3_PIECE;           // 50 688 B
+constexpr int B3_RAW = 33 * 1024;               // 33 hop blocks of raw audio
+constexpr int B3_IMG_U4 = 3 * 4 * 2 * 16 * 64;  // table image: [piece][wave][bin block][k-block][lane] x 16 B = 384 KB
+
+__device__ __forceinline__ unsigned b3_pk(float a, float b) {          // (bf16(a), bf16(b)) round-to-nearest-even, a in the low half
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float b3_lo(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float b3_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+// four float32 -> their three bf16 pieces (4 x bf16 = 8 bytes per piece)
+__device__ __forceinline__ void b3_split4(const float4 u, b3_u2& h, b3_u2& m, b3_u2& l) {
+    h.x = b3_pk(u.x, u.y); h.y = b3_pk(u.z, u.w);
+    const float r0 = u.x - b3_lo(h.x), r1 = u.y - b3_hi(h.x), r2 = u.z - b3_lo(h.y), r3 = u.w - b3_hi(h.y);
+    m.x = b3_pk(r0, r1); m.y = b3_pk(r2, r3);
+    l.x = b3_pk(r0 - b3_lo(m.x), r1 - b3_hi(m.x)); l.y = b3_pk(r2 - b3_lo(m.y), r3 - b3_hi(m.y));
+}
+__device__ __forceinline__ f32x16 b3_mfma(b3_u4 a, b3_u4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b3_bf8, a), __builtin_bit_cast(b3_bf8, b), c, 0, 0, 0);
+}
+// One LDS-DMA piece: 64 lanes x 16 bytes from the buffer at byte offset voff (per lane; out of range: zeros) to LDS byte address
+// lds_dst + 16 * lane.  Inline asm like dense_gemm.h::dg_dma16 (the builtin makes hipcc wait vmcnt(0) before the next ds_read).
+__device__ __forceinline__ void b3_dma16(unsigned voff, b3_v4i rsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ void b3_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Table image: img[(((p * 4 + wave) * 2 + blk) * 16 + kb) * 64 + lane] = piece p of D4[bin][16 kb + 8 (lane >> 5) + (0..7)],
+// bin = 64 wave + 32 blk + (lane & 31)  (D4 is symmetric: row bin == column bin): the B operand of MFMA step kb, coalesced.
+__global__ void dct4_b3_image_kernel(const float* __restrict__ d4, b3_u4* __restrict__ img) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * 2 * 16 * 64) return;
+    const int lane = i & 63, kb = (i >> 6) & 15, blk = (i >> 10) & 1, wave = i >> 11;
+    const float* src = d4 + (size_t)(64 * wave + 32 * blk + (lane & 31)) * M + 16 * kb + 8 * (lane >> 5);
+    b3_u2 h0, m0, l0, h1, m1, l1;
+    b3_split4(*reinterpret_cast<const float4*>(src), h0, m0, l0);
+    b3_split4(*reinterpret_cast<const float4*>(src + 4), h1, m1, l1);
+    constexpr int P = 4 * 2 * 16 * 64;
+    img[i] = b3_u4{h0.x, h0.y, h1.x, h1.y};
+    img[P + i] = b3_u4{m0.x, m0.y, m1.x, m1.y};
+    img[2 * P + i] = b3_u4{l0.x, l0.y, l1.x, l1.y};
+}
+
+// The 12 MFMAs of one k-block, smallest terms first; SLOT(s) runs the side work of MFMA slot 12 * kb + s right behind it.
+// a3 is used first and a1 last, so that the A pieces of the next k-block can be fetched into the same registers piece by
+// piece (a3 after slot 1, a2 after slot 5, a1 after slot 11): 12 registers of A operand, every fetch >= 6 MFMAs ahead.
+#define B3_KBLOCK(KB, SLOT)                                                                        \
+    acc0 = b3_mfma(a3, bt[0][0][KB], acc0); SLOT(0);  acc1 = b3_mfma(a3, bt[0][1][KB], acc1); SLOT(1);  \
+    if (KB + 1 < 16) a3 = *reinterpret_cast<const b3_u4*>(ap + 2 * B3_PIECE + (KB + 1) * 2 * B3_BLK);   \
+    acc0 = b3_mfma(a2, bt[1][0][KB], acc0); SLOT(2);  acc1 = b3_mfma(a2, bt[1][1][KB], acc1); SLOT(3);  \
+    acc0 = b3_mfma(a2, bt[0][0][KB], acc0); SLOT(4);  acc1 = b3_mfma(a2, bt[0][1][KB], acc1); SLOT(5);  \
+    if (KB + 1 < 16) a2 = *reinterpret_cast<const b3_u4*>(ap + B3_PIECE + (KB + 1) * 2 * B3_BLK);       \
+    acc0 = b3_mfma(a1, bt[2][0][KB], acc0); SLOT(6);  acc1 = b3_mfma(a1, bt[2][1][KB], acc1); SLOT(7);  \
+    acc0 = b3_mfma(a1, bt[1][0][KB], acc0); SLOT(8);  acc1 = b3_mfma(a1, bt[1][1][KB], acc1); SLOT(9);  \
+    acc0 = b3_mfma(a1, bt[0][0][KB], acc0); SLOT(10); acc1 = b3_mfma(a1, bt[0][1][KB], acc1); SLOT(11); \
+    if (KB + 1 < 16) a1 = *reinterpret_cast<const b3_u4*>(ap + (KB + 1) * 2 * B3_BLK);
+
+// ------------------------------------------------------------------------------------------------------------------
+// K1.  grid = workers (<= 256), block = 256.  SPEC: write the 1-channel spectrogram; PAIR: write the 2-channel network input
+// (v, 2|v| + nr0) -- with PAIR alone the spectrogram is channel 0 of the pair (393 216 B per clip instead of 526 848).
+// ------------------------------------------------------------------------------------------------------------------
+template <int MODE, bool SPEC, bool PAIR, bool STATS, int DBG = 0>
+__global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict__ audio, int B, int T, int F,
+                                                         const float* __restrict__ window, const b3_u4* __restrict__ img,
+                                                         CodecParams cp, float* __restrict__ spec, float* __restrict__ in2,
+                                                         double* __restrict__ stats) {
+    constexpr int Q = M / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char b3_smem[];
+    float* ws = reinterpret_cast<float*>(b3_smem);                 // [2 M] window, then [2 M] its negative
+    unsigned char* abuf = b3_smem + 4 * M * sizeof(float);         // [2][B3_ABUF] A operand pieces
+    float* raw = reinterpret_cast<float*>(abuf + 2 * B3_ABUF);     // [33][256] hop blocks of the tile being folded
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rows = B * F, n_tiles = (rows + B3_ROWS - 1) / B3_ROWS, G = gridDim.x;
+    const int col = wave * 64 + (lane & 31), kh = lane >> 5;       // bin of accumulator block 0 (block 1: col + 32)
+    const float k1 = (float)(((double)cp.nr1 - (double)cp.nr0) / ((double)cp.mx - (double)cp.mn));
+    const float k0 = (float)((double)cp.nr0 - (double)cp.mn * (((double)cp.nr1 - (double)cp.nr0) / ((double)cp.mx - (double)cp.mn)));
+    const float gain = cp.gain, nr0 = cp.nr0;
+    const b3_v4i r_audio = __builtin_bit_cast(b3_v4i, __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(audio), 0, (unsigned)B * (unsigned)T * 4u, 0x00020000));
+    const __amdgpu_buffer_rsrc_t r_spec = __builtin_amdgcn_make_buffer_rsrc(spec, 0, (SPEC && !(DBG & 1)) ? (unsigned)rows * M * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_in2 = __builtin_amdgcn_make_buffer_rsrc(in2, 0, (PAIR && !(DBG & 1)) ? (unsigned)rows * M * 8u : 0u, 0x00020000);
+    const unsigned raw_lds = (unsigned)(uintptr_t)raw;             // LDS byte address (the low 32 bits of a __shared__ pointer)
+
+    // hop block `slot` (0: the first half of row 0; r + 1: the second half of row r) of `tile`, fetched by wave slot % 4
+    auto dma_slot = [&](int tile, int slot) {
+        const int r = slot == 0 ? 0 : slot - 1;
+        const int m = tile * B3_ROWS + r;
+        const int b = m / F, f = m - b * F - (slot == 0 ? 1 : 0);
+        const int t = f * M + 4 * lane;                          // T % 4 == 0: a float4 is inside or outside the clip as a whole
+        const bool ok = m < rows && f >= 0 && t + 3 < T;
+        b3_dma16(ok ? ((unsigned)b * (unsigned)T + (unsigned)t) * 4u : BS_OOB, r_audio, raw_lds + 1024u * slot);
+    };
+    // Fold group gi: row r = wave + 4 gi, u[n .. n + 3], n = 4 lane (mdct_bs.h).  Lanes n < Q read the second half of the frame
+    // (hop block r + 1) only, lanes n >= Q the first half (hop block r: zero padding when the row is frame 0 of its clip):
+    //   n <  Q:  u = -rev(z[3Q-4-n ..]) - z[3Q+n ..]        n >= Q:  u = z[n-Q ..] - rev(z[3Q-4-n ..]),   z = fl32(x * w)
+    const int n = 4 * lane;
+    const bool lo = n < Q;
+    const int o1 = 3 * Q - 4 - n, o2 = lo ? 3 * Q + n : n - Q;     // frame sample index of the reversed / the straight run
+    const float* wS = ws + (lo ? 2 * M : 0) + o2;                  // (the straight run's sign rides in the window copy)
+    const int s1 = lo ? o1 - M : o1, s2 = lo ? o2 - M : o2;        // the same runs as offsets inside the lane's hop block
+    float4 fz1, fz2, fw1, fw2;
+    b3_u2 fh, fm, fl;
+    auto fold_piece = [&](int pc, int gi, int tile, int buf) {
+        const int r = wave + 4 * gi;
+        if (pc == 0) {
+            const float* blk = raw + (r + (lo ? 1 : 0)) * M;
+            fz1 = bs_ld4(blk + s1); fz2 = bs_ld4(blk + s2);
+        } else if (pc == 1) {
+            fw1 = bs_ld4(ws + o1); fw2 = bs_ld4(wS);
+            if (!lo) {                                             // frame 0 of a clip: its first half is the zero padding
+                const int m = tile * B3_ROWS + r;
+                const bool first = (m % F) == 0;
+                if (first) { fz1 = make_float4(0.f, 0.f, 0.f, 0.f); fz2 = fz1; }
+            }
+        } else if (pc == 2) {       // z = fl32(x * w) (mdct.py:410)
+            fz1 = make_float4(__fmul_rn(fz1.x, fw1.x), __fmul_rn(fz1.y, fw1.y), __fmul_rn(fz1.z, fw1.z), __fmul_rn(fz1.w, fw1.w));
+            fz2 = make_float4(__fmul_rn(fz2.x, fw2.x), __fmul_rn(fz2.y, fw2.y), __fmul_rn(fz2.z, fw2.z), __fmul_rn(fz2.w, fw2.w));
+        } else if (pc == 3) {       // the TDAC fold:  u = (+-z)[straight] - rev(z[reversed])
+            fz1 = make_float4(fz2.x - fz1.w, fz2.y - fz1.z, fz2.z - fz1.y, fz2.w - fz1.x);
+        } else if (pc == 4) {
+            b3_split4(fz1, fh, fm, fl);
+        } else {
+            // A image: k-block n >> 4, k-half (n >> 3) & 1 -> group n >> 3 = lane >> 1; 8-byte half (n >> 2) & 1 = lane & 1
+            unsigned char* dst = abuf + (size_t)buf * B3_ABUF + (lane >> 1) * B3_BLK + r * 16 + (lane & 1) * 8;
+            *reinterpret_cast<b3_u2*>(dst) = fh;
+            *reinterpret_cast<b3_u2*>(dst + B3_PIECE) = fm;
+            *reinterpret_cast<b3_u2*>(dst + 2 * B3_PIECE) = fl;
+        }
+    };
+    // epilogue of the previous tile: value v = 16 blk + reg of this lane: frame row em0 + (r & 3) + 8 (r >> 2), bin col + 32 blk
+    float ea, ea2, et, ep, esq, esm, el, ev, elog = 0.0f;
+    double sd1 = 0.0, sd2 = 0.0;
+    float f1 = 0.0f, f2 = 0.0f;
+    int em0 = 0;
+    unsigned eob = BS_OOB, eob2 = BS_OOB;
+    auto epi_piece = [&](int pc, float xv, int v) {
+        const int r = v & 15, blk = v >> 4;
+        const int dm = (r & 3) + 8 * (r >> 2);
+        if (MODE == CODEC_RAW || (DBG & 2)) {
+            if (pc == 0) ev = xv;
+        } else if (pc == 0) {
+            const float y = gain * xv;
+            ea = fabsf(y); ea2 = ea * ea; et = ea2 + 1.0f; el = y;
+        } else if (pc == 1) {
+            esq = __builtin_amdgcn_sqrtf(et);
+            ep = fmaf(ea2, fmaf(ea2, fmaf(ea2, -0.044642857142857144f, 0.075f), -0.16666666666666666f), 1.0f);
+        } else if (pc == 2) {
+            et = __builtin_amdgcn_logf(ea + esq);
+            esm = ea * ep * INV_LN10F;
+        } else if (pc == 3) {
+            const float big = et * LOG10_2F;
+            elog = copysignf(ea < 0.125f ? esm : big, el);
+        } else if (pc == 4) {
+            ev = fmaf(elog, k1, k0);          // (l - min) / (max - min) * (nr1 - nr0) + nr0, constants folded in double (mdct_bs.h)
+        }
+        if (STATS && pc == 5 && MODE != CODEC_RAW) {
+            const float l = (em0 + dm < rows) ? elog : 0.0f;
+            f1 += l; f2 = fmaf(l, l, f2);
+        }
+        if (pc == 6 && SPEC) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ev), r_spec, eob + 128u * blk, dm * (M * 4), 0);
+        } else if (pc == 7 && PAIR) {
+            const bs_v2u pr = {__float_as_uint(ev), __float_as_uint(fmaf(fabsf(ev), 2.0f, nr0))};
+            __builtin_amdgcn_raw_buffer_store_b64(pr, r_in2, eob2 + 256u * blk, dm * (M * 8), 0);
+        }
+    };
+    auto epi_begin = [&](int tile) {         // tile == n_tiles: nothing to store
+        if (STATS && MODE != CODEC_RAW) { sd1 += (double)f1; sd2 += (double)f2; f1 = f2 = 0.0f; }
+        const unsigned m0 = (unsigned)tile * B3_ROWS + 4u * kh;
+        eob = (tile < n_tiles) ? (m0 * M + (unsigned)col) * 4u : BS_OOB - 31u * M * 8u - 256u;
+        eob2 = (tile < n_tiles) ? 2u * eob : eob;
+        em0 = (tile < n_tiles) ? (int)m0 : rows;
+    };
+
+    // prologue: raw audio of the first tile by DMA, the window, the table (384 registers), then the first fold
+    int tile = blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { const int s = wave + 4 * i; if (s < 33) dma_slot(tile < n_tiles ? tile : n_tiles, s); }
+    if (tid < 2 * M / 4) {
+        const float4 wv = bs_ld4(window + 4 * tid);
+        reinterpret_cast<float4*>(ws)[tid] = wv;
+        reinterpret_cast<float4*>(ws + 2 * M)[tid] = make_float4(-wv.x, -wv.y, -wv.z, -wv.w);
+    }
+    b3_u4 bt[3][2][16];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int bk = 0; bk < 2; ++bk)
+#pragma unroll
+            for (int kb = 0; kb < 16; ++kb) bt[p][bk][kb] = img[(((p * 4 + wave) * 2 + bk) * 16 + kb) * 64 + lane];
+    b3_wait_vm0();
+    __syncthreads();
+#pragma unroll
+    for (int gi = 0; gi < 8; ++gi)
+#pragma unroll
+        for (int pc = 0; pc < 6; ++pc) fold_piece(pc, gi, tile, 0);
+    __syncthreads();
+
+    f32x16 accp0 = f32x16{0}, accp1 = f32x16{0};
+    int buf = 0;
+    epi_begin(n_tiles);
+    for (; tile < n_tiles; tile += G, buf ^= 1) {
+        const int next = (tile + G < n_tiles) ? tile + G : n_tiles;          // (tile n_tiles: every row out of range -> zeros)
+        f32x16 acc0 = f32x16{0}, acc1 = f32x16{0};
+        const unsigned char* ap = abuf + (size_t)buf * B3_ABUF + kh * B3_BLK + (lane & 31) * 16;
+        b3_u4 a1 = *reinterpret_cast<const b3_u4*>(ap), a2 = *reinterpret_cast<const b3_u4*>(ap + B3_PIECE),
+              a3 = *reinterpret_cast<const b3_u4*>(ap + 2 * B3_PIECE);
+        __builtin_amdgcn_sched_barrier(0);
+        // first half of the stream (k-blocks 0..9, 120 slots): per slot two codec / store pieces of the previous tile's 32 values
+        // (value v in slots 4 v' ..: 32 values x 8 pieces = 256 pieces over 128 slots -> k-blocks 0..10 carry them), and one
+        // DMA piece every third slot from slot 1 on
+#define B3_SLOT_A(KB, s)                                                                                         \
+        do {                                                                                                       \
+            constexpr int slot = 12 * (KB) + (s);                                                                  \
+            if (slot < 128) {                                                                                      \
+                constexpr int v = slot >> 2, p0 = 2 * (slot & 3);                                                  \
+                const float xv = v < 16 ? accp0[v & 15] : accp1[v & 15];                                           \
+                epi_piece(p0, xv, v); epi_piece(p0 + 1, xv, v);                                                    \
+            }                                                                                                      \
+            if (!(DBG & 4) && slot % 3 == 1 && slot / 3 < 9) { const int sl = wave + 4 * (slot / 3); if (sl < 33) dma_slot(next, sl); } \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+        } while (0)
+#define SLOT0(s) B3_SLOT_A(0, s)
+#define SLOT1(s) B3_SLOT_A(1, s)
+#define SLOT2(s) B3_SLOT_A(2, s)
+#define SLOT3(s) B3_SLOT_A(3, s)
+#define SLOT4(s) B3_SLOT_A(4, s)
+#define SLOT5(s) B3_SLOT_A(5, s)
+#define SLOT6(s) B3_SLOT_A(6, s)
+#define SLOT7(s) B3_SLOT_A(7, s)
+#define SLOT8(s) B3_SLOT_A(8, s)
+#define SLOT9(s) B3_SLOT_A(9, s)
+        B3_KBLOCK(0, SLOT0) B3_KBLOCK(1, SLOT1) B3_KBLOCK(2, SLOT2) B3_KBLOCK(3, SLOT3) B3_KBLOCK(4, SLOT4)
+        B3_KBLOCK(5, SLOT5) B3_KBLOCK(6, SLOT6) B3_KBLOCK(7, SLOT7) B3_KBLOCK(8, SLOT8) B3_KBLOCK(9, SLOT9)
+        // k-block 10: the last 8 epilogue slots (120..127); then the raw audio of the next tile must have landed everywhere
+#define SLOT10(s) B3_SLOT_A(10, s)
+        B3_KBLOCK(10, SLOT10)
+        b3_wait_vm0();
+        __syncthreads();
+        // second half (k-blocks 11..15, 60 slots): the fold of the next tile, 8 groups x 6 pieces = 48 pieces
+#define B3_SLOT_B(KB, s)                                                                                         \
+        do {                                                                                                       \
+            constexpr int q = 12 * ((KB) - 11) + (s);                                                              \
+            if (!(DBG & 4) && q < 48) fold_piece(q % 6, q / 6, next, buf ^ 1);                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+        } while (0)
+#define SLOT11(s) B3_SLOT_B(11, s)
+#define SLOT12(s) B3_SLOT_B(12, s)
+#define SLOT13(s) B3_SLOT_B(13, s)
+#define SLOT14(s) B3_SLOT_B(14, s)
+#define SLOT15(s) B3_SLOT_B(15, s)
+        B3_KBLOCK(11, SLOT11) B3_KBLOCK(12, SLOT12) B3_KBLOCK(13, SLOT13) B3_KBLOCK(14, SLOT14) B3_KBLOCK(15, SLOT15)
+#undef SLOT0
+#undef SLOT1
+#undef SLOT2
+#undef SLOT3
+#undef SLOT4
+#undef SLOT5
+#undef SLOT6
+#undef SLOT7
+#undef SLOT8
+#undef SLOT9
+#undef SLOT10
+#undef SLOT11
+#undef SLOT12
+#undef SLOT13
+#undef SLOT14
+#undef SLOT15
+#undef B3_SLOT_A
+#undef B3_SLOT_B
+        accp0 = acc0; accp1 = acc1;
+        epi_begin(tile);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int v = 0; v < 32; ++v)
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) epi_piece(pc, v < 16 ? accp0[v & 15] : accp1[v & 15], v);
+    if (STATS && MODE != CODEC_RAW) {
+        sd1 += (double)f1; sd2 += (double)f2;
+        sd1 = wave_sum_d(sd1); sd2 = wave_sum_d(sd2);
+        if (lane == 0) { atomicAdd(stats, sd1); atomicAdd(stats + 1, sd2); }
+    }
+}
+
+constexpr size_t B3_K1_LDS = (size_t)4 * M * sizeof(float) + 2 * B3_ABUF + B3_RAW;
+
+}  // namespace
