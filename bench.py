@@ -74,7 +74,7 @@ class KernelTimer:
     to find the dominant kernel; with a target only that kernel's launches are probed (cheap)."""
 
     def __init__(self, ops, lib, target=None):
-        self.ops, self.lib, self.target, self.records = ops, lib, target, []
+        self.ops, self.lib, self.target, self.records, self.stream_records = ops, lib, target, [], []
         self.ev = HipEvents()
         self.names = {}
 
@@ -92,6 +92,20 @@ class KernelTimer:
     def end(self):
         pass
 
+    # the optimiser's elementwise launches (ops.adam_step_* / scaler_check): events on torch's current stream -- the stream
+    # those single-kernel calls are launched on -- right around the launch; the "work" column holds algorithmic HBM bytes
+    def stream_begin(self, name, nbytes):
+        name = "[hbm] " + name
+        if self.target is not None and name != self.target:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return (name, nbytes, e0, e1)
+
+    def stream_end(self, token):
+        token[3].record()
+        self.stream_records.append(token)
+
     def summary(self):
         agg = {}
         for name, kflops, cflops, e0, e1 in self.records:
@@ -100,6 +114,11 @@ class KernelTimer:
             a[1] += kflops
             a[2] += self.ev.elapsed_s(e0, e1)
             a[3] += cflops
+        for name, nbytes, e0, e1 in self.stream_records:
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += nbytes
+            a[2] += e0.elapsed_time(e1) * 1e-3
         return agg
 
 
@@ -453,7 +472,28 @@ def main():
         dist_ranks = dist.get_world_size()          # the rank count the process group itself reports
 
     roofline = None
-    if timer is not None and timer.records:
+    if timer is not None and dominant.startswith("[hbm] ") and timer.stream_records:
+        # the step's dominant kernel is the optimiser's elementwise stream (configs[2]: 736 M parameters x 30 B): HBM-bound
+        torch.cuda.synchronize()
+        n, nbytes, secs, _ = timer.summary()[dominant]
+        gbps = nbytes / secs / 1e9
+        roofline = {"bound": "hbm", "kernel": dominant[6:], "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(gbps / 8000.0, 4), "traffic": None, "launches": n, "avg_launch_us": round(secs / n * 1e6, 2),
+                    "bytes_per_launch": nbytes / n,
+                    "bytes_definition": "algorithmic bytes of the Adam update: read p, g, m, v and write p, m, v in float32 (28 B per "
+                                        "parameter), + 2 B for the float16 shadow copy under --fp16 (30 B); summed over the launches",
+                    "timed": "torch events on the launch stream (torch's current stream, which these single-kernel calls are launched "
+                             "on) right around every launch of this kernel in %d eager iterations%s" % (
+                                 args.steps, " run right after the graph-replayed timed region" if use_graph else " of the timed region")}
+        tr = os.path.join(REPO, "profiles", "traffic.json")
+        if os.path.exists(tr):
+            try:
+                section = "configs[%d]%s" % (args.config, " --fp16" if args.fp16 else "")
+                doc = json.load(open(tr))
+                roofline["traffic"] = (doc.get(section) or {}).get(dominant[6:])
+            except Exception:
+                pass
+    elif timer is not None and timer.records:
         n, flops, secs, conv_flops = timer.summary()[dominant]
         achieved = flops / secs / 1e12
         f16_kernel = dominant.startswith("hgemm") or (     # float16 GEMMs (conv_h16.h), HALF / TAG bit 1 convolution instances

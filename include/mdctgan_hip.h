@@ -59,14 +59,20 @@ int mg_conv_geom_size(void);
  *   frames_out (nullable): windowed frames [B, F, n_fft] (return_frames=True).
  *   stats (nullable): double[2] = sum(L), sum(L^2) over the batch (for the returned mean / std).
  *   scratch_u32: >= 2*B uint32, required when per_sample != 0.
- *   window [n_fft] and dct4 are device tables.  dct4 = 2 * (n_fft/2)^2 floats: the [n_fft/2][n_fft/2] table
- *   cos(pi/M (n+1/2)(k+1/2)) followed by its register image, which mg_dct4_image(dct4, dct4 + (n_fft/2)^2, stream)
- *   writes once (the table-stationary kernels of csrc/mdct_bs.h load their operand slabs from it, coalesced).
+ *   window [n_fft] and dct4 [n_fft/2][n_fft/2] = cos(pi/M (n+1/2)(k+1/2)) are device tables.
+ *   dct4_image (nullable): mg_dct4_image_floats(n_fft) floats that mg_dct4_image(dct4, dct4_image, stream) fills once per
+ *   table -- the operand images the table-stationary kernels keep in registers (csrc/mdct_bs.h: the float32 register image;
+ *   csrc/mdct_b3.h: three bf16 piece images, the float32 value being their exact sum).  NULL selects the kernels that read
+ *   the plain table only (a caller written against the round-1 ABI passes its m*m table and NULL).  16-byte aligned.
+ *   spec may be NULL when in2 is given and the table-stationary kernels apply (dct4_image present, T % 4 == 0, 16-byte aligned
+ *   pointers, no per_sample, no frames_out; MG_ERR_ARG otherwise): the spectrogram is then channel 0 of the pair only
+ *   (393 216 B per clip moved instead of 526 848).
  */
-int mg_dct4_image(const float* dct4, float* image, void* stream);
+long long mg_dct4_image_floats(int n_fft);
+int mg_dct4_image(const float* dct4, float* dct4_image, void* stream);
 int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* window, const float* dct4,
-                     int codec, float gain, float nr0, float nr1, float src_min, float src_max, int per_sample,
-                     float* spec, float* in2, float* frames_out, float* min_out, float* max_out,
+                     const float* dct4_image, int codec, float gain, float nr0, float nr1, float src_min, float src_max,
+                     int per_sample, float* spec, float* in2, float* frames_out, float* min_out, float* max_out,
                      double* stats, unsigned* scratch_u32, void* stream);
 int mg_mdct4_num_frames(int T, int n_fft);
 
@@ -77,7 +83,7 @@ int mg_mdct4_num_frames(int T, int n_fft);
  *   frames_out (nullable): windowed synthesis frames [B, F, n_fft].
  */
 int mg_imdct4_forward(const float* spec, int B, int F, int n_fft, const float* window, const float* dct4,
-                      int codec, float gain, float nr0, float nr1, float src_min, float src_max,
+                      const float* dct4_image, int codec, float gain, float nr0, float nr1, float src_min, float src_max,
                       const float* min_b, const float* max_b, void* audio, int out_len, int out_f64,
                       float* frames_out, void* stream);
 

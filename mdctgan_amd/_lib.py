@@ -58,10 +58,11 @@ _WA = C.POINTER(WinoAdam)
 SIGNATURES = {
     "mg_abi_version": (_i, []),
     "mg_conv_geom_size": (_i, []),
-    "mg_mdct4_forward": (_i, [_p, _i, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "mg_mdct4_forward": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _f, _f, _f, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "mg_mdct4_num_frames": (_i, [_i, _i]),
     "mg_dct4_image": (_i, [_p, _p, _p]),
-    "mg_imdct4_forward": (_i, [_p, _i, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _p, _p, _p, _i, _i, _p, _p]),
+    "mg_dct4_image_floats": (_ll, [_i]),
+    "mg_imdct4_forward": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _f, _f, _f, _f, _f, _p, _p, _p, _i, _i, _p, _p]),
     "mg_conv_fwd": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p]),
     "mg_conv_fwd_workspace": (_sz, [_G]),
     "mg_conv_wino_weights_bytes": (_sz, [_G]),

@@ -442,6 +442,7 @@ __global__ void stitch_kernel(const T* __restrict__ seg, int n_seg, int L, int o
 }  // namespace
 
 #include "mdct_bs.h"
+#include "mdct_b3.h"
 
 // frames per workgroup: a whole-clip tile (4 MFMAs per B fetch) once the launch fills the chip, 32 otherwise
 static int frames_per_wg(int B, int F) {
@@ -462,10 +463,10 @@ size_t mg_mdct4_lds_bytes() { return (128 * LDA + 2 * M) * sizeof(float); }
 
 // See include/mdctgan_hip.h for the contract.
 int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* window, const float* dct4,
-                     int codec, float gain, float nr0, float nr1, float src_min, float src_max, int per_sample,
+                     const float* dct4_image, int codec, float gain, float nr0, float nr1, float src_min, float src_max, int per_sample,
                      float* spec, float* in2, float* frames_out, float* min_out, float* max_out,
                      double* stats, unsigned* scratch_u32, void* stream) {
-    if (!audio || !window || !dct4 || !spec || B <= 0 || T <= 0) return MG_ERR_ARG;
+    if (!audio || !window || !dct4 || (!spec && !in2) || B <= 0 || T <= 0) return MG_ERR_ARG;
     if (n_fft != 2 * M) return MG_ERR_UNSUPPORTED;
     if (per_sample && (!scratch_u32 || !min_out || !max_out || codec == CODEC_RAW)) return MG_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -483,12 +484,42 @@ int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* w
     // round 3: the table-stationary kernel (mdct_bs.h) wherever its fast path applies; MG_MDCT_BS=0, or any of the older
     // kernels' own switches (MG_MDCT_GEMM, MG_MDCT_FT), selects the round-1 / round-2 kernels below
     static const bool bs_off = (getenv("MG_MDCT_BS") && atoi(getenv("MG_MDCT_BS")) == 0);
-    const bool legacy_forced = bs_off || getenv("MG_MDCT_GEMM") || getenv("MG_MDCT_FT");
+    // the table-stationary kernels read register images of the table (mg_dct4_image): without one the round-1 / round-2 kernels run
+    const bool legacy_forced = bs_off || !dct4_image || getenv("MG_MDCT_GEMM") || getenv("MG_MDCT_FT");
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const long long n_rows = (long long)B * F;
+    // round 4: the bf16 x 3 kernel (mdct_b3.h) from 512 row tiles on (two per CU: below that the 384 KB table prologue is not
+    // amortised and the f32-pipe kernel with its 2-wave latency shape is faster); MG_MDCT_B3=0 / 1 overrides
+    {
+        const long long n_tiles = (n_rows + B3_ROWS - 1) / B3_ROWS;
+        bool b3 = n_tiles >= 512;
+        if (const char* e = getenv("MG_MDCT_B3")) b3 = atoi(e) != 0;
+        if (b3 && !legacy_forced && T % 4 == 0 && !per_sample && !frames_out && (codec == CODEC_RAW || codec == CODEC_ARCSINH) &&
+            !(codec == CODEC_RAW && in2) && n_rows * M * 8 < (1ll << 32) - (1ll << 18) && (long long)B * T * 4 < (1ll << 32) &&
+            al16(audio) && al16(window) && al16(dct4_image) && (!spec || al16(spec)) && (!in2 || al16(in2)) && (spec || in2)) {
+            const b3_u4* img = reinterpret_cast<const b3_u4*>(dct4_image + M * M);
+            const dim3 grid((unsigned)(n_tiles < 256 ? n_tiles : 256)), block(B3_NT);
+#define MG_K1_B3(MODE_, SPEC_, PAIR_, STATS_)                                                                             \
+    do {                                                                                                                   \
+        static bool attr = false;                                                                                          \
+        if (!attr) { allow_lds(mdct4_b3_kernel<MODE_, SPEC_, PAIR_, STATS_>, B3_K1_LDS); attr = true; }                    \
+        hipLaunchKernelGGL((mdct4_b3_kernel<MODE_, SPEC_, PAIR_, STATS_>), grid, block, B3_K1_LDS, st, audio, B, T, F, window, img, cp, \
+                           spec, in2, stats);                                                                              \
+    } while (0)
+#define MG_K1_B3_S(MODE_, SPEC_, PAIR_) do { if (stats) MG_K1_B3(MODE_, SPEC_, PAIR_, true); else MG_K1_B3(MODE_, SPEC_, PAIR_, false); } while (0)
+            if (codec == CODEC_RAW) MG_K1_B3(CODEC_RAW, true, false, false);
+            else if (in2 && spec) MG_K1_B3_S(CODEC_ARCSINH, true, true);
+            else if (in2) MG_K1_B3_S(CODEC_ARCSINH, false, true);
+            else MG_K1_B3_S(CODEC_ARCSINH, true, false);
+#undef MG_K1_B3_S
+#undef MG_K1_B3
+            MG_CHECK_LAUNCH();
+            return MG_OK;
+        }
+    }
     if (!legacy_forced && T % 4 == 0 && !per_sample && !frames_out && (codec == CODEC_RAW || codec == CODEC_ARCSINH) &&
         !(codec == CODEC_RAW && in2) && n_rows * M * 8 < (1ll << 32) - (1ll << 17) && (long long)B * T * 4 < (1ll << 32) &&
-        al16(audio) && al16(window) && al16(dct4) && al16(spec) && (!in2 || al16(in2))) {
+        al16(audio) && al16(window) && al16(dct4_image) && (!spec || al16(spec)) && (!in2 || al16(in2))) {
         const long long n_tiles = (n_rows + BS_ROWS - 1) / BS_ROWS;
         int nw = n_tiles >= 256 ? 8 : 2;
         if (const char* e = getenv("MG_MDCT_BS_NW")) nw = atoi(e) == 8 ? 8 : 2;
@@ -497,7 +528,7 @@ int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* w
     do {                                                                                                                   \
         static bool attr = false;                                                                                          \
         if (!attr) { allow_lds(mdct4_bs_kernel<NW_, MODE_, PAIR_, STATS_>, BS_K1_LDS); attr = true; }                      \
-        hipLaunchKernelGGL((mdct4_bs_kernel<NW_, MODE_, PAIR_, STATS_>), grid, block, BS_K1_LDS, st, audio, B, T, F, window, dct4, cp, \
+        hipLaunchKernelGGL((mdct4_bs_kernel<NW_, MODE_, PAIR_, STATS_>), grid, block, BS_K1_LDS, st, audio, B, T, F, window, dct4_image, cp, \
                            spec, in2, stats);                                                                              \
     } while (0)
 #define MG_K1_BS_S(NW_, MODE_, PAIR_) do { if (stats) MG_K1_BS(NW_, MODE_, PAIR_, true); else MG_K1_BS(NW_, MODE_, PAIR_, false); } while (0)
@@ -509,6 +540,7 @@ int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* w
         MG_CHECK_LAUNCH();
         return MG_OK;
     }
+    if (!spec) return MG_ERR_ARG;          // (only the table-stationary kernels write the pair alone)
     // large batches: the tiled GEMM kernel (B operand shared through LDS); MG_MDCT_GEMM=0/1 overrides
     const long long row_tiles = ((long long)B * F + 127) / 128;
     bool gemm = row_tiles >= 256;
@@ -542,9 +574,16 @@ int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* w
     return MG_OK;
 }
 
+long long mg_dct4_image_floats(int n_fft) {
+    if (n_fft != 2 * M) return 0;
+    return (long long)M * M + (long long)B3_IMG_U4 * 4;          // f32 register image + three bf16 piece images
+}
+
 int mg_dct4_image(const float* dct4, float* image, void* stream) {
     if (!dct4 || !image || (reinterpret_cast<uintptr_t>(dct4) & 15) || (reinterpret_cast<uintptr_t>(image) & 15)) return MG_ERR_ARG;
     hipLaunchKernelGGL(dct4_image_kernel, dim3(M * M / 4 / 256), dim3(256), 0, (hipStream_t)stream, dct4, image);
+    hipLaunchKernelGGL(dct4_b3_image_kernel, dim3(4 * 2 * 16 * 64 / 256), dim3(256), 0, (hipStream_t)stream, dct4,
+                       reinterpret_cast<b3_u4*>(image + M * M));
     MG_CHECK_LAUNCH();
     return MG_OK;
 }
@@ -556,7 +595,7 @@ int mg_mdct4_num_frames(int T, int n_fft) {
 }
 
 int mg_imdct4_forward(const float* spec, int B, int F, int n_fft, const float* window, const float* dct4,
-                      int codec, float gain, float nr0, float nr1, float src_min, float src_max,
+                      const float* dct4_image, int codec, float gain, float nr0, float nr1, float src_min, float src_max,
                       const float* min_b, const float* max_b, void* audio, int out_len, int out_f64,
                       float* frames_out, void* stream) {
     if (!spec || !window || !dct4 || !audio || B <= 0 || F <= 0) return MG_ERR_ARG;
@@ -575,7 +614,26 @@ int mg_imdct4_forward(const float* spec, int B, int F, int n_fft, const float* w
     {
         static const bool bs_off = (getenv("MG_MDCT_BS") && atoi(getenv("MG_MDCT_BS")) == 0);
         auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-        if (!bs_off && !getenv("MG_MDCT_FT") && !frames_out && !out_f64 && out_len % 4 == 0 && al16(spec) && al16(window) && al16(dct4) &&
+        // round 4: the bf16 x 3 kernel (mdct_b3.h): a workgroup walks whole clips, so it wants >= 256 clips (and >= 512 tiles)
+        bool b3 = B >= 256 && (long long)B * ((F + B3_ROWS - 1) / B3_ROWS) >= 512;
+        if (const char* e = getenv("MG_MDCT_B3")) b3 = atoi(e) != 0;
+        if (b3 && !bs_off && dct4_image && !getenv("MG_MDCT_FT") && !frames_out && !out_f64 && out_len % 4 == 0 && al16(spec) && al16(window) &&
+            al16(dct4_image) && al16(audio) && (long long)B * F * M * 4 < (1ll << 32) && (long long)B * out_len * 4 < (1ll << 32) - (1ll << 16) &&
+            codec >= CODEC_RAW && codec <= CODEC_RANGE) {
+            const b3_u4* img = reinterpret_cast<const b3_u4*>(dct4_image + M * M);
+            const dim3 grid((unsigned)(B < 256 ? B : 256));
+#define MG_K2_B3(MODE_)                                                                                                   \
+    do {                                                                                                                   \
+        static bool attr = false;                                                                                          \
+        if (!attr) { allow_lds(imdct4_b3_kernel<MODE_>, B3_K2_LDS); attr = true; }                                         \
+        hipLaunchKernelGGL((imdct4_b3_kernel<MODE_>), grid, dim3(B3_NT), B3_K2_LDS, st, spec, B, F, window, img, cp, (float*)audio, out_len); \
+    } while (0)
+            if (codec == CODEC_RAW) MG_K2_B3(CODEC_RAW); else if (codec == CODEC_ARCSINH) MG_K2_B3(CODEC_ARCSINH); else MG_K2_B3(CODEC_RANGE);
+#undef MG_K2_B3
+            MG_CHECK_LAUNCH();
+            return MG_OK;
+        }
+        if (!bs_off && dct4_image && !getenv("MG_MDCT_FT") && !frames_out && !out_f64 && out_len % 4 == 0 && al16(spec) && al16(window) && al16(dct4_image) &&
             al16(audio) && (long long)B * F * M * 4 < (1ll << 32) && (long long)B * out_len * 4 < (1ll << 32) - (1ll << 16) &&
             codec >= CODEC_RAW && codec <= CODEC_RANGE) {
             const long long n_tiles = (long long)B * ((F + BS_ROWS - 1) / BS_ROWS);
@@ -584,7 +642,7 @@ int mg_imdct4_forward(const float* spec, int B, int F, int n_fft, const float* w
     do {                                                                                                                   \
         static bool attr = false;                                                                                          \
         if (!attr) { allow_lds(imdct4_bs_kernel<MODE_>, BS_K2_LDS); attr = true; }                                         \
-        hipLaunchKernelGGL((imdct4_bs_kernel<MODE_>), grid, dim3(512), BS_K2_LDS, st, spec, B, F, window, dct4, cp, (float*)audio, out_len); \
+        hipLaunchKernelGGL((imdct4_bs_kernel<MODE_>), grid, dim3(512), BS_K2_LDS, st, spec, B, F, window, dct4_image, cp, (float*)audio, out_len); \
     } while (0)
             if (codec == CODEC_RAW) MG_K2_BS(CODEC_RAW); else if (codec == CODEC_ARCSINH) MG_K2_BS(CODEC_ARCSINH); else MG_K2_BS(CODEC_RANGE);
 #undef MG_K2_BS

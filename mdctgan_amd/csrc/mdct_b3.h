@@ -119,7 +119,12 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
     const float k1 = (float)(((double)cp.nr1 - (double)cp.nr0) / ((double)cp.mx - (double)cp.mn));
     const float k0 = (float)((double)cp.nr0 - (double)cp.mn * (((double)cp.nr1 - (double)cp.nr0) / ((double)cp.mx - (double)cp.mn)));
     const float gain = cp.gain, nr0 = cp.nr0;
-    const b3_v4i r_audio = __builtin_bit_cast(b3_v4i, __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(audio), 0, (unsigned)B * (unsigned)T * 4u, 0x00020000));
+    b3_v4i r_audio;                                                // (a plain V# for the inline-asm DMA)
+    {
+        const unsigned long long a = (unsigned long long)audio;
+        r_audio[0] = (int)(unsigned)a; r_audio[1] = (int)((unsigned)(a >> 32) & 0xffffu);
+        r_audio[2] = (int)((unsigned)B * (unsigned)T * 4u); r_audio[3] = 0x00020000;
+    }
     const __amdgpu_buffer_rsrc_t r_spec = __builtin_amdgcn_make_buffer_rsrc(spec, 0, (SPEC && !(DBG & 1)) ? (unsigned)rows * M * 4u : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_in2 = __builtin_amdgcn_make_buffer_rsrc(in2, 0, (PAIR && !(DBG & 1)) ? (unsigned)rows * M * 8u : 0u, 0x00020000);
     const unsigned raw_lds = (unsigned)(uintptr_t)raw;             // LDS byte address (the low 32 bits of a __shared__ pointer)
@@ -327,5 +332,210 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
 }
 
 constexpr size_t B3_K1_LDS = (size_t)4 * M * sizeof(float) + 2 * B3_ABUF + B3_RAW;
+
+// ------------------------------------------------------------------------------------------------------------------
+// K2.  grid = workers (<= 256, <= B), block = 256.  A workgroup walks whole clips b = blockIdx.x, + G, ..., each tile by tile in
+// frame order: tile = frames f0 .. f0 + 31, emits hop blocks h = f0 .. f0 + 31:
+//   out[(h - 1) M + n] = 4 / N * (w[n] y_h[n] + w[n + M] y_{h-1}[n + M]),  y = [v2, -v2_r, -v1_r, -v1] of v = DCT-IV(X);
+// frame f0 - 1 is row 31 of the tile before (same clip, kept in a 2-slot LDS ring; hop block 0 of a clip is cropped anyway).
+// Per tile behind the 192 MFMAs: the unfold / window / overlap-add / store of tile i - 1 out of the v tile in LDS, the loads
+// (two batches of four float4 per thread) and the decode (denormalise, sinh) + bf16 split of tile i + 1 into the other
+// operand buffer.  Two barriers per tile: every wave has finished reading v before the new v tile is written.
+// ------------------------------------------------------------------------------------------------------------------
+template <int MODE, int DBG = 0>
+__global__ __launch_bounds__(B3_NT) void imdct4_b3_kernel(const float* __restrict__ spec, int B, int F,
+                                                          const float* __restrict__ window, const b3_u4* __restrict__ img,
+                                                          CodecParams cp, float* __restrict__ audio, int out_len) {
+    constexpr int Q = M / 2;
+    constexpr int V_F = B3_ROWS * BS_LDA;                          // v tile: [32][M + 4] floats
+    extern __shared__ __attribute__((aligned(16))) unsigned char b3_smem[];
+    unsigned char* abuf = b3_smem;                                 // [2][B3_ABUF] decoded coefficients as bf16 pieces
+    float* vbuf = reinterpret_cast<float*>(abuf + 2 * B3_ABUF);    // [V_F] v = DCT-IV(X) of the tile before
+    float* halo = vbuf + V_F;                                      // [2][M] row 31 of the last two tiles
+    float* wl = halo + 2 * M;                                      // [2 M] window
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tpc = (F + B3_ROWS - 1) / B3_ROWS, G = gridDim.x;
+    const int my_clips = ((int)blockIdx.x < B) ? (B - 1 - (int)blockIdx.x) / G + 1 : 0;
+    const int n_seq = my_clips * tpc;                              // this workgroup's tiles, clip by clip, frames ascending
+    const int col = wave * 64 + (lane & 31), kh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t r_spec = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(spec), 0, (unsigned)B * (unsigned)F * M * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(audio, 0, (DBG & 1) ? 0u : (unsigned)B * (unsigned)out_len * 4u, 0x00020000);
+    auto clip_of = [&](int i) { return (int)blockIdx.x + (i / tpc) * G; };
+    auto f0_of = [&](int i) { return (i % tpc) * B3_ROWS; };
+
+    // x = v * c1 + c0 (= ln10 * ((v - nr0) / (nr1 - nr0) * (max - min) + min)), X = sinh(x) / gain; constants in double per tile
+    float c1 = 1.0f, c0 = 0.0f;
+    const float rgain = 1.0f / cp.gain;
+    auto tile_consts = [&](int i) {
+        const int b = i < n_seq ? clip_of(i) : 0;
+        float mn = cp.mn, mx = cp.mx;
+        if (cp.per_sample) { mn = cp.mn_b[b]; mx = cp.mx_b[b]; }
+        const double k = ((double)mx - (double)mn) / ((double)cp.nr1 - (double)cp.nr0);
+        const double sc = (MODE == CODEC_ARCSINH) ? (double)LN10F : 1.0;
+        c1 = (float)(k * sc);
+        c0 = (float)(((double)mn - (double)cp.nr0 * k) * sc);
+    };
+    bs_v4u xr[8];
+    int nf0 = 0;                                                 // first frame of the tile being prepared, F when there is none
+    auto load_tile = [&](int i) {                                // decode group g: row wave + 4 g, coefficients 4 lane ..+3
+        const int b = i < n_seq ? clip_of(i) : 0;
+        nf0 = i < n_seq ? f0_of(i) : F;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int f = nf0 + wave + 4 * q;                    // (wave-uniform: the validity test is scalar)
+            xr[q] = __builtin_amdgcn_raw_buffer_load_b128(r_spec, f < F ? (((unsigned)b * F + (unsigned)f) * M + 4u * lane) * 4u : BS_OOB, 0, 0);
+        }
+    };
+    auto dec1 = [&](float v) -> float {
+        if (MODE == CODEC_RAW) return v;
+        const float x = fmaf(v, c1, c0);
+        if (MODE == CODEC_ARCSINH) return sinh_fast(x) * rgain;
+        return x;
+    };
+    float4 dz;
+    b3_u2 dh, dm_, dl;
+    auto decode_piece = [&](int pc, int g, int buf) {            // group g (0..7) of the tile being prepared
+        const float4 x = __builtin_bit_cast(float4, xr[g]);
+        const bool ok = nf0 + wave + 4 * g < F;                   // frames outside the clip contribute nothing (decode(0) != 0)
+        if (pc == 0) dz.x = ok ? dec1(x.x) : 0.0f;
+        else if (pc == 1) dz.y = ok ? dec1(x.y) : 0.0f;
+        else if (pc == 2) dz.z = ok ? dec1(x.z) : 0.0f;
+        else if (pc == 3) dz.w = ok ? dec1(x.w) : 0.0f;
+        else if (pc == 4) b3_split4(dz, dh, dm_, dl);
+        else {
+            unsigned char* dst = abuf + (size_t)buf * B3_ABUF + (lane >> 1) * B3_BLK + (wave + 4 * g) * 16 + (lane & 1) * 8;
+            *reinterpret_cast<b3_u2*>(dst) = dh;
+            *reinterpret_cast<b3_u2*>(dst + B3_PIECE) = dm_;
+            *reinterpret_cast<b3_u2*>(dst + 2 * B3_PIECE) = dl;
+        }
+    };
+    // unfold of the previous tile, group gi: hop block j = wave + 4 gi, samples n = 4 lane ..+3
+    const float scale = 4.0f / (2 * M);
+    const int n = 4 * lane;
+    const bool lo = n < Q;
+    unsigned pbase = 0;         // element index of (clip, sample (f0 - 1) M + n) of the previous tile in the output
+    int pf0 = 0, phalo = 0;
+    bool pvalid = false;
+    float4 uc, up;
+    auto unfold_piece = [&](int pc, int gi) {
+        const int j = wave + 4 * gi;
+        const float* vc = vbuf + j * BS_LDA;                                       // frame h
+        const float* vp = (j == 0) ? halo + phalo * M : vbuf + (j - 1) * BS_LDA;   // frame h - 1
+        if (pc == 0) {
+            // y_h[n] = v_h[Q + n] | -v_h[3Q - 1 - n];   y_{h-1}[n + M] = -v_{h-1}[Q - 1 - n] | -v_{h-1}[n - Q]
+            uc = bs_ld4(vc + (lo ? Q + n : 3 * Q - 4 - n));
+            up = bs_ld4(vp + (lo ? Q - 4 - n : n - Q));
+        } else if (pc == 1) {
+            const float4 c = uc, q = up;
+            uc = lo ? c : make_float4(-c.w, -c.z, -c.y, -c.x);
+            up = lo ? make_float4(-q.w, -q.z, -q.y, -q.x) : make_float4(-q.x, -q.y, -q.z, -q.w);
+        } else if (pc == 2) {
+            const float4 uw0 = bs_ld4(wl + n), uw1 = bs_ld4(wl + n + M);      // (the window from LDS: the register file has no room for it)
+            uc = make_float4(scale * (uw0.x * uc.x + uw1.x * up.x), scale * (uw0.y * uc.y + uw1.y * up.y),
+                             scale * (uw0.z * uc.z + uw1.z * up.z), scale * (uw0.w * uc.w + uw1.w * up.w));
+        } else {
+            const int hh = pf0 + j, t0 = (hh - 1) * M + n;       // out_len % 4 == 0: a float4 is inside or outside the crop as a whole
+            const bool ok = pvalid && hh >= 1 && hh <= F - 1 && t0 + 3 < out_len;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bs_v4u, uc), r_out, ok ? (pbase + (unsigned)(j * M)) * 4u : BS_OOB, 0, 0);
+        }
+    };
+
+    // prologue: decode the first tile, then fetch the table
+    tile_consts(0);
+    load_tile(0);
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+#pragma unroll
+        for (int pc = 0; pc < 6; ++pc) { decode_piece(pc, g, 0); __builtin_amdgcn_sched_barrier(0); }
+    b3_u4 bt[3][2][16];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int bk = 0; bk < 2; ++bk)
+#pragma unroll
+            for (int kb = 0; kb < 16; ++kb) bt[p][bk][kb] = img[(((p * 4 + wave) * 2 + bk) * 16 + kb) * 64 + lane];
+    if (tid < M) { halo[tid] = 0.0f; halo[M + tid] = 0.0f; }
+    if (tid < 2 * M / 4) reinterpret_cast<float4*>(wl)[tid] = bs_ld4(window + 4 * tid);
+    __syncthreads();
+
+    int buf = 0;
+    for (int i = 0; i < n_seq; ++i, buf ^= 1) {
+        tile_consts(i + 1);
+        f32x16 acc0 = f32x16{0}, acc1 = f32x16{0};
+        const unsigned char* ap = abuf + (size_t)buf * B3_ABUF + kh * B3_BLK + (lane & 31) * 16;
+        b3_u4 a1 = *reinterpret_cast<const b3_u4*>(ap), a2 = *reinterpret_cast<const b3_u4*>(ap + B3_PIECE),
+              a3 = *reinterpret_cast<const b3_u4*>(ap + 2 * B3_PIECE);
+        __builtin_amdgcn_sched_barrier(0);
+        // slot 1: the 8 loads of the next tile (1.2 us ahead of their first use); even slots 0..62: the 32 unfold pieces of the
+        // previous tile; even slots 96..190: the 48 decode pieces of the next tile
+#define B3_SLOT_K2(KB, s)                                                                                        \
+        do {                                                                                                       \
+            constexpr int slot = 12 * (KB) + (s);                                                                  \
+            if (slot < 64 && (slot & 1) == 0) unfold_piece((slot >> 1) & 3, slot >> 3);                            \
+            if (slot == 1) load_tile(i + 1);                                                                       \
+            if (slot >= 96 && (slot & 1) == 0) decode_piece(((slot - 96) >> 1) % 6, ((slot - 96) >> 1) / 6, buf ^ 1); \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+        } while (0)
+#define SLOT0(s) B3_SLOT_K2(0, s)
+#define SLOT1(s) B3_SLOT_K2(1, s)
+#define SLOT2(s) B3_SLOT_K2(2, s)
+#define SLOT3(s) B3_SLOT_K2(3, s)
+#define SLOT4(s) B3_SLOT_K2(4, s)
+#define SLOT5(s) B3_SLOT_K2(5, s)
+#define SLOT6(s) B3_SLOT_K2(6, s)
+#define SLOT7(s) B3_SLOT_K2(7, s)
+#define SLOT8(s) B3_SLOT_K2(8, s)
+#define SLOT9(s) B3_SLOT_K2(9, s)
+#define SLOT10(s) B3_SLOT_K2(10, s)
+#define SLOT11(s) B3_SLOT_K2(11, s)
+#define SLOT12(s) B3_SLOT_K2(12, s)
+#define SLOT13(s) B3_SLOT_K2(13, s)
+#define SLOT14(s) B3_SLOT_K2(14, s)
+#define SLOT15(s) B3_SLOT_K2(15, s)
+        B3_KBLOCK(0, SLOT0) B3_KBLOCK(1, SLOT1) B3_KBLOCK(2, SLOT2) B3_KBLOCK(3, SLOT3) B3_KBLOCK(4, SLOT4) B3_KBLOCK(5, SLOT5)
+        B3_KBLOCK(6, SLOT6) B3_KBLOCK(7, SLOT7) B3_KBLOCK(8, SLOT8) B3_KBLOCK(9, SLOT9) B3_KBLOCK(10, SLOT10) B3_KBLOCK(11, SLOT11)
+        B3_KBLOCK(12, SLOT12) B3_KBLOCK(13, SLOT13) B3_KBLOCK(14, SLOT14) B3_KBLOCK(15, SLOT15)
+#undef SLOT0
+#undef SLOT1
+#undef SLOT2
+#undef SLOT3
+#undef SLOT4
+#undef SLOT5
+#undef SLOT6
+#undef SLOT7
+#undef SLOT8
+#undef SLOT9
+#undef SLOT10
+#undef SLOT11
+#undef SLOT12
+#undef SLOT13
+#undef SLOT14
+#undef SLOT15
+#undef B3_SLOT_K2
+        __syncthreads();                           // every wave is done with the previous v tile (and with abuf[buf])
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mfma32_row(r, lane);
+            vbuf[row * BS_LDA + col] = acc0[r];
+            vbuf[row * BS_LDA + col + 32] = acc1[r];
+        }
+        if (kh == 1) { halo[(i & 1) * M + col] = acc0[15]; halo[(i & 1) * M + col + 32] = acc1[15]; }      // row 31 = reg 15 of the upper half
+        {
+            const int pb = clip_of(i);
+            pf0 = f0_of(i);
+            pbase = (unsigned)pb * (unsigned)out_len + (unsigned)((pf0 - 1) * M + n);      // (wraps for pf0 == 0: that block is masked)
+            phalo = (i + 1) & 1;                   // the tile before this one wrote slot (i - 1) & 1
+            pvalid = true;
+        }
+        __syncthreads();
+    }
+    // drain: the last tile's unfold
+#pragma unroll
+    for (int gi = 0; gi < 8; ++gi)
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) unfold_piece(pc, gi);
+}
+
+constexpr size_t B3_K2_LDS = (size_t)2 * B3_ABUF + (size_t)(B3_ROWS * BS_LDA + 4 * M) * sizeof(float);
 
 }  // namespace

@@ -79,7 +79,7 @@ __device__ __forceinline__ float4 bs_rev4(const float4 v) { return make_float4(v
 // ------------------------------------------------------------------------------------------------------------------
 // K1
 // ------------------------------------------------------------------------------------------------------------------
-// Register image of the table (mg_dct4_image, stored right behind the [M][M] table): float4 img[slab = bin / 32][jj][lane] =
+// Register image of the table (mg_dct4_image; the kernels' `dct4` parameter IS this image): float4 img[slab = bin / 32][jj][lane] =
 // D4[32 slab + (lane & 31)][8 jj + 4 (lane >> 5) + (0..3)] -- a wave's load of step jj is one coalesced 1 KiB read (the
 // same values straight from the [M][M] table are 32 lines x 32 bytes per instruction).
 __global__ void dct4_image_kernel(const float* __restrict__ d4, float* __restrict__ img) {
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(NW * 64) void mdct4_bs_kernel(const float* __restri
     const float k0 = (float)((double)cp.nr0 - (double)cp.mn * (((double)cp.nr1 - (double)cp.nr0) / ((double)cp.mx - (double)cp.mn)));
     const __amdgpu_buffer_rsrc_t r_audio = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(audio), 0, (unsigned)B * (unsigned)T * 4u, 0x00020000);
     // DBG bit 0: an empty range drops every store (the arithmetic stays alive)
-    const __amdgpu_buffer_rsrc_t r_spec = __builtin_amdgcn_make_buffer_rsrc(spec, 0, (DBG & 1) ? 0u : (unsigned)rows * M * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_spec = __builtin_amdgcn_make_buffer_rsrc(spec, 0, ((DBG & 1) || !spec) ? 0u : (unsigned)rows * M * 4u, 0x00020000);      // (spec == NULL with the pair: an empty range drops the stores)
     const __amdgpu_buffer_rsrc_t r_in2 = __builtin_amdgcn_make_buffer_rsrc(in2, 0, (PAIR && !(DBG & 1)) ? (unsigned)rows * M * 8u : 0u, 0x00020000);
 
     // group gi of a thread: row r = (tid + gi * NT) / 64 of the tile, u[n .. n + 3] with n = 4 * lane.  With z = fl32(x * w):
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(NW * 64) void mdct4_bs_kernel(const float* __restri
     if (tid < 2 * M / 4) wv = bs_ld4(window + 4 * tid);
     float4 bt[32];          // the wave's slab of the table: bins [col] x k = 8 jj + 4 kh + (0..3)
     {
-        const float4* img = reinterpret_cast<const float4*>(dct4 + M * M) + (size_t)slab * 32 * 64 + lane;
+        const float4* img = reinterpret_cast<const float4*>(dct4) + (size_t)slab * 32 * 64 + lane;
 #pragma unroll
         for (int jj = 0; jj < 32; ++jj) bt[jj] = img[jj * 64];
     }
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(512) void imdct4_bs_kernel(const float* __restrict_
         }
     float4 bt[32];
     {
-        const float4* img = reinterpret_cast<const float4*>(dct4 + M * M) + (size_t)wave * 32 * 64 + lane;
+        const float4* img = reinterpret_cast<const float4*>(dct4) + (size_t)wave * 32 * 64 + lane;
 #pragma unroll
         for (int jj = 0; jj < 32; ++jj) bt[jj] = img[jj * 64];
     }

@@ -38,21 +38,28 @@ _dct4_cache = {}
 
 def dct4_table(m: int, device) -> torch.Tensor:
     """D4[n, k] = cos(pi/M (n + 1/2)(k + 1/2)) evaluated in float64 on the host, rounded once to float32 -- followed, in the
-    same buffer, by the register image of it that the table-stationary kernels load (mg_dct4_image; include/mdctgan_hip.h:
-    the `dct4` argument of mg_mdct4_forward / mg_imdct4_forward is 2 * m * m floats).  Returns the flat [2 * m * m] tensor;
-    ``dct4_table(m, dev)[:m * m].view(m, m)`` is the table itself."""
+    same buffer, by the operand images of it that the table-stationary kernels load (mg_dct4_image: the float32 register image
+    and the three bf16 piece images, mg_dct4_image_floats(2 m) floats; include/mdctgan_hip.h: the `dct4_image` argument of
+    mg_mdct4_forward / mg_imdct4_forward).  Returns the flat tensor; ``dct4_table(m, dev)[:m * m].view(m, m)`` is the table
+    itself, ``dct4_image(t, m)`` the image part (None for geometries without fused kernels)."""
     key = (m, str(device))
     t = _dct4_cache.get(key)
     if t is None:
         n = torch.arange(m, dtype=torch.float64) + 0.5
         tab = torch.cos((math.pi / m) * torch.outer(n, n)).to(torch.float32)
-        t = torch.zeros(2 * m * m, dtype=torch.float32, device=device)
+        lib = _lib.load() if m == 256 else None          # the fused n_fft = 512 kernels are the only users of the images
+        extra = int(lib.mg_dct4_image_floats(2 * m)) if lib is not None else 0
+        t = torch.zeros(m * m + extra, dtype=torch.float32, device=device)
         t[:m * m] = tab.reshape(-1).to(device)
-        if m == 256:        # the fused n_fft = 512 kernels are the only users of the image
-            lib = _lib.load()
+        if extra:
             _lib.check(lib.mg_dct4_image(_lib.ptr(t), t.data_ptr() + 4 * m * m, _lib.stream()), "mg_dct4_image")
         _dct4_cache[key] = t
     return t
+
+
+def dct4_image(table: torch.Tensor, m: int):
+    """The image part of a dct4_table() buffer as a raw pointer argument (None: no image behind the table)."""
+    return (table.data_ptr() + 4 * m * m) if table.numel() > m * m else None
 
 
 def _make_window(window, win_length, device):
@@ -197,8 +204,12 @@ def mdct4_codec(audio, window, dct4, n_fft, *, codec=_lib.MG_CODEC_RAW, gain=1.0
     M = n_fft // 2
     F = lib.mg_mdct4_num_frames(T, n_fft)
     dev = audio.device
-    spec = torch.empty(B, F, M, dtype=torch.float32, device=dev)
     pair = torch.empty(B, F, M, 2, dtype=torch.float32, device=dev) if want_pair else None
+    image = dct4_image(dct4, M)
+    # with the pair the spectrogram is its channel 0 (a strided view): K1 then writes 393 216 B per clip instead of 526 848
+    pair_only = (want_pair and image is not None and not per_sample and not want_frames and codec == _lib.MG_CODEC_ARCSINH
+                 and T % 4 == 0 and audio.data_ptr() % 16 == 0 and window.data_ptr() % 16 == 0)
+    spec = pair[..., 0] if pair_only else torch.empty(B, F, M, dtype=torch.float32, device=dev)
     frames = torch.empty(B, F, n_fft, dtype=torch.float32, device=dev) if want_frames else None
     stats = torch.empty(2, dtype=torch.float64, device=dev) if want_stats else None
     mn = mx = scratch = None
@@ -206,9 +217,9 @@ def mdct4_codec(audio, window, dct4, n_fft, *, codec=_lib.MG_CODEC_RAW, gain=1.0
         mn = torch.empty(B, dtype=torch.float32, device=dev)
         mx = torch.empty(B, dtype=torch.float32, device=dev)
         scratch = torch.empty(2 * B, dtype=torch.int32, device=dev)
-    rc = lib.mg_mdct4_forward(_lib.ptr(audio), B, T, n_fft, _lib.ptr(window), _lib.ptr(dct4), codec, gain,
+    rc = lib.mg_mdct4_forward(_lib.ptr(audio), B, T, n_fft, _lib.ptr(window), _lib.ptr(dct4), image, codec, gain,
                               norm_range[0], norm_range[1], src_range[0], src_range[1], int(per_sample),
-                              _lib.ptr(spec), _lib.ptr(pair), _lib.ptr(frames), _lib.ptr(mn), _lib.ptr(mx),
+                              None if pair_only else _lib.ptr(spec), _lib.ptr(pair), _lib.ptr(frames), _lib.ptr(mn), _lib.ptr(mx),
                               _lib.ptr(stats), _lib.ptr(scratch), _lib.stream())
     _lib.check(rc, "mg_mdct4_forward")
     return {"spec": spec, "pair": pair, "frames": frames, "min": mn, "max": mx, "stats": stats}
@@ -229,7 +240,7 @@ def imdct4_codec(spec, window, dct4, n_fft, *, codec=_lib.MG_CODEC_RAW, gain=1.0
     if min_b is not None:
         min_b, max_b = _lib.f32c(min_b.reshape(-1)), _lib.f32c(max_b.reshape(-1))
         assert min_b.numel() == B and max_b.numel() == B
-    rc = lib.mg_imdct4_forward(_lib.ptr(spec), B, F, n_fft, _lib.ptr(window), _lib.ptr(dct4), codec, gain,
+    rc = lib.mg_imdct4_forward(_lib.ptr(spec), B, F, n_fft, _lib.ptr(window), _lib.ptr(dct4), dct4_image(dct4, M), codec, gain,
                                norm_range[0], norm_range[1], src_range[0], src_range[1], _lib.ptr(min_b),
                                _lib.ptr(max_b), _lib.ptr(audio), t_out, int(out_dtype == torch.float64),
                                _lib.ptr(frames), _lib.stream())

@@ -410,15 +410,31 @@ def adam_tick(state, beta1, beta2):
     _lib.check(lib.mg_adam_tick(_lib.ptr(state), beta1, beta2, _lib.stream()), "mg_adam_tick")
 
 
+def _stream_probe(name, nbytes):
+    """bench.py's KernelTimer also times the optimiser launches (single elementwise kernels on torch's current stream): events on
+    that stream around the launch.  nbytes = the algorithmic HBM bytes of the launch.  None in normal operation."""
+    begin = getattr(PROFILER, "stream_begin", None) if PROFILER is not None else None
+    return begin(name, nbytes) if begin is not None else None
+
+
+def _stream_probe_end(token):
+    if token is not None:
+        PROFILER.stream_end(token)
+
+
 def adam_step_dev(p, g, m, v, state, beta1, beta2, eps, grad_scale=1.0):
     lib = _lib.load()
+    tok = _stream_probe("adam_dev_kernel", 28 * p.numel())      # reads p, g, m, v; writes p, m, v
     _lib.check(lib.mg_adam_step_dev(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), p.numel(), _lib.ptr(state),
                                     beta1, beta2, eps, grad_scale, _lib.stream()), "mg_adam_step_dev")
+    _stream_probe_end(tok)
 
 
 def scaler_check(g, scaler, slot):
     lib = _lib.load()
+    tok = _stream_probe("scaler_check_kernel", 4 * g.numel())
     _lib.check(lib.mg_scaler_check(_lib.ptr(g), g.numel(), _lib.ptr(scaler), slot, _lib.stream()), "mg_scaler_check")
+    _stream_probe_end(tok)
 
 
 def scaler_update(scaler, growth_factor, backoff_factor, growth_interval):
@@ -435,17 +451,21 @@ def adam_tick_amp(state, beta1, beta2, scaler, slot):
 
 def adam_step_amp(p, g, m, v, state, beta1, beta2, eps, grad_scale, scaler, slot):
     lib = _lib.load()
+    tok = _stream_probe("adam_dev_kernel (GradScaler)", 28 * p.numel())
     _lib.check(lib.mg_adam_step_amp(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), p.numel(), _lib.ptr(state),
                                     beta1, beta2, eps, grad_scale, _lib.ptr(scaler), slot, _lib.stream()),
                "mg_adam_step_amp")
+    _stream_probe_end(tok)
 
 
 def adam_step_h(p, g, m, v, p16, state, beta1, beta2, eps, grad_scale, scaler=None, slot=0):
     """Adam update that also refreshes the float16 shadow p16 of the parameters (scaler: GradScaler state or None)."""
     lib = _lib.load()
+    tok = _stream_probe("adam_dev_kernel (float16 shadow)", 30 * p.numel())      # ... + the 2-byte shadow write
     _lib.check(lib.mg_adam_step_h(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), _lib.ptr(p16), p.numel(),
                                   _lib.ptr(state), beta1, beta2, eps, grad_scale, _lib.ptr(scaler), slot, _lib.stream()),
                "mg_adam_step_h")
+    _stream_probe_end(tok)
 
 
 def weights_are_casts(g: ConvGeom) -> bool:

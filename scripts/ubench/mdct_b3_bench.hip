@@ -1,0 +1,97 @@
+// The bf16 x 3 table-stationary K1 / K2 (mdctgan_amd/csrc/mdct_b3.h) beside the f32-pipe kernels (mdct_bs.h): time per launch
+// with parts switched off, and the largest difference between the two kernels' spectra / waveforms on the same input.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I include scripts/ubench/mdct_b3_bench.hip -o scripts/ubench/mdct_b3_bench
+//   scripts/ubench/mdct_b3_bench [clips=4096]
+#include "../../mdctgan_amd/csrc/mdct.hip"
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+template <typename F>
+static float time_ms(F launch, int iters) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) launch();
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i) launch();
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms / iters;
+}
+
+static double max_diff(const float* a, const float* b, size_t n, double* amax) {
+    std::vector<float> ha(n), hb(n);
+    hipMemcpy(ha.data(), a, n * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(hb.data(), b, n * 4, hipMemcpyDeviceToHost);
+    double d = 0, m = 0;
+    for (size_t i = 0; i < n; ++i) { d = fmax(d, fabs((double)ha[i] - hb[i])); m = fmax(m, fabs((double)hb[i])); }
+    *amax = m;
+    return d;
+}
+
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 4096, T = 32512, F = 128;
+    std::vector<float> hx((size_t)B * T), hw(512), hd(256 * 256);
+    unsigned s = 12345u;
+    for (auto& v : hx) { s = s * 1664525u + 1013904223u; v = 0.05f * ((float)(s >> 8) / 8388608.0f - 1.0f); }
+    for (int i = 0; i < 512; ++i) hw[i] = (float)sin(M_PI * (i + 0.5) / 512.0);
+    for (int n = 0; n < 256; ++n) for (int k = 0; k < 256; ++k) hd[n * 256 + k] = (float)cos(M_PI / 256.0 * (n + 0.5) * (k + 0.5));
+    float *x, *w, *d, *spec, *spec2, *in2, *y, *y2;
+    hipMalloc(&x, hx.size() * 4); hipMalloc(&w, 2048); hipMalloc(&d, (256 * 256 + mg_dct4_image_floats(512)) * 4);
+    hipMalloc(&spec, (size_t)B * F * 256 * 4); hipMalloc(&spec2, (size_t)B * F * 256 * 4); hipMalloc(&in2, (size_t)B * F * 512 * 4);
+    hipMalloc(&y, (size_t)B * T * 4); hipMalloc(&y2, (size_t)B * T * 4);
+    hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(w, hw.data(), 2048, hipMemcpyHostToDevice);
+    hipMemcpy(d, hd.data(), 256 * 256 * 4, hipMemcpyHostToDevice);
+    float* dimg = d + 256 * 256;
+    mg_dct4_image(d, dimg, nullptr);
+    const b3_u4* img3 = reinterpret_cast<const b3_u4*>(dimg + 256 * 256);
+    CodecParams cp{CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, nullptr, nullptr, 0};
+    CodecParams cpr{CODEC_RAW, 1000.f, -1.f, 1.f, -5.f, 5.f, nullptr, nullptr, 0};
+    const int n_tiles = B * F / 32, iters = B >= 1024 ? 10 : 200;
+    const double gflop = 2.0 * B * F * 256.0 * 256.0 * 1e-9;
+    auto report = [&](const char* name, float ms) {
+        printf("%-52s %9.2f us  %6.1f TFLOP/s f32-equivalent  %6.0f GB/s (261 120 B per clip)\n", name, ms * 1e3, gflop / ms, B * 261120.0 / ms * 1e-6);
+    };
+    const dim3 grid(n_tiles < 256 ? n_tiles : 256);
+#define K1B3(MODE_, SPEC_, PAIR_, DBG_, cp_, out_, name)                                                                  \
+    {                                                                                                                       \
+        auto k = mdct4_b3_kernel<MODE_, SPEC_, PAIR_, false, DBG_>;                                                         \
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3_K1_LDS);                    \
+        report(name, time_ms([&] { hipLaunchKernelGGL(k, grid, dim3(256), B3_K1_LDS, 0, x, B, T, F, w, img3, cp_, out_, in2, (double*)nullptr); }, iters)); \
+    }
+    printf("== K1 bf16 x 3, %d clips (%d row tiles)\n", B, n_tiles);
+    K1B3(CODEC_RAW, true, false, 0, cpr, spec2, "K1 b3 RAW");
+    {
+        auto k = mdct4_bs_kernel<8, CODEC_RAW, false, false, 0>;
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BS_K1_LDS);
+        report("K1 f32 pipe (mdct_bs) RAW", time_ms([&] { hipLaunchKernelGGL(k, dim3(grid.x, 1), dim3(512), BS_K1_LDS, 0, x, B, T, F, w, dimg, cpr, spec, (float*)nullptr, (double*)nullptr); }, iters));
+        double amax;
+        const double dd = max_diff(spec2, spec, (size_t)B * F * 256, &amax);
+        printf("   RAW spectra: max |b3 - f32 pipe| = %.3e, max |X| = %.3e -> %.3e relative to the maximum\n", dd, amax, dd / amax);
+    }
+    K1B3(CODEC_ARCSINH, true, false, 0, cp, spec2, "K1 b3 arcsinh, spectrogram only (product)");
+    K1B3(CODEC_ARCSINH, false, true, 0, cp, spec2, "K1 b3 arcsinh, pair only");
+    K1B3(CODEC_ARCSINH, true, true, 0, cp, spec2, "K1 b3 arcsinh, spectrogram + pair");
+    K1B3(CODEC_ARCSINH, true, false, 1, cp, spec2, "K1 b3 arcsinh, no global stores");
+    K1B3(CODEC_ARCSINH, true, false, 2, cp, spec2, "K1 b3 arcsinh, no codec math");
+    K1B3(CODEC_ARCSINH, true, false, 4, cp, spec2, "K1 b3 arcsinh, no DMA, no fold");
+    K1B3(CODEC_ARCSINH, true, false, 7, cp, spec2, "K1 b3 MFMA + A reads only");
+    printf("== through the C ABI\n");
+    report("mg_mdct4_forward arcsinh", time_ms([&] { mg_mdct4_forward(x, B, T, 512, w, d, dimg, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, 0, spec, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr); }, iters));
+    report("mg_imdct4_forward arcsinh", time_ms([&] { mg_imdct4_forward(spec, B, F, 512, w, d, dimg, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, nullptr, nullptr, y, T, 0, nullptr, nullptr); }, iters));
+    {
+        setenv("MG_MDCT_B3", "0", 1);
+        mg_imdct4_forward(spec, B, F, 512, w, d, dimg, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, nullptr, nullptr, y2, T, 0, nullptr, nullptr);
+        unsetenv("MG_MDCT_B3");
+        double amax;
+        const double dd = max_diff(y, y2, (size_t)B * T, &amax);
+        printf("   waveforms: max |default - f32 pipe| = %.3e, max |y| = %.3e; round trip vs input:", dd, amax);
+        const double rt = max_diff(y, x, (size_t)B * T, &amax);
+        printf(" %.3e (max |x| %.3e)\n", rt, amax);
+    }
+    return 0;
+}

@@ -30,7 +30,8 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 512; ++i) hw[i] = (float)sin(M_PI * (i + 0.5) / 512.0);
     for (int n = 0; n < 256; ++n) for (int k = 0; k < 256; ++k) hd[n * 256 + k] = (float)cos(M_PI / 256.0 * (n + 0.5) * (k + 0.5));
     float *x, *w, *d, *spec, *in2, *y;
-    hipMalloc(&x, hx.size() * 4); hipMalloc(&w, 2048); hipMalloc(&d, 2 * 256 * 256 * 4);
+    hipMalloc(&x, hx.size() * 4); hipMalloc(&w, 2048); hipMalloc(&d, (256 * 256 + mg_dct4_image_floats(512)) * 4);
+    float* dimg = d + 256 * 256;
     hipMalloc(&spec, (size_t)B * F * 256 * 4); hipMalloc(&in2, (size_t)B * F * 512 * 4); hipMalloc(&y, (size_t)B * T * 4);
     hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(w, hw.data(), 2048, hipMemcpyHostToDevice);
@@ -48,7 +49,7 @@ int main(int argc, char** argv) {
         auto k = mdct4_bs_kernel<NW_, MODE_, PAIR_, false, DBG_>;                                                                  \
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BS_K1_LDS);                    \
         const dim3 grid(n_tiles < 256 ? n_tiles : 256, 8 / NW_);                                                            \
-        report(name, time_ms([&] { hipLaunchKernelGGL(k, grid, dim3(NW_ * 64), BS_K1_LDS, 0, x, B, T, F, w, d, cp, spec, in2, (double*)nullptr); }, iters)); \
+        report(name, time_ms([&] { hipLaunchKernelGGL(k, grid, dim3(NW_ * 64), BS_K1_LDS, 0, x, B, T, F, w, dimg, cp, spec, in2, (double*)nullptr); }, iters)); \
     }
     printf("== K1, %d clips (%d row tiles)\n", B, n_tiles);
     K1(8, CODEC_ARCSINH, true, 0, "K1 nw8 (product)");
@@ -62,8 +63,8 @@ int main(int argc, char** argv) {
     K1(8, CODEC_ARCSINH, false, 0, "K1 nw8, no pair");
     K1(8, CODEC_RAW, false, 0, "K1 nw8, RAW codec, no pair");
     printf("== through the C ABI (mg_mdct4_forward / mg_imdct4_forward)\n");
-    report("mg_mdct4_forward arcsinh + pair", time_ms([&] { mg_mdct4_forward(x, B, T, 512, w, d, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, 0, spec, in2, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr); }, iters));
-    report("mg_imdct4_forward arcsinh", time_ms([&] { mg_imdct4_forward(spec, B, F, 512, w, d, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, nullptr, nullptr, y, T, 0, nullptr, nullptr); }, iters));
-    report("mg_imdct4_forward raw", time_ms([&] { mg_imdct4_forward(spec, B, F, 512, w, d, CODEC_RAW, 1000.f, -1.f, 1.f, -5.f, 5.f, nullptr, nullptr, y, T, 0, nullptr, nullptr); }, iters));
+    report("mg_mdct4_forward arcsinh + pair", time_ms([&] { mg_mdct4_forward(x, B, T, 512, w, d, dimg, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, 0, spec, in2, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr); }, iters));
+    report("mg_imdct4_forward arcsinh", time_ms([&] { mg_imdct4_forward(spec, B, F, 512, w, d, dimg, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, nullptr, nullptr, y, T, 0, nullptr, nullptr); }, iters));
+    report("mg_imdct4_forward raw", time_ms([&] { mg_imdct4_forward(spec, B, F, 512, w, d, dimg, CODEC_RAW, 1000.f, -1.f, 1.f, -5.f, 5.f, nullptr, nullptr, y, T, 0, nullptr, nullptr); }, iters));
     return 0;
 }
