@@ -68,6 +68,8 @@ __device__ __forceinline__ void b3_dma16(unsigned voff, b3_v4i rsrc, unsigned ld
                  : "memory");
 }
 __device__ __forceinline__ void b3_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void b3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // Table image: img[(((p * 4 + wave) * 2 + blk) * 16 + kb) * 64 + lane] = piece p of D4[bin][16 kb + 8 (lane >> 5) + (0..7)],
 // bin = 64 wave + 32 blk + (lane & 31)  (D4 is symmetric: row bin == column bin): the B operand of MFMA step kb, coalesced.
@@ -283,7 +285,14 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
         // k-block 10: the last 8 epilogue slots (120..127); then the raw audio of the next tile must have landed everywhere
 #define SLOT10(s) B3_SLOT_A(10, s)
         B3_KBLOCK(10, SLOT10)
-        b3_wait_vm0();
+        // The DMA pieces were issued in slots 1 .. 25; vmcnt retires in order on gfx9 (loads and stores alike), so "at most as many
+        // operations outstanding as were issued after the last piece" means every piece has landed -- WITHOUT draining the
+        // codec's stores of slots 27 .. 127 (values 6 .. 31: 26 per output tensor), which vmcnt(0) would wait for (measured:
+        // +250 us per 4096 clips).  The counter saturates at 63.
+        {
+            constexpr int after = 26 * ((SPEC ? 1 : 0) + (PAIR ? 1 : 0));
+            b3_wait_vm<(after < 63 ? after : 63)>();
+        }
         __syncthreads();
         // second half (k-blocks 11..15, 60 slots): the fold of the next tile, 8 groups x 6 pieces = 48 pieces
 #define B3_SLOT_B(KB, s)                                                                                         \

@@ -207,8 +207,10 @@ def mdct4_codec(audio, window, dct4, n_fft, *, codec=_lib.MG_CODEC_RAW, gain=1.0
     pair = torch.empty(B, F, M, 2, dtype=torch.float32, device=dev) if want_pair else None
     image = dct4_image(dct4, M)
     # with the pair the spectrogram is its channel 0 (a strided view): K1 then writes 393 216 B per clip instead of 526 848
+    import os
+    legacy = os.environ.get("MG_MDCT_BS") == "0" or "MG_MDCT_GEMM" in os.environ or "MG_MDCT_FT" in os.environ      # (ablation switches)
     pair_only = (want_pair and image is not None and not per_sample and not want_frames and codec == _lib.MG_CODEC_ARCSINH
-                 and T % 4 == 0 and audio.data_ptr() % 16 == 0 and window.data_ptr() % 16 == 0)
+                 and T % 4 == 0 and audio.data_ptr() % 16 == 0 and window.data_ptr() % 16 == 0 and not legacy)
     spec = pair[..., 0] if pair_only else torch.empty(B, F, M, dtype=torch.float32, device=dev)
     frames = torch.empty(B, F, n_fft, dtype=torch.float32, device=dev) if want_frames else None
     stats = torch.empty(2, dtype=torch.float64, device=dev) if want_stats else None

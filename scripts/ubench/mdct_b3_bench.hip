@@ -80,6 +80,28 @@ int main(int argc, char** argv) {
     K1B3(CODEC_ARCSINH, true, false, 2, cp, spec2, "K1 b3 arcsinh, no codec math");
     K1B3(CODEC_ARCSINH, true, false, 4, cp, spec2, "K1 b3 arcsinh, no DMA, no fold");
     K1B3(CODEC_ARCSINH, true, false, 7, cp, spec2, "K1 b3 MFMA + A reads only");
+    printf("== K2 bf16 x 3\n");
+    {
+        hipMemsetAsync(y, 0, (size_t)B * T * 4, 0); hipMemsetAsync(y2, 0, (size_t)B * T * 4, 0);
+        mg_mdct4_forward(x, B, T, 512, w, d, dimg, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, 0, spec, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        auto k3 = imdct4_b3_kernel<CODEC_ARCSINH, 0>;
+        hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3_K2_LDS);
+        const dim3 g2(B < 256 ? B : 256);
+        report("K2 b3 arcsinh (product)", time_ms([&] { hipLaunchKernelGGL(k3, g2, dim3(256), B3_K2_LDS, 0, spec, B, F, w, img3, cp, y, T); }, iters));
+        auto k3n = imdct4_b3_kernel<CODEC_ARCSINH, 1>;
+        hipFuncSetAttribute((const void*)k3n, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3_K2_LDS);
+        report("K2 b3 arcsinh, no global stores", time_ms([&] { hipLaunchKernelGGL(k3n, g2, dim3(256), B3_K2_LDS, 0, spec, B, F, w, img3, cp, y2, T); }, iters));
+        auto k3r = imdct4_b3_kernel<CODEC_RAW, 0>;
+        hipFuncSetAttribute((const void*)k3r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3_K2_LDS);
+        report("K2 b3 RAW", time_ms([&] { hipLaunchKernelGGL(k3r, g2, dim3(256), B3_K2_LDS, 0, spec, B, F, w, img3, cpr, y2, T); }, iters));
+        auto kb = imdct4_bs_kernel<CODEC_ARCSINH>;
+        hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BS_K2_LDS);
+        const int nt2 = B * ((F + 31) / 32);
+        report("K2 f32 pipe (mdct_bs) arcsinh", time_ms([&] { hipLaunchKernelGGL(kb, dim3(nt2 < 256 ? nt2 : 256), dim3(512), BS_K2_LDS, 0, spec, B, F, w, dimg, cp, y2, T); }, iters));
+        double amax;
+        const double dd = max_diff(y, y2, (size_t)B * T, &amax);
+        printf("   waveforms: max |b3 - f32 pipe| = %.3e, max |y| = %.3e -> %.3e relative to the maximum\n", dd, amax, dd / amax);
+    }
     printf("== through the C ABI\n");
     report("mg_mdct4_forward arcsinh", time_ms([&] { mg_mdct4_forward(x, B, T, 512, w, d, dimg, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, 0, spec, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr); }, iters));
     report("mg_imdct4_forward arcsinh", time_ms([&] { mg_imdct4_forward(spec, B, F, 512, w, d, dimg, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, nullptr, nullptr, y, T, 0, nullptr, nullptr); }, iters));
