@@ -298,32 +298,59 @@ __device__ __forceinline__ unsigned dg_piece_voffset(int piece, int lane, int r0
     }
 }
 
+// Row-contiguous operands ([K][rows]) with TWO 32-row blocks per wave are read interleaved (round 4): lane r of the MFMA stands for
+// tile rows 2 r and 2 r + 1 (block mi = the row's parity) instead of r and 32 + r, so the two blocks' values of one k are
+// 8 adjacent bytes -- one ds_read_b64 per k instead of two ds_read_b32 (the weight-gradient GEMM, both operands row-contiguous,
+// issued 16 LDS reads per 8 MFMAs, the forward GEMM 4).  Which lane computes which element of C is the kernel's own business:
+// dg_tile_row / dg_tile_col give the epilogue the same mapping.
+template <int LAY, int BLOCKS>
+struct DgInterleave { static constexpr bool on = (LAY == DG_RC && BLOCKS == 2); };
+template <bool INT, int BLOCKS>
+__device__ __forceinline__ int dg_tile_index(int blk, int r) { return INT ? BLOCKS * r + blk : 32 * blk + r; }
+
 template <int MB, int NB, int ALAY, int BLAY, int BM, int BN>
 __device__ __forceinline__ void dg_chunk_g(const float* As, const float* Bs, f32x16 (&acc)[MB][NB], int wm0, int wn0,
                                            int lane) {
     const int r = lane & 31, kh = lane >> 5;
+    constexpr bool AINT = DgInterleave<ALAY, MB>::on, BINT = DgInterleave<BLAY, NB>::on;
     float a[2][MB][4], b[2][NB][4];
     auto fetch = [&](int s, int buf) {
+        if (AINT) {
 #pragma unroll
-        for (int mi = 0; mi < MB; ++mi) {
-            const int row = wm0 + 32 * mi + r;
-            if (ALAY == DG_KC) {
-                const float4 t = dg_ld4(As + row * DG_BK + 4 * ((2 * s + kh) ^ ((row >> 1) & 7)));
-                a[buf][mi][0] = t.x; a[buf][mi][1] = t.y; a[buf][mi][2] = t.z; a[buf][mi][3] = t.w;
-            } else {
+            for (int j = 0; j < 4; ++j) {
+                const float2 t = *reinterpret_cast<const float2*>(As + (8 * s + 4 * kh + j) * BM + wm0 + 2 * r);
+                a[buf][0][j] = t.x; a[buf][MB - 1][j] = t.y;
+            }
+        } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) a[buf][mi][j] = As[(8 * s + 4 * kh + j) * BM + row];
+            for (int mi = 0; mi < MB; ++mi) {
+                const int row = wm0 + 32 * mi + r;
+                if (ALAY == DG_KC) {
+                    const float4 t = dg_ld4(As + row * DG_BK + 4 * ((2 * s + kh) ^ ((row >> 1) & 7)));
+                    a[buf][mi][0] = t.x; a[buf][mi][1] = t.y; a[buf][mi][2] = t.z; a[buf][mi][3] = t.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[buf][mi][j] = As[(8 * s + 4 * kh + j) * BM + row];
+                }
             }
         }
+        if (BINT) {
 #pragma unroll
-        for (int ni = 0; ni < NB; ++ni) {
-            const int row = wn0 + 32 * ni + r;
-            if (BLAY == DG_KC) {
-                const float4 t = dg_ld4(Bs + row * DG_BK + 4 * ((2 * s + kh) ^ ((row >> 1) & 7)));
-                b[buf][ni][0] = t.x; b[buf][ni][1] = t.y; b[buf][ni][2] = t.z; b[buf][ni][3] = t.w;
-            } else {
+            for (int j = 0; j < 4; ++j) {
+                const float2 t = *reinterpret_cast<const float2*>(Bs + (8 * s + 4 * kh + j) * BN + wn0 + 2 * r);
+                b[buf][0][j] = t.x; b[buf][NB - 1][j] = t.y;
+            }
+        } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) b[buf][ni][j] = Bs[(8 * s + 4 * kh + j) * BN + row];
+            for (int ni = 0; ni < NB; ++ni) {
+                const int row = wn0 + 32 * ni + r;
+                if (BLAY == DG_KC) {
+                    const float4 t = dg_ld4(Bs + row * DG_BK + 4 * ((2 * s + kh) ^ ((row >> 1) & 7)));
+                    b[buf][ni][0] = t.x; b[buf][ni][1] = t.y; b[buf][ni][2] = t.z; b[buf][ni][3] = t.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b[buf][ni][j] = Bs[(8 * s + 4 * kh + j) * BN + row];
+                }
             }
         }
     };
@@ -544,24 +571,32 @@ __global__ __launch_bounds__(64 * WGM * WGN) void dgemm32g_kernel(DgArgs g) {
     float* o = g.part ? g.part + ((size_t)sp * nz + z) * ((size_t)g.M * g.N) : g.C + (size_t)z * g.sc;
     const size_t ldc = (g.part || !g.ldc) ? (size_t)g.N : (size_t)g.ldc;
     const bool rnd = g.round_f16 != 0 && g.part == nullptr;        // wave-uniform
+    // (the float32 chunk reads row-contiguous operands interleaved: see dg_chunk_g; the bf16 x 3 chunk keeps the block mapping)
+    constexpr bool AINT = !EMU && DgInterleave<ALAY, MB>::on, BINT = !EMU && DgInterleave<BLAY, NB>::on;
     if (m0 + BM <= g.M && n0 + BN <= g.N) {        // interior tile (wave-uniform): no per-element predicates
-        float* ow = o + (size_t)(m0 + wm0 + 4 * (lane >> 5)) * ldc + n0 + wn0 + (lane & 31);
+        float* ow = o + (size_t)(m0 + wm0) * ldc + n0 + wn0;
 #pragma unroll
         for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < NB; ++ni)
+            for (int r = 0; r < 16; ++r) {
+                float* orow = ow + (size_t)dg_tile_index<AINT, MB>(mi, mfma32_row(r, lane)) * ldc;
+                if (BINT) {        // the two column blocks of a lane are adjacent columns: one 8-byte store
+                    const float v0 = rnd ? round_h(acc[mi][0][r]) : acc[mi][0][r], v1 = rnd ? round_h(acc[mi][NB - 1][r]) : acc[mi][NB - 1][r];
+                    *reinterpret_cast<float2*>(orow + 2 * (lane & 31)) = make_float2(v0, v1);
+                } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    ow[(size_t)(32 * mi + (r & 3) + 8 * (r >> 2)) * ldc + 32 * ni] = rnd ? round_h(acc[mi][ni][r]) : acc[mi][ni][r];
+                    for (int ni = 0; ni < NB; ++ni) orow[32 * ni + (lane & 31)] = rnd ? round_h(acc[mi][ni][r]) : acc[mi][ni][r];
+                }
+            }
     } else {
 #pragma unroll
         for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NB; ++ni) {
-                const int col = n0 + wn0 + 32 * ni + (lane & 31);
+                const int col = n0 + wn0 + dg_tile_index<BINT, NB>(ni, lane & 31);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm0 + 32 * mi + mfma32_row(r, lane);
+                    const int row = m0 + wm0 + dg_tile_index<AINT, MB>(mi, mfma32_row(r, lane));
                     if (row < g.M && col < g.N) o[(size_t)row * ldc + col] = rnd ? round_h(acc[mi][ni][r]) : acc[mi][ni][r];
                 }
             }

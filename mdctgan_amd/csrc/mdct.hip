@@ -494,7 +494,7 @@ int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* w
         const long long n_tiles = (n_rows + B3_ROWS - 1) / B3_ROWS;
         bool b3 = n_tiles >= 512;
         if (const char* e = getenv("MG_MDCT_B3")) b3 = atoi(e) != 0;
-        if (b3 && !legacy_forced && T % 4 == 0 && !per_sample && !frames_out && (codec == CODEC_RAW || codec == CODEC_ARCSINH) &&
+        if (b3 && F >= B3_ROWS && !legacy_forced && T % 4 == 0 && !per_sample && !frames_out && (codec == CODEC_RAW || codec == CODEC_ARCSINH) &&
             !(codec == CODEC_RAW && in2) && n_rows * M * 8 < (1ll << 32) - (1ll << 18) && (long long)B * T * 4 < (1ll << 32) &&
             al16(audio) && al16(window) && al16(dct4_image) && (!spec || al16(spec)) && (!in2 || al16(in2)) && (spec || in2)) {
             const b3_u4* img = reinterpret_cast<const b3_u4*>(dct4_image + M * M);

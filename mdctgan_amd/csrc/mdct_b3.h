@@ -38,7 +38,7 @@ constexpr int B3_NT = 256;                      // 4 waves
 constexpr int B3_BLK = 33 * 16;                 // bytes of one (k-block, k-half) group of the A image: 32 rows x 16 B + 16 B pad
 constexpr int B3_PIECE = 32 * B3_BLK;           // one bf16 piece of a tile: 16 k-blocks x 2 halves
 constexpr int B3_ABUF = 3 * B3_PIECE;           // 50 688 B
-constexpr int B3_RAW = 33 * 1024;               // 33 hop blocks of raw audio
+constexpr int B3_RAW = 37 * 1024;               // 33 hop blocks of raw audio (+ 3 slots that only keep the DMA count uniform) + 1 KiB of zeros
 constexpr int B3_IMG_U4 = 3 * 4 * 2 * 16 * 64;  // table image: [piece][wave][bin block][k-block][lane] x 16 B = 384 KB
 
 __device__ __forceinline__ unsigned b3_pk(float a, float b) {          // (bf16(a), bf16(b)) round-to-nearest-even, a in the low half
@@ -58,13 +58,13 @@ __device__ __forceinline__ void b3_split4(const float4 u, b3_u2& h, b3_u2& m, b3
 __device__ __forceinline__ f32x16 b3_mfma(b3_u4 a, b3_u4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b3_bf8, a), __builtin_bit_cast(b3_bf8, b), c, 0, 0, 0);
 }
-// One LDS-DMA piece: 64 lanes x 16 bytes from the buffer at byte offset voff (per lane; out of range: zeros) to LDS byte address
+// One LDS-DMA piece: 64 lanes x 16 bytes from the buffer at byte offset voff (per lane) + soff (scalar) (out of range: zeros) to LDS byte address
 // lds_dst + 16 * lane.  Inline asm like dense_gemm.h::dg_dma16 (the builtin makes hipcc wait vmcnt(0) before the next ds_read).
-__device__ __forceinline__ void b3_dma16(unsigned voff, b3_v4i rsrc, unsigned lds_dst) {
+__device__ __forceinline__ void b3_dma16(unsigned voff, b3_v4i rsrc, unsigned lds_dst, unsigned soff) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(voff), "s"(rsrc), "s"(lds_dst)
+                 : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff)
                  : "memory");
 }
 __device__ __forceinline__ void b3_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -102,7 +102,8 @@ __global__ void dct4_b3_image_kernel(const float* __restrict__ d4, b3_u4* __rest
     if (KB + 1 < 16) a1 = *reinterpret_cast<const b3_u4*>(ap + (KB + 1) * 2 * B3_BLK);
 
 // ------------------------------------------------------------------------------------------------------------------
-// K1.  grid = workers (<= 256), block = 256.  SPEC: write the 1-channel spectrogram; PAIR: write the 2-channel network input
+// K1.  grid = workers (<= 256), block = 256; F >= 32.  DBG (ubench only): bit 0 no global stores, 1 no codec arithmetic, 2 neither
+// DMA nor fold, 3 no DMA, 4 no fold.  SPEC: write the 1-channel spectrogram; PAIR: write the 2-channel network input
 // (v, 2|v| + nr0) -- with PAIR alone the spectrogram is channel 0 of the pair (393 216 B per clip instead of 526 848).
 // ------------------------------------------------------------------------------------------------------------------
 template <int MODE, bool SPEC, bool PAIR, bool STATS, int DBG = 0>
@@ -131,14 +132,31 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
     const __amdgpu_buffer_rsrc_t r_in2 = __builtin_amdgcn_make_buffer_rsrc(in2, 0, (PAIR && !(DBG & 1)) ? (unsigned)rows * M * 8u : 0u, 0x00020000);
     const unsigned raw_lds = (unsigned)(uintptr_t)raw;             // LDS byte address (the low 32 bits of a __shared__ pointer)
 
-    // hop block `slot` (0: the first half of row 0; r + 1: the second half of row r) of `tile`, fetched by wave slot % 4
-    auto dma_slot = [&](int tile, int slot) {
+    // Row 0 of the tile in flight as (clip, frame): advanced by 32 G rows per iteration without a division (F >= 32: a tile
+    // touches at most two clips, row r is (nb + 1, nf + r - F) when nf + r >= F).  `next` describes the tile being prepared.
+    const int adv = B3_ROWS * G, adv_b = adv / F, adv_f = adv - adv_b * F;
+    int nb = 0, nf = 0;                                            // set in the prologue
+    bool nvalid = false;
+    auto advance = [&]() {
+        nb += adv_b; nf += adv_f;
+        if (nf >= F) { nf -= F; ++nb; }
+    };
+    // hop block `slot` (0: the first half of row 0; r + 1: the second half of row r; 33..35: nothing) of the tile being
+    // prepared, fetched by wave slot % 4.  No branch: an unused slot / a row outside the batch / samples behind the clip's end
+    // are out-of-range offsets, which the DMA fills with zeros.
+    auto dma_slot = [&](int slot) {
+        // everything but the last compare is scalar arithmetic, and the selects are masks -- written with `?:` on these
+        // wave-uniform conditions hipcc branches around each piece (18 branches in the MFMA stream)
         const int r = slot == 0 ? 0 : slot - 1;
-        const int m = tile * B3_ROWS + r;
-        const int b = m / F, f = m - b * F - (slot == 0 ? 1 : 0);
-        const int t = f * M + 4 * lane;                          // T % 4 == 0: a float4 is inside or outside the clip as a whole
-        const bool ok = m < rows && f >= 0 && t + 3 < T;
-        b3_dma16(ok ? ((unsigned)b * (unsigned)T + (unsigned)t) * 4u : BS_OOB, r_audio, raw_lds + 1024u * slot);
+        const int fr = nf + r;
+        const int wrap = (int)(fr >= F);
+        const int b = nb + wrap;
+        const int f = fr - (wrap ? F : 0) - (slot == 0 ? 1 : 0);
+        const unsigned row_ok = (unsigned)nvalid & (unsigned)(slot < 33) & (unsigned)(b < B) & (unsigned)(f >= 0);
+        const int lim = row_ok ? (T - f * M) >> 2 : 0;           // lanes [0, lim) hold samples of the clip (T % 4 == 0)
+        const unsigned soff = row_ok ? ((unsigned)b * (unsigned)T + (unsigned)(f * M)) * 4u : 0u;
+        const unsigned dead = 0u - (unsigned)(lane >= lim);      // all ones for a lane behind the clip's end / an unused piece
+        b3_dma16((16u * lane) | dead, r_audio, raw_lds + 1024u * slot, soff);
     };
     // Fold group gi: row r = wave + 4 gi, u[n .. n + 3], n = 4 lane (mdct_bs.h).  Lanes n < Q read the second half of the frame
     // (hop block r + 1) only, lanes n >= Q the first half (hop block r: zero padding when the row is frame 0 of its clip):
@@ -150,18 +168,18 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
     const int s1 = lo ? o1 - M : o1, s2 = lo ? o2 - M : o2;        // the same runs as offsets inside the lane's hop block
     float4 fz1, fz2, fw1, fw2;
     b3_u2 fh, fm, fl;
-    auto fold_piece = [&](int pc, int gi, int tile, int buf) {
+    auto fold_piece = [&](int pc, int gi, int buf) {
         const int r = wave + 4 * gi;
         if (pc == 0) {
-            const float* blk = raw + (r + (lo ? 1 : 0)) * M;
+            // frame 0 of a clip: its first half is the zero padding -> the upper lanes read the block of zeros instead (a
+            // scalar select of the block index: no branch, no per-lane select)
+            const int fr = nf + r;
+            const bool first = fr == 0 || fr == F;
+            const int slot = lo ? r + 1 : (first ? 36 : r);
+            const float* blk = raw + slot * M;
             fz1 = bs_ld4(blk + s1); fz2 = bs_ld4(blk + s2);
         } else if (pc == 1) {
             fw1 = bs_ld4(ws + o1); fw2 = bs_ld4(wS);
-            if (!lo) {                                             // frame 0 of a clip: its first half is the zero padding
-                const int m = tile * B3_ROWS + r;
-                const bool first = (m % F) == 0;
-                if (first) { fz1 = make_float4(0.f, 0.f, 0.f, 0.f); fz2 = fz1; }
-            }
         } else if (pc == 2) {       // z = fl32(x * w) (mdct.py:410)
             fz1 = make_float4(__fmul_rn(fz1.x, fw1.x), __fmul_rn(fz1.y, fw1.y), __fmul_rn(fz1.z, fw1.z), __fmul_rn(fz1.w, fw1.w));
             fz2 = make_float4(__fmul_rn(fz2.x, fw2.x), __fmul_rn(fz2.y, fw2.y), __fmul_rn(fz2.z, fw2.z), __fmul_rn(fz2.w, fw2.w));
@@ -224,8 +242,13 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
 
     // prologue: raw audio of the first tile by DMA, the window, the table (384 registers), then the first fold
     int tile = blockIdx.x;
+    {
+        const int m0 = tile * B3_ROWS;
+        nb = m0 / F; nf = m0 - nb * F; nvalid = tile < n_tiles;
+    }
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { const int s = wave + 4 * i; if (s < 33) dma_slot(tile < n_tiles ? tile : n_tiles, s); }
+    for (int i = 0; i < 9; ++i) dma_slot(wave + 4 * i);
+    if (tid < 64) reinterpret_cast<float4*>(raw + 36 * M)[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < 2 * M / 4) {
         const float4 wv = bs_ld4(window + 4 * tid);
         reinterpret_cast<float4*>(ws)[tid] = wv;
@@ -243,14 +266,15 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
 #pragma unroll
     for (int gi = 0; gi < 8; ++gi)
 #pragma unroll
-        for (int pc = 0; pc < 6; ++pc) fold_piece(pc, gi, tile, 0);
+        for (int pc = 0; pc < 6; ++pc) fold_piece(pc, gi, 0);
     __syncthreads();
 
     f32x16 accp0 = f32x16{0}, accp1 = f32x16{0};
     int buf = 0;
     epi_begin(n_tiles);
     for (; tile < n_tiles; tile += G, buf ^= 1) {
-        const int next = (tile + G < n_tiles) ? tile + G : n_tiles;          // (tile n_tiles: every row out of range -> zeros)
+        advance();                                                           // (nb, nf): row 0 of tile + G, the one being prepared
+        nvalid = tile + G < n_tiles;                                         // (behind the last tile: every row out of range -> zeros)
         f32x16 acc0 = f32x16{0}, acc1 = f32x16{0};
         const unsigned char* ap = abuf + (size_t)buf * B3_ABUF + kh * B3_BLK + (lane & 31) * 16;
         b3_u4 a1 = *reinterpret_cast<const b3_u4*>(ap), a2 = *reinterpret_cast<const b3_u4*>(ap + B3_PIECE),
@@ -267,7 +291,7 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
                 const float xv = v < 16 ? accp0[v & 15] : accp1[v & 15];                                           \
                 epi_piece(p0, xv, v); epi_piece(p0 + 1, xv, v);                                                    \
             }                                                                                                      \
-            if (!(DBG & 4) && slot % 3 == 1 && slot / 3 < 9) { const int sl = wave + 4 * (slot / 3); if (sl < 33) dma_slot(next, sl); } \
+            if (!(DBG & 4) && !(DBG & 8) && slot % 3 == 1 && slot / 3 < 9) dma_slot(wave + 4 * (slot / 3));             \
             __builtin_amdgcn_sched_barrier(0);                                                                     \
         } while (0)
 #define SLOT0(s) B3_SLOT_A(0, s)
@@ -298,7 +322,7 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
 #define B3_SLOT_B(KB, s)                                                                                         \
         do {                                                                                                       \
             constexpr int q = 12 * ((KB) - 11) + (s);                                                              \
-            if (!(DBG & 4) && q < 48) fold_piece(q % 6, q / 6, next, buf ^ 1);                                     \
+            if (!(DBG & 4) && !(DBG & 16) && q < 48) fold_piece(q % 6, q / 6, buf ^ 1);                            \
             __builtin_amdgcn_sched_barrier(0);                                                                     \
         } while (0)
 #define SLOT11(s) B3_SLOT_B(11, s)
@@ -369,14 +393,17 @@ __global__ __launch_bounds__(B3_NT) void imdct4_b3_kernel(const float* __restric
     const int col = wave * 64 + (lane & 31), kh = lane >> 5;
     const __amdgpu_buffer_rsrc_t r_spec = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(spec), 0, (unsigned)B * (unsigned)F * M * 4u, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(audio, 0, (DBG & 1) ? 0u : (unsigned)B * (unsigned)out_len * 4u, 0x00020000);
-    auto clip_of = [&](int i) { return (int)blockIdx.x + (i / tpc) * G; };
-    auto f0_of = [&](int i) { return (i % tpc) * B3_ROWS; };
+    // the tile being prepared (decoded) as (clip, tile of the clip): advanced without divisions; behind the last clip: nx_clip >= B
+    int nx_clip = blockIdx.x, nx_t = 0;
+    auto nx_advance = [&]() {
+        if (++nx_t == tpc) { nx_t = 0; nx_clip += G; }
+    };
 
     // x = v * c1 + c0 (= ln10 * ((v - nr0) / (nr1 - nr0) * (max - min) + min)), X = sinh(x) / gain; constants in double per tile
     float c1 = 1.0f, c0 = 0.0f;
     const float rgain = 1.0f / cp.gain;
-    auto tile_consts = [&](int i) {
-        const int b = i < n_seq ? clip_of(i) : 0;
+    auto tile_consts = [&]() {
+        const int b = nx_clip < B ? nx_clip : 0;
         float mn = cp.mn, mx = cp.mx;
         if (cp.per_sample) { mn = cp.mn_b[b]; mx = cp.mx_b[b]; }
         const double k = ((double)mx - (double)mn) / ((double)cp.nr1 - (double)cp.nr0);
@@ -386,13 +413,14 @@ __global__ __launch_bounds__(B3_NT) void imdct4_b3_kernel(const float* __restric
     };
     bs_v4u xr[8];
     int nf0 = 0;                                                 // first frame of the tile being prepared, F when there is none
-    auto load_tile = [&](int i) {                                // decode group g: row wave + 4 g, coefficients 4 lane ..+3
-        const int b = i < n_seq ? clip_of(i) : 0;
-        nf0 = i < n_seq ? f0_of(i) : F;
+    auto load_tile = [&]() {                                     // decode group g: row wave + 4 g, coefficients 4 lane ..+3
+        const int b = nx_clip < B ? nx_clip : 0;
+        nf0 = nx_clip < B ? nx_t * B3_ROWS : F;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int f = nf0 + wave + 4 * q;                    // (wave-uniform: the validity test is scalar)
-            xr[q] = __builtin_amdgcn_raw_buffer_load_b128(r_spec, f < F ? (((unsigned)b * F + (unsigned)f) * M + 4u * lane) * 4u : BS_OOB, 0, 0);
+            const int f = nf0 + wave + 4 * q;                    // (wave-uniform: the validity test is scalar; a mask, not a branch)
+            const unsigned dead = 0u - (unsigned)(f >= F);
+            xr[q] = __builtin_amdgcn_raw_buffer_load_b128(r_spec, ((((unsigned)b * F + (unsigned)f) * M + 4u * lane) * 4u) | dead, 0, 0);
         }
     };
     auto dec1 = [&](float v) -> float {
@@ -405,11 +433,14 @@ __global__ __launch_bounds__(B3_NT) void imdct4_b3_kernel(const float* __restric
     b3_u2 dh, dm_, dl;
     auto decode_piece = [&](int pc, int g, int buf) {            // group g (0..7) of the tile being prepared
         const float4 x = __builtin_bit_cast(float4, xr[g]);
-        const bool ok = nf0 + wave + 4 * g < F;                   // frames outside the clip contribute nothing (decode(0) != 0)
-        if (pc == 0) dz.x = ok ? dec1(x.x) : 0.0f;
-        else if (pc == 1) dz.y = ok ? dec1(x.y) : 0.0f;
-        else if (pc == 2) dz.z = ok ? dec1(x.z) : 0.0f;
-        else if (pc == 3) dz.w = ok ? dec1(x.w) : 0.0f;
+        // frames outside the clip contribute nothing (decode(0) != 0): an AND with a scalar mask (`ok ? dec1(x) : 0` on this
+        // wave-uniform condition compiles to a branch around the decode)
+        const unsigned live = 0u - (unsigned)(nf0 + wave + 4 * g < F);
+        auto keep = [&](float v) { return __uint_as_float(__float_as_uint(v) & live); };
+        if (pc == 0) dz.x = keep(dec1(x.x));
+        else if (pc == 1) dz.y = keep(dec1(x.y));
+        else if (pc == 2) dz.z = keep(dec1(x.z));
+        else if (pc == 3) dz.w = keep(dec1(x.w));
         else if (pc == 4) b3_split4(dz, dh, dm_, dl);
         else {
             unsigned char* dst = abuf + (size_t)buf * B3_ABUF + (lane >> 1) * B3_BLK + (wave + 4 * g) * 16 + (lane & 1) * 8;
@@ -450,8 +481,8 @@ __global__ __launch_bounds__(B3_NT) void imdct4_b3_kernel(const float* __restric
     };
 
     // prologue: decode the first tile, then fetch the table
-    tile_consts(0);
-    load_tile(0);
+    tile_consts();
+    load_tile();
 #pragma unroll
     for (int g = 0; g < 8; ++g)
 #pragma unroll
@@ -469,7 +500,9 @@ __global__ __launch_bounds__(B3_NT) void imdct4_b3_kernel(const float* __restric
 
     int buf = 0;
     for (int i = 0; i < n_seq; ++i, buf ^= 1) {
-        tile_consts(i + 1);
+        const int cur_clip = nx_clip, cur_f0 = nx_t * B3_ROWS;
+        nx_advance();
+        tile_consts();
         f32x16 acc0 = f32x16{0}, acc1 = f32x16{0};
         const unsigned char* ap = abuf + (size_t)buf * B3_ABUF + kh * B3_BLK + (lane & 31) * 16;
         b3_u4 a1 = *reinterpret_cast<const b3_u4*>(ap), a2 = *reinterpret_cast<const b3_u4*>(ap + B3_PIECE),
@@ -481,7 +514,7 @@ __global__ __launch_bounds__(B3_NT) void imdct4_b3_kernel(const float* __restric
         do {                                                                                                       \
             constexpr int slot = 12 * (KB) + (s);                                                                  \
             if (slot < 64 && (slot & 1) == 0) unfold_piece((slot >> 1) & 3, slot >> 3);                            \
-            if (slot == 1) load_tile(i + 1);                                                                       \
+            if (slot == 1) load_tile();                                                                            \
             if (slot >= 96 && (slot & 1) == 0) decode_piece(((slot - 96) >> 1) % 6, ((slot - 96) >> 1) / 6, buf ^ 1); \
             __builtin_amdgcn_sched_barrier(0);                                                                     \
         } while (0)
@@ -530,8 +563,8 @@ __global__ __launch_bounds__(B3_NT) void imdct4_b3_kernel(const float* __restric
         }
         if (kh == 1) { halo[(i & 1) * M + col] = acc0[15]; halo[(i & 1) * M + col + 32] = acc1[15]; }      // row 31 = reg 15 of the upper half
         {
-            const int pb = clip_of(i);
-            pf0 = f0_of(i);
+            const int pb = cur_clip;
+            pf0 = cur_f0;
             pbase = (unsigned)pb * (unsigned)out_len + (unsigned)((pf0 - 1) * M + n);      // (wraps for pf0 == 0: that block is masked)
             phalo = (i + 1) & 1;                   // the tile before this one wrote slot (i - 1) & 1
             pvalid = true;

@@ -5,6 +5,8 @@ from the reference.  Stated tolerances (float32 MFMA contraction vs the referenc
   IMDCT waveform      <= 2e-6 * max|y| (+1e-7)
   round trip          <= 5e-6 at sigma = 1 (max over 2M samples)
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -287,7 +289,7 @@ def test_table_stationary_k1_writes_nothing_outside_its_outputs(mods):
     descriptor's range check (voffset + scalar row offset against num_records), not by branches: outputs embedded in
     guard-filled arenas must come back with the guards intact and the same values as the stand-alone call."""
     from mdctgan_amd import _lib
-    from mdctgan_amd.mdct import dct4_table, mdct4_codec
+    from mdctgan_amd.mdct import dct4_image, dct4_table, mdct4_codec
     _, _, w = mods
     lib = _lib.load()
     B, T = 3, 32512 + 76
@@ -300,12 +302,26 @@ def test_table_stationary_k1_writes_nothing_outside_its_outputs(mods):
     arena_s = torch.full((G + n + G,), 7.5, device=DEV)
     arena_p = torch.full((G + 2 * n + G,), 7.5, device=DEV)
     spec, pair = arena_s[G:G + n], arena_p[G:G + 2 * n]
-    rc = lib.mg_mdct4_forward(_lib.ptr(x), B, T, 512, _lib.ptr(win), _lib.ptr(d4), _lib.MG_CODEC_ARCSINH, 1000.0, -1.0, 1.0, -5.0, 5.0, 0,
-                              spec.data_ptr(), pair.data_ptr(), None, None, None, None, None, _lib.stream())
-    assert rc == 0
-    torch.cuda.synchronize()
-    for arena, m in ((arena_s, n), (arena_p, 2 * n)):
-        assert bool((arena[:G] == 7.5).all()) and bool((arena[G + m:] == 7.5).all())
-    r = mdct4_codec(x, win, d4, 512, codec=_lib.MG_CODEC_ARCSINH, gain=1000.0, norm_range=(-1.0, 1.0), src_range=(-5.0, 5.0), want_pair=True)
-    assert torch.equal(r["spec"].reshape(-1), spec) and torch.equal(r["pair"].reshape(-1), pair)
-    assert bool((spec != 7.5).all())
+    for b3 in ("0", "1"):               # the f32-pipe kernel (mdct_bs.h) and the bf16 x 3 kernel (mdct_b3.h), both forced
+        os.environ["MG_MDCT_B3"] = b3
+        try:
+            arena_s.fill_(7.5)
+            arena_p.fill_(7.5)
+            rc = lib.mg_mdct4_forward(_lib.ptr(x), B, T, 512, _lib.ptr(win), _lib.ptr(d4), dct4_image(d4, 256), _lib.MG_CODEC_ARCSINH, 1000.0,
+                                      -1.0, 1.0, -5.0, 5.0, 0, spec.data_ptr(), pair.data_ptr(), None, None, None, None, None, _lib.stream())
+            assert rc == 0
+            torch.cuda.synchronize()
+            for arena, m in ((arena_s, n), (arena_p, 2 * n)):
+                assert bool((arena[:G] == 7.5).all()) and bool((arena[G + m:] == 7.5).all()), b3
+            r = mdct4_codec(x, win, d4, 512, codec=_lib.MG_CODEC_ARCSINH, gain=1000.0, norm_range=(-1.0, 1.0), src_range=(-5.0, 5.0), want_pair=True)
+            # (with the pair the launcher hands out the spectrogram as channel 0 of the pair)
+            assert torch.equal(r["spec"].reshape(-1), spec) and torch.equal(r["pair"].reshape(-1), pair), b3
+            assert r["spec"].data_ptr() == r["pair"].data_ptr() and bool((spec != 7.5).all())
+        finally:
+            del os.environ["MG_MDCT_B3"]
+    # a caller written against the round-1 ABI: the plain m x m table and no image -> the kernels that need none, same values
+    plain = d4[:256 * 256].clone()
+    spec1 = torch.empty_like(spec)
+    rc = lib.mg_mdct4_forward(_lib.ptr(x), B, T, 512, _lib.ptr(win), _lib.ptr(plain), None, _lib.MG_CODEC_ARCSINH, 1000.0,
+                              -1.0, 1.0, -5.0, 5.0, 0, spec1.data_ptr(), None, None, None, None, None, None, _lib.stream())
+    assert rc == 0 and (spec1 - spec).abs().max().item() <= 5e-6
