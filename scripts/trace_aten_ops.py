@@ -1,15 +1,17 @@
-"""Which Python lines launch torch (at::native) kernels inside one optimize_parameters() of a bench configuration: the step's own
-HIP kernels go through the C ABI, everything torch launches beside them (accumulate-adds, fills, copies) is overhead to remove.
-    python scripts/trace_aten_ops.py [--config 2] [--fp16]
-Prints, per aten op that launched a device kernel: calls per step, device time per step, and the innermost repo frames."""
+"""Which Python lines make torch launch its own (at::native) kernels inside one optimize_parameters() of a bench configuration:
+the step's HIP kernels go through the C ABI; everything torch launches beside them (accumulate-adds, fills, copies) is overhead
+to remove.  A TorchDispatchMode logs every aten op with the innermost repo frames (the profiler's with_stack aborts on this
+ROCm build).
+    python scripts/trace_aten_ops.py [--config 2] [--fp16]"""
 import argparse
 import collections
 import os
 import sys
+import traceback
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
-from torch.profiler import ProfilerActivity, profile  # noqa: E402
+from torch.utils._python_dispatch import TorchDispatchMode  # noqa: E402
 
 from bench import BATCH, synth_batch  # noqa: E402
 from mdctgan_amd import options  # noqa: E402
@@ -18,7 +20,6 @@ from mdctgan_amd.pix2pixHD_model import create_model  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", type=int, default=2)
 ap.add_argument("--fp16", action="store_true")
-ap.add_argument("--steps", type=int, default=3)
 args = ap.parse_args()
 if args.config == 1:
     net = ["--netG", "global", "--ngf", "64", "--n_downsample_global", "4", "--n_blocks_global", "9", "--n_blocks_attn_g", "0", "--num_D", "2"]
@@ -34,26 +35,31 @@ lr, hr = synth_batch(BATCH, 42, "cuda:0")
 for _ in range(4):
     model.optimize_parameters(lr, hr)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
-    for _ in range(args.steps):
-        model.optimize_parameters(lr, hr)
-    torch.cuda.synchronize()
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-agg = collections.defaultdict(lambda: [0, 0.0, ""])
-for ev in prof.events():
-    if ev.device_time_total <= 0 or not ev.name.startswith("aten::"):
-        continue
-    frames = [f for f in (ev.stack or []) if repo in f or "mdctgan_amd" in f]
-    site = " <- ".join(f.replace(repo + "/", "") for f in frames[:3]) or "(no repo frame)"
-    shapes = str(ev.input_shapes)[:60]
-    key = (ev.name, site, shapes)
-    a = agg[key]
-    a[0] += 1
-    a[1] += ev.device_time_total
-rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
-print("%-18s %8s %10s  %s" % ("op", "calls/it", "us/it", "site"))
-tot = 0.0
-for (name, site, shapes), (n, us, _) in rows[:60]:
-    tot += us / args.steps
-    print("%-18s %8.1f %10.1f  %s  %s" % (name, n / args.steps, us / args.steps, shapes, site))
-print("total aten device time per iteration (listed): %.1f us" % tot)
+SKIP = ("aten.view", "aten.detach", "aten._unsafe_view", "aten.t.", "aten.permute", "aten.transpose", "aten.slice", "aten.select",
+        "aten.as_strided", "aten.alias", "aten.expand", "aten.unsqueeze", "aten.squeeze", "aten.reshape", "aten.empty", "aten._local_scalar",
+        "aten.is_", "aten.split", "aten.unbind", "aten.lift_fresh", "aten.stride", "aten.sym_", "aten.size")
+log = collections.Counter()
+
+
+class Log(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, fargs=(), kwargs=None):
+        name = str(func)
+        if not name.startswith(SKIP):
+            big = 0
+            for a in fargs:
+                if isinstance(a, torch.Tensor):
+                    big = max(big, a.numel())
+            frames = [f for f in traceback.extract_stack() if repo in f.filename and "trace_aten_ops" not in f.filename]
+            site = " <- ".join("%s:%d" % (f.filename.replace(repo + "/", ""), f.lineno) for f in frames[-3:][::-1])
+            log[(name, site, big)] += 1
+        return func(*fargs, **(kwargs or {}))
+
+
+with Log():
+    model.optimize_parameters(lr, hr)
+torch.cuda.synchronize()
+print("%6s %12s  %-28s %s" % ("calls", "max numel", "op", "site (innermost first)"))
+for (name, site, big), n in sorted(log.items(), key=lambda kv: (-kv[0][2] * kv[1], kv[0][0])):
+    print("%6d %12d  %-28s %s" % (n, big, name, site))
+print("total logged aten calls per iteration:", sum(log.values()))

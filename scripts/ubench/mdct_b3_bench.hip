@@ -79,6 +79,8 @@ int main(int argc, char** argv) {
     K1B3(CODEC_ARCSINH, true, false, 1, cp, spec2, "K1 b3 arcsinh, no global stores");
     K1B3(CODEC_ARCSINH, true, false, 2, cp, spec2, "K1 b3 arcsinh, no codec math");
     K1B3(CODEC_ARCSINH, true, false, 4, cp, spec2, "K1 b3 arcsinh, no DMA, no fold");
+    K1B3(CODEC_ARCSINH, true, false, 8, cp, spec2, "K1 b3 arcsinh, no DMA (fold of stale data)");
+    K1B3(CODEC_ARCSINH, true, false, 16, cp, spec2, "K1 b3 arcsinh, no fold (DMA + wait + barrier)");
     K1B3(CODEC_ARCSINH, true, false, 7, cp, spec2, "K1 b3 MFMA + A reads only");
     printf("== K2 bf16 x 3\n");
     {

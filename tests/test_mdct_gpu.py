@@ -324,4 +324,6 @@ def test_table_stationary_k1_writes_nothing_outside_its_outputs(mods):
     spec1 = torch.empty_like(spec)
     rc = lib.mg_mdct4_forward(_lib.ptr(x), B, T, 512, _lib.ptr(win), _lib.ptr(plain), None, _lib.MG_CODEC_ARCSINH, 1000.0,
                               -1.0, 1.0, -5.0, 5.0, 0, spec1.data_ptr(), None, None, None, None, None, None, _lib.stream())
-    assert rc == 0 and (spec1 - spec).abs().max().item() <= 5e-6
+    # (two float32 evaluations of arcsinh(1000 X): bins next to zero differ by a few 1e-5 of the [-1, 1] range; the bar vs the
+    # reference is 5e-4)
+    assert rc == 0 and (spec1 - spec).abs().max().item() <= 2e-4
