@@ -265,39 +265,49 @@ def bench_codec(args, dev, rank, world):
     k1 = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps * 1e-3
     k2 = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps * 1e-3
     bytes_k = 261120.0 * B
+    flop32 = 2.0 * 128 * 256 * 256 * B
+    b3 = B >= 256 and os.environ.get("MG_MDCT_B3", "1") != "0"        # mdct.hip: K1 from 512 row tiles (128 clips), K2 from 256 clips
+    pipe_mult, pipe_peak = (6.0, PEAK_F16_MFMA_TFLOPS) if b3 else (1.0, PEAK_F32_MFMA_TFLOPS)
     out = {"metric": "codec clips/sec (MDCT4+norm, denorm+IMDCT4)", "value": round(world * args.steps * B / dt, 1),
            "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "K1+K2 on %d clips x 32512 samples (128 frames x 256 bins), arcsinh codec" % B,
                       "global_batch": B * world, "segment_length": T_SEG, "parallelism": "dp%d" % world},
-           "roofline": {"bound": "hbm", "kernel": "mdct4_bs_kernel<8, CODEC_ARCSINH, pair, stats> / imdct4_bs_kernel<CODEC_ARCSINH> (csrc/mdct_bs.h)",
+           "roofline": {"bound": "hbm",
+                        "kernel": ("mdct4_b3_kernel<CODEC_ARCSINH, spec, stats> / imdct4_b3_kernel<CODEC_ARCSINH> (csrc/mdct_b3.h: the DCT-IV as "
+                                   "exact three-piece bf16 products)") if b3 else
+                                  "mdct4_bs_kernel<CODEC_ARCSINH, stats> / imdct4_bs_kernel<CODEC_ARCSINH> (csrc/mdct_bs.h, f32 MFMA pipe)",
                         "achieved": round(bytes_k / k1 / 1e9, 1), "peak": 8000.0,
                         "unit": "GB/s", "frac": round(bytes_k / k1 / 8e12, 4), "traffic": None,
                         "k1_ms": round(k1 * 1e3, 4), "k2_ms": round(k2 * 1e3, 4),
                         "k2_achieved": round(bytes_k / k2 / 1e9, 1), "k2_frac": round(bytes_k / k2 / 8e12, 4),
                         "bytes_per_clip": 261120,
-                        "mfma_tflops_k1": round(2.0 * 128 * 256 * 256 * B / k1 / 1e12, 2),
-                        "mfma_tflops_k2": round(2.0 * 128 * 256 * 256 * B / k2 / 1e12, 2),
-                        "mfma_frac_k1": round(2.0 * 128 * 256 * 256 * B / k1 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                        "mfma_frac_k2": round(2.0 * 128 * 256 * 256 * B / k2 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                        "note": "the contraction is MFMA-bound (64 FLOP per algorithmic byte against a ridge of ~20): mfma_frac_* is the "
-                                "fraction that says how good the kernels are; frac / k2_frac are the HBM view BASELINE asks for; K1 "
-                                "here includes the pair (393 216 B per clip really move) and the mean / std statistics",
+                        "f32_equivalent_tflops_k1": round(flop32 / k1 / 1e12, 2), "f32_equivalent_tflops_k2": round(flop32 / k2 / 1e12, 2),
+                        "mfma_pipe": "bf16 (6 piece products per float32 product)" if b3 else "f32",
+                        "mfma_tflops_k1": round(pipe_mult * flop32 / k1 / 1e12, 2), "mfma_tflops_k2": round(pipe_mult * flop32 / k2 / 1e12, 2),
+                        "mfma_frac_k1": round(pipe_mult * flop32 / k1 / 1e12 / pipe_peak, 4),
+                        "mfma_frac_k2": round(pipe_mult * flop32 / k2 / 1e12 / pipe_peak, 4),
+                        "note": "SURVEY 8d asks for both views.  HBM: 261 120 algorithmic bytes per clip and kernel (frac / k2_frac).  MFMA: the "
+                                "folded 256 x 256 contraction is 16.8 MFLOP per clip in float32 terms (64 FLOP per byte, above the f32 ridge of "
+                                "~20); from 128 clips on K1 and from 256 clips on K2 form every float32 product from 6 exact bf16 piece products "
+                                "on the bf16 pipe (mfma_* count those against the dense bf16 peak); K1 here also returns the mean / std statistics",
                         "timed": "torch events on the launch stream around to_spectro / to_audio (each is one kernel "
                                  "launch plus the output allocation)"}}
     tr = os.path.join(REPO, "profiles", "traffic.json")      # HBM bytes per launch from the rocprofv3 --pmc passes (4096 clips)
     if os.path.exists(tr):
         table = json.load(open(tr)).get("codec", {})
-        t1, t2 = table.get("mdct4_bs_kernel<8, 1, true, false, 0>"), table.get("imdct4_bs_kernel<1>")
+        def first(prefix):
+            hits = [v for k, v in table.items() if k.startswith(prefix)]
+            return hits[0] if hits else None
+        t1, t2 = ((first("mdct4_b3_kernel<1, true, false, true"), first("imdct4_b3_kernel<1")) if b3 else
+                  (first("mdct4_bs_kernel<8, 1, false, true"), first("imdct4_bs_kernel<1")))
         if t1 and t2:
             out["roofline"]["traffic"] = int(t1 * B / 4096)
             out["roofline"]["k2_traffic"] = int(t2 * B / 4096)
             out["roofline"]["traffic_definition"] = (
-                "HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 from separate rocprofv3 --pmc passes over "
-                "scripts/ubench/mdct_bs_bench at 4096 clips (%s), scaled by clips / 4096; K1 = the pair variant without the "
-                "statistics (526.9 KB per clip: 130 048 read, spectrogram + 2-channel network input written), K2 = 267.5 KB per clip"
-                % table.get("_source"))
+                "HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 from separate rocprofv3 --pmc passes over this bench "
+                "mode at 4096 clips (%s), scaled by clips / 4096" % table.get("_source"))
     if rank == 0:
         print(json.dumps(out), flush=True)
 

@@ -308,11 +308,13 @@ struct DgInterleave { static constexpr bool on = (LAY == DG_RC && BLOCKS == 2); 
 template <bool INT, int BLOCKS>
 __device__ __forceinline__ int dg_tile_index(int blk, int r) { return INT ? BLOCKS * r + blk : 32 * blk + r; }
 
-template <int MB, int NB, int ALAY, int BLAY, int BM, int BN>
+// INTL: opt-in (dgemm32g_kernel, whose epilogue knows the mapping); the direct-convolution kernels of conv_dma.h share this
+// chunk with their own block-mapped epilogues.
+template <int MB, int NB, int ALAY, int BLAY, int BM, int BN, bool INTL = false>
 __device__ __forceinline__ void dg_chunk_g(const float* As, const float* Bs, f32x16 (&acc)[MB][NB], int wm0, int wn0,
                                            int lane) {
     const int r = lane & 31, kh = lane >> 5;
-    constexpr bool AINT = DgInterleave<ALAY, MB>::on, BINT = DgInterleave<BLAY, NB>::on;
+    constexpr bool AINT = INTL && DgInterleave<ALAY, MB>::on, BINT = INTL && DgInterleave<BLAY, NB>::on;
     float a[2][MB][4], b[2][NB][4];
     auto fetch = [&](int s, int buf) {
         if (AINT) {
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void dgemm32g_kernel(DgArgs g) {
             __builtin_amdgcn_sched_barrier(0);
             if (c + 1 < c_end) issue(c + 1, cur ^ 1);
             if constexpr (EMU) dg_chunk_b8<MB, NB, ALAY, BLAY, BM, BN>(As0 + cur * Cfg::ASZ, Bs0 + cur * Cfg::BSZ, acc, wm0, wn0, lane);
-            else dg_chunk_g<MB, NB, ALAY, BLAY, BM, BN>(As0 + cur * Cfg::ASZ, Bs0 + cur * Cfg::BSZ, acc, wm0, wn0, lane);
+            else dg_chunk_g<MB, NB, ALAY, BLAY, BM, BN, true>(As0 + cur * Cfg::ASZ, Bs0 + cur * Cfg::BSZ, acc, wm0, wn0, lane);
         }
     } else {
         // three buffers: two chunks in flight, the DMA of chunk c + 1 stays outstanding across the barrier of chunk c
@@ -563,7 +565,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void dgemm32g_kernel(DgArgs g) {
             const int nxt2 = cur == 0 ? 2 : cur - 1;
             if (c + 2 < c_end) issue(c + 2, nxt2);
             if constexpr (EMU) dg_chunk_b8<MB, NB, ALAY, BLAY, BM, BN>(As0 + cur * Cfg::ASZ, Bs0 + cur * Cfg::BSZ, acc, wm0, wn0, lane);
-            else dg_chunk_g<MB, NB, ALAY, BLAY, BM, BN>(As0 + cur * Cfg::ASZ, Bs0 + cur * Cfg::BSZ, acc, wm0, wn0, lane);
+            else dg_chunk_g<MB, NB, ALAY, BLAY, BM, BN, true>(As0 + cur * Cfg::ASZ, Bs0 + cur * Cfg::BSZ, acc, wm0, wn0, lane);
             cur = cur == 2 ? 0 : cur + 1;
         }
     }

@@ -106,7 +106,7 @@ __global__ void dct4_b3_image_kernel(const float* __restrict__ d4, b3_u4* __rest
 // DMA nor fold, 3 no DMA, 4 no fold.  SPEC: write the 1-channel spectrogram; PAIR: write the 2-channel network input
 // (v, 2|v| + nr0) -- with PAIR alone the spectrogram is channel 0 of the pair (393 216 B per clip instead of 526 848).
 // ------------------------------------------------------------------------------------------------------------------
-template <int MODE, bool SPEC, bool PAIR, bool STATS, int DBG = 0>
+template <int MODE, bool SPEC, bool PAIR, bool STATS, int DBG = 0, int DS = 3>      // DS: one DMA piece every DS-th slot (from slot 1 on)
 __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict__ audio, int B, int T, int F,
                                                          const float* __restrict__ window, const b3_u4* __restrict__ img,
                                                          CodecParams cp, float* __restrict__ spec, float* __restrict__ in2,
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
                 const float xv = v < 16 ? accp0[v & 15] : accp1[v & 15];                                           \
                 epi_piece(p0, xv, v); epi_piece(p0 + 1, xv, v);                                                    \
             }                                                                                                      \
-            if (!(DBG & 4) && !(DBG & 8) && slot % 3 == 1 && slot / 3 < 9) dma_slot(wave + 4 * (slot / 3));             \
+            if (!(DBG & 4) && !(DBG & 8) && slot % DS == 1 % DS && slot / DS < 9) dma_slot(wave + 4 * (slot / DS));     \
             __builtin_amdgcn_sched_barrier(0);                                                                     \
         } while (0)
 #define SLOT0(s) B3_SLOT_A(0, s)
@@ -314,7 +314,10 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
         // codec's stores of slots 27 .. 127 (values 6 .. 31: 26 per output tensor), which vmcnt(0) would wait for (measured:
         // +250 us per 4096 clips).  The counter saturates at 63.
         {
-            constexpr int after = 26 * ((SPEC ? 1 : 0) + (PAIR ? 1 : 0));
+            constexpr int last_dma = 1 % DS + 8 * DS;                      // slot of the last piece
+            constexpr int first_after = (last_dma - 3 + 4) / 4 + ((last_dma - 3) % 4 == 0 ? 1 : 0);   // first value whose store slot 4 v + 3 lies behind it
+            constexpr int after = (32 - (first_after < 0 ? 0 : first_after)) * ((SPEC ? 1 : 0) + (PAIR ? 1 : 0));
+            static_assert(DS != 3 || after == 26 * ((SPEC ? 1 : 0) + (PAIR ? 1 : 0)), "count");
             b3_wait_vm<(after < 63 ? after : 63)>();
         }
         __syncthreads();

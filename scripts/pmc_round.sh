@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic per launch from PMC counters, collected as /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and
-# WRITE_SIZE in SEPARATE rocprofv3 passes with --kernel-trace only.   usage (GPU box, repo root): bash scripts/pmc_round.sh r03
-tag=${1:-r03}
+# WRITE_SIZE in SEPARATE rocprofv3 passes with --kernel-trace only.   usage (GPU box, repo root): bash scripts/pmc_round.sh r04
+tag=${1:-r04}
 R=$(pwd); out=$R/gpurun_out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 pass() {   # name counter cmd...
@@ -15,8 +15,8 @@ f=$(pass conv FETCH_SIZE python $R/scripts/bench_conv.py --only bottleneck --ite
 w=$(pass conv WRITE_SIZE python $R/scripts/bench_conv.py --only bottleneck --iters 2)
 python $R/scripts/pmc_traffic.py $f $w $out/${tag}_pmc_hbm_traffic.csv $R/profiles/traffic.json
 # K1 / K2 at 4096 clips
-f=$(pass mdct FETCH_SIZE $R/scripts/ubench/mdct_bs_bench 4096)
-w=$(pass mdct WRITE_SIZE $R/scripts/ubench/mdct_bs_bench 4096)
+f=$(pass mdct FETCH_SIZE python $R/bench.py --mode codec --steps 3 --warmup 1)
+w=$(pass mdct WRITE_SIZE python $R/bench.py --mode codec --steps 3 --warmup 1)
 python $R/scripts/pmc_traffic.py $f $w $out/${tag}_pmc_hbm_traffic_codec.csv $R/profiles/traffic.json "codec"
 # the dominant kernels of the other bench lines (same symbols, other layer shapes): one section each
 for spec in "configs[1] --fp16:c1h:bottleneck:--f16" "configs[2]:c2:trunk2048:" "configs[2] --fp16:c2h:trunk2048:--f16" "configs[4]:c4:bottleneck_b64:"; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round evidence in one GPU call: rocprofv3 --kernel-trace --stats summaries of the bench lines (-> gpurun_out/rNN_*), to be
-# copied into profiles/.   usage (GPU box, from the repo root): bash scripts/profile_round.sh r03
-tag=${1:-r03}
+# copied into profiles/.   usage (GPU box, from the repo root): bash scripts/profile_round.sh r04
+tag=${1:-r04}
 R=$(pwd)
 out=$R/gpurun_out
 mkdir -p $out
@@ -31,16 +31,16 @@ for f in bench_codec bench_cfg2_f32 bench_train_fp16 bench_train; do tail -c 300
 # K1 / K2 micro-benchmark (product kernels + variants with parts switched off) and their SQ counters
 hipcc --version > /dev/null 2>&1
 for b in 4096 64 8; do scripts/ubench/mdct_bs_bench $b; done > $out/${tag}_mdct_bs_ubench.log 2>&1
+for b in 4096 1024; do scripts/ubench/mdct_b3_bench $b; done > $out/${tag}_mdct_b3_ubench.log 2>&1
 cd /tmp
 rm -rf /tmp/pmc_bs
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY \
-    -d /tmp/pmc_bs --output-format csv -- $R/scripts/ubench/mdct_bs_bench 4096 > /dev/null 2>&1
+    -d /tmp/pmc_bs --output-format csv -- $R/scripts/ubench/mdct_b3_bench 4096 > /dev/null 2>&1
 f=$(find /tmp/pmc_bs -name "*counter_collection.csv" | head -1)
-[ -n "$f" ] && python $R/scripts/pmc_sq.py $f $out/${tag}_pmc_sq_mdct_bs.csv > /dev/null
+[ -n "$f" ] && python $R/scripts/pmc_sq.py $f $out/${tag}_pmc_sq_mdct_b3.csv > /dev/null
 cd $R
 # full-size step parity by kernel family + op-level accuracy of the 25-position Winograd families
-bash scripts/diag_fullsize_step.sh $out/${tag}_step_report.jsonl > $out/${tag}_fullsize_step_parity.txt 2>&1
-python scripts/diag_wino4_accuracy.py >> $out/${tag}_fullsize_step_parity.txt 2>&1
+bash scripts/r04_step_parity.sh $out/${tag}_step_report.jsonl > $out/${tag}_fullsize_step_parity.txt 2>&1
 tail -5 $out/${tag}_mdct_bs_ubench.log
 
 # float16 GEMM structure ablation on the dense twin of the 128-channel 64x128 layers (--fp16): which part of

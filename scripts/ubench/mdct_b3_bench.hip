@@ -82,6 +82,16 @@ int main(int argc, char** argv) {
     K1B3(CODEC_ARCSINH, true, false, 8, cp, spec2, "K1 b3 arcsinh, no DMA (fold of stale data)");
     K1B3(CODEC_ARCSINH, true, false, 16, cp, spec2, "K1 b3 arcsinh, no fold (DMA + wait + barrier)");
     K1B3(CODEC_ARCSINH, true, false, 7, cp, spec2, "K1 b3 MFMA + A reads only");
+#define K1B3D(DS_, name)                                                                                                  \
+    {                                                                                                                       \
+        auto k = mdct4_b3_kernel<CODEC_ARCSINH, true, false, false, 0, DS_>;                                                \
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3_K1_LDS);                    \
+        report(name, time_ms([&] { hipLaunchKernelGGL(k, grid, dim3(256), B3_K1_LDS, 0, x, B, T, F, w, img3, cp, spec2, in2, (double*)nullptr); }, iters)); \
+    }
+    K1B3D(1, "K1 b3 product, DMA pieces in slots 0..8");
+    K1B3D(2, "K1 b3 product, DMA piece every 2nd slot");
+    K1B3D(6, "K1 b3 product, DMA piece every 6th slot");
+    K1B3D(12, "K1 b3 product, DMA piece every 12th slot");
     printf("== K2 bf16 x 3\n");
     {
         hipMemsetAsync(y, 0, (size_t)B * T * 4, 0); hipMemsetAsync(y2, 0, (size_t)B * T * 4, 0);
