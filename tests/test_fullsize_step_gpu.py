@@ -266,9 +266,9 @@ def test_full_size_step_gradients(tag, fp16, feat, monkeypatch):
                 # The losses of iteration it + 1 see the parameters after `it` Adam steps.  Adam's first steps amplify float32
                 # noise (the first update is lr * sign(g) element by element: an element whose gradient is inside the noise goes either
                 # way, the next gradient is taken at a different point), and the GAN losses move by 2x per iteration here, so two float32
-                # evaluations drift apart: measured 4e-4 at iteration 2 and 2.5e-2 at iteration 3 (the discriminator-only loss
+                # evaluations drift apart: measured 4e-4 (configs[1]) / 5e-3 (configs[2]) at iteration 2, 2.5e-2 at iteration 3 (the discriminator-only loss
                 # D_real stays at 3e-6).  A missing / doubled / mis-clocked update or a stale transformed weight moves them by O(1).
-                if not abs(v.item() - want) <= (2e-3 if it == 1 else 6e-2) * abs(want):
+                if not abs(v.item() - want) <= (1e-2 if it == 1 else 6e-2) * abs(want):
                     bad.append(("loss %s at iteration %d" % (k, it + 1), v.item(), want))
         lr_adam = 2e-4
         for net, ref_sd, p_init, pre, g64 in ((model.netG, ref_after[0], p0[0], "G.", gG64), (model.netD, ref_after[1], p0[1], "D.", gD64)):
@@ -290,7 +290,8 @@ def test_full_size_step_gradients(tag, fp16, feat, monkeypatch):
                     if np.abs(d_hip).max() != 0.0:
                         bad.append((pre + k, "the oracle left this parameter alone, the HIP step moved it"))
                     continue
-                if not (rel <= 0.7 or d_ref.size == 1) or not np.abs(d_hip - d_ref).max() <= 2.02 * n_steps * lr_adam:
+                # (|m / sqrt(v)| exceeds 1 after the first step: an element's move per step is ~lr, not bounded by it)
+                if not (rel <= 0.7 or d_ref.size == 1) or not np.abs(d_hip - d_ref).max() <= 3.0 * n_steps * lr_adam:
                     bad.append((pre + k, "3-step update: rel-L2 %.3e, max |diff| %.3e" % (rel, np.abs(d_hip - d_ref).max())))
         # ... and bit for bit what the three separate kernels (weight gradient, Adam, transform) leave
         if not bad:
