@@ -120,8 +120,7 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
                                                          double* __restrict__ stats) {
     constexpr int Q = M / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char b3_smem[];
-    float* ws = reinterpret_cast<float*>(b3_smem);                 // [2 M] window, then [2 M] its negative
-    unsigned char* abuf = b3_smem + 4 * M * sizeof(float);         // [2][B3_ABUF] A operand pieces
+    unsigned char* abuf = b3_smem;                                 // [2][B3_ABUF] operand pieces of the frames
     float* raw = reinterpret_cast<float*>(abuf + 2 * B3_ABUF);     // [33][256] hop blocks of the tile being folded
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rows = B * F, n_tiles = (rows + B3_ROWS - 1) / B3_ROWS, G = gridDim.x;
@@ -171,9 +170,13 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
     const int n = 4 * lane;
     const bool lo = n < Q;
     const int o1 = 3 * Q - 4 - n, o2 = lo ? 3 * Q + n : n - Q;     // frame sample index of the reversed / the straight run
-    const float* wS = ws + (lo ? 2 * M : 0) + o2;                  // (the straight run's sign rides in the window copy)
     const int s1 = lo ? o1 - M : o1, s2 = lo ? o2 - M : o2;        // the same runs as offsets inside the lane's hop block
-    float4 fz1, fz2, fw1, fw2;
+    // this lane's eight window values are the same for every row: registers (the straight run's sign rides in them:
+    // fl32(x * -w) = -fl32(x * w))
+    const float4 fw1 = bs_ld4(window + o1);
+    float4 fw2 = bs_ld4(window + o2);
+    if (lo) fw2 = make_float4(-fw2.x, -fw2.y, -fw2.z, -fw2.w);
+    float4 fz1, fz2;
     b3_u2 fh, fm, fl;
     auto fold_piece = [&](int pc, int gi, int buf) {
         const int r = wave + 4 * gi;
@@ -186,7 +189,6 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
             const float* blk = raw + slot * M;
             fz1 = bs_ld4(blk + s1); fz2 = bs_ld4(blk + s2);
         } else if (pc == 1) {
-            fw1 = bs_ld4(ws + o1); fw2 = bs_ld4(wS);
         } else if (pc == 2) {       // z = fl32(x * w) (mdct.py:410)
             fz1 = make_float4(__fmul_rn(fz1.x, fw1.x), __fmul_rn(fz1.y, fw1.y), __fmul_rn(fz1.z, fw1.z), __fmul_rn(fz1.w, fw1.w));
             fz2 = make_float4(__fmul_rn(fz2.x, fw2.x), __fmul_rn(fz2.y, fw2.y), __fmul_rn(fz2.z, fw2.z), __fmul_rn(fz2.w, fw2.w));
@@ -266,11 +268,6 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < 9; ++i) dma_slot(wave + 4 * i);
     if (tid < 64) reinterpret_cast<float4*>(raw + 36 * M)[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < 2 * M / 4) {
-        const float4 wv = bs_ld4(window + 4 * tid);
-        reinterpret_cast<float4*>(ws)[tid] = wv;
-        reinterpret_cast<float4*>(ws + 2 * M)[tid] = make_float4(-wv.x, -wv.y, -wv.z, -wv.w);
-    }
     b3_u4 bt[3][2][16];
 #pragma unroll
     for (int p = 0; p < 3; ++p)
@@ -384,7 +381,7 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
     }
 }
 
-constexpr size_t B3_K1_LDS = (size_t)4 * M * sizeof(float) + 2 * B3_ABUF + B3_RAW;
+constexpr size_t B3_K1_LDS = (size_t)2 * B3_ABUF + B3_RAW;
 
 // ------------------------------------------------------------------------------------------------------------------
 // K2.  grid = workers (<= 256, <= B), block = 256.  A workgroup walks whole clips b = blockIdx.x, + G, ..., each tile by tile in
