@@ -236,7 +236,7 @@ def bench_codec(args, dev, rank, world):
     and writes 131 072 B, K2 reads 131 072 B and writes 130 048 B (261 120 B each)."""
     from mdctgan_amd import options
     from mdctgan_amd.pix2pixHD_model import Audio2MDCT
-    opt = options.make_opt(*options.SPECTRAL_FLAGS, "--lr_sampling_rate", "12000", "--gpu_ids", str(rank))
+    opt = options.make_opt(*options.SPECTRAL_FLAGS, "--lr_sampling_rate", "12000", "--gpu_ids", str(torch.device(dev).index))
     codec = Audio2MDCT(opt)
     B = args.codec_batch
     g = torch.Generator().manual_seed(7)
@@ -410,7 +410,7 @@ def main():
         workload = workload.replace("in FLOAT32 (the reference config adds --fp16)", "with --fp16").replace(
             ", fp32", ", --fp16 (autocast convolutions on the f16 MFMA pipe, float32 storage, GradScaler)")
     opt = options.make_opt(*options.SPECTRAL_FLAGS, "--lr_sampling_rate", str(lr_rate), *net_flags,
-                           "--batchSize", str(batch), "--gpu_ids", str(local_rank))
+                           "--batchSize", str(batch), "--gpu_ids", str(dev_index))
     model = create_model(opt)
     if use_ddp:
         ddp.attach(model)

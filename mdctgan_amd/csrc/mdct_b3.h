@@ -87,23 +87,18 @@ __global__ void dct4_b3_image_kernel(const float* __restrict__ d4, b3_u4* __rest
     img[2 * P + i] = b3_u4{l0.x, l0.y, l1.x, l1.y};
 }
 
-// Operand roles: the TABLE is the MFMA's A operand (rows = bins), the frames its B operand (columns = frames) -- both are "8
-// consecutive k of index lane & 31", so the registers are the same either way -- and the accumulator is the TRANSPOSED tile:
-// a lane holds ONE frame (lane & 31) and, in registers 4 q .. 4 q + 3, FOUR CONSECUTIVE BINS 8 q + 4 (lane >> 5) + (0..3) of its
-// 32-bin block: 16-byte stores (K1: 8 per tile and wave instead of 32 dword stores -- the epilogue was store-ISSUE bound) and
-// 16-byte LDS writes of the v tile (K2).
 // The 12 MFMAs of one k-block, smallest terms first; SLOT(s) runs the side work of MFMA slot 12 * kb + s right behind it.
 // a3 is used first and a1 last, so that the A pieces of the next k-block can be fetched into the same registers piece by
 // piece (a3 after slot 1, a2 after slot 5, a1 after slot 11): 12 registers of A operand, every fetch >= 6 MFMAs ahead.
 #define B3_KBLOCK(KB, SLOT)                                                                        \
-    acc0 = b3_mfma(bt[0][0][KB], a3, acc0); SLOT(0);  acc1 = b3_mfma(bt[0][1][KB], a3, acc1); SLOT(1);  \
+    acc0 = b3_mfma(a3, bt[0][0][KB], acc0); SLOT(0);  acc1 = b3_mfma(a3, bt[0][1][KB], acc1); SLOT(1);  \
     if (KB + 1 < 16) a3 = *reinterpret_cast<const b3_u4*>(ap + 2 * B3_PIECE + (KB + 1) * 2 * B3_BLK);   \
-    acc0 = b3_mfma(bt[1][0][KB], a2, acc0); SLOT(2);  acc1 = b3_mfma(bt[1][1][KB], a2, acc1); SLOT(3);  \
-    acc0 = b3_mfma(bt[0][0][KB], a2, acc0); SLOT(4);  acc1 = b3_mfma(bt[0][1][KB], a2, acc1); SLOT(5);  \
+    acc0 = b3_mfma(a2, bt[1][0][KB], acc0); SLOT(2);  acc1 = b3_mfma(a2, bt[1][1][KB], acc1); SLOT(3);  \
+    acc0 = b3_mfma(a2, bt[0][0][KB], acc0); SLOT(4);  acc1 = b3_mfma(a2, bt[0][1][KB], acc1); SLOT(5);  \
     if (KB + 1 < 16) a2 = *reinterpret_cast<const b3_u4*>(ap + B3_PIECE + (KB + 1) * 2 * B3_BLK);       \
-    acc0 = b3_mfma(bt[2][0][KB], a1, acc0); SLOT(6);  acc1 = b3_mfma(bt[2][1][KB], a1, acc1); SLOT(7);  \
-    acc0 = b3_mfma(bt[1][0][KB], a1, acc0); SLOT(8);  acc1 = b3_mfma(bt[1][1][KB], a1, acc1); SLOT(9);  \
-    acc0 = b3_mfma(bt[0][0][KB], a1, acc0); SLOT(10); acc1 = b3_mfma(bt[0][1][KB], a1, acc1); SLOT(11); \
+    acc0 = b3_mfma(a1, bt[2][0][KB], acc0); SLOT(6);  acc1 = b3_mfma(a1, bt[2][1][KB], acc1); SLOT(7);  \
+    acc0 = b3_mfma(a1, bt[1][0][KB], acc0); SLOT(8);  acc1 = b3_mfma(a1, bt[1][1][KB], acc1); SLOT(9);  \
+    acc0 = b3_mfma(a1, bt[0][0][KB], acc0); SLOT(10); acc1 = b3_mfma(a1, bt[0][1][KB], acc1); SLOT(11); \
     if (KB + 1 < 16) a1 = *reinterpret_cast<const b3_u4*>(ap + (KB + 1) * 2 * B3_BLK);
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -111,20 +106,19 @@ __global__ void dct4_b3_image_kernel(const float* __restrict__ d4, b3_u4* __rest
 // DMA nor fold, 3 no DMA, 4 no fold.  SPEC: write the 1-channel spectrogram; PAIR: write the 2-channel network input
 // (v, 2|v| + nr0) -- with PAIR alone the spectrogram is channel 0 of the pair (393 216 B per clip instead of 526 848).
 // ------------------------------------------------------------------------------------------------------------------
-// DS: one DMA piece every DS-th slot from slot 1 on.  Measured at 4096 clips (scripts/ubench/mdct_b3_bench): 1, 2, 6, 12 -> 474 .. 478 us,
-// 3 -> 595 us (its slots 7, 19, 31, ... are also the codec's store slots 4 v + 3: the piece's M0 swap lands on a store's address setup)
-template <int MODE, bool SPEC, bool PAIR, bool STATS, int DBG = 0, int DS = 6>
+template <int MODE, bool SPEC, bool PAIR, bool STATS, int DBG = 0, int DS = 6>      // DS: one DMA piece every DS-th slot (from slot 1 on)
 __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict__ audio, int B, int T, int F,
                                                          const float* __restrict__ window, const b3_u4* __restrict__ img,
                                                          CodecParams cp, float* __restrict__ spec, float* __restrict__ in2,
                                                          double* __restrict__ stats) {
     constexpr int Q = M / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char b3_smem[];
-    unsigned char* abuf = b3_smem;                                 // [2][B3_ABUF] operand pieces of the frames
+    float* ws = reinterpret_cast<float*>(b3_smem);                 // [2 M] window, then [2 M] its negative
+    unsigned char* abuf = b3_smem + 4 * M * sizeof(float);         // [2][B3_ABUF] A operand pieces
     float* raw = reinterpret_cast<float*>(abuf + 2 * B3_ABUF);     // [33][256] hop blocks of the tile being folded
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rows = B * F, n_tiles = (rows + B3_ROWS - 1) / B3_ROWS, G = gridDim.x;
-    const int kh = lane >> 5;
+    const int col = wave * 64 + (lane & 31), kh = lane >> 5;       // bin of accumulator block 0 (block 1: col + 32)
     const float k1 = (float)(((double)cp.nr1 - (double)cp.nr0) / ((double)cp.mx - (double)cp.mn));
     const float k0 = (float)((double)cp.nr0 - (double)cp.mn * (((double)cp.nr1 - (double)cp.nr0) / ((double)cp.mx - (double)cp.mn)));
     const float gain = cp.gain, nr0 = cp.nr0;
@@ -170,13 +164,9 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
     const int n = 4 * lane;
     const bool lo = n < Q;
     const int o1 = 3 * Q - 4 - n, o2 = lo ? 3 * Q + n : n - Q;     // frame sample index of the reversed / the straight run
+    const float* wS = ws + (lo ? 2 * M : 0) + o2;                  // (the straight run's sign rides in the window copy)
     const int s1 = lo ? o1 - M : o1, s2 = lo ? o2 - M : o2;        // the same runs as offsets inside the lane's hop block
-    // this lane's eight window values are the same for every row: registers (the straight run's sign rides in them:
-    // fl32(x * -w) = -fl32(x * w))
-    const float4 fw1 = bs_ld4(window + o1);
-    float4 fw2 = bs_ld4(window + o2);
-    if (lo) fw2 = make_float4(-fw2.x, -fw2.y, -fw2.z, -fw2.w);
-    float4 fz1, fz2;
+    float4 fz1, fz2, fw1, fw2;
     b3_u2 fh, fm, fl;
     auto fold_piece = [&](int pc, int gi, int buf) {
         const int r = wave + 4 * gi;
@@ -189,6 +179,7 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
             const float* blk = raw + slot * M;
             fz1 = bs_ld4(blk + s1); fz2 = bs_ld4(blk + s2);
         } else if (pc == 1) {
+            fw1 = bs_ld4(ws + o1); fw2 = bs_ld4(wS);
         } else if (pc == 2) {       // z = fl32(x * w) (mdct.py:410)
             fz1 = make_float4(__fmul_rn(fz1.x, fw1.x), __fmul_rn(fz1.y, fw1.y), __fmul_rn(fz1.z, fw1.z), __fmul_rn(fz1.w, fw1.w));
             fz2 = make_float4(__fmul_rn(fz2.x, fw2.x), __fmul_rn(fz2.y, fw2.y), __fmul_rn(fz2.z, fw2.z), __fmul_rn(fz2.w, fw2.w));
@@ -204,16 +195,15 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
             *reinterpret_cast<b3_u2*>(dst + 2 * B3_PIECE) = fl;
         }
     };
-    // epilogue of the previous tile: value v = 16 blk + reg of this lane = frame row em + (lane & 31) of the tile, bin
-    // 64 wave + 32 blk + 8 (reg >> 2) + 4 kh + (reg & 3); the four values of a group g = v >> 2 leave as one 16-byte store
+    // epilogue of the previous tile: value v = 16 blk + reg of this lane: frame row em0 + (r & 3) + 8 (r >> 2), bin col + 32 blk
     float ea, ea2, et, ep, esq, esm, el, ev, elog = 0.0f;
-    float evq[4];
     double sd1 = 0.0, sd2 = 0.0;
     float f1 = 0.0f, f2 = 0.0f;
-    bool erow = false;                       // STATS: this lane's frame row of the previous tile exists
-    unsigned eob = BS_OOB, eob2 = BS_OOB;    // byte offset of (this lane's frame row, bin 64 wave + 4 kh) in spec / in the pair
+    int em0 = 0;
+    unsigned eob = BS_OOB, eob2 = BS_OOB;
     auto epi_piece = [&](int pc, float xv, int v) {
-        const int g = v >> 2, e = v & 3;
+        const int r = v & 15, blk = v >> 4;
+        const int dm = (r & 3) + 8 * (r >> 2);
         if (MODE == CODEC_RAW || (DBG & 2)) {
             if (pc == 0) ev = xv;
         } else if (pc == 0) {
@@ -232,31 +222,22 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
             ev = fmaf(elog, k1, k0);          // (l - min) / (max - min) * (nr1 - nr0) + nr0, constants folded in double (mdct_bs.h)
         }
         if (STATS && pc == 5 && MODE != CODEC_RAW) {
-            const float l = erow ? elog : 0.0f;
+            const float l = (em0 + dm < rows) ? elog : 0.0f;
             f1 += l; f2 = fmaf(l, l, f2);
         }
-        if (pc == 5) evq[e] = ev;
-        // group g = 4 blk + q starts at bin 32 blk + 8 q of the lane's 64-bin slab: byte 128 blk + 32 q (pair: twice that)
-        const unsigned goff = 128u * (g >> 2) + 32u * (g & 3);
-        if (pc == 6 && e == 3 && SPEC) {
-            const bs_v4u q4 = {__float_as_uint(evq[0]), __float_as_uint(evq[1]), __float_as_uint(evq[2]), __float_as_uint(evq[3])};
-            __builtin_amdgcn_raw_buffer_store_b128(q4, r_spec, eob, goff, 0);
-        } else if (pc == 7 && e == 3 && PAIR) {          // (v, 2 |v| + nr0) x 4 bins  (x 2 is exact: == |v| * 2 + nr0)
-            const bs_v4u p0 = {__float_as_uint(evq[0]), __float_as_uint(fmaf(fabsf(evq[0]), 2.0f, nr0)),
-                               __float_as_uint(evq[1]), __float_as_uint(fmaf(fabsf(evq[1]), 2.0f, nr0))};
-            const bs_v4u p1 = {__float_as_uint(evq[2]), __float_as_uint(fmaf(fabsf(evq[2]), 2.0f, nr0)),
-                               __float_as_uint(evq[3]), __float_as_uint(fmaf(fabsf(evq[3]), 2.0f, nr0))};
-            __builtin_amdgcn_raw_buffer_store_b128(p0, r_in2, eob2, 2u * goff, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(p1, r_in2, eob2, 2u * goff + 16u, 0);
+        if (pc == 6 && SPEC) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ev), r_spec, eob + 128u * blk, dm * (M * 4), 0);
+        } else if (pc == 7 && PAIR) {
+            const bs_v2u pr = {__float_as_uint(ev), __float_as_uint(fmaf(fabsf(ev), 2.0f, nr0))};
+            __builtin_amdgcn_raw_buffer_store_b64(pr, r_in2, eob2 + 256u * blk, dm * (M * 8), 0);
         }
     };
     auto epi_begin = [&](int tile) {         // tile == n_tiles: nothing to store
         if (STATS && MODE != CODEC_RAW) { sd1 += (double)f1; sd2 += (double)f2; f1 = f2 = 0.0f; }
-        const unsigned m = (unsigned)tile * B3_ROWS + (unsigned)(lane & 31);
-        // a row behind the batch lies behind num_records: the hardware drops its stores (no branch, no select per store)
-        eob = (tile < n_tiles) ? (m * M + (unsigned)(64 * wave + 4 * kh)) * 4u : BS_OOB - 1024u;
+        const unsigned m0 = (unsigned)tile * B3_ROWS + 4u * kh;
+        eob = (tile < n_tiles) ? (m0 * M + (unsigned)col) * 4u : BS_OOB - 31u * M * 8u - 256u;
         eob2 = (tile < n_tiles) ? 2u * eob : eob;
-        erow = tile < n_tiles && (int)m < rows;
+        em0 = (tile < n_tiles) ? (int)m0 : rows;
     };
 
     // prologue: raw audio of the first tile by DMA, the window, the table (384 registers), then the first fold
@@ -268,6 +249,11 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < 9; ++i) dma_slot(wave + 4 * i);
     if (tid < 64) reinterpret_cast<float4*>(raw + 36 * M)[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 2 * M / 4) {
+        const float4 wv = bs_ld4(window + 4 * tid);
+        reinterpret_cast<float4*>(ws)[tid] = wv;
+        reinterpret_cast<float4*>(ws + 2 * M)[tid] = make_float4(-wv.x, -wv.y, -wv.z, -wv.w);
+    }
     b3_u4 bt[3][2][16];
 #pragma unroll
     for (int p = 0; p < 3; ++p)
@@ -323,15 +309,15 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
         // k-block 10: the last 8 epilogue slots (120..127); then the raw audio of the next tile must have landed everywhere
 #define SLOT10(s) B3_SLOT_A(10, s)
         B3_KBLOCK(10, SLOT10)
-        // The DMA pieces were issued in slots 1 .. 1 + 8 DS; vmcnt retires in order on gfx9 (loads and stores alike), so "at most as
-        // many operations outstanding as were issued after the last piece" means every piece has landed -- without draining the
-        // codec's stores that followed it (DS = 6: the 16-byte stores of groups 3 .. 7 in slots 63, 79, .. 127), which vmcnt(0)
-        // would wait for.
+        // The DMA pieces were issued in slots 1 .. 25; vmcnt retires in order on gfx9 (loads and stores alike), so "at most as many
+        // operations outstanding as were issued after the last piece" means every piece has landed -- WITHOUT draining the
+        // codec's stores of slots 27 .. 127 (values 6 .. 31: 26 per output tensor), which vmcnt(0) would wait for (measured:
+        // +250 us per 4096 clips).  The counter saturates at 63.
         {
             constexpr int last_dma = 1 % DS + 8 * DS;                      // slot of the last piece
-            constexpr int groups_after = 8 - (last_dma < 15 ? 0 : (last_dma - 15) / 16 + 1);      // store slots 16 g + 15 behind it
-            constexpr int after = groups_after * ((SPEC ? 1 : 0) + (PAIR ? 2 : 0));
-            static_assert(DS != 6 || groups_after == 5, "count");
+            constexpr int first_after = (last_dma - 3 + 4) / 4 + ((last_dma - 3) % 4 == 0 ? 1 : 0);   // first value whose store slot 4 v + 3 lies behind it
+            constexpr int after = (32 - (first_after < 0 ? 0 : first_after)) * ((SPEC ? 1 : 0) + (PAIR ? 1 : 0));
+            static_assert(DS != 6 || after == 20 * ((SPEC ? 1 : 0) + (PAIR ? 1 : 0)), "count");
             b3_wait_vm<(after < 63 ? after : 63)>();
         }
         __syncthreads();
@@ -381,7 +367,7 @@ __global__ __launch_bounds__(B3_NT) void mdct4_b3_kernel(const float* __restrict
     }
 }
 
-constexpr size_t B3_K1_LDS = (size_t)2 * B3_ABUF + B3_RAW;
+constexpr size_t B3_K1_LDS = (size_t)4 * M * sizeof(float) + 2 * B3_ABUF + B3_RAW;
 
 // ------------------------------------------------------------------------------------------------------------------
 // K2.  grid = workers (<= 256, <= B), block = 256.  A workgroup walks whole clips b = blockIdx.x, + G, ..., each tile by tile in
@@ -407,7 +393,7 @@ __global__ __launch_bounds__(B3_NT) void imdct4_b3_kernel(const float* __restric
     const int tpc = (F + B3_ROWS - 1) / B3_ROWS, G = gridDim.x;
     const int my_clips = ((int)blockIdx.x < B) ? (B - 1 - (int)blockIdx.x) / G + 1 : 0;
     const int n_seq = my_clips * tpc;                              // this workgroup's tiles, clip by clip, frames ascending
-    const int kh = lane >> 5;
+    const int col = wave * 64 + (lane & 31), kh = lane >> 5;
     const __amdgpu_buffer_rsrc_t r_spec = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(spec), 0, (unsigned)B * (unsigned)F * M * 4u, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(audio, 0, (DBG & 1) ? 0u : (unsigned)B * (unsigned)out_len * 4u, 0x00020000);
     // the tile being prepared (decoded) as (clip, tile of the clip): advanced without divisions; behind the last clip: nx_clip >= B
@@ -572,23 +558,13 @@ __global__ __launch_bounds__(B3_NT) void imdct4_b3_kernel(const float* __restric
 #undef SLOT15
 #undef B3_SLOT_K2
         __syncthreads();                           // every wave is done with the previous v tile (and with abuf[buf])
-        {
-            // transposed accumulators: this lane holds frame lane & 31; registers 4 q .. 4 q + 3 are bins 8 q + 4 kh + (0..3) of a block
-            float* vrow = vbuf + (lane & 31) * BS_LDA + 64 * wave + 4 * kh;
-            float* hrow = halo + (i & 1) * M + 64 * wave + 4 * kh;
-            const bool last_row = (lane & 31) == B3_ROWS - 1;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v0 = make_float4(acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]);
-                const float4 v1 = make_float4(acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]);
-                *reinterpret_cast<float4*>(vrow + 8 * q) = v0;
-                *reinterpret_cast<float4*>(vrow + 32 + 8 * q) = v1;
-                if (last_row) {
-                    *reinterpret_cast<float4*>(hrow + 8 * q) = v0;
-                    *reinterpret_cast<float4*>(hrow + 32 + 8 * q) = v1;
-                }
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int row = mfma32_row(r, lane);
+            vbuf[row * BS_LDA + col] = acc0[r];
+            vbuf[row * BS_LDA + col + 32] = acc1[r];
         }
+        if (kh == 1) { halo[(i & 1) * M + col] = acc0[15]; halo[(i & 1) * M + col + 32] = acc1[15]; }      // row 31 = reg 15 of the upper half
         {
             const int pb = cur_clip;
             pf0 = cur_f0;

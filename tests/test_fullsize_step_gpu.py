@@ -297,6 +297,8 @@ def test_full_size_step_gradients(tag, fp16, feat, monkeypatch):
         if not bad:
             monkeypatch.setenv("MG_NO_WINO_ADAM_FUSION", "1")
             plain = build()
+            with torch.no_grad():          # (the same history as `model`: leg 1's forward also moved the BatchNorm running statistics)
+                plain._forward(lr_d, hr_d)
             share_spectrograms(plain)
             for _ in range(n_steps):
                 plain.optimize_parameters(lr_d, hr_d)
