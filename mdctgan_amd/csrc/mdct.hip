@@ -443,6 +443,7 @@ __global__ void stitch_kernel(const T* __restrict__ seg, int n_seg, int L, int o
 
 #include "mdct_bs.h"
 #include "mdct_b3.h"
+#include "mdct_ct.h"
 
 // frames per workgroup: a whole-clip tile (4 MFMAs per B fetch) once the launch fills the chip, 32 otherwise
 static int frames_per_wg(int B, int F) {
@@ -490,6 +491,35 @@ int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* w
     const long long n_rows = (long long)B * F;
     // round 4: the bf16 x 3 kernel (mdct_b3.h) from 512 row tiles on (two per CU: below that the 384 KB table prologue is not
     // amortised and the f32-pipe kernel with its 2-wave latency shape is faster); MG_MDCT_B3=0 / 1 overrides
+    // round 4 (second half): the factored transform (mdct_ct.h): two small dense stages on the f32 pipe instead of the 256 x 256
+    // table, two 8-wave workgroups per CU.  MG_MDCT_CT=0 / 1 overrides.
+    {
+        const long long n_tiles = (n_rows + CT_ROWS - 1) / CT_ROWS;
+        bool ct = n_tiles >= 512;
+        if (const char* e = getenv("MG_MDCT_CT")) ct = atoi(e) != 0;
+        if (ct && !legacy_forced && T % 4 == 0 && !per_sample && !frames_out && (codec == CODEC_RAW || codec == CODEC_ARCSINH) &&
+            !(codec == CODEC_RAW && in2) && n_rows * M * 8 < (1ll << 32) - (1ll << 18) && (long long)B * T * 4 < (1ll << 32) &&
+            al16(audio) && al16(window) && al16(dct4_image) && (!spec || al16(spec)) && (!in2 || al16(in2)) && (spec || in2)) {
+            const float* img = dct4_image + M * M + B3_IMG_U4 * 4;
+            const dim3 grid((unsigned)(n_tiles < 512 ? n_tiles : 512)), block(CT_NT);
+#define MG_K1_CT(MODE_, SPEC_, PAIR_, STATS_)                                                                             \
+    do {                                                                                                                   \
+        static bool attr = false;                                                                                          \
+        if (!attr) { allow_lds(mdct4_ct_kernel<MODE_, SPEC_, PAIR_, STATS_>, CT_K1_LDS); attr = true; }                    \
+        hipLaunchKernelGGL((mdct4_ct_kernel<MODE_, SPEC_, PAIR_, STATS_>), grid, block, CT_K1_LDS, st, audio, B, T, F, window, img, cp, \
+                           spec, in2, stats);                                                                              \
+    } while (0)
+#define MG_K1_CT_S(MODE_, SPEC_, PAIR_) do { if (stats) MG_K1_CT(MODE_, SPEC_, PAIR_, true); else MG_K1_CT(MODE_, SPEC_, PAIR_, false); } while (0)
+            if (codec == CODEC_RAW) MG_K1_CT(CODEC_RAW, true, false, false);
+            else if (in2 && spec) MG_K1_CT_S(CODEC_ARCSINH, true, true);
+            else if (in2) MG_K1_CT_S(CODEC_ARCSINH, false, true);
+            else MG_K1_CT_S(CODEC_ARCSINH, true, false);
+#undef MG_K1_CT_S
+#undef MG_K1_CT
+            MG_CHECK_LAUNCH();
+            return MG_OK;
+        }
+    }
     {
         const long long n_tiles = (n_rows + B3_ROWS - 1) / B3_ROWS;
         bool b3 = n_tiles >= 512;
@@ -576,7 +606,7 @@ int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* w
 
 long long mg_dct4_image_floats(int n_fft) {
     if (n_fft != 2 * M) return 0;
-    return (long long)M * M + (long long)B3_IMG_U4 * 4;          // f32 register image + three bf16 piece images
+    return (long long)M * M + (long long)B3_IMG_U4 * 4 + CT_IMG;      // f32 register image + three bf16 piece images + stage matrices
 }
 
 int mg_dct4_image(const float* dct4, float* image, void* stream) {
@@ -584,6 +614,7 @@ int mg_dct4_image(const float* dct4, float* image, void* stream) {
     hipLaunchKernelGGL(dct4_image_kernel, dim3(M * M / 4 / 256), dim3(256), 0, (hipStream_t)stream, dct4, image);
     hipLaunchKernelGGL(dct4_b3_image_kernel, dim3(4 * 2 * 16 * 64 / 256), dim3(256), 0, (hipStream_t)stream, dct4,
                        reinterpret_cast<b3_u4*>(image + M * M));
+    hipLaunchKernelGGL(dct4_ct_image_kernel, dim3(CT_IMG / 256), dim3(256), 0, (hipStream_t)stream, image + M * M + B3_IMG_U4 * 4);
     MG_CHECK_LAUNCH();
     return MG_OK;
 }
@@ -614,6 +645,25 @@ int mg_imdct4_forward(const float* spec, int B, int F, int n_fft, const float* w
     {
         static const bool bs_off = (getenv("MG_MDCT_BS") && atoi(getenv("MG_MDCT_BS")) == 0);
         auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        // round 4 (second half): the factored transform (mdct_ct.h); a workgroup walks whole clips: >= 512 clips fill two per CU
+        bool ct = B >= 512 && (long long)B * ((F + CT_ROWS - 1) / CT_ROWS) >= 1024;
+        if (const char* e = getenv("MG_MDCT_CT")) ct = atoi(e) != 0;
+        if (ct && !bs_off && dct4_image && !getenv("MG_MDCT_FT") && !frames_out && !out_f64 && out_len % 4 == 0 && al16(spec) && al16(window) &&
+            al16(dct4_image) && al16(audio) && (long long)B * F * M * 4 < (1ll << 32) && (long long)B * out_len * 4 < (1ll << 32) - (1ll << 16) &&
+            codec >= CODEC_RAW && codec <= CODEC_RANGE) {
+            const float* img = dct4_image + M * M + B3_IMG_U4 * 4;
+            const dim3 grid((unsigned)(B < 512 ? B : 512));
+#define MG_K2_CT(MODE_)                                                                                                   \
+    do {                                                                                                                   \
+        static bool attr = false;                                                                                          \
+        if (!attr) { allow_lds(imdct4_ct_kernel<MODE_>, CT_K2_LDS); attr = true; }                                         \
+        hipLaunchKernelGGL((imdct4_ct_kernel<MODE_>), grid, dim3(CT_NT), CT_K2_LDS, st, spec, B, F, window, img, cp, (float*)audio, out_len); \
+    } while (0)
+            if (codec == CODEC_RAW) MG_K2_CT(CODEC_RAW); else if (codec == CODEC_ARCSINH) MG_K2_CT(CODEC_ARCSINH); else MG_K2_CT(CODEC_RANGE);
+#undef MG_K2_CT
+            MG_CHECK_LAUNCH();
+            return MG_OK;
+        }
         // round 4: the bf16 x 3 kernel (mdct_b3.h): a workgroup walks whole clips, so it wants >= 256 clips (and >= 512 tiles)
         bool b3 = B >= 256 && (long long)B * ((F + B3_ROWS - 1) / B3_ROWS) >= 512;
         if (const char* e = getenv("MG_MDCT_B3")) b3 = atoi(e) != 0;

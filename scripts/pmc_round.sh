@@ -25,4 +25,12 @@ for spec in "configs[1] --fp16:c1h:bottleneck:--f16" "configs[2]:c2:trunk2048:" 
     w=$(pass $key WRITE_SIZE python $R/scripts/bench_conv.py --only $layer --iters 2 $flag)
     python $R/scripts/pmc_traffic.py $f $w $out/${tag}_pmc_hbm_traffic_$key.csv $R/profiles/traffic.json "$section" > /dev/null
 done
+# configs[4]: the stride-2 ladder at the inference batch (conv_fwd_dma / conv_dgrad_dma: 30 % of that step) -- time, TFLOP/s and
+# HBM bytes per launch of every rung (forward = the down rungs, data gradient = the transposed-convolution up rungs)
+export MG_BENCH_BATCH=64
+( cd $R; python scripts/bench_conv.py --only down512,down256,down128,down64 --iters 10 ) > $out/${tag}_ladder_b64_times.txt 2>/dev/null
+f=$(pass lad FETCH_SIZE python $R/scripts/bench_conv.py --only down512,down256,down128,down64 --iters 2)
+w=$(pass lad WRITE_SIZE python $R/scripts/bench_conv.py --only down512,down256,down128,down64 --iters 2)
+PMC_BY_GRID=1 python $R/scripts/pmc_traffic.py $f $w $out/${tag}_pmc_hbm_traffic_c4_ladder.csv $R/profiles/traffic.json "configs[4] ladder" > /dev/null
+unset MG_BENCH_BATCH
 cp $R/profiles/traffic.json $out/${tag}_traffic.json

@@ -16,12 +16,18 @@ def short(name):
     return name.split("(")[0].strip()
 
 
+import os
+BY_GRID = os.environ.get("PMC_BY_GRID", "0") == "1"      # one row per (kernel, grid size): the same symbol on several layer shapes
+
+
 def collect(path, counter):
     acc, n = defaultdict(float), defaultdict(int)
     for r in csv.DictReader(open(path)):
         if r.get("Counter_Name") != counter:
             continue
         k = short(r["Kernel_Name"])
+        if BY_GRID:
+            k += " @grid %s" % r.get("Grid_Size")
         acc[k] += float(r["Counter_Value"])
         n[k] += 1
     return acc, n

@@ -121,6 +121,47 @@ int main(int argc, char** argv) {
         const double dd = max_diff(y, y2, (size_t)B * T, &amax);
         printf("   waveforms: max |b3 - f32 pipe| = %.3e, max |y| = %.3e -> %.3e relative to the maximum\n", dd, amax, dd / amax);
     }
+    printf("== factored transform (mdct_ct.h), two 8-wave workgroups per CU\n");
+    {
+        const float* imgc = dimg + 256 * 256 + B3_IMG_U4 * 4;
+        const dim3 gc(n_tiles < 512 ? n_tiles : 512);
+#define K1CT(MODE_, SPEC_, PAIR_, cp_, out_, name)                                                                        \
+    {                                                                                                                       \
+        auto k = mdct4_ct_kernel<MODE_, SPEC_, PAIR_, false>;                                                               \
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT_K1_LDS);                    \
+        report(name, time_ms([&] { hipLaunchKernelGGL(k, gc, dim3(512), CT_K1_LDS, 0, x, B, T, F, w, imgc, cp_, out_, in2, (double*)nullptr); }, iters)); \
+    }
+        {
+            auto kb = mdct4_bs_kernel<8, CODEC_RAW, false, false, 0>;
+            hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BS_K1_LDS);
+            hipLaunchKernelGGL(kb, dim3(grid.x, 1), dim3(512), BS_K1_LDS, 0, x, B, T, F, w, dimg, cpr, spec, (float*)nullptr, (double*)nullptr);
+        }
+        K1CT(CODEC_RAW, true, false, cpr, spec2, "K1 ct RAW");
+        double amax;
+        double dd = max_diff(spec2, spec, (size_t)B * F * 256, &amax);
+        printf("   RAW spectra: max |ct - f32 pipe| = %.3e, max |X| = %.3e -> %.3e relative to the maximum\n", dd, amax, dd / amax);
+        K1CT(CODEC_ARCSINH, true, false, cp, spec2, "K1 ct arcsinh, spectrogram only (product)");
+        K1CT(CODEC_ARCSINH, false, true, cp, spec2, "K1 ct arcsinh, pair only");
+        K1CT(CODEC_ARCSINH, true, true, cp, spec2, "K1 ct arcsinh, spectrogram + pair");
+        // K2
+        mg_mdct4_forward(x, B, T, 512, w, d, dimg, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, 0, spec, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        auto kc = imdct4_ct_kernel<CODEC_ARCSINH>;
+        hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT_K2_LDS);
+        const dim3 g2c(B < 512 ? B : 512);
+        hipMemsetAsync(y, 0, (size_t)B * T * 4, 0);
+        report("K2 ct arcsinh (product)", time_ms([&] { hipLaunchKernelGGL(kc, g2c, dim3(512), CT_K2_LDS, 0, spec, B, F, w, imgc, cp, y, T); }, iters));
+        auto kcr = imdct4_ct_kernel<CODEC_RAW>;
+        hipFuncSetAttribute((const void*)kcr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT_K2_LDS);
+        report("K2 ct RAW", time_ms([&] { hipLaunchKernelGGL(kcr, g2c, dim3(512), CT_K2_LDS, 0, spec, B, F, w, imgc, cpr, y2, T); }, iters));
+        auto kb2 = imdct4_bs_kernel<CODEC_ARCSINH>;
+        hipFuncSetAttribute((const void*)kb2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BS_K2_LDS);
+        const int nt2 = B * ((F + 31) / 32);
+        hipLaunchKernelGGL(kb2, dim3(nt2 < 256 ? nt2 : 256), dim3(512), BS_K2_LDS, 0, spec, B, F, w, dimg, cp, y2, T);
+        dd = max_diff(y, y2, (size_t)B * T, &amax);
+        printf("   waveforms: max |ct - f32 pipe| = %.3e, max |y| = %.3e -> %.3e relative to the maximum\n", dd, amax, dd / amax);
+        dd = max_diff(y, x, (size_t)B * T, &amax);
+        printf("   round trip ct K1 (default dispatch) -> ct K2 vs input: %.3e (max |x| %.3e)\n", dd, amax);
+    }
     printf("== through the C ABI\n");
     report("mg_mdct4_forward arcsinh", time_ms([&] { mg_mdct4_forward(x, B, T, 512, w, d, dimg, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, 0, spec, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr); }, iters));
     report("mg_imdct4_forward arcsinh", time_ms([&] { mg_imdct4_forward(spec, B, F, 512, w, d, dimg, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, nullptr, nullptr, y, T, 0, nullptr, nullptr); }, iters));

@@ -327,3 +327,62 @@ def test_table_stationary_k1_writes_nothing_outside_its_outputs(mods):
     # (two float32 evaluations of arcsinh(1000 X): bins next to zero differ by a few 1e-5 of the [-1, 1] range; the bar vs the
     # reference is 5e-4)
     assert rc == 0 and (spec1 - spec).abs().max().item() <= 2e-4
+
+
+@pytest.mark.parametrize("family", ["b3", "ct"])
+@pytest.mark.parametrize("shape", [(5, 32512), (3, 32512 + 76), (64, 32512), (2, 7936)],
+                         ids=["5x128fr", "3x129fr_ragged", "64x128fr", "2x32fr"])
+def test_large_batch_kernels_against_oracle(mods, golden, family, shape, monkeypatch):
+    """The kernels the dispatcher only picks from 512 row tiles on -- csrc/mdct_b3.h (the DCT-IV as exact three-piece bf16 products,
+    table in 384 registers) and csrc/mdct_ct.h (the DCT-IV factored into 8- and 16-point DFT stages on the f32 pipe) -- FORCED on
+    test-sized batches (MG_MDCT_B3 / MG_MDCT_CT = 1) and held to the same bars as every other K1 / K2 against the float64
+    oracle: raw coefficients 2e-6 * max|X|, normalised spectrogram 5e-4, pair channel 0 == spectrogram and channel 1 = 2|v| - 1,
+    statistics, waveform 2e-6 * max|y|, K2(K1(x)) == x; clips of 129 frames: row tiles straddle clips in K1 and the last
+    tile of a clip is ragged in K2.  Plus the golden fixture G2 / G3 through the same kernels."""
+    from mdctgan_amd import _lib
+    from mdctgan_amd.mdct import dct4_table, imdct4_codec, mdct4_codec
+    _, _, w = mods
+    monkeypatch.setenv("MG_MDCT_B3", "1" if family == "b3" else "0")
+    monkeypatch.setenv("MG_MDCT_CT", "1" if family == "ct" else "0")
+    B, T = shape
+    gen = torch.Generator().manual_seed(B * 1000 + T + 7)
+    x = (0.05 * torch.randn(B, T, generator=gen)).to(DEV)
+    win, d4 = torch.from_numpy(w).to(DEV), dct4_table(256, DEV)
+    kw = dict(codec=_lib.MG_CODEC_ARCSINH, gain=1000.0, norm_range=(-1.0, 1.0), src_range=(-5.0, 5.0))
+    raw = mdct4_codec(x, win, d4, 512)["spec"]
+    r = mdct4_codec(x, win, d4, 512, want_pair=True, want_stats=True, **kw)
+    r1 = mdct4_codec(x, win, d4, 512, want_stats=True, **kw)                 # spectrogram only
+    want_raw, _ = transform.mdct4(x.cpu().numpy(), w, 512, 256)
+    scale = np.abs(want_raw).max()
+    assert np.abs(raw.cpu().numpy() - want_raw).max() <= 2e-6 * scale
+    want, _ = transform.to_spectro(x.cpu().numpy(), w, 512, 256, arcsinh_transform=True, raw_mdct=False, arcsinh_gain=1000.0,
+                                   abs_norm=True, src_range=(-5.0, 5.0), norm_range=(-1.0, 1.0))
+    s_pair, s_only = r["spec"].cpu().numpy(), r1["spec"].cpu().numpy()
+    assert np.abs(s_only - want[:, 0]).max() <= 5e-4 and np.array_equal(s_pair, s_only)
+    pair = r["pair"].cpu().numpy()
+    np.testing.assert_array_equal(pair[..., 0], s_only)
+    np.testing.assert_allclose(pair[..., 1], np.abs(s_only) * 2 - 1, atol=1e-7)
+    l64 = np.arcsinh(1000.0 * want_raw) / np.log(10.0)
+    st = r1["stats"].cpu().numpy()
+    assert abs(st[0] - l64.sum()) <= 1e-5 * np.abs(l64).sum() and abs(st[1] - (l64 ** 2).sum()) <= 1e-5 * (l64 ** 2).sum()
+    assert torch.equal(r["stats"], r1["stats"])
+    # K2 on the float64-exact coefficients / spectrogram
+    yraw, _ = imdct4_codec(raw, win, d4, 512)
+    want_y, _ = transform.imdct4(raw.double().cpu().numpy(), w, 512, 256)
+    want_y = want_y.reshape(B, -1)
+    got_y = yraw.reshape(B, -1).cpu().numpy()
+    assert got_y.shape == want_y.shape and np.abs(got_y - want_y).max() <= 2e-6 * np.abs(want_y).max() + 1e-7
+    assert (yraw.reshape(B, -1)[:, :T] - x[:, :got_y.shape[1]]).abs().max().item() <= 5e-6 * max(1.0, x.abs().max().item())
+    y, _ = imdct4_codec(r1["spec"], win, d4, 512, **kw)
+    want_a = transform.to_audio(r1["spec"][:, None].cpu().numpy(), {"min": np.float64(-5.0), "max": np.float64(5.0)}, w, 512, 256,
+                                arcsinh_transform=True, raw_mdct=False, arcsinh_gain=1000.0, abs_norm=True, src_range=(-5.0, 5.0),
+                                norm_range=(-1.0, 1.0))
+    want_a = np.asarray(want_a).reshape(B, -1)
+    # (the float32 decode -- one fma + sinh on v_exp_f32, 3e-7 relative per coefficient -- in front of the transform)
+    assert np.abs(y.reshape(B, -1).cpu().numpy() - want_a).max() <= 2e-5 * np.abs(want_a).max() + 1e-7
+    # the golden fixtures of the reference through the forced kernels
+    g2, g3 = golden("g2_mdct4"), golden("g3_imdct4")
+    X = mdct4_codec(torch.from_numpy(g2["x"]).to(DEV), win, d4, 512)["spec"]
+    assert np.abs(X.cpu().numpy() - g2["X"]).max() <= 2e-6 * np.abs(g2["X"]).max()
+    yg, _ = imdct4_codec(torch.from_numpy(g3["Xr"]).float().to(DEV), win, d4, 512)
+    assert np.abs(yg.cpu().numpy() - g3["yr"].reshape(yg.shape)).max() <= 2e-6 * np.abs(g3["yr"]).max() + 1e-7
