@@ -87,6 +87,27 @@ int mg_imdct4_forward(const float* spec, int B, int F, int n_fft, const float* w
                       const float* min_b, const float* max_b, void* audio, int out_len, int out_f64,
                       float* frames_out, void* stream);
 
+/* K2 + generate_audio.py:40-53 in ONE kernel: IMDCT4.forward whose overlap-add store writes straight into the stitched waveform,
+ *     replacing `audio.append(sr_audio)` (generate_audio.py:37), the two `*= 0.5`, F.fold and the final crop (generate_audio.py:
+ *     43-50) -- and torch.cat(...).view(1, -1) (generate_audio.py:52) when gen_overlap == 0.
+ *   spec [B, F, 256] are segments first_seg .. first_seg + B - 1 of a signal cut into segments of seg_len samples at stride
+ *   seg_len - overlap (data/audio_dataset.py:153-167 seg_pad_audio); out is the WHOLE stitched waveform, out_total =
+ *   mg_stitch_length(n_seg, seg_len, overlap) samples.  Sample t of segment s lands at s * (seg_len - overlap) - overlap + t
+ *   (positions outside [0, out_total) are the reference's crop); the first / last `overlap` samples of every segment are halved
+ *   and added to the neighbour's (two-term float sums: order-free, equal to F.fold's bit for bit), the rest is stored.  So with
+ *   overlap > 0 the waveform must be zero before the first batch writes: zero_out != 0 makes this call clear it first
+ *   (a memset node in front of the kernel: pass it for the batch with first_seg == 0).  Batches may arrive in any order.
+ *   float32 output (float64 when out_f64 -- generic kernel); seg_len <= (F-1)*256.  Same codec arguments as mg_imdct4_forward.
+ */
+int mg_imdct4_stitched(const float* spec, int B, int F, int n_fft, const float* window, const float* dct4,
+                       const float* dct4_image, int codec, float gain, float nr0, float nr1, float src_min, float src_max,
+                       const float* min_b, const float* max_b, void* out, long long out_total, int seg_len, int overlap,
+                       long long first_seg, int zero_out, int out_f64, void* stream);
+
+/* Which kernel the last mg_mdct4_forward (which == 0) / mg_imdct4_forward / mg_imdct4_stitched (which == 1) call of this process
+ * launched -- a static string ("mdct4_ct_kernel (csrc/mdct_ct.h)", ...).  Diagnostic: bench.py names the measured kernel with it. */
+const char* mg_mdct_last_kernel(int which);
+
 /* F1  torchaudio.functional.resample(waveform, orig_freq, new_freq) with its defaults (sinc_interp_hann,
  * lowpass_filter_width 6, rolloff 0.99) as the reference's data path calls it (data/audio_dataset.py:66-71, 171-177):
  * x [B, L] -> out [B, mg_resample_length(L, orig, new)], orig / new the gcd-reduced rates.  kern [new, 2*width + orig]

@@ -63,6 +63,8 @@ SIGNATURES = {
     "mg_dct4_image": (_i, [_p, _p, _p]),
     "mg_dct4_image_floats": (_ll, [_i]),
     "mg_imdct4_forward": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _f, _f, _f, _f, _f, _p, _p, _p, _i, _i, _p, _p]),
+    "mg_imdct4_stitched": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _f, _f, _f, _f, _f, _p, _p, _p, _ll, _i, _i, _ll, _i, _i, _p]),
+    "mg_mdct_last_kernel": (C.c_char_p, [_i]),
     "mg_conv_fwd": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p]),
     "mg_conv_fwd_workspace": (_sz, [_G]),
     "mg_conv_wino_weights_bytes": (_sz, [_G]),

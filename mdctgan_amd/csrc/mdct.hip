@@ -36,6 +36,10 @@ struct CodecParams {
     int per_sample;
 };
 
+// K2 writing into ONE stitched waveform (generate_audio.py:40-53): segment index of clip 0 times pitch minus overlap, samples of
+// the waveform, pitch = segment length - overlap, overlap.  pitch == 0: the plain [B, out_len] output.
+struct StitchArgs { long long base, total; int pitch, overlap; };
+
 constexpr float LN10F = 2.3025851249694824f;   // float32(log(10)), as torch.log(torch.tensor(10.0))
 
 __device__ __forceinline__ float decode(float v, const CodecParams& c, float mn, float mx) {
@@ -316,7 +320,7 @@ __global__ void fill_u32_pairs(unsigned* p, int n_pairs) {
 template <typename OutT, int FT>
 __global__ __launch_bounds__(256) void imdct4_kernel(
     const float* __restrict__ spec, int F, const float* __restrict__ window, const float* __restrict__ dct4,
-    CodecParams cp, OutT* __restrict__ audio, int out_len, float* __restrict__ frames_out) {
+    CodecParams cp, OutT* __restrict__ audio, int out_len, float* __restrict__ frames_out, StitchArgs sa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* as = smem;                     // [(FT + 1)][LDA]: rows 0..FT-1 = frames f0.., row FT = halo frame f0-1
     float* ws = as + (FT + 1) * LDA;      // [2 * M]
@@ -393,7 +397,14 @@ __global__ __launch_bounds__(256) void imdct4_kernel(
         const float yc = (n < Q) ? vc[Q + n] : -vc[3 * Q - 1 - n];     // y_h[n]
         const float yp = (n < Q) ? -vp[Q - 1 - n] : -vp[n - Q];        // y_{h-1}[n + M]
         const int t = (h - 1) * M + n;
-        if (t < out_len) audio[(size_t)b * out_len + t] = (OutT)(scale * (ws[n] * yc + ws[n + M] * yp));
+        if (t >= out_len) continue;
+        const OutT o = (OutT)(scale * (ws[n] * yc + ws[n + M] * yp));
+        if (sa.pitch == 0) { audio[(size_t)b * out_len + t] = o; continue; }
+        // the stitched waveform (see imdct4_ct_kernel): halved and added inside the cross-fade zones, stored elsewhere
+        const long long gi = sa.base + (long long)b * sa.pitch + t;
+        if (gi < 0 || gi >= sa.total) continue;
+        if (t < sa.overlap || t >= out_len - sa.overlap) unsafeAtomicAdd(audio + gi, (OutT)0.5 * o);
+        else audio[gi] = o;
     }
     if (frames_out) {   // windowed synthesis frames [B, F, 2M] (return_frames=True), mdct.py:473-475
         for (int i = tid; i < FT * 2 * M; i += 256) {
@@ -451,6 +462,8 @@ static int frames_per_wg(int B, int F) {
     (void)B; (void)F;
     return 32;      // measured on MI355X at 4096 clips: K1 1.99 / 1.87 / 2.95 ms and K2 1.19 / 1.54 / 2.49 ms for 32 / 64 / 128
 }
+// which kernel the last mg_mdct4_forward [0] / mg_imdct4_* [1] call launched (mg_mdct_last_kernel: bench.py names it in `roofline`)
+static const char* g_last_kernel[2] = {"", ""};
 template <typename K>
 static void allow_lds(K kernel, size_t lds) {
     hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -495,7 +508,7 @@ int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* w
     // table, two 8-wave workgroups per CU.  MG_MDCT_CT=0 / 1 overrides.
     {
         const long long n_tiles = (n_rows + CT_ROWS - 1) / CT_ROWS;
-        bool ct = n_tiles >= 512;
+        bool ct = true;       // measured faster than the f32-pipe / bf16 x 3 kernels at every size: 6.5 vs 12.2 us at 8 clips, 7.9 vs 16.3 at 64, 260 vs 446 at 4096
         if (const char* e = getenv("MG_MDCT_CT")) ct = atoi(e) != 0;
         if (ct && !legacy_forced && T % 4 == 0 && !per_sample && !frames_out && (codec == CODEC_RAW || codec == CODEC_ARCSINH) &&
             !(codec == CODEC_RAW && in2) && n_rows * M * 8 < (1ll << 32) - (1ll << 18) && (long long)B * T * 4 < (1ll << 32) &&
@@ -517,6 +530,7 @@ int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* w
 #undef MG_K1_CT_S
 #undef MG_K1_CT
             MG_CHECK_LAUNCH();
+            g_last_kernel[0] = "mdct4_ct_kernel (csrc/mdct_ct.h)";
             return MG_OK;
         }
     }
@@ -544,6 +558,7 @@ int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* w
 #undef MG_K1_B3_S
 #undef MG_K1_B3
             MG_CHECK_LAUNCH();
+            g_last_kernel[0] = "mdct4_b3_kernel (csrc/mdct_b3.h)";
             return MG_OK;
         }
     }
@@ -568,6 +583,7 @@ int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* w
 #undef MG_K1_BS_S
 #undef MG_K1_BS
         MG_CHECK_LAUNCH();
+        g_last_kernel[0] = "mdct4_bs_kernel (csrc/mdct_bs.h)";
         return MG_OK;
     }
     if (!spec) return MG_ERR_ARG;          // (only the table-stationary kernels write the pair alone)
@@ -583,6 +599,7 @@ int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* w
         hipLaunchKernelGGL(mdct4_gemm_kernel, dim3((unsigned)(row_tiles * 2)), dim3(256), lds, st, audio, B, T, F, window,
                            dct4, cp, spec, in2, stats);
         MG_CHECK_LAUNCH();
+        g_last_kernel[0] = "mdct4_gemm_kernel (csrc/mdct.hip)";
         return MG_OK;
     }
     const int ft = frames_per_wg(B, F);
@@ -596,6 +613,7 @@ int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* w
         hipLaunchKernelGGL(mdct4_kernel<32>, dim3((F + 31) / 32, B), dim3(256), (32 * LDA + 2 * M) * sizeof(float), st,
                            audio, T, F, window, dct4, cp, spec, in2, frames_out, per_sample, scratch_u32, stats);
     MG_CHECK_LAUNCH();
+    g_last_kernel[0] = "mdct4_kernel (csrc/mdct.hip)";
     if (per_sample) {
         hipLaunchKernelGGL(range_norm_kernel, dim3(64, B), dim3(256), 0, st, spec, in2, F * M, scratch_u32, nr0,
                            nr1, min_out, max_out);
@@ -625,10 +643,10 @@ int mg_mdct4_num_frames(int T, int n_fft) {
     return (T + pad_tail) / m + 1;
 }
 
-int mg_imdct4_forward(const float* spec, int B, int F, int n_fft, const float* window, const float* dct4,
-                      const float* dct4_image, int codec, float gain, float nr0, float nr1, float src_min, float src_max,
-                      const float* min_b, const float* max_b, void* audio, int out_len, int out_f64,
-                      float* frames_out, void* stream) {
+static int imdct4_dispatch(const float* spec, int B, int F, int n_fft, const float* window, const float* dct4,
+                           const float* dct4_image, int codec, float gain, float nr0, float nr1, float src_min, float src_max,
+                           const float* min_b, const float* max_b, void* audio, int out_len, int out_f64,
+                           float* frames_out, StitchArgs sa, void* stream) {
     if (!spec || !window || !dct4 || !audio || B <= 0 || F <= 0) return MG_ERR_ARG;
     if (n_fft != 2 * M) return MG_ERR_UNSUPPORTED;
     if (out_len <= 0 || out_len > (F - 1) * M) return MG_ERR_ARG;
@@ -646,28 +664,36 @@ int mg_imdct4_forward(const float* spec, int B, int F, int n_fft, const float* w
         static const bool bs_off = (getenv("MG_MDCT_BS") && atoi(getenv("MG_MDCT_BS")) == 0);
         auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
         // round 4 (second half): the factored transform (mdct_ct.h); a workgroup walks whole clips: >= 512 clips fill two per CU
-        bool ct = B >= 512 && (long long)B * ((F + CT_ROWS - 1) / CT_ROWS) >= 1024;
-        if (const char* e = getenv("MG_MDCT_CT")) ct = atoi(e) != 0;
-        if (ct && !bs_off && dct4_image && !getenv("MG_MDCT_FT") && !frames_out && !out_f64 && out_len % 4 == 0 && al16(spec) && al16(window) &&
+        // Measured (scripts/ubench/mdct_b3_bench, profiles/r04_mdct_ct_ubench.log): 249 vs 442 us at 4096 clips, 18.3 vs 27.9 at 128,
+        // 17.6 vs 17.0 at 64, 16.7 vs 15.5 at 8 against the f32-pipe / bf16 x 3 kernels (a workgroup's tiles of a clip are sequential:
+        // latency, not work, below ~96 clips -- a microsecond there buys one kernel for every size, so that the stitched store,
+        // which exists in this kernel and the generic one only, gives the bits of the plain store followed by mg_stitch_segments).
+        const bool st4 = sa.pitch != 0 && sa.pitch % 4 == 0 && sa.overlap % 4 == 0 && sa.total * 4 < (1ll << 32) - (1ll << 16);
+        bool ct = true;
+        if (const char* e = getenv("MG_MDCT_CT")) ct = atoi(e) != 0 || st4;
+        if (ct && (sa.pitch == 0 || st4) && !bs_off && dct4_image && !getenv("MG_MDCT_FT") && !frames_out && !out_f64 && out_len % 4 == 0 && al16(spec) && al16(window) &&
             al16(dct4_image) && al16(audio) && (long long)B * F * M * 4 < (1ll << 32) && (long long)B * out_len * 4 < (1ll << 32) - (1ll << 16) &&
             codec >= CODEC_RAW && codec <= CODEC_RANGE) {
             const float* img = dct4_image + M * M + B3_IMG_U4 * 4;
             const dim3 grid((unsigned)(B < 512 ? B : 512));
-#define MG_K2_CT(MODE_)                                                                                                   \
+#define MG_K2_CT(MODE_, ST_)                                                                                              \
     do {                                                                                                                   \
         static bool attr = false;                                                                                          \
-        if (!attr) { allow_lds(imdct4_ct_kernel<MODE_>, CT_K2_LDS); attr = true; }                                         \
-        hipLaunchKernelGGL((imdct4_ct_kernel<MODE_>), grid, dim3(CT_NT), CT_K2_LDS, st, spec, B, F, window, img, cp, (float*)audio, out_len); \
+        if (!attr) { allow_lds(imdct4_ct_kernel<MODE_, ST_>, CT_K2_LDS); attr = true; }                                    \
+        hipLaunchKernelGGL((imdct4_ct_kernel<MODE_, ST_>), grid, dim3(CT_NT), CT_K2_LDS, st, spec, B, F, window, img, cp, (float*)audio, out_len, sa); \
     } while (0)
-            if (codec == CODEC_RAW) MG_K2_CT(CODEC_RAW); else if (codec == CODEC_ARCSINH) MG_K2_CT(CODEC_ARCSINH); else MG_K2_CT(CODEC_RANGE);
+#define MG_K2_CT_S(MODE_) do { if (st4) MG_K2_CT(MODE_, true); else MG_K2_CT(MODE_, false); } while (0)
+            if (codec == CODEC_RAW) MG_K2_CT_S(CODEC_RAW); else if (codec == CODEC_ARCSINH) MG_K2_CT_S(CODEC_ARCSINH); else MG_K2_CT_S(CODEC_RANGE);
+#undef MG_K2_CT_S
 #undef MG_K2_CT
             MG_CHECK_LAUNCH();
+            g_last_kernel[1] = st4 ? "imdct4_ct_kernel<stitched> (csrc/mdct_ct.h)" : "imdct4_ct_kernel (csrc/mdct_ct.h)";
             return MG_OK;
         }
         // round 4: the bf16 x 3 kernel (mdct_b3.h): a workgroup walks whole clips, so it wants >= 256 clips (and >= 512 tiles)
         bool b3 = B >= 256 && (long long)B * ((F + B3_ROWS - 1) / B3_ROWS) >= 512;
         if (const char* e = getenv("MG_MDCT_B3")) b3 = atoi(e) != 0;
-        if (b3 && !bs_off && dct4_image && !getenv("MG_MDCT_FT") && !frames_out && !out_f64 && out_len % 4 == 0 && al16(spec) && al16(window) &&
+        if (b3 && sa.pitch == 0 && !bs_off && dct4_image && !getenv("MG_MDCT_FT") && !frames_out && !out_f64 && out_len % 4 == 0 && al16(spec) && al16(window) &&
             al16(dct4_image) && al16(audio) && (long long)B * F * M * 4 < (1ll << 32) && (long long)B * out_len * 4 < (1ll << 32) - (1ll << 16) &&
             codec >= CODEC_RAW && codec <= CODEC_RANGE) {
             const b3_u4* img = reinterpret_cast<const b3_u4*>(dct4_image + M * M);
@@ -681,9 +707,10 @@ int mg_imdct4_forward(const float* spec, int B, int F, int n_fft, const float* w
             if (codec == CODEC_RAW) MG_K2_B3(CODEC_RAW); else if (codec == CODEC_ARCSINH) MG_K2_B3(CODEC_ARCSINH); else MG_K2_B3(CODEC_RANGE);
 #undef MG_K2_B3
             MG_CHECK_LAUNCH();
+            g_last_kernel[1] = "imdct4_b3_kernel (csrc/mdct_b3.h)";
             return MG_OK;
         }
-        if (!bs_off && dct4_image && !getenv("MG_MDCT_FT") && !frames_out && !out_f64 && out_len % 4 == 0 && al16(spec) && al16(window) && al16(dct4_image) &&
+        if (sa.pitch == 0 && !bs_off && dct4_image && !getenv("MG_MDCT_FT") && !frames_out && !out_f64 && out_len % 4 == 0 && al16(spec) && al16(window) && al16(dct4_image) &&
             al16(audio) && (long long)B * F * M * 4 < (1ll << 32) && (long long)B * out_len * 4 < (1ll << 32) - (1ll << 16) &&
             codec >= CODEC_RAW && codec <= CODEC_RANGE) {
             const long long n_tiles = (long long)B * ((F + BS_ROWS - 1) / BS_ROWS);
@@ -697,13 +724,14 @@ int mg_imdct4_forward(const float* spec, int B, int F, int n_fft, const float* w
             if (codec == CODEC_RAW) MG_K2_BS(CODEC_RAW); else if (codec == CODEC_ARCSINH) MG_K2_BS(CODEC_ARCSINH); else MG_K2_BS(CODEC_RANGE);
 #undef MG_K2_BS
             MG_CHECK_LAUNCH();
+            g_last_kernel[1] = "imdct4_bs_kernel (csrc/mdct_bs.h)";
             return MG_OK;
         }
     }
 #define MG_IMDCT(T_, FT_)                                                                                            \
     hipLaunchKernelGGL((imdct4_kernel<T_, FT_>), dim3((F + FT_ - 1) / FT_, B), dim3(256),                            \
                        ((FT_ + 1) * LDA + 2 * M) * sizeof(float), st, spec, F, window, dct4, cp, (T_*)audio, out_len, \
-                       frames_out)
+                       frames_out, sa)
     const int ft = frames_per_wg(B, F);
     if (ft == 128) {
         if (out_f64) MG_IMDCT(double, 128); else MG_IMDCT(float, 128);
@@ -714,8 +742,31 @@ int mg_imdct4_forward(const float* spec, int B, int F, int n_fft, const float* w
     }
 #undef MG_IMDCT
     MG_CHECK_LAUNCH();
+    g_last_kernel[1] = "imdct4_kernel (csrc/mdct.hip)";
     return MG_OK;
 }
+
+int mg_imdct4_forward(const float* spec, int B, int F, int n_fft, const float* window, const float* dct4,
+                      const float* dct4_image, int codec, float gain, float nr0, float nr1, float src_min, float src_max,
+                      const float* min_b, const float* max_b, void* audio, int out_len, int out_f64,
+                      float* frames_out, void* stream) {
+    return imdct4_dispatch(spec, B, F, n_fft, window, dct4, dct4_image, codec, gain, nr0, nr1, src_min, src_max, min_b, max_b, audio,
+                           out_len, out_f64, frames_out, StitchArgs{0, 0, 0, 0}, stream);
+}
+
+// See include/mdctgan_hip.h: K2 with generate_audio.py:40-53 folded into its overlap-add store.
+int mg_imdct4_stitched(const float* spec, int B, int F, int n_fft, const float* window, const float* dct4,
+                       const float* dct4_image, int codec, float gain, float nr0, float nr1, float src_min, float src_max,
+                       const float* min_b, const float* max_b, void* out, long long out_total, int seg_len, int overlap,
+                       long long first_seg, int zero_out, int out_f64, void* stream) {
+    if (!out || seg_len <= 0 || overlap < 0 || 2 * overlap >= seg_len || first_seg < 0 || out_total <= 0) return MG_ERR_ARG;
+    if (zero_out && overlap > 0) hipMemsetAsync(out, 0, (size_t)out_total * (out_f64 ? 8 : 4), (hipStream_t)stream);
+    const int pitch = seg_len - overlap;
+    return imdct4_dispatch(spec, B, F, n_fft, window, dct4, dct4_image, codec, gain, nr0, nr1, src_min, src_max, min_b, max_b, out,
+                           seg_len, out_f64, nullptr, StitchArgs{first_seg * pitch - overlap, out_total, pitch, overlap}, stream);
+}
+
+const char* mg_mdct_last_kernel(int which) { return g_last_kernel[which == 1 ? 1 : 0]; }
 
 long long mg_stitch_length(int n_seg, int seg_len, int overlap) {
     if (n_seg <= 0 || seg_len <= 0 || overlap < 0 || 2 * overlap >= seg_len) return -1;

@@ -247,10 +247,16 @@ constexpr size_t CT_K1_LDS = (size_t)(CT_U1 + CT_YB) * sizeof(float);
 // K2.  grid = workers (<= 512, <= B), block = 512.  A workgroup walks whole clips, tile by tile in frame order: the frame in front
 // of a tile is row 31 of the tile before (2-slot LDS ring).
 // ------------------------------------------------------------------------------------------------------------------
-template <int MODE>
+//
+// ST (generate_audio.py:40-53 folded into the overlap-add store): clip c is segment sa.first + c of ONE stitched waveform of
+// sa.total samples; its sample t lands at (sa.first + c) * sa.pitch - sa.overlap + t (pitch = segment length - overlap; positions
+// outside [0, total) are the reference's final crop).  The first and last `overlap` samples of every segment are halved and ADDED
+// (global_atomic_add_f32 into a waveform the caller zeroed: at most two segments meet in a sample and a two-term float sum does
+// not depend on the order, so the result equals F.fold's bit for bit); everything else is a plain 16-byte store.  (StitchArgs: mdct.hip)
+template <int MODE, bool ST = false>
 __global__ __launch_bounds__(CT_NT, 4) void imdct4_ct_kernel(const float* __restrict__ spec, int B, int F,
                                                              const float* __restrict__ window, const float* __restrict__ img,
-                                                             CodecParams cp, float* __restrict__ audio, int out_len) {
+                                                             CodecParams cp, float* __restrict__ audio, int out_len, StitchArgs sa) {
     constexpr int Q = M / 2;
     extern __shared__ __attribute__((aligned(16))) float ct_smem[];
     float* U1 = ct_smem;
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(CT_NT, 4) void imdct4_ct_kernel(const float* __rest
     const int my_clips = ((int)blockIdx.x < B) ? (B - 1 - (int)blockIdx.x) / G + 1 : 0;
     const int n_seq = my_clips * tpc;
     const __amdgpu_buffer_rsrc_t r_spec = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(spec), 0, (unsigned)B * (unsigned)F * M * 4u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(audio, 0, (unsigned)B * (unsigned)out_len * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(audio, 0, ST ? (unsigned)sa.total * 4u : (unsigned)B * (unsigned)out_len * 4u, 0x00020000);
 
     float ma[2][4], mb[16];
     ct_load_matrices(img, ma, mb, wave, lane);
@@ -332,8 +338,24 @@ __global__ __launch_bounds__(CT_NT, 4) void imdct4_ct_kernel(const float* __rest
                                          scale * (uw0.z * yc.z + uw1.z * yp.z), scale * (uw0.w * yc.w + uw1.w * yp.w));
             const int hh = f0 + fr, t0 = (hh - 1) * M + n;                   // out_len % 4 == 0: a float4 is inside or outside the crop as a whole
             const bool ok = hh >= 1 && hh <= F - 1 && t0 + 3 < out_len;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bs_v4u, o), r_out,
-                                                   ok ? ((unsigned)clip * (unsigned)out_len + (unsigned)t0) * 4u : BS_OOB, 0, 0);
+            if (!ST) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bs_v4u, o), r_out,
+                                                       ok ? ((unsigned)clip * (unsigned)out_len + (unsigned)t0) * 4u : BS_OOB, 0, 0);
+            } else {
+                // pitch, overlap, out_len % 4 == 0: a float4 is inside or outside a cross-fade zone / the final crop as a whole
+                const long long gi = sa.base + (long long)clip * sa.pitch + t0;
+                const bool in = ok && gi >= 0 && gi + 3 < sa.total;
+                const bool zone = t0 < sa.overlap || t0 >= out_len - sa.overlap;
+                if (zone) {
+                    if (in) {
+                        float* dst = audio + gi;
+                        unsafeAtomicAdd(dst, 0.5f * o.x); unsafeAtomicAdd(dst + 1, 0.5f * o.y);
+                        unsafeAtomicAdd(dst + 2, 0.5f * o.z); unsafeAtomicAdd(dst + 3, 0.5f * o.w);
+                    }
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bs_v4u, o), r_out, in ? (unsigned)gi * 4u : BS_OOB, 0, 0);
+                }
+            }
         }
         __syncthreads();
     }

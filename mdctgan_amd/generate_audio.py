@@ -1,14 +1,19 @@
 """Whole-utterance inference: the device-side part of generate_audio.py:22-53.
 
 The reference script walks the dataset loader, calls ``model.inference`` per batch, copies every ``sr_audio`` to the
-host and concatenates (or cross-fades with ``F.fold`` when ``--gen_overlap > 0``).  Here the segments stay in HBM:
-batches of low-rate segments go through ``model.inference`` and one gather kernel (``mg_stitch_segments``) writes the
-waveform.  Dataset loading, resampling and the metrics of ``util.compute_matrics`` are outside the hot path.
+host and concatenates (or cross-fades with ``F.fold`` when ``--gen_overlap > 0``).  Here the waveform is built in HBM by
+the decoder itself: batches of low-rate segments go through ``model.inference`` and K2's overlap-add store writes each
+segment at its place in the stitched waveform, cross-fade included (``mg_imdct4_stitched``); codec geometries K2 does not
+cover decode per batch and one gather kernel (``mg_stitch_segments``) stitches.  Dataset loading, resampling and the
+metrics of ``util.compute_matrics`` are outside the hot path.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
+from . import _lib
 from . import functional as Fh
 from . import ops
 
@@ -33,6 +38,19 @@ def generate(model, lr_segments: torch.Tensor, batch_size: int = 64, gen_overlap
     if lr_segments.dim() != 2:
         raise ValueError("lr_segments must be [n_seg, T]")
     outs = []
+    # The fused codec geometry: K2's overlap-add store writes every batch's segments straight into the stitched waveform
+    # (mg_imdct4_stitched: the halving, F.fold and the crop of generate_audio.py:43-50 -- or the torch.cat of :52 -- happen in
+    # the store; no list of segments, no concatenation, no stitching launch).  Other geometries decode per batch and stitch after.
+    pre = model.preprocess
+    fused = bool(getattr(pre, "fused", False)) and os.environ.get("MG_NO_STITCHED_K2") != "1"
+    out = None
+    if fused:
+        n_seg, T = lr_segments.shape
+        seg_len = (_lib.load().mg_mdct4_num_frames(T, pre.n_fft) - 1) * (pre.n_fft // 2)
+        total = _lib.load().mg_stitch_length(n_seg, seg_len, gen_overlap)
+        if total <= 0:
+            raise ValueError("invalid stitching geometry: n_seg=%d segment_length=%d gen_overlap=%d" % (n_seg, seg_len, gen_overlap))
+        out = torch.empty(total, dtype=torch.float32, device=lr_segments.device)
     # generate_audio.py:27 calls model.eval() first: the BatchNorm2d layers of the bottleneck-attention blocks must use
     # their running statistics (and must not update them) during inference
     was_training = model.training
@@ -40,17 +58,22 @@ def generate(model, lr_segments: torch.Tensor, batch_size: int = 64, gen_overlap
     try:
         with torch.no_grad():
             for i in range(0, lr_segments.shape[0], batch_size):
-                _, sr_audio, _, _, _ = model.inference(lr_segments[i:i + batch_size])
-                outs.append(sr_audio)
+                if fused:
+                    model.inference(lr_segments[i:i + batch_size], stitch=(out, gen_overlap, i))
+                else:
+                    _, sr_audio, _, _, _ = model.inference(lr_segments[i:i + batch_size])
+                    outs.append(sr_audio)
     finally:
         model.train(was_training)
+    if fused:
+        return out.view(1, -1)
     audio = torch.cat(outs, dim=0)                      # [n_seg, 1, 1, T]
     return ops.stitch_segments(audio, audio.shape[-1], gen_overlap)
 
 
 def make_graphed_generate(model, lr_segments: torch.Tensor, batch_size: int = 64, gen_overlap: int = 0, warmup: int = 2):
-    """Capture generate() for a fixed segment count into one hipGraph (K1, ~120 generator launches, K2 and the stitch
-    kernel per batch) and return run(lr_segments) -> stitched waveform (a buffer that the next replay overwrites).  The
+    """Capture generate() for a fixed segment count into one hipGraph (K1, ~120 generator launches and the stitching K2
+    per batch) and return run(lr_segments) -> stitched waveform (a buffer that the next replay overwrites).  The
     generator weights must not change between capture and replay without re-capturing: the Winograd layers read the
     transformed-weight images cached by the warm-up calls."""
     static_in = lr_segments.clone()

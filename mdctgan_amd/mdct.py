@@ -229,14 +229,31 @@ def mdct4_codec(audio, window, dct4, n_fft, *, codec=_lib.MG_CODEC_RAW, gain=1.0
 
 def imdct4_codec(spec, window, dct4, n_fft, *, codec=_lib.MG_CODEC_RAW, gain=1.0, norm_range=(0.0, 1.0),
                  src_range=(0.0, 1.0), min_b=None, max_b=None, out_length=None, out_dtype=torch.float32,
-                 want_frames=False):
-    """K2 launcher.  spec [B, F, M] (device) -> (audio [B, T_out], frames|None)."""
+                 want_frames=False, stitch=None):
+    """K2 launcher.  spec [B, F, M] (device) -> (audio [B, T_out], frames|None).
+
+    stitch = (out, gen_overlap, first_seg): the clips are segments first_seg.. of ONE waveform and K2's overlap-add store writes them
+    straight into `out` [mg_stitch_length(n_seg, T_out, gen_overlap)] with generate_audio.py:40-53's cross-fade (mg_imdct4_stitched);
+    returns (out, None).  The batch with first_seg == 0 clears `out` when gen_overlap > 0."""
     lib = _lib.load()
     spec = _lib.f32c(spec)
     B, F, M = spec.shape
     t_out = (F - 1) * M
     if out_length is not None:
         t_out = min(t_out, int(out_length))
+    if stitch is not None:
+        out, overlap, first = stitch
+        if want_frames or out.dtype != out_dtype or not out.is_contiguous():
+            raise ValueError("stitched K2: contiguous output of the requested dtype, no synthesis frames")
+        if min_b is not None:
+            min_b, max_b = _lib.f32c(min_b.reshape(-1)), _lib.f32c(max_b.reshape(-1))
+            assert min_b.numel() == B and max_b.numel() == B
+        rc = lib.mg_imdct4_stitched(_lib.ptr(spec), B, F, n_fft, _lib.ptr(window), _lib.ptr(dct4), dct4_image(dct4, M), codec, gain,
+                                    norm_range[0], norm_range[1], src_range[0], src_range[1], _lib.ptr(min_b), _lib.ptr(max_b),
+                                    _lib.ptr(out), out.numel(), t_out, int(overlap), int(first), int(first == 0),
+                                    int(out_dtype == torch.float64), _lib.stream())
+        _lib.check(rc, "mg_imdct4_stitched")
+        return out, None
     audio = torch.empty(B, t_out, dtype=out_dtype, device=spec.device)
     frames = torch.empty(B, F, n_fft, dtype=torch.float32, device=spec.device) if want_frames else None
     if min_b is not None:

@@ -173,7 +173,11 @@ class Audio2MDCT(torch.nn.Module):
             return torch.sinh(x * torch.log(torch.tensor(10.0))) / self.arcsinh_gain
         return x
 
-    def to_audio(self, log_spectro: torch.Tensor, norm_param: Dict[str, torch.Tensor], pha: torch.Tensor = None):
+    def to_audio(self, log_spectro: torch.Tensor, norm_param: Dict[str, torch.Tensor], pha: torch.Tensor = None, stitch=None):
+        """pix2pixHD_model.py:139-165.  stitch = (out, gen_overlap, first_seg) (fused geometry only): K2 writes the segments
+        straight into the stitched waveform `out` (generate_audio.py:40-53 inside the kernel) and `out` is returned."""
+        if stitch is not None and not self.fused:
+            raise NotImplementedError("stitched decode needs the fused 512 / 256 geometry")
         nr, sr = self._ranges()
         mn, mx = norm_param["min"], norm_param["max"]
         per_sample = mn.numel() > 1
@@ -184,8 +188,8 @@ class Audio2MDCT(torch.nn.Module):
             spec = log_spectro.squeeze(1) if log_spectro.dim() == 4 else log_spectro
             audio, _ = imdct4_codec(spec, window, d4, self.n_fft, codec=self.codec, gain=float(self.arcsinh_gain),
                                     norm_range=nr, src_range=sr, min_b=mn if per_sample else None,
-                                    max_b=mx if per_sample else None)
-            return audio[:, None, None, :]
+                                    max_b=mx if per_sample else None, stitch=stitch)
+            return audio if stitch is not None else audio[:, None, None, :]
         spec4 = log_spectro if log_spectro.dim() == 4 else log_spectro[:, None]
         raw = codec_inverse(spec4, codec=self.codec, gain=float(self.arcsinh_gain), alpha=float(self.alpha),
                             min_value=float(self.min_value), norm_range=nr, src_range=sr,
@@ -508,8 +512,8 @@ class Pix2PixHDModel(BaseModel):
         run.graph = graph
         return run
 
-    def inference(self, lr_audio):
-        """pix2pixHD_model.py:618-638."""
+    def inference(self, lr_audio, stitch=None):
+        """pix2pixHD_model.py:618-638.  stitch: see Audio2MDCT.to_audio (sr_audio is then the stitched waveform)."""
         self._finish_pending()
         with torch.no_grad():
             lr_spectro, lr_pha, lr_norm_param = self.preprocess.forward(lr_audio)
@@ -518,7 +522,7 @@ class Pix2PixHDModel(BaseModel):
                 lr_part = int(sr_spectro.size(-1) / self.preprocess.up_ratio)
                 sr_spectro[..., :lr_part] *= 1e-3
                 sr_spectro = Fh.add(sr_spectro, lr_spectro)
-            sr_audio = self.preprocess.to_audio(sr_spectro, lr_norm_param, lr_pha)
+            sr_audio = self.preprocess.to_audio(sr_spectro, lr_norm_param, lr_pha, stitch=stitch)
         return sr_spectro, sr_audio, lr_pha, lr_norm_param, lr_spectro
 
     # -- bookkeeping ----------------------------------------------------------------------------

@@ -149,10 +149,10 @@ int main(int argc, char** argv) {
         hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT_K2_LDS);
         const dim3 g2c(B < 512 ? B : 512);
         hipMemsetAsync(y, 0, (size_t)B * T * 4, 0);
-        report("K2 ct arcsinh (product)", time_ms([&] { hipLaunchKernelGGL(kc, g2c, dim3(512), CT_K2_LDS, 0, spec, B, F, w, imgc, cp, y, T); }, iters));
+        report("K2 ct arcsinh (product)", time_ms([&] { hipLaunchKernelGGL(kc, g2c, dim3(512), CT_K2_LDS, 0, spec, B, F, w, imgc, cp, y, T, StitchArgs{0, 0, 0, 0}); }, iters));
         auto kcr = imdct4_ct_kernel<CODEC_RAW>;
         hipFuncSetAttribute((const void*)kcr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT_K2_LDS);
-        report("K2 ct RAW", time_ms([&] { hipLaunchKernelGGL(kcr, g2c, dim3(512), CT_K2_LDS, 0, spec, B, F, w, imgc, cpr, y2, T); }, iters));
+        report("K2 ct RAW", time_ms([&] { hipLaunchKernelGGL(kcr, g2c, dim3(512), CT_K2_LDS, 0, spec, B, F, w, imgc, cpr, y2, T, StitchArgs{0, 0, 0, 0}); }, iters));
         auto kb2 = imdct4_bs_kernel<CODEC_ARCSINH>;
         hipFuncSetAttribute((const void*)kb2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BS_K2_LDS);
         const int nt2 = B * ((F + 31) / 32);

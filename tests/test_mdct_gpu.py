@@ -386,3 +386,44 @@ def test_large_batch_kernels_against_oracle(mods, golden, family, shape, monkeyp
     assert np.abs(X.cpu().numpy() - g2["X"]).max() <= 2e-6 * np.abs(g2["X"]).max()
     yg, _ = imdct4_codec(torch.from_numpy(g3["Xr"]).float().to(DEV), win, d4, 512)
     assert np.abs(yg.cpu().numpy() - g3["yr"].reshape(yg.shape)).max() <= 2e-6 * np.abs(g3["yr"]).max() + 1e-7
+
+
+@pytest.mark.parametrize("overlap", [0, 1024, 256, 100], ids=["cat", "ov1024", "ov256", "ov100_generic"])
+def test_stitched_k2_equals_decode_then_stitch(mods, golden, overlap):
+    """mg_imdct4_stitched (generate_audio.py:40-53 inside K2's overlap-add store): 7 segments decoded in batches of 3 / 3 / 1
+    -- handed over out of order -- land in ONE waveform that is bit for bit mg_stitch_segments(mg_imdct4_forward(...)), whose
+    stitching is pinned to the reference's F.fold by fixture G8; overlap 100 is not a multiple of 4 and takes the generic
+    kernel (scalar stores), float64 output included.  Then G8 itself through K1 -> stitching K2: the reference's stitched
+    waveform to the transform's round-trip accuracy."""
+    from mdctgan_amd import _lib, ops
+    from mdctgan_amd.mdct import dct4_table, imdct4_codec, mdct4_codec
+    _, _, w = mods
+    win, d4 = torch.from_numpy(w).to(DEV), dct4_table(256, DEV)
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(31 + overlap)
+    n_seg, F = 7, 128
+    spec = (2 * torch.rand(n_seg, F, 256, generator=gen) - 1).to(DEV)
+    kw = dict(codec=_lib.MG_CODEC_ARCSINH, gain=1000.0, norm_range=(-1.0, 1.0), src_range=(-5.0, 5.0))
+    for dtype in (torch.float32, torch.float64):
+        plain, _ = imdct4_codec(spec, win, d4, 512, out_dtype=dtype, **kw)
+        L = plain.shape[-1]
+        want = ops.stitch_segments(plain, L, overlap)
+        total = lib.mg_stitch_length(n_seg, L, overlap)
+        out = torch.full((total,), float("nan"), dtype=dtype, device=DEV)      # (the first batch clears it when overlap > 0)
+        for first, n in ((0, 3), (6, 1), (3, 3)):
+            imdct4_codec(spec[first:first + n], win, d4, 512, out_dtype=dtype, stitch=(out, overlap, first), **kw)
+        assert want.shape == (1, total) and torch.equal(out, want[0]), (overlap, dtype, (out - want[0]).abs().max().item())
+        name = lib.mg_mdct_last_kernel(1).decode()
+        fast = dtype == torch.float32 and overlap % 4 == 0
+        assert ("imdct4_ct_kernel<stitched>" in name) == fast and (fast or "imdct4_kernel" in name), name
+    # G8: the reference's segments -> K1 (raw coefficients) -> stitching K2 == the reference's fold-based stitching
+    g = golden("g8_stitch")
+    seg = torch.from_numpy(g["seg"]).float().reshape(3, -1).to(DEV)
+    ov = int(g["overlap"])
+    X = mdct4_codec(seg, win, d4, 512)["spec"]
+    for o, ref in ((ov, g["stitched"]), (0, g["concat"])):
+        out = torch.empty(ref.shape[-1], device=DEV)
+        imdct4_codec(X, win, d4, 512, stitch=(out, o, 0))
+        assert np.abs(out.cpu().double().numpy() - ref[0]).max() <= 5e-6 * np.abs(ref).max()
+    with pytest.raises(ValueError):
+        imdct4_codec(X, win, d4, 512, stitch=(torch.empty(100, device=DEV), seg.shape[-1] // 2, 0))
