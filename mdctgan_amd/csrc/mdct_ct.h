@@ -28,10 +28,13 @@ namespace {
 constexpr int CT_ROWS = 32;
 constexpr int CT_NT = 512;
 constexpr int CT_REC = 20;                       // floats between the n2 records of a frame (16 used: conflict-free scatter)
-constexpr int CT_FS1 = 16 * CT_REC + 4;          // floats between frames in U1 (324 = 4 mod 64: conflict-free 16-lane b128 reads)
+constexpr int CT_FS1 = 16 * CT_REC + 8;          // floats between frames in U1 (328 = 8 mod 64: conflict-free 16-lane b128 reads)
 constexpr int CT_FS2 = 36;                       // floats between frames in Yb
-constexpr int CT_KS2 = CT_ROWS * CT_FS2 + 4;     // floats between the k1 blocks of Yb
-constexpr int CT_OS = M + 4;                     // floats between rows of the output tile
+constexpr int CT_KS2 = CT_ROWS * CT_FS2;         // floats between the k1 blocks of Yb (0 mod 32: the rotation by k1 below spreads the writes)
+constexpr int CT_OS = M;                         // floats between rows of the output tile
+// LDS layouts: every access of a tile is conflict-free under CDNA4's per-instruction banking (ds_write_b32: two 32-lane groups on
+// (a / 4) mod 32; ds_read_b128: four 16-lane groups on (a / 4) mod 64) -- checked with a bank simulator that reproduced the first
+// version's SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE exactly (240 conflict cycles of 384 per wave and tile; now 0 of 144).
 constexpr int CT_U1 = CT_ROWS * CT_FS1;          // 10 368 floats
 constexpr int CT_YB = 8 * CT_KS2;                // 9 248 floats
 constexpr int CT_IMG = 512 * 24;                 // floats of the matrix image: 24 per (wave, lane)
@@ -41,8 +44,9 @@ typedef float ct_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ ct_f4 ct_mfma16(float a, float b, ct_f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // Matrix image (mg_dct4_image): img[(wave * 64 + lane) * 24 + r]
-//   r = 4 q + s  (q = 0, 1; s = 0..3):  MA_{n2 = 2 wave + q}[kk = 4 s + (lane >> 4)][j = lane & 15]      (B operand of 16x16x4 step s)
-//   r = 8 + s    (s = 0..15):           MB_{k1 = wave}[kk = 2 s + (lane >> 5)][j = lane & 31]            (B operand of 32x32x2 step s)
+//   r = 4 q + s  (q = 0, 1; s = 0..3):  MA_{n2 = 2 wave + q}[kk = 4 (lane >> 4) + s][j = lane & 15]      (B operand of 16x16x4 step s)
+//   r = 8 + s    (s = 0..15):           MB_{k1 = wave}[kk = 2 ((s - wave) & 15) + (lane >> 5)][j = lane & 31]   (B operand of 32x32x2 step s)
+// (which input an MFMA step contracts is free as long as both operands agree: the orders follow the LDS layouts below)
 // evaluated in double from integer phase numerators (exact argument reduction), rounded once to float32.
 __global__ void dct4_ct_image_kernel(float* __restrict__ img) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -50,14 +54,14 @@ __global__ void dct4_ct_image_kernel(float* __restrict__ img) {
     const int r = i % 24, lane = (i / 24) & 63, wave = i / (24 * 64);
     double v;
     if (r < 8) {
-        const int q = r >> 2, s = r & 3, n2 = 2 * wave + q, kk = 4 * s + (lane >> 4), j = lane & 15;
+        const int q = r >> 2, s = r & 3, n2 = 2 * wave + q, kk = 4 * (lane >> 4) + s, j = lane & 15;
         const int n1 = kk & 7, k1 = j & 7;
         const bool b_in = kk >= 8, im_out = j >= 8;
         const int t = (4 * n2 * k1 + 64 * n1 * k1 + 16 * n1 + n2) & 511;          // c = exp(-i pi t / 256)
         const double re = cospi(t / 256.0), im = -sinpi(t / 256.0);
         v = !im_out ? (b_in ? -im : re) : (b_in ? re : im);       // Re Y' = Re c a - Im c b;  Im Y' = Im c a + Re c b
     } else {
-        const int s = r - 8, k1 = wave, kk = 2 * s + (lane >> 5), j = lane & 31;
+        const int s = r - 8, k1 = wave, kk = 2 * ((s - wave) & 15) + (lane >> 5), j = lane & 31;
         const int n2 = kk & 15, k2 = j & 15, k = k1 + 8 * k2;
         const bool im_in = kk >= 16, odd_out = j >= 16;
         const int t = (4 * k + 1 + 128 * n2 * k2) & 2047;                          // d = exp(-i pi t / 1024)
@@ -68,18 +72,22 @@ __global__ void dct4_ct_image_kernel(float* __restrict__ img) {
 }
 
 // word offset of u[m] (m = 0..255) inside a frame's U1 block: even m = 32 n1 + 2 n2 is input a_n1 of record n2, odd m is
-// input b_n1 of the record of 255 - m
+// input b_n1 of the record of 255 - m.  Input kk of a record sits in float4 (kk >> 2) ^ (n2 >> 3), component kk & 3: the 32 lanes of
+// a fold / decode store (8 records x 4 inputs) then cover the 32 banks once.
 __device__ __forceinline__ int ct_u1_word(int m) {
     const int e = (m & 1) ? 255 - m : m;
     const int n2 = (e & 31) >> 1, kk = (e >> 5) + ((m & 1) ? 8 : 0);
-    return n2 * CT_REC + 4 * (kk & 3) + (kk >> 2);
+    return n2 * CT_REC + 4 * ((kk >> 2) ^ (n2 >> 3)) + (kk & 3);
 }
-// word offset of bin b inside a row of the output tile: float4 index swizzled by its bits 4-5 (the 16 even bins a wave writes per
-// instruction are 16 words apart: unswizzled they share four banks)
+// word offset of bin b inside a row of the output tile: float4 index swizzled by its bits 4-5, component by bit 3 (the 16 even bins
+// a wave writes per instruction are 16 words apart: unswizzled they share two banks).  A reader of float4 q4 fetches slot
+// ct_out_slot(q4) and swaps its halves when q4 & 8 (ct_out_fix).
+__device__ __forceinline__ int ct_out_slot(int q4) { return q4 ^ ((q4 >> 4) & 3); }
 __device__ __forceinline__ int ct_out_word(int b) {
     const int q4 = b >> 2;
-    return 4 * (q4 ^ ((q4 >> 4) & 3)) + (b & 3);
+    return 4 * ct_out_slot(q4) + ((b & 3) ^ ((q4 >> 2) & 2));
 }
+__device__ __forceinline__ float4 ct_out_fix(float4 v, int q4) { return (q4 & 8) ? make_float4(v.z, v.w, v.x, v.y) : v; }
 
 // Stages A and B of one tile.  U1 holds the 32 frames' operand records; on return lane (j = lane & 31, kh = lane >> 5) of wave k1
 // holds, in acc[r], output column j of frame mfma32_row(r, lane): bin ct_bin(k1, j).  Contains the barrier between the stages;
@@ -96,10 +104,10 @@ __device__ __forceinline__ f32x16 ct_stages(const float* __restrict__ U1, float*
         for (int q = 0; q < 2; ++q) {
             const int n2 = 2 * wave + q;
             const int kk2 = n2 + 16 * reim;                                     // input index of stage B
-            float* ydst = Yb + k1o * CT_KS2 + 16 * (kk2 & 1) + (kk2 >> 1);
+            float* ydst = Yb + k1o * CT_KS2 + 16 * (kk2 & 1) + (((kk2 >> 1) + k1o) & 15);     // rotated by k1: MB's row order follows
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
-                const float4 a = bs_ld4(U1 + (16 * rb + i) * CT_FS1 + n2 * CT_REC + 4 * kq);
+                const float4 a = bs_ld4(U1 + (16 * rb + i) * CT_FS1 + n2 * CT_REC + 4 * (kq ^ (n2 >> 3)));      // inputs 4 kq .. 4 kq + 3
                 ct_f4 d = ct_f4{0.f, 0.f, 0.f, 0.f};
                 d = ct_mfma16(a.x, ma[q][0], d);
                 d = ct_mfma16(a.y, ma[q][1], d);
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(CT_NT, 4) void mdct4_ct_kernel(const float* __restr
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int fr = fr0 + 8 * g;
-            const float4 v = bs_ld4(U1 + fr * CT_OS + 4 * (q4 ^ ((q4 >> 4) & 3)));
+            const float4 v = ct_out_fix(bs_ld4(U1 + fr * CT_OS + 4 * ct_out_slot(q4)), q4);
             const unsigned row = (unsigned)(tile * CT_ROWS + fr);
             if (SPEC) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bs_v4u, v), r_spec, (row * M + 4u * q4) * 4u, 0, 0);
             if (PAIR) {
@@ -236,8 +244,17 @@ __global__ __launch_bounds__(CT_NT, 4) void mdct4_ct_kernel(const float* __restr
         __syncthreads();                                          // the tile has been read: the next fold may overwrite it
     }
     if (STATS && MODE != CODEC_RAW) {
+        // one pair of double atomics per WORKGROUP (the grid ends together: 8 192 atomics on two addresses were a serial tail)
         sd1 = wave_sum_d(sd1); sd2 = wave_sum_d(sd2);
-        if (lane == 0) { atomicAdd(stats, sd1); atomicAdd(stats + 1, sd2); }
+        double* red = reinterpret_cast<double*>(Yb);               // (the loop ended on a barrier: the tile buffers are free)
+        if (lane == 0) { red[2 * wave] = sd1; red[2 * wave + 1] = sd2; }
+        __syncthreads();
+        if (tid < 2) {
+            double a = 0.0;
+#pragma unroll
+            for (int w = 0; w < CT_NT / 64; ++w) a += red[2 * w + tid];
+            atomicAdd(stats + tid, a);
+        }
     }
 }
 
@@ -280,7 +297,7 @@ __global__ __launch_bounds__(CT_NT, 4) void imdct4_ct_kernel(const float* __rest
     const int obin = ct_out_word(ct_bin(wave, j));
     // unfold reads of this lane: y_h[n] = v_h[Q + n] | -v_h[3Q - 1 - n];   y_{h-1}[n + M] = -v_{h-1}[Q - 1 - n] | -v_{h-1}[n - Q]
     const int uc_q4 = (lo ? Q + n : 3 * Q - 4 - n) >> 2, up_q4 = (lo ? Q - 4 - n : n - Q) >> 2;
-    const int uc_w = 4 * (uc_q4 ^ ((uc_q4 >> 4) & 3)), up_w = 4 * (up_q4 ^ ((up_q4 >> 4) & 3));
+    const int uc_w = 4 * ct_out_slot(uc_q4), up_w = 4 * ct_out_slot(up_q4);
 
     int nx_clip = blockIdx.x, nx_t = 0;                            // the tile being loaded
     bs_v4u xr[4];
@@ -331,7 +348,7 @@ __global__ __launch_bounds__(CT_NT, 4) void imdct4_ct_kernel(const float* __rest
             const int fr = wave + 8 * g;
             const float* vc = U1 + fr * CT_OS;
             const float* vp = fr == 0 ? halo + ((i + 1) & 1) * CT_OS : U1 + (fr - 1) * CT_OS;     // (the tile before wrote slot (i - 1) & 1)
-            const float4 c = bs_ld4(vc + uc_w), q = bs_ld4(vp + up_w);
+            const float4 c = ct_out_fix(bs_ld4(vc + uc_w), uc_q4), q = ct_out_fix(bs_ld4(vp + up_w), up_q4);
             const float4 yc = lo ? c : make_float4(-c.w, -c.z, -c.y, -c.x);
             const float4 yp = lo ? make_float4(-q.w, -q.z, -q.y, -q.x) : make_float4(-q.x, -q.y, -q.z, -q.w);
             const float4 o = make_float4(scale * (uw0.x * yc.x + uw1.x * yp.x), scale * (uw0.y * yc.y + uw1.y * yp.y),

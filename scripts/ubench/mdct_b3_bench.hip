@@ -141,6 +141,13 @@ int main(int argc, char** argv) {
         double dd = max_diff(spec2, spec, (size_t)B * F * 256, &amax);
         printf("   RAW spectra: max |ct - f32 pipe| = %.3e, max |X| = %.3e -> %.3e relative to the maximum\n", dd, amax, dd / amax);
         K1CT(CODEC_ARCSINH, true, false, cp, spec2, "K1 ct arcsinh, spectrogram only (product)");
+        {
+            double* st2; hipMalloc(&st2, 16); hipMemset(st2, 0, 16);
+            auto k = mdct4_ct_kernel<CODEC_ARCSINH, true, false, true>;
+            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT_K1_LDS);
+            report("K1 ct arcsinh, spectrogram + statistics", time_ms([&] { hipLaunchKernelGGL(k, gc, dim3(512), CT_K1_LDS, 0, x, B, T, F, w, imgc, cp, spec2, in2, st2); }, iters));
+            hipFree(st2);
+        }
         K1CT(CODEC_ARCSINH, false, true, cp, spec2, "K1 ct arcsinh, pair only");
         K1CT(CODEC_ARCSINH, true, true, cp, spec2, "K1 ct arcsinh, spectrogram + pair");
         // K2
