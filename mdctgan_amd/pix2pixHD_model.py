@@ -489,7 +489,12 @@ class Pix2PixHDModel(BaseModel):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # Under data parallelism ProcessGroupNCCL's watchdog thread polls events while this thread captures: in the default
+        # "global" capture mode any such call from another thread invalidates the capture ("operation failed due to a previous
+        # error during capture": seen on 2 of 5 fresh boxes in the first RCCL process, where start-up is slowest).  Only this
+        # thread's calls belong to the capture.
+        mode = "thread_local" if getattr(self, "reducers", None) else "global"
+        with torch.cuda.graph(graph, capture_error_mode=mode):
             losses = self.optimize_parameters(static_lr, static_hr)
 
         captured = (self.optimizer_G, self.optimizer_D)
