@@ -254,8 +254,15 @@ def bench_codec(args, dev, rank, world):
             if e:
                 e[2].record()
         return y
-    for _ in range(max(args.warmup, 2)):
+    # a step is ~0.6 ms: the W warm-up steps alone end before the clocks have ramped (the first launches of a process read 20-30 %
+    # slow, profiles/r04_mdct_ct_ubench.log), so keep warming until 0.25 s of steps have run; the count goes into the line
+    n_warm = 0
+    t_w = time.perf_counter()
+    while n_warm < max(args.warmup, 2) or time.perf_counter() - t_w < 0.25:
         step()
+        n_warm += 1
+        if n_warm % 16 == 0:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -275,7 +282,7 @@ def bench_codec(args, dev, rank, world):
     issued = {"ct": 2.0 * 128 * 12288 * B, "b3": 6.0 * flop32, "bs": flop32}[fam]
     pipe_peak = PEAK_F16_MFMA_TFLOPS if fam == "b3" else PEAK_F32_MFMA_TFLOPS
     out = {"metric": "codec clips/sec (MDCT4+norm, denorm+IMDCT4)", "value": round(world * args.steps * B / dt, 1),
-           "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_run": n_warm,
            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "K1+K2 on %d clips x 32512 samples (128 frames x 256 bins), arcsinh codec" % B,

@@ -28,16 +28,32 @@ python bench.py --fp16 --steps 20 --warmup 5 --no-also > $out/${tag}_bench_train
 python bench.py --steps 20 --warmup 5 > $out/${tag}_bench_train_line.json 2>/dev/null
 for f in bench_codec bench_cfg2_f32 bench_train_fp16 bench_train; do tail -c 300 $out/${tag}_${f}_line.json; echo; done
 
-# K1 / K2 micro-benchmark (product kernels + variants with parts switched off) and their SQ counters
+# K1 / K2 micro-benchmark (the factored-transform product kernels of mdct_ct.h beside the bf16 x 3 and f32-pipe dense-table kernels,
+# with parts switched off) and their SQ / LDS counters
 hipcc --version > /dev/null 2>&1
-for b in 4096 64 8; do scripts/ubench/mdct_bs_bench $b; done > $out/${tag}_mdct_bs_ubench.log 2>&1
-for b in 4096 1024; do scripts/ubench/mdct_b3_bench $b; done > $out/${tag}_mdct_b3_ubench.log 2>&1
+[ -x scripts/ubench/mdct_bs_bench ] && for b in 4096 64 8; do scripts/ubench/mdct_bs_bench $b; done > $out/${tag}_mdct_bs_ubench.log 2>&1
+for b in 4096 1024 512 256 128 64 8; do echo "##### clips $b"; scripts/ubench/mdct_b3_bench $b; done > $out/${tag}_mdct_ct_ubench.log 2>&1
 cd /tmp
-rm -rf /tmp/pmc_bs
+rm -rf /tmp/pmc_bs /tmp/pmc_lds
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY \
     -d /tmp/pmc_bs --output-format csv -- $R/scripts/ubench/mdct_b3_bench 4096 > /dev/null 2>&1
 f=$(find /tmp/pmc_bs -name "*counter_collection.csv" | head -1)
-[ -n "$f" ] && python $R/scripts/pmc_sq.py $f $out/${tag}_pmc_sq_mdct_b3.csv > /dev/null
+[ -n "$f" ] && python $R/scripts/pmc_sq.py $f $out/${tag}_pmc_sq_mdct.csv > /dev/null
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD \
+    -d /tmp/pmc_lds --output-format csv -- $R/scripts/ubench/mdct_b3_bench 1024 > /dev/null 2>&1
+f=$(find /tmp/pmc_lds -name "*counter_collection.csv" | head -1)
+[ -n "$f" ] && python - "$f" > $out/${tag}_pmc_lds_mdct_ct.txt <<'PY'
+import csv, re, sys
+from collections import defaultdict
+acc = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(lambda: defaultdict(int))
+for r in csv.DictReader(open(sys.argv[1])):
+    k = re.sub(r"^void ", "", r["Kernel_Name"]).replace("(anonymous namespace)::", "").split("(")[0]
+    acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
+print("# per dispatch at 1024 clips (4096 tiles x 8 waves = 32768 wave-tiles): counter sums over the chip")
+for k, c in acc.items():
+    if "mdct4_" in k:
+        print(k, {n: round(v / cnt[k][n]) for n, v in sorted(c.items())})
+PY
 cd $R
 # full-size step parity by kernel family + op-level accuracy of the 25-position Winograd families
 bash scripts/r04_step_parity.sh $out/${tag}_step_report.jsonl > $out/${tag}_fullsize_step_parity.txt 2>&1
