@@ -185,14 +185,11 @@ def cpu_baseline_train_cfg2(max_threads):
 def also_lines(args):
     """The other BASELINE configurations as their own bench lines, each from a child process of this script (own model, own
     hipGraph, own roofline probe and cpu_baseline), embedded in the headline's JSON so that the driver's one command shows
-    them: configs[2] with --fp16 (the reference's configuration for configs[2] / [3]), configs[4] (inference) and the
-    headline configuration under the MG_F32_SPLIT=1 opt-in."""
+    them: configs[2] with --fp16 (the reference's configuration for configs[2] / [3]), configs[4] (inference) and the codec pair
+    K1 + K2 alone at 4096 clips (north_star's first-named kernels against their HBM roofline)."""
     import subprocess
     out = []
-    # third line: the headline configuration with MG_F32_SPLIT=1 (float32 products of the Winograd-domain GEMMs formed from three
-    # bf16 pieces on the bf16 MFMA pipe, float32-accurate: DESIGN section 3).  An opt-in, shown beside the headline, never in it.
-    for extra, env in ((["--config", "2", "--fp16"], None), (["--config", "4"], None),
-                       (["--config", "1", "--no-cpu-baseline"], {"MG_F32_SPLIT": "1"})):
+    for extra, env in ((["--config", "2", "--fp16"], None), (["--config", "4"], None), (["--mode", "codec"], None)):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
                "--no-also"] + extra
         t0 = time.perf_counter()
@@ -227,6 +224,35 @@ def cpu_baseline_infer(max_threads, lr_rate):
             "sample": "oracle inference (float64 MDCT + float32 generator + float64 IMDCT) on 2 segments x 32512 samples: "
                       "3 warm-ups + 5 timed, median %.2f s (min %.2f, max %.2f), %d threads (fixed; host has %d cores)"
                       % (med, ts[0], ts[-1], threads, max_threads)}
+
+
+def cpu_baseline_codec(max_threads):
+    """The codec pair on the CPU oracle (oracle/transform.py: numpy, float64 transform -- to_spectro + to_audio as K1 + K2 run them)
+    on 64 clips of 32512 samples after an 8-clip warm-up: clips/s of the pair."""
+    import numpy as np
+    from oracle import transform as T
+    threads = min(CPU_THREADS, max_threads)
+    try:
+        from threadpoolctl import threadpool_limits
+        limit = threadpool_limits(limits=threads)
+    except Exception:       # noqa: BLE001  (no threadpoolctl: numpy's own default)
+        limit, threads = None, max_threads
+    w = T.kbd_window(512)
+    kw = dict(arcsinh_transform=True, raw_mdct=False, arcsinh_gain=1000.0, abs_norm=True, src_range=(-5.0, 5.0), norm_range=(-1.0, 1.0))
+    x = (0.05 * np.random.default_rng(7).standard_normal((64, T_SEG))).astype(np.float32)
+
+    def pair(a):
+        s, n = T.to_spectro(a, w, 512, 256, **kw)
+        return T.to_audio(s, n, w, 512, 256, **kw)
+    pair(x[:8])
+    t0 = time.perf_counter()
+    pair(x)
+    dt = time.perf_counter() - t0
+    if limit is not None:
+        limit.restore_original_limits()
+    return {"value": round(64 / dt, 2), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": "oracle/transform.py to_spectro + to_audio (numpy, float64) on 64 clips x 32512 samples after an 8-clip warm-up: "
+                      "%.2f s, BLAS limited to %d threads (host has %d cores)" % (dt, threads, max_threads)}
 
 
 def bench_codec(args, dev, rank, world):
@@ -321,6 +347,8 @@ def bench_codec(args, dev, rank, world):
             out["roofline"]["traffic_definition"] = (
                 "HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 from separate rocprofv3 --pmc passes over this bench "
                 "mode at 4096 clips (%s), scaled by clips / 4096" % table.get("_source"))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_codec(os.cpu_count() or 1)
     if rank == 0:
         print(json.dumps(out), flush=True)
 

@@ -100,11 +100,10 @@ __global__ void h16_dycol_kernel(Geom g, const float* __restrict__ dy, _Float16*
 // Transposed float16 gather: out[(tap * C + c)][Mp] = src[pixel(m, tap)][c] (0 past M / in the padding), 64 x 64 tiles
 // through LDS so both the float32 reads (along c) and the float16 writes (along m) are coalesced.  KT == 1 with an
 // identity geometry transposes a plain [M][C] matrix (dy -> dYt).
-__global__ __launch_bounds__(256) void h16_colT_kernel(Geom g, const float* __restrict__ src, int C, int M, int Mp,
-                                                       int identity, _Float16* __restrict__ out) {
+__device__ __forceinline__ void h16_colT_body(const Geom& g, const float* __restrict__ src, int C, int M, int Mp, int identity,
+                                              _Float16* __restrict__ out, int m0, int c0, int tap) {
     __shared__ _Float16 tile[64][72];                  // [c][m], pitch 72 halves: 16-byte aligned rows
     const int KT = identity ? 1 : g.KH * g.KW;
-    const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tap = blockIdx.z;
     const int t = threadIdx.x;
     const int ky = tap / (identity ? 1 : g.KW), kx = tap - ky * (identity ? 1 : g.KW);
 #pragma unroll
@@ -129,6 +128,23 @@ __global__ __launch_bounds__(256) void h16_colT_kernel(Geom g, const float* __re
         *reinterpret_cast<uint4*>(out + ((size_t)tap * C + c0 + c) * Mp + m0 + 8 * m8) = v;
     }
     (void)KT;
+}
+__global__ __launch_bounds__(256) void h16_colT_kernel(Geom g, const float* __restrict__ src, int C, int M, int Mp,
+                                                       int identity, _Float16* __restrict__ out) {
+    h16_colT_body(g, src, C, M, Mp, identity, out, blockIdx.x * 64, blockIdx.y * 64, blockIdx.z);
+}
+// Both operands of the weight gradient in ONE launch: z == 0 transposes dy -> dYt [Co][Mp], z = 1 + tap gathers x -> XcolT rows of
+// that tap (grid.y covers the wider of Co / 64 and Ci / 64: blocks past an operand's channels leave).  The two launches it replaces
+// were 5-6 us each on the 2048-channel trunk (25 pairs per configs[2] --fp16 step); same stores, same values.
+__global__ __launch_bounds__(256) void h16_colT2_kernel(Geom g, const float* __restrict__ dy, int Co, _Float16* __restrict__ dyt,
+                                                        const float* __restrict__ x, int Ci, _Float16* __restrict__ xct, int M,
+                                                        int Mp) {
+    const int c0 = blockIdx.y * 64;
+    if (blockIdx.z == 0) {
+        if (c0 < Co) h16_colT_body(g, dy, Co, M, Mp, 1, dyt, blockIdx.x * 64, c0, 0);
+    } else {
+        if (c0 < Ci) h16_colT_body(g, x, Ci, M, Mp, 0, xct, blockIdx.x * 64, c0, (int)blockIdx.z - 1);
+    }
 }
 
 inline double h16_max_ratio() {
@@ -290,8 +306,15 @@ int h16_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw,
     _Float16* xct = (_Float16*)(ws + h16_al((size_t)g->Co * Mp * 2));
     float* part = (float*)((char*)xct + h16_al((size_t)N * Mp * 2));
     const Geom gg = to_geom(g);
-    hipLaunchKernelGGL(h16_colT_kernel, dim3(Mp / 64, g->Co / 64, 1), dim3(256), 0, st, gg, dy, g->Co, (int)M, Mp, 1, dyt);
-    hipLaunchKernelGGL(h16_colT_kernel, dim3(Mp / 64, g->Ci / 64, g->KH * g->KW), dim3(256), 0, st, gg, x, g->Ci, (int)M, Mp, 0, xct);
+    static const bool two = getenv("MG_H16_COLT_TWO_LAUNCHES") != nullptr;
+    if (two) {
+        hipLaunchKernelGGL(h16_colT_kernel, dim3(Mp / 64, g->Co / 64, 1), dim3(256), 0, st, gg, dy, g->Co, (int)M, Mp, 1, dyt);
+        hipLaunchKernelGGL(h16_colT_kernel, dim3(Mp / 64, g->Ci / 64, g->KH * g->KW), dim3(256), 0, st, gg, x, g->Ci, (int)M, Mp, 0, xct);
+    } else {
+        const int cy = (g->Co > g->Ci ? g->Co : g->Ci) / 64;
+        hipLaunchKernelGGL(h16_colT2_kernel, dim3(Mp / 64, cy, 1 + g->KH * g->KW), dim3(256), 0, st, gg, dy, g->Co, dyt, x, g->Ci, xct,
+                           (int)M, Mp);
+    }
     if (h16_wgrad_as(g)) {
         probe_begin(st);
         hgemm_as_launch(dyt, xct, dw, g->Co, N, Mp, accumulate, found_inf, st);
