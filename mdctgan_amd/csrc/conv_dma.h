@@ -76,7 +76,74 @@ struct CdArgs {
     int act, tiles_m, tiles_n, splits, cps, accumulate;
     int round_f16;           // HALF: round the direct result through float16 (autocast output)
     int cls_order;           // DGRAD, stride 2: 1 = classes in the order (all taps, half, one tap, half), see the kernel
+    int gm;                  // FWD: tile order inside a K split: groups of gm row tiles x all column tiles, row tiles fastest
+                             // (0: row tiles fastest over the whole split).  Chosen on the host by cd_pick_gm.
 };
+
+// The tile order decides what an XCD's private 4 MB L2 can share: an XCD is handed a contiguous run of the linear tile index
+// (xcd_remap) and runs ~64 of its tiles at a time, which walk K together -- an operand panel is fetched once per WINDOW of
+// concurrent tiles that use it.  With row tiles fastest over the whole launch, an XCD of the batch-64 512 -> 1024 ladder rung
+// (64 x 8 tiles) runs one column of 64 row tiles: the weight panel is shared, but every XCD pulls the WHOLE input through its
+// L2 -- measured 1.20 GB per launch against 119 MB algorithmic.  cd_pick_gm evaluates that window model for a few group sizes and
+// returns the cheapest (0 = keep the plain order).  a_bytes / b_bytes: what one tile reads of either operand per K split.
+inline int cd_pick_gm(int tiles_m, int tiles_n, int splits, double a_bytes, double b_bytes) {
+    static const int forced = getenv("MG_CONV_DMA_GM") ? atoi(getenv("MG_CONV_DMA_GM")) : -1;
+    if (forced >= 0) return forced >= tiles_m ? 0 : forced;
+    const long long tiles = (long long)tiles_m * tiles_n, total = tiles * splits;
+    if (tiles_m < 2 || tiles_n < 2 || total > (1 << 16)) return 0;
+    // (memoised: the model walks every tile of the launch -- once per shape, not once per call)
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, long long, long long>, int> memo;
+    const auto key = std::make_tuple(tiles_m, tiles_n, splits, (long long)a_bytes, (long long)b_bytes);
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = memo.find(key);
+        if (it != memo.end()) return it->second;
+    }
+    constexpr int WINDOW = 64;
+    auto cost = [&](int gm) {
+        double c = 0.0;
+        const long long q = total / 8, r = total % 8;
+        long long base = 0;
+        for (int x = 0; x < 8; ++x) {
+            const long long cnt = q + (x < r ? 1 : 0);
+            for (long long w0 = 0; w0 < cnt; w0 += WINDOW) {
+                unsigned long long seen_m[64] = {0}, seen_n[64] = {0};     // (split, tile) bitmaps, up to 4096 each
+                int um = 0, un = 0;
+                const long long w1 = w0 + WINDOW < cnt ? w0 + WINDOW : cnt;
+                for (long long i = w0; i < w1; ++i) {
+                    const long long L = base + i;
+                    const int sp = (int)(L / tiles);
+                    const int rem = (int)(L - (long long)sp * tiles);
+                    int tn, tm;
+                    if (gm > 0) {
+                        const int per = gm * tiles_n, grp = rem / per, r2 = rem - grp * per;
+                        const int sz = tiles_m - grp * gm < gm ? tiles_m - grp * gm : gm;
+                        tn = r2 / sz; tm = grp * gm + (r2 - tn * sz);
+                    } else {
+                        tn = rem / tiles_m; tm = rem - tn * tiles_m;
+                    }
+                    const unsigned km = (unsigned)(sp * tiles_m + tm) & 4095u, kn = (unsigned)(sp * tiles_n + tn) & 4095u;
+                    if (!(seen_m[km >> 6] >> (km & 63) & 1ull)) { seen_m[km >> 6] |= 1ull << (km & 63); ++um; }
+                    if (!(seen_n[kn >> 6] >> (kn & 63) & 1ull)) { seen_n[kn >> 6] |= 1ull << (kn & 63); ++un; }
+                }
+                c += um * a_bytes + un * b_bytes;
+            }
+            base += cnt;
+        }
+        return c;
+    };
+    int best = 0;
+    double best_c = cost(0);
+    for (int gm : {1, 2, 4, 8, 16, 32}) {
+        if (gm >= tiles_m) break;
+        const double c = cost(gm);
+        if (c < 0.9 * best_c) { best_c = c; best = gm; }       // (a tenth better or the plain order stays)
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    memo[key] = best;
+    return best;
+}
 
 __device__ __forceinline__ unsigned cd_pixel_off(const CdArgs& g, int pb, int iy, int ix, unsigned cbytes) {
     if (g.reflect) {
@@ -107,7 +174,16 @@ __global__ __launch_bounds__(256) void conv_fwd_dma_kernel(CdArgs g) {
     const int tiles = g.tiles_m * g.tiles_n;
     const int L = xcd_remap(blockIdx.x, tiles * g.splits);
     const int sp = L / tiles, rem = L - sp * tiles;
-    const int tn = rem / g.tiles_m, tm = rem - tn * g.tiles_m;      // consecutive tiles share the weight panel
+    int tn, tm;
+    if (g.gm > 0) {                                                 // groups of gm row tiles x all column tiles (cd_pick_gm)
+        const int per = g.gm * g.tiles_n, grp = rem / per, r2 = rem - grp * per;
+        const int sz = min(g.gm, g.tiles_m - grp * g.gm);
+        tn = r2 / sz;
+        tm = grp * g.gm + (r2 - tn * sz);
+    } else {
+        tn = rem / g.tiles_m;                                       // consecutive tiles share the weight panel
+        tm = rem - tn * g.tiles_m;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int cpt = g.Ci / CK, total_chunks = KT * cpt;
     const int c_begin = sp * g.cps, c_end = min(total_chunks, c_begin + g.cps);
@@ -386,7 +462,16 @@ __global__ __launch_bounds__(256) void conv_dgrad_dma_kernel(CdArgs g) {
     const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
     if ((int)blockIdx.x >= tiles_m * tiles_n) return;
     const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tn = t / tiles_m, tm = t - tn * tiles_m;
+    int tn, tm;
+    if (g.gm > 0) {                                                 // groups of gm row tiles x all column tiles (cd_pick_gm)
+        const int per = g.gm * tiles_n, grp = t / per, r2 = t - grp * per;
+        const int sz = min(g.gm, tiles_m - grp * g.gm);
+        tn = r2 / sz;
+        tm = grp * g.gm + (r2 - tn * sz);
+    } else {
+        tn = t / tiles_m;
+        tm = t - tn * tiles_m;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int ky0 = (py + g.p) % s, kx0 = (px + g.p) % s;
     const int nky = (g.KH - ky0 + s - 1) / s, nkx = (g.KW - kx0 + s - 1) / s;
@@ -640,6 +725,13 @@ void conv_dma_fwd_launch(const mg_conv_geom* g, const CdPlan& p, const void* x, 
     a.x = x; a.w = w; a.bias = bias; a.y = y; a.part = p.splits > 1 ? part : nullptr; a.act = act;
     const long long M = (long long)g->B * g->OH * g->OW;
     a.tiles_m = (int)((M + p.bm - 1) / p.bm); a.tiles_n = g->Co / p.bn; a.splits = p.splits; a.cps = p.cps;
+    {
+        const double es = conv_dma_half(g) ? 2.0 : 4.0;
+        // a row tile's share of the input (every input pixel belongs to ~one row tile; taps re-read it from L2), a column tile's weights
+        const double a_bytes = (double)g->B * g->H * g->W * g->Ci * es / a.tiles_m / a.splits;
+        const double b_bytes = (double)p.bn * g->KH * g->KW * g->Ci * es / a.splits;
+        a.gm = cd_pick_gm(a.tiles_m, a.tiles_n, a.splits, a_bytes, b_bytes);
+    }
     const dim3 grid((unsigned)((long long)a.tiles_m * a.tiles_n * a.splits));
     CD_DISPATCH(conv_fwd_dma_kernel, 0, 0, conv_dma_half(g));
 }
@@ -713,5 +805,14 @@ void conv_dma_dgrad_launch(const mg_conv_geom* g, const CdPlan& p, const void* d
     const long long slots = 256LL * (p.bm == 64 && p.bn == 64 ? 5 : (p.bm == 128 && p.bn == 128 ? 2 : 3));
     a.cls_order = (long long)grid.x * grid.y * grid.z <= slots ? 1 : 0;
     if (const char* e = getenv("MG_DGRAD_CLASS_ORDER")) a.cls_order = e[0] == '1' ? 1 : 0;
+    {
+        // per parity class (grid.y) and K split (grid.z) the tiles of grid.x are handed to the XCDs in runs: same window model as
+        // the forward pass, with dy as the row operand (a class reads its taps' share of dy) and the weights as the column operand
+        const int tiles_m = (int)((Mc + p.bm - 1) / p.bm), tiles_n = g->Ci / p.bn;
+        const double es = conv_dma_half(g) ? 2.0 : 4.0;
+        const double a_bytes = (double)g->B * g->OH * g->OW * g->Co * es / tiles_m / p.splits;
+        const double b_bytes = (double)p.bn * g->KH * g->KW * g->Co * es / (s * s) / p.splits;
+        a.gm = cd_pick_gm(tiles_m, tiles_n, 1, a_bytes, b_bytes);
+    }
     CD_DISPATCH(conv_dgrad_dma_kernel, 0, 1, conv_dma_half(g));
 }

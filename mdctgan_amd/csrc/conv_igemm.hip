@@ -24,6 +24,9 @@
 #include <stdlib.h>
 #include <cstring>
 #include <type_traits>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <hip/hip_ext.h>
 
 namespace {
