@@ -226,6 +226,55 @@ def cpu_baseline_infer(max_threads, lr_rate):
                       % (med, ts[0], ts[-1], threads, max_threads)}
 
 
+def live_traffic(child_args, kernels):
+    """HBM bytes per launch of `kernels` (short symbol names) MEASURED IN THIS RUN: two rocprofv3 passes -- `--kernel-trace --pmc
+    FETCH_SIZE`, then `--pmc WRITE_SIZE`, separate runs as MI355X_MICROARCH.md prescribes -- over a short child process that launches
+    those kernels at this line's shapes, reduced like scripts/pmc_traffic.py: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 reports
+    half of a wide coalesced read).  Returns {kernel: bytes} for the kernels seen in both passes; {} when rocprofv3 is missing,
+    fails or takes longer than 150 s per pass (the caller then keeps the table of profiles/traffic.json and says so)."""
+    import csv
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None or os.environ.get("MG_BENCH_LIVE_PMC", "1") == "0":
+        return {}
+
+    def short(name):
+        return re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "").split("(")[0].strip()
+    sums = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="mg_pmc_", dir="/tmp")
+            cmd = [rp, "--kernel-trace", "--pmc", ctr, "-d", d, "--output-format", "csv", "--", sys.executable] + child_args
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", MG_BENCH_LIVE_PMC="0"), capture_output=True, timeout=150)
+            acc, cnt = {}, {}
+            for root, _, files in os.walk(d):
+                for fn in files:
+                    if fn.endswith("counter_collection.csv"):
+                        for r in csv.DictReader(open(os.path.join(root, fn))):
+                            if r.get("Counter_Name") == ctr:
+                                k = short(r["Kernel_Name"])
+                                acc[k] = acc.get(k, 0.0) + float(r["Counter_Value"])
+                                cnt[k] = cnt.get(k, 0) + 1
+            shutil.rmtree(d, ignore_errors=True)
+            sums[ctr] = {k: acc[k] / cnt[k] for k in acc}
+    except Exception:       # noqa: BLE001  (a profiler problem must not cost the bench line)
+        return {}
+    out = {}
+    for k in kernels:
+        hit = [n for n in sums.get("FETCH_SIZE", {}) if n.startswith(k) and n in sums.get("WRITE_SIZE", {})]
+        if hit:
+            out[k] = int((2.0 * sums["FETCH_SIZE"][hit[0]] + sums["WRITE_SIZE"][hit[0]]) * 1024)
+    return out
+
+
+LIVE_PMC_NOTE = ("measured in THIS run: separate `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes over `%s` in "
+                 "child processes right after the timed region, (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch (gfx950 reports half of "
+                 "a wide coalesced read: MI355X_MICROARCH.md, HBM section); `traffic_table` is the value of profiles/traffic.json")
+
+
 def cpu_baseline_codec(max_threads):
     """The codec pair on the CPU oracle (oracle/transform.py: numpy, float64 transform -- to_spectro + to_audio as K1 + K2 run them)
     on 64 clips of 32512 samples after an 8-clip warm-up: clips/s of the pair."""
@@ -344,9 +393,17 @@ def bench_codec(args, dev, rank, world):
         if t1 and t2:
             out["roofline"]["traffic"] = int(t1 * B / 4096)
             out["roofline"]["k2_traffic"] = int(t2 * B / 4096)
+            out["roofline"]["traffic_table"] = [int(t1 * B / 4096), int(t2 * B / 4096)]
             out["roofline"]["traffic_definition"] = (
                 "HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 from separate rocprofv3 --pmc passes over this bench "
                 "mode at 4096 clips (%s), scaled by clips / 4096" % table.get("_source"))
+    if rank == 0 and world == 1 and not args.no_roofline:
+        child = [os.path.abspath(__file__), "--mode", "codec", "--codec-batch", str(B), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                 "--no-roofline"]
+        live = live_traffic(child, ["mdct4_", "imdct4_"])
+        if len(live) == 2:
+            out["roofline"]["traffic"], out["roofline"]["k2_traffic"] = live["mdct4_"], live["imdct4_"]
+            out["roofline"]["traffic_definition"] = LIVE_PMC_NOTE % "python bench.py --mode codec --steps 3 --warmup 1"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_codec(os.cpu_count() or 1)
     if rank == 0:
@@ -580,6 +637,7 @@ def main():
                 doc = json.load(open(tr))
                 table = doc.get(section) or (doc if section == "configs[1]" else {})
                 roofline["traffic"] = table.get(dominant)
+                roofline["traffic_table"] = table.get(dominant)
                 roofline["traffic_definition"] = ("HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 from separate "
                                                   "rocprofv3 --pmc passes on this kernel at this layer shape (gfx950 reports "
                                                   "half of a wide coalesced read: MI355X_MICROARCH.md, HBM section); "
@@ -598,6 +656,20 @@ def main():
                                                         "measured traffic of its trunk-layer launch (PMC), time = its average launch"}
             except Exception:
                 pass
+        # the same two PMC passes, live: the dominant kernel's layer of this line through scripts/bench_conv.py in a child process
+        layer = {"configs[1]": ["--only", "bottleneck"], "configs[1] --fp16": ["--only", "bottleneck", "--f16"],
+                 "configs[2]": ["--only", "trunk2048"], "configs[2] --fp16": ["--only", "trunk2048", "--f16"],
+                 "configs[4]": ["--only", "bottleneck_b64"]}.get("configs[%d]%s" % (args.config, " --fp16" if args.fp16 else ""))
+        if layer and world == 1 and rank == 0 and dominant.startswith(("dgemm32g", "hgemm", "conv_")):
+            torch.cuda.synchronize()
+            child = [os.path.join(REPO, "scripts", "bench_conv.py")] + layer + ["--iters", "2"]
+            live = live_traffic(child, [dominant])
+            if live.get(dominant):
+                roofline["traffic"] = live[dominant]
+                roofline["traffic_definition"] = LIVE_PMC_NOTE % ("python scripts/bench_conv.py " + " ".join(layer) + " --iters 2")
+                if roofline.get("hbm_view") and roofline.get("avg_launch_us"):
+                    gbps = live[dominant] / (roofline["avg_launch_us"] * 1e-6) / 1e9
+                    roofline["hbm_view"].update({"traffic_GBps": round(gbps, 1), "frac": round(gbps / 8000.0, 4)})
 
     codec_line = None
     if args.mode == "infer" and not args.no_roofline:
