@@ -240,6 +240,10 @@ def live_traffic(child_args, kernels):
     rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if rp is None or os.environ.get("MG_BENCH_LIVE_PMC", "1") == "0":
         return {}
+    # this process is itself running under a profiler (scripts/profile_round.sh): no nested passes
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or "HSA_TOOLS_LIB" in os.environ or any(
+            k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return {}
 
     def short(name):
         return re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "").split("(")[0].strip()
