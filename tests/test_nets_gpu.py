@@ -848,3 +848,24 @@ def test_no_lsgan_step_against_oracle():
     for net in (model.netG, model.netD):
         for k, p in net.named_parameters():
             assert p.grad is not None and torch.isfinite(p.grad).all(), k
+
+
+@pytest.mark.parametrize("gen_overlap", [0, 1024, 100])
+def test_generate_with_stitching_k2_equals_decode_then_stitch(gen_overlap, monkeypatch):
+    """generate_audio.py:28-53 end to end on a toy generator: 5 segments in batches of 2 -- K2 writing every batch straight into
+    the stitched waveform (mg_imdct4_stitched) gives the bits of the reference's order of operations (decode every batch, concatenate,
+    halve the edges / fold / crop: MG_NO_STITCHED_K2=1), for --gen_overlap 0, a multiple of 4 and one that is not; and
+    segment_audio -> generate reproduces the input's length bookkeeping (the stitched waveform covers every input sample)."""
+    from mdctgan_amd.generate_audio import generate, segment_audio
+    model = make_model()
+    T = 7936
+    gen = torch.Generator().manual_seed(3)
+    wave = 0.05 * torch.randn(4 * T + 123, generator=gen)
+    segs = segment_audio(wave.to(DEV), T, gen_overlap)
+    assert segs.shape[1] == T and segs.shape[0] >= 5
+    monkeypatch.setenv("MG_NO_STITCHED_K2", "1")
+    want = generate(model, segs, batch_size=2, gen_overlap=gen_overlap)
+    monkeypatch.delenv("MG_NO_STITCHED_K2")
+    got = generate(model, segs, batch_size=2, gen_overlap=gen_overlap)
+    assert got.shape == want.shape and got.shape[-1] >= wave.numel()
+    assert torch.equal(got, want), (gen_overlap, (got - want).abs().max().item())
