@@ -40,6 +40,35 @@ def test_instnorm_fwd_bwd(shape, act):
     assert rel_err(y2, nhwc((y - res).detach())) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(8, 64, 128, 256), (2, 64, 32, 64), (8, 128, 64, 128), (3, 12, 7, 9), (2, 4, 19, 35), (8, 256, 33, 65)])
+@pytest.mark.parametrize("act", ["none", "relu", "lrelu"])
+def test_instnorm_row_kernels_equal_the_flat_ones(shape, act, monkeypatch):
+    """norm_apply_rows_kernel (statistics in registers, threads walk pixel rows) against norm_apply_{fwd,bwd}_kernel
+    (MG_NO_NORM_ROWS=1): the same arithmetic per element, so the same bits -- outputs, the float16 copies, with and without the
+    residual, ragged pixel counts and channel counts that do not fill a 64-channel block."""
+    from mdctgan_amd import ops
+    code = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU02}[act]
+    B, C, H, W = shape
+    gen = torch.Generator().manual_seed(11)
+    x = (torch.randn(B, H, W, C, generator=gen) * 2 + 0.5).to(DEV)
+    res = torch.randn(B, H, W, C, generator=gen).to(DEV)
+    gy = torch.randn(B, H, W, C, generator=gen).to(DEV)
+    outs = []
+    for rows in (False, True):
+        if rows:
+            monkeypatch.delenv("MG_NO_NORM_ROWS", raising=False)
+        else:
+            monkeypatch.setenv("MG_NO_NORM_ROWS", "1")
+        y16 = torch.zeros(x.numel(), dtype=torch.float16, device=DEV)
+        d16 = torch.zeros(x.numel(), dtype=torch.float16, device=DEV)
+        y, mean, rstd = ops.instnorm_fwd(x, code, res, y16=y16)
+        y2, _, _ = ops.instnorm_fwd(x, code, None)
+        dx = ops.instnorm_bwd(gy, x, mean, rstd, code, dx16=d16)
+        outs.append((y, y2, dx, y16, d16, mean, rstd))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b), (shape, act)
+
+
 def test_act_bwd_add_pool_upsample():
     from mdctgan_amd import ops
     gen = torch.Generator().manual_seed(2)
