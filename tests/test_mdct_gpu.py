@@ -427,3 +427,19 @@ def test_stitched_k2_equals_decode_then_stitch(mods, golden, overlap):
         assert np.abs(out.cpu().double().numpy() - ref[0]).max() <= 5e-6 * np.abs(ref).max()
     with pytest.raises(ValueError):
         imdct4_codec(X, win, d4, 512, stitch=(torch.empty(100, device=DEV), seg.shape[-1] // 2, 0))
+    # edges: ONE segment (both cross-fade zones are cropped away: the waveform is the segment's middle, untouched by the halving),
+    # and a single-clip batch landing in the middle of a longer waveform
+    one = spec[:1]
+    plain1, _ = imdct4_codec(one, win, d4, 512, **kw)
+    if overlap:
+        out1 = torch.full((lib.mg_stitch_length(1, L, overlap),), float("nan"), device=DEV)
+        imdct4_codec(one, win, d4, 512, stitch=(out1, overlap, 0), **kw)
+        assert out1.numel() == L - 2 * overlap and torch.equal(out1, plain1[0, overlap:L - overlap])
+    out = torch.zeros(lib.mg_stitch_length(n_seg, L, overlap), device=DEV)
+    imdct4_codec(spec[3:4], win, d4, 512, stitch=(out, overlap, 3), **kw)
+    lo = 3 * (L - overlap) - overlap
+    ref = imdct4_codec(spec[3:4], win, d4, 512, **kw)[0][0].clone()
+    if overlap:
+        ref[:overlap] *= 0.5
+        ref[L - overlap:] *= 0.5
+    assert torch.equal(out[lo:lo + L], ref) and out[:lo].abs().max().item() == 0 and out[lo + L:].abs().max().item() == 0
