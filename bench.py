@@ -69,6 +69,17 @@ class HipEvents:
         return ms.value * 1e-3 if rc == 0 else float("nan")
 
 
+def is_f16_symbol(name):
+    """Which MFMA pipe a GEMM / convolution symbol issues on: hgemm* and the HALF instances of conv_*_dma_kernel<BM, BN, HALF, NBUF>
+    (third template argument) the f16 pipe, as do the round-1 conv_*_kernel<..., TAG> instances with TAG bit 1; the rest float32."""
+    name = name.rstrip()
+    if name.startswith("hgemm"):
+        return True
+    if "_dma_kernel<" in name:
+        return ", true," in name
+    return name.startswith("conv_") and name.endswith((", 2>", ", 3>"))
+
+
 class KernelTimer:
     """Per-kernel GPU time of the conv launches.  mode 'all' (target None): every conv call, used on one warm-up step
     to find the dominant kernel; with a target only that kernel's launches are probed (cheap)."""
@@ -546,6 +557,24 @@ def main():
         ops.PROFILER = None
     torch.cuda.synchronize()
     dominant = None
+    symbols = None
+
+    def symbol_table(agg):
+        # every GEMM / convolution / optimiser symbol of ONE probed eager step, by time: launches, time per launch, and the rate of the
+        # work it was launched with (FLOPs the kernel issues against its MFMA pipe; algorithmic bytes of the "[hbm]" streams)
+        rows = []
+        for k in sorted(agg, key=lambda k: -agg[k][2])[:12]:
+            n, work, secs, _ = agg[k]
+            if secs <= 0:
+                continue
+            if k.startswith("[hbm] "):
+                rows.append({"kernel": k[6:], "launches": n, "avg_us": round(secs / n * 1e6, 1), "bound": "hbm",
+                             "GBps": round(work / secs / 1e9, 1), "frac": round(work / secs / 8e12, 3)})
+            else:
+                pk = PEAK_F16_MFMA_TFLOPS if is_f16_symbol(k) else PEAK_F32_MFMA_TFLOPS
+                rows.append({"kernel": k, "launches": n, "avg_us": round(secs / n * 1e6, 1), "bound": "mfma",
+                             "TFLOPs": round(work / secs / 1e12, 1), "frac": round(work / secs / 1e12 / pk, 3)})
+        return rows
     if not args.no_roofline:
         agg = timer_all.summary()
         dominant = max(agg, key=lambda k: agg[k][2]) if agg else None
@@ -576,6 +605,14 @@ def main():
             eager_step()
         torch.cuda.synchronize()
         ops.PROFILER = None
+    if timer is not None and not use_ddp:
+        # one more eager step, every launch probed, with the clocks warm: the per-symbol table of the line
+        probe_all = KernelTimer(ops, mglib.load())
+        ops.PROFILER = probe_all
+        eager_step()
+        torch.cuda.synchronize()
+        ops.PROFILER = None
+        symbols = symbol_table(probe_all.summary())
     dist_ranks = None
     if use_ddp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -608,8 +645,7 @@ def main():
     elif timer is not None and timer.records:
         n, flops, secs, conv_flops = timer.summary()[dominant]
         achieved = flops / secs / 1e12
-        f16_kernel = dominant.startswith("hgemm") or (     # float16 GEMMs (conv_h16.h), HALF / TAG bit 1 convolution instances
-            dominant.startswith("conv_") and dominant.rstrip().endswith((", 2>", ", 3>", ", true>")))
+        f16_kernel = is_f16_symbol(dominant)      # float16 GEMMs (conv_h16.h), HALF / TAG bit 1 convolution instances
         peak = PEAK_F16_MFMA_TFLOPS if f16_kernel else PEAK_F32_MFMA_TFLOPS
         split = dominant.startswith("dgemm32g_kernel") and dominant.rstrip().endswith(", 1>")
         if split:      # MG_F32_SPLIT=1: 8 bf16 piece products per float32 product, issued on the bf16 pipe
@@ -719,6 +755,11 @@ def main():
                "roofline": roofline}
         if codec_line is not None:
             out["roofline_codec"] = codec_line
+        if symbols:
+            out["roofline_symbols"] = {"note": "the 12 heaviest GEMM / convolution / optimiser symbols of ONE eager step probed right after "
+                                               "the timed region (the library's own dispatch events; FLOPs = what the kernel issues, "
+                                               "2*M*N*K of its GEMM -- the Winograd-domain GEMMs' direct-convolution equivalent is 2.25x)",
+                                       "symbols": symbols}
         if world == 1 and not args.no_cpu_baseline and args.mode == "train" and args.config == 1:
             out["cpu_baseline"] = cpu_baseline_train(os.cpu_count() or 1)
         if world == 1 and not args.no_cpu_baseline and args.mode == "train" and args.config == 2:
