@@ -13,6 +13,8 @@ inline void mg_launch(KernelT kern, dim3 grid, dim3 block, size_t lds, hipStream
 }
 #include "dense_gemm.h"
 #include "dense_gemm_h.h"
+#include <type_traits>
+#include "dense_gemm_h8.h"
 
 __global__ void ref_kernel(const _Float16* A, const _Float16* B, float* out, int M, int N, int K, int lda, int ldb) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -46,6 +48,13 @@ __global__ void reduce_kernel(const float* part, int S, size_t n, float* out) {
     }
 }
 struct Variant { const char* name; int bm, bn; void (*launch)(const HgArgs&, hipStream_t); };
+template <int DBG>
+void h8_adapter(const HgArgs& g, hipStream_t st) {
+    Hg8Args a{};
+    a.A = g.A; a.B = g.B; a.C = g.part ? g.part : g.C; a.bias = nullptr;
+    a.M = g.M; a.N = g.N; a.K = g.K; a.lda = g.lda; a.ldb = g.ldb; a.ldc = g.N;
+    hgemm8_launch<DBG>(a, st);
+}
 __global__ void ref_rc_kernel(const _Float16* A, const _Float16* B, float* out, int M, int N, int K) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)M * N) return;
@@ -61,7 +70,7 @@ const Variant vrc[] = {VR(128, 64, 2, 2), VR(128, 128, 4, 2), VR(256, 64, 4, 2),
                        VRN(256, 128, 4, 2, 3)};
 #define V(BM, BN, WM, WN) {#BM "x" #BN "/" #WM "x" #WN, BM, BN, hgemm_launch<BM, BN, WM, WN>}
 #define VN(BM, BN, WM, WN, NB) {#BM "x" #BN "/" #WM "x" #WN " n" #NB, BM, BN, hgemm_launch<BM, BN, WM, WN, false, NB>}
-const Variant vs[] = {V(128, 64, 2, 2), V(128, 128, 2, 2), V(128, 128, 4, 2), V(256, 64, 4, 2), V(256, 128, 4, 2), V(256, 256, 4, 2),
+const Variant vs[] = {{"8-phase 256x256", 256, 256, h8_adapter<0>}, {"8p agpr", 256, 256, h8_adapter<32>}, {"8p agpr noprio", 256, 256, h8_adapter<48>}, {"8p agpr noDMA", 256, 256, h8_adapter<33>}, {"8p agpr noLDS", 256, 256, h8_adapter<34>}, {"8p agpr noDMA noLDS", 256, 256, h8_adapter<35>}, {"8p noDMA", 256, 256, h8_adapter<1>}, {"8p noLDS", 256, 256, h8_adapter<2>}, {"8p noMFMA", 256, 256, h8_adapter<4>}, {"8p nowait", 256, 256, h8_adapter<8>}, {"8p noprio", 256, 256, h8_adapter<16>}, {"8p noDMA noLDS", 256, 256, h8_adapter<3>}, {"8p noDMA noMFMA", 256, 256, h8_adapter<5>}, {"8p noLDS noMFMA", 256, 256, h8_adapter<6>}, {"8p barriers only", 256, 256, h8_adapter<7>}, V(128, 64, 2, 2), V(128, 128, 2, 2), V(128, 128, 4, 2), V(256, 64, 4, 2), V(256, 128, 4, 2), V(256, 256, 4, 2),
                       V(256, 128, 2, 2), V(256, 256, 2, 2), V(512, 128, 4, 2), V(256, 128, 4, 1), V(512, 128, 4, 1),
                       VN(128, 64, 2, 2, 3), VN(128, 64, 2, 2, 4), VN(128, 128, 2, 2, 3), VN(128, 128, 2, 2, 4), VN(128, 128, 4, 2, 3), VN(128, 128, 4, 2, 4),
                       VN(256, 64, 4, 2, 3), VN(256, 64, 4, 2, 4), VN(256, 128, 4, 2, 3), VN(256, 256, 4, 2, 3) };
@@ -77,6 +86,7 @@ int main(int argc, char** argv) {
         {"cfg1 1024ch wgrad    px1024", 1024, 9216, 1024},
         {"ladder 1024->2048    px256", 256, 2048, 9216},
         {"square 4096", 4096, 4096, 4096},
+        {"square 8192", 8192, 8192, 8192},
         {"local128 as a dense GEMM (65536 px x 128 co, K = 9 x 128)", 65536, 128, 1152},
     };
     hipStream_t st; hipStreamCreate(&st);
@@ -105,6 +115,8 @@ int main(int argc, char** argv) {
                 if (sp > 1 && (chunks / sp < 4 || pr.M * (size_t)pr.N > (64u << 20))) continue;
                 const long long wgs = (long long)((pr.M + v.bm - 1) / v.bm) * (pr.N / v.bn) * sp;
                 if (wgs > 16384 || (sp > 1 && wgs > 2048) || (wgs < 64)) continue;
+                if (v.name[0] == '8' && sp > 1) continue;
+                if (getenv("HG_ONLY8") && !strstr(v.name, "8p") && !strstr(v.name, "8-phase")) continue;
                 HgArgs g{};
                 g.A = A; g.B = B; g.C = C; g.part = sp > 1 ? part : nullptr; g.bias = nullptr;
                 g.M = pr.M; g.N = pr.N; g.K = pr.K; g.lda = pr.K; g.ldb = pr.K;
@@ -139,6 +151,29 @@ int main(int argc, char** argv) {
                 printf("   %-18s splits %2d wgs %5lld  med %8.1f us  %7.1f TF  %6.2f TB/s  relerr %.1e%s\n", v.name, g.splits, wgs, ts[1],
                        flops / ts[1] / 1e6, bytes / ts[1] / 1e6, err, err > 1e-4f ? "  <-- WRONG" : "");
             }
+        }
+        if (getenv("HG_STAMPS") && pr.N % 256 == 0 && pr.M % 256 == 0) {
+            unsigned* dts; hipMalloc(&dts, 8 * 32 * 4);
+            auto dump = [&](const char* nm, void (*fn)(const Hg8Args&, hipStream_t)) {
+                hipMemsetAsync(dts, 0, 8 * 32 * 4, st);
+                Hg8Args a{};
+                a.A = A; a.B = B; a.C = C; a.bias = (const float*)dts; a.M = pr.M; a.N = pr.N; a.K = pr.K; a.lda = pr.K; a.ldb = pr.K; a.ldc = pr.N;
+                fn(a, st); fn(a, st);
+                unsigned h[8 * 32];
+                hipMemcpyAsync(h, dts, sizeof h, hipMemcpyDeviceToHost, st);
+                hipStreamSynchronize(st);
+                printf("   stamps %s (cycles since the K-tile's first stamp of wave 0; rows = waves 0, 1, 4, 5)\n", nm);
+                for (int w : {0, 1, 4, 5}) {
+                    printf("     w%d:", w);
+                    for (int i = 0; i < 23; ++i) printf(" %5d", (int)(h[w * 32 + i] - h[0]));
+                    printf("\n");
+                }
+            };
+            dump("full", hgemm8_launch<64>);
+            dump("noprio", hgemm8_launch<64 + 16>);
+            dump("noDMA", hgemm8_launch<64 + 1>);
+            dump("noDMA noprio", hgemm8_launch<64 + 1 + 16>);
+            hipFree(dts);
         }
         if (hgemm_as_ok(pr.M, pr.N, pr.K)) {
             const int tn = pr.N / 128, tmm = pr.M / 128;
