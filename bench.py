@@ -193,6 +193,43 @@ def cpu_baseline_train_cfg2(max_threads):
                       "max %.2f), scaled x1/8 to batch 8; %d threads (fixed; host has %d cores)" % (med, ts[0], ts[-1], threads, max_threads)}
 
 
+def _compact(d):
+    """A side line as embedded in the headline: without the per-symbol table and the long definition / sample strings (the driver
+    keeps the last 8 KB of stdout; round 4's configs[2] --fp16 value was pushed out of it).  The full line is what
+    `python bench.py --no-also <that configuration>` prints; the committed copies are under profiles/."""
+    d = {k: v for k, v in d.items() if k != "roofline_symbols"}
+    for key in ("roofline", "roofline_codec", "cpu_baseline"):
+        sub = d.get(key)
+        if isinstance(sub, dict):
+            d[key] = {k: v for k, v in sub.items() if not k.endswith("_definition") and k not in ("sample", "timed", "note")}
+        elif isinstance(sub, list):
+            d[key] = [{k: v for k, v in e.items() if not k.endswith("_definition") and k not in ("sample", "timed", "note")}
+                      if isinstance(e, dict) else e for e in sub]
+    cfg = d.get("config")
+    if isinstance(cfg, dict):
+        d["config"] = {k: v for k, v in cfg.items() if k != "steps_counted"}
+    return d
+
+
+def also_summary(also):
+    """The side lines' values once more, as the LAST key of the headline JSON (inside the final 500 characters of stdout)."""
+    out = {}
+    for d in also:
+        cmd = d.get("cmd", "")
+        if "error" in d:
+            out["error"] = (out.get("error", "") + " | " + cmd)[:120]
+        elif "--config 2" in cmd:
+            out["cfg2_fp16_steps_s"], out["cfg2_fp16_ms"] = d.get("value"), d.get("ms_per_step")
+        elif "--config 4" in cmd:
+            out["cfg4_audio_s_s"], out["cfg4_ms"] = d.get("value"), d.get("ms_per_step")
+            out["cfg4_frac"] = (d.get("roofline") or {}).get("frac")
+        elif "--mode codec" in cmd:
+            out["codec_clips_s"] = d.get("value")
+            rc = d.get("roofline")
+            out["codec_frac"] = rc.get("frac") if isinstance(rc, dict) else None
+    return out
+
+
 def also_lines(args):
     """The other BASELINE configurations as their own bench lines, each from a child process of this script (own model, own
     hipGraph, own roofline probe and cpu_baseline), embedded in the headline's JSON so that the driver's one command shows
@@ -209,7 +246,7 @@ def also_lines(args):
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
             line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
-            d = json.loads(line)
+            d = _compact(json.loads(line))
             d["wall_s"] = round(time.perf_counter() - t0, 1)
             d["cmd"] = label
         except Exception as e:      # the headline line must survive a failing side line
@@ -771,6 +808,7 @@ def main():
         del model
         torch.cuda.empty_cache()
         out["also"] = also_lines(args)
+        out["also_summary"] = also_summary(out["also"])
     # the JSON line must be the LAST thing on stdout: RCCL prints a version banner through C stdio, which a pipe only sees
     # when the library's buffer is flushed (normally at exit, i.e. after a line printed here)
     if use_ddp:

@@ -43,6 +43,8 @@ extern "C" {
 #define MG_ACT_LRELU02 2
 #define MG_ACT_TANH 3
 
+/* 3 since mg_mdct4_forward / mg_imdct4_forward take the factored DCT-IV image (dct4_image) in the middle of their argument lists: a
+   caller built against an older header must see a different number here before it passes `codec` where a pointer is expected */
 int mg_abi_version(void);
 /* sizeof(mg_conv_geom) as the library was built (13 ints = 52 bytes): a binding checks its own struct against it */
 int mg_conv_geom_size(void);

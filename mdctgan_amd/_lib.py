@@ -155,6 +155,9 @@ SIGNATURES = {
 _lib = None
 
 
+ABI_VERSION = 3       # include/mdctgan_hip.h: mg_abi_version (3: dct4_image in mg_mdct4_forward / mg_imdct4_forward)
+
+
 def load():
     """Load the shared library (once).  Raises HipLibraryError when it has not been built."""
     global _lib
@@ -174,6 +177,9 @@ def load():
         except AttributeError as e:
             raise HipLibraryError("libmdctgan_hip.so lacks symbol %s (stale build?)" % name) from e
         fn.restype, fn.argtypes = res, args
+    if lib.mg_abi_version() != ABI_VERSION:
+        raise HipLibraryError("libmdctgan_hip.so speaks C-ABI version %d, these bindings version %d (stale build: run "
+                              "`python -m mdctgan_amd.build`)" % (lib.mg_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 
@@ -195,7 +201,28 @@ def ptr(t):
     if not t.is_cuda:
         raise HipLibraryError("the MI355X hot path needs device tensors (got a %s tensor); "
                               "there is no CPU fallback" % t.device)
+    # the kernels address their operands densely: a strided view (a channel slice of an NHWC pair, say) must go through
+    # f32c() / .contiguous() first -- handing out its data_ptr would silently read the neighbouring elements
+    if not (t.is_contiguous() or _dense(t)):
+        raise HipLibraryError("the HIP kernels take dense tensors; got a strided view of shape %s, strides %s"
+                              % (tuple(t.shape), tuple(t.stride())))
     return t.data_ptr()
+
+
+def _dense(t):
+    if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+        return True
+    if t.dim() == 5 and t.is_contiguous(memory_format=torch.channels_last_3d):
+        return True
+    # any permutation of a dense block (NHWC views of channels_last storage and the like)
+    n, expect = t.numel(), 1
+    if n == 0:
+        return True
+    for size, stride in sorted(((s, st) for s, st in zip(t.shape, t.stride()) if s != 1), key=lambda p: p[1]):
+        if stride != expect:
+            return False
+        expect *= size
+    return True
 
 
 def stream():

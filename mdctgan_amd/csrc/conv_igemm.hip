@@ -2477,7 +2477,7 @@ size_t mg_conv_rowdot_wgrad_workspace(const mg_conv_geom* g);
 int mg_conv_rowdot_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias,
                          int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
-int mg_abi_version(void) { return 2; }
+int mg_abi_version(void) { return 3; }
 int mg_conv_geom_size(void) { return (int)sizeof(mg_conv_geom); }
 
 void mg_probe_arm(void* e0, void* e1) {

@@ -1,26 +1,29 @@
-// The f16 MFMA main loop, second generation: a 256 x BN x 64 workgroup tile run as a ping-pong between two groups of four waves.
+// The f16 MFMA main loop, second generation: a 256 x 256 x 64 workgroup tile run as a BALANCED ping-pong of two groups of four waves.
 //
-// dense_gemm_h.h's loop (one barrier per 64-deep chunk, all waves in lock step) leaves the matrix pipe idle whenever the waves of a
-// SIMD read fragments or wait for a chunk at the same time: 0.63-0.99 PFLOP/s on 4096^3.  Here the eight waves of a workgroup are two
-// groups (wave >> 2) that run ONE BARRIER APART: while group 0 multiplies (8 MFMAs = 256 cycles on its SIMD), group 1 -- the other
-// wave of every SIMD -- reads its next fragments from LDS and issues the next LDS-DMA pieces, and at the next barrier they swap.
-// A K-tile (64 halves) is four such phases, one 64 x 32 quadrant of the wave's 128 x 64 (BN = 256) results each:
-//     q0  read A-top (8 x ds_read_b128) + B-left (4)   -> (top, left)
-//     q1  read B-right (4)                             -> (top, right)
-//     q2  read A-bottom (8)                            -> (bottom, right)
-//     q3  --                                           -> (bottom, left)       (B-left stays in registers)
-// Operands are staged by LDS-DMA in HALF-tiles of 16 KiB (A-top / A-bottom = the 64-row halves of both groups' 128 rows, B-left /
-// B-right = the 32-column halves of the four column blocks), 2 pieces of 1 KiB per wave, one half-tile per phase, into two K-tile
-// buffers of 64 KiB.  A half-tile buffer is re-filled two phases after its last fragment read and read five phases after its issue:
-//     phase 4u + 0 issues B-right(u + 1), + 1: A-bottom(u + 1), + 2: A-top(u + 2), + 3: B-left(u + 2)
-// so four half-tiles (64 KiB) are always in flight per CU and the only wait is a counted `s_waitcnt vmcnt(8)` per phase (the
-// half-tile read in phase p + 1 is retired in phase p, one barrier before the first reader: the other group's pieces are waited for
-// one barrier later than ours).  LDS rows are 128 bytes, 16-byte slots XOR-swizzled on the DMA source side (slot ^ ((row >> 1) & 7)):
-// every 16-lane group of a ds_read_b128 covers all 64 banks once.
+// dense_gemm_h.h's loop (one barrier per 64-deep chunk: wait for the whole chunk, then every wave reads fragments, then multiplies)
+// tops out at 0.63-0.99 PFLOP/s on 4096^3.  Here the eight waves (2 x 4, 128 x 64 results each) are two groups (wave >> 2) that run
+// ONE BARRIER APART: while group 0 multiplies (8 MFMAs back to back = 256 cycles on its SIMD), group 1 -- the other wave of every
+// SIMD -- reads fragments and issues LDS-DMA, and at the next barrier they swap.  What makes it work is that the two kinds of slot
+// take the same time.  Measured (s_memtime stamps, scripts/ubench/h8pp.h): a wave issues one ds_read_b128 per ~20 cycles and one
+// LDS-DMA piece per ~65, so a load slot has room for SIX reads and TWO pieces against the partner's 256 MFMA cycles:
+//   * a K-tile (64 halves) is four phases, one 64 x 32 quadrant of the wave's results each: (top, left), (top, right), (bottom, right),
+//     (bottom, left).  Their fragments -- A-top 8 reads, B-left 4, B-right 4, A-bottom 8 -- are read six per load slot:
+//         slot 0: A-top[k-steps 1..3]            slot 1: B-right + A-bottom[k-step 0]
+//         slot 2: A-bottom[k-steps 1..3]         slot 3: B-left and A-top[k-step 0] of the NEXT K-tile
+//     (the first version read 12 / 4 / 8 / 0 and ran at 1.04-1.10 PF: the 12-read slot took 370+ cycles);
+//   * operands are staged in HALF-tiles of 16 KiB (A-top / A-bottom = the 64-row halves of both groups' 128 rows, B-left / B-right
+//     = the 32-column halves of the four wave columns), 2 pieces of 1 KiB per wave and phase, into 8 slots (two per kind):
+//     phase 4t + 0 issues A-bottom(t + 1), + 1: B-left(t + 2), + 2: A-top(t + 2), + 3: B-right(t + 2) -- every slot is re-filled two
+//     phases after its last fragment read and first read four to five phases after its issue, four half-tiles (64 KiB) are in flight
+//     per CU, and the only wait is a counted `s_waitcnt vmcnt(8)` (a half-tile is retired one phase before its first reader: the
+//     other group's pieces are waited for one barrier later than ours);
+//   * LDS rows are 128 bytes, 16-byte slots XOR-swizzled on the DMA source side (slot ^ ((row >> 1) & 7)): every 16-lane group of
+//     a ds_read_b128 covers all 64 banks once.
 //
 // C[M][N] (float32) = A[M][K] (float16) * B[N][K]^T (float16); K % 64 == 0, K >= 128.  Included inside the anonymous namespace after
 // dense_gemm.h / dense_gemm_h.h.
 #pragma once
+#include <type_traits>
 
 struct Hg8Args {
     const void* A;           // float16 [M][lda]
@@ -33,19 +36,14 @@ struct Hg8Args {
     int accumulate;          // C += result
 };
 
-// LDS byte offsets inside a K-tile buffer
-constexpr unsigned H8_AT = 0, H8_AB = 16384, H8_BL = 32768, H8_BR = 49152, H8_BUF = 65536;
+// half-tile kinds: slot of (K-tile t, kind) = 4 (t & 1) + kind
+enum { H8_BL = 0, H8_AT = 1, H8_BR = 2, H8_AB = 3 };
+constexpr unsigned H8_SLOT = 16384, H8_LDS = 8 * H8_SLOT;
 
 template <int N>
 __device__ __forceinline__ void h8_wait_raw() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int DBG>
-struct h8_wait_sel {
-    template <int N>
-    static __device__ __forceinline__ void go() { if (!(DBG & 8)) h8_wait_raw<N>(); }
-};
-// DBG (ubench ablations only; results are wrong): 1 no DMA in the main loop, 2 no fragment reads, 4 no MFMAs, 8 no counted waits,
-// 16 no priority flips
+// DBG (ubench ablations only; results are wrong): 1 no DMA in the main loop, 2 no fragment reads, 4 no MFMAs, 8 no counted waits
 template <int DBG = 0>
 __global__ __launch_bounds__(512) void hgemm8_kernel(Hg8Args g) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -97,20 +95,13 @@ __global__ __launch_bounds__(512) void hgemm8_kernel(Hg8Args g) {
     }
     const unsigned half_a = 64u * (unsigned)g.lda * 2u, half_b = 32u * (unsigned)g.ldb * 2u;
     const unsigned lds0 = (unsigned)(size_t)(dg_lds_ptr)h8_smem + (unsigned)wave * 2048u;
-    // kind: 0 A-top, 1 A-bottom, 2 B-left, 3 B-right of K-tile t
-    auto issue = [&](int kind, int t) {
+    // piece i (0 / 1) of half-tile (K-tile t, kind); par = t & 1
+    auto issue = [&](int t, int par, int kind, int i) {
         if ((DBG & 1) && t >= 2) return;
-        const unsigned dst = lds0 + (unsigned)(t & 1) * H8_BUF + (unsigned)kind * 16384u;
-        const unsigned koff = (unsigned)t * 128u;
-        if (kind < 2) {
-            const unsigned so = koff + (kind == 1 ? half_a : 0u);
-            dg_dma16(va[0], ra, dst, so);
-            dg_dma16(va[1], ra, dst + 1024u, so);
-        } else {
-            const unsigned so = koff + (kind == 3 ? half_b : 0u);
-            dg_dma16(vb[0], rb, dst, so);
-            dg_dma16(vb[1], rb, dst + 1024u, so);
-        }
+        const unsigned dst = lds0 + (unsigned)(4 * par + kind) * H8_SLOT + 1024u * (unsigned)i;
+        const unsigned koff = t < T ? (unsigned)t * 128u : 0x80000000u;      // the padding K-tile of an odd K / 64 reads zeros
+        if (kind == H8_AT || kind == H8_AB) dg_dma16(va[i], ra, dst, (unsigned)__builtin_amdgcn_readfirstlane((int)(koff + (kind == H8_AB ? half_a : 0u))));
+        else dg_dma16(vb[i], rb, dst, (unsigned)__builtin_amdgcn_readfirstlane((int)(koff + (kind == H8_BR ? half_b : 0u))));
     };
 
     f32x16 acc[4][2];
@@ -118,140 +109,146 @@ __global__ __launch_bounds__(512) void hgemm8_kernel(Hg8Args g) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
-#define h8_wait h8_wait_sel<DBG>::template go
 
     const int r = lane & 31, kh = lane >> 5, x = (r >> 1) & 7;
-    // fragment addresses: lane part per k-step s (the swizzled slot), the rest is wave-uniform
-    unsigned fo[4];
+    // fragment addresses: per k-step s one register for A and one for B (lane part = the swizzled slot, plus the wave's rows); the
+    // K-tile parity (64 KiB) and the half-tile kind are immediate offsets
+    unsigned fa[4], fb[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) fo[s] = (unsigned)r * 128u + 16u * (unsigned)((2 * s + kh) ^ x);
-    const unsigned a_w = (unsigned)wr * 8192u, b_w = (unsigned)wc * 4096u;
-    const char* smem = reinterpret_cast<const char*>(h8_smem);
-
-    f16x8 a[2][4], bl[4], br[4];
-    auto read_a = [&](unsigned base) {      // base: buffer + H8_AT / H8_AB
-        if ((DBG & 2) && g.K > 0) return;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) a[mi][s] = *reinterpret_cast<const f16x8*>(smem + base + a_w + 4096u * mi + fo[s]);
+    for (int s = 0; s < 4; ++s) {
+        const unsigned fo = (unsigned)r * 128u + 16u * (unsigned)((2 * s + kh) ^ x);
+        fa[s] = fo + (unsigned)wr * 8192u;
+        fb[s] = fo + (unsigned)wc * 4096u;
+    }
+    // (dynamic LDS starts at address 0 of the workgroup's allocation -- the kernel has no static __shared__ -- so the addresses are
+    // used as they are: going through the h8_smem pointer costs a v_add of zero per read, in the slot that has no time to spare)
+    typedef f16x8 __attribute__((address_space(3))) * h8_frag_ptr;
+    auto frag_a = [&](int par, int kind, int mi, int s) -> f16x8 {
+        return *(h8_frag_ptr)(size_t)(fa[s] + (unsigned)(4 * par + kind) * H8_SLOT + 4096u * mi);
     };
-    auto read_b = [&](f16x8 (&b)[4], unsigned base) {
-        if ((DBG & 2) && g.K > 0) return;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) b[s] = *reinterpret_cast<const f16x8*>(smem + base + b_w + fo[s]);
-    };
-    auto mma = [&](int row2, int col, const f16x8 (&b)[4]) {
-        if ((DBG & 4) && g.K > 0) return;
-        if (!(DBG & 16)) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                if constexpr (DBG & 32) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[row2 + mi][col]) : "v"(a[mi][s]), "v"(b[s]));
-                else acc[row2 + mi][col] = mfma32x32x16h(a[mi][s], b[s], acc[row2 + mi][col]);
-            }
-        if (!(DBG & 16)) __builtin_amdgcn_s_setprio(0);
-    };
+    auto frag_b = [&](int par, int kind, int s) -> f16x8 { return *(h8_frag_ptr)(size_t)(fb[s] + (unsigned)(4 * par + kind) * H8_SLOT); };
+    // (the second K-tile parity is 64 KiB away, beyond a ds_read's 16-bit offset: the compiler keeps a second set of eight address
+    // registers for it.  Toggling one set instead costs eight VALU operations per K-tile, and a VALU operation between two MFMAs of a
+    // back-to-back stream costs ~40 cycles of the matrix pipe: measured 1.25 -> 1.13 PF)
 
-    // ---- prologue: the six half-tiles phases -6 .. -1 would have issued
-    issue(0, 0); issue(2, 0); issue(3, 0); issue(1, 0); issue(0, 1); issue(2, 1);
-    h8_wait<8>();                                   // A-top(0), B-left(0) have landed
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();      // group 1 runs one barrier behind
-    __builtin_amdgcn_sched_barrier(0);
+    // Registers: a[mi][s] holds A-top, then (k-steps 1..3) A-bottom; y0[mi] the k-step 0 fragments of A-bottom, which are read while
+    // A-top is still in use.  B-left of K-tile t lives in b[t & 1], B-right in b[(t & 1) ^ 1]: B-left(t + 1) is read into the registers
+    // B-right(t) has just left.
+    f16x8 a[2][4], y0[2], b[2][4];
 
-    // One K-tile = four phases.  ISS: how many of this K-tile's four issues exist (4: all, 2: only q0 / q1, 0: none);
-    // W0..W3: the vmcnt each phase leaves outstanding (-1: no wait).
-    unsigned ts[28];
-#pragma unroll
-    for (int i = 0; i < 28; ++i) ts[i] = 0;
-#define H8_TS(i) do { if constexpr (DBG & 64) { if (u == T / 2) ts[i] = (unsigned)__builtin_amdgcn_s_memtime(); } } while (0)
 #define H8_PHASE_END()                     \
     __builtin_amdgcn_sched_barrier(0);     \
     __builtin_amdgcn_s_barrier();          \
     __builtin_amdgcn_sched_barrier(0)
-    auto ktile = [&](int u, auto iss_c, auto w0_c, auto w1_c, auto w3_c) {
-        constexpr int ISS = decltype(iss_c)::value, W0 = decltype(w0_c)::value, W1 = decltype(w1_c)::value, W3 = decltype(w3_c)::value;
-        const unsigned buf = (unsigned)(u & 1) * H8_BUF;
-        // q0
-        H8_TS(0);
-        read_b(bl, buf + H8_BL);
-        read_a(buf + H8_AT);
+    const bool no_lds = (DBG & 2) && g.K > 0, no_mma = (DBG & 4) && g.K > 0;
+    // One K-tile of parity PAR.  MODE 0: steady state; 1: K-tile T - 2 (only A-bottom(T - 1) is still to issue); 2: K-tile T - 1.
+    auto ktile = [&](int t, auto par_c, auto mode_c) {
+        constexpr int PAR = decltype(par_c)::value, MODE = decltype(mode_c)::value;
+        // ---- phase 0: (top, left)
+        if (!no_lds) {
+#pragma unroll
+            for (int s = 1; s < 4; ++s)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) a[mi][s] = frag_a(PAR, H8_AT, mi, s);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        H8_TS(1);
-        if (ISS >= 2) issue(3, u + 1);
-        H8_TS(2);
-        h8_wait<W0>();
-        H8_TS(3);
+        if (MODE <= 1) { issue(t + 1, PAR ^ 1, H8_AB, 0); issue(t + 1, PAR ^ 1, H8_AB, 1); }
+        if (!(DBG & 8)) h8_wait_raw<(MODE == 2 ? 0 : 8)>();           // B-right(t), A-bottom(t)
         H8_PHASE_END();
-        H8_TS(4);
-        mma(0, 0, bl);
-        H8_TS(5);
+        if (!no_mma) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) acc[mi][0] = mfma32x32x16h(a[mi][s], b[PAR][s], acc[mi][0]);
+        }
         H8_PHASE_END();
-        H8_TS(6);
-        // q1
-        read_b(br, buf + H8_BR);
+        // ---- phase 1: (top, right)
+        if (!no_lds) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) b[PAR ^ 1][s] = frag_b(PAR, H8_BR, s);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) y0[mi] = frag_a(PAR, H8_AB, mi, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        H8_TS(7);
-        if (ISS >= 2) issue(1, u + 1);
-        H8_TS(8);
-        h8_wait<W1>();
-        H8_TS(9);
+        if (MODE == 0) { issue(t + 2, PAR, H8_BL, 0); issue(t + 2, PAR, H8_BL, 1); }
         H8_PHASE_END();
-        H8_TS(10);
-        mma(0, 1, br);
-        H8_TS(11);
+        if (!no_mma) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) acc[mi][1] = mfma32x32x16h(a[mi][s], b[PAR ^ 1][s], acc[mi][1]);
+        }
         H8_PHASE_END();
-        H8_TS(12);
-        // q2 (nothing is read in q3, so nothing to retire here)
-        read_a(buf + H8_AB);
+        // ---- phase 2: (bottom, right)
+        if (!no_lds) {
+#pragma unroll
+            for (int s = 1; s < 4; ++s)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) a[mi][s] = frag_a(PAR, H8_AB, mi, s);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        H8_TS(13);
-        if (ISS >= 4) issue(0, u + 2);
-        H8_TS(14);
+        if (MODE == 0) { issue(t + 2, PAR, H8_AT, 0); issue(t + 2, PAR, H8_AT, 1); }
+        if (MODE <= 1 && !(DBG & 8)) h8_wait_raw<(MODE == 0 ? 8 : 4)>();   // B-left(t + 1), A-top(t + 1)
         H8_PHASE_END();
-        H8_TS(15);
-        mma(2, 1, br);
-        H8_TS(16);
+if (!no_mma) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) acc[2 + mi][1] = mfma32x32x16h(s == 0 ? y0[mi] : a[mi][s], b[PAR ^ 1][s], acc[2 + mi][1]);
+        }
         H8_PHASE_END();
-        H8_TS(17);
-        // q3
-        if (ISS >= 4) issue(2, u + 2);
-        H8_TS(18);
-        if (W3 >= 0) h8_wait<(W3 >= 0 ? W3 : 0)>();
-        H8_TS(19);
+        // ---- phase 3: (bottom, left); the load slot fetches the first fragments of K-tile t + 1
+        if (MODE <= 1 && !no_lds) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) b[PAR ^ 1][s] = frag_b(PAR ^ 1, H8_BL, s);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) a[mi][0] = frag_a(PAR ^ 1, H8_AT, mi, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (MODE == 0) { issue(t + 2, PAR, H8_BR, 0); issue(t + 2, PAR, H8_BR, 1); }
         H8_PHASE_END();
-        H8_TS(20);
-        mma(2, 0, bl);
-        H8_TS(21);
+        if (!no_mma) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) acc[2 + mi][0] = mfma32x32x16h(s == 0 ? y0[mi] : a[mi][s], b[PAR][s], acc[2 + mi][0]);
+        }
         H8_PHASE_END();
-        H8_TS(22);
     };
     using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
-    using I4 = std::integral_constant<int, 4>;
-    using I8 = std::integral_constant<int, 8>;
-    for (int u = 0; u < T - 2; ++u) ktile(u, I4{}, I8{}, I8{}, I8{});
-    // K-tile T - 2: B-right / A-bottom of the last tile are still to issue; at q3 A-top / B-left of the last tile must have
-    // landed with only those two behind them
-    ktile(T - 2, I2{}, I8{}, I8{}, I4{});
-    // K-tile T - 1: q0 retires B-right (A-bottom behind it), q1 retires A-bottom
-    ktile(T - 1, I0{}, I2{}, I0{}, std::integral_constant<int, -1>{});
-#undef H8_PHASE_END
-#undef H8_TS
-    if constexpr (DBG & 64) {
-        if (blockIdx.x == 8 && lane == 0 && g.bias) {
-            unsigned* o = (unsigned*)g.bias + wave * 32;
+
+    // ---- prologue: the seven half-tiles phases -7 .. -1 would have issued, then the fragments phase -1 would have read
 #pragma unroll
-            for (int i = 0; i < 28; ++i) o[i] = ts[i];
-        }
+    for (int j = 0; j < 7; ++j) { issue(j >> 2, j >> 2, j & 3, 0); issue(j >> 2, j >> 2, j & 3, 1); }
+    h8_wait_raw<10>();                              // B-left(0), A-top(0) have landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) b[0][s] = frag_b(0, H8_BL, s);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) a[mi][0] = frag_a(0, H8_AT, mi, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 1) __builtin_amdgcn_s_barrier();      // group 1 runs one barrier behind
+    __builtin_amdgcn_sched_barrier(0);
+
+    // an odd number of K-tiles runs one more, which reads zeros (see issue): the loop body is two K-tiles (the B register sets swap roles)
+    const int Te = T + (T & 1);
+    unsigned long long tc0 = 0, tc1 = 0;
+    if constexpr (DBG & 64) tc0 = __builtin_amdgcn_s_memtime();
+    int t = 0;
+    for (; t < Te - 2; t += 2) {
+        ktile(t, I0{}, I0{});
+        ktile(t + 1, I1{}, I0{});
     }
-#undef h8_wait
+    ktile(t, I0{}, I1{});
+    ktile(t + 1, I1{}, I2{});
+#undef H8_PHASE_END
     if (wr == 0) __builtin_amdgcn_s_barrier();      // pairs with group 1's last barrier
+    if constexpr (DBG & 64) tc1 = __builtin_amdgcn_s_memtime();
 
     // ---- epilogue
-    if constexpr (DBG & 32) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");     // asm MFMAs: the compiler does not know their latency
     const bool rnd = g.round_f16 != 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -271,6 +268,12 @@ __global__ __launch_bounds__(512) void hgemm8_kernel(Hg8Args g) {
                 }
             }
         }
+    if constexpr (DBG & 64) {
+        if (lane == 0 && wave == 0 && g.bias) {
+            unsigned long long* o = (unsigned long long*)g.bias + 4 * blockIdx.x;
+            o[0] = tc0; o[1] = tc1; o[2] = __builtin_amdgcn_s_memtime();
+        }
+    }
 #endif
 }
 
@@ -283,8 +286,8 @@ inline void hgemm8_launch(const Hg8Args& a0, hipStream_t st) {
     a.tiles_n = (a.N + 255) / 256;
     static bool once = false;
     if (!once) {
-        hipFuncSetAttribute((const void*)hgemm8_kernel<DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * H8_BUF));
+        (void)hipFuncSetAttribute((const void*)hgemm8_kernel<DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H8_LDS);
         once = true;
     }
-    mg_launch(hgemm8_kernel<DBG>, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), (size_t)(2 * H8_BUF), st, a);
+    mg_launch(hgemm8_kernel<DBG>, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), (size_t)H8_LDS, st, a);
 }

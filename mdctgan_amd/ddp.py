@@ -18,6 +18,7 @@ ranks (call it before saving a checkpoint so rank 0's file does not carry rank-0
 from __future__ import annotations
 
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -183,21 +184,42 @@ def broadcast_arena(flat_p, src=0, group=None):
         dist.broadcast(flat_p, src=src, group=group)
 
 
-SHARD_MIN_PARAMS = 64 << 20      # elements of one optimiser's arena from which "sharded" becomes the default at world >= 4
+SHARD_MIN_PARAMS = 64 << 20      # elements of one optimiser's arena from which MDCTGAN_DDP_MODE=auto picks "sharded" at world >= 4
 
 
 def default_mode(world, n_params):
-    """The reduction mode when MDCTGAN_DDP_MODE is unset.  Rule: "sharded" (reduce-scatter, Adam on 1/world of the arena,
-    all-gather of the updated parameters) when world >= 4 AND the arena holds >= 64 Mi parameters; "allreduce" otherwise.
-    Why: both move the same bytes over xGMI, but the Adam kernel streams 28 B (float32) / 30 B (--fp16 shadow) per parameter at
-    ~4.9 TB/s and is a serial tail after backward -- configs[3]'s generator (736 M parameters) pays 4.6 ms of it per step and
-    rank, 0.6 ms at world 8 when sharded; the price is one found_inf MAX-agreement (--fp16) and a parameter all-gather that is
-    left running under the discriminator's backward pass.  Below 64 Mi parameters (every discriminator: 5.5 / 8.3 M) the whole
-    Adam launch is < 0.4 ms and not worth a second collective per bucket; at world 2 the saving is at most half of it."""
+    """The reduction mode when MDCTGAN_DDP_MODE is unset: "allreduce", always.
+    MDCTGAN_DDP_MODE=auto applies the size rule instead -- "sharded" (reduce-scatter, Adam on 1/world of the arena, all-gather of
+    the updated parameters) when world >= 4 AND the arena holds >= 64 Mi parameters: both modes move the same bytes over xGMI, but
+    the Adam kernel streams 28 B (float32) / 30 B (--fp16 shadow) per parameter and is a serial tail after backward -- configs[3]'s
+    generator (736 M parameters) pays 4.6 ms of it per step and rank, 0.6 ms at world 8 when sharded.  The rule is NOT the default:
+    the sharded path (found_inf MAX agreement, asynchronous parameter all-gather left running under the discriminator's backward
+    pass, shadow re-sync) has only ever run over gloo and with a 1-rank RCCL group; until a world >= 4 RCCL run has shown loss and
+    parameter equality against "allreduce" it stays opt-in.  Whatever the mode, attach() cross-checks a parameter
+    checksum over the ranks after each of the first steps (MDCTGAN_DDP_CHECK_STEPS, default 3)."""
     env = os.environ.get("MDCTGAN_DDP_MODE")
-    if env:
+    if env and env != "auto":
         return env
-    return "sharded" if (world >= 4 and n_params >= SHARD_MIN_PARAMS) else "allreduce"
+    if env == "auto":
+        return "sharded" if (world >= 4 and n_params >= SHARD_MIN_PARAMS) else "allreduce"
+    return "allreduce"
+
+
+def check_replicas(flat_p, group=None, what="parameters"):
+    """Cross-rank agreement of a parameter arena: every rank's (sum, sum of squares) in float64 must equal rank 0's bit for bit
+    (identical weights, identical kernel, identical reduction order).  Raises on the first divergent step instead of letting the
+    replicas drift apart silently."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    d = flat_p.double()
+    mine = torch.stack([d.sum(), (d * d).sum()])
+    ref = mine.clone()
+    dist.broadcast(ref, src=0, group=group)
+    bad = (mine != ref).any().float()
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+    if float(bad) != 0.0:
+        raise RuntimeError("data-parallel replicas diverged: the %s checksum of rank %d differs from rank 0's (%r vs %r)"
+                           % (what, dist.get_rank(group), mine.tolist(), ref.tolist()))
 
 
 def attach_optimizer(opt, writes_per_step=1, bucket_bytes=128 << 20, group=None):
@@ -208,7 +230,10 @@ def attach_optimizer(opt, writes_per_step=1, bucket_bytes=128 << 20, group=None)
     broadcast_arena(opt.flat_p, 0, group)
     opt.resync_shadow()        # --fp16: the float16 shadow was cast from the PRE-broadcast weights
     n_params = sum(n for _, _, n in slices)
-    red = ArenaReducer(opt.flat_g, slices, writes_per_step, bucket_bytes, group, mode=default_mode(world, n_params))
+    mode = default_mode(world, n_params)
+    if world > 1 and (not dist.is_initialized() or dist.get_rank(group) == 0):
+        print("[mdctgan_amd.ddp] %d ranks, %.1f M parameters: gradient reduction mode %r" % (world, n_params / 1e6, mode), file=sys.stderr, flush=True)
+    red = ArenaReducer(opt.flat_g, slices, writes_per_step, bucket_bytes, group, mode=mode)
     red.bucket_bytes = bucket_bytes
     opt.grad_scale = 1.0 / world
     opt.pre_step_hook = red.finish
@@ -274,6 +299,7 @@ def attach(model, bucket_bytes=None, group=None):
             dist.broadcast(t, src=0, group=group)
     reducers["D"].active = False
     model.reducers = reducers
+    model.ddp_check_steps = int(os.environ.get("MDCTGAN_DDP_CHECK_STEPS", "3"))      # see check_replicas
     if os.environ.get("MDCTGAN_SYNC_BN", "0") == "1" and dist.is_initialized():
         enable_sync_batchnorm(group)
     return reducers

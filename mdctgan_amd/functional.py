@@ -89,6 +89,7 @@ def mark_fresh(params):
     for p in params:
         p._mg_fresh = True
         p._mg_inf_checked = False
+        p._mg_fused_stamp = None        # a backward pass that was never followed by optimizer.step() must not poison the next one
 
 
 # A bias added right before InstanceNorm2d(affine=False) is removed again by the mean subtraction: its gradient is
@@ -236,10 +237,11 @@ def _wgrad_fused(ctx_u, g, weight, x, gy, v, md):
     # One Adam update per weight and optimiser step: a module applied twice in one forward whose weight was not annotated
     # with _mg_writes = 2 would otherwise be stepped twice from the same bias-correction terms, with U rewritten between the
     # two data gradients.  opt._step is the host's count of optimizer.step() calls.
-    if getattr(weight, "_mg_fused_stamp", None) == opt._step:
+    stamp = (id(opt), opt._step)      # (a rebuilt optimiser restarts _step at 0: the identity keeps its first step from matching a stale stamp)
+    if getattr(weight, "_mg_fused_stamp", None) == stamp:
         raise RuntimeError("a weight whose gradient, Adam update and transform are fused received a second gradient "
                            "contribution in one backward pass: set weight._mg_writes = <uses per forward> on shared modules")
-    weight._mg_fused_stamp = opt._step
+    weight._mg_fused_stamp = stamp
     grp = opt.param_groups[0]
     (b1, b2), eps = grp["betas"], grp["eps"]
     opt.sync_lr()

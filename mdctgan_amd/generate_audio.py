@@ -59,7 +59,7 @@ def generate(model, lr_segments: torch.Tensor, batch_size: int = 64, gen_overlap
         with torch.no_grad():
             for i in range(0, lr_segments.shape[0], batch_size):
                 if fused:
-                    model.inference(lr_segments[i:i + batch_size], stitch=(out, gen_overlap, i))
+                    model.inference(lr_segments[i:i + batch_size], stitch=(out, gen_overlap, i, seg_len))
                 else:
                     _, sr_audio, _, _, _ = model.inference(lr_segments[i:i + batch_size])
                     outs.append(sr_audio)

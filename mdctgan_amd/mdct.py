@@ -210,7 +210,10 @@ def mdct4_codec(audio, window, dct4, n_fft, *, codec=_lib.MG_CODEC_RAW, gain=1.0
     import os
     legacy = os.environ.get("MG_MDCT_BS") == "0" or "MG_MDCT_GEMM" in os.environ or "MG_MDCT_FT" in os.environ      # (ablation switches)
     pair_only = (want_pair and image is not None and not per_sample and not want_frames and codec == _lib.MG_CODEC_ARCSINH
-                 and T % 4 == 0 and audio.data_ptr() % 16 == 0 and window.data_ptr() % 16 == 0 and not legacy)
+                 and T % 4 == 0 and audio.data_ptr() % 16 == 0 and window.data_ptr() % 16 == 0 and not legacy
+                 # the factored kernels address through 32-bit buffer offsets (csrc/mdct.hip: the same guards decide there);
+                 # beyond them the dense-table kernel runs and needs a real spectrogram buffer
+                 and B * F * M * 8 < (1 << 32) - (1 << 18) and B * T * 4 < (1 << 32))
     spec = pair[..., 0] if pair_only else torch.empty(B, F, M, dtype=torch.float32, device=dev)
     frames = torch.empty(B, F, n_fft, dtype=torch.float32, device=dev) if want_frames else None
     stats = torch.empty(2, dtype=torch.float64, device=dev) if want_stats else None
@@ -232,7 +235,7 @@ def imdct4_codec(spec, window, dct4, n_fft, *, codec=_lib.MG_CODEC_RAW, gain=1.0
                  want_frames=False, stitch=None):
     """K2 launcher.  spec [B, F, M] (device) -> (audio [B, T_out], frames|None).
 
-    stitch = (out, gen_overlap, first_seg): the clips are segments first_seg.. of ONE waveform and K2's overlap-add store writes them
+    stitch = (out, gen_overlap, first_seg[, segment_length]): the clips are segments first_seg.. of ONE waveform and K2's overlap-add store writes them
     straight into `out` [mg_stitch_length(n_seg, T_out, gen_overlap)] with generate_audio.py:40-53's cross-fade (mg_imdct4_stitched);
     returns (out, None).  The batch with first_seg == 0 clears `out` when gen_overlap > 0."""
     lib = _lib.load()
@@ -242,7 +245,12 @@ def imdct4_codec(spec, window, dct4, n_fft, *, codec=_lib.MG_CODEC_RAW, gain=1.0
     if out_length is not None:
         t_out = min(t_out, int(out_length))
     if stitch is not None:
-        out, overlap, first = stitch
+        out, overlap, first = stitch[:3]
+        if len(stitch) > 3 and int(stitch[3]) != t_out:
+            # the caller sized `out` for segments of stitch[3] samples; the spectrogram handed in decodes to t_out: the store's
+            # bounds check would drop samples or leave part of `out` unwritten without a word
+            raise ValueError("stitched K2: the output was sized for %d-sample segments, the spectrogram decodes to %d"
+                             % (int(stitch[3]), t_out))
         if want_frames or out.dtype != out_dtype or not out.is_contiguous():
             raise ValueError("stitched K2: contiguous output of the requested dtype, no synthesis frames")
         if min_b is not None:

@@ -456,6 +456,13 @@ class Pix2PixHDModel(BaseModel):
             else:
                 loss_D.backward(**d_kw)
                 self.optimizer_D.step()
+        if red and getattr(self, "ddp_check_steps", 0) > 0 and not torch.cuda.is_current_stream_capturing():
+            # the first data-parallel steps: every rank's parameter arenas must equal rank 0's bit for bit (ddp.check_replicas)
+            from . import ddp
+            self.ddp_check_steps -= 1
+            self._finish_pending()
+            ddp.check_replicas(self.optimizer_G.flat_p, red["G"].group, "generator")
+            ddp.check_replicas(self.optimizer_D.flat_p, red["D"].group, "discriminator")
         # detached: the caller only prints / logs these; handing out the graph would keep one generator's worth of
         # saved activations alive until the next iteration overwrites the dict
         return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss_dict.items()}

@@ -13,8 +13,8 @@ inline void mg_launch(KernelT kern, dim3 grid, dim3 block, size_t lds, hipStream
 }
 #include "dense_gemm.h"
 #include "dense_gemm_h.h"
-#include <type_traits>
 #include "dense_gemm_h8.h"
+#include "h8pp.h"
 
 __global__ void ref_kernel(const _Float16* A, const _Float16* B, float* out, int M, int N, int K, int lda, int ldb) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -29,6 +29,13 @@ __global__ void fill_h(_Float16* p, size_t n, unsigned seed) {
         unsigned x = (unsigned)i * 2654435761u + seed;
         x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
         p[i] = (_Float16)(((float)(x & 0xffffff) / 8388608.0f) - 1.0f);
+    }
+}
+// HG_DATA=zero | relu (half the values zero, the rest uniform in [0, 1)) | small (uniform * 2^-6): what the DVFS governor does with the data
+__global__ void refill_h(_Float16* p, size_t n, int mode) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = (float)p[i];
+        p[i] = (_Float16)(mode == 0 ? 0.0f : mode == 1 ? (v > 0.0f ? v : 0.0f) : v * 0.015625f);
     }
 }
 __global__ void maxdiff_kernel(const float* a, const float* b, size_t n, float* out) {
@@ -47,6 +54,8 @@ __global__ void reduce_kernel(const float* part, int S, size_t n, float* out) {
         *(float4*)(out + 4 * i) = s;
     }
 }
+template <int DBG>
+void hpp_adapter(const HgArgs& g, hipStream_t st);
 struct Variant { const char* name; int bm, bn; void (*launch)(const HgArgs&, hipStream_t); };
 template <int DBG>
 void h8_adapter(const HgArgs& g, hipStream_t st) {
@@ -54,6 +63,13 @@ void h8_adapter(const HgArgs& g, hipStream_t st) {
     a.A = g.A; a.B = g.B; a.C = g.part ? g.part : g.C; a.bias = nullptr;
     a.M = g.M; a.N = g.N; a.K = g.K; a.lda = g.lda; a.ldb = g.ldb; a.ldc = g.N;
     hgemm8_launch<DBG>(a, st);
+}
+template <int DBG>
+void hpp_adapter(const HgArgs& g, hipStream_t st) {
+    HppArgs a{};
+    a.A = g.A; a.B = g.B; a.C = g.part ? g.part : g.C; a.bias = nullptr;
+    a.M = g.M; a.N = g.N; a.K = g.K; a.lda = g.lda; a.ldb = g.ldb; a.ldc = g.N;
+    hpp_launch<DBG>(a, st);
 }
 __global__ void ref_rc_kernel(const _Float16* A, const _Float16* B, float* out, int M, int N, int K) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -70,7 +86,7 @@ const Variant vrc[] = {VR(128, 64, 2, 2), VR(128, 128, 4, 2), VR(256, 64, 4, 2),
                        VRN(256, 128, 4, 2, 3)};
 #define V(BM, BN, WM, WN) {#BM "x" #BN "/" #WM "x" #WN, BM, BN, hgemm_launch<BM, BN, WM, WN>}
 #define VN(BM, BN, WM, WN, NB) {#BM "x" #BN "/" #WM "x" #WN " n" #NB, BM, BN, hgemm_launch<BM, BN, WM, WN, false, NB>}
-const Variant vs[] = {{"8-phase 256x256", 256, 256, h8_adapter<0>}, {"8p agpr", 256, 256, h8_adapter<32>}, {"8p agpr noprio", 256, 256, h8_adapter<48>}, {"8p agpr noDMA", 256, 256, h8_adapter<33>}, {"8p agpr noLDS", 256, 256, h8_adapter<34>}, {"8p agpr noDMA noLDS", 256, 256, h8_adapter<35>}, {"8p noDMA", 256, 256, h8_adapter<1>}, {"8p noLDS", 256, 256, h8_adapter<2>}, {"8p noMFMA", 256, 256, h8_adapter<4>}, {"8p nowait", 256, 256, h8_adapter<8>}, {"8p noprio", 256, 256, h8_adapter<16>}, {"8p noDMA noLDS", 256, 256, h8_adapter<3>}, {"8p noDMA noMFMA", 256, 256, h8_adapter<5>}, {"8p noLDS noMFMA", 256, 256, h8_adapter<6>}, {"8p barriers only", 256, 256, h8_adapter<7>}, V(128, 64, 2, 2), V(128, 128, 2, 2), V(128, 128, 4, 2), V(256, 64, 4, 2), V(256, 128, 4, 2), V(256, 256, 4, 2),
+const Variant vs[] = {{"8-phase 256x256", 256, 256, h8_adapter<0>}, {"8p noDMA", 256, 256, h8_adapter<1>}, {"8p noLDS", 256, 256, h8_adapter<2>}, {"8p noMFMA", 256, 256, h8_adapter<4>}, {"8p nowait", 256, 256, h8_adapter<8>}, {"8p noDMA noLDS", 256, 256, h8_adapter<3>}, {"8p barriers only", 256, 256, h8_adapter<7>}, {"8pp pingpong", 256, 256, hpp_adapter<16>}, {"8pp balanced6", 256, 256, hpp_adapter<16 + 128>}, {"8pp balanced6 noDMA", 256, 256, hpp_adapter<16 + 128 + 1>}, {"8pp balanced6 nowait", 256, 256, hpp_adapter<16 + 128 + 8>}, V(128, 64, 2, 2), V(128, 128, 2, 2), V(128, 128, 4, 2), V(256, 64, 4, 2), V(256, 128, 4, 2), V(256, 256, 4, 2),
                       V(256, 128, 2, 2), V(256, 256, 2, 2), V(512, 128, 4, 2), V(256, 128, 4, 1), V(512, 128, 4, 1),
                       VN(128, 64, 2, 2, 3), VN(128, 64, 2, 2, 4), VN(128, 128, 2, 2, 3), VN(128, 128, 2, 2, 4), VN(128, 128, 4, 2, 3), VN(128, 128, 4, 2, 4),
                       VN(256, 64, 4, 2, 3), VN(256, 64, 4, 2, 4), VN(256, 128, 4, 2, 3), VN(256, 256, 4, 2, 3) };
@@ -102,6 +118,11 @@ int main(int argc, char** argv) {
         hipMalloc(&part, nc * 4 * (pr.M * (size_t)pr.N > (64u << 20) ? 1 : max_splits));
         fill_h<<<1024, 256, 0, st>>>(A, na, 1u);
         for (int i = 0; i < nrot; ++i) fill_h<<<1024, 256, 0, st>>>(B + (size_t)i * nb, nb, 7u);
+        if (const char* dm = getenv("HG_DATA")) {
+            const int mode = !strcmp(dm, "zero") ? 0 : !strcmp(dm, "relu") ? 1 : 2;
+            refill_h<<<1024, 256, 0, st>>>(A, na, mode);
+            if (mode != 1) refill_h<<<1024, 256, 0, st>>>(B, nb * nrot, mode);      // relu: activations only, weights stay dense
+        }
         ref_kernel<<<(unsigned)((nc + 255) / 256), 256, 0, st>>>(A, B, R, pr.M, pr.N, pr.K, pr.K, pr.K);
         hipStreamSynchronize(st);
         const double flops = 2.0 * pr.M * (double)pr.N * pr.K;
@@ -152,27 +173,24 @@ int main(int argc, char** argv) {
                        flops / ts[1] / 1e6, bytes / ts[1] / 1e6, err, err > 1e-4f ? "  <-- WRONG" : "");
             }
         }
-        if (getenv("HG_STAMPS") && pr.N % 256 == 0 && pr.M % 256 == 0) {
-            unsigned* dts; hipMalloc(&dts, 8 * 32 * 4);
-            auto dump = [&](const char* nm, void (*fn)(const Hg8Args&, hipStream_t)) {
-                hipMemsetAsync(dts, 0, 8 * 32 * 4, st);
-                Hg8Args a{};
-                a.A = A; a.B = B; a.C = C; a.bias = (const float*)dts; a.M = pr.M; a.N = pr.N; a.K = pr.K; a.lda = pr.K; a.ldb = pr.K; a.ldc = pr.N;
-                fn(a, st); fn(a, st);
-                unsigned h[8 * 32];
-                hipMemcpyAsync(h, dts, sizeof h, hipMemcpyDeviceToHost, st);
-                hipStreamSynchronize(st);
-                printf("   stamps %s (cycles since the K-tile's first stamp of wave 0; rows = waves 0, 1, 4, 5)\n", nm);
-                for (int w : {0, 1, 4, 5}) {
-                    printf("     w%d:", w);
-                    for (int i = 0; i < 23; ++i) printf(" %5d", (int)(h[w * 32 + i] - h[0]));
-                    printf("\n");
-                }
-            };
-            dump("full", hgemm8_launch<64>);
-            dump("noprio", hgemm8_launch<64 + 16>);
-            dump("noDMA", hgemm8_launch<64 + 1>);
-            dump("noDMA noprio", hgemm8_launch<64 + 1 + 16>);
+        if (getenv("HG_CLOCK") && pr.N % 256 == 0 && pr.M % 256 == 0) {
+            const int nwg = (pr.M / 256) * (pr.N / 256);
+            unsigned long long* dts; hipMalloc(&dts, (size_t)nwg * 32);
+            hipMemsetAsync(dts, 0, (size_t)nwg * 32, st);
+            Hg8Args a{};
+            a.A = A; a.B = B; a.C = C; a.bias = (const float*)dts; a.M = pr.M; a.N = pr.N; a.K = pr.K; a.lda = pr.K; a.ldb = pr.K; a.ldc = pr.N;
+            for (int i = 0; i < 5; ++i) hgemm8_launch<64>(a, st);
+            hipEventRecord(e0, st);
+            hgemm8_launch<64>(a, st);
+            hipEventRecord(e1, st);
+            hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            std::vector<unsigned long long> h((size_t)nwg * 4);
+            hipMemcpy(h.data(), dts, (size_t)nwg * 32, hipMemcpyDeviceToHost);
+            unsigned long long tmin = ~0ull, tmax = 0; double loop = 0, epi = 0;
+            for (int w = 0; w < nwg; ++w) { tmin = std::min(tmin, h[4 * w]); tmax = std::max(tmax, h[4 * w + 2]); loop += (double)(h[4 * w + 1] - h[4 * w]); epi += (double)(h[4 * w + 2] - h[4 * w + 1]); }
+            printf("   clock probe: launch %.1f us (events); first loop start -> last workgroup end %llu ticks; per workgroup: main loop %.0f ticks (%.0f per K-tile), epilogue %.0f ticks\n",
+                   ms * 1e3, tmax - tmin, loop / nwg, loop / nwg / (pr.K / 64), epi / nwg);
             hipFree(dts);
         }
         if (hgemm_as_ok(pr.M, pr.N, pr.K)) {

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for s in header_symbols():
         assert hasattr(lib, s), s
-    assert _lib.load().mg_abi_version() == 2
+    assert _lib.load().mg_abi_version() == 3 == _lib.ABI_VERSION
     assert _lib.load().mg_mdct4_num_frames(32512, 512) == 128
     assert _lib.load().mg_mdct4_num_frames(7936, 512) == 32
 

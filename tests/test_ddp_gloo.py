@@ -237,10 +237,14 @@ def _sharded_worker(rank, world, port, out_dir):
 
 
 def test_default_mode_rule(monkeypatch):
-    """ddp.default_mode: sharded from 4 ranks and 64 Mi parameters on (configs[1] / configs[3] generators), all-reduce for the
-    discriminators and at world 2; MDCTGAN_DDP_MODE overrides."""
+    """ddp.default_mode: all-reduce unless asked otherwise (the sharded optimiser has never run over RCCL with world >= 4: opt-in,
+    ADVICE r4); MDCTGAN_DDP_MODE=auto applies the size rule (sharded from 4 ranks and 64 Mi parameters on -- the configs[1] /
+    configs[3] generators); an explicit mode overrides."""
     from mdctgan_amd import ddp
     monkeypatch.delenv("MDCTGAN_DDP_MODE", raising=False)
+    for world, n in ((8, 736491201), (4, 182433857), (8, 8294232), (2, 736491201), (1, 736491201)):
+        assert ddp.default_mode(world, n) == "allreduce"
+    monkeypatch.setenv("MDCTGAN_DDP_MODE", "auto")
     assert ddp.default_mode(8, 736491201) == "sharded" and ddp.default_mode(4, 182433857) == "sharded"
     assert ddp.default_mode(8, 8294232) == "allreduce" and ddp.default_mode(2, 736491201) == "allreduce"
     assert ddp.default_mode(1, 736491201) == "allreduce"
