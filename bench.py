@@ -573,7 +573,8 @@ def main():
         else:
             generate(model, lr, batch_size=batch, gen_overlap=0)
     step = eager_step
-    use_graph = (not args.no_graph) and (not use_ddp or os.environ.get("MDCTGAN_DDP_GRAPH", "0") == "1")
+    # data parallel: eager unless MDCTGAN_DDP_GRAPH=1 | auto (auto: every rank tries the capture, all fall back together: Pix2PixHDModel.make_step)
+    use_graph = (not args.no_graph) and (not use_ddp or os.environ.get("MDCTGAN_DDP_GRAPH", "0") in ("1", "auto"))
 
     def fence():
         torch.cuda.synchronize()
@@ -617,9 +618,11 @@ def main():
         dominant = max(agg, key=lambda k: agg[k][2]) if agg else None
     timer = KernelTimer(ops, mglib.load(), target=dominant) if dominant else None
     if use_graph and args.mode == "train":
-        graphed = model.make_graphed_step(lr, hr, warmup=2)   # whole G+D iteration as one hipGraph
+        graphed = model.make_step(lr, hr, warmup=2)           # whole G+D iteration as one hipGraph (data parallel + auto: or eager on every rank)
         step = lambda: graphed()                                # noqa: E731  (inputs already in the captured buffers)
         step()
+        if getattr(graphed, "graph", None) is None:
+            use_graph = False                                   # the collective fallback took the eager step
     elif use_graph:
         graphed = make_graphed_generate(model, lr, batch_size=batch, gen_overlap=0)   # K1 + generator + K2 + stitch
         step = lambda: graphed()                                # noqa: E731

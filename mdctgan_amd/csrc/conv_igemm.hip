@@ -1147,7 +1147,7 @@ __global__ void colsum_partial_kernel(const float* __restrict__ a, long long M, 
 
 }  // namespace
 
-extern "C" int mg_conv_rowdot_kq(const mg_conv_geom* g);       // conv_rowdot.hip
+extern "C" __attribute__((visibility("hidden"))) int mg_conv_rowdot_kq(const mg_conv_geom* g);       // conv_rowdot.hip (library-internal)
 #include "wino.h"
 #include "wino4.h"
 #include "wino42.h"
@@ -2470,11 +2470,12 @@ int smallc_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* 
 
 extern "C" {
 
-int mg_conv_rowdot_kq(const mg_conv_geom* g);
-int mg_conv_rowdot_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
+// (library-internal: conv_rowdot.hip; hidden from the .so's exports)
+__attribute__((visibility("hidden"))) int mg_conv_rowdot_kq(const mg_conv_geom* g);
+__attribute__((visibility("hidden"))) int mg_conv_rowdot_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
                        void* stream);
-size_t mg_conv_rowdot_wgrad_workspace(const mg_conv_geom* g);
-int mg_conv_rowdot_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias,
+__attribute__((visibility("hidden"))) size_t mg_conv_rowdot_wgrad_workspace(const mg_conv_geom* g);
+__attribute__((visibility("hidden"))) int mg_conv_rowdot_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias,
                          int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 int mg_abi_version(void) { return 3; }

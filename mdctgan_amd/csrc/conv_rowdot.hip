@@ -289,10 +289,12 @@ inline int rowdot_waves(long long M) {
 
 }  // namespace
 
+// internal to the library (called from conv_igemm.hip, another translation unit): not part of the C ABI, hidden from the .so's exports
+#define MG_INTERNAL __attribute__((visibility("hidden")))
 extern "C" {
 
 // 0: not applicable, otherwise the per-lane slice count of the kernel instance that would run
-int mg_conv_rowdot_kq(const mg_conv_geom* g) {
+MG_INTERNAL int mg_conv_rowdot_kq(const mg_conv_geom* g) {
     if (!g || g->Co != 1 || g->Ci % 4 != 0 || g->KH > 255 || g->KW > 255 || g->Ci >= 32768) return 0;
     const int K = g->KH * g->KW * g->Ci;
     if (K <= 16 * 256) return 16;
@@ -300,7 +302,7 @@ int mg_conv_rowdot_kq(const mg_conv_geom* g) {
     return 0;
 }
 
-int mg_conv_rowdot_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
+MG_INTERNAL int mg_conv_rowdot_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
                        void* stream) {
     const int kq = mg_conv_rowdot_kq(g);
     if (!kq || !x || !w || !y) return MG_ERR_ARG;
@@ -326,7 +328,7 @@ int mg_conv_rowdot_fwd(const mg_conv_geom* g, const float* x, const float* w, co
     return MG_OK;
 }
 
-size_t mg_conv_rowdot_wgrad_workspace(const mg_conv_geom* g) {
+MG_INTERNAL size_t mg_conv_rowdot_wgrad_workspace(const mg_conv_geom* g) {
     if (!mg_conv_rowdot_kq(g)) return 0;
     const int KP = g->KH * g->KW * g->Ci + 4;
     const dim3 tg = co1_grid(g);
@@ -334,7 +336,7 @@ size_t mg_conv_rowdot_wgrad_workspace(const mg_conv_geom* g) {
     return ((size_t)nw * KP + KP) * sizeof(float) + mg_colsum_workspace(nw, KP) + 512;
 }
 
-int mg_conv_rowdot_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias,
+MG_INTERNAL int mg_conv_rowdot_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias,
                          int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     const int kq = mg_conv_rowdot_kq(g);
     if (!kq || !x || !dy || !dw || !workspace || workspace_bytes < mg_conv_rowdot_wgrad_workspace(g)) return MG_ERR_ARG;

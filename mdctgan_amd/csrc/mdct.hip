@@ -6,16 +6,17 @@
 //       + :400-402 (the |x|*2+nr0 second channel)
 //   K2  models/pix2pixHD_model.py:127-137 (denormalize) + models/mdct.py:457-489 (IMDCT4.forward)
 //
-// Geometry: n_fft = win = 2*M, hop = M (M = 256 on the hot path).  One workgroup = FT frames of one clip = one
-// FT x 256 x 256 GEMM tile; 4 waves, each owning 64 output columns of every frame (FT/32 x 2 MFMA 32x32
-// blocks).  A (frames x k) is folded straight from HBM into LDS, row-major with a 257-float row pitch (odd ->
-// conflict-free ds_read_b32 for the MFMA A fragment and conflict-free scalar writes); B = the DCT-IV cosine table
-// streams from L2 straight into VGPRs.  The contraction is MFMA-bound, not HBM-bound (64 FLOP per algorithmic byte
-// vs a ridge of ~20).  FT is a template parameter (32 / 64 / 128 frames; MG_MDCT_FT overrides): larger tiles reuse
-// each B element for more MFMAs but leave fewer waves per CU to hide the L2 latency of the B stream, and FT = 32
-// (34 KB of LDS, 4 workgroups per CU) measures fastest; spectra are bit-identical for every FT.  Known limit: the B
-// stream is fetched per wave (16 FLOP per L2 byte), which holds K1 at ~22 % and K2 at ~37 % of the f32 MFMA peak --
-// the next step is staging B through LDS in a 128 x 128 GEMM tiling like csrc/conv_igemm.hip.
+// Geometry: n_fft = win = 2*M, hop = M (M = 256 on the hot path).
+//
+// Two kernels per direction:
+//   * mdct_ct.h (mdct4_ct_kernel / imdct4_ct_kernel): the DCT-IV factored into 8- and 16-point DFT stages (12 288 multiply-adds
+//     per frame instead of 65 536) -- the default at every size; also writes the NHWC pair alone and the stitched waveform;
+//   * this file (mdct4_kernel / imdct4_kernel): the generic dense-table kernels -- per-sample min / max normalisation, returned
+//     frames (return_frames=True), float64 output, unaligned or > 4 GiB operands, no stage-matrix image.  One workgroup = FT frames
+//     of one clip = one FT x 256 x 256 GEMM tile; 4 waves, each owning 64 output columns of every frame; A (frames x k) is folded
+//     straight from HBM into LDS (257-float row pitch), B = the DCT-IV cosine table streams from L2 into VGPRs.
+// (Rounds 2-4 also had a tiled-GEMM K1, a table-stationary f32 pair and a bf16 x 3 pair; the factored kernels beat them at every
+// size and they were retired from the library in round 5 -- scripts/ubench/mdct_bs.h, mdct_b3.h keep the latter two for the harnesses.)
 #include <cstdlib>
 #include "common.h"
 
@@ -159,131 +160,6 @@ __global__ __launch_bounds__(256) void mdct4_kernel(
             atomicMax(minmax_ord + 2 * b + 1, f2ord(vmax));
         }
     }
-    if (stats && cp.mode != CODEC_RAW) {
-        s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
-        if (lane == 0) { atomicAdd(stats, s1); atomicAdd(stats + 1, s2); }
-    }
-}
-
-#include "gemm32.h"
-
-// ---------------------------------------------------------------------------------------------
-// K1 as a tiled GEMM (large batches): U [B*F, 256] x D4 [256, 256] with 128 x 128 output tiles, both operands staged
-// through LDS in 32-deep row-major chunks (gemm32.h) so a D4 element fetched from L2 feeds 128 frames instead of the
-// 32 of mdct4_kernel's per-wave B stream.  The A operand never exists in memory: a thread builds four consecutive
-// folded samples u[n..n+3] of its frame from two float4 loads of the signal (one of them reversed) and the matching
-// window values.  D4 is symmetric, so row `bin` of the table is the k-contiguous B row.  Requirements: T % 4 == 0
-// (float4 loads never straddle the zero padding), the fixed-range codec (--abs_norm) or raw output, no frames_out.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float4 rev4(const float4 v) { return make_float4(v.w, v.z, v.y, v.x); }
-
-__global__ __launch_bounds__(256) void mdct4_gemm_kernel(const float* __restrict__ audio, int B, int T, int F,
-                                                         const float* __restrict__ window,
-                                                         const float* __restrict__ dct4, CodecParams cp,
-                                                         float* __restrict__ spec, float* __restrict__ in2,
-                                                         double* __restrict__ stats) {
-    constexpr int BM = 128, BN = 128, MB = 2, NB = 2, NV = 4, Q = M / 2;
-    extern __shared__ __attribute__((aligned(16))) float smem32[];
-    auto As = [&](int buf) -> float* { return smem32 + buf * (BM * LDK2); };
-    auto Bs = [&](int buf) -> float* { return smem32 + 2 * BM * LDK2 + buf * (BN * LDK2); };
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rows = B * F;
-    const int m0 = (blockIdx.x >> 1) * BM, n0 = (blockIdx.x & 1) * BN;     // the two column tiles of a row tile are neighbours
-    const int q = tid & 7, r0 = tid >> 3;
-
-    const float* xrow[NV];      // audio of the clip + the frame's offset (sample of padded position f*M is xrow[-M])
-    int tbase[NV];              // f * M - M: sample index of the frame's first padded position
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int m = m0 + r0 + 32 * i;
-        if (m < rows) {
-            const int b = m / F, f = m - b * F;
-            xrow[i] = audio + (size_t)b * T;
-            tbase[i] = f * M - M;
-        } else {
-            xrow[i] = nullptr;
-            tbase[i] = 0;
-        }
-    }
-    auto ldx = [&](int i, int off) -> float4 {         // 4 samples at frame position `off` (multiple of 4), 0 outside
-        const int t = tbase[i] + off;
-        return (xrow[i] && t >= 0 && t + 3 < T) ? g32_ld4(xrow[i] + t) : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    auto zmul = [&](const float4 x4, const float4 w4) -> float4 {     // fl32(x * w), like mdct.py:410
-        return make_float4(__fmul_rn(x4.x, w4.x), __fmul_rn(x4.y, w4.y), __fmul_rn(x4.z, w4.z), __fmul_rn(x4.w, w4.w));
-    };
-    auto load_a = [&](int c, float4 (&va)[NV]) {
-        const int n = c * BK2 + 4 * q;                 // u[n .. n+3]; a chunk never straddles Q
-        int o1, o2;
-        if (n < Q) { o1 = 3 * Q - 4 - n; o2 = 3 * Q + n; }       // -z[3Q-1-n-j] - z[3Q+n+j]
-        else { o1 = n - Q; o2 = 3 * Q - 4 - n; }                 //  z[n-Q+j]    - z[2Q-1-(n-Q)-j]  (2Q-4-(n-Q) = 3Q-4-n)
-        const float4 w1 = g32_ld4(window + o1), w2 = g32_ld4(window + o2);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const float4 z1 = zmul(ldx(i, o1), w1), z2 = zmul(ldx(i, o2), w2);
-            if (n < Q) {
-                const float4 r1 = rev4(z1);
-                va[i] = make_float4(-r1.x - z2.x, -r1.y - z2.y, -r1.z - z2.z, -r1.w - z2.w);
-            } else {
-                const float4 r2 = rev4(z2);
-                va[i] = make_float4(z1.x - r2.x, z1.y - r2.y, z1.z - r2.z, z1.w - r2.w);
-            }
-        }
-    };
-    auto load_b = [&](int c, float4 (&vb)[NV]) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) vb[i] = g32_ld4(dct4 + (size_t)(n0 + r0 + 32 * i) * M + c * BK2 + 4 * q);
-    };
-    f32x16 acc[MB][NB];
-#pragma unroll
-    for (int mi = 0; mi < MB; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = f32x16{0};
-    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
-    float4 va[NV], vb[NV];
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(As(buf) + (r0 + 32 * i) * LDK2 + 4 * q) = va[i];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(Bs(buf) + (r0 + 32 * i) * LDK2 + 4 * q) = vb[i];
-    };
-    constexpr int NCH = M / BK2;
-    load_a(0, va); load_b(0, vb); stash(0);
-    __syncthreads();
-    load_a(1, va); load_b(1, vb);
-    for (int c = 0; c < NCH; ++c) {
-        const int cur = c & 1;
-        mma_chunk32<MB, NB>(
-            As(cur), Bs(cur), acc, wm0, wn0, lane,
-            [&]() { if (c + 1 < NCH) stash(cur ^ 1); },
-            [&]() { if (c + 2 < NCH) { load_a(c + 2, va); load_b(c + 2, vb); } });
-        __syncthreads();
-    }
-
-    // epilogue: codec + stores (fixed-range normalisation or raw)
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int mi = 0; mi < MB; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NB; ++ni) {
-            const int col = n0 + wn0 + 32 * ni + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + 32 * mi + mfma32_row(r, lane);
-                if (m >= rows) continue;
-                const float xv = acc[mi][ni][r];
-                float v = xv;
-                if (cp.mode != CODEC_RAW) {
-                    float l = xv;
-                    if (cp.mode == CODEC_ARCSINH) l = asinhf(cp.gain * xv) / LN10F;
-                    if (stats) { s1 += (double)l; s2 += (double)l * (double)l; }
-                    v = (l - cp.mn) / (cp.mx - cp.mn) * (cp.nr1 - cp.nr0) + cp.nr0;
-                }
-                const size_t o = (size_t)m * M + col;
-                spec[o] = v;
-                if (in2) *reinterpret_cast<float2*>(in2 + 2 * o) = make_float2(v, fabsf(v) * 2.0f + cp.nr0);
-            }
-        }
     if (stats && cp.mode != CODEC_RAW) {
         s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
         if (lane == 0) { atomicAdd(stats, s1); atomicAdd(stats + 1, s2); }
@@ -452,8 +328,7 @@ __global__ void stitch_kernel(const T* __restrict__ seg, int n_seg, int L, int o
 
 }  // namespace
 
-#include "mdct_bs.h"
-#include "mdct_b3.h"
+#include "mdct_codec.h"
 #include "mdct_ct.h"
 
 // frames per workgroup: a whole-clip tile (4 MFMAs per B fetch) once the launch fills the chip, 32 otherwise
@@ -472,8 +347,6 @@ static void allow_lds(K kernel, size_t lds) {
 // C ABI
 // ---------------------------------------------------------------------------------------------
 extern "C" {
-
-size_t mg_mdct4_lds_bytes() { return (128 * LDA + 2 * M) * sizeof(float); }
 
 // See include/mdctgan_hip.h for the contract.
 int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* window, const float* dct4,
@@ -495,25 +368,22 @@ int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* w
     }
     if (stats) hipMemsetAsync(stats, 0, 2 * sizeof(double), st);
     if (per_sample) hipLaunchKernelGGL(fill_u32_pairs, dim3((B + 255) / 256), dim3(256), 0, st, scratch_u32, B);
-    // round 3: the table-stationary kernel (mdct_bs.h) wherever its fast path applies; MG_MDCT_BS=0, or any of the older
-    // kernels' own switches (MG_MDCT_GEMM, MG_MDCT_FT), selects the round-1 / round-2 kernels below
-    static const bool bs_off = (getenv("MG_MDCT_BS") && atoi(getenv("MG_MDCT_BS")) == 0);
-    // the table-stationary kernels read register images of the table (mg_dct4_image): without one the round-1 / round-2 kernels run
-    const bool legacy_forced = bs_off || !dct4_image || getenv("MG_MDCT_GEMM") || getenv("MG_MDCT_FT");
+    // The factored transform (mdct_ct.h: two small dense stages on the f32 pipe instead of the 256 x 256 table, two 8-wave workgroups
+    // per CU) wherever its fast path applies -- measured faster than every earlier kernel at every size (6.5 vs 12.2 us at 8 clips,
+    // 7.9 vs 16.3 at 64, 260 vs 446 at 4096; the table-stationary f32 / bf16 x 3 kernels of rounds 3-4 live on under scripts/ubench/).
+    // It reads the stage-matrix image (mg_dct4_image): without one, for per-sample ranges, returned frames, unaligned or > 4 GiB
+    // operands the generic kernel below runs.  MG_MDCT_CT=0 forces the generic kernel.
+    const bool legacy_forced = !dct4_image || getenv("MG_MDCT_FT");
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const long long n_rows = (long long)B * F;
-    // round 4: the bf16 x 3 kernel (mdct_b3.h) from 512 row tiles on (two per CU: below that the 384 KB table prologue is not
-    // amortised and the f32-pipe kernel with its 2-wave latency shape is faster); MG_MDCT_B3=0 / 1 overrides
-    // round 4 (second half): the factored transform (mdct_ct.h): two small dense stages on the f32 pipe instead of the 256 x 256
-    // table, two 8-wave workgroups per CU.  MG_MDCT_CT=0 / 1 overrides.
     {
         const long long n_tiles = (n_rows + CT_ROWS - 1) / CT_ROWS;
-        bool ct = true;       // measured faster than the f32-pipe / bf16 x 3 kernels at every size: 6.5 vs 12.2 us at 8 clips, 7.9 vs 16.3 at 64, 260 vs 446 at 4096
+        bool ct = true;
         if (const char* e = getenv("MG_MDCT_CT")) ct = atoi(e) != 0;
         if (ct && !legacy_forced && T % 4 == 0 && !per_sample && !frames_out && (codec == CODEC_RAW || codec == CODEC_ARCSINH) &&
             !(codec == CODEC_RAW && in2) && n_rows * M * 8 < (1ll << 32) - (1ll << 18) && (long long)B * T * 4 < (1ll << 32) &&
             al16(audio) && al16(window) && al16(dct4_image) && (!spec || al16(spec)) && (!in2 || al16(in2)) && (spec || in2)) {
-            const float* img = dct4_image + M * M + B3_IMG_U4 * 4;
+            const float* img = dct4_image;
             const dim3 grid((unsigned)(n_tiles < 512 ? n_tiles : 512)), block(CT_NT);
 #define MG_K1_CT(MODE_, SPEC_, PAIR_, STATS_)                                                                             \
     do {                                                                                                                   \
@@ -534,74 +404,7 @@ int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* w
             return MG_OK;
         }
     }
-    {
-        const long long n_tiles = (n_rows + B3_ROWS - 1) / B3_ROWS;
-        bool b3 = n_tiles >= 512;
-        if (const char* e = getenv("MG_MDCT_B3")) b3 = atoi(e) != 0;
-        if (b3 && F >= B3_ROWS && !legacy_forced && T % 4 == 0 && !per_sample && !frames_out && (codec == CODEC_RAW || codec == CODEC_ARCSINH) &&
-            !(codec == CODEC_RAW && in2) && n_rows * M * 8 < (1ll << 32) - (1ll << 18) && (long long)B * T * 4 < (1ll << 32) &&
-            al16(audio) && al16(window) && al16(dct4_image) && (!spec || al16(spec)) && (!in2 || al16(in2)) && (spec || in2)) {
-            const b3_u4* img = reinterpret_cast<const b3_u4*>(dct4_image + M * M);
-            const dim3 grid((unsigned)(n_tiles < 256 ? n_tiles : 256)), block(B3_NT);
-#define MG_K1_B3(MODE_, SPEC_, PAIR_, STATS_)                                                                             \
-    do {                                                                                                                   \
-        static bool attr = false;                                                                                          \
-        if (!attr) { allow_lds(mdct4_b3_kernel<MODE_, SPEC_, PAIR_, STATS_>, B3_K1_LDS); attr = true; }                    \
-        hipLaunchKernelGGL((mdct4_b3_kernel<MODE_, SPEC_, PAIR_, STATS_>), grid, block, B3_K1_LDS, st, audio, B, T, F, window, img, cp, \
-                           spec, in2, stats);                                                                              \
-    } while (0)
-#define MG_K1_B3_S(MODE_, SPEC_, PAIR_) do { if (stats) MG_K1_B3(MODE_, SPEC_, PAIR_, true); else MG_K1_B3(MODE_, SPEC_, PAIR_, false); } while (0)
-            if (codec == CODEC_RAW) MG_K1_B3(CODEC_RAW, true, false, false);
-            else if (in2 && spec) MG_K1_B3_S(CODEC_ARCSINH, true, true);
-            else if (in2) MG_K1_B3_S(CODEC_ARCSINH, false, true);
-            else MG_K1_B3_S(CODEC_ARCSINH, true, false);
-#undef MG_K1_B3_S
-#undef MG_K1_B3
-            MG_CHECK_LAUNCH();
-            g_last_kernel[0] = "mdct4_b3_kernel (csrc/mdct_b3.h)";
-            return MG_OK;
-        }
-    }
-    if (!legacy_forced && T % 4 == 0 && !per_sample && !frames_out && (codec == CODEC_RAW || codec == CODEC_ARCSINH) &&
-        !(codec == CODEC_RAW && in2) && n_rows * M * 8 < (1ll << 32) - (1ll << 17) && (long long)B * T * 4 < (1ll << 32) &&
-        al16(audio) && al16(window) && al16(dct4_image) && (!spec || al16(spec)) && (!in2 || al16(in2))) {
-        const long long n_tiles = (n_rows + BS_ROWS - 1) / BS_ROWS;
-        int nw = n_tiles >= 256 ? 8 : 2;
-        if (const char* e = getenv("MG_MDCT_BS_NW")) nw = atoi(e) == 8 ? 8 : 2;
-        const dim3 grid((unsigned)(n_tiles < 256 ? n_tiles : 256), 8 / nw), block(nw * 64);
-#define MG_K1_BS(NW_, MODE_, PAIR_, STATS_)                                                                              \
-    do {                                                                                                                   \
-        static bool attr = false;                                                                                          \
-        if (!attr) { allow_lds(mdct4_bs_kernel<NW_, MODE_, PAIR_, STATS_>, BS_K1_LDS); attr = true; }                      \
-        hipLaunchKernelGGL((mdct4_bs_kernel<NW_, MODE_, PAIR_, STATS_>), grid, block, BS_K1_LDS, st, audio, B, T, F, window, dct4_image, cp, \
-                           spec, in2, stats);                                                                              \
-    } while (0)
-#define MG_K1_BS_S(NW_, MODE_, PAIR_) do { if (stats) MG_K1_BS(NW_, MODE_, PAIR_, true); else MG_K1_BS(NW_, MODE_, PAIR_, false); } while (0)
-        if (codec == CODEC_RAW) { if (nw == 8) MG_K1_BS(8, CODEC_RAW, false, false); else MG_K1_BS(2, CODEC_RAW, false, false); }
-        else if (in2) { if (nw == 8) MG_K1_BS_S(8, CODEC_ARCSINH, true); else MG_K1_BS_S(2, CODEC_ARCSINH, true); }
-        else { if (nw == 8) MG_K1_BS_S(8, CODEC_ARCSINH, false); else MG_K1_BS_S(2, CODEC_ARCSINH, false); }
-#undef MG_K1_BS_S
-#undef MG_K1_BS
-        MG_CHECK_LAUNCH();
-        g_last_kernel[0] = "mdct4_bs_kernel (csrc/mdct_bs.h)";
-        return MG_OK;
-    }
-    if (!spec) return MG_ERR_ARG;          // (only the table-stationary kernels write the pair alone)
-    // large batches: the tiled GEMM kernel (B operand shared through LDS); MG_MDCT_GEMM=0/1 overrides
-    const long long row_tiles = ((long long)B * F + 127) / 128;
-    bool gemm = row_tiles >= 256;
-    if (const char* e = getenv("MG_MDCT_GEMM")) gemm = atoi(e) != 0;
-    if (gemm && T % 4 == 0 && !per_sample && !frames_out && (reinterpret_cast<uintptr_t>(audio) & 15) == 0 &&
-        (reinterpret_cast<uintptr_t>(window) & 15) == 0 && (reinterpret_cast<uintptr_t>(dct4) & 15) == 0) {
-        constexpr size_t lds = (size_t)2 * (128 + 128) * LDK2 * sizeof(float);
-        static bool attr2 = false;
-        if (!attr2) { allow_lds(mdct4_gemm_kernel, lds); attr2 = true; }
-        hipLaunchKernelGGL(mdct4_gemm_kernel, dim3((unsigned)(row_tiles * 2)), dim3(256), lds, st, audio, B, T, F, window,
-                           dct4, cp, spec, in2, stats);
-        MG_CHECK_LAUNCH();
-        g_last_kernel[0] = "mdct4_gemm_kernel (csrc/mdct.hip)";
-        return MG_OK;
-    }
+    if (!spec) return MG_ERR_ARG;          // (only the factored kernel writes the pair alone)
     const int ft = frames_per_wg(B, F);
     if (ft == 128)
         hipLaunchKernelGGL(mdct4_kernel<128>, dim3((F + 127) / 128, B), dim3(256), (128 * LDA + 2 * M) * sizeof(float), st,
@@ -624,15 +427,12 @@ int mg_mdct4_forward(const float* audio, int B, int T, int n_fft, const float* w
 
 long long mg_dct4_image_floats(int n_fft) {
     if (n_fft != 2 * M) return 0;
-    return (long long)M * M + (long long)B3_IMG_U4 * 4 + CT_IMG;      // f32 register image + three bf16 piece images + stage matrices
+    return CT_IMG;      // the stage matrices of the factored transform, in the lane order the kernels load them
 }
 
 int mg_dct4_image(const float* dct4, float* image, void* stream) {
     if (!dct4 || !image || (reinterpret_cast<uintptr_t>(dct4) & 15) || (reinterpret_cast<uintptr_t>(image) & 15)) return MG_ERR_ARG;
-    hipLaunchKernelGGL(dct4_image_kernel, dim3(M * M / 4 / 256), dim3(256), 0, (hipStream_t)stream, dct4, image);
-    hipLaunchKernelGGL(dct4_b3_image_kernel, dim3(4 * 2 * 16 * 64 / 256), dim3(256), 0, (hipStream_t)stream, dct4,
-                       reinterpret_cast<b3_u4*>(image + M * M));
-    hipLaunchKernelGGL(dct4_ct_image_kernel, dim3(CT_IMG / 256), dim3(256), 0, (hipStream_t)stream, image + M * M + B3_IMG_U4 * 4);
+    hipLaunchKernelGGL(dct4_ct_image_kernel, dim3(CT_IMG / 256), dim3(256), 0, (hipStream_t)stream, image);
     MG_CHECK_LAUNCH();
     return MG_OK;
 }
@@ -661,7 +461,6 @@ static int imdct4_dispatch(const float* spec, int B, int F, int n_fft, const flo
         attr_done = true;
     }
     {
-        static const bool bs_off = (getenv("MG_MDCT_BS") && atoi(getenv("MG_MDCT_BS")) == 0);
         auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
         // round 4 (second half): the factored transform (mdct_ct.h); a workgroup walks whole clips: >= 512 clips fill two per CU
         // Measured (scripts/ubench/mdct_b3_bench, profiles/r04_mdct_ct_ubench.log): 249 vs 442 us at 4096 clips, 18.3 vs 27.9 at 128,
@@ -671,10 +470,10 @@ static int imdct4_dispatch(const float* spec, int B, int F, int n_fft, const flo
         const bool st4 = sa.pitch != 0 && sa.pitch % 4 == 0 && sa.overlap % 4 == 0 && sa.total * 4 < (1ll << 32) - (1ll << 16);
         bool ct = true;
         if (const char* e = getenv("MG_MDCT_CT")) ct = atoi(e) != 0 || st4;
-        if (ct && (sa.pitch == 0 || st4) && !bs_off && dct4_image && !getenv("MG_MDCT_FT") && !frames_out && !out_f64 && out_len % 4 == 0 && al16(spec) && al16(window) &&
+        if (ct && (sa.pitch == 0 || st4) && dct4_image && !getenv("MG_MDCT_FT") && !frames_out && !out_f64 && out_len % 4 == 0 && al16(spec) && al16(window) &&
             al16(dct4_image) && al16(audio) && (long long)B * F * M * 4 < (1ll << 32) && (long long)B * out_len * 4 < (1ll << 32) - (1ll << 16) &&
             codec >= CODEC_RAW && codec <= CODEC_RANGE) {
-            const float* img = dct4_image + M * M + B3_IMG_U4 * 4;
+            const float* img = dct4_image;
             const dim3 grid((unsigned)(B < 512 ? B : 512));
 #define MG_K2_CT(MODE_, ST_)                                                                                              \
     do {                                                                                                                   \
@@ -688,43 +487,6 @@ static int imdct4_dispatch(const float* spec, int B, int F, int n_fft, const flo
 #undef MG_K2_CT
             MG_CHECK_LAUNCH();
             g_last_kernel[1] = st4 ? "imdct4_ct_kernel<stitched> (csrc/mdct_ct.h)" : "imdct4_ct_kernel (csrc/mdct_ct.h)";
-            return MG_OK;
-        }
-        // round 4: the bf16 x 3 kernel (mdct_b3.h): a workgroup walks whole clips, so it wants >= 256 clips (and >= 512 tiles)
-        bool b3 = B >= 256 && (long long)B * ((F + B3_ROWS - 1) / B3_ROWS) >= 512;
-        if (const char* e = getenv("MG_MDCT_B3")) b3 = atoi(e) != 0;
-        if (b3 && sa.pitch == 0 && !bs_off && dct4_image && !getenv("MG_MDCT_FT") && !frames_out && !out_f64 && out_len % 4 == 0 && al16(spec) && al16(window) &&
-            al16(dct4_image) && al16(audio) && (long long)B * F * M * 4 < (1ll << 32) && (long long)B * out_len * 4 < (1ll << 32) - (1ll << 16) &&
-            codec >= CODEC_RAW && codec <= CODEC_RANGE) {
-            const b3_u4* img = reinterpret_cast<const b3_u4*>(dct4_image + M * M);
-            const dim3 grid((unsigned)(B < 256 ? B : 256));
-#define MG_K2_B3(MODE_)                                                                                                   \
-    do {                                                                                                                   \
-        static bool attr = false;                                                                                          \
-        if (!attr) { allow_lds(imdct4_b3_kernel<MODE_>, B3_K2_LDS); attr = true; }                                         \
-        hipLaunchKernelGGL((imdct4_b3_kernel<MODE_>), grid, dim3(B3_NT), B3_K2_LDS, st, spec, B, F, window, img, cp, (float*)audio, out_len); \
-    } while (0)
-            if (codec == CODEC_RAW) MG_K2_B3(CODEC_RAW); else if (codec == CODEC_ARCSINH) MG_K2_B3(CODEC_ARCSINH); else MG_K2_B3(CODEC_RANGE);
-#undef MG_K2_B3
-            MG_CHECK_LAUNCH();
-            g_last_kernel[1] = "imdct4_b3_kernel (csrc/mdct_b3.h)";
-            return MG_OK;
-        }
-        if (sa.pitch == 0 && !bs_off && dct4_image && !getenv("MG_MDCT_FT") && !frames_out && !out_f64 && out_len % 4 == 0 && al16(spec) && al16(window) && al16(dct4_image) &&
-            al16(audio) && (long long)B * F * M * 4 < (1ll << 32) && (long long)B * out_len * 4 < (1ll << 32) - (1ll << 16) &&
-            codec >= CODEC_RAW && codec <= CODEC_RANGE) {
-            const long long n_tiles = (long long)B * ((F + BS_ROWS - 1) / BS_ROWS);
-            const dim3 grid((unsigned)(n_tiles < 256 ? n_tiles : 256));
-#define MG_K2_BS(MODE_)                                                                                                   \
-    do {                                                                                                                   \
-        static bool attr = false;                                                                                          \
-        if (!attr) { allow_lds(imdct4_bs_kernel<MODE_>, BS_K2_LDS); attr = true; }                                         \
-        hipLaunchKernelGGL((imdct4_bs_kernel<MODE_>), grid, dim3(512), BS_K2_LDS, st, spec, B, F, window, dct4_image, cp, (float*)audio, out_len); \
-    } while (0)
-            if (codec == CODEC_RAW) MG_K2_BS(CODEC_RAW); else if (codec == CODEC_ARCSINH) MG_K2_BS(CODEC_ARCSINH); else MG_K2_BS(CODEC_RANGE);
-#undef MG_K2_BS
-            MG_CHECK_LAUNCH();
-            g_last_kernel[1] = "imdct4_bs_kernel (csrc/mdct_bs.h)";
             return MG_OK;
         }
     }

@@ -1,5 +1,5 @@
 // K1 / K2 with the 256-point DCT-IV FACTORED into two small dense stages on the f32 MFMA pipe (round 4).  Included by mdct.hip
-// after mdct_bs.h / mdct_b3.h (needs M, CodecParams, bs_* helpers).
+// after mdct_codec.h (needs M, CodecParams, the bs_* helpers).
 //
 // The dense table costs 65 536 multiply-adds per frame whatever pipe runs them.  The DCT-IV of size N = 256 is an N/2-point complex
 // DFT between two twiddles (models/mdct.py:596-628 FastMDCT4 uses the same identity with torch.fft):

@@ -38,8 +38,7 @@ _dct4_cache = {}
 
 def dct4_table(m: int, device) -> torch.Tensor:
     """D4[n, k] = cos(pi/M (n + 1/2)(k + 1/2)) evaluated in float64 on the host, rounded once to float32 -- followed, in the
-    same buffer, by the operand images of it that the table-stationary kernels load (mg_dct4_image: the float32 register image
-    and the three bf16 piece images, mg_dct4_image_floats(2 m) floats; include/mdctgan_hip.h: the `dct4_image` argument of
+    same buffer, by the stage-matrix image the factored kernels load (mg_dct4_image, mg_dct4_image_floats(2 m) floats; include/mdctgan_hip.h: the `dct4_image` argument of
     mg_mdct4_forward / mg_imdct4_forward).  Returns the flat tensor; ``dct4_table(m, dev)[:m * m].view(m, m)`` is the table
     itself, ``dct4_image(t, m)`` the image part (None for geometries without fused kernels)."""
     key = (m, str(device))
@@ -208,7 +207,7 @@ def mdct4_codec(audio, window, dct4, n_fft, *, codec=_lib.MG_CODEC_RAW, gain=1.0
     image = dct4_image(dct4, M)
     # with the pair the spectrogram is its channel 0 (a strided view): K1 then writes 393 216 B per clip instead of 526 848
     import os
-    legacy = os.environ.get("MG_MDCT_BS") == "0" or "MG_MDCT_GEMM" in os.environ or "MG_MDCT_FT" in os.environ      # (ablation switches)
+    legacy = os.environ.get("MG_MDCT_CT") == "0" or "MG_MDCT_FT" in os.environ      # (the generic kernels, forced)
     pair_only = (want_pair and image is not None and not per_sample and not want_frames and codec == _lib.MG_CODEC_ARCSINH
                  and T % 4 == 0 and audio.data_ptr() % 16 == 0 and window.data_ptr() % 16 == 0 and not legacy
                  # the factored kernels address through 32-bit buffer offsets (csrc/mdct.hip: the same guards decide there);

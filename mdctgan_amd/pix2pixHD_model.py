@@ -10,6 +10,7 @@ optimiser / module containers.
 from __future__ import annotations
 
 import os
+import sys
 from typing import Dict
 
 import torch
@@ -522,6 +523,51 @@ class Pix2PixHDModel(BaseModel):
             Fh.bump_weight_epoch()            # the replay ran both Adam steps
             return losses
         run.graph = graph
+        return run
+
+    def make_step(self, lr_audio, hr_audio, warmup=3):
+        """run(lr, hr) -> loss dict for a training loop: the captured step (make_graphed_step) where that is safe, eager
+        optimize_parameters() otherwise.  run.graph is the hipGraph or None.
+          * single process: captured;
+          * data parallel, MDCTGAN_DDP_GRAPH unset / "0": eager (the default: a capture with RCCL collectives inside has only ever
+            run with a 1-rank group on this hardware pool -- DESIGN section 5);
+          * MDCTGAN_DDP_GRAPH=1: captured, a capture error propagates;
+          * MDCTGAN_DDP_GRAPH=auto: every rank tries the capture; one MAX all-reduce of "it failed here" before the first replay
+            makes ALL ranks fall back to eager steps when ANY rank's capture failed -- eight ranks cannot strand each other with
+            seven replaying a graph (whose collectives wait for the eighth) and one stepping eagerly."""
+        import torch.distributed as dist
+        red = getattr(self, "reducers", None)
+        how = os.environ.get("MDCTGAN_DDP_GRAPH", "0") if red else "1"
+
+        def eager(lr=None, hr=None):
+            return self.optimize_parameters(lr_audio if lr is None else lr, hr_audio if hr is None else hr)
+        eager.graph = None
+        if how == "0":
+            return eager
+        if how == "1":
+            return self.make_graphed_step(lr_audio, hr_audio, warmup=warmup)
+        if how != "auto":
+            raise ValueError("MDCTGAN_DDP_GRAPH must be 0, 1 or auto")
+        run, failed = None, 0
+        os.environ["MDCTGAN_DDP_GRAPH"] = "1"             # make_graphed_step's own gate
+        try:
+            fail_rank = os.environ.get("MDCTGAN_DDP_GRAPH_FAIL_RANK")       # test hook: this rank's capture "fails"
+            if fail_rank is not None and dist.is_initialized() and dist.get_rank() == int(fail_rank):
+                raise RuntimeError("simulated capture failure (MDCTGAN_DDP_GRAPH_FAIL_RANK)")
+            run = self.make_graphed_step(lr_audio, hr_audio, warmup=warmup)
+        except Exception as e:      # noqa: BLE001 -- whatever the capture raised, the decision is collective
+            failed = 1
+            print("[mdctgan_amd] hipGraph capture of the data-parallel step failed on this rank (%s): asking every rank to step "
+                  "eagerly" % (repr(e)[:200],), file=sys.stderr, flush=True)
+        finally:
+            os.environ["MDCTGAN_DDP_GRAPH"] = "auto"
+        if dist.is_initialized():
+            flag = torch.tensor([float(failed)], device=lr_audio.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=red["G"].group)
+            failed = int(flag.item())
+        if failed:
+            run = None
+            return eager
         return run
 
     def inference(self, lr_audio, stitch=None):

@@ -1,8 +1,10 @@
 // The bf16 x 3 table-stationary K1 / K2 (mdctgan_amd/csrc/mdct_b3.h) beside the f32-pipe kernels (mdct_bs.h): time per launch
 // with parts switched off, and the largest difference between the two kernels' spectra / waveforms on the same input.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I include scripts/ubench/mdct_b3_bench.hip -o scripts/ubench/mdct_b3_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I include -I scripts/ubench scripts/ubench/mdct_b3_bench.hip -o scripts/ubench/mdct_b3_bench
 //   scripts/ubench/mdct_b3_bench [clips=4096]
 #include "../../mdctgan_amd/csrc/mdct.hip"
+#include "mdct_bs.h"       // the retired table-stationary kernels (round 5: no longer in the library)
+#include "mdct_b3.h"
 #include <cmath>
 #include <cstdio>
 #include <vector>
@@ -47,14 +49,17 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 512; ++i) hw[i] = (float)sin(M_PI * (i + 0.5) / 512.0);
     for (int n = 0; n < 256; ++n) for (int k = 0; k < 256; ++k) hd[n * 256 + k] = (float)cos(M_PI / 256.0 * (n + 0.5) * (k + 0.5));
     float *x, *w, *d, *spec, *spec2, *in2, *y, *y2;
-    hipMalloc(&x, hx.size() * 4); hipMalloc(&w, 2048); hipMalloc(&d, (256 * 256 + mg_dct4_image_floats(512)) * 4);
+    hipMalloc(&x, hx.size() * 4); hipMalloc(&w, 2048); hipMalloc(&d, (256 * 256 + 256 * 256 + B3_IMG_U4 * 4 + mg_dct4_image_floats(512)) * 4);
     hipMalloc(&spec, (size_t)B * F * 256 * 4); hipMalloc(&spec2, (size_t)B * F * 256 * 4); hipMalloc(&in2, (size_t)B * F * 512 * 4);
     hipMalloc(&y, (size_t)B * T * 4); hipMalloc(&y2, (size_t)B * T * 4);
     hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(w, hw.data(), 2048, hipMemcpyHostToDevice);
     hipMemcpy(d, hd.data(), 256 * 256 * 4, hipMemcpyHostToDevice);
     float* dimg = d + 256 * 256;
-    mg_dct4_image(d, dimg, nullptr);
+    hipLaunchKernelGGL(dct4_image_kernel, dim3(256 * 256 / 4 / 256), dim3(256), 0, 0, d, dimg);
+    hipLaunchKernelGGL(dct4_b3_image_kernel, dim3(4 * 2 * 16 * 64 / 256), dim3(256), 0, 0, d, reinterpret_cast<b3_u4*>(dimg + 256 * 256));
+    float* dimg_ct = dimg + 256 * 256 + B3_IMG_U4 * 4;          // the library's image (factored kernels)
+    mg_dct4_image(d, dimg_ct, nullptr);
     const b3_u4* img3 = reinterpret_cast<const b3_u4*>(dimg + 256 * 256);
     CodecParams cp{CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, nullptr, nullptr, 0};
     CodecParams cpr{CODEC_RAW, 1000.f, -1.f, 1.f, -5.f, 5.f, nullptr, nullptr, 0};
@@ -102,7 +107,7 @@ int main(int argc, char** argv) {
     printf("== K2 bf16 x 3\n");
     {
         hipMemsetAsync(y, 0, (size_t)B * T * 4, 0); hipMemsetAsync(y2, 0, (size_t)B * T * 4, 0);
-        mg_mdct4_forward(x, B, T, 512, w, d, dimg, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, 0, spec, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        mg_mdct4_forward(x, B, T, 512, w, d, dimg_ct, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, 0, spec, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
         auto k3 = imdct4_b3_kernel<CODEC_ARCSINH, 0>;
         hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3_K2_LDS);
         const dim3 g2(B < 256 ? B : 256);
@@ -123,7 +128,7 @@ int main(int argc, char** argv) {
     }
     printf("== factored transform (mdct_ct.h), two 8-wave workgroups per CU\n");
     {
-        const float* imgc = dimg + 256 * 256 + B3_IMG_U4 * 4;
+        const float* imgc = dimg_ct;
         const dim3 gc(n_tiles < 512 ? n_tiles : 512);
 #define K1CT(MODE_, SPEC_, PAIR_, cp_, out_, name)                                                                        \
     {                                                                                                                       \
@@ -151,7 +156,7 @@ int main(int argc, char** argv) {
         K1CT(CODEC_ARCSINH, false, true, cp, spec2, "K1 ct arcsinh, pair only");
         K1CT(CODEC_ARCSINH, true, true, cp, spec2, "K1 ct arcsinh, spectrogram + pair");
         // K2
-        mg_mdct4_forward(x, B, T, 512, w, d, dimg, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, 0, spec, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        mg_mdct4_forward(x, B, T, 512, w, d, dimg_ct, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, 0, spec, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
         auto kc = imdct4_ct_kernel<CODEC_ARCSINH>;
         hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT_K2_LDS);
         const dim3 g2c(B < 512 ? B : 512);
@@ -170,15 +175,15 @@ int main(int argc, char** argv) {
         printf("   round trip ct K1 (default dispatch) -> ct K2 vs input: %.3e (max |x| %.3e)\n", dd, amax);
     }
     printf("== through the C ABI\n");
-    report("mg_mdct4_forward arcsinh", time_ms([&] { mg_mdct4_forward(x, B, T, 512, w, d, dimg, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, 0, spec, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr); }, iters));
-    report("mg_imdct4_forward arcsinh", time_ms([&] { mg_imdct4_forward(spec, B, F, 512, w, d, dimg, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, nullptr, nullptr, y, T, 0, nullptr, nullptr); }, iters));
+    report("mg_mdct4_forward arcsinh", time_ms([&] { mg_mdct4_forward(x, B, T, 512, w, d, dimg_ct, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, 0, spec, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr); }, iters));
+    report("mg_imdct4_forward arcsinh", time_ms([&] { mg_imdct4_forward(spec, B, F, 512, w, d, dimg_ct, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, nullptr, nullptr, y, T, 0, nullptr, nullptr); }, iters));
     {
-        setenv("MG_MDCT_B3", "0", 1);
-        mg_imdct4_forward(spec, B, F, 512, w, d, dimg, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, nullptr, nullptr, y2, T, 0, nullptr, nullptr);
-        unsetenv("MG_MDCT_B3");
+        setenv("MG_MDCT_CT", "0", 1);
+        mg_imdct4_forward(spec, B, F, 512, w, d, dimg_ct, CODEC_ARCSINH, 1000.f, -1.f, 1.f, -5.f, 5.f, nullptr, nullptr, y2, T, 0, nullptr, nullptr);
+        unsetenv("MG_MDCT_CT");
         double amax;
         const double dd = max_diff(y, y2, (size_t)B * T, &amax);
-        printf("   waveforms: max |default - f32 pipe| = %.3e, max |y| = %.3e; round trip vs input:", dd, amax);
+        printf("   waveforms: max |default - generic kernel| = %.3e, max |y| = %.3e; round trip vs input:", dd, amax);
         const double rt = max_diff(y, x, (size_t)B * T, &amax);
         printf(" %.3e (max |x| %.3e)\n", rt, amax);
     }

@@ -31,6 +31,14 @@ def test_library_exports_every_declared_symbol():
     for s in header_symbols():
         assert hasattr(lib, s), s
     assert _lib.load().mg_abi_version() == 3 == _lib.ABI_VERSION
+    # ... and nothing else: every exported mg_* symbol is declared (library-internal cross-file helpers are hidden)
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or shutil.which("llvm-nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    if os.path.exists(nm):
+        out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+        exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("mg_")}
+        assert exported == set(header_symbols()), (exported ^ set(header_symbols()))
     assert _lib.load().mg_mdct4_num_frames(32512, 512) == 128
     assert _lib.load().mg_mdct4_num_frames(7936, 512) == 32
 

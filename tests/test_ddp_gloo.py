@@ -89,6 +89,69 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _worker_wire16(rank, world, port, out_dir, wire):
+    """MDCTGAN_DDP_GRAD_DTYPE: the same exchange through a 16-bit wire format, with loss-scaled gradients (x 1024) as under --fp16."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["MDCTGAN_DDP_GRAD_DTYPE"] = wire
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from mdctgan_amd import ddp
+    from mdctgan_amd import functional as Fh
+    from oracle import nets as onets
+    torch.manual_seed(7)
+    netD = onets.init_weights(onets.MultiscaleDRef(3, ndf=4, n_layers=3, num_D=2))
+    params = list(netD.parameters())
+    flat_g, gslices = _arena(params)
+    red = ddp.ArenaReducer(flat_g, gslices, writes_per_step=1, bucket_bytes=4096, mode="allreduce")
+    assert red.wire is not None and red.wire.dtype == {"bf16": torch.bfloat16, "f16": torch.float16}[wire]
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2 * world, 3, 32, 64, generator=g)
+    mine = x[rank * 2:(rank + 1) * 2]
+    scale = 1024.0
+    eps = {"bf16": 2.0 ** -8, "f16": 2.0 ** -10}[wire]           # half an ulp per rank's addend, with margin
+    for step in range(2):
+        netD.zero_grad()
+        (scale * _loss(netD, mine)).backward()
+        for p, o, n in reversed(gslices):
+            flat_g[o:o + p.numel()].copy_(p.grad.reshape(-1))
+            Fh._notify(p)
+        red.finish()
+        got_all = flat_g / world / scale
+        netD.zero_grad()
+        _loss(netD, x).backward()
+        gmax = max(float(p.grad.abs().max()) for p in params)
+        for p, o, n in gslices:
+            want = p.grad.reshape(-1)
+            got = got_all[o:o + p.numel()]
+            # every rank's addend is rounded to the wire format once: the error of the mean is bounded by eps x the largest
+            # per-rank magnitude, itself bounded by a few times the mean's -- 4 eps |want|_max + the float32 floor of the plain test
+            err = float((got - want).abs().max())
+            assert err <= 2e-6 * gmax + (4 * eps + 2e-5) * float(want.abs().max()), (wire, rank, step, o, err, float(want.abs().max()))
+    # a non-finite gradient on ONE rank reaches every rank's arena (the GradScaler's check runs on the reduced arena)
+    netD.zero_grad()
+    (scale * _loss(netD, mine)).backward()
+    for p, o, n in reversed(gslices):
+        flat_g[o:o + p.numel()].copy_(p.grad.reshape(-1))
+        if rank == world - 1 and o == gslices[2][1]:
+            flat_g[o] = float("inf")
+        Fh._notify(p)
+    red.finish()
+    assert not bool(torch.isfinite(flat_g[gslices[2][1]]))
+    red.close()
+    np.save(os.path.join(out_dir, "ok%d.npy" % rank), np.ones(1))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,wire", [(2, "f16"), (2, "bf16"), (4, "bf16")])
+def test_gradient_average_through_16_bit_wire_format(tmp_path, world, wire):
+    """MDCTGAN_DDP_GRAD_DTYPE=bf16 | f16 (opt-in for --fp16 runs: half the all-reduce payload, configs[3] 2.98 -> 1.49 GB per step):
+    the averaged gradient equals the single-process gradient on the concatenated batch to the wire format's rounding, with
+    loss-scaled (x 1024) gradients, and an inf on one rank is seen by all."""
+    port = _free_port()
+    mp.spawn(_worker_wire16, args=(world, port, str(tmp_path), wire), nprocs=world, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d.npy" % r)) for r in range(world))
+
+
 def test_two_rank_gradient_average(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)

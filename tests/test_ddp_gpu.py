@@ -116,6 +116,32 @@ def test_data_parallel_step_captures_into_a_hipgraph(mode):
     assert line and line[-1] == "DDP_GRAPH_PROBE capture=ok replay_equals_eager=True", (r.stdout[-500:], r.stderr[-500:])
 
 
+def test_capture_failure_on_any_rank_makes_every_rank_step_eagerly(one_rank_group, golden, monkeypatch):
+    """Pix2PixHDModel.make_step under MDCTGAN_DDP_GRAPH=auto: a rank whose capture fails (simulated: MDCTGAN_DDP_GRAPH_FAIL_RANK)
+    reports it through one MAX all-reduce and EVERY rank gets the eager step back -- same parameters as plain eager data-parallel
+    steps.  (The capture that succeeds is scripts/ddp_graph_probe.py's business, in its own process.)"""
+    from mdctgan_amd import ddp
+    lr, hr = _batch(golden)
+    monkeypatch.setenv("MDCTGAN_DDP_GRAPH", "auto")
+    monkeypatch.setenv("MDCTGAN_DDP_GRAPH_FAIL_RANK", "0")
+    a, b = _model(), _model()
+    ddp.attach(a)
+    run = a.make_step(lr, hr, warmup=2)
+    assert run.graph is None and os.environ["MDCTGAN_DDP_GRAPH"] == "auto"
+    for _ in range(3):
+        run(lr, hr)
+    for r in a.reducers.values():
+        r.close()
+    ddp.attach(b)
+    for _ in range(3):
+        b.optimize_parameters(lr, hr)
+    torch.cuda.synchronize()
+    for (k, x), (_, y) in zip(a.netG.state_dict().items(), b.netG.state_dict().items()):
+        assert torch.equal(x, y), k
+    for r in b.reducers.values():
+        r.close()
+
+
 def test_sync_batchnorm_one_rank_equals_plain(one_rank_group):
     """ddp.enable_sync_batchnorm (SURVEY 8e opt-in): with one rank the all-reduced partial sums are the local ones -- the
     bottleneck-attention stack must give the same outputs, gradients and running statistics bit for bit, through the

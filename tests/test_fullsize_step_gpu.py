@@ -12,6 +12,10 @@ split plan of the bench in ONE backward chain -- against the CPU oracle (oracle/
   -- against the oracle's three Adam steps, bit for bit against the same run with the separate kernels
   (MG_NO_WINO_ADAM_FUSION=1), and at batch 8 bit for bit as a hipGraph replay (test_bench_step_*).
 
+* (round 5) the bench's own batch: configs[1] at batch 8 (losses 1e-4, every gradient; the float32 yardstick at 16 threads), and the
+  --fp16 step over THREE iterations against the oracle's CPU-autocast + torch.amp.GradScaler steps (same loss-scale trajectory,
+  losses, per-parameter update size).
+
 Both legs get the same float32 spectrograms (the oracle's float64 transform, pinned to the reference at 1e-11 by
 tests/test_oracle_golden.py) so K1's worst-case 5e-4 bins do not enter the gradient comparison; K1 on the same audio is
 checked beside it through the losses.  The bottleneck-transformer arithmetic inside configs[2] is the oracle's
@@ -115,16 +119,26 @@ def _snapshot(net):
     return {k: v.detach().clone() for k, v in net.state_dict().items()}
 
 
-@pytest.mark.parametrize("tag,fp16,feat", [("configs1", False, True), ("configs2", False, True), ("configs2", True, True),
-                                           ("configs2", True, False)],
-                         ids=["configs1_f32_batch2", "configs2_f32_batch1", "configs2_fp16_batch1", "configs2_fp16_noFeat_batch1"])
-def test_full_size_step_gradients(tag, fp16, feat, monkeypatch):
+# --fp16 over several iterations: a loss scale at which NEITHER leg overflows on these weights (the oracle's float16 gradients
+# overflow at 1024 and 512 -- measured: 1024 -> 512 -> 256 over its first two iterations; the HIP step keeps float32 gradients
+# between layers and survives 1024), so that both take three real Adam steps and the scale trajectories can be required equal
+AMP_SCALE = 128.0
+
+
+@pytest.mark.parametrize("tag,fp16,feat,batch,n_steps",
+                         [("configs1", False, True, None, 3), ("configs2", False, True, None, 3), ("configs2", True, True, None, 3),
+                          ("configs2", True, False, None, 1), ("configs1", False, True, 8, 1)],
+                         ids=["configs1_f32_batch2", "configs2_f32_batch1", "configs2_fp16_batch1_3steps", "configs2_fp16_noFeat_batch1",
+                              "configs1_f32_batch8"])
+def test_full_size_step_gradients(tag, fp16, feat, batch, n_steps, monkeypatch):
+    """n_steps = 3: the oracle also takes three Adam steps (float32: iterations 2, 3 run the fused weight-gradient + Adam + transform
+    kernels; --fp16: CPU autocast + torch.amp.GradScaler, train.py:183-199).  batch = 8: the bench's own batch (one iteration; the
+    float32 yardstick then runs on 16 threads -- its run-to-run spread is far below the bars)."""
     from mdctgan_amd import options
     from mdctgan_amd.pix2pixHD_model import create_model
     cfg = CONFIGS[tag]
-    B = cfg["batch"]
+    B = batch or cfg["batch"]
     threads = torch.get_num_threads()
-    n_steps = 3 if not fp16 else 1                   # float32: the oracle also takes three Adam steps (iterations 2, 3 = fused path)
     try:
         torch.manual_seed(1234)          # module-default biases / position embeddings come from the GLOBAL generator: fix it too
         gen = torch.Generator().manual_seed(2024)
@@ -134,17 +148,20 @@ def test_full_size_step_gradients(tag, fp16, feat, monkeypatch):
         sdG = {k: v.clone() for k, v in netG.state_dict().items()}
         sdD = {k: v.clone() for k, v in netD.state_dict().items()}
         lr, hr = synth(B, 5)
-        torch.set_num_threads(1)                     # the deterministic yardstick
+        torch.set_num_threads(1 if batch is None else min(16, threads))     # the deterministic yardstick (bench batch: 16 threads)
         ref32 = ostep.HotPathRef(netG, netD, ostep.CodecCfg(), num_D=cfg["num_D"], feat_loss=feat)
         # yardstick: the oracle's own float32 run -- under --fp16 the oracle's CPU-autocast run (the reference's arithmetic)
         l32, gG32, gD32 = oracle_gradients(ref32, lr.numpy(), hr.numpy(), amp=fp16)
         lr_s, _ = ref32.spectro(lr.numpy())
         hr_s, _ = ref32.spectro(hr.numpy())
-        ref_losses, ref_after = [], None
+        ref_losses, ref_after, ref_scales = [], None, []
         if n_steps > 1:                              # train.py:160-202 three times on the oracle (torch.optim.Adam)
             torch.set_num_threads(min(16, threads))
+            ref_scaler = torch.amp.GradScaler("cpu", init_scale=AMP_SCALE) if fp16 else None
             for _ in range(n_steps):
-                ref_losses.append(ref32.train_step(lr.numpy(), hr.numpy()))
+                ref_losses.append(ref32.train_step(lr.numpy(), hr.numpy(), amp=fp16, scaler=ref_scaler))
+                if fp16:
+                    ref_scales.append(ref_scaler.get_scale())
             ref_after = ({k: v.clone() for k, v in netG.state_dict().items()}, {k: v.clone() for k, v in netD.state_dict().items()})
             netG.load_state_dict(sdG)
             netD.load_state_dict(sdD)
@@ -181,7 +198,7 @@ def test_full_size_step_gradients(tag, fp16, feat, monkeypatch):
     if fp16:
         # a scale at which float16-rounded gradients stay finite on these weights (the default 65536 backs off on the first
         # iterations, as in the reference -- tests/test_amp_gpu.py pins that behaviour; here the step must NOT be skipped)
-        scale = 1024.0
+        scale = 1024.0 if n_steps == 1 else AMP_SCALE
         model.scaler.state[0] = scale
     lr_d, hr_d = lr.to(DEV), hr.to(DEV)
 
@@ -249,16 +266,27 @@ def test_full_size_step_gradients(tag, fp16, feat, monkeypatch):
                     bad.append((pre + k, "no mask behind this layer: rel-L2 %.3e" % e_hip, "fp32-CPU %.3e" % e_32))
     import json, os
     rep = os.environ.get("MG_STEP_REPORT")
-    case = tag + ("_fp16" if fp16 else "") + ("" if feat else "_noFeat")
+    case = tag + ("_fp16" if fp16 else "") + ("" if feat else "_noFeat") + ("_batch%d" % batch if batch else "")
     steps_report = {}
 
     # 3) iterations 2 and 3 (float32): the weight-side fusion runs from the second iteration on
     if n_steps > 1 and not bad:
         trunk = [p for k, p in model.netG.named_parameters() if "conv_block" in k and k.endswith("weight") and p.dim() == 4]
-        more = [model.optimize_parameters(lr_d, hr_d) for _ in range(n_steps - 1)]
+        hip_scales = [model.scaler.get_scale()] if fp16 else []
+        more = []
+        for _ in range(n_steps - 1):
+            more.append(model.optimize_parameters(lr_d, hr_d))
+            if fp16:
+                hip_scales.append(model.scaler.get_scale())
         torch.cuda.synchronize()
-        fused = [p for p in trunk if getattr(p, "_mg_u_persist", None) is not None]
-        assert len(fused) >= 18, "the trunk layers did not take the fused weight-gradient + Adam path (%d of %d)" % (len(fused), len(trunk))
+        if fp16:
+            # the GradScaler's trajectory (train.py:183-199: step skipped and scale halved on inf / nan): equal, and no step skipped --
+            # otherwise the update comparison below would compare different numbers of Adam steps
+            steps_report["scales"] = [hip_scales, ref_scales]
+            assert hip_scales == ref_scales == [AMP_SCALE] * n_steps, ("loss-scale trajectories (HIP, oracle)", hip_scales, ref_scales)
+        else:
+            fused = [p for p in trunk if getattr(p, "_mg_u_persist", None) is not None]
+            assert len(fused) >= 18, "the trunk layers did not take the fused weight-gradient + Adam path (%d of %d)" % (len(fused), len(trunk))
         for it, lossd in enumerate(more, start=1):
             for k, v in lossd.items():
                 want = ref_losses[it][k]
@@ -268,7 +296,15 @@ def test_full_size_step_gradients(tag, fp16, feat, monkeypatch):
                 # way, the next gradient is taken at a different point), and the GAN losses move by 2x per iteration here, so two float32
                 # evaluations drift apart: measured 4e-4 (configs[1]) / 5e-3 (configs[2]) at iteration 2, 2.5e-2 at iteration 3 (the discriminator-only loss
                 # D_real stays at 3e-6).  A missing / doubled / mis-clocked update or a stale transformed weight moves them by O(1).
-                if not abs(v.item() - want) <= (1e-2 if it == 1 else 6e-2) * abs(want):
+                # --fp16 (measured, profiles/r05_fullsize_step_parity.txt): D_real and G_GAN_Feat stay within 5e-3 / 1e-2 of the oracle's
+                # CPU-autocast trajectory and are held to 2e-2; G_GAN and D_fake -- functions of D(G(x)) after BOTH nets took sign-like
+                # first Adam steps from float16-rounded gradients, moving 7.6 -> 8.8 -> 21.6 here -- differ by 2.7e-2 / 3.8e-2 at
+                # iteration 2 and 8.6e-2 at iteration 3 between the two float16 evaluations.
+                if fp16:
+                    tol = 2e-2 if k in ("D_real", "G_GAN_Feat") else (6e-2 if it == 1 else 1.5e-1)
+                else:
+                    tol = 1e-2 if it == 1 else 6e-2
+                if not abs(v.item() - want) <= tol * abs(want):
                     bad.append(("loss %s at iteration %d" % (k, it + 1), v.item(), want))
         lr_adam = 2e-4
         for net, ref_sd, p_init, pre, g64 in ((model.netG, ref_after[0], p0[0], "G.", gG64), (model.netD, ref_after[1], p0[1], "D.", gD64)):
@@ -291,10 +327,19 @@ def test_full_size_step_gradients(tag, fp16, feat, monkeypatch):
                         bad.append((pre + k, "the oracle left this parameter alone, the HIP step moved it"))
                     continue
                 # (|m / sqrt(v)| exceeds 1 after the first step: an element's move per step is ~lr, not bounded by it)
-                if not (rel <= 0.7 or d_ref.size == 1) or not np.abs(d_hip - d_ref).max() <= 3.0 * n_steps * lr_adam:
+                ratio = np.linalg.norm(d_hip) / max(np.linalg.norm(d_ref), 1e-30)
+                steps_report["update-size " + pre + k] = float(ratio)
+                if fp16:
+                    # two float16 evaluations of the generator's gradient are 0.35-0.47 apart (fp16_gradient_verdict), and Adam turns a
+                    # sign disagreement into a full-size disagreement of the move: the elementwise comparison says nothing.  What
+                    # three Adam steps of either leg must agree on is the SIZE of the move (a skipped / doubled step, a wrong
+                    # 1 / scale or a stale float16 shadow changes it by >= 1.5x) and its bound.
+                    if not (0.5 <= ratio <= 2.0 or d_ref.size == 1) or not np.abs(d_hip - d_ref).max() <= 3.0 * n_steps * lr_adam:
+                        bad.append((pre + k, "3-step update: |hip| / |oracle| %.3f, max |diff| %.3e" % (ratio, np.abs(d_hip - d_ref).max())))
+                elif not (rel <= 0.7 or d_ref.size == 1) or not np.abs(d_hip - d_ref).max() <= 3.0 * n_steps * lr_adam:
                     bad.append((pre + k, "3-step update: rel-L2 %.3e, max |diff| %.3e" % (rel, np.abs(d_hip - d_ref).max())))
         # ... and bit for bit what the three separate kernels (weight gradient, Adam, transform) leave
-        if not bad:
+        if not bad and not fp16:
             monkeypatch.setenv("MG_NO_WINO_ADAM_FUSION", "1")
             plain = build()
             with torch.no_grad():          # (the same history as `model`: leg 1's forward also moved the BatchNorm running statistics)

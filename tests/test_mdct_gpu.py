@@ -174,42 +174,11 @@ def test_frame_tile_sizes_agree(mods, monkeypatch):
         assert (outs["32"][2] - outs[ft][2]).abs().max().item() <= 2e-6 * outs["32"][2].abs().max().item()
 
 
-def test_mdct_gemm_kernel_matches(mods, golden, monkeypatch):
-    """The tiled-GEMM K1 kernel (used for large batches) against the golden spectra and against the per-wave kernel:
-    same float32 window products and fold, a different (still exact-f32) accumulation order -> 2e-6 * max|X|; the codec
-    epilogue (arcsinh + fixed range + pair + statistics) agrees to 1e-6."""
-    from mdctgan_amd import _lib
-    from mdctgan_amd.mdct import dct4_table, mdct4_codec
-    mdct, _, w = mods
-    g = golden("g2_mdct4")
-    monkeypatch.setenv("MG_MDCT_GEMM", "1")
-    X, _ = mdct(torch.from_numpy(g["x"]).to(DEV))
-    Xc = X.cpu().numpy().astype(np.float64)
-    for b in range(2):
-        assert np.abs(Xc[b] - g["X"][b]).max() <= 2e-6 * np.abs(g["X"][b]).max()
-    gen = torch.Generator().manual_seed(3)
-    x = (0.05 * torch.randn(5, 32512, generator=gen)).to(DEV)     # 5 clips x 128 frames = 5 row tiles
-    win, d4 = torch.from_numpy(w).to(DEV), dct4_table(256, DEV)
-    outs = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("MG_MDCT_GEMM", mode)
-        r = mdct4_codec(x, win, d4, 512, codec=_lib.MG_CODEC_ARCSINH, gain=1000.0, norm_range=(-1.0, 1.0), src_range=(-5.0, 5.0),
-                        per_sample=False, want_pair=True, want_stats=True, want_frames=False)
-        outs[mode] = (r["spec"].clone(), r["pair"].clone(), r["stats"].clone())
-    want, _ = transform.to_spectro(x.cpu().numpy(), w, 512, 256, arcsinh_transform=True, raw_mdct=False,
-                                   arcsinh_gain=1000.0, abs_norm=True, src_range=(-5.0, 5.0), norm_range=(-1.0, 1.0))
-    for mode in ("0", "1"):     # both kernels within the header's 5e-4 of the float64 oracle (gain 1000 amplifies near-zero bins)
-        assert np.abs(outs[mode][0].cpu().numpy() - want[:, 0]).max() <= 5e-4, mode
-        pair = outs[mode][1].cpu().numpy()
-        assert np.abs(pair[..., 0] - want[:, 0]).max() <= 5e-4 and np.abs(pair[..., 1] - (2 * np.abs(want[:, 0]) - 1.0)).max() <= 1e-3
-    assert torch.allclose(outs["0"][2], outs["1"][2], rtol=1e-5)
-
-
 @pytest.mark.parametrize("shape", [(2, 7936), (5, 32512), (3, 32512 + 76), (64, 32512), (1, 260)],
-                         ids=["2x32fr", "5x128fr", "3x129fr_ragged", "64x128fr_nw8", "1x3fr"])
-def test_table_stationary_kernels_match_round2_kernels_and_oracle(mods, shape, monkeypatch):
-    """csrc/mdct_bs.h (K1 / K2 with the DCT-IV table resident in registers; NW = 2 below 256 row tiles, NW = 8 from there)
-    against the round-1/2 kernels (MG_MDCT_BS=0) and the float64 oracle: raw coefficients 2e-6 * max|X|, the arcsinh /
+                         ids=["2x32fr", "5x128fr", "3x129fr_ragged", "64x128fr", "1x3fr"])
+def test_factored_kernels_match_generic_kernels_and_oracle(mods, shape, monkeypatch):
+    """csrc/mdct_ct.h (K1 / K2 with the DCT-IV factored into 8- and 16-point DFT stages: the default)
+    against the generic dense-table kernels of csrc/mdct.hip (MG_MDCT_CT=0) and the float64 oracle: raw coefficients 2e-6 * max|X|, the arcsinh /
     fixed-range codec 5e-4 against the oracle (its own bar) and 2e-6 against the older kernel (same coefficients to 2e-6 of
     the largest, different libm: the fast asinh is a few ulp from asinhf), K2 on one and the same spectrogram 2e-6 * max|y|.
     129 frames per clip: row tiles straddle clips in K1 and the last tile of a clip is ragged in K2."""
@@ -224,7 +193,7 @@ def test_table_stationary_kernels_match_round2_kernels_and_oracle(mods, shape, m
               want_pair=True, want_stats=True)
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("MG_MDCT_BS", mode)
+        monkeypatch.setenv("MG_MDCT_CT", mode)
         raw = mdct4_codec(x, win, d4, 512)["spec"]
         r = mdct4_codec(x, win, d4, 512, **kw)
         y, _ = imdct4_codec(r["spec"] if mode == "1" else out["1"][1], win, d4, 512, codec=_lib.MG_CODEC_ARCSINH, gain=1000.0,
@@ -256,7 +225,7 @@ def test_table_stationary_kernels_match_round2_kernels_and_oracle(mods, shape, m
 
 
 def test_fast_codec_math(mods):
-    """The codec arithmetic of csrc/mdct_bs.h on its own: K1's normalised output against a float64 evaluation of
+    """The codec arithmetic of csrc/mdct_codec.h on its own: K1's normalised output against a float64 evaluation of
     (asinh(gain X) / ln 10 - min) / (max - min) * (nr1 - nr0) + nr0 on K1's own raw coefficients X (so the contraction's
     rounding drops out): <= 1e-6 in the [-1, 1] range (a float32 ulp of |l| <= 5 is 4.8e-7), over amplitudes from 1e-9
     (series branch) to 50 (log branch); K2's decode (sinh) against float64 on the same spectrogram: 1e-6 relative."""
@@ -284,8 +253,8 @@ def test_fast_codec_math(mods):
     assert (y - y2).abs().max().item() <= 3e-6 * y2.abs().max().item()
 
 
-def test_table_stationary_k1_writes_nothing_outside_its_outputs(mods):
-    """The last row tile of a ragged batch (3 clips x 129 frames = 387 rows, 13 tiles of 32) is masked by the buffer
+def test_k1_writes_nothing_outside_its_outputs(mods):
+    """The last row tile of a ragged batch (3 clips x 129 frames = 387 rows) is masked by the buffer
     descriptor's range check (voffset + scalar row offset against num_records), not by branches: outputs embedded in
     guard-filled arenas must come back with the guards intact and the same values as the stand-alone call."""
     from mdctgan_amd import _lib
@@ -302,23 +271,18 @@ def test_table_stationary_k1_writes_nothing_outside_its_outputs(mods):
     arena_s = torch.full((G + n + G,), 7.5, device=DEV)
     arena_p = torch.full((G + 2 * n + G,), 7.5, device=DEV)
     spec, pair = arena_s[G:G + n], arena_p[G:G + 2 * n]
-    for b3 in ("0", "1"):               # the f32-pipe kernel (mdct_bs.h) and the bf16 x 3 kernel (mdct_b3.h), both forced
-        os.environ["MG_MDCT_B3"] = b3
-        try:
-            arena_s.fill_(7.5)
-            arena_p.fill_(7.5)
-            rc = lib.mg_mdct4_forward(_lib.ptr(x), B, T, 512, _lib.ptr(win), _lib.ptr(d4), dct4_image(d4, 256), _lib.MG_CODEC_ARCSINH, 1000.0,
-                                      -1.0, 1.0, -5.0, 5.0, 0, spec.data_ptr(), pair.data_ptr(), None, None, None, None, None, _lib.stream())
-            assert rc == 0
-            torch.cuda.synchronize()
-            for arena, m in ((arena_s, n), (arena_p, 2 * n)):
-                assert bool((arena[:G] == 7.5).all()) and bool((arena[G + m:] == 7.5).all()), b3
-            r = mdct4_codec(x, win, d4, 512, codec=_lib.MG_CODEC_ARCSINH, gain=1000.0, norm_range=(-1.0, 1.0), src_range=(-5.0, 5.0), want_pair=True)
-            # (with the pair the launcher hands out the spectrogram as channel 0 of the pair)
-            assert torch.equal(r["spec"].reshape(-1), spec) and torch.equal(r["pair"].reshape(-1), pair), b3
-            assert r["spec"].data_ptr() == r["pair"].data_ptr() and bool((spec != 7.5).all())
-        finally:
-            del os.environ["MG_MDCT_B3"]
+    arena_s.fill_(7.5)
+    arena_p.fill_(7.5)
+    rc = lib.mg_mdct4_forward(_lib.ptr(x), B, T, 512, _lib.ptr(win), _lib.ptr(d4), dct4_image(d4, 256), _lib.MG_CODEC_ARCSINH, 1000.0,
+                              -1.0, 1.0, -5.0, 5.0, 0, spec.data_ptr(), pair.data_ptr(), None, None, None, None, None, _lib.stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    for arena, m in ((arena_s, n), (arena_p, 2 * n)):
+        assert bool((arena[:G] == 7.5).all()) and bool((arena[G + m:] == 7.5).all())
+    r = mdct4_codec(x, win, d4, 512, codec=_lib.MG_CODEC_ARCSINH, gain=1000.0, norm_range=(-1.0, 1.0), src_range=(-5.0, 5.0), want_pair=True)
+    # (with the pair the launcher hands out the spectrogram as channel 0 of the pair)
+    assert torch.equal(r["spec"].reshape(-1), spec) and torch.equal(r["pair"].reshape(-1), pair)
+    assert r["spec"].data_ptr() == r["pair"].data_ptr() and bool((spec != 7.5).all())
     # a caller written against the round-1 ABI: the plain m x m table and no image -> the kernels that need none, same values
     plain = d4[:256 * 256].clone()
     spec1 = torch.empty_like(spec)
@@ -329,21 +293,18 @@ def test_table_stationary_k1_writes_nothing_outside_its_outputs(mods):
     assert rc == 0 and (spec1 - spec).abs().max().item() <= 2e-4
 
 
-@pytest.mark.parametrize("family", ["b3", "ct"])
 @pytest.mark.parametrize("shape", [(5, 32512), (3, 32512 + 76), (64, 32512), (2, 7936)],
                          ids=["5x128fr", "3x129fr_ragged", "64x128fr", "2x32fr"])
-def test_large_batch_kernels_against_oracle(mods, golden, family, shape, monkeypatch):
-    """The kernels the dispatcher only picks from 512 row tiles on -- csrc/mdct_b3.h (the DCT-IV as exact three-piece bf16 products,
-    table in 384 registers) and csrc/mdct_ct.h (the DCT-IV factored into 8- and 16-point DFT stages on the f32 pipe) -- FORCED on
-    test-sized batches (MG_MDCT_B3 / MG_MDCT_CT = 1) and held to the same bars as every other K1 / K2 against the float64
+def test_large_batch_kernels_against_oracle(mods, golden, shape, monkeypatch):
+    """csrc/mdct_ct.h (the DCT-IV factored into 8- and 16-point DFT stages on the f32 pipe; the default K1 / K2 at every size)
+    held to the same bars as every other K1 / K2 against the float64
     oracle: raw coefficients 2e-6 * max|X|, normalised spectrogram 5e-4, pair channel 0 == spectrogram and channel 1 = 2|v| - 1,
     statistics, waveform 2e-6 * max|y|, K2(K1(x)) == x; clips of 129 frames: row tiles straddle clips in K1 and the last
     tile of a clip is ragged in K2.  Plus the golden fixture G2 / G3 through the same kernels."""
     from mdctgan_amd import _lib
     from mdctgan_amd.mdct import dct4_table, imdct4_codec, mdct4_codec
     _, _, w = mods
-    monkeypatch.setenv("MG_MDCT_B3", "1" if family == "b3" else "0")
-    monkeypatch.setenv("MG_MDCT_CT", "1" if family == "ct" else "0")
+    monkeypatch.setenv("MG_MDCT_CT", "1")
     B, T = shape
     gen = torch.Generator().manual_seed(B * 1000 + T + 7)
     x = (0.05 * torch.randn(B, T, generator=gen)).to(DEV)
