@@ -220,6 +220,8 @@ def also_summary(also):
             out["error"] = (out.get("error", "") + " | " + cmd)[:120]
         elif "--config 2" in cmd:
             out["cfg2_fp16_steps_s"], out["cfg2_fp16_ms"] = d.get("value"), d.get("ms_per_step")
+        elif "--config 4" in cmd and "MG_F32_SPLIT" in cmd:
+            out["cfg4_f32split_audio_s_s"] = d.get("value")
         elif "--config 4" in cmd:
             out["cfg4_audio_s_s"], out["cfg4_ms"] = d.get("value"), d.get("ms_per_step")
             out["cfg4_frac"] = (d.get("roofline") or {}).get("frac")
@@ -237,7 +239,11 @@ def also_lines(args):
     K1 + K2 alone at 4096 clips (north_star's first-named kernels against their HBM roofline)."""
     import subprocess
     out = []
-    for extra, env in ((["--config", "2", "--fp16"], None), (["--config", "4"], None), (["--mode", "codec"], None)):
+    # (the fourth line is configs[4] once more with MG_F32_SPLIT=1: the Winograd-domain GEMMs as exact three-piece bf16 products --
+    # float32-accurate results, tests/test_conv_gpu.py::test_f32_split_gemms_are_float32_accurate -- reported BESIDE the float32-pipe
+    # line, never instead of it: DESIGN section 3)
+    for extra, env in ((["--config", "2", "--fp16"], None), (["--config", "4"], None), (["--mode", "codec"], None),
+                       (["--config", "4", "--no-cpu-baseline"], {"MG_F32_SPLIT": "1"})):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
                "--no-also"] + extra
         t0 = time.perf_counter()

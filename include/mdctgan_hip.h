@@ -230,7 +230,8 @@ int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const f
  * pairs of ResnetBlock (models/networks.py:440-462).  When the layer runs as Winograd F(2x2,3x3) and a sample's map is
  * <= 640 pixels, the inverse transform, the statistics and the normalisation are ONE kernel; otherwise the two calls are
  * made back to back -- same results either way (statistics in double, fixed reduction order).  y_raw is kept because the
- * InstanceNorm backward recomputes the normalised value from it.  workspace >= mg_conv_fwd_instnorm_workspace(g). */
+ * InstanceNorm backward recomputes the normalised value from it; y_raw = NULL (inference) skips that store (the two-call path
+ * then normalises in place).  workspace >= mg_conv_fwd_instnorm_workspace(g). */
 size_t mg_conv_fwd_instnorm_workspace(const mg_conv_geom* g);
 int mg_conv_fwd_instnorm_w(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y_raw, float eps,
                            int act, const float* residual, float* y, float* mean, float* rstd, void* workspace,

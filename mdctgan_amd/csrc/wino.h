@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void wino_out_norm_kernel(const float* __restr
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const size_t off = ((size_t)(b * 2 * TH + 2 * ty + (q >> 1)) * (2 * TW) + 2 * tx + (q & 1)) * C + c0;
-                *reinterpret_cast<float4*>(y_raw + off) = v[i][q];
+                if (y_raw) *reinterpret_cast<float4*>(y_raw + off) = v[i][q];      // (inference: nobody reads the raw output again)
                 float4 o;
                 o.x = apply_act((v[i][q].x - mu[0]) * rs[0], nrm.act);
                 o.y = apply_act((v[i][q].y - mu[1]) * rs[1], nrm.act);

@@ -510,12 +510,15 @@ class _ConvInstNormFn(torch.autograd.Function):
             v, _ = ops.wino_tile_buffers(g, x.device, want_md=False)
         y16 = (torch.empty(B * g.OH * g.OW * g.Co, dtype=torch.float16, device=x.device)
                if _want_h16(B, g.OH * g.OW, g.Co) else None)
+        need_raw = any(ctx.needs_input_grad)          # under torch.no_grad() nobody reads the raw convolution output again
         y, y_raw, mean, rstd = ops.conv_fwd_instnorm(g, nhwc_view(x), w, bias.detach() if bias is not None else None, act,
-                                                     nhwc_view(res) if res is not None else None, eps, u, v, v_filled, y16)
+                                                     nhwc_view(res) if res is not None else None, eps, u, v, v_filled, y16,
+                                                     need_raw=need_raw)
         ctx.u, ctx.v = u, (v if (weight_grad and weight.requires_grad) else None)
         ctx.g, ctx.cfg = g, (1, pad, reflect, ACT_NONE, False, weight_grad)
         ctx.weight, ctx.bias, ctx.norm_act = weight, bias, act
-        ctx.save_for_backward(x, nchw_view(y_raw), mean, rstd)
+        if need_raw:
+            ctx.save_for_backward(x, nchw_view(y_raw), mean, rstd)
         return _attach_h16(nchw_view(y), y16)
 
     @staticmethod

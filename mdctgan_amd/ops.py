@@ -125,12 +125,13 @@ def conv_fwd(g: ConvGeom, x, w, bias=None, act=ACT_NONE, u=None, v_out=None, v_f
 
 
 def conv_fwd_instnorm(g: ConvGeom, x, w, bias=None, act=ACT_NONE, residual=None, eps=1e-5, u=None, v_out=None, v_filled=False,
-                      y16=None):
+                      y16=None, need_raw=True):
     """conv + InstanceNorm2d(affine=False) (+ act, + residual) -> (y, y_raw, mean, rstd); one kernel does the Winograd
-    inverse transform and the normalisation when the layer and the map size allow (csrc/wino.h: wino_out_norm_kernel)."""
+    inverse transform and the normalisation when the layer and the map size allow (csrc/wino.h: wino_out_norm_kernel).
+    need_raw=False (no backward pass will follow): y_raw is None and never written -- a fifth of the fused kernel's HBM bytes."""
     lib = _lib.load()
-    y_raw = torch.empty(g.B, g.OH, g.OW, g.Co, dtype=torch.float32, device=x.device)
-    y = torch.empty_like(y_raw)
+    y = torch.empty(g.B, g.OH, g.OW, g.Co, dtype=torch.float32, device=x.device)
+    y_raw = torch.empty_like(y) if need_raw else None
     mean = torch.empty(g.B, g.Co, dtype=torch.float32, device=x.device)
     rstd = torch.empty(g.B, g.Co, dtype=torch.float32, device=x.device)
     ws = _ws(lib.mg_conv_fwd_instnorm_workspace(g), x.device)

@@ -20,7 +20,9 @@
 //   * LDS rows are 128 bytes, 16-byte slots XOR-swizzled on the DMA source side (slot ^ ((row >> 1) & 7)): every 16-lane group of
 //     a ds_read_b128 covers all 64 banks once.
 //
-// C[M][N] (float32) = A[M][K] (float16) * B[N][K]^T (float16); K % 64 == 0, K >= 128.  Included inside the anonymous namespace after
+// C[M][N] (float32) = A[M][K] (float16) * B[N][K]^T (float16); K % 64 == 0 (an odd K / 64 runs one zero K-tile more).  A ubench-only
+// kernel (scripts/ubench/hgemm_bench.hip): no layer of this model has the >= 256 tiles of 256 x 256 it
+// needs.  Included inside the anonymous namespace after
 // dense_gemm.h / dense_gemm_h.h.
 #pragma once
 #include <type_traits>

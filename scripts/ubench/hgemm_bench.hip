@@ -1,5 +1,6 @@
 // Tuning harness for mdctgan_amd/csrc/dense_gemm_h.h (f16 GEMM, LDS-DMA): the im2col GEMM shapes of the --fp16 trunk layers.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mdctgan_amd/csrc -I include scripts/ubench/hgemm_bench.hip -o scripts/ubench/hgemm_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mdctgan_amd/csrc -I include -I scripts/ubench scripts/ubench/hgemm_bench.hip -o scripts/ubench/hgemm_bench
+// plus dense_gemm_h8.h (round 5: the 256 x 256 x 64 balanced ping-pong) and h8pp.h (its unbalanced first version, for the slot stamps)
 #include "common.h"
 #include <algorithm>
 #include <cstdio>

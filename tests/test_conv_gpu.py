@@ -337,6 +337,10 @@ def test_conv_fwd_instnorm_matches_separate_calls(case):
         v, _ = ops.wino_tile_buffers(g, x.device, want_md=False)
         y2, yr2, _, _ = ops.conv_fwd_instnorm(g, x, w, b, act, res, 1e-5, u=u, v_out=v)
         assert torch.equal(yr2, y_raw) and torch.equal(y2, y)
+    # inference (torch.no_grad(): no backward pass will read the raw convolution output): y_raw = NULL -- the fused kernel skips
+    # that store, the two-call path normalises in place; same y and statistics bit for bit
+    y3, yr3, m3, r3 = ops.conv_fwd_instnorm(g, x, w, b, act, res, 1e-5, need_raw=False)
+    assert yr3 is None and torch.equal(y3, y) and torch.equal(m3, mean) and torch.equal(r3, rstd)
 
 
 @pytest.mark.parametrize("case", [("small_map_fused", 4, 128, 8, 16, 3, 1, 1, True), ("big_map_two_kernels", 2, 64, 32, 64, 3, 1, 1, True),
