@@ -19,7 +19,7 @@
 constexpr int CO1_TAPS = 64;       // tap rows of the padded weight matrix / Zt / Gt
 
 inline bool co1_gemm_ok(const mg_conv_geom* g) {
-    static const bool off = getenv("MG_NO_CO1_GEMM") != nullptr;
+    constexpr bool off = false;
     const long long Mp = (long long)g->B * g->H * g->W;
     return !off && (g->precision == MG_PRECISION_F32 || g->precision == MG_PRECISION_F16) && g->Co == 1 && g->KH * g->KW <= CO1_TAPS && g->Ci % 64 == 0 && Mp % 4 == 0 &&
            Mp * CO1_TAPS < (1LL << 29) && Mp * g->Ci < (1LL << 29);

@@ -87,8 +87,6 @@ struct CdArgs {
 // L2 -- measured 1.20 GB per launch against 119 MB algorithmic.  cd_pick_gm evaluates that window model for a few group sizes and
 // returns the cheapest (0 = keep the plain order).  a_bytes / b_bytes: what one tile reads of either operand per K split.
 inline int cd_pick_gm(int tiles_m, int tiles_n, int splits, double a_bytes, double b_bytes) {
-    static const int forced = getenv("MG_CONV_DMA_GM") ? atoi(getenv("MG_CONV_DMA_GM")) : -1;
-    if (forced >= 0) return forced >= tiles_m ? 0 : forced;
     const long long tiles = (long long)tiles_m * tiles_n, total = tiles * splits;
     if (tiles_m < 2 || tiles_n < 2 || total > (1 << 16)) return 0;
     // (memoised: the model walks every tile of the launch -- once per shape, not once per call)
@@ -589,10 +587,10 @@ __global__ __launch_bounds__(256) void conv_dgrad_dma_kernel(CdArgs g) {
 #endif
 }
 
-inline bool conv_dma_enabled() { static const bool off = getenv("MG_NO_CONV_DMA") != nullptr; return !off; }
+inline bool conv_dma_enabled() { return true; }
 inline bool conv_dma_half(const mg_conv_geom* g) { return g->precision == MG_PRECISION_F16; }
 inline bool conv_dma_prec_ok(const mg_conv_geom* g) {
-    static const bool off_h = getenv("MG_NO_CONV_DMA_H") != nullptr;
+    constexpr bool off_h = false;
     if (!conv_dma_enabled()) return false;
     return g->precision == MG_PRECISION_F32 || (g->precision == MG_PRECISION_F16 && !off_h);
 }
@@ -618,17 +616,12 @@ inline size_t conv_dma_h_dy_bytes(const mg_conv_geom* g) { return cd_al((size_t)
 inline size_t conv_dma_h_w_bytes(const mg_conv_geom* g) { return cd_al((size_t)g->Co * g->KH * g->KW * g->Ci * 2); }
 struct CdPlan { int bm, bn, splits, cps; };
 // cost-model constants of the float16 instances (tuning: MG_HALF_RATE / MG_HALF_FIXED / MG_HALF_FILL)
-inline double cd_env(const char* name, double dflt) { const char* v = getenv(name); return v ? atof(v) : dflt; }
-inline double cd_half_rate() { static const double v = cd_env("MG_HALF_RATE", 4.0); return v; }
-inline double cd_half_fixed() { static const double v = cd_env("MG_HALF_FIXED", 4.0); return v; }
-inline long long cd_half_fill() { static const long long v = (long long)cd_env("MG_HALF_FILL", 512); return v; }
+// cost-model constants of the float16 instances, fitted in round 3 (scripts/sweep_half_tiles.sh)
+inline double cd_half_rate() { return 4.0; }
+inline double cd_half_fixed() { return 4.0; }
+inline long long cd_half_fill() { return 512; }
 inline double cd_half_wgrad_eff(int i) {
-    static double v[4] = {0.83, 0.80, 1.0, 0.88};
-    static const bool init = [] {
-        if (const char* e = getenv("MG_HALF_WGRAD_EFF")) { double a, b, c, d; if (sscanf(e, "%lf,%lf,%lf,%lf", &a, &b, &c, &d) == 4) { v[0] = a; v[1] = b; v[2] = c; v[3] = d; } }
-        return true;
-    }();
-    (void)init;
+    constexpr double v[4] = {0.83, 0.80, 1.0, 0.88};
     return v[i];
 }
 // the dense plan's cost model (dense_plan above) on the convolution's GEMM view, DMA instances only.  ck = K depth of a chunk
@@ -759,7 +752,7 @@ inline CdPlan conv_dma_dgrad_plan(const mg_conv_geom* g) {
     static const Cand cands_f[4] = {{64, 64, 0.83}, {64, 128, 0.885}, {128, 64, 0.855}, {128, 128, 0.91}};
     // float16 instances: 64 x 128 is the fastest tile on 7 of the 10 configs[2] shapes that admit it (same sweep as the weight
     // gradient's: 512 -> 1024 channels 41.6 vs 46.9 us, 1024 -> 2048 50.9 vs 58.9) and within 2 us on the rest
-    static const Cand cands_h[4] = {{64, 64, 0.83}, {64, 128, cd_env("MG_HALF_DGRAD_EFF_64x128", 1.0)}, {128, 64, 0.855}, {128, 128, 0.91}};
+    static const Cand cands_h[4] = {{64, 64, 0.83}, {64, 128, 1.0}, {128, 64, 0.855}, {128, 128, 0.91}};
     const Cand* cands = half ? cands_h : cands_f;
     static const int split_opts[8] = {1, 2, 3, 4, 6, 8, 12, 16};
     int f_bm = 0, f_bn = 0, f_sp = 0;
@@ -804,7 +797,6 @@ void conv_dma_dgrad_launch(const mg_conv_geom* g, const CdPlan& p, const void* d
     // (128 -> 256 channels at 64x128: 87 against 100 us).  MG_DGRAD_CLASS_ORDER=0|1 forces one.
     const long long slots = 256LL * (p.bm == 64 && p.bn == 64 ? 5 : (p.bm == 128 && p.bn == 128 ? 2 : 3));
     a.cls_order = (long long)grid.x * grid.y * grid.z <= slots ? 1 : 0;
-    if (const char* e = getenv("MG_DGRAD_CLASS_ORDER")) a.cls_order = e[0] == '1' ? 1 : 0;
     {
         // per parity class (grid.y) and K split (grid.z) the tiles of grid.x are handed to the XCDs in runs: same window model as
         // the forward pass, with dy as the row operand (a class reads its taps' share of dy) and the weights as the column operand

@@ -148,11 +148,11 @@ __global__ __launch_bounds__(256) void h16_colT2_kernel(Geom g, const float* __r
 }
 
 inline double h16_max_ratio() {
-    static const double r = getenv("MG_H16_MAX_RATIO") ? atof(getenv("MG_H16_MAX_RATIO")) : 2.0;
+    constexpr double r = 2.0;
     return r;
 }
 bool h16_ok(const mg_conv_geom* g) {
-    static const bool off = getenv("MG_NO_H16_GEMM") != nullptr;
+    constexpr bool off = false;
     if (off || g->precision != MG_PRECISION_F16 || g->stride != 1) return false;
     if (g->Ci % 64 != 0 || g->Co % 64 != 0) return false;
     const long long M = (long long)g->B * g->OH * g->OW, Min = (long long)g->B * g->H * g->W;
@@ -172,7 +172,6 @@ H16Plan h16_plan(long long M, int N, int K, bool brc) {
     const int chunks = K / HG_BK;
     int s = 1;
     while (tiles * s < 256 && chunks / (2 * s) >= 4 && s < 64) s *= 2;
-    if (const char* f = getenv("MG_FORCE_H16_SPLITS")) { const int v = atoi(f); if (v >= 1 && chunks / v >= 1) s = v; }
     if (s > 1) { p.cps = (chunks + s - 1) / s; p.splits = (chunks + p.cps - 1) / p.cps; }
     if (p.splits == 1) p.cps = 1 << 28;
     return p;
@@ -293,7 +292,7 @@ int h16_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* dx,
 // Short reductions (the padded pixel count is the K of this GEMM: 256 on the 2048-channel 4x8 trunk) run A-stationary
 // (hgemm_as_kernel); MG_HGEMM_AS=0 keeps them on hgemm_kernel.
 inline bool h16_wgrad_as(const mg_conv_geom* g) {
-    static const bool on = !(getenv("MG_HGEMM_AS") && atoi(getenv("MG_HGEMM_AS")) == 0);
+    constexpr bool on = true;
     const long long M = (long long)g->B * g->OH * g->OW;
     return on && hgemm_as_ok(g->Co, g->KH * g->KW * g->Ci, h16_mp(M));
 }
@@ -306,7 +305,7 @@ int h16_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw,
     _Float16* xct = (_Float16*)(ws + h16_al((size_t)g->Co * Mp * 2));
     float* part = (float*)((char*)xct + h16_al((size_t)N * Mp * 2));
     const Geom gg = to_geom(g);
-    static const bool two = getenv("MG_H16_COLT_TWO_LAUNCHES") != nullptr;
+    constexpr bool two = false;
     if (two) {
         hipLaunchKernelGGL(h16_colT_kernel, dim3(Mp / 64, g->Co / 64, 1), dim3(256), 0, st, gg, dy, g->Co, (int)M, Mp, 1, dyt);
         hipLaunchKernelGGL(h16_colT_kernel, dim3(Mp / 64, g->Ci / 64, g->KH * g->KW), dim3(256), 0, st, gg, x, g->Ci, (int)M, Mp, 0, xct);

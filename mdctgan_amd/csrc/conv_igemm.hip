@@ -1192,8 +1192,7 @@ inline DenseDims dense_dims(int pass, long long T, int Co, int Kc) {
     return {(long long)Co, Kc, (int)T};
 }
 DensePlan dense_plan(int pass, int P, long long T, int Co, int Kc, bool hp) {
-    static const bool off = getenv("MG_NO_DENSE_GEMM") != nullptr;
-    static const bool no_dma = getenv("MG_DENSE_NO_DMA") != nullptr;
+    constexpr bool off = false, no_dma = false;      // (rounds 1-4 had ablation switches here; the register-staged path below stays for shapes the DMA path does not take)
     const DenseDims dd = dense_dims(pass, T, Co, Kc);
     DensePlan p{64, 64, 1, 1 << 28, false, false};
     if (off || hp || dd.N % 64 != 0 || dd.K % 4 != 0 || dd.K < 4 || dd.M < 1 || T >= (1LL << 31)) return p;
@@ -1212,9 +1211,6 @@ DensePlan dense_plan(int pass, int P, long long T, int Co, int Kc, bool hp) {
     static const int split_opts[8] = {1, 2, 3, 4, 6, 8, 12, 16};
     const int chunks = (dd.K + DG_BK - 1) / DG_BK;
     int f_bm = 0, f_bn = 0, f_sp = 0;
-    if (const char* f = getenv("MG_FORCE_DENSE")) {      // tuning harness: "bm,bn,splits"
-        if (sscanf(f, "%d,%d,%d", &f_bm, &f_bn, &f_sp) != 3) f_bm = f_bn = f_sp = 0;
-    }
     double best = 1e300;
     for (const Cand& c : cands) {
         if (dd.N % c.bn != 0) continue;
@@ -1610,11 +1606,11 @@ bool h16_ok(const mg_conv_geom* g);
 bool wino_ok(const mg_conv_geom* g) {
     static const bool off = getenv("MG_NO_WINOGRAD") != nullptr;
     if (h16_ok(g)) return false;             // weight-dominated autocast layers take the float16 GEMM path (conv_h16.h)
-    static const bool off_h = getenv("MG_NO_WINOGRAD_F16") != nullptr;
+    constexpr bool off_h = false;
     // f16 GEMMs are fast enough that Winograd only pays where the 16 transformed-weight matrices are amortised over
     // many tiles: wide layers (>= 256 channels) with >= 256 tiles (the 1024-channel 8x16 blocks of configs[1]; not the
     // 2048-channel 4x8 trunk of configs[2], where reading 16 * Co * Ci transformed weights would dominate)
-    static const int min_tiles_h = getenv("MG_WINO_F16_MIN_TILES") ? atoi(getenv("MG_WINO_F16_MIN_TILES")) : 256;
+    constexpr int min_tiles_h = 256;       // (64 measured slower on configs[2])
     if (prec_h(g) && (off_h || g->Ci < 256 || g->Co < 256 || (long long)g->B * (g->H / 2) * (g->W / 2) < min_tiles_h)) return false;
     return !off && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1 && g->Ci % 16 == 0 && g->Co % 16 == 0 &&
            g->Ci >= 32 && g->Co >= 32 && g->H % 2 == 0 && g->W % 2 == 0 && g->H >= 2 && g->W >= 2;
@@ -1634,22 +1630,11 @@ size_t wino_fwd_ws(const mg_conv_geom* g) {
     return (al256((size_t)16 * g->Co * g->Ci) + al256((size_t)16 * d.T * g->Ci) + al256((size_t)16 * d.T * g->Co) +
             al256(slab_count(tp.splits, dense_splits(0, 16, d.T, g->Co, g->Ci, prec_h(g))) * 16 * d.T * g->Co)) * sizeof(float) + 256;
 }
-inline bool wino_dgrad_padded() {
-    static const bool v = [] { const char* e = getenv("MG_WINO_DGRAD"); return e && !strcmp(e, "padded"); }();
-    return v;
-}
-size_t wino_dgrad_ws(const mg_conv_geom* g) {
+size_t wino_dgrad_ws(const mg_conv_geom* g) {      // U | A dy A^T | dV | dd | split-K slabs
     const WinoDims d = wino_dims(g);
-    if (!wino_dgrad_padded()) {      // U | A dy A^T | dV | dd | split-K slabs
-        const TilePlan tp = gemm_plan(d.T, g->Ci, g->Co / BK, 16, true, 1);
-        return (al256((size_t)16 * g->Co * g->Ci) + al256((size_t)16 * d.T * g->Co) + 2 * al256((size_t)16 * d.T * g->Ci) +
-                al256(slab_count(tp.splits, dense_splits(1, 16, d.T, g->Co, g->Ci, prec_h(g))) * 16 * d.T * g->Ci)) * sizeof(float) + 256;
-    }
-    const long long T = g->reflect ? d.Tp : d.T;
-    const TilePlan tp = gemm_plan(T, g->Ci, g->Co / BK, 16, true, 1);
-    return (al256((size_t)16 * g->Co * g->Ci) + al256((size_t)16 * T * g->Co) + al256((size_t)16 * T * g->Ci) +
-            (g->reflect ? al256((size_t)g->B * (g->H + 2) * (g->W + 2) * g->Ci) : 0) +
-            (tp.splits > 1 ? al256((size_t)tp.splits * 16 * T * g->Ci) : 0)) * sizeof(float) + 256;
+    const TilePlan tp = gemm_plan(d.T, g->Ci, g->Co / BK, 16, true, 1);
+    return (al256((size_t)16 * g->Co * g->Ci) + al256((size_t)16 * d.T * g->Co) + 2 * al256((size_t)16 * d.T * g->Ci) +
+            al256(slab_count(tp.splits, dense_splits(1, 16, d.T, g->Co, g->Ci, prec_h(g))) * 16 * d.T * g->Ci)) * sizeof(float) + 256;
 }
 struct WinoWgradPlan { bool big; int tiles, splits, cps; };
 WinoWgradPlan wino_wgrad_plan(const mg_conv_geom* g) {
@@ -1658,11 +1643,7 @@ WinoWgradPlan wino_wgrad_plan(const mg_conv_geom* g) {
     const int t128 = ((g->Co + 127) / 128) * ((g->Ci + 127) / 128);
     // short reductions (<= 1024 tiles per position, the 8x16 blocks of configs[1]): 64x64 tiles measured 125 vs 148 us
     bool big = g->Co >= 128 && g->Ci >= 128 && d.T > 1024;
-    int want = -1;
-    if (const char* f = getenv("MG_FORCE_WINO_WGRAD")) {      // tuning harness: "big(0|1),splits"
-        int b = 0, sp = 1;
-        if (sscanf(f, "%d,%d", &b, &sp) == 2 && sp >= 1) { big = b != 0; want = sp; }
-    }
+    const int want = -1;
     const int tiles = big ? t128 : ((g->Co + 63) / 64) * ((g->Ci + 63) / 64);
     int splits = want > 0 ? want : (tiles * 16 >= 512 ? 1 : (768 + tiles * 16 - 1) / (tiles * 16));
     const int max_splits = chunks / 8 > 0 ? chunks / 8 : 1;
@@ -1692,13 +1673,13 @@ int wino_launch_tiles(const TilePlan& tp, Launch&& launch) {
 
 // The Winograd-domain weight-gradient GEMM on dense_tn64_kernel (64x64 tiles, float32): Kc = Ci, or 4 Ci for wino42
 inline bool lean_wgrad_ok(const WinoWgradPlan& p, long long T, int Co, int Kc, bool hp) {
-    static const bool off = getenv("MG_NO_LEAN_WGRAD") != nullptr;
+    constexpr bool off = false;
     return !off && !hp && !p.big && Co % 64 == 0 && Kc % 64 == 0 && T % BK == 0;
 }
 // 64 x 128 tiles (two MFMAs per A fragment) where they still give >= 4 workgroups per CU: 83 -> 79.5 us on the
 // 1024-channel layer
 inline bool lean_wgrad_wide(const WinoWgradPlan& p, int P, int Co, int Kc) {
-    static const bool on = getenv("MG_NO_TN_WIDE") == nullptr;
+    constexpr bool on = true;
     return on && P == 16 && Kc % 128 == 0 && (long long)(Co / 64) * (Kc / 128) * P * p.splits >= 1024;
 }
 inline void launch_lean_wgrad(const WinoWgradPlan& p, int P, long long T, int Co, int Kc, const float* Md, const float* V,
@@ -1721,7 +1702,7 @@ inline void launch_lean_wgrad(const WinoWgradPlan& p, int P, long long T, int Co
 
 // ... and the data-gradient GEMM on dense_nn64_kernel (64x64 plans only)
 inline bool lean_dgrad_ok(const TilePlan& tp, long long T, int Nc, int Kc, bool hp) {
-    static const bool off = getenv("MG_NO_LEAN_DGRAD") != nullptr;
+    constexpr bool off = false;
     return !off && !hp && tp.bm == 64 && tp.bn == 64 && Nc % 64 == 0 && Kc % BK == 0 && T >= 1;
 }
 inline void launch_lean_dgrad(const TilePlan& tp, int P, long long T, int Nc, int Kc, const float* Md, const float* U,
@@ -1866,53 +1847,7 @@ int wino_dgrad_t(const mg_conv_geom* g, const float* dy, const float* w, const f
 
 int wino_dgrad(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act, float* ws,
                hipStream_t st, const float* u_pre, float* md_keep) {
-    if (!wino_dgrad_padded()) return wino_dgrad_t(g, dy, w, bias, dx, act, ws, st, u_pre, md_keep);
-    const WinoDims d = wino_dims(g);
-    const long long T = g->reflect ? d.Tp : d.T;
-    const int TH = g->reflect ? d.THp : d.TH, TW = g->reflect ? d.TWp : d.TW;
-    float* U = ws;
-    float* V = U + al256((size_t)16 * g->Co * g->Ci);
-    float* Mx = V + al256((size_t)16 * T * g->Co);
-    float* dxp = Mx + al256((size_t)16 * T * g->Ci);
-    float* part = dxp + (g->reflect ? al256((size_t)g->B * (g->H + 2) * (g->W + 2) * g->Ci) : 0);
-    if (u_pre) U = const_cast<float*>(u_pre);
-    else hipLaunchKernelGGL(wino_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 4)), dim3(256), 0, st, w,
-                            g->Co, g->Ci, U);
-    // dy is [B, OH, OW, Co] with OH == H, OW == W; "full" (origin -2, zero) for reflect, "same" (origin -1) otherwise
-    hipLaunchKernelGGL(wino_input_xform_kernel, dim3(wino_grid((size_t)T * g->Co / 4)), dim3(256), 0, st, dy, g->B, g->H,
-                       g->W, g->Co, TH, TW, g->reflect ? 2 : 1, 0, V);
-    const Geom gg{1, 1, (int)T, g->Ci, 1, (int)T, g->Co, 1, 1, 1, 0, 0};
-    const TilePlan tp = gemm_plan(T, g->Ci, g->Co / BK, 16, true, 1);
-    float* pp = tp.splits > 1 ? part : nullptr;
-    const Batch bt{T * g->Co, (long long)g->Co * g->Ci, T * g->Ci, 1};
-    probe_begin(st);
-    wino_launch_tiles(tp, [&](auto bm, auto bn) {
-        constexpr int BM_ = decltype(bm)::value, BN_ = decltype(bn)::value;
-        dim3 grid((unsigned)(((T + BM_ - 1) / BM_) * ((g->Ci + BN_ - 1) / BN_)), tp.splits, 16);
-        if (prec_h(g))
-            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, true, 3>), grid, dim3(256), 0, st, gg, (const float*)V,
-                               (const float*)U, (const float*)nullptr, Mx, MG_ACT_NONE, tp.cps, pp, bt);
-        else
-            hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, true, true, 1>), grid, dim3(256), 0, st, gg, (const float*)V,
-                               (const float*)U, (const float*)nullptr, Mx, MG_ACT_NONE, tp.cps, pp, bt);
-    });
-    probe_end(st);
-    if (pp) {
-        const size_t n = (size_t)16 * T * g->Ci;
-        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(wino_grid(n / 4)), dim3(256), 0, st, (const float*)pp, tp.splits,
-                           n, g->Ci, (const float*)nullptr, MG_ACT_NONE, Mx);
-    }
-    if (g->reflect) {
-        hipLaunchKernelGGL(wino_output_xform_kernel, dim3(wino_grid((size_t)T * g->Ci / 4)), dim3(256), 0, st,
-                           (const float*)Mx, g->B, TH, TW, g->Ci, (const float*)nullptr, MG_ACT_NONE, dxp, (int)prec_h(g));
-        hipLaunchKernelGGL(wino_fold_reflect_kernel, dim3(wino_grid((size_t)g->B * g->H * g->W * g->Ci / 4)), dim3(256), 0,
-                           st, (const float*)dxp, g->B, g->H, g->W, g->Ci, dx, (int)prec_h(g));
-    } else {
-        hipLaunchKernelGGL(wino_output_xform_kernel, dim3(wino_grid((size_t)T * g->Ci / 4)), dim3(256), 0, st,
-                           (const float*)Mx, g->B, TH, TW, g->Ci, bias, act, dx, (int)prec_h(g));
-    }
-    MG_CHECK_LAUNCH();
-    return MG_OK;
+    return wino_dgrad_t(g, dy, w, bias, dx, act, ws, st, u_pre, md_keep);
 }
 
 int wino_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate, float* ws,
@@ -1973,7 +1908,7 @@ int wino_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw
 // ---------------------------------------------------------------------------------------------------------
 bool wino4_ok(const mg_conv_geom* g) {
     static const bool off = getenv("MG_NO_WINOGRAD4") != nullptr;
-    static const int min_c = getenv("MG_WINO4_MIN_C") ? atoi(getenv("MG_WINO4_MIN_C")) : 32;
+    constexpr int min_c = 32;
     return !off && !prec_h(g) && g->KH == 4 && g->KW == 4 && g->stride == 1 && g->pad == 2 && !g->reflect &&
            g->Ci % 16 == 0 && g->Co % 16 == 0 && g->Ci >= min_c && g->Co >= min_c && (g->H & 1) && (g->W & 1);
 }
@@ -1988,10 +1923,6 @@ WinoWgradPlan wino4_wgrad_plan(const mg_conv_geom* g) {
     const int chunks = (int)((d.T + BK - 1) / BK);
     bool big = g->Co >= 128 && g->Ci >= 128 && d.T > 4096;      // measured at 2448 tiles: 64x64 232 us, 128x128 252 us
     int want = -1;
-    if (const char* f = getenv("MG_FORCE_WINO4_WGRAD")) {      // tuning harness: "big(0|1),splits"
-        int b = 0, sp = 1;
-        if (sscanf(f, "%d,%d", &b, &sp) == 2 && sp >= 1) { big = b != 0; want = sp; }
-    }
     const int tiles = big ? ((g->Co + 127) / 128) * ((g->Ci + 127) / 128) : ((g->Co + 63) / 64) * ((g->Ci + 63) / 64);
     int splits = want > 0 ? want : (tiles * 25 >= 512 ? (chunks >= 128 ? 3 : 1) : (768 + tiles * 25 - 1) / (tiles * 25));
     const int max_splits = chunks / 8 > 0 ? chunks / 8 : 1;
@@ -2157,7 +2088,7 @@ int wino4_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* d
 // ---------------------------------------------------------------------------------------------------------
 bool wino42_ok(const mg_conv_geom* g) {
     static const bool off = getenv("MG_NO_WINOGRAD42") != nullptr;
-    static const int min_c = getenv("MG_WINO42_MIN_C") ? atoi(getenv("MG_WINO42_MIN_C")) : 16;
+    constexpr int min_c = 16;
     if (off || prec_h(g) || g->KH != 4 || g->KW != 4 || g->stride != 2 || g->pad != 2 || g->reflect || g->Ci % 16 ||
         g->Co % 16 || g->Ci < min_c || g->Co < min_c || g->H < 2 || g->W < 2)
         return false;
@@ -2180,10 +2111,6 @@ WinoWgradPlan wino42_wgrad_plan(const mg_conv_geom* g) {
     const int chunks = (int)((d.T + BK - 1) / BK);
     bool big = g->Co >= 128 && d.K4 >= 128 && d.T > 4096;
     int want = -1;
-    if (const char* f = getenv("MG_FORCE_WINO42_WGRAD")) {      // tuning harness: "big(0|1),splits"
-        int b = 0, sp = 1;
-        if (sscanf(f, "%d,%d", &b, &sp) == 2 && sp >= 1) { big = b != 0; want = sp; }
-    }
     const int tiles = big ? ((g->Co + 127) / 128) * ((d.K4 + 127) / 128) : ((g->Co + 63) / 64) * ((d.K4 + 63) / 64);
     int splits = want > 0 ? want : (tiles * 25 >= 512 ? (chunks >= 128 ? 3 : 1) : (768 + tiles * 25 - 1) / (tiles * 25));
     const int max_splits = chunks / 8 > 0 ? chunks / 8 : 1;
@@ -2348,7 +2275,7 @@ int wino42_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* 
 // Ci <= 4 layers (conv_smallc.h): VALU kernels for the data gradient and the weight gradient
 // ---------------------------------------------------------------------------------------------------------
 bool smallc_enabled() {
-    static const bool off = getenv("MG_NO_SMALLC") != nullptr;
+    constexpr bool off = false;
     return !off;
 }
 bool smallc_dgrad_ok(const mg_conv_geom* g) {
@@ -2370,7 +2297,7 @@ int smallc_wgrad_kind(const mg_conv_geom* g) {
 struct SmallcWgradPlan { int wgs, rowlen; size_t lds; int mfma_g; };     // wgs: partial rows; mfma_g: 0 or the MFMA kernel's pixel groups
 // the MFMA form (conv_smallc_wgrad_mfma_kernel): pixel groups per output row (each writes a partial row), 0 = VALU kernel
 int smallc_wgrad_mfma_groups(const mg_conv_geom* g, int rowlen) {
-    static const bool off = getenv("MG_NO_SMALLC_WGRAD_MFMA") != nullptr;
+    constexpr bool off = false;
     if (off || (size_t)g->KH * rowlen > 256 * 16 || g->Co % 64 != 0) return 0;
     if (g->KH == 7 && g->KW == 7 && g->Ci == 2 && g->stride == 1) return 1;     // K = 98: four k blocks, one per wave
     if (g->KH == 4 && g->KW == 4 && g->Ci == 3 && g->stride == 2) return 2;     // K = 48: two k blocks x two pixel groups
@@ -2418,13 +2345,13 @@ int smallc_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* 
 }
 // forward on the MFMA pipe (conv_smallc_fwd_kernel): 0 = not eligible, else the template instance
 int smallc_fwd_kind(const mg_conv_geom* g) {
-    static const bool off = getenv("MG_NO_SMALLC_FWD") != nullptr;
+    constexpr bool off = false;
     if (!smallc_enabled() || off || g->Co % 64 != 0 || (long long)g->B * g->OH > 0x7fffffffLL) return 0;
     if ((size_t)g->KH * (((g->OW - 1) * g->stride + g->KW) * g->Ci + 4) > 256 * 16) return 0;      // staged through 16 registers per thread
     if (g->KH == 7 && g->KW == 7 && g->Ci == 2 && g->stride == 1) return 1;      // the generator stem: 66 against 93 us
     // the 3 -> 64 4x4 stride-2 first discriminator layer (K = 48, 129-pixel rows = 5 pixel blocks for 4 waves) measured
     // SLOWER here than on the generic kernel (44 against 37 us at batch 16): instance kept for MG_SMALLC_FWD_D=1 only
-    static const bool with_d = getenv("MG_SMALLC_FWD_D") != nullptr;
+    constexpr bool with_d = false;
     if (with_d && g->KH == 4 && g->KW == 4 && g->Ci == 3 && g->stride == 2) return 2;
     return 0;
 }
@@ -2433,8 +2360,7 @@ int smallc_fwd(const mg_conv_geom* g, const float* x, const float* w, const floa
     const Geom gg = to_geom(g);
     const int rows = g->B * g->OH, cblocks = (g->Co + 63) / 64;
     int rpw = 1;                                        // rows per workgroup: one workgroup per CU (260 VGPRs: one fits)
-    if (const char* e = getenv("MG_SMALLC_FWD_ROWS")) rpw = atoi(e) > 0 ? atoi(e) : 1;
-    else while ((long long)((rows + rpw - 1) / rpw) * cblocks > 256 && rpw < 8) ++rpw;
+    while ((long long)((rows + rpw - 1) / rpw) * cblocks > 256 && rpw < 8) ++rpw;
     const dim3 grid((unsigned)((rows + rpw - 1) / rpw), (unsigned)cblocks);
     const size_t lds = p.lds + (size_t)64 * g->KH * g->KW * g->Ci * sizeof(float);
     switch (smallc_fwd_kind(g)) {
@@ -2494,7 +2420,7 @@ double mg_conv_plan_flops(int pass, const mg_conv_geom* g) {
     if (co1_gemm_ok(g)) return 2.0 * CO1_TAPS * (double)g->B * g->H * g->W * g->Ci;      // the 64-tap GEMM (conv_co1.h)
     if (wino_ok(g) && !mg_conv_rowdot_kq(g)) {
         const WinoDims d = wino_dims(g);
-        const double T = (pass == 1 && g->reflect && wino_dgrad_padded()) ? (double)d.Tp : (double)d.T;
+        const double T = (double)d.T;
         return 2.0 * 16.0 * T * (double)g->Co * g->Ci;
     }
     if (wino4_ok(g) && !mg_conv_rowdot_kq(g)) return 2.0 * 25.0 * (double)wino4_dims(g).T * (double)g->Co * g->Ci;
@@ -2522,7 +2448,7 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
         if (pass == 2 && h16_wgrad_as(g)) snprintf(out, out_len, "hgemm_as_kernel<%d, false>", h16_mp(px) / 64);
         else
         snprintf(out, out_len, pass == 1 ? "hgemm_kernel<128, 128, 4, 2, true, %d>" : "hgemm_kernel<128, 128, 4, 2, false, %d>", deep ? 3 : 2);
-    } else if (wino_ok(g) && !kq && !(pass == 1 && wino_dgrad_padded()) &&
+    } else if (wino_ok(g) && !kq && 
         dense_plan(pass, 16, wino_dims(g).T, g->Co, g->Ci, prec_h(g)).ok) {
         dense_name(pass, 16, dense_plan(pass, 16, wino_dims(g).T, g->Co, g->Ci, prec_h(g)), dense_dims(pass, wino_dims(g).T, g->Co, g->Ci).N, out, out_len);
     } else if (wino4_ok(g) && !kq && dense_plan(pass, 25, wino4_dims(g).T, g->Co, g->Ci, false).ok) {
@@ -2543,8 +2469,8 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
             else
                 snprintf(out, out_len, "conv_fwd_kernel<%d, %d, true, 1>", tp.bm, tp.bn);
         } else if (pass == 1) {
-            const TilePlan tp = gemm_plan((g->reflect && wino_dgrad_padded()) ? d.Tp : d.T, g->Ci, g->Co / BK, 16, true, 1);
-            if (!wino_dgrad_padded() && lean_dgrad_ok(tp, d.T, g->Ci, g->Co, prec_h(g))) snprintf(out, out_len, "dense_nn64_kernel<1>");
+            const TilePlan tp = gemm_plan(d.T, g->Ci, g->Co / BK, 16, true, 1);
+            if (lean_dgrad_ok(tp, d.T, g->Ci, g->Co, prec_h(g))) snprintf(out, out_len, "dense_nn64_kernel<1>");
             else
             snprintf(out, out_len, "conv_dgrad_kernel<%d, %d, true, true, %d>", tp.bm, tp.bn, prec_h(g) ? 3 : 1);
         } else {
@@ -2726,7 +2652,7 @@ size_t mg_conv_wino_tiles_bytes(const mg_conv_geom* g, int which) {
     }
     const WinoDims d = wino_dims(g);
     if (which == 0) return (size_t)16 * d.T * g->Ci * sizeof(float);
-    if (which == 1) return wino_dgrad_padded() ? 0 : (size_t)16 * d.T * g->Co * sizeof(float);
+    if (which == 1) return (size_t)16 * d.T * g->Co * sizeof(float);
     return 0;
 }
 static bool wino_tiles_ok(const mg_conv_geom* g, const mg_wino_tiles* t) {
@@ -2749,7 +2675,7 @@ int mg_conv_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float*
 }
 
 int mg_conv_wino_md_from_norm_ok(const mg_conv_geom* g) {
-    return (geom_ok(g) && wino_ok(g) && !prec_h(g) && !mg_conv_rowdot_kq(g) && !wino_dgrad_padded() &&
+    return (geom_ok(g) && wino_ok(g) && !prec_h(g) && !mg_conv_rowdot_kq(g) &&
             wino_out_norm_ok(g->OH / 2, g->OW / 2, g->Co)) ? 1 : 0;
 }
 int mg_instnorm_bwd_wino_md(const mg_conv_geom* g, const float* gy, const float* y_raw, const float* mean, const float* rstd,
@@ -2947,7 +2873,7 @@ static int dgrad_dispatch(const mg_conv_geom* g, const float* dy, const float* w
         probe_end((hipStream_t)stream);
         return rc;
     }
-    if (wino_ok(g) && !(wino_dgrad_padded() && g->reflect && (bias || act != MG_ACT_NONE)) && workspace &&
+    if (wino_ok(g) && workspace &&
         workspace_bytes >= wino_dgrad_ws(g) &&
         aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(workspace) && (!bias || aligned16(bias)))
         return wino_dgrad(g, dy, w, bias, dx, act, (float*)workspace, (hipStream_t)stream, u, wt ? wt->md : nullptr);

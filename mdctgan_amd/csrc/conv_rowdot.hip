@@ -266,13 +266,13 @@ __global__ __launch_bounds__(256) void co1_tile_wgrad_kernel(Geom g, const float
 }
 
 inline int co1_tile_kind(const mg_conv_geom* g) {      // 0: not eligible, 1: 7x7, 2: 4x4
-    static const bool off = getenv("MG_NO_CO1_TILE") != nullptr;
+    constexpr bool off = false;
     if (off || g->Co != 1 || g->stride != 1 || g->Ci % CT_CC != 0) return 0;
     if (g->reflect && (g->pad >= g->H || g->pad >= g->W)) return 0;
     if (g->KH == 7 && g->KW == 7) return 1;
     // 4x4 PatchGAN outputs (512 channels on 19x35 maps: few tiles, 32 channel chunks each) measured 4x slower than
     // the wave-per-pixel kernels -- instantiated for tests (MG_CO1_TILE_4X4=1), not used by default
-    static const bool k4 = getenv("MG_CO1_TILE_4X4") != nullptr;
+    constexpr bool k4 = false;           // (the tiled 4x4 form measured 4x slower than wave-per-pixel on the PatchGAN outputs)
     if (k4 && g->KH == 4 && g->KW == 4) return 2;
     return 0;
 }

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void wino_norm_bwd_dy_kernel(const float* __re
     }
 }
 inline bool wino_out_norm_ok(int TH, int TW, int C) {
-    static const bool off = getenv("MG_NO_WINO_NORM_FUSION") != nullptr;
+    constexpr bool off = false;
     return !off && C % 32 == 0 && TH * TW <= 160;
 }
 
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void wino_dd_gather_kernel(const float* __rest
     }
 }
 inline bool wino_dd_gather_ok(int H, int W, int C) {
-    static const bool off = getenv("MG_NO_WINO_DD_GATHER_FUSION") != nullptr;
+    constexpr bool off = false;
     return !off && C % 32 == 0 && (H / 2) * (W / 2) <= 64;
 }
 
