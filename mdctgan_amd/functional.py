@@ -510,7 +510,9 @@ class _ConvInstNormFn(torch.autograd.Function):
             v, _ = ops.wino_tile_buffers(g, x.device, want_md=False)
         y16 = (torch.empty(B * g.OH * g.OW * g.Co, dtype=torch.float16, device=x.device)
                if _want_h16(B, g.OH * g.OW, g.Co) else None)
-        need_raw = any(ctx.needs_input_grad)          # under torch.no_grad() nobody reads the raw convolution output again
+        # under torch.no_grad() nobody reads the raw convolution output again (grad mode is read by conv_instnorm(): inside a
+        # Function's forward it is always off, and needs_input_grad ignores it)
+        need_raw = bool(cfg[6]) and any(ctx.needs_input_grad) if len(cfg) > 6 else any(ctx.needs_input_grad)
         y, y_raw, mean, rstd = ops.conv_fwd_instnorm(g, nhwc_view(x), w, bias.detach() if bias is not None else None, act,
                                                      nhwc_view(res) if res is not None else None, eps, u, v, v_filled, y16,
                                                      need_raw=need_raw)
@@ -578,7 +580,7 @@ class SkipGrad:
 
 def conv_instnorm(x, weight, bias, padding=0, reflect=False, act=ACT_NONE, residual=None, eps=1e-5, weight_grad=True, skip=None):
     """act(InstanceNorm2d(affine=False)(conv2d(x, weight, bias, stride 1))) + residual.  skip: ("give" | "take", SkipGrad)."""
-    cfg = (padding, bool(reflect), weight_grad, act, eps) + ((skip,) if skip is not None else ())
+    cfg = (padding, bool(reflect), weight_grad, act, eps, skip, torch.is_grad_enabled())
     return _ConvInstNormFn.apply(x, weight, bias, residual, cfg)
 
 

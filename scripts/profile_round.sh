@@ -28,8 +28,8 @@ python bench.py --fp16 --steps 20 --warmup 5 --no-also > $out/${tag}_bench_train
 python bench.py --steps 20 --warmup 5 > $out/${tag}_bench_train_line.json 2>/dev/null
 for f in bench_codec bench_cfg2_f32 bench_train_fp16 bench_train; do tail -c 300 $out/${tag}_${f}_line.json; echo; done
 
-# K1 / K2 micro-benchmark (the factored-transform product kernels of mdct_ct.h beside the bf16 x 3 and f32-pipe dense-table kernels,
-# with parts switched off) and their SQ / LDS counters
+# K1 / K2 micro-benchmark (the factored-transform product kernels of mdct_ct.h beside the retired bf16 x 3 and f32-pipe dense-table
+# kernels, which live on in scripts/ubench/ for this comparison) and their SQ / LDS counters
 hipcc --version > /dev/null 2>&1
 [ -x scripts/ubench/mdct_bs_bench ] && for b in 4096 64 8; do scripts/ubench/mdct_bs_bench $b; done > $out/${tag}_mdct_bs_ubench.log 2>&1
 for b in 4096 1024 512 256 128 64 8; do echo "##### clips $b"; scripts/ubench/mdct_b3_bench $b; done > $out/${tag}_mdct_ct_ubench.log 2>&1
@@ -55,8 +55,7 @@ for k, c in acc.items():
         print(k, {n: round(v / cnt[k][n]) for n, v in sorted(c.items())})
 PY
 cd $R
-# full-size step parity by kernel family + op-level accuracy of the 25-position Winograd families
-bash scripts/r04_step_parity.sh $out/${tag}_step_report.jsonl > $out/${tag}_fullsize_step_parity.txt 2>&1
+# (the full-size step parity report is its own call: scripts/r05_step_parity.sh)
 tail -5 $out/${tag}_mdct_bs_ubench.log
 
 # float16 GEMM structure ablation on the dense twin of the 128-channel 64x128 layers (--fp16): which part of

@@ -343,6 +343,29 @@ def test_conv_fwd_instnorm_matches_separate_calls(case):
     assert yr3 is None and torch.equal(y3, y) and torch.equal(m3, mean) and torch.equal(r3, rstd)
 
 
+def test_conv_instnorm_skips_the_raw_output_under_no_grad(monkeypatch):
+    """functional.conv_instnorm asks for y_raw only when a backward pass can follow: torch.no_grad() (generate / inference) -> NULL,
+    same output bit for bit; with gradients enabled the raw output is saved as before."""
+    from mdctgan_amd import functional as Fh
+    from mdctgan_amd import ops
+    seen = []
+    real = ops.conv_fwd_instnorm
+
+    def spy(*a, **kw):
+        seen.append(kw.get("need_raw", True))
+        return real(*a, **kw)
+    monkeypatch.setattr(ops, "conv_fwd_instnorm", spy)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 8, 16, generator=gen).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = torch.nn.Parameter((torch.randn(64, 64, 3, 3, generator=gen) / 24).to(DEV).contiguous(memory_format=torch.channels_last))
+    with torch.no_grad():
+        y0 = Fh.conv_instnorm(x, w, None, padding=1, reflect=True, act=Fh.ACT_RELU)
+    y1 = Fh.conv_instnorm(x, w, None, padding=1, reflect=True, act=Fh.ACT_RELU)
+    assert seen == [False, True] and torch.equal(y0, y1)
+    y1.sum().backward()
+    assert w.grad is not None and bool(torch.isfinite(w.grad).all())
+
+
 @pytest.mark.parametrize("case", [("small_map_fused", 4, 128, 8, 16, 3, 1, 1, True), ("big_map_two_kernels", 2, 64, 32, 64, 3, 1, 1, True),
                                   ("stride2_direct", 2, 64, 16, 32, 3, 2, 1, False),
                                   ("configs1_trunk_1024_8x16", 8, 1024, 8, 16, 3, 1, 1, True),

@@ -148,7 +148,9 @@ def test_full_size_step_gradients(tag, fp16, feat, batch, n_steps, monkeypatch):
         sdG = {k: v.clone() for k, v in netG.state_dict().items()}
         sdD = {k: v.clone() for k, v in netD.state_dict().items()}
         lr, hr = synth(B, 5)
-        torch.set_num_threads(1 if batch is None else min(16, threads))     # the deterministic yardstick (bench batch: 16 threads)
+        # the deterministic yardstick: one thread for the float32 cases at batch 1 / 2; the bench batch and the --fp16 cases (CPU autocast
+        # is ~4x slower, their bars are 3e-2 / relative to this very run) take 16 threads -- the spread between thread counts is far below the bars
+        torch.set_num_threads(1 if (batch is None and not fp16) else min(16, threads))
         ref32 = ostep.HotPathRef(netG, netD, ostep.CodecCfg(), num_D=cfg["num_D"], feat_loss=feat)
         # yardstick: the oracle's own float32 run -- under --fp16 the oracle's CPU-autocast run (the reference's arithmetic)
         l32, gG32, gD32 = oracle_gradients(ref32, lr.numpy(), hr.numpy(), amp=fp16)
@@ -156,7 +158,9 @@ def test_full_size_step_gradients(tag, fp16, feat, batch, n_steps, monkeypatch):
         hr_s, _ = ref32.spectro(hr.numpy())
         ref_losses, ref_after, ref_scales = [], None, []
         if n_steps > 1:                              # train.py:160-202 three times on the oracle (torch.optim.Adam)
-            torch.set_num_threads(min(16, threads))
+            # (CPU autocast runs the float16 convolutions ~4x slower than float32: the three --fp16 iterations get every core the box
+            # has up to 64 -- thread count changes the oracle's float32 rounding by far less than the bars below)
+            torch.set_num_threads(min(64 if fp16 else 16, threads))
             ref_scaler = torch.amp.GradScaler("cpu", init_scale=AMP_SCALE) if fp16 else None
             for _ in range(n_steps):
                 ref_losses.append(ref32.train_step(lr.numpy(), hr.numpy(), amp=fp16, scaler=ref_scaler))
