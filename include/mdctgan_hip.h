@@ -218,7 +218,8 @@ typedef struct {
                          * the buffer -- written by the kernel that produced x / dy (mg_instnorm_fwd_h, mg_instnorm_bwd_h,
                          * mg_conv_fwd_instnorm_h) -- so the call skips its own cast pass.  Paths that do not use the copy ignore it. */
 } mg_wino_tiles;
-#define MG_TILES_V_FILLED 1u    /* mg_conv_fwd_w: v holds float16(x) */
+#define MG_TILES_V_FILLED 1u    /* mg_conv_fwd_w: v holds float16(x) (MG_PRECISION_F16 implicit GEMMs) / B^T x B written by
+                                   mg_conv_fwd_instnorm_next of the layer in front (float32 F(2x2,3x3) layers) */
 #define MG_TILES_MD_FILLED 2u   /* mg_conv_dgrad_w: md holds float16(dy) */
 size_t mg_conv_wino_weights_bytes(const mg_conv_geom* g);
 size_t mg_conv_wino_tiles_bytes(const mg_conv_geom* g, int which);
@@ -249,6 +250,17 @@ int mg_instnorm_bwd_wino_md(const mg_conv_geom* g, const float* gy, const float*
 int mg_conv_fwd_instnorm_h(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y_raw, float eps,
                            int act, const float* residual, float* y, float* mean, float* rstd, void* workspace,
                            size_t workspace_bytes, void* stream, const mg_wino_tiles* tiles, void* y16);
+/* mg_conv_fwd_instnorm_w that ALSO writes v_next = B^T y B, the Winograd input image of its own output y for a following 3x3
+ * stride-1 pad-1 convolution over the same map (next_reflect: that layer's padding mode): ResnetBlock chains conv -> InstanceNorm ->
+ * conv (models/networks.py:440-462), and the workgroup that normalises a slab of y holds exactly the pixels the next layer's
+ * tiles need.  v_next: mg_conv_wino_tiles_bytes(g_next, 0) bytes (16 * T * Co floats); the next layer's call takes it as tiles->v
+ * with MG_TILES_V_FILLED and skips its own input transform -- bit-identical results (the same float32 arithmetic on the same
+ * values).  Only where mg_conv_wino_vnext_ok(g) != 0 (float32 F(2x2,3x3) layers on maps of <= 64 tiles per sample); MG_ERR_ARG
+ * elsewhere.  Replaces nothing in the reference: it removes one launch and one read of y per trunk layer. */
+int mg_conv_wino_vnext_ok(const mg_conv_geom* g);
+int mg_conv_fwd_instnorm_next(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y_raw, float eps,
+                              int act, const float* residual, float* y, float* mean, float* rstd, void* workspace,
+                              size_t workspace_bytes, void* stream, const mg_wino_tiles* tiles, float* v_next, int next_reflect);
 int mg_conv_dgrad_w(const mg_conv_geom* g, const float* dy, const float* w, const float* bias, float* dx, int act,
                     void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* tiles);
 /* dw [Co, KH, KW, Ci] = sum over pixels; dbias [Co] (nullable) = column sums of dy.

@@ -76,6 +76,8 @@ SIGNATURES = {
     "mg_instnorm_bwd_wino_md": (_i, [_G, _p, _p, _p, _p, _i, _p, _p]),
     "mg_conv_fwd_instnorm_w": (_i, [_G, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _sz, _p, _W]),
     "mg_conv_fwd_instnorm_h": (_i, [_G, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _sz, _p, _W, _p]),
+    "mg_conv_fwd_instnorm_next": (_i, [_G, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _sz, _p, _W, _p, _i]),
+    "mg_conv_wino_vnext_ok": (_i, [_G]),
     "mg_conv_dgrad_w": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p, _W]),
     "mg_conv_wgrad_w": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p, _W]),
     "mg_conv_wgrad_chk": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p, _W, _p]),

@@ -1718,7 +1718,7 @@ inline void launch_lean_dgrad(const TilePlan& tp, int P, long long T, int Nc, in
 }
 
 int wino_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act, float* ws,
-             hipStream_t st, const float* u_pre, float* v_keep, const WinoNorm* nrm = nullptr) {
+             hipStream_t st, const float* u_pre, float* v_keep, const WinoNorm* nrm = nullptr, bool v_filled = false) {
     const WinoDims d = wino_dims(g);
     float* U = ws;
     float* V = U + al256((size_t)16 * g->Co * g->Ci);
@@ -1728,8 +1728,10 @@ int wino_fwd(const mg_conv_geom* g, const float* x, const float* w, const float*
     else hipLaunchKernelGGL(wino_weight_xform_kernel, dim3(wino_grid((size_t)g->Co * g->Ci / 4)), dim3(256), 0, st, w,
                             g->Co, g->Ci, U);
     if (v_keep) V = v_keep;          // the caller keeps B^T x B for the weight gradient
-    hipLaunchKernelGGL(wino_input_xform_kernel, dim3(wino_grid((size_t)d.T * g->Ci / 4)), dim3(256), 0, st, x, g->B, g->H,
-                       g->W, g->Ci, d.TH, d.TW, 1, g->reflect, V);
+    // (v_filled: x's producer wrote B^T x B already -- mg_conv_fwd_instnorm_next of the layer in front)
+    if (!(v_filled && v_keep))
+        hipLaunchKernelGGL(wino_input_xform_kernel, dim3(wino_grid((size_t)d.T * g->Ci / 4)), dim3(256), 0, st, x, g->B, g->H,
+                           g->W, g->Ci, d.TH, d.TW, 1, g->reflect, V);
     if (!dense_wino_gemm(0, 16, d.T, g->Co, g->Ci, V, U, Mx, part, prec_h(g), st)) {
     const Geom gg{1, 1, (int)d.T, g->Ci, 1, (int)d.T, g->Co, 1, 1, 1, 0, 0};
     const TilePlan tp = gemm_plan(d.T, g->Co, g->Ci / BK, 16, true, 0);
@@ -1765,7 +1767,12 @@ int wino_fwd(const mg_conv_geom* g, const float* x, const float* w, const float*
         const dim3 grid(g->Co / 32, g->B);
         const int nt = (d.TH * d.TW + 31) / 32;
 #define MG_OUT_NORM(NT_) hipLaunchKernelGGL(wino_out_norm_kernel<NT_>, grid, dim3(256), 0, st, (const float*)Mx, g->B, d.TH, d.TW, g->Co, bias, *nrm, y)
-        if (nt == 1) MG_OUT_NORM(1); else if (nt == 2) MG_OUT_NORM(2); else if (nt == 3) MG_OUT_NORM(3); else if (nt == 4) MG_OUT_NORM(4); else MG_OUT_NORM(5);
+#define MG_OUT_NORM_NEXT(NT_) hipLaunchKernelGGL((wino_out_norm_kernel<NT_, true>), grid, dim3(256), 0, st, (const float*)Mx, g->B, d.TH, d.TW, g->Co, bias, *nrm, y)
+        if (nrm->v_next && nt == 1) MG_OUT_NORM_NEXT(1);
+        else if (nrm->v_next && nt == 2) MG_OUT_NORM_NEXT(2);
+        else if (nrm->v_next) return MG_ERR_ARG;       // (callers ask mg_conv_wino_vnext_ok first)
+        else if (nt == 1) MG_OUT_NORM(1); else if (nt == 2) MG_OUT_NORM(2); else if (nt == 3) MG_OUT_NORM(3); else if (nt == 4) MG_OUT_NORM(4); else MG_OUT_NORM(5);
+#undef MG_OUT_NORM_NEXT
 #undef MG_OUT_NORM
         MG_CHECK_LAUNCH();
         return MG_OK;
@@ -2704,9 +2711,38 @@ int mg_conv_fwd_instnorm_w(const mg_conv_geom* g, const float* x, const float* w
                            size_t workspace_bytes, void* stream, const mg_wino_tiles* wt) {
     return mg_conv_fwd_instnorm_h(g, x, w, bias, y_raw, eps, act, residual, y, mean, rstd, workspace, workspace_bytes, stream, wt, nullptr);
 }
+// The fused F(2x2,3x3) output transform + InstanceNorm kernel can also write the NEXT 3x3 stride-1 pad-1 layer's input image
+// (wino.h: wino_out_norm_kernel<NT, true>): float32, maps of <= 64 tiles per sample.
+static bool wino_vnext_ok(const mg_conv_geom* g) {
+    return geom_ok(g) && wino_ok(g) && !prec_h(g) && !mg_conv_rowdot_kq(g) && wino_out_norm_ok(g->OH / 2, g->OW / 2, g->Co) &&
+           wino_out_norm_next_ok(g->OH / 2, g->OW / 2, g->Co) && g->Co % 16 == 0;
+}
+int mg_conv_wino_vnext_ok(const mg_conv_geom* g) { return g && wino_vnext_ok(g) ? 1 : 0; }
+
+static int conv_fwd_instnorm_impl(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y_raw, float eps,
+                                  int act, const float* residual, float* y, float* mean, float* rstd, void* workspace,
+                                  size_t workspace_bytes, void* stream, const mg_wino_tiles* wt, void* y16, float* v_next,
+                                  int next_reflect);
+
+int mg_conv_fwd_instnorm_next(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y_raw, float eps,
+                              int act, const float* residual, float* y, float* mean, float* rstd, void* workspace,
+                              size_t workspace_bytes, void* stream, const mg_wino_tiles* wt, float* v_next, int next_reflect) {
+    if (!g || !v_next || !aligned16(v_next) || !wino_vnext_ok(g)) return MG_ERR_ARG;
+    return conv_fwd_instnorm_impl(g, x, w, bias, y_raw, eps, act, residual, y, mean, rstd, workspace, workspace_bytes, stream, wt, nullptr,
+                                  v_next, next_reflect);
+}
+
 int mg_conv_fwd_instnorm_h(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y_raw, float eps,
                            int act, const float* residual, float* y, float* mean, float* rstd, void* workspace,
                            size_t workspace_bytes, void* stream, const mg_wino_tiles* wt, void* y16) {
+    return conv_fwd_instnorm_impl(g, x, w, bias, y_raw, eps, act, residual, y, mean, rstd, workspace, workspace_bytes, stream, wt, y16,
+                                  nullptr, 0);
+}
+
+static int conv_fwd_instnorm_impl(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y_raw, float eps,
+                                  int act, const float* residual, float* y, float* mean, float* rstd, void* workspace,
+                                  size_t workspace_bytes, void* stream, const mg_wino_tiles* wt, void* y16, float* v_next,
+                                  int next_reflect) {
     if (y16 && !prec_h(g)) return MG_ERR_UNSUPPORTED;          // the float32 layers' fused inverse transform + norm has no float16 output
     if (!geom_ok(g) || !x || !w || !y || !mean || !rstd) return MG_ERR_ARG;
     if (!wino_tiles_ok(g, wt)) return MG_ERR_ARG;
@@ -2716,10 +2752,11 @@ int mg_conv_fwd_instnorm_h(const mg_conv_geom* g, const float* x, const float* w
     if (wino_ok(g) && !prec_h(g) && !mg_conv_rowdot_kq(g) && wino_out_norm_ok(g->OH / 2, g->OW / 2, g->Co) && aligned16(x) &&
         aligned16(w) && (!y_raw || aligned16(y_raw)) && aligned16(y) && aligned16(mean) && aligned16(rstd) && aligned16(workspace) &&
         (!bias || aligned16(bias)) && (!residual || aligned16(residual))) {
-        const WinoNorm nrm{eps, act, residual, y, mean, rstd};
+        const WinoNorm nrm{eps, act, residual, y, mean, rstd, v_next, next_reflect};
         return wino_fwd(g, x, w, bias, y_raw, MG_ACT_NONE, (float*)workspace, (hipStream_t)stream, wt ? wt->u : nullptr,
-                        wt ? wt->v : nullptr, &nrm);
+                        wt ? wt->v : nullptr, &nrm, wt && wt->v && (wt->flags & MG_TILES_V_FILLED));
     }
+    if (v_next) return MG_ERR_ARG;           // (unreachable after wino_vnext_ok: the fused path above is the only writer of v_next)
     if (!y_raw) y_raw = y;
     const int rc = mg_conv_fwd_w(g, x, w, bias, y_raw, MG_ACT_NONE, workspace, workspace_bytes, stream, wt);
     if (rc != MG_OK) return rc;
@@ -2744,7 +2781,8 @@ int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const f
     }
     if (wino_ok(g) && workspace && workspace_bytes >= wino_fwd_ws(g) && aligned16(x) && aligned16(w) && aligned16(y) &&
         aligned16(workspace) && (!bias || aligned16(bias)))
-        return wino_fwd(g, x, w, bias, y, act, (float*)workspace, (hipStream_t)stream, u, wt ? wt->v : nullptr);
+        return wino_fwd(g, x, w, bias, y, act, (float*)workspace, (hipStream_t)stream, u, wt ? wt->v : nullptr, nullptr,
+                        wt && wt->v && !prec_h(g) && (wt->flags & MG_TILES_V_FILLED));
     if (wino4_ok(g) && workspace && workspace_bytes >= wino4_fwd_ws(g) && aligned16(x) && aligned16(w) && aligned16(y) &&
         aligned16(workspace) && (!bias || aligned16(bias)))
         return wino4_fwd(g, x, w, bias, y, act, (float*)workspace, (hipStream_t)stream, u, wt ? wt->v : nullptr);

@@ -154,12 +154,18 @@ struct WinoNorm {
     float* y;                  // act((y_raw - mean) * rstd) + residual
     float* mean;               // [B][C]
     float* rstd;
+    float* v_next;             // NEXT instances: V' = B^T y B of the OUTPUT y, [16][T][C] -- the input image of a following 3x3 stride-1
+    int next_reflect;          //   pad-1 convolution over the same map (reflect / zero padding): ResnetBlock's next layer skips its transform
 };
-template <int NT>
+// NEXT: the slab's normalised plane (the 2TH x 2TW pixels x 32 channels the workgroup has just produced) is also staged in LDS and every
+// thread builds the next convolution's Winograd input tiles from it -- the arithmetic of wino_input_xform_kernel on the same float32
+// values, so V' is bit for bit what that kernel would compute from y: one launch and one read of y less per trunk layer.
+template <int NT, bool NEXT = false>
 __global__ __launch_bounds__(256) void wino_out_norm_kernel(const float* __restrict__ Mx, int B, int TH, int TW, int C,
                                                             const float* __restrict__ bias, WinoNorm nrm,
                                                             float* __restrict__ y_raw) {
     __shared__ double red[2][32][32];
+    __shared__ __attribute__((aligned(16))) float plane[NEXT ? NT * 32 * 4 * 32 : 4];      // [pixel][32 channels]
     const int cq = threadIdx.x & 7, tl = threadIdx.x >> 3;
     const int b = blockIdx.y, c0 = blockIdx.x * 32 + 4 * cq;
     const int Ts = TH * TW;
@@ -256,10 +262,54 @@ __global__ __launch_bounds__(256) void wino_out_norm_kernel(const float* __restr
                     o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
                 }
                 *reinterpret_cast<float4*>(nrm.y + off) = o;
+                if (NEXT) *reinterpret_cast<float4*>(plane + ((2 * ty + (q >> 1)) * (2 * TW) + 2 * tx + (q & 1)) * 32 + 4 * cq) = o;
+            }
+        }
+    }
+    if (NEXT) {
+        __syncthreads();
+        const int H = 2 * TH, W = 2 * TW;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int tile = tl + 32 * i;
+            if (tile < Ts) {
+                const int ty = tile / TW, tx = tile - ty * TW;
+                const size_t t = (size_t)b * Ts + tile;
+                float4 d[4][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int iy = 2 * ty - 1 + r;
+                    bool oky = true;
+                    if (nrm.next_reflect) iy = reflect_idx(iy, H); else oky = (iy >= 0 && iy < H);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        int ix = 2 * tx - 1 + c;
+                        bool ok = oky;
+                        if (nrm.next_reflect) ix = reflect_idx(ix, W); else ok = ok && (ix >= 0 && ix < W);
+                        d[r][c] = ok ? *reinterpret_cast<const float4*>(plane + (iy * W + ix) * 32 + 4 * cq) : zero4();
+                    }
+                }
+                float4 tmp[4][4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float4 o[4];
+                    bt4(d[0][c], d[1][c], d[2][c], d[3][c], o);
+                    tmp[0][c] = o[0]; tmp[1][c] = o[1]; tmp[2][c] = o[2]; tmp[3][c] = o[3];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float4 o[4];
+                    bt4(tmp[r][0], tmp[r][1], tmp[r][2], tmp[r][3], o);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        *reinterpret_cast<float4*>(nrm.v_next + ((size_t)(r * 4 + c) * T + t) * C + c0) = o[c];
+                }
             }
         }
     }
 }
+// the NEXT instances keep a slab's plane in LDS: up to 64 tiles (NT <= 2: 32 KiB beside the 16 KiB reduction buffer)
+inline bool wino_out_norm_next_ok(int TH, int TW, int C) { return C % 32 == 0 && TH * TW <= 64; }
 
 // ---- InstanceNorm backward fused with the data gradient's A dy A^T transform ------------------------------------------------
 // The mirror of wino_out_norm_kernel: a workgroup owns a (sample, 32-channel) slab, a thread NT tiles of 2x2 pixels.  It

@@ -72,6 +72,29 @@ def _h16_of(t):
     return buf
 
 
+# ResnetBlock chains conv3x3 -> InstanceNorm -> (ReLU) -> conv3x3 on the trunk's small maps: the fused output-transform + norm kernel
+# of one layer can write the NEXT layer's Winograd input image B^T y B (ops.conv_fwd_instnorm(v_next=...)).  Like the float16 copies
+# above, the image travels as an attribute of the tensor it was made from and is only trusted while that tensor is the very one it
+# was made from and the consumer's geometry is the one the producer was told (3x3, stride 1, pad 1, same padding mode).
+WINO_NEXT_STATS = {"made": 0, "used": 0}
+
+
+def _attach_wino_v(t, v, key):
+    t._mg_wino_v = (v, t.data_ptr(), t._version, key)
+    WINO_NEXT_STATS["made"] += 1
+    return t
+
+
+def _wino_v_of(t, key):
+    rec = getattr(t, "_mg_wino_v", None)
+    if rec is None:
+        return None
+    v, ptr, ver, k = rec
+    if t.data_ptr() != ptr or t._version != ver or k != key or not t.is_contiguous(memory_format=CL):
+        return None
+    return v
+
+
 def grad_buffer(p: torch.nn.Parameter):
     """(buffer, accumulate?) for a parameter: allocates p.grad with p's own strides on first use; a buffer that
     was handed out fresh (after zero_grad) is overwritten by the first kernel and accumulated into afterwards."""
@@ -503,11 +526,21 @@ class _ConvInstNormFn(torch.autograd.Function):
             u = None
         v, v_filled = None, False
         x16 = _h16_of(x) if ops.precast_ok(0, g) else None
+        xv = (_wino_v_of(x, (B, H, W, w.shape[1], bool(reflect), g.precision))
+              if (pad == 1 and w.shape[2] == 3 and w.shape[3] == 3 and ops.wino_vnext_ok(g)) else None)
         if x16 is not None:
             v, v_filled = x16, True
             H16_STATS["used_fwd"] += 1
+        elif xv is not None:          # x's producer (the trunk layer in front) wrote B^T x B: this layer's own V, kept for its weight gradient
+            v, v_filled = xv, True
+            WINO_NEXT_STATS["used"] += 1
         elif u is not None and weight_grad and weight.requires_grad:
             v, _ = ops.wino_tile_buffers(g, x.device, want_md=False)
+        # ... and this layer writes the NEXT trunk layer's image when told that one follows (cfg[7]: its padding mode)
+        next_reflect = cfg[7] if len(cfg) > 7 else None
+        v_next = None
+        if next_reflect is not None and ops.wino_vnext_ok(g) and os.environ.get("MG_NO_WINO_NEXT", "0") != "1":
+            v_next = torch.empty(16 * B * (g.OH // 2) * (g.OW // 2) * g.Co, dtype=torch.float32, device=x.device)
         y16 = (torch.empty(B * g.OH * g.OW * g.Co, dtype=torch.float16, device=x.device)
                if _want_h16(B, g.OH * g.OW, g.Co) else None)
         # under torch.no_grad() nobody reads the raw convolution output again (grad mode is read by conv_instnorm(): inside a
@@ -515,13 +548,16 @@ class _ConvInstNormFn(torch.autograd.Function):
         need_raw = bool(cfg[6]) and any(ctx.needs_input_grad) if len(cfg) > 6 else any(ctx.needs_input_grad)
         y, y_raw, mean, rstd = ops.conv_fwd_instnorm(g, nhwc_view(x), w, bias.detach() if bias is not None else None, act,
                                                      nhwc_view(res) if res is not None else None, eps, u, v, v_filled, y16,
-                                                     need_raw=need_raw)
+                                                     need_raw=need_raw, v_next=v_next, next_reflect=bool(next_reflect))
         ctx.u, ctx.v = u, (v if (weight_grad and weight.requires_grad) else None)
         ctx.g, ctx.cfg = g, (1, pad, reflect, ACT_NONE, False, weight_grad)
         ctx.weight, ctx.bias, ctx.norm_act = weight, bias, act
         if need_raw:
             ctx.save_for_backward(x, nchw_view(y_raw), mean, rstd)
-        return _attach_h16(nchw_view(y), y16)
+        out = _attach_h16(nchw_view(y), y16)
+        if v_next is not None:
+            _attach_wino_v(out, v_next, (B, g.OH, g.OW, g.Co, bool(next_reflect), g.precision))
+        return out
 
     @staticmethod
     def backward(ctx, gy):
@@ -578,9 +614,12 @@ class SkipGrad:
         self.g = None
 
 
-def conv_instnorm(x, weight, bias, padding=0, reflect=False, act=ACT_NONE, residual=None, eps=1e-5, weight_grad=True, skip=None):
-    """act(InstanceNorm2d(affine=False)(conv2d(x, weight, bias, stride 1))) + residual.  skip: ("give" | "take", SkipGrad)."""
-    cfg = (padding, bool(reflect), weight_grad, act, eps, skip, torch.is_grad_enabled())
+def conv_instnorm(x, weight, bias, padding=0, reflect=False, act=ACT_NONE, residual=None, eps=1e-5, weight_grad=True, skip=None,
+                  next_reflect=None):
+    """act(InstanceNorm2d(affine=False)(conv2d(x, weight, bias, stride 1))) + residual.  skip: ("give" | "take", SkipGrad).
+    next_reflect (None | bool): the output feeds another 3x3 stride-1 pad-1 convolution with that padding mode -- where the fused
+    kernel runs it also writes that layer's Winograd input image (see _attach_wino_v)."""
+    cfg = (padding, bool(reflect), weight_grad, act, eps, skip, torch.is_grad_enabled(), next_reflect)
     return _ConvInstNormFn.apply(x, weight, bias, residual, cfg)
 
 

@@ -135,6 +135,11 @@ class FusedSequence:
                 self.steps.append(("sigmoid",))
             else:
                 raise NotImplementedError("no HIP lowering for layer %s in this position" % m.__class__.__name__)
+        # a ResnetBlock followed by another one: its output's only convolution consumer is that block's first 3x3 layer
+        for k in range(len(self.steps) - 1):
+            a, b = self.steps[k], self.steps[k + 1]
+            if a[0] == "module" and b[0] == "module" and isinstance(a[1], ResnetBlock) and isinstance(b[1], ResnetBlock):
+                self.steps[k] = ("module", a[1], True)
 
     def __call__(self, x, weight_grad=True):
         for st in self.steps:
@@ -160,7 +165,7 @@ class FusedSequence:
         elif st[0] == "sigmoid":
             x = Fh.sigmoid(x)
         elif st[0] == "module":
-            x = st[1](x, weight_grad=weight_grad)
+            x = st[1](x, weight_grad=weight_grad, feeds_resblock=True) if len(st) > 2 else st[1](x, weight_grad=weight_grad)
         else:
             x = st[1](x, weight_grad)
         return x
@@ -285,14 +290,16 @@ class ResnetBlock(nn.Module):
         Fh.mark_bias_feeds_norm(self.conv_block[1].bias)
         Fh.mark_bias_feeds_norm(self.conv_block[5].bias)
 
-    def forward(self, x, weight_grad=True):
+    def forward(self, x, weight_grad=True, feeds_resblock=False):
+        """feeds_resblock: the output goes into another ResnetBlock (FusedSequence knows) -- both convolutions then hand the layer
+        behind them its Winograd input image (Fh.conv_instnorm(next_reflect=True))."""
         cb = self.conv_block
         # the skip connection's gradient rides into conv 1's data gradient instead of an autograd add (Fh.SkipGrad)
         skip = Fh.SkipGrad() if (torch.is_grad_enabled() and x.requires_grad) else None
         h = Fh.conv_instnorm(x, cb[1].weight, cb[1].bias, 1, True, ACT_RELU, None, cb[2].eps, weight_grad,
-                             ("take", skip) if skip else None)
+                             ("take", skip) if skip else None, next_reflect=True)
         return Fh.conv_instnorm(h, cb[5].weight, cb[5].bias, 1, True, ACT_NONE, x, cb[6].eps, weight_grad,
-                                ("give", skip) if skip else None)
+                                ("give", skip) if skip else None, next_reflect=True if feeds_resblock else None)
 
 
 class ConvResBlock(nn.Module):

@@ -124,11 +124,22 @@ def conv_fwd(g: ConvGeom, x, w, bias=None, act=ACT_NONE, u=None, v_out=None, v_f
     return y
 
 
+def wino_vnext_ok(g: ConvGeom) -> bool:
+    """True when conv_fwd_instnorm can also write the next 3x3 layer's Winograd input image (float32 F(2x2,3x3), small maps)."""
+    key = ("vn", g.B, g.H, g.W, g.Ci, g.Co, g.KH, g.KW, g.stride, g.pad, g.reflect, g.precision)
+    hit = _CASTS.get(key)
+    if hit is None:
+        hit = _CASTS[key] = bool(_lib.load().mg_conv_wino_vnext_ok(g))
+    return hit
+
+
 def conv_fwd_instnorm(g: ConvGeom, x, w, bias=None, act=ACT_NONE, residual=None, eps=1e-5, u=None, v_out=None, v_filled=False,
-                      y16=None, need_raw=True):
+                      y16=None, need_raw=True, v_next=None, next_reflect=False):
     """conv + InstanceNorm2d(affine=False) (+ act, + residual) -> (y, y_raw, mean, rstd); one kernel does the Winograd
     inverse transform and the normalisation when the layer and the map size allow (csrc/wino.h: wino_out_norm_kernel).
-    need_raw=False (no backward pass will follow): y_raw is None and never written -- a fifth of the fused kernel's HBM bytes."""
+    need_raw=False (no backward pass will follow): y_raw is None and never written -- a fifth of the fused kernel's HBM bytes.
+    v_next (only where wino_vnext_ok(g)): receives B^T y B of the output for a following 3x3 stride-1 pad-1 layer with padding mode
+    next_reflect, which then passes it as v_out with v_filled=True."""
     lib = _lib.load()
     y = torch.empty(g.B, g.OH, g.OW, g.Co, dtype=torch.float32, device=x.device)
     y_raw = torch.empty_like(y) if need_raw else None
@@ -137,11 +148,17 @@ def conv_fwd_instnorm(g: ConvGeom, x, w, bias=None, act=ACT_NONE, residual=None,
     ws = _ws(lib.mg_conv_fwd_instnorm_workspace(g), x.device)
     if PROFILER is not None:
         PROFILER.begin(0, g)
-    _lib.check(lib.mg_conv_fwd_instnorm_h(g, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y_raw), eps, act,
-                                          _lib.ptr(residual), _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(ws),
-                                          ws.numel(), _lib.stream(),
-                                          _tiles(u, v_out, None, None, TILES_V_FILLED if v_filled else 0), _lib.ptr(y16)),
-               "mg_conv_fwd_instnorm")
+    tiles = _tiles(u, v_out, None, None, TILES_V_FILLED if v_filled else 0)
+    if v_next is not None:
+        _lib.check(lib.mg_conv_fwd_instnorm_next(g, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y_raw), eps, act,
+                                                 _lib.ptr(residual), _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(ws),
+                                                 ws.numel(), _lib.stream(), tiles, _lib.ptr(v_next), int(bool(next_reflect))),
+                   "mg_conv_fwd_instnorm_next")
+    else:
+        _lib.check(lib.mg_conv_fwd_instnorm_h(g, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y_raw), eps, act,
+                                              _lib.ptr(residual), _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(ws),
+                                              ws.numel(), _lib.stream(), tiles, _lib.ptr(y16)),
+                   "mg_conv_fwd_instnorm")
     if PROFILER is not None:
         PROFILER.end()
     return y, y_raw, mean, rstd

@@ -74,11 +74,12 @@ class HotPathRef:
             losses["G_GAN_Feat"] = nets.feature_matching_loss(pred_fake, pred_real, self.n_layers_D, self.num_D, self.lambda_feat)
         return losses, sr_s
 
-    def train_step(self, lr_audio, hr_audio, amp=False, scaler=None):
+    def train_step(self, lr_audio, hr_audio, amp=False, scaler=None, grads_out=None):
         """One train.py:160-202 iteration.  amp=False: the fp32 branch.  amp=True: the --fp16 branch -- the forward
         under torch.autocast(float16) (train.py:161-164; on the CPU here, same op lists for conv / norm / losses) and
         one GradScaler (torch.amp.GradScaler("cpu")): scale(loss).backward(), scaler.step(opt) for G then D,
-        scaler.update() once (train.py:183-199).  Returns the loss dict (floats)."""
+        scaler.update() once (train.py:183-199).  Returns the loss dict (floats).  grads_out (a dict, tests only): receives
+        "G" / "D" -> {name: gradient} as each optimiser saw them (after the GradScaler's unscale)."""
         if amp:
             with torch.autocast("cpu", dtype=torch.float16):
                 losses, _ = self.forward_losses(lr_audio, hr_audio)
@@ -93,6 +94,8 @@ class HotPathRef:
         else:
             loss_G.backward()
             self.opt_G.step()
+        if grads_out is not None:
+            grads_out["G"] = {k: p.grad.detach().numpy().copy() for k, p in self.netG.named_parameters()}
         self.opt_D.zero_grad()
         if amp:
             scaler.scale(loss_D).backward()
@@ -101,7 +104,9 @@ class HotPathRef:
         else:
             loss_D.backward()
             self.opt_D.step()
-        return {k: float(v) for k, v in losses.items()}
+        if grads_out is not None:
+            grads_out["D"] = {k: p.grad.detach().numpy().copy() for k, p in self.netD.named_parameters()}
+        return {k: float(v.detach()) for k, v in losses.items()}
 
     # -- inference -----------------------------------------------------
     @torch.no_grad()

@@ -802,6 +802,55 @@ def test_weight_side_fusion_is_bit_identical(golden, monkeypatch):
     assert torch.equal(fused.inference(lr)[0], plain.inference(lr)[0])
 
 
+def test_next_layer_winograd_image_is_bit_identical(golden, monkeypatch):
+    """mg_conv_fwd_instnorm_next (csrc/wino.h::wino_out_norm_kernel<NT, true>): inside a chain of ResnetBlocks the fused output
+    transform + InstanceNorm kernel of a layer also writes the NEXT layer's Winograd input image, which then skips its own input
+    transform.  Same float32 arithmetic on the same values: four training iterations (the image is also the consumer's saved
+    operand for its weight gradient) and an inference pass must be bit for bit what MG_NO_WINO_NEXT=1 gives, eagerly and as a
+    hipGraph replay, and the hand-over must really happen (3 blocks: 5 images made, 5 used per forward)."""
+    from mdctgan_amd import functional as Fh
+    g = golden("g6_step_global")
+    lr, hr = torch.from_numpy(g["lr"]).to(DEV), torch.from_numpy(g["hr"]).to(DEV)
+
+    def build():
+        from mdctgan_amd import options
+        from mdctgan_amd.pix2pixHD_model import create_model
+        opt = options.make_opt(*options.SPECTRAL_FLAGS, "--lr_sampling_rate", "12000", "--netG", "global", "--ngf", "8",
+                               "--n_blocks_global", "3", "--n_blocks_attn_g", "0", "--num_D", "2", "--ndf", "8", "--batchSize", "2",
+                               "--bins", "32", "--segment_length", "7936", "--gpu_ids", "0")
+        m = create_model(opt)
+        onets.fill_deterministic(m.netG)
+        onets.fill_deterministic(m.netD)
+        return m
+
+    def run(m, graphed):
+        step = m.make_graphed_step(lr, hr, warmup=2) if graphed else (lambda: m.optimize_parameters(lr, hr))
+        for _ in range(2 if graphed else 0, 4):
+            step()
+        torch.cuda.synchronize()
+        return m
+
+    monkeypatch.setenv("MG_NO_WINO_NEXT", "1")
+    Fh.WINO_NEXT_STATS.update(made=0, used=0)
+    plain = run(build(), False)
+    assert Fh.WINO_NEXT_STATS == {"made": 0, "used": 0}
+    monkeypatch.delenv("MG_NO_WINO_NEXT")
+    handed = run(build(), False)
+    # per generator forward: conv 1 of every block hands over to conv 2 (3), conv 2 of blocks 0 / 1 to the next block (2)
+    assert Fh.WINO_NEXT_STATS["made"] == Fh.WINO_NEXT_STATS["used"] == 4 * 5, Fh.WINO_NEXT_STATS
+    graphed = run(build(), True)
+    for other in (handed, graphed):
+        for a_net, b_net in ((plain.netG, other.netG), (plain.netD, other.netD)):
+            for (k, a), (_, b) in zip(a_net.state_dict().items(), b_net.state_dict().items()):
+                assert torch.equal(a, b), k
+        assert torch.equal(plain.optimizer_G.flat_m, other.optimizer_G.flat_m) and torch.equal(plain.optimizer_G.flat_v, other.optimizer_G.flat_v)
+    n0 = dict(Fh.WINO_NEXT_STATS)
+    out_h = handed.inference(lr)[0]
+    assert Fh.WINO_NEXT_STATS["used"] - n0["used"] == 5
+    monkeypatch.setenv("MG_NO_WINO_NEXT", "1")
+    assert torch.equal(out_h, plain.inference(lr)[0])
+
+
 def test_no_lsgan_step_against_oracle():
     """--no_lsgan --no_ganFeat_loss (networks.py:106-109 BCELoss, :676-677 Sigmoid; the only form in which the reference's
     BCE branch runs -- with feature matching on, its discriminator forward never applies the Sigmoid and BCELoss rejects the
