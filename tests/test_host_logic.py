@@ -305,3 +305,33 @@ def test_fp16_gradient_verdict_rejects_zero_and_flipped_gradients():
     assert not verdict(3.0 * g16, g64, g16)[0]               # scale error (a lost 1 / loss-scale)
     assert not verdict(noise(1.0), g64, g16)[0]              # unrelated values of the right size
     assert not verdict(g64 + noise(0.8), g64, g16)[0]        # twice the reference's error
+
+
+def test_bench_side_lines_are_compact_and_summarised_last():
+    """bench.py embeds the other BASELINE configurations' lines in the headline JSON: compact (no per-symbol table, no definition /
+    sample strings -- the driver keeps the last 8 KB of stdout and round 4's configs[2] --fp16 value fell out of it) and once more
+    as `also_summary`, the LAST key of the line."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    child = {"metric": "train steps/sec", "value": 73.4, "ms_per_step": 13.62, "roofline_symbols": {"symbols": [{"kernel": "k"}] * 12},
+             "roofline": {"frac": 0.68, "traffic": 1, "flops_definition": "x" * 900, "timed": "y" * 400},
+             "cpu_baseline": {"value": 0.037, "cores": 16, "sample": "z" * 300}, "config": {"workload": "w", "steps_counted": "s" * 200}}
+    c = bench._compact(child)
+    assert "roofline_symbols" not in c and c["roofline"] == {"frac": 0.68, "traffic": 1} and c["cpu_baseline"] == {"value": 0.037, "cores": 16}
+    assert c["config"] == {"workload": "w"} and len(json.dumps(c)) < 400
+    also = [dict(c, cmd="python bench.py --gpus 1 --no-also --config 2 --fp16"),
+            {"cmd": "python bench.py --no-also --config 4", "value": 2500.0, "ms_per_step": 17.3, "roofline": {"frac": 0.89}},
+            {"cmd": "python bench.py --no-also --mode codec", "value": 7.7e6, "roofline": {"frac": 0.51}},
+            {"cmd": "MG_F32_SPLIT=1 python bench.py --no-also --config 4 --no-cpu-baseline", "value": 2520.0}]
+    sm = bench.also_summary(also)
+    assert sm == {"cfg2_fp16_steps_s": 73.4, "cfg2_fp16_ms": 13.62, "cfg4_audio_s_s": 2500.0, "cfg4_ms": 17.3, "cfg4_frac": 0.89,
+                  "codec_clips_s": 7.7e6, "codec_frac": 0.51, "cfg4_f32split_audio_s_s": 2520.0}
+    line = json.dumps({"metric": "m", "value": 1.0, "also": also, "also_summary": sm})
+    assert line.rstrip("}").endswith(json.dumps(sm).rstrip("}")) and len(json.dumps(sm)) < 500
+    # a failing side line must not take the others with it
+    assert "error" in bench.also_summary([{"cmd": "python bench.py --config 2 --fp16", "error": "boom"}])
