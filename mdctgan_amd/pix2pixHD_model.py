@@ -475,12 +475,12 @@ class Pix2PixHDModel(BaseModel):
             if opt_ is not None:
                 opt_.finish_pending()
 
-    def make_graphed_step(self, lr_audio, hr_audio, warmup=3):
+    def make_graphed_step(self, lr_audio, hr_audio, warmup=3, _ddp_ok=False):
         """Capture one full optimize_parameters() iteration (~470 launches: forward, both backward passes, both Adam
         steps) into a hipGraph and return run(lr, hr) -> loss dict, which copies the batch into the captured input
         buffers and replays.  The optimiser clock and learning rate live in HBM, so replays advance Adam exactly
         like eager steps.  The warm-up iterations are real training steps."""
-        if getattr(self, "reducers", None) and os.environ.get("MDCTGAN_DDP_GRAPH", "0") != "1":
+        if getattr(self, "reducers", None) and not _ddp_ok and os.environ.get("MDCTGAN_DDP_GRAPH", "0") != "1":
             # RCCL collectives are capturable (ProcessGroupNCCL records them into the graph from its own stream), but
             # that path has only been exercised with a 1-rank group on this hardware pool: opt-in
             raise NotImplementedError("graph capture of the data-parallel step is opt-in: MDCTGAN_DDP_GRAPH=1")
@@ -545,22 +545,19 @@ class Pix2PixHDModel(BaseModel):
         if how == "0":
             return eager
         if how == "1":
-            return self.make_graphed_step(lr_audio, hr_audio, warmup=warmup)
+            return self.make_graphed_step(lr_audio, hr_audio, warmup=warmup, _ddp_ok=True)
         if how != "auto":
             raise ValueError("MDCTGAN_DDP_GRAPH must be 0, 1 or auto")
         run, failed = None, 0
-        os.environ["MDCTGAN_DDP_GRAPH"] = "1"             # make_graphed_step's own gate
         try:
             fail_rank = os.environ.get("MDCTGAN_DDP_GRAPH_FAIL_RANK")       # test hook: this rank's capture "fails"
             if fail_rank is not None and dist.is_initialized() and dist.get_rank() == int(fail_rank):
                 raise RuntimeError("simulated capture failure (MDCTGAN_DDP_GRAPH_FAIL_RANK)")
-            run = self.make_graphed_step(lr_audio, hr_audio, warmup=warmup)
+            run = self.make_graphed_step(lr_audio, hr_audio, warmup=warmup, _ddp_ok=True)
         except Exception as e:      # noqa: BLE001 -- whatever the capture raised, the decision is collective
             failed = 1
             print("[mdctgan_amd] hipGraph capture of the data-parallel step failed on this rank (%s): asking every rank to step "
                   "eagerly" % (repr(e)[:200],), file=sys.stderr, flush=True)
-        finally:
-            os.environ["MDCTGAN_DDP_GRAPH"] = "auto"
         if dist.is_initialized():
             flag = torch.tensor([float(failed)], device=lr_audio.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=red["G"].group)
