@@ -143,6 +143,11 @@ inline int cd_pick_gm(int tiles_m, int tiles_n, int splits, double a_bytes, doub
     return best;
 }
 
+// K-split boundaries: split j of S covers the chunks [total * j / S, total * (j + 1) / S) -- any S <= total works and the splits
+// differ by at most one chunk (a ceil(total / S) stride leaves a short or an empty last split).
+__device__ __forceinline__ int cd_split_bound(int total, int S, int j) {
+    return j <= 0 ? 0 : (j >= S ? total : (int)(((long long)total * j) / S));
+}
 __device__ __forceinline__ unsigned cd_pixel_off(const CdArgs& g, int pb, int iy, int ix, unsigned cbytes) {
     if (g.reflect) {
         iy = reflect_idx(iy, g.H);
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(256) void conv_fwd_dma_kernel(CdArgs g) {
     }
     const int m0 = tm * BM, n0 = tn * BN;
     const int cpt = g.Ci / CK, total_chunks = KT * cpt;
-    const int c_begin = sp * g.cps, c_end = min(total_chunks, c_begin + g.cps);
+    const int c_begin = cd_split_bound(total_chunks, g.splits, sp), c_end = cd_split_bound(total_chunks, g.splits, sp + 1);
 
     auto make_rsrc = [](const void* p, unsigned bytes) -> dg_v4i {
         const unsigned long long a = (unsigned long long)p;
@@ -284,7 +289,13 @@ __global__ __launch_bounds__(256) void conv_fwd_dma_kernel(CdArgs g) {
 // ------------------------------------------------------------------------------------------------------------------
 // weight gradient: rows co, columns (tap, ci), reduction over output pixels (split over workgroups)
 // ------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, bool HALF = false, int NBUF = 2>
+// RR ("row-regular" gather, float32, zero padding): when a 32-pixel chunk is a whole number of output rows or an aligned piece of one
+// (OW % 32 == 0 or 32 % OW == 0 -- every ladder rung), the source pixel of chunk row k is  S(chunk) + const(k):  S is wave-uniform
+// and advanced on the scalar unit, the per-lane part never changes, and the padding turns into three precomputed lane offsets
+// (first / interior / last chunk of a row or image; out-of-range lanes hold CD_OOB).  The general path's per-lane coordinate
+// walk is ~50 VALU instructions per chunk, and a VALU instruction issued while the other resident waves keep the matrix pipe
+// full waits for a gap between their MFMAs: s_memtime stamps put the gather at 2300-2600 of a chunk's ~4800 cycles per wave.
+template <int BM, int BN, bool HALF = false, int NBUF = 2, bool RR = false>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(CdArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using Cfg = DgCfgG<BM, BN, 2, 2, DG_RC, DG_RC, NBUF>;
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(CdArgs g) {
     const int tap = n0 / g.Ci, ci0 = n0 - tap * g.Ci;
     const int ky = tap / g.KW, kx = tap - ky * g.KW;
     const int total_chunks = (Mpx + CK - 1) / CK;
-    const int c_begin = sp * g.cps, c_end = min(total_chunks, c_begin + g.cps);
+    const int c_begin = cd_split_bound(total_chunks, g.splits, sp), c_end = cd_split_bound(total_chunks, g.splits, sp + 1);
 
     auto make_rsrc = [](const void* p, unsigned bytes) -> dg_v4i {
         const unsigned long long a = (unsigned long long)p;
@@ -352,7 +363,73 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(CdArgs g) {
     const int w_y = g.OH * g.s, wb_src = (g.H - w_y) * g.W;                               // oy wrapped: next sample
     const unsigned lds_a0 = (unsigned)(size_t)(dg_lds_ptr)As0 + (unsigned)(wave * PA) * 1024u;
     const unsigned lds_b0 = (unsigned)(size_t)(dg_lds_ptr)Bs0 + (unsigned)(wave * PB) * 1024u;
+    // row-regular gather state (RR): lane constants and the scalar walk
+    unsigned vfirst[PB], vmid[PB], vlast[PB];
+    const bool rr_a = g.OW >= CK;                                     // a chunk is a piece of one output row / a chunk is CK / OW whole rows
+    const int rr_rows = rr_a ? 1 : CK / g.OW;
+    const int rr_cpp = rr_a ? g.OW / CK : (g.OH * g.OW) / CK;         // chunks per period (row / image)
+    const int rr_n2 = rr_a ? g.OH : 1;                                // periods per second-level wrap
+    const int rr_step = (rr_a ? CK * g.s : rr_rows * g.s * g.W) * (int)cbytes;
+    const int rr_w1 = (rr_a ? (g.s * g.W - g.OW * g.s) : (g.H - g.OH * g.s) * g.W) * (int)cbytes;
+    const int rr_w2 = rr_a ? (g.H - g.OH * g.s) * g.W * (int)cbytes : 0;
+    int rr_pos = 0, rr_r2 = 0, rr_S = 0;
+    dg_v4i rbr = rb;
+    if constexpr (RR) {
+        const long long shift = ((long long)(ky - g.p) * g.W + (kx - g.p)) * (long long)cbytes;
+        rbr = make_rsrc((const char*)g.x + shift, 0x80000000u);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            int k, col;
+            cd_rc_lane<HALF, BN>(wave * PB + i, lane, k, col);
+            const int j = rr_a ? 0 : k / g.OW, xk = rr_a ? k : k - (k / g.OW) * g.OW;
+            const unsigned lc = (unsigned)((j * g.s * g.W + xk * g.s) * (int)cbytes) + (unsigned)(ci0 + col) * ES;
+            // first / last chunk of the period: the lanes whose pixel falls into the padding
+            const int ox_f = xk, ox_l = rr_a ? g.OW - CK + xk : xk;
+            const int oy_f = j, oy_l = rr_a ? 0 : g.OH - rr_rows + j;             // (rr_a: the row check is scalar)
+            const bool okf = (unsigned)(ox_f * g.s + kx - g.p) < (unsigned)g.W && (rr_a || (unsigned)(oy_f * g.s + ky - g.p) < (unsigned)g.H);
+            const bool okl = (unsigned)(ox_l * g.s + kx - g.p) < (unsigned)g.W && (rr_a || (unsigned)(oy_l * g.s + ky - g.p) < (unsigned)g.H);
+            vfirst[i] = (okf && (rr_cpp > 1 || okl)) ? lc : CD_OOB;
+            vlast[i] = okl ? lc : CD_OOB;
+            vmid[i] = (rr_a || (unsigned)(xk * g.s + kx - g.p) < (unsigned)g.W) ? lc : CD_OOB;      // (rr_a: interior chunks never touch the edge, checked on the host)
+        }
+        const int per = c_begin / rr_cpp;                               // c = (per, pos);  per = (b, r2)
+        rr_pos = c_begin - per * rr_cpp;
+        const int bb = per / rr_n2;
+        rr_r2 = per - bb * rr_n2;
+        rr_S = rr_a ? ((bb * g.H + rr_r2 * g.s) * g.W + rr_pos * CK * g.s) * (int)cbytes
+                    : ((bb * g.H + rr_pos * rr_rows * g.s) * g.W) * (int)cbytes;
+    }
+    auto issue_rr = [&](int c, int buf) {
+        const unsigned la = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_a0 + (unsigned)buf * (unsigned)(Cfg::ASZ * 4)));
+        const unsigned lb = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_b0 + (unsigned)buf * (unsigned)(Cfg::BSZ * 4)));
+        const unsigned sa_off = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)c * (unsigned)CK * (unsigned)g.Co * ES));
+        const unsigned sb_off = (unsigned)__builtin_amdgcn_readfirstlane(rr_S);
+        const int pos = __builtin_amdgcn_readfirstlane(rr_pos);
+        const bool row_ok = !rr_a || (unsigned)(__builtin_amdgcn_readfirstlane(rr_r2) * g.s + ky - g.p) < (unsigned)g.H;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) dg_dma16(va[i], ra, la + 1024u * i, sa_off);
+        if (!row_ok) {
+            const unsigned voob = CD_OOB;
+#pragma unroll
+            for (int i = 0; i < PB; ++i) dg_dma16(voob, rbr, lb + 1024u * i, 0u);
+        } else if (pos == 0) {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) dg_dma16(vfirst[i], rbr, lb + 1024u * i, sb_off);
+        } else if (pos == rr_cpp - 1) {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) dg_dma16(vlast[i], rbr, lb + 1024u * i, sb_off);
+        } else {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) dg_dma16(vmid[i], rbr, lb + 1024u * i, sb_off);
+        }
+        rr_S += rr_step;
+        if (++rr_pos == rr_cpp) {
+            rr_pos = 0; rr_S += rr_w1;
+            if (++rr_r2 == rr_n2) { rr_r2 = 0; rr_S += rr_w2; }
+        }
+    };
     auto issue = [&](int c, int buf) {
+        if constexpr (RR) { issue_rr(c, buf); return; }
         // wave-uniform values; readfirstlane keeps them in SGPRs under the register pressure of the 128-column instances
         const unsigned la = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_a0 + (unsigned)buf * (unsigned)(Cfg::ASZ * 4)));
         const unsigned lb = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_b0 + (unsigned)buf * (unsigned)(Cfg::BSZ * 4)));
@@ -475,8 +552,8 @@ __global__ __launch_bounds__(256) void conv_dgrad_dma_kernel(CdArgs g) {
     const int nky = (g.KH - ky0 + s - 1) / s, nkx = (g.KW - kx0 + s - 1) / s;
     const int oyb = (py + g.p) / s, oxb = (px + g.p) / s;
     const int cpt = g.Co / CK, total_chunks = nky * nkx * cpt;
-    const int cps = (total_chunks + (int)gridDim.z - 1) / (int)gridDim.z;     // every class splits its own K range evenly
-    const int c_begin = blockIdx.z * cps, c_end = min(total_chunks, c_begin + cps);
+    // every class splits its own K range evenly
+    const int c_begin = cd_split_bound(total_chunks, (int)gridDim.z, (int)blockIdx.z), c_end = cd_split_bound(total_chunks, (int)gridDim.z, (int)blockIdx.z + 1);
 
     auto make_rsrc = [](const void* p, unsigned bytes) -> dg_v4i {
         const unsigned long long a = (unsigned long long)p;
@@ -646,6 +723,44 @@ CdPlan conv_dma_plan(long long M, int N, int chunks, bool wgrad, int ck, int tap
         if (sscanf(f, "%d,%d,%d", &f_bm, &f_bn, &f_sp) != 3) f_bm = f_bn = f_sp = 0;
     }
     double best = 1e300;
+    if (!half && wgrad) {
+        // float32 weight gradients: rounds of resident workgroups (round 5; s_memtime stamps in the kernels -- scripts/ubench/
+        // conv_dma_stamps.diff -- and scripts/tune_ladder.py sweeps at batch 2 / 8 / 64).  A CU holds `slots` workgroups of a tile
+        // shape (measured: 4 of the 32 KiB ones, not the 5 the LDS size suggests); r of them sharing the matrix pipe take
+        // max(r x MFMA cycles / eff, ~3000) shader cycles per 32-deep chunk each -- a lone 64 x 64 workgroup is bound by its own DMA
+        // round trip, not by the pipe -- and the workgroups of a round start and finish together, so the rounds add up and a last
+        // round of one workgroup per CU costs almost a full one.  Hence: any split count up to 64 (not a fixed ladder of them), and
+        // the count that fills the slots exactly once wins (64 -> 128 rung: 18 tiles x 42 = 756 workgroups, 118 -> 104 us; 128 -> 256:
+        // 72 x 14 = 1008, 102 -> 95).  Constants fitted to the sweeps (pick within 3 % of the measured best on the four rungs);
+        // the forward pass keeps the model below -- re-planning it bought nothing and re-associates the forward sums.
+        struct CandW { int bm, bn, slots; double pen; };
+        static const CandW cw[4] = {{64, 64, 4, 1.06}, {64, 128, 3, 0.91}, {128, 64, 3, 0.93}, {128, 128, 2, 0.90}};
+        for (const CandW& c : cw) {
+            if (N % c.bn != 0 || tap_cols % c.bn != 0) continue;                 // a column tile lies inside one tap
+            if (f_bm && (c.bm != f_bm || c.bn != f_bn)) continue;
+            const long long w = ((M + c.bm - 1) / c.bm) * (long long)(N / c.bn);
+            const double mfma = 1024.0 * (c.bm / 64) * (c.bn / 64), eff = 0.903 * c.pen;
+            const int sp_max = f_sp ? f_sp : (chunks / 2 < 64 ? (chunks / 2 < 1 ? 1 : chunks / 2) : 64);
+            for (int sp = f_sp ? f_sp : 1; sp <= sp_max && sp <= chunks; ++sp) {
+                const long long wg = w * sp;
+                if (wg > (1 << 16)) break;
+                const int cps = (chunks + sp - 1) / sp;
+                long long left = (wg + 255) / 256;
+                double cycles = 0.0;
+                while (left > 0) {
+                    const int r = left < c.slots ? (int)left : c.slots;
+                    left -= r;
+                    const double per_chunk = r * mfma / eff;
+                    cycles += 1000.0 + cps * (per_chunk > 2971.0 ? per_chunk : 2971.0) + (double)r * c.bm * c.bn * 4.0 * 256.0 / 4000.0;
+                }
+                double t = 8.0 + cycles / 2200.0;
+                if (sp > 1) t += (double)(sp + 1) * (double)M * N * 4.0 / 6e12 * 1e6 + 6.74;      // slabs + the reduce launch
+                if (t < best) { best = t; p = {c.bm, c.bn, sp, cps}; }
+            }
+        }
+        if (p.splits == 1) p.cps = 1 << 28;
+        return p;
+    }
     for (int ci = 0; ci < 4; ++ci) {
         const Cand& c = cands[ci];
         if (N % c.bn != 0 || (wgrad && tap_cols % c.bn != 0)) continue;      // a weight-gradient column tile lies inside one tap
@@ -657,7 +772,7 @@ CdPlan conv_dma_plan(long long M, int N, int chunks, bool wgrad, int ck, int tap
             if (sp > 1 && chunks / sp < 8) break;
             if (f_sp && sp != f_sp) continue;
             const int cps = (chunks + sp - 1) / sp;
-            const int spl = (chunks + cps - 1) / cps;
+            const int spl = sp;                                  // (cd_split_bound: every split count up to `chunks` is exact)
             const long long wg = w * spl;
             double t = (double)((wg + 255) / 256) * tile_us * (cps + fixed);
             if (wg < fill) t /= 0.85;
@@ -728,12 +843,47 @@ void conv_dma_fwd_launch(const mg_conv_geom* g, const CdPlan& p, const void* x, 
     const dim3 grid((unsigned)((long long)a.tiles_m * a.tiles_n * a.splits));
     CD_DISPATCH(conv_fwd_dma_kernel, 0, 0, conv_dma_half(g));
 }
+// eligibility of the row-regular gather (conv_wgrad_dma_kernel<..., RR = true>): float32, zero padding, whole 32-pixel chunks that
+// are an aligned piece of one output row or a whole number of rows of one image, and only the first / last chunk of a row (image)
+// may touch the padding -- the kernel masks those two with precomputed lane offsets and takes the interior ones unmasked
+inline bool conv_dma_wgrad_rowreg(const mg_conv_geom* g) {
+    if (conv_dma_half(g) || g->reflect) return false;
+    constexpr int CK = 32;
+    const long long Mpx = (long long)g->B * g->OH * g->OW;
+    if (Mpx % CK != 0) return false;
+    const int s = g->stride, p = g->pad;
+    if (g->OW >= CK) {
+        if (g->OW % CK != 0) return false;
+        const int cpp = g->OW / CK;
+        for (int pos = 1; pos + 1 < cpp; ++pos)
+            for (int k = 0; k < CK; ++k) {
+                const int lo = (pos * CK + k) * s - p, hi = lo + g->KW - 1;
+                if (lo < 0 || hi >= g->W) return false;
+            }
+    } else {
+        if (CK % g->OW != 0 || (g->OH * g->OW) % CK != 0) return false;
+        const int rows = CK / g->OW, cpp = g->OH * g->OW / CK;
+        for (int pos = 1; pos + 1 < cpp; ++pos)
+            for (int j = 0; j < rows; ++j) {
+                const int lo = (pos * rows + j) * s - p, hi = lo + g->KH - 1;
+                if (lo < 0 || hi >= g->H) return false;
+            }
+    }
+    return true;
+}
 void conv_dma_wgrad_launch(const mg_conv_geom* g, const CdPlan& p, const void* x, const void* dy, float* dw, int accumulate,
                            float* part, hipStream_t st) {
     CdArgs a = cd_args(g);
     a.x = x; a.w = dy; a.y = dw; a.part = p.splits > 1 ? part : nullptr; a.accumulate = accumulate;
     a.tiles_m = (g->Co + p.bm - 1) / p.bm; a.tiles_n = g->KH * g->KW * g->Ci / p.bn; a.splits = p.splits; a.cps = p.cps;
     const dim3 grid((unsigned)((long long)a.tiles_m * a.tiles_n * a.splits));
+    if (conv_dma_wgrad_rowreg(g) && !getenv("MG_NO_WGRAD_RR")) {
+        if (p.bm == 128 && p.bn == 128) cd_launch(conv_wgrad_dma_kernel<128, 128, false, 2, true>, DgCfgG<128, 128, 2, 2, 1, 1, 2>::LDS_BYTES, grid, a, st);
+        else if (p.bm == 64 && p.bn == 128) cd_launch(conv_wgrad_dma_kernel<64, 128, false, 2, true>, DgCfgG<64, 128, 2, 2, 1, 1, 2>::LDS_BYTES, grid, a, st);
+        else if (p.bm == 128 && p.bn == 64) cd_launch(conv_wgrad_dma_kernel<128, 64, false, 2, true>, DgCfgG<128, 64, 2, 2, 1, 1, 2>::LDS_BYTES, grid, a, st);
+        else cd_launch(conv_wgrad_dma_kernel<64, 64, false, 2, true>, DgCfgG<64, 64, 2, 2, 1, 1, 2>::LDS_BYTES, grid, a, st);
+        return;
+    }
     CD_DISPATCH(conv_wgrad_dma_kernel, 1, 1, conv_dma_half(g));
 }
 

@@ -132,6 +132,59 @@ def test_conv_fwd_dgrad_wgrad(case, small_wino42):
         assert torch.equal(ops.conv_fwd(g, xd, wd, bd, act=ops.ACT_TANH), torch.tanh(yd))
 
 
+# (name, B, Ci, H, W, Co, k, stride, pad): Ci % 64 == 0 -> the LDS-DMA weight gradient (csrc/conv_dma.h); the first five are
+# eligible for its row-regular gather (a 32-pixel chunk = an aligned piece of one output row, one row, or whole rows of one image)
+RR_CASES = [
+    ("row_pieces_OW128", 2, 64, 8, 256, 64, 3, 2, 1, True),
+    ("row_pieces_OW64_4x4", 1, 64, 16, 128, 128, 4, 2, 1, True),
+    ("one_row_OW32", 2, 64, 16, 64, 64, 3, 2, 1, True),
+    ("two_rows_OW16", 3, 128, 16, 32, 64, 3, 2, 1, True),
+    ("whole_image_OW8", 2, 64, 8, 16, 64, 3, 2, 1, True),
+    ("odd_width_general_path", 2, 64, 17, 33, 64, 3, 2, 1, False),
+    ("pixels_not_a_multiple_of_32", 1, 64, 6, 10, 64, 3, 2, 1, False),
+]
+
+
+@pytest.mark.parametrize("case", RR_CASES, ids=[c[0] for c in RR_CASES])
+def test_wgrad_row_regular_gather_is_the_general_gather(case, monkeypatch):
+    """conv_wgrad_dma_kernel<..., RR = true> (scalar source walk + three precomputed lane offsets) against the per-lane coordinate
+    walk of the same kernel (MG_NO_WGRAD_RR=1): the same bits, and both against float64."""
+    from mdctgan_amd import ops
+    name, B, Ci, H, W, Co, k, s, p, eligible = case
+    gen = torch.Generator().manual_seed(len(name))
+    x = torch.randn(B, Ci, H, W, generator=gen, dtype=torch.float64)
+    w = torch.zeros(Co, Ci, k, k, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x, w, None, stride=s, padding=p)
+    gy = torch.randn(y.shape, generator=gen, dtype=torch.float64)
+    y.backward(gy)
+    g = ops.conv_geom(B, H, W, Ci, Co, k, k, s, p, False)
+    assert "conv_wgrad_dma_kernel" in ops.plan_name(2, g)
+    pixels = B * g.OH * g.OW
+    assert eligible == (pixels % 32 == 0 and (g.OW % 32 == 0 or 32 % g.OW == 0))
+    xd, gyd = nhwc(x).float().to(DEV), nhwc(gy).float().to(DEV)
+    out = {}
+    for tag, env in (("rr", None), ("general", "1")):
+        if env:
+            monkeypatch.setenv("MG_NO_WGRAD_RR", env)
+        else:
+            monkeypatch.delenv("MG_NO_WGRAD_RR", raising=False)
+        dw = torch.full((Co, k, k, Ci), 3.0, dtype=torch.float32, device=DEV)
+        ops.conv_wgrad(g, xd, gyd, dw, None)
+        assert rel_err(dw, nhwc(w.grad)) < 3e-5, tag
+        ops.conv_wgrad(g, xd, gyd, dw, None, accumulate=True)
+        assert rel_err(dw, 2 * nhwc(w.grad)) < 3e-5, tag
+        out[tag] = dw
+    assert torch.equal(out["rr"], out["general"])
+    for splits in (3, 7, 13):            # any split count: the K range is cut at floor(chunks * j / splits)
+        if (pixels + 31) // 32 >= splits:
+            monkeypatch.setenv("MG_FORCE_CONV_DMA", "64,64,%d" % splits)
+            monkeypatch.delenv("MG_NO_WGRAD_RR", raising=False)
+            dw = torch.empty(Co, k, k, Ci, dtype=torch.float32, device=DEV)
+            ops.conv_wgrad(g, xd, gyd, dw, None)
+            assert rel_err(dw, nhwc(w.grad)) < 3e-5, splits
+            monkeypatch.delenv("MG_FORCE_CONV_DMA")
+
+
 def test_conv_fwd_fused_activations():
     from mdctgan_amd import ops
     gen = torch.Generator().manual_seed(5)
