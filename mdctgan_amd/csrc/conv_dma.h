@@ -289,8 +289,8 @@ __global__ __launch_bounds__(256) void conv_fwd_dma_kernel(CdArgs g) {
 // ------------------------------------------------------------------------------------------------------------------
 // weight gradient: rows co, columns (tap, ci), reduction over output pixels (split over workgroups)
 // ------------------------------------------------------------------------------------------------------------------
-// RR ("row-regular" gather, float32, zero padding): when a 32-pixel chunk is a whole number of output rows or an aligned piece of one
-// (OW % 32 == 0 or 32 % OW == 0 -- every ladder rung), the source pixel of chunk row k is  S(chunk) + const(k):  S is wave-uniform
+// RR ("row-regular" gather, zero padding): when a chunk of 32 pixels (float16 instances: 64) is a whole number of output rows or an aligned piece of one
+// (OW % CK == 0 or CK % OW == 0 -- every ladder rung), the source pixel of chunk row k is  S(chunk) + const(k):  S is wave-uniform
 // and advanced on the scalar unit, the per-lane part never changes, and the padding turns into three precomputed lane offsets
 // (first / interior / last chunk of a row or image; out-of-range lanes hold CD_OOB).  The general path's per-lane coordinate
 // walk is ~50 VALU instructions per chunk, and a VALU instruction issued while the other resident waves keep the matrix pipe
@@ -843,12 +843,12 @@ void conv_dma_fwd_launch(const mg_conv_geom* g, const CdPlan& p, const void* x, 
     const dim3 grid((unsigned)((long long)a.tiles_m * a.tiles_n * a.splits));
     CD_DISPATCH(conv_fwd_dma_kernel, 0, 0, conv_dma_half(g));
 }
-// eligibility of the row-regular gather (conv_wgrad_dma_kernel<..., RR = true>): float32, zero padding, whole 32-pixel chunks that
+// eligibility of the row-regular gather (conv_wgrad_dma_kernel<..., RR = true>): zero padding, whole 32- / 64-pixel chunks that
 // are an aligned piece of one output row or a whole number of rows of one image, and only the first / last chunk of a row (image)
 // may touch the padding -- the kernel masks those two with precomputed lane offsets and takes the interior ones unmasked
 inline bool conv_dma_wgrad_rowreg(const mg_conv_geom* g) {
-    if (conv_dma_half(g) || g->reflect) return false;
-    constexpr int CK = 32;
+    if (g->reflect) return false;
+    const int CK = conv_dma_ck(g);                       // 32 pixels (float32) / 64 (float16 instances)
     const long long Mpx = (long long)g->B * g->OH * g->OW;
     if (Mpx % CK != 0) return false;
     const int s = g->stride, p = g->pad;
@@ -877,7 +877,14 @@ void conv_dma_wgrad_launch(const mg_conv_geom* g, const CdPlan& p, const void* x
     a.x = x; a.w = dy; a.y = dw; a.part = p.splits > 1 ? part : nullptr; a.accumulate = accumulate;
     a.tiles_m = (g->Co + p.bm - 1) / p.bm; a.tiles_n = g->KH * g->KW * g->Ci / p.bn; a.splits = p.splits; a.cps = p.cps;
     const dim3 grid((unsigned)((long long)a.tiles_m * a.tiles_n * a.splits));
-    if (conv_dma_wgrad_rowreg(g) && !getenv("MG_NO_WGRAD_RR")) {
+    if (conv_dma_wgrad_rowreg(g) && !getenv("MG_NO_WGRAD_RR") && (!conv_dma_half(g) || cd_half_nbuf() == 2)) {
+        if (conv_dma_half(g)) {
+            if (p.bm == 128 && p.bn == 128) cd_launch(conv_wgrad_dma_kernel<128, 128, true, 2, true>, DgCfgG<128, 128, 2, 2, 1, 1, 2>::LDS_BYTES, grid, a, st);
+            else if (p.bm == 64 && p.bn == 128) cd_launch(conv_wgrad_dma_kernel<64, 128, true, 2, true>, DgCfgG<64, 128, 2, 2, 1, 1, 2>::LDS_BYTES, grid, a, st);
+            else if (p.bm == 128 && p.bn == 64) cd_launch(conv_wgrad_dma_kernel<128, 64, true, 2, true>, DgCfgG<128, 64, 2, 2, 1, 1, 2>::LDS_BYTES, grid, a, st);
+            else cd_launch(conv_wgrad_dma_kernel<64, 64, true, 2, true>, DgCfgG<64, 64, 2, 2, 1, 1, 2>::LDS_BYTES, grid, a, st);
+            return;
+        }
         if (p.bm == 128 && p.bn == 128) cd_launch(conv_wgrad_dma_kernel<128, 128, false, 2, true>, DgCfgG<128, 128, 2, 2, 1, 1, 2>::LDS_BYTES, grid, a, st);
         else if (p.bm == 64 && p.bn == 128) cd_launch(conv_wgrad_dma_kernel<64, 128, false, 2, true>, DgCfgG<64, 128, 2, 2, 1, 1, 2>::LDS_BYTES, grid, a, st);
         else if (p.bm == 128 && p.bn == 64) cd_launch(conv_wgrad_dma_kernel<128, 64, false, 2, true>, DgCfgG<128, 64, 2, 2, 1, 1, 2>::LDS_BYTES, grid, a, st);

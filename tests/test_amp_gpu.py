@@ -71,6 +71,35 @@ def close_f16(got, want, ulps=1.5, floor=2.0 ** -11):
     assert torch.equal(got.float().half().float().double(), got), "output is not float16-representable"
 
 
+@pytest.mark.parametrize("case", [("row_pieces_OW128", 2, 64, 8, 256, 128, 3), ("one_row_OW64_4x4", 1, 128, 8, 128, 64, 4),
+                                  ("two_rows_OW32", 2, 64, 32, 64, 128, 3), ("whole_image_OW8", 4, 64, 16, 16, 64, 3)],
+                         ids=lambda c: c[0])
+def test_f16_wgrad_row_regular_gather_is_the_general_gather(case, monkeypatch):
+    """The float16 instances of the LDS-DMA weight gradient (64-pixel chunks) with the row-regular gather (csrc/conv_dma.h,
+    RR = true) against the per-lane coordinate walk (MG_NO_WGRAD_RR=1): the same bits; accuracy is test_conv_f16_precision's
+    (its cdh_down3x3_s2 case takes the row-regular kernel)."""
+    from mdctgan_amd import _lib, ops
+    name, B, Ci, H, W, Co, k = case
+    g = ops.conv_geom(B, H, W, Ci, Co, k, k, 2, 1, False, _lib.PRECISION_F16)
+    assert "conv_wgrad_dma_kernel" in ops.plan_name(2, g) and ", true" in ops.plan_name(2, g)
+    assert (B * g.OH * g.OW) % 64 == 0 and (g.OW % 64 == 0 or (64 % g.OW == 0 and (g.OH * g.OW) % 64 == 0))
+    gen = torch.Generator().manual_seed(len(name))
+    x = torch.randn(B, H, W, Ci, generator=gen).to(DEV)
+    gy = torch.randn(B, g.OH, g.OW, Co, generator=gen).to(DEV)
+    out = []
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("MG_NO_WGRAD_RR", env)
+        dw = torch.full((Co, k, k, Ci), 3.0, dtype=torch.float32, device=DEV)
+        ops.conv_wgrad(g, x, gy, dw, None)
+        out.append(dw)
+    assert torch.equal(out[0], out[1])
+    ref = torch.zeros(Co, Ci, k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(h(x.cpu().permute(0, 3, 1, 2)), ref, None, stride=2, padding=1).backward(h(gy.cpu().permute(0, 3, 1, 2)))
+    want = nhwc(ref.grad)
+    assert (out[0].double().cpu() - want).abs().max().item() <= 3e-5 * want.abs().max().item()
+
+
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_conv_f16_precision(case):
     from mdctgan_amd import _lib, ops
