@@ -12,12 +12,13 @@ def main():
     ap.add_argument("--only", default="down64,down128,down256,down512")
     ap.add_argument("--iters", type=int, default=15)
     ap.add_argument("--splits", default="1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,21,22,24,26,28,30,32,36,40,42,48,56,64")
+    ap.add_argument("--f16", action="store_true", help="MG_PRECISION_F16 (the float16 instances)")
     a = ap.parse_args()
     splits = [int(v) for v in a.splits.split(",")]
     for name in a.only.split(","):
         B, H, W, Ci, Co, k, s, p, refl = SHAPES[name]
         B = a.batch
-        g = ops.conv_geom(B, H, W, Ci, Co, k, k, s, p, refl, 0)
+        g = ops.conv_geom(B, H, W, Ci, Co, k, k, s, p, refl, 1 if a.f16 else 0)
         x = torch.randn(B, H, W, Ci, device="cuda"); w = torch.randn(Co, k, k, Ci, device="cuda") * 0.02
         b = torch.zeros(Co, device="cuda"); dy = torch.randn(B, g.OH, g.OW, Co, device="cuda"); dw = torch.empty_like(w)
         fl = ops.conv_flops(g)
