@@ -692,31 +692,20 @@ inline size_t conv_dma_h_x_bytes(const mg_conv_geom* g) { return cd_al((size_t)g
 inline size_t conv_dma_h_dy_bytes(const mg_conv_geom* g) { return cd_al((size_t)g->B * g->OH * g->OW * g->Co * 2); }
 inline size_t conv_dma_h_w_bytes(const mg_conv_geom* g) { return cd_al((size_t)g->Co * g->KH * g->KW * g->Ci * 2); }
 struct CdPlan { int bm, bn, splits, cps; };
-// cost-model constants of the float16 instances (tuning: MG_HALF_RATE / MG_HALF_FIXED / MG_HALF_FILL)
-// cost-model constants of the float16 instances, fitted in round 3 (scripts/sweep_half_tiles.sh)
+// cost-model constants of the float16 data gradient (conv_dma_dgrad_plan), fitted in round 3 (scripts/sweep_half_tiles.sh)
 inline double cd_half_rate() { return 4.0; }
 inline double cd_half_fixed() { return 4.0; }
 inline long long cd_half_fill() { return 512; }
-inline double cd_half_wgrad_eff(int i) {
-    constexpr double v[4] = {0.83, 0.80, 1.0, 0.88};
-    return v[i];
-}
-// the dense plan's cost model (dense_plan above) on the convolution's GEMM view, DMA instances only.  ck = K depth of a chunk
-// (32 float32 / 64 float16); the float16 instances are priced at 4x the float32 MFMA rate (what the staging sustains) with a
-// proportionally larger fixed cost per workgroup.
+// Plans of the forward pass and the weight gradient on the convolution's GEMM view.  ck = K depth of a chunk (32 float32 / 64 float16).
+// Three models: rounds of resident workgroups for the float32 weight gradient and for both float16 passes (round 5), the dense
+// plan's cost model (dense_plan above) for the float32 forward pass.
 CdPlan conv_dma_plan(long long M, int N, int chunks, bool wgrad, int ck, int tap_cols = 0) {   // tap_cols: Ci of a weight gradient
     struct Cand { int bm, bn; double eff; };
-    static const Cand cands_f[4] = {{64, 64, 0.83}, {64, 128, 0.885}, {128, 64, 0.855}, {128, 128, 0.91}};
-    // float16 weight gradients (both operands row-contiguous, transpose reads): measured with forced tiles and free splits on the
-    // configs[2] layer shapes (scripts/bench_conv.py --f16, MG_FORCE_CONV_DMA=bm,bn,0), 128 x 64 is the fastest or within 3 % of it
-    // on 11 of 13 shapes (down128: 47 vs 67 us for 64 x 64, the batch-16 discriminator layer 79 vs 101) -- MG_HALF_WGRAD_EFF=a,b,c,d
-    static const Cand cands_hw[4] = {{64, 64, cd_half_wgrad_eff(0)}, {64, 128, cd_half_wgrad_eff(1)}, {128, 64, cd_half_wgrad_eff(2)},
-                                     {128, 128, cd_half_wgrad_eff(3)}};
+    static const Cand cands[4] = {{64, 64, 0.83}, {64, 128, 0.885}, {128, 64, 0.855}, {128, 128, 0.91}};
     static const int split_opts[12] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
     const bool half = ck == 64;
-    const Cand* cands = (half && wgrad) ? cands_hw : cands_f;
-    const double rate = (half ? cd_half_rate() : 1.0) * 157.3e12 / 256.0, fixed = half ? cd_half_fixed() : 1.2;
-    const long long fill = half ? cd_half_fill() : 512;
+    const double rate = 157.3e12 / 256.0, fixed = 1.2;
+    const long long fill = 512;
     CdPlan p{64, 64, 1, 1 << 28};
     int f_bm = 0, f_bn = 0, f_sp = 0;
     if (const char* f = getenv("MG_FORCE_CONV_DMA")) {      // tuning harness: "bm,bn,splits"
@@ -761,10 +750,44 @@ CdPlan conv_dma_plan(long long M, int N, int chunks, bool wgrad, int ck, int tap
         if (p.splits == 1) p.cps = 1 << 28;
         return p;
     }
+    if (half) {
+        // float16 instances, forward and weight gradient: the same rounds model with its own constants.  A chunk holds only 4 / 8 / 16
+        // MFMAs per wave here, so a workgroup's chunk is bound by its DMA round trip (~1500 cycles) up to four resident ones and
+        // the fixed costs of a 30-50 us launch weigh more.  Fitted to scripts/tune_ladder.py --f16 on the configs[2] rungs
+        // (profiles/r05_ladder_tile_split_sweep_f16.log: the pick is within 3 % of the measured best on 12 of 12 layer passes where
+        // the round-3 model was 8 % off on average, 30 % on the 512 -> 1024 forward); configs[2] --fp16: six interleaved pairs of
+        // bench runs, 13.86 -> 13.67 ms in the mean, every pair <= 0.
+        struct CandH { int bm, bn, slots; double pen_f, pen_w; };
+        static const CandH ch[4] = {{64, 64, 4, 1.064, 1.3}, {64, 128, 3, 0.74, 0.966}, {128, 64, 3, 0.716, 1.3}, {128, 128, 2, 1.057, 1.3}};
+        for (const CandH& c : ch) {
+            if (N % c.bn != 0 || (wgrad && tap_cols % c.bn != 0)) continue;
+            if (f_bm && (c.bm != f_bm || c.bn != f_bn)) continue;
+            const long long w = ((M + c.bm - 1) / c.bm) * (long long)(N / c.bn);
+            const double mfma = 495.0 * (c.bm / 64) * (c.bn / 64) / (wgrad ? c.pen_w : c.pen_f);
+            const int sp_max = f_sp ? f_sp : (chunks / 2 < 32 ? (chunks / 2 < 1 ? 1 : chunks / 2) : 32);
+            for (int sp = f_sp ? f_sp : 1; sp <= sp_max && sp <= chunks; ++sp) {
+                const long long wg = w * sp;
+                if (wg > (1 << 16)) break;
+                const int cps = (chunks + sp - 1) / sp;
+                long long left = (wg + 255) / 256;
+                double cycles = 0.0;
+                while (left > 0) {
+                    const int r = left < c.slots ? (int)left : c.slots;
+                    left -= r;
+                    const double per_chunk = r * mfma;
+                    cycles += 500.0 + cps * (per_chunk > 1477.0 ? per_chunk : 1477.0) + (double)r * c.bm * c.bn * 4.0 * 256.0 / 5000.0;
+                }
+                double t = 12.0 + cycles / 2200.0;
+                if (sp > 1) t += (double)(sp + 1) * (double)M * N * 4.0 / 8e12 * 1e6 + 2.13;
+                if (t < best) { best = t; p = {c.bm, c.bn, sp, cps}; }
+            }
+        }
+        if (p.splits == 1) p.cps = 1 << 28;
+        return p;
+    }
     for (int ci = 0; ci < 4; ++ci) {
         const Cand& c = cands[ci];
-        if (N % c.bn != 0 || (wgrad && tap_cols % c.bn != 0)) continue;      // a weight-gradient column tile lies inside one tap
-        if (half && wgrad && c.bm == 128 && M < 256) continue;               // one row of tiles only: 64-row tiles split it better (128 channels: 79 vs 89 us)
+        if (N % c.bn != 0) continue;                              // (float32 forward pass)
         if (f_bm && (c.bm != f_bm || c.bn != f_bn)) continue;
         const long long w = ((M + c.bm - 1) / c.bm) * (long long)(N / c.bn);
         const double tile_us = 2.0 * c.bm * c.bn * ck / rate * 1e6 / c.eff;
