@@ -300,6 +300,9 @@ int mg_conv_wgrad_adam_w(const mg_conv_geom* g, const float* x, const float* dy,
 /* Name of the kernel instance a pass (0 fwd, 1 dgrad, 2 wgrad) launches for this geometry -- the symbol
  * rocprofv3 reports -- so bench.py can attribute event-timed launches per kernel.  out: host buffer >= 64 B. */
 int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len);
+/* K splits of that launch where the pass takes the LDS-DMA implicit-GEMM kernels (conv_{fwd,dgrad,wgrad}_dma_kernel; 1 = unsplit),
+ * 0 for every other kernel family: lets a host-only test pin the planner (workgroups = tiles x splits). */
+int mg_conv_plan_splits(int pass, const mg_conv_geom* g);
 /* FLOPs issued by that kernel for this geometry (direct: 2*MACs; Winograd layers: the P batched GEMMs, 2*P*T*Co*K). */
 double mg_conv_plan_flops(int pass, const mg_conv_geom* g);
 /* One-shot timing probe for bench.py: the next mg_conv_{fwd,dgrad,wgrad} call records hipEvent e0 / e1 on its launch

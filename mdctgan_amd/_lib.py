@@ -89,6 +89,7 @@ SIGNATURES = {
     "mg_conv_wgrad": (_i, [_G, _p, _p, _p, _p, _i, _p, _sz, _p]),
     "mg_conv_wgrad_workspace": (_sz, [_G]),
     "mg_conv_plan_name": (_i, [_i, _G, C.c_char_p, _i]),
+    "mg_conv_plan_splits": (_i, [_i, _G]),
     "mg_conv_plan_flops": (C.c_double, [_i, _G]),
     "mg_probe_arm": (None, [_p, _p]),
     "mg_resample_length": (_ll, [_ll, _i, _i]),

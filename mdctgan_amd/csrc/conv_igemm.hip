@@ -2437,6 +2437,17 @@ double mg_conv_plan_flops(int pass, const mg_conv_geom* g) {
 
 // Name of the kernel instance a pass would launch for this geometry (matches the symbol rocprofv3 reports,
 // minus the anonymous-namespace prefix).  pass: 0 fwd, 1 dgrad, 2 wgrad.
+int mg_conv_plan_splits(int pass, const mg_conv_geom* g) {
+    char name[96];
+    if (!geom_ok(g) || mg_conv_plan_name(pass, g, name, (int)sizeof name) != MG_OK) return 0;
+    if (pass == 0 && strncmp(name, "conv_fwd_dma_kernel", 19) == 0) return conv_dma_fwd_plan(g).splits;
+    if (pass == 2 && strncmp(name, "conv_wgrad_dma_kernel", 21) == 0) return conv_dma_wgrad_plan(g).splits;
+    if (pass == 1 && strncmp(name, "conv_dgrad_dma_kernel", 21) == 0) {
+        mg_conv_geom gp;
+        return (conv_dma_dgrad_ok(g) ? conv_dma_dgrad_plan(g) : (cd_reflect_dgrad_geom(g, &gp), conv_dma_dgrad_plan(&gp))).splits;
+    }
+    return 0;
+}
 int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
     if (!geom_ok(g) || !out || out_len < 64) return MG_ERR_ARG;
     const int kq = mg_conv_rowdot_kq(g);
@@ -2542,7 +2553,9 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
         snprintf(out, out_len, "conv_fwd_dma_kernel<%d, %d, %s, %d>", cp.bm, cp.bn, prec_h(g) ? "true" : "false", prec_h(g) ? cd_half_nbuf() : 2);
     } else if (pass == 2 && conv_dma_wgrad_ok(g)) {
         const CdPlan cp = conv_dma_wgrad_plan(g);
-        snprintf(out, out_len, "conv_wgrad_dma_kernel<%d, %d, %s, %d>", cp.bm, cp.bn, prec_h(g) ? "true" : "false", prec_h(g) ? cd_half_nbuf() : 2);
+        const bool rr = conv_dma_wgrad_rowreg(g) && !getenv("MG_NO_WGRAD_RR") && (!prec_h(g) || cd_half_nbuf() == 2);
+        snprintf(out, out_len, "conv_wgrad_dma_kernel<%d, %d, %s, %d, %s>", cp.bm, cp.bn, prec_h(g) ? "true" : "false", prec_h(g) ? cd_half_nbuf() : 2,
+                 rr ? "true" : "false");
     } else if (pass == 0) {
         const TilePlan tp = fwd_plan(g);
         const bool vec16 = g->Ci % BK == 0;

@@ -54,6 +54,35 @@ def test_conv_geom_layout_matches_library_and_integration_doc():
     assert fields == [f[0] for f in _lib.ConvGeom._fields_]
 
 
+def test_ladder_weight_gradient_plans_fill_the_resident_slots():
+    """Host-side planner of the LDS-DMA weight gradient (csrc/conv_dma.h): a CU holds 4 / 3 / 2 workgroups
+    of the 64x64 / 64x128, 128x64 / 128x128 tiles; for the stride-2 rungs of configs[1] at the bench's batch the plan must fit in
+    whole rounds of them with the last round at least three quarters full (the old fixed ladder of split counts left a round of
+    one workgroup per CU), take the row-regular gather, and reproduce itself (the workspace query and the launch call it twice)."""
+    from mdctgan_amd import ops
+    slots = {(64, 64): 4, (64, 128): 3, (128, 64): 3, (128, 128): 2}
+    for prec in (0, _lib.PRECISION_F16):
+        for (H, W, Ci, Co) in ((128, 256, 64, 128), (64, 128, 128, 256), (32, 64, 256, 512), (16, 32, 512, 1024)):
+            g = ops.conv_geom(8, H, W, Ci, Co, 3, 3, 2, 1, False, prec)
+            name = ops.plan_name(2, g)
+            m = re.match(r"conv_wgrad_dma_kernel<(\d+), (\d+), (true|false), 2, true>", name)
+            assert m, name
+            assert (m.group(3) == "true") == (prec == _lib.PRECISION_F16)
+            bm, bn = int(m.group(1)), int(m.group(2))
+            splits = _lib.load().mg_conv_plan_splits(2, g)
+            assert splits == _lib.load().mg_conv_plan_splits(2, g) >= 1
+            chunks = 8 * (H // 2) * (W // 2) // (64 if prec else 32)
+            assert splits <= chunks
+            wgs = (Co // bm) * (9 * Ci // bn) * splits
+            per_cu = -(-wgs // 256)
+            last = per_cu % slots[(bm, bn)] or slots[(bm, bn)]
+            if prec == 0:
+                assert 4 * last >= 3 * slots[(bm, bn)] or per_cu >= 2 * slots[(bm, bn)], (name, splits, wgs)
+    # a geometry the LDS-DMA kernels do not take reports 0 splits
+    g = ops.conv_geom(2, 32, 64, 2, 16, 7, 7, 1, 3, True, 0)
+    assert _lib.load().mg_conv_plan_splits(0, g) == 0
+
+
 def test_host_tensors_are_refused():
     import torch
     with pytest.raises(_lib.HipLibraryError):
