@@ -35,6 +35,21 @@ def nchw_view(y):
 
 
 # ------------------------------------------------------------------------------------------------
+# sign-decision capture (mask-pinned gradient parity, tests/test_fullsize_step_gpu.py)
+# ------------------------------------------------------------------------------------------------
+# Every non-smooth point of the step -- ReLU / LeakyReLU masks, sign(fake - real) of the L1 feature loss, sign(s) of the
+# discriminator input's |s| channel -- as the forward pass decided it.  TAP = [] switches the capture on: the networks append
+# (module in front of the activation, output > 0), the two Functions below their signs.  The oracle then evaluates its float64
+# backward on these very decisions (oracle/step.py::MaskPins).  None (always, outside that test): no launch, no copy.
+TAP = None
+
+
+def tap(key, y):
+    if TAP is not None:
+        TAP.append((key, y.detach() > 0))
+
+
+# ------------------------------------------------------------------------------------------------
 # fused gradient accumulation
 # ------------------------------------------------------------------------------------------------
 # --fp16: a kernel that produces an activation (InstanceNorm forward) or an activation gradient (InstanceNorm backward) can
@@ -877,6 +892,8 @@ class _DInputSharedFn(torch.autograd.Function):
         out = torch.empty(2 * B, H, W, 3, dtype=torch.float32, device=a.device)
         ops.dinput_fwd(nhwc_view(lr), nhwc_view(a), nr0, out=out[:B])
         ops.dinput_fwd(nhwc_view(lr), nhwc_view(b), nr0, out=out[B:])
+        if TAP is not None:
+            TAP.append(("abs_sign", torch.sign(a.detach())))
         ctx.save_for_backward(a)
         return nchw_view(out)
 
@@ -1021,6 +1038,8 @@ class _L1HalvesSumFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, scale, *ts):
         ts = [_cl(t) for t in ts]
+        if TAP is not None:
+            TAP.append(("l1_sign", [torch.sign(t[:t.shape[0] // 2].detach() - t[t.shape[0] // 2:].detach()) for t in ts]))
         loss = torch.empty(1, dtype=torch.float32, device=ts[0].device)
         # all layers in one partial + one final launch (mg_loss_multi_fwd): same blocks, same order of additions
         ops.loss_multi_fwd(ops.LOSS_L1, [(t[:t.shape[0] // 2], t[t.shape[0] // 2:], None, 0) for t in ts], 0.0, scale, loss)

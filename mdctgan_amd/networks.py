@@ -162,6 +162,8 @@ class FusedSequence:
                     raise NotImplementedError("activation directly after %s" % m.__class__.__name__)
             if norm:
                 x = Fh.instance_norm_act(x, act, None, eps)
+            if act in (ACT_RELU, ACT_LRELU02):
+                Fh.tap(m, x)
         elif st[0] == "sigmoid":
             x = Fh.sigmoid(x)
         elif st[0] == "module":
@@ -243,11 +245,16 @@ class BottleBlock(nn.Module):
             shortcut = x
         else:
             shortcut = self.shortcut[1](self.shortcut[0](x, weight_grad=weight_grad), ACT_RELU)
+            Fh.tap(self.shortcut[1], shortcut)
         h = n[1](n[0](x, weight_grad=weight_grad), ACT_RELU)
+        Fh.tap(n[1], h)
         h = n[3](h, weight_grad=weight_grad)
         h = n[5](h, ACT_RELU)
+        Fh.tap(n[5], h)
         h = n[7](h, weight_grad=weight_grad)
-        return n[8](h, ACT_RELU, shortcut)           # relu(bn(h) + shortcut)
+        out = n[8](h, ACT_RELU, shortcut)            # relu(bn(h) + shortcut)
+        Fh.tap(n[8], out)
+        return out
 
 
 class BottleStack(FusedModule):
@@ -298,6 +305,7 @@ class ResnetBlock(nn.Module):
         skip = Fh.SkipGrad() if (torch.is_grad_enabled() and x.requires_grad) else None
         h = Fh.conv_instnorm(x, cb[1].weight, cb[1].bias, 1, True, ACT_RELU, None, cb[2].eps, weight_grad,
                              ("take", skip) if skip else None, next_reflect=True)
+        Fh.tap(cb[1], h)
         return Fh.conv_instnorm(h, cb[5].weight, cb[5].bias, 1, True, ACT_NONE, x, cb[6].eps, weight_grad,
                                 ("give", skip) if skip else None, next_reflect=True if feeds_resblock else None)
 

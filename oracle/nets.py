@@ -120,9 +120,10 @@ class _BotBlock(nn.Module):
             nn.BatchNorm2d(attn_out), act,
             nn.Conv2d(attn_out, dim_out, 1, bias=False), nn.BatchNorm2d(dim_out))
         nn.init.zeros_(self.net[-1].weight)
+        self.out_act = nn.ReLU()      # a slot (no parameters, no state-dict key) so that oracle/step.py::pin_activations can pin it
 
     def forward(self, x):
-        return F.relu(self.net(x) + self.shortcut(x))
+        return self.out_act(self.net(x) + self.shortcut(x))
 
 
 class BotStackRef(nn.Module):
@@ -329,11 +330,18 @@ def lsgan_loss(preds, target_is_real: bool):
     return sum(F.mse_loss(p[-1], torch.full_like(p[-1], t)) for p in preds)
 
 
-def feature_matching_loss(pred_fake, pred_real, n_layers_D=3, num_D=2, lambda_feat=10.0):
-    """pix2pixHD_model.py:443-451."""
+def feature_matching_loss(pred_fake, pred_real, n_layers_D=3, num_D=2, lambda_feat=10.0, signs=None):
+    """pix2pixHD_model.py:443-451.  signs (mask-pinned evaluation, oracle/step.py::MaskPins): sign(fake - real) per term, in this
+    loop's order -- |d| is then evaluated as d * sign, the linear map the other evaluation's backward applied."""
     loss = 0
     fw, dw = 4.0 / (n_layers_D + 1), 1.0 / num_D
+    n = 0
     for i in range(num_D):
         for j in range(len(pred_fake[i]) - 1):
-            loss = loss + dw * fw * F.l1_loss(pred_fake[i][j], pred_real[i][j].detach()) * lambda_feat
+            if signs is None:
+                term = F.l1_loss(pred_fake[i][j], pred_real[i][j].detach())
+            else:
+                term = ((pred_fake[i][j] - pred_real[i][j].detach()) * signs[n].to(pred_fake[i][j].dtype)).mean()
+            loss = loss + dw * fw * term * lambda_feat
+            n += 1
     return loss

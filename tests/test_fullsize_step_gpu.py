@@ -376,6 +376,138 @@ def test_full_size_step_gradients(tag, fp16, feat, batch, n_steps, monkeypatch):
     print("full-size step %s: %d gradients, worst rel-L2 %.3e at %s (CPU yardstick: %.3e)" % (case, checked, worst[0], worst[1], worst[2]))
 
 
+def hip_masks(model, tap):
+    """Fh.TAP records -> oracle/step.py::MaskPins (module objects -> the state-dict names both module trees share)."""
+    names = {m: n for net in (model.netG, model.netD) for n, m in net.named_modules()}
+    in_G = {m for m in model.netG.modules()}
+    act_G, act_D, l1_sign, abs_sign = {}, {}, None, None
+    for key, val in tap:
+        if key == "l1_sign":
+            l1_sign = [v.cpu() for v in val]
+        elif key == "abs_sign":
+            abs_sign = val.cpu()
+        else:
+            table = act_G if key in in_G else act_D
+            assert names[key] not in table, "activation tapped twice in one forward: " + names[key]
+            table[names[key]] = val.cpu()
+    return ostep.MaskPins(act_G, act_D, l1_sign, abs_sign)
+
+
+# Mask-pinned bars (relative L2 per parameter against the float64 oracle evaluated on the HIP forward's own sign decisions).
+# float32: the two backward passes are the same linear map; what is left is float32 rounding of the forward values and of the
+# kernels' sums (Winograd included).  --fp16: the float64 leg keeps unrounded weights / activations, the HIP leg rounds both to
+# float16 at every autocast convolution (relative 2^-11 per element) -- the bar is that rounding, not a sign lottery.
+PINNED_BAR = {False: 1e-4, True: 2e-2}
+
+
+@pytest.mark.parametrize("tag,fp16,batch", [("configs1", False, 8), ("configs2", False, 2), ("configs2", False, 8), ("configs2", True, 8)],
+                         ids=["configs1_f32_batch8", "configs2_f32_batch2", "configs2_f32_batch8", "configs2_fp16_batch8"])
+def test_full_size_step_gradients_mask_pinned(tag, fp16, batch):
+    """train.py:160-202's two backward passes at full size, EVERY gradient against the float64 oracle evaluated on the HIP
+    forward's own ReLU / LeakyReLU masks, sign(fake - real) of the feature loss and sign(s) of the discriminator input
+    (oracle/step.py::MaskPins).  The statistical test above compares two independent float evaluations, whose masks differ where
+    a pre-activation is within rounding of zero (0.4-1.8 % of a gradient's norm, a different draw for every change of any
+    kernel's summation order); with the decisions shared the bar is rounding itself: 1e-4, and a 1 % kernel bug
+    is two orders of magnitude above it.  configs[2] at batch 2 / 8: the bottleneck-transformer BatchNorm's cross-sample
+    statistics and the multi-slice sum kernels at full width (networks.py:232-235)."""
+    from mdctgan_amd import functional as Fh
+    from mdctgan_amd import options
+    from mdctgan_amd.pix2pixHD_model import create_model
+    cfg = CONFIGS[tag]
+    B = batch
+    threads = torch.get_num_threads()
+    torch.manual_seed(1234)
+    gen = torch.Generator().manual_seed(2024)
+    netG = onets.init_weights(cfg["gen"](), gen)
+    netD = onets.init_weights(onets.MultiscaleDRef(3, 64, 3, cfg["num_D"]), gen)
+    sdG = {k: v.clone() for k, v in netG.state_dict().items()}
+    sdD = {k: v.clone() for k, v in netD.state_dict().items()}
+    lr, hr = synth(B, 5)
+    ref = ostep.HotPathRef(netG, netD, ostep.CodecCfg(), num_D=cfg["num_D"], dtype=torch.float64)
+    lr_s, _ = ref.spectro(lr.numpy())
+    hr_s, _ = ref.spectro(hr.numpy())
+    lr_s, hr_s = lr_s.float(), hr_s.float()          # the float32-rounded spectrograms both legs see
+
+    # the HIP step, sign decisions recorded
+    opt = options.make_opt(*options.SPECTRAL_FLAGS, "--lr_sampling_rate", "12000", *cfg["flags"], "--batchSize", str(B),
+                           "--gpu_ids", "0", *(["--fp16"] if fp16 else []))
+    model = create_model(opt)
+    model.netG.load_state_dict(sdG)
+    model.netD.load_state_dict(sdD)
+    scale = 1.0
+    if fp16:
+        scale = 1024.0
+        model.scaler.state[0] = scale
+    s_lr, s_hr = lr_s.to(DEV), hr_s.to(DEV)
+    model.preprocess.forward = lambda audio: (s_lr, None, None)
+    model.preprocess.hr_forward = lambda audio: (s_hr, None, None)
+    Fh.TAP = []
+    try:
+        ld = model.optimize_parameters(lr.to(DEV), hr.to(DEV))
+        torch.cuda.synchronize()
+        tap = Fh.TAP
+    finally:
+        Fh.TAP = None
+    assert model._shared_rows == B, "the bench's shared discriminator pass must be the path under test"
+    if fp16:
+        assert model.scaler.get_scale() == scale, "the AMP step was skipped (inf gradients): nothing to compare"
+    pins = hip_masks(model, tap)
+    got_G = {k: p.grad.detach().double().cpu().numpy() / scale for k, p in model.netG.named_parameters() if p.grad is not None}
+    got_D = {k: p.grad.detach().double().cpu().numpy() / scale for k, p in model.netD.named_parameters() if p.grad is not None}
+    losses_hip = {k: v.item() for k, v in ld.items()}
+    del model, tap
+    torch.cuda.empty_cache()
+
+    # the float64 oracle on those decisions
+    try:
+        torch.set_num_threads(min(64, threads))
+        used_G = ostep.pin_activations(ref.netG, pins, pins.act_G)
+        used_D = ostep.pin_activations(ref.netD, pins, pins.act_D)
+        assert sorted(set(used_G)) == sorted(pins.act_G) and sorted(set(used_D)) == sorted(pins.act_D), "a captured mask found no slot"
+        ref.spectro = lambda audio, _t={id(lr): lr_s, id(hr): hr_s}: (_t[id(audio)].double(), None)
+        losses, _ = ref.forward_losses(lr, hr, pins=pins)
+        ref.netG.zero_grad(); ref.netD.zero_grad()
+        (losses["G_GAN"] + losses["G_GAN_Feat"]).backward(retain_graph=True)
+        gG = {k: p.grad.detach().numpy().copy() for k, p in ref.netG.named_parameters()}
+        ref.netD.zero_grad()
+        ((losses["D_fake"] + losses["D_real"]) * 0.5).backward()
+        gD = {k: p.grad.detach().numpy().copy() for k, p in ref.netD.named_parameters()}
+        l64 = {k: float(v.detach()) for k, v in losses.items()}
+    finally:
+        torch.set_num_threads(threads)
+    bar = PINNED_BAR[fp16]
+    bad, worst, checked, report = [], (0.0, None), 0, {}
+    for k, v in losses_hip.items():
+        if not abs(v - l64[k]) <= (2e-2 if fp16 else 1e-4) * abs(l64[k]):
+            bad.append(("loss " + k, v, l64[k]))
+    for pre, got, want in (("G.", got_G, gG), ("D.", got_D, gD)):
+        for k, g64 in want.items():
+            if dead_bias(k, g64, want):
+                continue
+            assert k in got, pre + k
+            assert np.isfinite(got[k]).all(), pre + k
+            nrm = max(np.linalg.norm(g64), 1e-30)
+            err = float(np.linalg.norm(got[k] - g64) / nrm)
+            report[pre + k] = err
+            checked += 1
+            if err > worst[0]:
+                worst = (err, pre + k)
+            # a one-element gradient (the 64 -> 1 head's bias) is a signed sum that cancels to ~1e-3 of its terms: no averaging
+            if not err <= bar * (8.0 if g64.size == 1 else 1.0):
+                bad.append((pre + k, "rel-L2 %.3e" % err))
+    import json, os
+    rep = os.environ.get("MG_STEP_REPORT")
+    if rep:
+        with open(rep, "a") as f:
+            f.write(json.dumps({"case": "pinned_%s%s_batch%d" % (tag, "_fp16" if fp16 else "", B), "losses": {k: [losses_hip[k], l64[k]] for k in l64},
+                                "grads": report}) + "\n")
+    errs = sorted(report.values())
+    print("mask-pinned full-size step %s%s batch %d: %d gradients, worst rel-L2 %.3e at %s, median %.3e"
+          % (tag, " --fp16" if fp16 else "", B, checked, worst[0], worst[1], errs[len(errs) // 2]))
+    assert not bad, "%d of %d failed (worst %r): %r" % (len(bad), checked, worst, bad[:12])
+    assert checked >= 40, checked
+
+
 def _bench_model(tag, fp16, batch):
     from mdctgan_amd import options
     from mdctgan_amd.pix2pixHD_model import create_model
