@@ -98,6 +98,12 @@ class ArenaReducer:
     def close(self):
         Fh.remove_grad_ready_hook(self._hook)
 
+    def abort(self):
+        """Forget a step that did not finish (a hipGraph capture that failed half way, Pix2PixHDModel.make_step): the handles of
+        its collectives belong to the aborted capture, the bucket counters are mid-step."""
+        self.works, self._unpack = [], []
+        self._reset()
+
     def _split(self, lo, hi):
         """A bucket [lo, hi) is handed out in shards only over its prefix [lo, mid) whose length is a multiple of 8 * world:
         every shard then starts 16-byte aligned in the float32 arenas AND in the float16 shadow (the Adam / scaler kernels
@@ -238,13 +244,17 @@ def check_replicas(flat_p, group=None, what="parameters"):
     replicas drift apart silently."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    d = flat_p.double()
-    mine = torch.stack([d.sum(), (d * d).sum()])
+    # float64 accumulation without a float64 copy of the arena (736 M parameters: 6 GB + 6 GB of temporaries otherwise)
+    mine = torch.stack([flat_p.sum(dtype=torch.float64), torch.linalg.vector_norm(flat_p, ord=2, dtype=torch.float64)])
     ref = mine.clone()
     dist.broadcast(ref, src=0, group=group)
-    bad = (mine != ref).any().float()
-    dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
-    if float(bad) != 0.0:
+    # every rank raises together: [this rank differs from rank 0, this rank's checksum is not finite]
+    flags = torch.stack([(mine != ref).any().float(), (~torch.isfinite(mine)).any().float()])
+    dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
+    if float(flags[1]) != 0.0:      # nan != nan: do not report a blown-up run as divergence
+        raise RuntimeError("data-parallel check: the %s checksum is not finite on at least one rank (rank %d holds %r): the "
+                           "parameters contain inf / nan" % (what, dist.get_rank(group), mine.tolist()))
+    if float(flags[0]) != 0.0:
         raise RuntimeError("data-parallel replicas diverged: the %s checksum of rank %d differs from rank 0's (%r vs %r)"
                            % (what, dist.get_rank(group), mine.tolist(), ref.tolist()))
 
@@ -315,6 +325,10 @@ def attach(model, bucket_bytes=None, group=None):
     every floating-point buffer from rank 0, create the G and D reducers and fold 1/world into the Adam kernels."""
     if bucket_bytes is None:       # MDCTGAN_DDP_BUCKET_MB: bucket size in MiB (default 128)
         bucket_bytes = int(os.environ.get("MDCTGAN_DDP_BUCKET_MB", "128")) << 20
+    if os.environ.get("MDCTGAN_DDP_GRAD_DTYPE", "") == "f16" and getattr(model, "scaler", None) is None:
+        # float16 on the wire overflows at 65504: safe only where a GradScaler checks the reduced arena before Adam (--fp16);
+        # a float32 run would turn |g| > 65504 into inf silently (bf16 keeps float32's range)
+        raise ValueError("MDCTGAN_DDP_GRAD_DTYPE=f16 needs --fp16 (a GradScaler that checks found_inf); use bf16 for float32 runs")
     reducers = {}
     d_writes = 1 if getattr(model, "stack_d_loss_passes", False) else 2    # wgrad launches per D parameter and step
     arena_params = set()

@@ -149,6 +149,10 @@ def conv_fwd_instnorm(g: ConvGeom, x, w, bias=None, act=ACT_NONE, residual=None,
     if PROFILER is not None:
         PROFILER.begin(0, g)
     tiles = _tiles(u, v_out, None, None, TILES_V_FILLED if v_filled else 0)
+    if v_next is not None and y16 is not None:
+        # the two entry points each write ONE of the side outputs (v_next: float32 layers, y16: autocast layers); a caller that
+        # asks for both would get an uninitialised float16 copy attached to the output
+        raise ValueError("conv_fwd_instnorm: v_next and y16 are mutually exclusive")
     if v_next is not None:
         _lib.check(lib.mg_conv_fwd_instnorm_next(g, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y_raw), eps, act,
                                                  _lib.ptr(residual), _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(ws),

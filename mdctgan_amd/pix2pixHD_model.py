@@ -475,7 +475,7 @@ class Pix2PixHDModel(BaseModel):
             if opt_ is not None:
                 opt_.finish_pending()
 
-    def make_graphed_step(self, lr_audio, hr_audio, warmup=3, _ddp_ok=False):
+    def make_graphed_step(self, lr_audio, hr_audio, warmup=3, _ddp_ok=False, _fail_in_capture=False):
         """Capture one full optimize_parameters() iteration (~470 launches: forward, both backward passes, both Adam
         steps) into a hipGraph and return run(lr, hr) -> loss dict, which copies the batch into the captured input
         buffers and replays.  The optimiser clock and learning rate live in HBM, so replays advance Adam exactly
@@ -503,6 +503,8 @@ class Pix2PixHDModel(BaseModel):
         # thread's calls belong to the capture.
         mode = "thread_local" if getattr(self, "reducers", None) else "global"
         with torch.cuda.graph(graph, capture_error_mode=mode):
+            if _fail_in_capture:       # test hook (make_step, MDCTGAN_DDP_GRAPH_FAIL_RANK): after the warm-up steps every rank took part in
+                raise RuntimeError("simulated capture failure (MDCTGAN_DDP_GRAPH_FAIL_RANK)")
             losses = self.optimize_parameters(static_lr, static_hr)
 
         captured = (self.optimizer_G, self.optimizer_D)
@@ -550,10 +552,11 @@ class Pix2PixHDModel(BaseModel):
             raise ValueError("MDCTGAN_DDP_GRAPH must be 0, 1 or auto")
         run, failed = None, 0
         try:
-            fail_rank = os.environ.get("MDCTGAN_DDP_GRAPH_FAIL_RANK")       # test hook: this rank's capture "fails"
-            if fail_rank is not None and dist.is_initialized() and dist.get_rank() == int(fail_rank):
-                raise RuntimeError("simulated capture failure (MDCTGAN_DDP_GRAPH_FAIL_RANK)")
-            run = self.make_graphed_step(lr_audio, hr_audio, warmup=warmup, _ddp_ok=True)
+            # test hook: this rank's capture "fails" -- AFTER the warm-up iterations (real training steps whose bucket all-reduces
+            # every rank must take part in), where a real capture error would strike
+            fail_rank = os.environ.get("MDCTGAN_DDP_GRAPH_FAIL_RANK")
+            fail_here = fail_rank is not None and dist.is_initialized() and (fail_rank == "all" or dist.get_rank() == int(fail_rank))
+            run = self.make_graphed_step(lr_audio, hr_audio, warmup=warmup, _ddp_ok=True, _fail_in_capture=fail_here)
         except Exception as e:      # noqa: BLE001 -- whatever the capture raised, the decision is collective
             failed = 1
             print("[mdctgan_amd] hipGraph capture of the data-parallel step failed on this rank (%s): asking every rank to step "
@@ -563,7 +566,15 @@ class Pix2PixHDModel(BaseModel):
             dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=red["G"].group)
             failed = int(flag.item())
         if failed:
+            # EVERY rank drops what the attempt left behind before its first eager step -- the rank whose capture broke holds
+            # collective handles of the aborted capture and half-counted buckets, the others a graph nobody will replay
             run = None
+            torch.cuda.synchronize()
+            for r in red.values():
+                r.abort()
+            for opt_ in (self.optimizer_G, self.optimizer_D):
+                opt_._pending = None
+                opt_.resync_shadow()
             return eager
         return run
 

@@ -364,3 +364,67 @@ def test_shard_spans_are_aligned_at_every_world_size(world, monkeypatch):
             assert hi - mid < 8 * world and (mid - lo) % (8 * world) == 0
             assert (cover[lo:mid] == 1).all() and (cover[mid:hi] == world).all()
         red.close()
+
+
+def _replica_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mdctgan_amd import ddp
+    g = torch.Generator().manual_seed(3)
+    flat = torch.randn(100003, generator=g)
+    ddp.check_replicas(flat, None, "agreeing")                      # identical arenas: silent on every rank
+    out = {}
+    # one element differs on the last rank by one ulp: EVERY rank raises (the decision is a MAX all-reduce), naming divergence
+    div = flat.clone()
+    if rank == world - 1:
+        div[77] = torch.nextafter(div[77], torch.tensor(float("inf")))
+    try:
+        ddp.check_replicas(div, None, "diverging")
+        out["div"] = "silent"
+    except RuntimeError as e:
+        out["div"] = str(e)
+    # a non-finite arena (the same nan on every rank: nan != nan) is reported as non-finite, not as divergence
+    bad = flat.clone()
+    bad[5] = float("nan")
+    try:
+        ddp.check_replicas(bad, None, "blown-up")
+        out["nan"] = "silent"
+    except RuntimeError as e:
+        out["nan"] = str(e)
+    # ... and so is an inf on one rank only
+    one = flat.clone()
+    if rank == 0:
+        one[9] = float("inf")
+    try:
+        ddp.check_replicas(one, None, "one-rank-inf")
+        out["inf"] = "silent"
+    except RuntimeError as e:
+        out["inf"] = str(e)
+    torch.save(out, os.path.join(out_dir, "rep%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_check_replicas_agreement_divergence_and_non_finite(tmp_path, world):
+    """ddp.check_replicas (on by default for the first data-parallel steps): silent when every rank holds rank 0's arena,
+    raises ON EVERY RANK when one rank differs by one ulp in one element, and reports inf / nan checksums as such (nan != nan
+    must not read as "diverged").  Checksums are float64 accumulations over the float32 arena without a float64 copy."""
+    port = _free_port()
+    mp.spawn(_replica_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        out = torch.load(os.path.join(str(tmp_path), "rep%d.pt" % r))
+        assert "diverged" in out["div"] and "diverging" in out["div"], (r, out["div"])
+        assert "not finite" in out["nan"] and "diverged" not in out["nan"], (r, out["nan"])
+        assert "not finite" in out["inf"], (r, out["inf"])
+
+
+def test_f16_wire_needs_a_gradscaler(monkeypatch):
+    """MDCTGAN_DDP_GRAD_DTYPE=f16 in a float32 run (no GradScaler, nothing checks found_inf before Adam) is refused at
+    attach(); bf16 keeps float32's exponent range and is accepted (the refusal happens before any arena is touched)."""
+    from mdctgan_amd import ddp
+
+    class _M:
+        scaler = None
+    monkeypatch.setenv("MDCTGAN_DDP_GRAD_DTYPE", "f16")
+    with pytest.raises(ValueError, match="needs --fp16"):
+        ddp.attach(_M())

@@ -126,14 +126,15 @@ def test_capture_failure_on_any_rank_makes_every_rank_step_eagerly(one_rank_grou
     monkeypatch.setenv("MDCTGAN_DDP_GRAPH_FAIL_RANK", "0")
     a, b = _model(), _model()
     ddp.attach(a)
-    run = a.make_step(lr, hr, warmup=2)
+    run = a.make_step(lr, hr, warmup=2)          # two warm-up steps (real training steps), then the capture "fails" on rank 0
     assert run.graph is None
+    assert all(r.works == [] and r._unpack == [] and r.pending == list(r._bucket_writes) for r in a.reducers.values())
     for _ in range(3):
         run(lr, hr)
     for r in a.reducers.values():
         r.close()
     ddp.attach(b)
-    for _ in range(3):
+    for _ in range(2 + 3):
         b.optimize_parameters(lr, hr)
     torch.cuda.synchronize()
     for (k, x), (_, y) in zip(a.netG.state_dict().items(), b.netG.state_dict().items()):
@@ -339,6 +340,51 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path, mode, sync_bn):
     dD = (r0["pD"] - single.optimizer_D.flat_p.cpu()).abs()
     if sync_bn:
         assert dD.max().item() <= 2 * 2e-4 + 1e-6
+
+
+def _fallback_worker(rank, world, port, out_dir, auto):
+    """Two processes on ONE GPU over gloo: make_step under MDCTGAN_DDP_GRAPH=auto with the capture failing on EVERY rank after the
+    warm-up steps (a gloo collective cannot be captured, so no rank may enter one inside a capture here), against plain eager
+    data-parallel steps."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    if auto:
+        os.environ["MDCTGAN_DDP_GRAPH"], os.environ["MDCTGAN_DDP_GRAPH_FAIL_RANK"] = "auto", "all"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mdctgan_amd import ddp
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g6_step_global.npz"))
+    lr, hr = torch.from_numpy(g["lr"]).cuda()[rank:rank + 1], torch.from_numpy(g["hr"]).cuda()[rank:rank + 1]
+    m = _model(batch=1)
+    ddp.attach(m)
+    if auto:
+        run = m.make_step(lr, hr, warmup=2)
+        assert run.graph is None
+        assert all(r.works == [] and r._unpack == [] and r.pending == list(r._bucket_writes) for r in m.reducers.values())
+    else:
+        run = m.optimize_parameters
+        for _ in range(2):
+            run(lr, hr)
+    for _ in range(3):
+        ld = run(lr, hr)
+    m._finish_pending()
+    torch.cuda.synchronize()
+    assert m.ddp_check_steps == 0            # check_replicas ran after each of the first three steps (2 ranks: really compared)
+    torch.save({"pG": m.optimizer_G.flat_p.cpu(), "pD": m.optimizer_D.flat_p.cpu(), "losses": {k: v.item() for k, v in ld.items()}},
+               os.path.join(out_dir, "%s%d.pt" % ("auto" if auto else "eager", rank)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_capture_fallback_equals_eager_steps(tmp_path):
+    """with 2 ranks the fallback of make_step(MDCTGAN_DDP_GRAPH=auto) must leave every rank where plain eager
+    data-parallel steps leave it -- the failing ranks take part in the warm-up steps' bucket all-reduces (the failure is simulated
+    inside the capture, after them), the "it failed here" MAX all-reduce pairs up, and every reducer is reset before the first
+    eager step.  ddp.check_replicas compares the two ranks' arenas after each of the first three steps on the way."""
+    import torch.multiprocessing as mp
+    for auto in (True, False):
+        mp.spawn(_fallback_worker, args=(2, _free_port(), str(tmp_path), auto), nprocs=2, join=True)
+    a0, a1, e0 = (torch.load(os.path.join(str(tmp_path), n)) for n in ("auto0.pt", "auto1.pt", "eager0.pt"))
+    assert torch.equal(a0["pG"], a1["pG"]) and torch.equal(a0["pD"], a1["pD"])
+    assert torch.equal(a0["pG"], e0["pG"]) and torch.equal(a0["pD"], e0["pD"]) and a0["losses"] == e0["losses"]
 
 
 def _run_bench(*argv, env=None, timeout=900):
