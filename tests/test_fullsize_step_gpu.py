@@ -397,9 +397,14 @@ def hip_masks(model, tap):
 
 # Mask-pinned bars (relative L2 per parameter against the float64 oracle evaluated on the HIP forward's own sign decisions).
 # float32: the two backward passes are the same linear map; what is left is float32 rounding of the forward values and of the
-# kernels' sums (Winograd included).  --fp16: the float64 leg keeps unrounded weights / activations, the HIP leg rounds both to
-# float16 at every autocast convolution (relative 2^-11 per element) -- the bar is that rounding, not a sign lottery.
-PINNED_BAR = {False: 1e-4, True: 2e-1}
+# kernels' sums (Winograd included).  Measured (profiles/r06_pinned_step_parity.txt): configs[1] batch 8 worst 1.6e-5 (the CPU
+# oracle's own float32 run on the same decisions: 1.5e-5); configs[2] batch 8 6e-5 / one 1-element bias 1.2e-4 (CPU 9e-5);
+# configs[2] batch 2 4.0e-4 (CPU 2.4e-4: BatchNorm over 64 tokens and InstanceNorm over 4 x 8 maps amplify forward rounding).
+# Bar: max(1e-4, 3 x the CPU float32 yardstick of that parameter) -- a 1 % kernel bug is 20 x above either.
+# --fp16: float16 arithmetic itself is 0.14 (median) / 0.46-0.70 (stem) from float64 at batch 2 even with the decisions shared --
+# HIP 0.144 / 0.46, the reference's arithmetic (the oracle under CPU autocast, same decisions) 0.189 / 0.70 -- so the float64
+# oracle is no 1e-4 target there; the bar is the reference's own error on the same decisions: <= 1.25 x yardstick + 2e-2.
+PINNED_BAR = {False: 1e-4, True: 2e-2}
 
 
 @pytest.mark.parametrize("tag,fp16,batch", [("configs1", False, 8), ("configs2", False, 2), ("configs2", False, 8), ("configs2", True, 2)],
@@ -485,11 +490,9 @@ def test_full_size_step_gradients_mask_pinned(tag, fp16, batch):
     try:
         torch.set_num_threads(min(64, threads))
         l64, gG, gD = pinned_gradients(torch.float64)
-        # (the CPU-autocast yardstick of the --fp16 case is a diagnostic: minutes of float16 convolutions on the host)
-        yard = None
-        if not fp16 or os.environ.get("MG_PINNED_FP16_YARDSTICK", "0") == "1":
-            _, yG, yD = pinned_gradients(torch.float32, amp=fp16)
-            yard = {"G.": yG, "D.": yD}
+        # yardstick: the oracle's own float32 evaluation (--fp16: under CPU autocast, the reference's arithmetic; ~1 min at batch 2)
+        _, yG, yD = pinned_gradients(torch.float32, amp=fp16)
+        yard = {"G.": yG, "D.": yD}
     finally:
         torch.set_num_threads(threads)
     bar = PINNED_BAR[fp16]
@@ -505,7 +508,7 @@ def test_full_size_step_gradients_mask_pinned(tag, fp16, batch):
             assert np.isfinite(got[k]).all(), pre + k
             nrm = max(np.linalg.norm(g64), 1e-30)
             err = float(np.linalg.norm(got[k] - g64) / nrm)
-            e_y = float(np.linalg.norm(yard[pre][k] - g64) / nrm) if yard is not None else 0.0
+            e_y = float(np.linalg.norm(yard[pre][k] - g64) / nrm)
             report[pre + k] = err
             yreport[pre + k] = e_y
             checked += 1
@@ -513,8 +516,9 @@ def test_full_size_step_gradients_mask_pinned(tag, fp16, batch):
                 worst = (err, pre + k, e_y)
             # a one-element gradient (the 64 -> 1 head's bias) is a signed sum that cancels to ~1e-3 of its terms: no averaging.
             # The bar: rounding (1e-4) -- or, where float32 arithmetic itself is further from float64 on this graph with
-            # the decisions shared (the yardstick), 2 x that.
-            if not err <= max(bar * (8.0 if g64.size == 1 else 1.0), 2.0 * e_y):
+            # the decisions shared (the yardstick), 3 x that; --fp16: 1.25 x the reference arithmetic's own error + 2e-2.
+            ok = (err <= 1.25 * e_y + bar) if fp16 else (err <= max(bar * (8.0 if g64.size == 1 else 1.0), 3.0 * e_y))
+            if not ok:
                 bad.append((pre + k, "rel-L2 %.3e" % err, "CPU yardstick on the same decisions %.3e" % e_y))
     import json
     rep = os.environ.get("MG_STEP_REPORT")
