@@ -44,7 +44,9 @@ extern "C" {
 #define MG_ACT_TANH 3
 
 /* 3 since mg_mdct4_forward / mg_imdct4_forward take the factored DCT-IV image (dct4_image) in the middle of their argument lists: a
-   caller built against an older header must see a different number here before it passes `codec` where a pointer is expected */
+   caller built against an older header must see a different number here before it passes `codec` where a pointer is expected.
+   4 (round 6): mg_grad_seg / mg_scaler_check_segs / mg_adam_step_segs / mg_conv_wgrad_h16 added; mg_conv_wgrad_chk's found_inf
+   test uses float16's overflow criterion (|v| >= 65520), as the --fp16 optimiser passes do. */
 int mg_abi_version(void);
 /* sizeof(mg_conv_geom) as the library was built (13 ints = 52 bytes): a binding checks its own struct against it */
 int mg_conv_geom_size(void);
@@ -278,6 +280,14 @@ int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, floa
 int mg_conv_wgrad_checks_finite(const mg_conv_geom* g);
 int mg_conv_wgrad_chk(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias, int accumulate,
                       void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* tiles, float* found_inf);
+/* Round 6: the same weight gradient STORED as float16 (dw16: Co * KH * KW * Ci halves, OHWI) -- the dtype an autocast layer's
+ * weight gradient has in the reference (train.py:161-164).  Only where mg_conv_wgrad_h16_ok(g) != 0 (the short-reduction GEMM
+ * of the weight-streaming trunk layers, whose 151 MB float32 output stream is what bounds it); found_inf (nullable) as above,
+ * with float16's overflow criterion; accumulate adds into the float16 values.  No bias gradient (those layers' biases feed an
+ * InstanceNorm: identically zero). */
+int mg_conv_wgrad_h16_ok(const mg_conv_geom* g);
+int mg_conv_wgrad_h16(const mg_conv_geom* g, const float* x, const float* dy, void* dw16, int accumulate, void* workspace,
+                      size_t workspace_bytes, void* stream, float* found_inf);
 /* Round 3 (single process, float32): the weight side of a Winograd F(2x2,3x3) layer in one pass.  Instead of writing dw,
  * the call applies torch.optim.Adam's update (pix2pixHD_model.py:350-351) to (w, m, v) straight from the Winograd-domain
  * gradient and leaves u = G w G^T of the UPDATED weights (mg_conv_wino_weights_bytes(g) bytes) for the next forward:
@@ -476,6 +486,31 @@ int mg_adam_step_amp(float* p, const float* g, float* m, float* v, long long n, 
  * instead of by one cast launch per layer.  A skipped step (found_inf) leaves p and p16 untouched. */
 int mg_adam_step_h(float* p, const float* g, float* m, float* v, void* p16, long long n, const double* state, float beta1,
                    float beta2, float eps, float grad_scale, const float* scaler, int slot, void* stream);
+
+/* Round 6 -- the --fp16 optimiser passes over a SEGMENTED gradient arena (train.py:161-164, 183-199).  Under torch.autocast a
+ * convolution's weight / bias gradient is a float16 tensor (the cast's backward widens it into the float32 .grad): its values are
+ * float16-rounded and overflow at 65504 -- which is what the reference's GradScaler backs off on.  A segment = a run of the arena
+ * [off, off + n) (multiples of 8 elements; device array `segs`) and how its gradient is carried:
+ *   MG_GRAD_F32       float32 in g, used as stored (BatchNorm and position-embedding parameters: float32 in the reference too)
+ *   MG_GRAD_AUTOCAST  float32 in g, rounded through float16 where it is consumed: finite iff |v| < 65520, Adam reads half(v)
+ *   MG_GRAD_F16       float16 in g16 at the same element index, written by mg_conv_wgrad_h16 (half the bytes in both passes)
+ * skip_check != 0: the producing kernel already ran the inf / nan test on this segment (mg_conv_wgrad_h16 / mg_conv_wgrad_chk).
+ * mg_scaler_check_segs == mg_scaler_check, mg_adam_step_segs == mg_adam_step_h (p16 nullable), one launch each over all
+ * segments; n_total (sum of the lengths) sizes the grid. */
+#define MG_GRAD_F32 0
+#define MG_GRAD_AUTOCAST 1
+#define MG_GRAD_F16 2
+typedef struct {
+    long long off;
+    long long n;
+    int mode;
+    int skip_check;
+} mg_grad_seg;
+int mg_scaler_check_segs(const float* g, const void* g16, const mg_grad_seg* segs, int nsegs, long long n_total, float* scaler,
+                         int slot, void* stream);
+int mg_adam_step_segs(float* p, const float* g, const void* g16, float* m, float* v, void* p16, const mg_grad_seg* segs, int nsegs,
+                      long long n_total, const double* state, float beta1, float beta2, float eps, float grad_scale,
+                      const float* scaler, int slot, void* stream);
 
 #ifdef __cplusplus
 }

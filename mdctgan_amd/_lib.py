@@ -153,12 +153,17 @@ SIGNATURES = {
     "mg_adam_tick_amp": (_i, [_p, _f, _f, _p, _i, _p]),
     "mg_adam_step_amp": (_i, [_p, _p, _p, _p, _ll, _p, _f, _f, _f, _f, _p, _i, _p]),
     "mg_adam_step_h": (_i, [_p, _p, _p, _p, _p, _ll, _p, _f, _f, _f, _f, _p, _i, _p]),
+    "mg_scaler_check_segs": (_i, [_p, _p, _p, _i, _ll, _p, _i, _p]),
+    "mg_adam_step_segs": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _ll, _p, _f, _f, _f, _f, _p, _i, _p]),
+    "mg_conv_wgrad_h16_ok": (_i, [C.POINTER(ConvGeom)]),
+    "mg_conv_wgrad_h16": (_i, [C.POINTER(ConvGeom), _p, _p, _p, _i, _p, _sz, _p, _p]),
 }
 
 _lib = None
 
 
-ABI_VERSION = 3       # include/mdctgan_hip.h: mg_abi_version (3: dct4_image in mg_mdct4_forward / mg_imdct4_forward)
+ABI_VERSION = 4       # include/mdctgan_hip.h: mg_abi_version (4: segmented --fp16 optimiser passes, float16-stored weight gradients)
+GRAD_F32, GRAD_AUTOCAST, GRAD_F16 = 0, 1, 2      # mg_grad_seg.mode
 
 
 def load():

@@ -296,8 +296,9 @@ inline bool h16_wgrad_as(const mg_conv_geom* g) {
     const long long M = (long long)g->B * g->OH * g->OW;
     return on && hgemm_as_ok(g->Co, g->KH * g->KW * g->Ci, h16_mp(M));
 }
+// dw16 != NULL (only with h16_wgrad_as(g)): the gradient is stored as float16 there and dw is not touched
 int h16_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate, char* ws, hipStream_t st,
-              float* found_inf) {
+              float* found_inf, void* dw16 = nullptr) {
     const long long M = (long long)g->B * g->OH * g->OW;
     const int Mp = h16_mp(M), N = g->KH * g->KW * g->Ci;
     const H16Plan p = h16_plan(g->Co, N, Mp, false);
@@ -316,11 +317,13 @@ int h16_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw,
     }
     if (h16_wgrad_as(g)) {
         probe_begin(st);
-        hgemm_as_launch(dyt, xct, dw, g->Co, N, Mp, accumulate, found_inf, st);
+        if (dw16) hgemm_as_launch(dyt, xct, dw16, g->Co, N, Mp, accumulate, found_inf, st, true);
+        else hgemm_as_launch(dyt, xct, dw, g->Co, N, Mp, accumulate, found_inf, st);
         probe_end(st);
         MG_CHECK_LAUNCH();
         return MG_OK;
     }
+    if (dw16) return MG_ERR_UNSUPPORTED;
     HgArgs a{};
     a.A = dyt; a.B = xct; a.C = dw; a.part = p.splits > 1 ? part : nullptr;
     a.M = g->Co; a.N = N; a.K = Mp; a.lda = Mp; a.ldb = Mp; a.splits = p.splits; a.cps = p.cps;

@@ -2411,7 +2411,7 @@ __attribute__((visibility("hidden"))) size_t mg_conv_rowdot_wgrad_workspace(cons
 __attribute__((visibility("hidden"))) int mg_conv_rowdot_wgrad(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias,
                          int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
-int mg_abi_version(void) { return 3; }
+int mg_abi_version(void) { return 4; }
 int mg_conv_geom_size(void) { return (int)sizeof(mg_conv_geom); }
 
 void mg_probe_arm(void* e0, void* e1) {
@@ -3062,6 +3062,15 @@ int mg_conv_wgrad_w(const mg_conv_geom* g, const float* x, const float* dy, floa
 }
 int mg_conv_wgrad_checks_finite(const mg_conv_geom* g) {
     return (geom_ok(g) && !co1_gemm_ok(g) && !mg_conv_rowdot_kq(g) && h16_ok(g) && h16_wgrad_as(g)) ? 1 : 0;
+}
+int mg_conv_wgrad_h16_ok(const mg_conv_geom* g) { return mg_conv_wgrad_checks_finite(g); }
+int mg_conv_wgrad_h16(const mg_conv_geom* g, const float* x, const float* dy, void* dw16, int accumulate, void* workspace,
+                      size_t workspace_bytes, void* stream, float* found_inf) {
+    if (!geom_ok(g) || !dw16 || !x || !dy) return MG_ERR_ARG;
+    if (!mg_conv_wgrad_h16_ok(g)) return MG_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < mg_conv_wgrad_workspace(g)) return MG_ERR_ARG;
+    if (!aligned16(x) || !aligned16(dy) || !aligned16(dw16) || !aligned16(workspace)) return MG_ERR_ARG;
+    return h16_wgrad(g, x, dy, nullptr, accumulate, (char*)workspace, (hipStream_t)stream, found_inf, dw16);
 }
 int mg_conv_wgrad_chk(const mg_conv_geom* g, const float* x, const float* dy, float* dw, float* dbias, int accumulate,
                       void* workspace, size_t workspace_bytes, void* stream, const mg_wino_tiles* wt, float* found_inf) {

@@ -264,18 +264,24 @@ inline void hgemm_launch(const HgArgs& a0, hipStream_t st) {
 // LW dedicated loader waves.  The loaders are the only waves that count vmcnt -- the eight MFMA waves' global stores (32 per tile
 // and lane) would otherwise sit in the same counter and every "chunk landed" wait would also drain the stores of the tile before.
 // NBUF buffers of 16 KiB: NBUF - 1 chunks (112 KiB at 8) in flight per CU, one workgroup per CU.
-// `flag` (optional): set to 1.0f when a result is not finite -- the GradScaler's inf / nan check (scaler_check_kernel) done on
-// the accumulators, which saves a second pass over the largest gradients of the model.
+// `flag` (optional): set to 1.0f when a result is not a finite float16 (|v| >= 65520 rounds to inf) -- the GradScaler's inf / nan
+// check done on the accumulators, which saves a second pass over the largest gradients of the model.  The results are an autocast
+// layer's weight gradient: float16 values in the reference (the cast's backward widens them into the float32 .grad), so float16
+// is both the overflow criterion and -- H16 instances -- the storage format (round 6: half the output stream, which is what
+// bounds this kernel, and 2 bytes fewer per parameter in the Adam pass).
 struct HgAsArgs {
     const void* A;           // float16 [M][K]   (lda = K)
     const void* B;           // float16 [N][K]   (ldb = K)
-    float* C;                // float32 [M][N]
+    void* C;                 // [M][N] float32, or float16 (H16 instances)
     float* flag;
     int M, N, groups, accumulate;
 };
 constexpr int HG_AS_NBUF = 8, HG_AS_LW = 2;
 
-template <int KC, bool ACC>  // K = 64 KC; ACC: C += result
+__device__ __forceinline__ float hg_swap_adjacent(float v) {      // the value of lane ^ 1 (DPP quad_perm [1, 0, 3, 2])
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+template <int KC, bool ACC, bool H16 = false>  // K = 64 KC; ACC: C += result; H16: C is float16
 __global__ __launch_bounds__(64 * (8 + HG_AS_LW)) void hgemm_as_kernel(HgAsArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NBUF = HG_AS_NBUF, LW = HG_AS_LW, AHEAD = NBUF - 1, BSZ = 128 * 32, K = 64 * KC;
@@ -373,14 +379,36 @@ __global__ __launch_bounds__(64 * (8 + HG_AS_LW)) void hgemm_as_kernel(HgAsArgs 
             c = 0;
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
-                float* o = g.C + (size_t)(m0 + 32 * wm) * g.N + (size_t)t * 128 + wn0 + 32 * ni + r;
+                if constexpr (H16) {
+                    // float16 store: a lane holds one column and 16 rows, so adjacent lanes trade one value per row pair and every
+                    // lane stores 4 bytes -- even lanes row rr of columns (r, r + 1), odd lanes row rr + 1 of (r - 1, r): 64-byte
+                    // runs, half the store instructions of the float32 form
+                    _Float16* o = (_Float16*)g.C + (size_t)(m0 + 32 * wm) * g.N + (size_t)t * 128 + wn0 + 32 * ni + (r & ~1);
+                    const bool odd = lane & 1;
 #pragma unroll
-                for (int rr = 0; rr < 16; ++rr) {
-                    float v = acc[ni][rr];
-                    float* p = o + (size_t)mfma32_row(rr, lane) * g.N;
-                    if constexpr (ACC) v += *p;
-                    bad |= !(fabsf(v) <= 3.4028234663852886e38f);
-                    *p = v;
+                    for (int rr = 0; rr < 16; rr += 2) {
+                        const float v0 = acc[ni][rr], v1 = acc[ni][rr + 1];
+                        const float got = hg_swap_adjacent(odd ? v0 : v1);
+                        float lo = odd ? got : v0, hi = odd ? v1 : got;
+                        unsigned* p = reinterpret_cast<unsigned*>(o + (size_t)mfma32_row(odd ? rr + 1 : rr, lane) * g.N);
+                        if constexpr (ACC) {
+                            const unsigned old = *p;
+                            lo += (float)__builtin_bit_cast(_Float16, (unsigned short)(old & 0xffffu));
+                            hi += (float)__builtin_bit_cast(_Float16, (unsigned short)(old >> 16));
+                        }
+                        bad |= !(fabsf(lo) < 65520.0f) | !(fabsf(hi) < 65520.0f);
+                        *p = pack_h2(lo, hi);
+                    }
+                } else {
+                    float* o = (float*)g.C + (size_t)(m0 + 32 * wm) * g.N + (size_t)t * 128 + wn0 + 32 * ni + r;
+#pragma unroll
+                    for (int rr = 0; rr < 16; ++rr) {
+                        float v = acc[ni][rr];
+                        float* p = o + (size_t)mfma32_row(rr, lane) * g.N;
+                        if constexpr (ACC) v += *p;
+                        bad |= !(fabsf(v) < 65520.0f);          // the float16 criterion (see HgAsArgs): the consumer rounds through float16
+                        *p = v;
+                    }
                 }
                 acc[ni] = f32x16{0};
             }
@@ -395,22 +423,29 @@ inline bool hgemm_as_ok(long long M, int N, int K) {
     return M % 128 == 0 && N % 128 == 0 && (K == 64 || K == 128 || K == 192 || K == 256) && M / 128 <= 256 &&
            (long long)N * K * 2 < (1ll << 32);
 }
-template <int KC, bool ACC>
+template <int KC, bool ACC, bool H16>
 inline void hgemm_as_go2(const HgAsArgs& a, int grid, hipStream_t st) {
     constexpr size_t lds = (size_t)HG_AS_NBUF * 128 * 32 * 4;
     static bool once = false;
     if (!once) {
-        hipFuncSetAttribute((const void*)hgemm_as_kernel<KC, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)hgemm_as_kernel<KC, ACC, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         once = true;
     }
-    mg_launch(hgemm_as_kernel<KC, ACC>, dim3((unsigned)grid), dim3(64 * (8 + HG_AS_LW)), lds, st, a);
+    mg_launch(hgemm_as_kernel<KC, ACC, H16>, dim3((unsigned)grid), dim3(64 * (8 + HG_AS_LW)), lds, st, a);
 }
 template <int KC>
-inline void hgemm_as_go(const HgAsArgs& a, int grid, hipStream_t st) {
-    if (a.accumulate) hgemm_as_go2<KC, true>(a, grid, st);
-    else hgemm_as_go2<KC, false>(a, grid, st);
+inline void hgemm_as_go(const HgAsArgs& a, int grid, hipStream_t st, bool h16) {
+    if (h16) {
+        if (a.accumulate) hgemm_as_go2<KC, true, true>(a, grid, st);
+        else hgemm_as_go2<KC, false, true>(a, grid, st);
+    } else {
+        if (a.accumulate) hgemm_as_go2<KC, true, false>(a, grid, st);
+        else hgemm_as_go2<KC, false, false>(a, grid, st);
+    }
 }
-inline void hgemm_as_launch(const void* A, const void* B, float* C, long long M, int N, int K, int accumulate, float* flag, hipStream_t st) {
+// C: float32 [M][N], or float16 when c_half
+inline void hgemm_as_launch(const void* A, const void* B, void* C, long long M, int N, int K, int accumulate, float* flag, hipStream_t st,
+                            bool c_half = false) {
     HgAsArgs a{A, B, C, flag, (int)M, N, 1, accumulate};
     const int tiles_m = (int)(M / 128), tiles_n = N / 128;
     int groups = 256 / tiles_m;                              // one workgroup per CU ...
@@ -419,9 +454,9 @@ inline void hgemm_as_launch(const void* A, const void* B, float* C, long long M,
     if (const char* f = getenv("MG_HGEMM_AS_GROUPS")) { const int v = atoi(f); if (v >= 1 && v <= tiles_n) groups = v; }
     a.groups = groups;
     switch (K / 64) {
-        case 1: hgemm_as_go<1>(a, tiles_m * groups, st); break;
-        case 2: hgemm_as_go<2>(a, tiles_m * groups, st); break;
-        case 3: hgemm_as_go<3>(a, tiles_m * groups, st); break;
-        default: hgemm_as_go<4>(a, tiles_m * groups, st); break;
+        case 1: hgemm_as_go<1>(a, tiles_m * groups, st, c_half); break;
+        case 2: hgemm_as_go<2>(a, tiles_m * groups, st, c_half); break;
+        case 3: hgemm_as_go<3>(a, tiles_m * groups, st, c_half); break;
+        default: hgemm_as_go<4>(a, tiles_m * groups, st, c_half); break;
     }
 }

@@ -815,6 +815,104 @@ __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__
         }
 }
 
+// ---- --fp16 optimiser passes over a SEGMENTED arena (round 6) ----------------------------------------------------------
+// Under torch.autocast a convolution's weight / bias gradient is a float16 tensor (the cast's backward widens it into the
+// float32 .grad, train.py:161-164, 183-199): its values are float16-rounded and it overflows at 65504.  Segments say how a run of
+// the arena carries that: MG_GRAD_F32 (BatchNorm / position-embedding parameters: float32 in the reference too), MG_GRAD_AUTOCAST
+// (float32 storage, rounded through float16 where it is consumed -- here), MG_GRAD_F16 (stored as float16 in g16 by its own
+// weight-gradient kernel: mg_conv_wgrad_h16).  Offsets / lengths are multiples of 8 elements.
+typedef _Float16 seg_h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float seg_round_h(float v) { return (float)(_Float16)v; }
+template <int MODE>
+__device__ __forceinline__ void adam_seg_span(float* __restrict__ p, const float* __restrict__ g, const _Float16* __restrict__ g16,
+                                              float* __restrict__ m, float* __restrict__ v, _Float16* __restrict__ p16, size_t n4,
+                                              float step_size, float bc2_sqrt, float b1, float b2, float eps, float gscale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 pv = *reinterpret_cast<float4*>(p + 4 * i), mv = *reinterpret_cast<float4*>(m + 4 * i),
+               vv = *reinterpret_cast<float4*>(v + 4 * i);
+        float gg[4];
+        if (MODE == MG_GRAD_F16) {
+            const seg_h4 h = *reinterpret_cast<const seg_h4*>(g16 + 4 * i);
+            gg[0] = (float)h[0]; gg[1] = (float)h[1]; gg[2] = (float)h[2]; gg[3] = (float)h[3];
+        } else {
+            const float4 gv = *reinterpret_cast<const float4*>(g + 4 * i);
+            gg[0] = gv.x; gg[1] = gv.y; gg[2] = gv.z; gg[3] = gv.w;
+            if (MODE == MG_GRAD_AUTOCAST) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gg[j] = seg_round_h(gg[j]);
+            }
+        }
+        float* pp = reinterpret_cast<float*>(&pv); float* mm = reinterpret_cast<float*>(&mv); float* vp = reinterpret_cast<float*>(&vv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gi = gg[j] * gscale;
+            const float mi = mm[j] + (gi - mm[j]) * (1.0f - b1);
+            const float vi = vp[j] * b2 + (1.0f - b2) * gi * gi;
+            mm[j] = mi; vp[j] = vi;
+            pp[j] = pp[j] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        }
+        *reinterpret_cast<float4*>(p + 4 * i) = pv;
+        *reinterpret_cast<float4*>(m + 4 * i) = mv;
+        *reinterpret_cast<float4*>(v + 4 * i) = vv;
+        if (p16) {
+            const seg_h4 hv = {(_Float16)pp[0], (_Float16)pp[1], (_Float16)pp[2], (_Float16)pp[3]};
+            *reinterpret_cast<seg_h4*>(p16 + 4 * i) = hv;
+        }
+    }
+}
+__global__ void adam_seg_kernel(float* __restrict__ p, const float* __restrict__ g, const _Float16* __restrict__ g16,
+                                float* __restrict__ m, float* __restrict__ v, _Float16* __restrict__ p16,
+                                const mg_grad_seg* __restrict__ segs, int nsegs, const double* __restrict__ state, float b1,
+                                float b2, float eps, float gscale, const float* __restrict__ loss_scale,
+                                const float* __restrict__ found_inf) {
+    if (found_inf && *found_inf != 0.0f) return;          // GradScaler.step: skip the update on inf / nan gradients
+    if (loss_scale) gscale = gscale / *loss_scale;        // unscale
+    const float step_size = (float)state[2], bc2_sqrt = (float)state[3];
+    for (int s = 0; s < nsegs; ++s) {
+        const size_t off = (size_t)segs[s].off, n4 = (size_t)segs[s].n / 4;
+        const int mode = segs[s].mode;
+        _Float16* h = p16 ? p16 + off : nullptr;
+        if (mode == MG_GRAD_F16)
+            adam_seg_span<MG_GRAD_F16>(p + off, g + off, g16 + off, m + off, v + off, h, n4, step_size, bc2_sqrt, b1, b2, eps, gscale);
+        else if (mode == MG_GRAD_AUTOCAST)
+            adam_seg_span<MG_GRAD_AUTOCAST>(p + off, g + off, g16, m + off, v + off, h, n4, step_size, bc2_sqrt, b1, b2, eps, gscale);
+        else
+            adam_seg_span<MG_GRAD_F32>(p + off, g + off, g16, m + off, v + off, h, n4, step_size, bc2_sqrt, b1, b2, eps, gscale);
+    }
+}
+// GradScaler's inf / nan test per segment: float32 -> finite; autocast -> a finite float16 after rounding (|v| < 65520); float16
+// storage -> exponent bits.  Segments with skip_check != 0 were checked by the kernel that produced them.
+__global__ __launch_bounds__(256) void scaler_check_seg_kernel(const float* __restrict__ g, const _Float16* __restrict__ g16,
+                                                               const mg_grad_seg* __restrict__ segs, int nsegs,
+                                                               float* __restrict__ flag) {
+    bool bad = false;
+    for (int s = 0; s < nsegs; ++s) {
+        if (segs[s].skip_check) continue;
+        const size_t off = (size_t)segs[s].off, n = (size_t)segs[s].n;
+        const int mode = segs[s].mode;
+        if (mode == MG_GRAD_F16) {
+            const size_t n8 = n / 8;
+            for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+                const uint4 q = *reinterpret_cast<const uint4*>(g16 + off + 8 * i);
+                const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bad |= ((w[j] & 0x7c00u) == 0x7c00u) | ((w[j] & 0x7c000000u) == 0x7c000000u);
+            }
+        } else {
+            const float lim = mode == MG_GRAD_AUTOCAST ? 65520.0f : 3.4028234663852886e38f;
+            const size_t n4 = n / 4;
+            for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+                const float4 q = *reinterpret_cast<const float4*>(g + off + 4 * i);
+                if (mode == MG_GRAD_AUTOCAST)
+                    bad |= !(fabsf(q.x) < lim) | !(fabsf(q.y) < lim) | !(fabsf(q.z) < lim) | !(fabsf(q.w) < lim);
+                else
+                    bad |= !(fabsf(q.x) <= lim) | !(fabsf(q.y) <= lim) | !(fabsf(q.z) <= lim) | !(fabsf(q.w) <= lim);
+            }
+        }
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) *flag = 1.0f;     // every writer stores the same value
+}
+
 inline unsigned grid_for(size_t n, int per_thread = 1) {
     size_t b = (n + 256 * (size_t)per_thread - 1) / (256 * (size_t)per_thread);
     if (b > 4096) b = 4096;
@@ -1223,6 +1321,29 @@ int mg_adam_step_h(float* p, const float* g, float* m, float* v, void* p16, long
     hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for((size_t)n, 8)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
                        (size_t)n, state, beta1, beta2, eps, grad_scale, scaler, scaler ? scaler + 2 + slot : (const float*)nullptr,
                        (_Float16*)p16);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+static bool segs_ok(const mg_grad_seg* segs, int nsegs) { return segs && nsegs > 0 && nsegs <= 4096; }
+int mg_scaler_check_segs(const float* g, const void* g16, const mg_grad_seg* segs, int nsegs, long long n_total, float* scaler,
+                         int slot, void* stream) {
+    if (!g || !scaler || !segs_ok(segs, nsegs) || n_total <= 0 || slot < 0 || slot >= MG_SCALER_SLOTS || !al16(g) || (g16 && !al16(g16)))
+        return MG_ERR_ARG;
+    hipLaunchKernelGGL(scaler_check_seg_kernel, dim3(grid_for((size_t)n_total, 16)), dim3(256), 0, (hipStream_t)stream, g,
+                       (const _Float16*)g16, segs, nsegs, scaler + 2 + slot);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+int mg_adam_step_segs(float* p, const float* g, const void* g16, float* m, float* v, void* p16, const mg_grad_seg* segs, int nsegs,
+                      long long n_total, const double* state, float beta1, float beta2, float eps, float grad_scale,
+                      const float* scaler, int slot, void* stream) {
+    if (!p || !g || !m || !v || !state || !segs_ok(segs, nsegs) || n_total <= 0) return MG_ERR_ARG;
+    if (scaler && (slot < 0 || slot >= MG_SCALER_SLOTS)) return MG_ERR_ARG;
+    if (!al16(p) || !al16(g) || !al16(m) || !al16(v) || (p16 && !al16(p16)) || (g16 && !al16(g16))) return MG_ERR_ARG;
+    hipLaunchKernelGGL(adam_seg_kernel, dim3(grid_for((size_t)n_total, 8)), dim3(256), 0, (hipStream_t)stream, p, g,
+                       (const _Float16*)g16, m, v, (_Float16*)p16, segs, nsegs, state, beta1, beta2, eps, grad_scale, scaler,
+                       scaler ? scaler + 2 + slot : (const float*)nullptr);
     MG_CHECK_LAUNCH();
     return MG_OK;
 }

@@ -264,6 +264,8 @@ def attach_optimizer(opt, writes_per_step=1, bucket_bytes=128 << 20, group=None)
     kernel.  Returns the reducer (also used by Pix2PixHDModel.update_fixed_params when it replaces optimizer_G)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     slices = opt.arena_slices()
+    if hasattr(opt, "disable_g16"):
+        opt.disable_g16()      # the reducer reads the float32 gradient arena: no float16-stored gradients under data parallelism
     broadcast_arena(opt.flat_p, 0, group)
     opt.resync_shadow()        # --fp16: the float16 shadow was cast from the PRE-broadcast weights (ADVICE r2, medium)
     n_params = sum(n for _, _, n in slices)

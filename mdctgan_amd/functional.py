@@ -122,6 +122,31 @@ def grad_buffer(p: torch.nn.Parameter):
     return p.grad, (not fresh)
 
 
+def grad_buffer16(p: torch.nn.Parameter):
+    """(float16 buffer, accumulate?) of a parameter whose gradient is STORED as float16 (FusedAdam GRAD_F16, --fp16): the same
+    fresh / accumulate bookkeeping as grad_buffer; p.grad (the float32 arena view) is not written -- read gradients through grad_of."""
+    fresh = getattr(p, "_mg_fresh", True)
+    p._mg_fresh = False
+    p._mg_inf_checked = False
+    return p._mg_g16, (not fresh)
+
+
+def grad_of(p: torch.nn.Parameter):
+    """The gradient the last backward pass left for p, as a float32 tensor shaped like p: p.grad, or -- where the weight-gradient
+    kernel stores float16 (the reference's dtype for an autocast layer's gradient) -- that buffer widened."""
+    opt = getattr(p, "_mg_opt", None)
+    if opt is not None and getattr(p, "_mg_g16", None) is not None:
+        return opt.grad_of(p)
+    return p.grad
+
+
+def _tag_g16(g, weight, bias, weight_grad):
+    """Remember (before the optimiser lays out its arenas) that this weight's gradient kernel can store float16."""
+    if (g.precision == _lib.PRECISION_F16 and weight_grad is True and weight.requires_grad
+            and not hasattr(weight, "_mg_g16_ok")):
+        weight._mg_g16_ok = bool(ops.wgrad_h16_ok(g))
+
+
 def mark_fresh(params):
     """zero_grad without a memset: the next wgrad kernel overwrites instead of accumulating."""
     for p in params:
@@ -369,6 +394,7 @@ class _ConvFn(torch.autograd.Function):
             Co, Ci = w.shape[0], w.shape[1]
             assert Ci == x.shape[1]
             g = ops.conv_geom(B, H, W, Ci, Co, KH, KW, stride, pad, reflect, amp.current_precision())
+            _tag_g16(g, weight, bias, weight_grad)
             # Winograd layers: transform the weights once, reuse the image for the data gradient of this step
             if ctx.needs_input_grad[0]:
                 u = _weight_image(g, weight, weight_grad)
@@ -473,6 +499,34 @@ def _conv_backward(ctx, gy, x, y):
                 _notify(bias)
             ctx.v = None
             want_dw = False
+    if want_dw and not transposed and getattr(weight, "_mg_g16", None) is not None:
+        # --fp16, FusedAdam GRAD_F16: the kernel stores the gradient as float16 (and runs the GradScaler's check on it)
+        w16, wacc = grad_buffer16(weight)
+        if bias is not None and bias.requires_grad:
+            if getattr(bias, "_mg_zero_grad", False) and not COMPUTE_DEAD_BIAS_GRADS:
+                _zero_grad_bias(bias)
+            else:
+                bbuf, bacc = grad_buffer(bias)
+                ops.colsum(nhwc_view(gy).reshape(-1, g.Co), bbuf, bacc)
+        flag = _producer_flag(weight, g)
+        if ops.wgrad_h16_ok(g):
+            ops.conv_wgrad_h16(g, nhwc_view(x), nhwc_view(gy), w16, wacc, found_inf=flag)
+            weight._mg_inf_checked = flag is not None
+        else:
+            # another geometry than the one the arena was laid out for (a batch the float16-storing kernel does not take): the
+            # float32 kernel, then one cast into the float16 slot the optimiser reads
+            tmp = torch.empty(weight.numel(), dtype=torch.float32, device=gy.device)
+            ops.conv_wgrad(g, nhwc_view(x), nhwc_view(gy), tmp, None, False)
+            if wacc:
+                w16.add_(tmp)
+            else:
+                w16.copy_(tmp)
+            weight._mg_inf_checked = False
+        ctx.v = None
+        _notify(weight)
+        if bias is not None and bias.requires_grad:
+            _notify(bias)
+        want_dw = False
     if want_dw:
         wbuf, wacc = grad_buffer(weight)
         bbuf = bacc = None
@@ -533,6 +587,7 @@ class _ConvInstNormFn(torch.autograd.Function):
         w = weight.detach()
         assert w.is_contiguous(memory_format=CL), "conv weights must be channels_last (OHWI) tensors"
         g = ops.conv_geom(B, H, W, w.shape[1], w.shape[0], w.shape[2], w.shape[3], 1, pad, reflect, amp.current_precision())
+        _tag_g16(g, weight, bias, weight_grad)
         if ctx.needs_input_grad[0]:
             u = _weight_image(g, weight, weight_grad)
         elif x.is_cuda and not torch.is_grad_enabled():

@@ -189,7 +189,14 @@ class FusedModule(nn.Module):
 # net.{b}.net.3.pos_emb.{height,width}).  Third-party arithmetic, parity UNPINNED.
 ###############################################################################
 class BatchNorm2d(nn.BatchNorm2d):
-    """nn.BatchNorm2d executed by the HIP batch-norm kernel (training statistics + running buffers)."""
+    """nn.BatchNorm2d executed by the HIP batch-norm kernel (training statistics + running buffers).  Its affine parameters stay
+    float32 under torch.autocast (batch_norm keeps float32 weights), so do their gradients: `_mg_grad_f32` tells FusedAdam
+    (--fp16) not to round them through float16 like the convolutions' gradients."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        for prm in self.parameters():
+            prm._mg_grad_f32 = True
 
     def forward(self, x, act: int = ACT_NONE, residual=None):
         return Fh.batch_norm_act(x, self, act, residual)
@@ -202,6 +209,8 @@ class AbsPosEmb(nn.Module):
         scale = dim_head ** -0.5
         self.height = nn.Parameter(torch.randn(height, dim_head) * scale)
         self.width = nn.Parameter(torch.randn(width, dim_head) * scale)
+        # float32 sums of the (float16) embedding gradient over the broadcast axis under autocast: not float16 values
+        self.height._mg_grad_f32 = self.width._mg_grad_f32 = True
 
 
 class Attention(nn.Module):

@@ -225,6 +225,28 @@ def wgrad_checks_finite(g: ConvGeom) -> bool:
     return hit
 
 
+def wgrad_h16_ok(g: ConvGeom) -> bool:
+    """True when the layer's weight gradient can be STORED as float16 by its own kernel (mg_conv_wgrad_h16: the weight-streaming
+    trunk layers under --fp16)."""
+    key = ("wh", g.B, g.H, g.W, g.Ci, g.Co, g.KH, g.KW, g.stride, g.pad, g.reflect, g.precision)
+    hit = _CASTS.get(key)
+    if hit is None:
+        hit = _CASTS[key] = bool(_lib.load().mg_conv_wgrad_h16_ok(g))
+    return hit
+
+
+def conv_wgrad_h16(g: ConvGeom, x, dy, dw16, accumulate=False, found_inf=None):
+    """dw16: float16 buffer of Co*KH*KW*Ci elements in OHWI order (written / accumulated in place); found_inf as in conv_wgrad."""
+    lib = _lib.load()
+    ws = _ws(lib.mg_conv_wgrad_workspace(g), dw16.device)
+    if PROFILER is not None:
+        PROFILER.begin(2, g)
+    _lib.check(lib.mg_conv_wgrad_h16(g, _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw16), int(accumulate), _lib.ptr(ws), ws.numel(),
+                                     _lib.stream(), _lib.ptr(found_inf)), "mg_conv_wgrad_h16")
+    if PROFILER is not None:
+        PROFILER.end()
+
+
 def wgrad_adam_ok(g: ConvGeom) -> bool:
     """True when the layer's weight gradient can run as mg_conv_wgrad_adam_w (Winograd F(2x2,3x3), float32)."""
     key = ("wa", g.B, g.H, g.W, g.Ci, g.Co, g.KH, g.KW, g.stride, g.pad, g.reflect, g.precision)
@@ -487,6 +509,26 @@ def adam_step_h(p, g, m, v, p16, state, beta1, beta2, eps, grad_scale, scaler=No
     _lib.check(lib.mg_adam_step_h(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), _lib.ptr(p16), p.numel(),
                                   _lib.ptr(state), beta1, beta2, eps, grad_scale, _lib.ptr(scaler), slot, _lib.stream()),
                "mg_adam_step_h")
+    _stream_probe_end(tok)
+
+
+def scaler_check_segs(g, g16, segs, nsegs, n_total, nbytes, scaler, slot):
+    """mg_scaler_check over a segmented arena (segs: uint8 device tensor holding nsegs mg_grad_seg records)."""
+    lib = _lib.load()
+    tok = _stream_probe("scaler_check_seg_kernel", nbytes)
+    _lib.check(lib.mg_scaler_check_segs(_lib.ptr(g), _lib.ptr(g16), _lib.ptr(segs), nsegs, n_total, _lib.ptr(scaler), slot,
+                                        _lib.stream()), "mg_scaler_check_segs")
+    _stream_probe_end(tok)
+
+
+def adam_step_segs(p, g, g16, m, v, p16, segs, nsegs, n_total, nbytes, state, beta1, beta2, eps, grad_scale, scaler=None, slot=0):
+    """mg_adam_step_h over a segmented arena: one launch, per-segment gradient source (float32 / float32 rounded through float16 /
+    float16 storage).  nbytes: the launch's algorithmic HBM bytes (for bench.py's probe)."""
+    lib = _lib.load()
+    tok = _stream_probe("adam_seg_kernel", nbytes)
+    _lib.check(lib.mg_adam_step_segs(_lib.ptr(p), _lib.ptr(g), _lib.ptr(g16), _lib.ptr(m), _lib.ptr(v), _lib.ptr(p16), _lib.ptr(segs),
+                                     nsegs, n_total, _lib.ptr(state), beta1, beta2, eps, grad_scale, _lib.ptr(scaler), slot,
+                                     _lib.stream()), "mg_adam_step_segs")
     _stream_probe_end(tok)
 
 

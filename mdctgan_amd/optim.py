@@ -9,8 +9,12 @@ float32 arena that holds every parameter, its gradient and both moments contiguo
 """
 from __future__ import annotations
 
+import os
+
+import numpy as np
 import torch
 
+from . import _lib
 from . import functional as Fh
 from . import ops
 
@@ -44,6 +48,13 @@ class FusedAdam(torch.optim.Optimizer):
         self.half_shadow = bool(half_shadow)
         self.flat_h = None
         self._scaler_flag = None       # GradScaler.state[2 + slot : 3 + slot] once a scaler has stepped this optimiser
+        # --fp16 (round 6): how each parameter's gradient is carried (mg_grad_seg.mode, include/mdctgan_hip.h) -- an autocast
+        # layer's weight / bias gradient is a float16 tensor in the reference (train.py:161-164), so it is rounded through float16
+        # where it is consumed (GRAD_AUTOCAST) or stored as float16 by its own kernel (GRAD_F16, flat_g16); BatchNorm and
+        # position-embedding parameters stay float32 (GRAD_F32: they are float32 under torch.autocast too)
+        self.flat_g16 = None
+        self._modes = None
+        self._seg_cache = {}
 
     # -- arena ---------------------------------------------------------------------------------
     def _build(self):
@@ -92,7 +103,82 @@ class FusedAdam(torch.optim.Optimizer):
                     # flat views in arena (= OHWI memory) order; valid while the parameter's version counter stands still
                     # (the Adam kernel writes both through raw pointers, which does not move it)
                     p._mg_h, p._mg_flat, p._mg_h_version = self.flat_h[off:off + n], self.flat_p[off:off + n], p._version
+                self._modes = []
+                store16 = os.environ.get("MG_NO_G16", "0") != "1"
+                for p in ps:
+                    if getattr(p, "_mg_grad_f32", False):
+                        self._modes.append(_lib.GRAD_F32)
+                    elif store16 and getattr(p, "_mg_g16_ok", False):
+                        self._modes.append(_lib.GRAD_F16)
+                    else:
+                        self._modes.append(_lib.GRAD_AUTOCAST)
+                if _lib.GRAD_F16 in self._modes:
+                    # same element index as the float32 arenas; only the GRAD_F16 parameters' slices are ever touched
+                    self.flat_g16 = torch.zeros(total, dtype=torch.float16, device=dev)
+                    for p, off, mode in zip(ps, offs, self._modes):
+                        p._mg_g16 = self.flat_g16[off:off + p.numel()] if mode == _lib.GRAD_F16 else None
         self._built = True
+
+    def disable_g16(self):
+        """Gradients back into the float32 arena (a data-parallel reducer reads flat_g: ddp.attach_optimizer calls this)."""
+        if self.flat_g16 is None:
+            return
+        for i, p in enumerate(self._params):
+            if self._modes[i] == _lib.GRAD_F16:
+                self._modes[i] = _lib.GRAD_AUTOCAST
+            p._mg_g16 = None
+        self.flat_g16 = None
+        self._seg_cache = {}
+
+    def grad_of(self, p):
+        """The gradient of p as a float32 tensor shaped like p -- p.grad, or the widened float16-stored gradient."""
+        g16 = getattr(p, "_mg_g16", None)
+        if g16 is None:
+            return p.grad
+        return _arena_view(g16.float(), 0, p)
+
+    def _segments(self, kinds, spans):
+        """(device table of mg_grad_seg records, count, elements, bytes moved by Adam, any unchecked) for this step's live
+        parameters: runs of equal (mode, skip_check) over the stepped parameters, cut to `spans`.  Cached per live set -- the table
+        a captured step reads was made by its eager warm-up iterations."""
+        ps = self._params
+        flags = tuple((k != 0, bool(getattr(p, "_mg_inf_checked", False)) and self.shard is None) for k, p in zip(kinds, ps))
+        key = (flags, tuple(spans))
+        hit = self._seg_cache.get(key)
+        if hit is not None:
+            return hit
+        runs = []          # [lo, hi, mode, skip]
+        n = len(ps)
+        for i, p in enumerate(ps):
+            if kinds[i] == 0:
+                continue
+            lo = self.offsets[i]
+            hi = self.total if i + 1 == n else self.offsets[i + 1]
+            mode = self._modes[i]
+            zero = bool(getattr(p, "_mg_known_zero", False))
+            skip = int(flags[i][1] or zero)        # an exactly-zero bias gradient needs no look
+            if runs and runs[-1][1] == lo and runs[-1][2] == mode and (runs[-1][3] == skip or zero):
+                runs[-1][1] = hi
+            else:
+                runs.append([lo, hi, mode, skip])
+        segs = []
+        for lo, hi, mode, skip in runs:
+            for a, b in spans:
+                x, y = max(lo, a), min(hi, b)
+                if x < y:
+                    segs.append((x, y - x, mode, skip))
+        rec = np.zeros(len(segs), dtype=np.dtype([("off", "<i8"), ("n", "<i8"), ("mode", "<i4"), ("skip", "<i4")]))
+        for j, sg in enumerate(segs):
+            rec[j] = sg
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the set of stepped parameters changed inside a graph capture: run one eager step with it first")
+        table = torch.from_numpy(rec.view(np.uint8).copy()).to(self.flat_p.device) if len(segs) else None
+        n_total = sum(sg[1] for sg in segs)
+        # p, m, v read + written (24), float16 shadow written (2), gradient read (4 or 2)
+        nbytes = sum(sg[1] * (26 + (2 if sg[2] == _lib.GRAD_F16 else 4)) for sg in segs)
+        check_bytes = sum(sg[1] * (2 if sg[2] == _lib.GRAD_F16 else 4) for sg in segs if not sg[3])
+        hit = self._seg_cache[key] = (table, len(segs), n_total, nbytes, check_bytes)
+        return hit
 
     @torch.no_grad()
     def resync_shadow(self):
@@ -200,6 +286,24 @@ class FusedAdam(torch.optim.Optimizer):
             spans.append((lo, hi))
         if self.shard is not None:
             spans = self.shard.restrict(spans)         # reduce-scattered gradients: only this rank's shards are complete
+        if self._modes is not None:
+            # --fp16: one segmented launch each for the GradScaler's check and the update (see __init__)
+            table, nsegs, n_total, nbytes, check_bytes = self._segments(kinds, spans)
+            if scaler_state is None:
+                ops.adam_tick(self.state, b1, b2)
+            else:
+                if nsegs and check_bytes:
+                    ops.scaler_check_segs(self.flat_g, self.flat_g16, table, nsegs, n_total, check_bytes, scaler_state, scaler_slot)
+                self._scaler_flag = scaler_state[2 + scaler_slot:3 + scaler_slot]
+                if self.shard is not None:
+                    self.shard.agree(scaler_state[2 + scaler_slot:3 + scaler_slot])
+                ops.adam_tick_amp(self.state, b1, b2, scaler_state, scaler_slot)
+            if nsegs:
+                ops.adam_step_segs(self.flat_p, self.flat_g, self.flat_g16, self.flat_m, self.flat_v, self.flat_h, table, nsegs,
+                                   n_total, nbytes, self.state, b1, b2, eps, self.grad_scale, scaler_state, scaler_slot)
+            if self.shard is not None:
+                self._pending = self.shard.gather(self.flat_p)
+            return None
         if scaler_state is None:
             ops.adam_tick(self.state, b1, b2)
         else:

@@ -459,3 +459,106 @@ def test_producer_written_float16_copies_change_nothing(monkeypatch):
     for a, b in ((g_on, g_off), (d_on, d_off)):
         for k in a:
             assert torch.equal(a[k], b[k]), k
+
+
+def test_weight_gradient_stored_as_float16_is_the_rounded_float32_one():
+    """mg_conv_wgrad_h16 (round 6): the trunk's short-reduction weight-gradient GEMM storing float16 -- the dtype an autocast
+    layer's weight gradient has in the reference (train.py:161-164) -- writes exactly half(what mg_conv_wgrad_chk writes), accumulates
+    in float16 storage with a float32 add, and flags a result that is not a finite float16 (|v| >= 65520), which is also the
+    criterion of the float32-storing instance now."""
+    from mdctgan_amd import _lib, ops
+    B, H, W, C = 8, 4, 8, 256
+    g = ops.conv_geom(B, H, W, C, C, 3, 3, 1, 1, True, _lib.PRECISION_F16)
+    assert ops.wgrad_h16_ok(g) and not ops.wgrad_h16_ok(ops.conv_geom(B, H, W, C, C, 3, 3, 1, 1, True, _lib.PRECISION_F32))
+    gen = torch.Generator().manual_seed(3)
+    xd = nhwc(torch.randn(B, C, H, W, generator=gen)).to(DEV)
+    dyd = nhwc(torch.randn(B, C, H, W, generator=gen)).to(DEV)
+    dw = torch.empty(C, 3, 3, C, device=DEV)
+    flag = torch.zeros(1, device=DEV)
+    ops.conv_wgrad(g, xd, dyd, dw, None, found_inf=flag)
+    dw16 = torch.full((C, 3, 3, C), float("nan"), dtype=torch.float16, device=DEV)
+    ops.conv_wgrad_h16(g, xd, dyd, dw16, False, found_inf=flag)
+    assert flag.item() == 0.0 and torch.equal(dw16, dw.half())
+    ops.conv_wgrad_h16(g, xd, dyd, dw16, True, found_inf=flag)                  # += in float32, rounded once
+    assert flag.item() == 0.0 and torch.equal(dw16, (dw.half().float() + dw).half())
+    # a result beyond float16's range: inf in the float16 store, flagged by BOTH instances (the float32 one keeps the finite value)
+    big = dyd * 4096.0
+    ops.conv_wgrad(g, xd, big, dw, None, found_inf=flag)
+    assert torch.isfinite(dw).all() and dw.abs().max().item() > 65520.0 and flag.item() == 1.0
+    flag.zero_()
+    ops.conv_wgrad_h16(g, xd, big, dw16, False, found_inf=flag)
+    assert flag.item() == 1.0 and torch.equal(dw16, dw.half()) and torch.isinf(dw16).any()
+    # a geometry the float16-storing kernel does not take is refused
+    g2 = ops.conv_geom(2, 32, 64, 64, 64, 3, 3, 2, 1, False, _lib.PRECISION_F16)
+    with pytest.raises(RuntimeError):
+        ops.conv_wgrad_h16(g2, torch.zeros(2, 32, 64, 64, device=DEV), torch.zeros(2, 16, 32, 64, device=DEV),
+                           torch.zeros(64, 3, 3, 64, dtype=torch.float16, device=DEV), False)
+
+
+def test_segmented_fp16_optimizer_passes():
+    """FusedAdam(half_shadow=True) (--fp16, round 6): one segmented launch per pass (mg_scaler_check_segs / mg_adam_step_segs) in
+    which every run of the arena carries its gradient the way the reference's autocast does -- convolution parameters as float16
+    VALUES (float32 storage rounded through float16 where consumed, or float16 storage written by the weight-gradient kernel),
+    BatchNorm / position-embedding parameters as float32 -- against torch.optim.Adam on those very gradients; the overflow
+    criterion follows: 70 000 is inf for an autocast gradient and a number for a float32 one; a skipped step touches nothing."""
+    from mdctgan_amd import _lib, amp
+    from mdctgan_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    shapes = [(64, 3, 3, 32), (64,), (40,), (128, 1, 1, 64), (24,), (16, 8)]
+    ps = [torch.nn.Parameter(torch.randn(*sh, device=DEV)) for sh in shapes]
+    ps[2]._mg_grad_f32 = True          # a BatchNorm weight
+    ps[5]._mg_grad_f32 = True          # a position embedding
+    ps[3]._mg_g16_ok = True            # a weight whose gradient kernel stores float16
+    opt = FusedAdam(ps, lr=1e-2, betas=(0.5, 0.999), half_shadow=True)
+    refs = [p.detach().clone().cpu().requires_grad_() for p in ps]
+    ref_opt = torch.optim.Adam(refs, lr=1e-2, betas=(0.5, 0.999))
+    sc = amp.GradScaler(init_scale=256.0, growth_interval=1000)
+    opt.zero_grad()
+    assert opt._modes == [_lib.GRAD_AUTOCAST, _lib.GRAD_AUTOCAST, _lib.GRAD_F32, _lib.GRAD_F16, _lib.GRAD_AUTOCAST, _lib.GRAD_F32]
+    assert ps[3]._mg_g16 is not None and ps[3]._mg_g16.dtype == torch.float16 and ps[0]._mg_g16 is None
+    gen = torch.Generator().manual_seed(1)
+    for it in range(5):
+        opt.zero_grad()
+        scale = sc.get_scale()
+        overflow_autocast, big_f32 = it == 1, it == 3
+        grads = [torch.randn(*sh, generator=gen) * 3.0 for sh in shapes]
+        if big_f32:
+            grads[2][7] = 70000.0 / scale * 1.0            # x scale = 70 000: finite as a float32 gradient
+        scaled = [g * scale for g in grads]
+        if overflow_autocast:
+            scaled[0].view(-1)[11] = 70000.0                # ... and inf as a float16 one
+        before = [p.detach().clone() for p in ps]
+        for p, g_ in zip(ps, scaled):
+            if getattr(p, "_mg_g16", None) is not None:
+                p._mg_g16.copy_(g_.reshape(-1).half().to(DEV))
+            else:
+                p.grad.copy_(g_.to(DEV))
+            p._mg_fresh = False
+        sc.step(opt)
+        sc.update()
+        if overflow_autocast:
+            assert sc.get_scale() == scale * 0.5 and all(torch.equal(p.detach(), b) for p, b in zip(ps, before))
+            assert opt.state[0].item() == it               # the clock did not tick
+            continue
+        assert sc.get_scale() == scale
+        ref_opt.zero_grad()
+        for r, g_, p in zip(refs, scaled, ps):
+            seen = g_ if getattr(p, "_mg_grad_f32", False) else g_.half().float()      # what the reference's .grad holds
+            r.grad = seen / scale
+        ref_opt.step()
+        for p, r in zip(ps, refs):
+            assert (p.detach().cpu() - r.detach()).abs().max().item() < 2e-6
+        assert torch.equal(opt.flat_h, opt.flat_p.half())
+        got = opt.grad_of(ps[3])
+        assert got.shape == ps[3].shape and torch.equal(got.reshape(-1), ps[3]._mg_g16.float())
+    # MG_NO_G16-style fallback: the same parameters with float32 storage give the same update bit for bit (rounded where consumed)
+    a = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    a[3]._mg_g16_ok = True
+    oa, ob = FusedAdam(a, lr=1e-2, betas=(0.5, 0.999), half_shadow=True), FusedAdam(b, lr=1e-2, betas=(0.5, 0.999), half_shadow=True)
+    oa.zero_grad(); ob.zero_grad()
+    g3 = torch.randn(*shapes[3], generator=gen) * 100.0
+    a[3]._mg_g16.copy_(g3.reshape(-1).half().to(DEV)); a[3]._mg_fresh = False
+    b[3].grad.copy_(g3.to(DEV)); b[3]._mg_fresh = False
+    oa.step(); ob.step()
+    assert torch.equal(a[3].detach(), b[3].detach()) and torch.equal(oa.flat_m, ob.flat_m) and torch.equal(oa.flat_v, ob.flat_v)

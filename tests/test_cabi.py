@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for s in header_symbols():
         assert hasattr(lib, s), s
-    assert _lib.load().mg_abi_version() == 3 == _lib.ABI_VERSION
+    assert _lib.load().mg_abi_version() == 4 == _lib.ABI_VERSION
     # ... and nothing else: every exported mg_* symbol is declared (library-internal cross-file helpers are hidden)
     import shutil
     import subprocess

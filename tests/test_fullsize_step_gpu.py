@@ -121,10 +121,13 @@ def _snapshot(net):
     return {k: v.detach().clone() for k, v in net.state_dict().items()}
 
 
-# --fp16 over several iterations: a loss scale at which NEITHER leg overflows on these weights (the oracle's float16 gradients
-# overflow at 1024 and 512 -- measured: 1024 -> 512 -> 256 over its first two iterations; the HIP step keeps float32 gradients
-# between layers and survives 1024), so that both take three real Adam steps and the scale trajectories can be required equal
-AMP_SCALE = 128.0
+# --fp16 over several iterations, from a loss scale at which the REFERENCE's arithmetic overflows on these weights: under autocast a
+# convolution's weight gradient is a float16 tensor, and at scale 1024 the 7 x 7 stem's (model.1.weight, 22 elements up to 98 000)
+# exceeds 65504 in the oracle's CPU-autocast run -- GradScaler skips the generator's step and halves the scale (train.py:183-199);
+# at 512 everything is finite.  Round 6: the HIP step applies the same criterion (float16 rounding of autocast gradients where they
+# are consumed / stored: FusedAdam's gradient segments), so the two loss-scale trajectories must be EQUAL from here -- back-off
+# included -- where rounds 3-5 had to start both legs at 128 because float32-kept gradients survived 1024.
+AMP_SCALE = 1024.0
 
 
 @pytest.mark.parametrize("tag,fp16,feat,batch,n_steps",
@@ -210,9 +213,9 @@ def test_full_size_step_gradients(tag, fp16, feat, batch, n_steps, monkeypatch):
     model = build()
     scale = 1.0
     if fp16:
-        # a scale at which float16-rounded gradients stay finite on these weights (the default 65536 backs off on the first
-        # iterations, as in the reference -- tests/test_amp_gpu.py pins that behaviour; here the step must NOT be skipped)
-        scale = 1024.0 if n_steps == 1 else AMP_SCALE
+        # one iteration: a scale at which float16-rounded gradients stay finite on these weights (the step must NOT be skipped);
+        # three iterations: AMP_SCALE, where the first generator step IS skipped in both legs (see above)
+        scale = 128.0 if n_steps == 1 else AMP_SCALE
         model.scaler.state[0] = scale
     lr_d, hr_d = lr.to(DEV), hr.to(DEV)
 
@@ -236,23 +239,33 @@ def test_full_size_step_gradients(tag, fp16, feat, batch, n_steps, monkeypatch):
     ld = model.optimize_parameters(lr_d, hr_d)
     # (--no_ganFeat_loss: the discriminator is built without intermediate outputs and the step keeps its three passes)
     assert model._shared_rows == (B if feat else 0), "the bench's shared discriminator pass must be the path under test"
-    if fp16:
+    if fp16 and n_steps == 1:
         assert model.scaler.get_scale() == scale, "the AMP step was skipped (inf gradients): nothing to compare"
+    elif fp16:
+        assert ref_scales[0] == 0.5 * AMP_SCALE, "the oracle's first iteration was expected to overflow at this scale"
+        assert model.scaler.get_scale() == ref_scales[0], ("loss scale after iteration 1 (HIP, oracle)", model.scaler.get_scale(), ref_scales[0])
     rtol = 2e-2 if fp16 else 1e-4
     bad = []
     for k, v in ld.items():
         e32 = abs(l32[k] - l64[k])
         if not abs(v.item() - l64[k]) <= rtol * abs(l64[k]) + 4 * e32:
             bad.append(("loss " + k, v.item(), l64[k], l32[k]))
-    checked, worst, report = 0, (0.0, None), {}
+    checked, worst, report, overflowed = 0, (0.0, None), {}, []
     d_back = {d_key(k): k for k in sdD}          # the product discriminator's key -> the oracle's
     for net, g64, g32, pre in ((model.netG, gG64, gG32, "G."), (model.netD, gD64, gD32, "D.")):
         for k, p in net.named_parameters():
             k = d_back[k] if pre == "D." else k
             if dead_bias(k, g64[k], g64):
                 continue
-            assert p.grad is not None, pre + k
-            got = p.grad.detach().double().cpu().numpy() / scale
+            from mdctgan_amd import functional as Fh
+            assert Fh.grad_of(p) is not None, pre + k
+            got = Fh.grad_of(p).detach().double().cpu().numpy() / scale
+            if fp16 and not np.isfinite(g32[k]).all():
+                # the reference's float16 gradient of this parameter overflowed at this scale (the skipped step): the HIP gradient,
+                # rounded through float16 as its optimiser pass consumes it, must overflow too
+                assert not np.isfinite((got * scale).astype(np.float16)).all(), pre + k + ": the reference overflows here, HIP does not"
+                overflowed.append(pre + k)
+                continue
             assert np.isfinite(got).all(), pre + k
             nrm = max(np.linalg.norm(g64[k]), 1e-30)
             e_hip = np.linalg.norm(got - g64[k]) / nrm
@@ -296,8 +309,9 @@ def test_full_size_step_gradients(tag, fp16, feat, batch, n_steps, monkeypatch):
         if fp16:
             # the GradScaler's trajectory (train.py:183-199: step skipped and scale halved on inf / nan): equal, and no step skipped --
             # otherwise the update comparison below would compare different numbers of Adam steps
-            steps_report["scales"] = [hip_scales, ref_scales]
-            assert hip_scales == ref_scales == [AMP_SCALE] * n_steps, ("loss-scale trajectories (HIP, oracle)", hip_scales, ref_scales)
+            steps_report["scales"] = [hip_scales, ref_scales, overflowed]
+            assert hip_scales == ref_scales, ("loss-scale trajectories (HIP, oracle)", hip_scales, ref_scales)
+            assert overflowed and ref_scales[-1] == ref_scales[0], "expected exactly one back-off (iteration 1), then real steps"
         else:
             fused = [p for p in trunk if getattr(p, "_mg_u_persist", None) is not None]
             assert len(fused) >= 18, "the trunk layers did not take the fused weight-gradient + Adam path (%d of %d)" % (len(fused), len(trunk))
@@ -407,16 +421,25 @@ def hip_masks(model, tap):
 PINNED_BAR = {False: 1e-4, True: 2e-2}
 
 
-@pytest.mark.parametrize("tag,fp16,batch", [("configs1", False, 8), ("configs2", False, 2), ("configs2", False, 8), ("configs2", True, 2)],
-                         ids=["configs1_f32_batch8", "configs2_f32_batch2", "configs2_f32_batch8", "configs2_fp16_batch2"])
-def test_full_size_step_gradients_mask_pinned(tag, fp16, batch):
+@pytest.mark.parametrize("tag,fp16,batch,force_plan",
+                         [("configs1", False, 8, None), ("configs1", False, 8, "64,64,3"), ("configs2", False, 2, None), ("configs2", False, 8, None),
+                          ("configs2", True, 2, None)],
+                         ids=["configs1_f32_batch8", "configs1_f32_batch8_replanned", "configs2_f32_batch2", "configs2_f32_batch8",
+                              "configs2_fp16_batch2"])
+def test_full_size_step_gradients_mask_pinned(tag, fp16, batch, force_plan, monkeypatch):
     """train.py:160-202's two backward passes at full size, EVERY gradient against the float64 oracle evaluated on the HIP
     forward's own ReLU / LeakyReLU masks, sign(fake - real) of the feature loss and sign(s) of the discriminator input
     (oracle/step.py::MaskPins).  The statistical test above compares two independent float evaluations, whose masks differ where
     a pre-activation is within rounding of zero (0.4-1.8 % of a gradient's norm, a different draw for every change of any
     kernel's summation order); with the decisions shared the bar is rounding itself: 1e-4, and a 1 % kernel bug
     is two orders of magnitude above it.  configs[2] at batch 2 / 8: the bottleneck-transformer BatchNorm's cross-sample
-    statistics and the multi-slice sum kernels at full width (networks.py:232-235)."""
+    statistics and the multi-slice sum kernels at full width (networks.py:232-235).
+    force_plan ("bm,bn,splits" -> MG_FORCE_CONV_DMA): every LDS-DMA ladder convolution of the step, forward and weight gradient, on
+    another tile and K-split -- the kind of re-association of forward sums that moved all 26 generator gradients of the
+    statistical test from 6e-3 to 1.75e-2 in round 5 (one flipped LeakyReLU mask in the discriminators) and made it fail.  With the
+    decisions shared the re-planned step must sit at the same 1e-5 as the committed plans: summation order is not a parity risk."""
+    if force_plan:
+        monkeypatch.setenv("MG_FORCE_CONV_DMA", force_plan)
     from mdctgan_amd import functional as Fh
     from mdctgan_amd import options
     from mdctgan_amd.pix2pixHD_model import create_model
@@ -459,8 +482,8 @@ def test_full_size_step_gradients_mask_pinned(tag, fp16, batch):
     if fp16:
         assert model.scaler.get_scale() == scale, "the AMP step was skipped (inf gradients): nothing to compare"
     pins = hip_masks(model, tap)
-    got_G = {k: p.grad.detach().double().cpu().numpy() / scale for k, p in model.netG.named_parameters() if p.grad is not None}
-    got_D = {k: p.grad.detach().double().cpu().numpy() / scale for k, p in model.netD.named_parameters() if p.grad is not None}
+    got_G = {k: Fh.grad_of(p).detach().double().cpu().numpy() / scale for k, p in model.netG.named_parameters() if p.grad is not None}
+    got_D = {k: Fh.grad_of(p).detach().double().cpu().numpy() / scale for k, p in model.netD.named_parameters() if p.grad is not None}
     losses_hip = {k: v.item() for k, v in ld.items()}
     del model, tap
     torch.cuda.empty_cache()
@@ -588,3 +611,41 @@ def test_bench_step_replay_equals_eager(tag, fp16, monkeypatch):
         for oa, ob in ((eager.optimizer_G, other.optimizer_G), (eager.optimizer_D, other.optimizer_D)):
             assert torch.equal(oa.flat_m, ob.flat_m) and torch.equal(oa.flat_v, ob.flat_v), name
     assert all(np.isfinite(v) for v in le.values())
+
+
+def test_float16_stored_trunk_gradients_change_nothing(monkeypatch):
+    """configs[2] --fp16 at the bench's batch 8: the 18 trunk weight gradients (680 M of 736 M parameters) are STORED as float16 by
+    their own kernel (mg_conv_wgrad_h16 -> FusedAdam GRAD_F16 segments: half the weight-gradient output stream, 2 bytes fewer per
+    parameter in the Adam pass) -- and four iterations, one of them skipped by the GradScaler, must leave every parameter, both Adam
+    moments, the float16 shadow and the losses bit for bit where float32 storage rounded through float16 at the consumer
+    (MG_NO_G16=1: GRAD_AUTOCAST) leaves them: rounding once at the store or once at the read is the same number."""
+    from mdctgan_amd import _lib
+    lr, hr = synth(8, 42)
+    lr, hr = lr.to(DEV), hr.to(DEV)
+
+    def run(no_g16):
+        if no_g16:
+            monkeypatch.setenv("MG_NO_G16", "1")
+        else:
+            monkeypatch.delenv("MG_NO_G16", raising=False)
+        m = _bench_model("configs2", True, 8)
+        m.scaler.state[0] = 2048.0          # the first generator step overflows (the stem's float16 gradient), the rest are real steps
+        scales = []
+        for _ in range(4):
+            losses = m.optimize_parameters(lr, hr)
+            scales.append(m.scaler.get_scale())
+        torch.cuda.synchronize()
+        return m, {k: v.item() for k, v in losses.items()}, scales
+    a, la, sa = run(False)
+    stored = [p for p in a.netG.parameters() if getattr(p, "_mg_g16", None) is not None]
+    assert len(stored) >= 18 and sum(p.numel() for p in stored) >= 600e6, len(stored)
+    assert a.optimizer_G._modes.count(_lib.GRAD_F32) >= 12          # the BatchNorm / position-embedding parameters of the two BoT blocks
+    b, lb, sb = run(True)
+    assert not any(getattr(p, "_mg_g16", None) is not None for p in b.netG.parameters())
+    assert la == lb and sa == sb, (la, lb, sa, sb)
+    assert sa[0] < 2048.0 and sa[-1] == sa[1], ("expected a back-off and then real steps", sa)
+    for (k, x), (_, y) in zip(a.netG.state_dict().items(), b.netG.state_dict().items()):
+        assert torch.equal(x, y), k
+    for oa, ob in ((a.optimizer_G, b.optimizer_G), (a.optimizer_D, b.optimizer_D)):
+        assert torch.equal(oa.flat_m, ob.flat_m) and torch.equal(oa.flat_v, ob.flat_v) and torch.equal(oa.flat_h, ob.flat_h)
+    assert all(np.isfinite(v) for v in la.values())
