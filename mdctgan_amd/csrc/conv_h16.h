@@ -262,7 +262,10 @@ int h16_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* 
     return MG_OK;
 }
 
-int h16_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* dx, char* ws, hipStream_t st, const void* w16_pre) {
+// addend (nullable in / out): a tensor to add to dx (mg_wino_tiles.add); consumed -- *addend set to NULL -- when the split-K
+// epilogue launch can take it
+int h16_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* dx, char* ws, hipStream_t st, const void* w16_pre,
+              const float** addend = nullptr) {
     const long long M = (long long)g->B * g->H * g->W;
     const int KT = g->KH * g->KW, K = KT * g->Co;
     const H16Plan p = h16_plan(M, g->Ci, K, true);
@@ -282,8 +285,10 @@ int h16_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* dx,
     probe_end(st);
     if (p.splits > 1) {
         const size_t n = (size_t)M * g->Ci;
+        const float* ad = addend ? *addend : nullptr;
+        if (addend) *addend = nullptr;
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(h16_grid(n / 4)), dim3(256), 0, st, (const float*)part, p.splits, n, g->Ci,
-                           (const float*)nullptr, MG_ACT_NONE, dx, 1);
+                           (const float*)nullptr, MG_ACT_NONE, dx, 1, ad);
     }
     MG_CHECK_LAUNCH();
     return MG_OK;

@@ -1111,9 +1111,11 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, int S, size
 }
 
 // split-K epilogue of the forward / data-gradient passes: out = act(sum_s part[s] + bias[col])
+// addend (optional): out = result + addend -- a skip connection's gradient joining a data gradient (mg_wino_tiles.add), added in
+// float32 AFTER the float16 rounding of an autocast result, exactly where the separate add launch put it
 __global__ void splitk_epilogue_kernel(const float* __restrict__ part, int S, size_t n, int N,
                                        const float* __restrict__ bias, int act, float* __restrict__ out,
-                                       int round_f16 = 0) {
+                                       int round_f16 = 0, const float* __restrict__ addend = nullptr) {
     const size_t n4 = n / 4;   // launcher guarantees N % 4 == 0
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 s = zero4();
@@ -1121,6 +1123,7 @@ __global__ void splitk_epilogue_kernel(const float* __restrict__ part, int S, si
         if (bias) add4(s, ld4(bias + (4 * i) % N));
         s.x = apply_act(s.x, act); s.y = apply_act(s.y, act); s.z = apply_act(s.z, act); s.w = apply_act(s.w, act);
         if (round_f16) { s.x = round_h(s.x); s.y = round_h(s.y); s.z = round_h(s.z); s.w = round_h(s.w); }
+        if (addend) add4(s, ld4(addend + 4 * i));
         *reinterpret_cast<float4*>(out + 4 * i) = s;
     }
 }
@@ -2914,7 +2917,7 @@ static int dgrad_dispatch(const mg_conv_geom* g, const float* dy, const float* w
     if (g->reflect && g->stride != 1) return MG_ERR_UNSUPPORTED;
     if (h16_ok(g) && !bias && act == MG_ACT_NONE && workspace && workspace_bytes >= h16_dgrad_ws(g) && aligned16(dy) &&
         aligned16(w) && aligned16(dx) && aligned16(workspace))
-        return h16_dgrad(g, dy, w, dx, (char*)workspace, (hipStream_t)stream, u);
+        return h16_dgrad(g, dy, w, dx, (char*)workspace, (hipStream_t)stream, u, &g_dgrad_add);
     if (co1_gemm_ok(g) && !bias && act == MG_ACT_NONE && workspace && workspace_bytes >= co1_dgrad_ws(g) && aligned16(w) &&
         aligned16(dx) && aligned16(workspace))
         return co1_dgrad(g, dy, w, dx, (char*)workspace, (hipStream_t)stream, u, wt ? wt->md : nullptr);
@@ -2949,8 +2952,10 @@ static int dgrad_dispatch(const mg_conv_geom* g, const float* dy, const float* w
             const int rc = cd_dgrad_run(&gp, dy, w, nullptr, dxp, MG_ACT_NONE, (char*)workspace + cd_reflect_dxp_bytes(&gp), st, u,
                                         md, 0, (wt && (wt->flags & MG_TILES_MD_FILLED)) ? 1 : 0);
             if (rc != MG_OK) return rc;
+            const float* addend = g_dgrad_add;      // the skip connection's gradient rides in the fold (mg_wino_tiles.add)
+            g_dgrad_add = nullptr;
             hipLaunchKernelGGL(wino_fold_reflect_kernel, dim3(wino_grid((size_t)g->B * g->H * g->W * g->Ci / 4)), dim3(256), 0,
-                               st, (const float*)dxp, g->B, g->H, g->W, g->Ci, dx, (int)prec_h(g));
+                               st, (const float*)dxp, g->B, g->H, g->W, g->Ci, dx, (int)prec_h(g), addend);
             MG_CHECK_LAUNCH();
             return MG_OK;
         }

@@ -420,8 +420,9 @@ inline bool wino_out_norm_ok(int TH, int TW, int C) {
 }
 
 // ReflectionPad2d(1) backward: dX[i][j] = sum of the padded positions aliasing (i, j).  dXp: [B][H+2][W+2][C]
+// addend (optional): dx = fold + addend (float32 add after the autocast rounding: a skip connection's gradient, mg_wino_tiles.add)
 __global__ void wino_fold_reflect_kernel(const float* __restrict__ dxp, int B, int H, int W, int C,
-                                         float* __restrict__ dx, int round_f16 = 0) {
+                                         float* __restrict__ dx, int round_f16 = 0, const float* __restrict__ addend = nullptr) {
     const int C4 = C / 4;
     const size_t total = (size_t)B * H * W * C4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -443,6 +444,7 @@ __global__ void wino_fold_reflect_kernel(const float* __restrict__ dxp, int B, i
             }
         }
         if (round_f16) { s.x = round_h(s.x); s.y = round_h(s.y); s.z = round_h(s.z); s.w = round_h(s.w); }
+        if (addend) add4(s, ld4(addend + i * 4));
         *reinterpret_cast<float4*>(dx + i * 4) = s;
     }
 }

@@ -440,9 +440,13 @@ class _ConvFn(torch.autograd.Function):
         return _conv_backward(ctx, gy, x, y), None, None, None
 
 
-def _conv_backward(ctx, gy, x, y):
-    """Data and weight gradient of a _ConvFn / _ConvInstNormFn node; returns dx (weight gradients go to the arena)."""
+def _conv_backward(ctx, gy, x, y, add=None):
+    """Data and weight gradient of a _ConvFn / _ConvInstNormFn node; returns dx (weight gradients go to the arena).
+    add (NHWC view, stride-1 convolutions without live rows only): dx += add inside the data gradient's last kernel where the
+    layer's path has one that takes it (mg_wino_tiles.add: Winograd gather, reflection fold, split-K epilogue), by one add
+    launch of the library otherwise."""
     stride, pad, reflect, act, transposed, weight_grad = ctx.cfg
+    assert add is None or not transposed
     g, weight, bias = ctx.g, ctx.weight, ctx.bias
     gy = to_cl(gy)
     kind = _BackwardPass.kind
@@ -475,10 +479,12 @@ def _conv_backward(ctx, gy, x, y):
             elif u is not None and want_dw and (getattr(ctx, "v", None) is not None or ops.tiles_are_casts(g)):
                 _, md = ops.wino_tile_buffers(g, gy.device, want_v=False)
             if rows is not None:
+                assert add is None
                 dx = torch.empty_like(x_full)
                 ops.conv_dgrad(g, nhwc_view(gy), w, u=u, out=nhwc_view(dx[:rows]))
             else:
-                dx = nchw_view(ops.conv_dgrad(g, nhwc_view(gy), w, u=u, md_out=md, md_filled=md_filled))
+                dx = nchw_view(ops.conv_dgrad(g, nhwc_view(gy), w, u=u, md_out=md, md_filled=md_filled, add=add))
+                add = None
             if last_use:
                 ctx.u = None
         else:
@@ -666,9 +672,10 @@ class _ConvInstNormFn(torch.autograd.Function):
         d16 = (torch.empty(gy.numel(), dtype=torch.float16, device=gy.device)
                if (_want_h16(g.B, g.OH * g.OW, g.Co, g.precision == _lib.PRECISION_F16) and ops.precast_ok(1, g)) else None)
         d_raw = _attach_h16(nchw_view(ops.instnorm_bwd(nhwc_view(gy), nhwc_view(y_raw), mean, rstd, ctx.norm_act, dx16=d16)), d16)
-        dx = _conv_backward(ctx, d_raw, x, None)
-        if skip_g is not None:
-            dx = skip_g if dx is None else add(dx, skip_g)
+        # the skip connection's gradient joins the data gradient inside its last kernel (no elementwise add launch)
+        dx = _conv_backward(ctx, d_raw, x, None, add=nhwc_view(skip_g) if (skip_g is not None and ctx.needs_input_grad[0]) else None)
+        if skip_g is not None and dx is None:
+            dx = skip_g
         return dx, None, None, dres, None
 
 
@@ -740,7 +747,7 @@ class _BatchNormFn(torch.autograd.Function):
         y, mean, rstd = ops.batchnorm_fwd(nhwc_view(x), gamma.detach(), beta.detach(), bn.running_mean, bn.running_var,
                                           bn.eps, bn.momentum if bn.momentum is not None else 0.1, training,
                                           nhwc_view(res) if res is not None else None, act)
-        if training and bn.num_batches_tracked is not None:
+        if training and bn.num_batches_tracked is not None and not getattr(bn, "_mg_counter_external", False):
             bn.num_batches_tracked.add_(1)
         y = nchw_view(y)
         ctx.act, ctx.training, ctx.gamma, ctx.beta = act, training, gamma, beta

@@ -311,7 +311,9 @@ def test_full_size_step_gradients(tag, fp16, feat, batch, n_steps, monkeypatch):
             # otherwise the update comparison below would compare different numbers of Adam steps
             steps_report["scales"] = [hip_scales, ref_scales, overflowed]
             assert hip_scales == ref_scales, ("loss-scale trajectories (HIP, oracle)", hip_scales, ref_scales)
-            assert overflowed and ref_scales[-1] == ref_scales[0], "expected exactly one back-off (iteration 1), then real steps"
+            # (measured: 1024 -> 512 -> 256 -> 256 in both legs -- the generator's stem overflows at 1024, a second back-off follows at
+            # 512, iteration 3 is a real step of both optimisers)
+            assert overflowed and ref_scales[-1] == ref_scales[-2], "expected back-offs first (iteration 1 at least), then a real step"
         else:
             fused = [p for p in trunk if getattr(p, "_mg_u_persist", None) is not None]
             assert len(fused) >= 18, "the trunk layers did not take the fused weight-gradient + Adam path (%d of %d)" % (len(fused), len(trunk))
