@@ -255,8 +255,12 @@ int h16_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* 
     probe_end(st);
     if (!fused_epilogue) {
         const size_t n = (size_t)M * g->Co;
-        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(h16_grid(n / 4)), dim3(256), 0, st, (const float*)part, p.splits, n, g->Co,
-                           bias, act, y, 1);
+        if (g_fwd_defer && act == MG_ACT_NONE && p.splits > 1) {
+            *g_fwd_defer = FwdDefer{part, p.splits, bias, 1, true};        // the caller's InstanceNorm kernel finishes the sum
+        } else {
+            hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(h16_grid(n / 4)), dim3(256), 0, st, (const float*)part, p.splits, n, g->Co,
+                               bias, act, y, 1);
+        }
     }
     MG_CHECK_LAUNCH();
     return MG_OK;

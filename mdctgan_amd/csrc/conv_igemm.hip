@@ -1151,6 +1151,11 @@ __global__ void colsum_partial_kernel(const float* __restrict__ a, long long M, 
 }  // namespace
 
 extern "C" __attribute__((visibility("hidden"))) int mg_conv_rowdot_kq(const mg_conv_geom* g);       // conv_rowdot.hip (library-internal)
+extern "C" __attribute__((visibility("hidden"))) int mg_instnorm_slab_ok(int HW, int C);              // norm_act.hip (library-internal)
+extern "C" __attribute__((visibility("hidden"))) int mg_instnorm_fwd_slabs(const float* part, int S, const float* bias, int round_f16,
+                                                                          float* x_out, int B, int HW, int C, float eps, int act,
+                                                                          const float* residual, float* y, float* mean, float* rstd,
+                                                                          void* stream, void* y16);
 #include "wino.h"
 #include "wino4.h"
 #include "wino42.h"
@@ -1343,6 +1348,11 @@ inline size_t slab_count(int old_splits, int dense) {      // split-K slabs a wo
     return m > 1 ? (size_t)m : 0;
 }
 
+// A forward convolution whose caller normalises the result right away (mg_conv_fwd_instnorm_*) may leave its split-K slabs
+// unreduced: the InstanceNorm slab kernel sums them itself (norm_act.hip: mg_instnorm_fwd_slabs) -- one launch fewer per layer.
+// The caller arms g_fwd_defer; a path that can oblige fills it INSTEAD of launching splitk_epilogue_kernel.
+struct FwdDefer { const float* part; int splits; const float* bias; int round_f16; bool filled; };
+static thread_local FwdDefer* g_fwd_defer = nullptr;
 #include "dense_gemm_h.h"
 #include "conv_h16.h"
 #include "conv_dma.h"
@@ -2773,9 +2783,19 @@ static int conv_fwd_instnorm_impl(const mg_conv_geom* g, const float* x, const f
                         wt ? wt->v : nullptr, &nrm, wt && wt->v && (wt->flags & MG_TILES_V_FILLED));
     }
     if (v_next) return MG_ERR_ARG;           // (unreachable after wino_vnext_ok: the fused path above is the only writer of v_next)
+    float* const raw_out = y_raw;            // NULL under no_grad: the slab kernel then skips that store, the two-launch path normalises in place
     if (!y_raw) y_raw = y;
+    // small maps: the one-launch InstanceNorm kernel also finishes a split-K convolution (sums the slabs, bias, autocast rounding)
+    FwdDefer defer{nullptr, 0, nullptr, 0, false};
+    const bool no_defer = getenv("MG_NO_FWD_DEFER") != nullptr;      // (read per call: the bit-identity test flips it)
+    const bool can_defer = !no_defer && mg_instnorm_slab_ok(g->OH * g->OW, g->Co) && g->Co % 4 == 0 && (!bias || aligned16(bias));
+    g_fwd_defer = can_defer ? &defer : nullptr;
     const int rc = mg_conv_fwd_w(g, x, w, bias, y_raw, MG_ACT_NONE, workspace, workspace_bytes, stream, wt);
+    g_fwd_defer = nullptr;
     if (rc != MG_OK) return rc;
+    if (defer.filled)
+        return mg_instnorm_fwd_slabs(defer.part, defer.splits, defer.bias, defer.round_f16, raw_out, g->B, g->OH * g->OW, g->Co, eps, act,
+                                     residual, y, mean, rstd, stream, y16);
     return mg_instnorm_fwd_h(y_raw, g->B, g->OH * g->OW, g->Co, eps, act, residual, y, mean, rstd, workspace, workspace_bytes, stream, y16);
 }
 
@@ -2847,6 +2867,10 @@ int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const f
         MG_CHECK_LAUNCH();
         if (cp.splits > 1) {
             const size_t n = (size_t)M * N;
+            if (g_fwd_defer && act == MG_ACT_NONE) {
+                *g_fwd_defer = FwdDefer{(const float*)wsp, cp.splits, bias, cd_half ? 1 : 0, true};
+                return MG_OK;
+            }
             const unsigned blocks = (unsigned)((n / 4 + 255) / 256 > 4096 ? 4096 : (n / 4 + 255) / 256);
             hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, (const float*)wsp, cp.splits, n, N,
                                bias, act, y, cd_half ? 1 : 0);

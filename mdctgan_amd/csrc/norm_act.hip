@@ -320,23 +320,43 @@ __device__ __forceinline__ void slab_reduce(double s1[4], double s2[4], double (
     }
 }
 
-template <int NP>
+// SLABS: x is not a tensor yet but the S split-K slabs of the convolution in front (part[z][B*HW][C], summed in slab order, + bias,
+// rounded through float16 for an autocast layer: exactly splitk_epilogue_kernel's arithmetic) -- the kernel finishes the
+// convolution, writes its raw output to x_out (nullable: nobody reads it under no_grad) and normalises, one launch instead of two.
+struct NormSlabSrc { const float* part; const float* bias; float* x_out; size_t n; int S, round_f16; };
+__device__ __forceinline__ float norm_round_h(float v) { return (float)(_Float16)v; }
+template <int NP, bool SLABS = false>
 __global__ __launch_bounds__(256) void norm_slab_fwd_kernel(const float* __restrict__ x, int HW, int C, float eps,
                                                             int act, const float* __restrict__ residual,
                                                             float* __restrict__ y, float* __restrict__ mean,
-                                                            float* __restrict__ rstd, _Float16* __restrict__ y16 = nullptr) {
+                                                            float* __restrict__ rstd, _Float16* __restrict__ y16 = nullptr,
+                                                            NormSlabSrc src = NormSlabSrc{}) {
     __shared__ double red[2][32][32];
     const int cq = threadIdx.x & 7, pl = threadIdx.x >> 3;
     const int b = blockIdx.y, c0 = blockIdx.x * 32 + 4 * cq;
     const size_t base = (size_t)b * HW * C + c0;
     float4 v[NP];
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (SLABS && src.bias) bias4 = *reinterpret_cast<const float4*>(src.bias + c0);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int p = pl + 32 * i;
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p < HW) {
-            v[i] = *reinterpret_cast<const float4*>(x + base + (size_t)p * C);
+            if (SLABS) {
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int z = 0; z < src.S; ++z) {
+                    const float4 q = *reinterpret_cast<const float4*>(src.part + (size_t)z * src.n + base + (size_t)p * C);
+                    a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+                }
+                a.x += bias4.x; a.y += bias4.y; a.z += bias4.z; a.w += bias4.w;
+                if (src.round_f16) { a.x = norm_round_h(a.x); a.y = norm_round_h(a.y); a.z = norm_round_h(a.z); a.w = norm_round_h(a.w); }
+                if (src.x_out) *reinterpret_cast<float4*>(src.x_out + base + (size_t)p * C) = a;
+                v[i] = a;
+            } else {
+                v[i] = *reinterpret_cast<const float4*>(x + base + (size_t)p * C);
+            }
             s1[0] += (double)v[i].x; s2[0] += (double)v[i].x * (double)v[i].x;
             s1[1] += (double)v[i].y; s2[1] += (double)v[i].y * (double)v[i].y;
             s1[2] += (double)v[i].z; s2[2] += (double)v[i].z * (double)v[i].z;
@@ -943,7 +963,7 @@ int mg_instnorm_fwd_h(const float* x, int B, int HW, int C, float eps, int act, 
     hipStream_t st = (hipStream_t)stream;
     if (const int np = slab_np(HW, C); np && al16(x) && al16(y) && al16(mean) && al16(rstd) && (!residual || al16(residual))) {
         const dim3 grid(C / 32, B);
-#define MG_SLAB_FWD(NP_) hipLaunchKernelGGL(norm_slab_fwd_kernel<NP_>, grid, dim3(256), 0, st, x, HW, C, eps, act, residual, y, mean, rstd, y16)
+#define MG_SLAB_FWD(NP_) hipLaunchKernelGGL((norm_slab_fwd_kernel<NP_, false>), grid, dim3(256), 0, st, x, HW, C, eps, act, residual, y, mean, rstd, y16, NormSlabSrc{})
         if (np == 4) MG_SLAB_FWD(4); else if (np == 8) MG_SLAB_FWD(8); else if (np == 16) MG_SLAB_FWD(16); else MG_SLAB_FWD(20);
 #undef MG_SLAB_FWD
         MG_CHECK_LAUNCH();
@@ -972,6 +992,27 @@ int mg_instnorm_fwd_h(const float* x, int B, int HW, int C, float eps, int act, 
     else
         hipLaunchKernelGGL(norm_apply_fwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, x, mean, rstd,
                            residual, HW, C, act, y, total, y16);
+    MG_CHECK_LAUNCH();
+    return MG_OK;
+}
+
+// library-internal (conv_igemm.hip: mg_conv_fwd_instnorm_*): InstanceNorm straight from a convolution's split-K slabs
+__attribute__((visibility("hidden"))) int mg_instnorm_slab_ok(int HW, int C) { return slab_np(HW, C) ? 1 : 0; }
+__attribute__((visibility("hidden"))) int mg_instnorm_fwd_slabs(const float* part, int S, const float* bias, int round_f16, float* x_out,
+                                                               int B, int HW, int C, float eps, int act, const float* residual,
+                                                               float* y, float* mean, float* rstd, void* stream, void* y16v) {
+    const int np = slab_np(HW, C);
+    _Float16* y16 = (_Float16*)y16v;
+    if (!np || !part || S < 1 || !y || !mean || !rstd) return MG_ERR_ARG;
+    if (!al16(part) || !al16(y) || !al16(mean) || !al16(rstd) || (residual && !al16(residual)) || (bias && !al16(bias)) ||
+        (x_out && !al16(x_out)) || (y16 && (reinterpret_cast<uintptr_t>(y16) & 7)))
+        return MG_ERR_ARG;
+    const NormSlabSrc src{part, bias, x_out, (size_t)B * HW * C, S, round_f16};
+    const dim3 grid(C / 32, B);
+    hipStream_t st = (hipStream_t)stream;
+#define MG_SLAB_FWD_S(NP_) hipLaunchKernelGGL((norm_slab_fwd_kernel<NP_, true>), grid, dim3(256), 0, st, (const float*)nullptr, HW, C, eps, act, residual, y, mean, rstd, y16, src)
+    if (np == 4) MG_SLAB_FWD_S(4); else if (np == 8) MG_SLAB_FWD_S(8); else if (np == 16) MG_SLAB_FWD_S(16); else MG_SLAB_FWD_S(20);
+#undef MG_SLAB_FWD_S
     MG_CHECK_LAUNCH();
     return MG_OK;
 }

@@ -67,7 +67,10 @@ def _want_h16(B, HW, C, half=None):
     conv_h16.h instead)."""
     if half is None:
         half = amp.current_precision() == _lib.PRECISION_F16
-    return bool(half) and C % 64 == 0 and B * HW > 2 * C and os.environ.get("MG_NO_H16_PRODUCER", "0") != "1"
+    # (round 6: also every SMALL tensor, <= 2 Mi elements -- 2 more bytes per element in a kernel that sits at the launch floor cost
+    # nothing, and the stride-2 / transposed rungs next to the trunk then skip their cast launch)
+    return (bool(half) and C % 64 == 0 and (B * HW > 2 * C or B * HW * C <= (1 << 21))
+            and os.environ.get("MG_NO_H16_PRODUCER", "0") != "1")
 
 
 def _attach_h16(t, buf):
@@ -455,7 +458,8 @@ def _conv_backward(ctx, gy, x, y, add=None):
     want_dx = ctx.needs_input_grad[0] and not (weight_grad == "D0" and kind == "D")
     want_dw = bool(weight_grad) and weight.requires_grad and not (shared and kind == "G")
     rows = _live_rows(x) if shared else None
-    x_full = x
+    x_full, gy_full = x, gy
+    rec16 = getattr(gy, "_mg_h16_rows", None) if rows is not None else None
     if rows is not None:                                   # pass "G" over a stacked batch: the fake half only
         assert not transposed and not want_dw
         x, gy = x[:rows], gy[:rows]
@@ -481,7 +485,13 @@ def _conv_backward(ctx, gy, x, y, add=None):
             if rows is not None:
                 assert add is None
                 dx = torch.empty_like(x_full)
-                ops.conv_dgrad(g, nhwc_view(gy), w, u=u, out=nhwc_view(dx[:rows]))
+                g16r = None
+                if rec16 is not None and act == ACT_NONE and ops.precast_ok(1, g):
+                    buf, ptr, ver, r_ = rec16
+                    if ptr == gy_full.data_ptr() and ver == gy_full._version and r_ == rows and gy_full.is_contiguous(memory_format=CL):
+                        g16r = buf
+                        H16_STATS["used_bwd"] += 1
+                ops.conv_dgrad(g, nhwc_view(gy), w, u=u, out=nhwc_view(dx[:rows]), md_out=g16r, md_filled=g16r is not None)
             else:
                 dx = nchw_view(ops.conv_dgrad(g, nhwc_view(gy), w, u=u, md_out=md, md_filled=md_filled, add=add))
                 add = None
@@ -721,8 +731,15 @@ class _InstNormFn(torch.autograd.Function):
             rows = _live_rows(x)
             if rows is not None:                               # pass "G" over a stacked discriminator batch
                 dx = torch.empty_like(x)
+                B, C, H, W = x.shape
+                # the float16 copy of the live rows for the data gradient in front (round 6: the fake half only)
+                d16 = (torch.empty(rows * H * W * C, dtype=torch.float16, device=x.device)
+                       if _want_h16(rows, H * W, C, ctx.half) else None)
                 ops.instnorm_bwd(nhwc_view(gy[:rows]), nhwc_view(x[:rows]), mean[:rows], rstd[:rows], ctx.act,
-                                 out=nhwc_view(dx[:rows]))
+                                 out=nhwc_view(dx[:rows]), dx16=d16)
+                if d16 is not None:
+                    dx._mg_h16_rows = (d16, dx.data_ptr(), dx._version, rows)
+                    H16_STATS["made"] += 1
             else:
                 B, C, H, W = x.shape
                 d16 = torch.empty(x.numel(), dtype=torch.float16, device=x.device) if _want_h16(B, H * W, C, ctx.half) else None

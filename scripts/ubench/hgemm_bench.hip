@@ -1,6 +1,8 @@
 // Tuning harness for mdctgan_amd/csrc/dense_gemm_h.h (f16 GEMM, LDS-DMA): the im2col GEMM shapes of the --fp16 trunk layers.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mdctgan_amd/csrc -I include -I scripts/ubench scripts/ubench/hgemm_bench.hip -o scripts/ubench/hgemm_bench
-// plus dense_gemm_h8.h (round 5: the 256 x 256 x 64 balanced ping-pong) and h8pp.h (its unbalanced first version, for the slot stamps)
+// (round 6: the round-5 research kernels -- dense_gemm_h8.h, the 256 x 256 x 64 balanced ping-pong at 98.7 % of the MFMA issue bound /
+// 1.07-1.25 PF wall clock under DVFS, and h8pp.h, its unbalanced first version -- left the tree: no layer of this model has the >= 256
+// tiles of 256 x 256 they need; findings and numbers are in HISTORY.md section 3 "Round 5", logs in profiles/r05_hgemm8_ubench.log)
 #include "common.h"
 #include <algorithm>
 #include <cstdio>
@@ -14,8 +16,6 @@ inline void mg_launch(KernelT kern, dim3 grid, dim3 block, size_t lds, hipStream
 }
 #include "dense_gemm.h"
 #include "dense_gemm_h.h"
-#include "dense_gemm_h8.h"
-#include "h8pp.h"
 
 __global__ void ref_kernel(const _Float16* A, const _Float16* B, float* out, int M, int N, int K, int lda, int ldb) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -55,23 +55,7 @@ __global__ void reduce_kernel(const float* part, int S, size_t n, float* out) {
         *(float4*)(out + 4 * i) = s;
     }
 }
-template <int DBG>
-void hpp_adapter(const HgArgs& g, hipStream_t st);
 struct Variant { const char* name; int bm, bn; void (*launch)(const HgArgs&, hipStream_t); };
-template <int DBG>
-void h8_adapter(const HgArgs& g, hipStream_t st) {
-    Hg8Args a{};
-    a.A = g.A; a.B = g.B; a.C = g.part ? g.part : g.C; a.bias = nullptr;
-    a.M = g.M; a.N = g.N; a.K = g.K; a.lda = g.lda; a.ldb = g.ldb; a.ldc = g.N;
-    hgemm8_launch<DBG>(a, st);
-}
-template <int DBG>
-void hpp_adapter(const HgArgs& g, hipStream_t st) {
-    HppArgs a{};
-    a.A = g.A; a.B = g.B; a.C = g.part ? g.part : g.C; a.bias = nullptr;
-    a.M = g.M; a.N = g.N; a.K = g.K; a.lda = g.lda; a.ldb = g.ldb; a.ldc = g.N;
-    hpp_launch<DBG>(a, st);
-}
 __global__ void ref_rc_kernel(const _Float16* A, const _Float16* B, float* out, int M, int N, int K) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)M * N) return;
@@ -87,7 +71,7 @@ const Variant vrc[] = {VR(128, 64, 2, 2), VR(128, 128, 4, 2), VR(256, 64, 4, 2),
                        VRN(256, 128, 4, 2, 3)};
 #define V(BM, BN, WM, WN) {#BM "x" #BN "/" #WM "x" #WN, BM, BN, hgemm_launch<BM, BN, WM, WN>}
 #define VN(BM, BN, WM, WN, NB) {#BM "x" #BN "/" #WM "x" #WN " n" #NB, BM, BN, hgemm_launch<BM, BN, WM, WN, false, NB>}
-const Variant vs[] = {{"8-phase 256x256", 256, 256, h8_adapter<0>}, {"8p noDMA", 256, 256, h8_adapter<1>}, {"8p noLDS", 256, 256, h8_adapter<2>}, {"8p noMFMA", 256, 256, h8_adapter<4>}, {"8p nowait", 256, 256, h8_adapter<8>}, {"8p noDMA noLDS", 256, 256, h8_adapter<3>}, {"8p barriers only", 256, 256, h8_adapter<7>}, {"8pp pingpong", 256, 256, hpp_adapter<16>}, {"8pp balanced6", 256, 256, hpp_adapter<16 + 128>}, {"8pp balanced6 noDMA", 256, 256, hpp_adapter<16 + 128 + 1>}, {"8pp balanced6 nowait", 256, 256, hpp_adapter<16 + 128 + 8>}, V(128, 64, 2, 2), V(128, 128, 2, 2), V(128, 128, 4, 2), V(256, 64, 4, 2), V(256, 128, 4, 2), V(256, 256, 4, 2),
+const Variant vs[] = {V(128, 64, 2, 2), V(128, 128, 2, 2), V(128, 128, 4, 2), V(256, 64, 4, 2), V(256, 128, 4, 2), V(256, 256, 4, 2),
                       V(256, 128, 2, 2), V(256, 256, 2, 2), V(512, 128, 4, 2), V(256, 128, 4, 1), V(512, 128, 4, 1),
                       VN(128, 64, 2, 2, 3), VN(128, 64, 2, 2, 4), VN(128, 128, 2, 2, 3), VN(128, 128, 2, 2, 4), VN(128, 128, 4, 2, 3), VN(128, 128, 4, 2, 4),
                       VN(256, 64, 4, 2, 3), VN(256, 64, 4, 2, 4), VN(256, 128, 4, 2, 3), VN(256, 256, 4, 2, 3) };
@@ -173,26 +157,6 @@ int main(int argc, char** argv) {
                 printf("   %-18s splits %2d wgs %5lld  med %8.1f us  %7.1f TF  %6.2f TB/s  relerr %.1e%s\n", v.name, g.splits, wgs, ts[1],
                        flops / ts[1] / 1e6, bytes / ts[1] / 1e6, err, err > 1e-4f ? "  <-- WRONG" : "");
             }
-        }
-        if (getenv("HG_CLOCK") && pr.N % 256 == 0 && pr.M % 256 == 0) {
-            const int nwg = (pr.M / 256) * (pr.N / 256);
-            unsigned long long* dts; hipMalloc(&dts, (size_t)nwg * 32);
-            hipMemsetAsync(dts, 0, (size_t)nwg * 32, st);
-            Hg8Args a{};
-            a.A = A; a.B = B; a.C = C; a.bias = (const float*)dts; a.M = pr.M; a.N = pr.N; a.K = pr.K; a.lda = pr.K; a.ldb = pr.K; a.ldc = pr.N;
-            for (int i = 0; i < 5; ++i) hgemm8_launch<64>(a, st);
-            hipEventRecord(e0, st);
-            hgemm8_launch<64>(a, st);
-            hipEventRecord(e1, st);
-            hipEventSynchronize(e1);
-            float ms; hipEventElapsedTime(&ms, e0, e1);
-            std::vector<unsigned long long> h((size_t)nwg * 4);
-            hipMemcpy(h.data(), dts, (size_t)nwg * 32, hipMemcpyDeviceToHost);
-            unsigned long long tmin = ~0ull, tmax = 0; double loop = 0, epi = 0;
-            for (int w = 0; w < nwg; ++w) { tmin = std::min(tmin, h[4 * w]); tmax = std::max(tmax, h[4 * w + 2]); loop += (double)(h[4 * w + 1] - h[4 * w]); epi += (double)(h[4 * w + 2] - h[4 * w + 1]); }
-            printf("   clock probe: launch %.1f us (events); first loop start -> last workgroup end %llu ticks; per workgroup: main loop %.0f ticks (%.0f per K-tile), epilogue %.0f ticks\n",
-                   ms * 1e3, tmax - tmin, loop / nwg, loop / nwg / (pr.K / 64), epi / nwg);
-            hipFree(dts);
         }
         if (hgemm_as_ok(pr.M, pr.N, pr.K)) {
             const int tn = pr.N / 128, tmm = pr.M / 128;

@@ -468,3 +468,56 @@ def test_instnorm_bwd_wino_md_matches_separate_calls(case):
     assert (md1 - md2).abs().max().item() <= 2e-6 * scale
     assert (dx1 - dx2).abs().max().item() <= 1e-5 * dx1.abs().max().item()
     assert (dw1 - dw2).abs().max().item() <= 1e-5 * dw1.abs().max().item()
+
+
+@pytest.mark.parametrize("case", [("local_block_128_64x128_f16", 2, 128, 64, 128, True, True), ("local_block_128_16x32_f32", 2, 128, 16, 32, True, False),
+                                  ("trunk_2048_4x8_f16", 8, 2048, 4, 8, True, True), ("trunk_256_4x8_f16", 8, 256, 4, 8, True, True),
+                                  ("zero_pad_128_16x32_f16", 2, 128, 16, 32, False, True)], ids=lambda c: c[0])
+def test_dgrad_add_rides_in_the_fold_and_the_split_k_epilogue(case):
+    """Round 6: mg_wino_tiles.add is also taken by the reflection fold of the LDS-DMA data gradient (wino_fold_reflect_kernel) and by
+    the split-K epilogue of the weight-streaming float16 GEMM -- the ResnetBlock skip gradient of the local enhancer's 128-channel
+    blocks and of the --fp16 trunk no longer costs an add launch.  dx == dgrad(dy) + add bit for bit (the addition is float32,
+    AFTER the autocast result's float16 rounding, where the separate launch had it)."""
+    from mdctgan_amd import _lib, ops
+    name, B, C, H, W, reflect, half = case
+    gen = torch.Generator().manual_seed(len(name))
+    g = ops.conv_geom(B, H, W, C, C, 3, 3, 1, 1, reflect, _lib.PRECISION_F16 if half else _lib.PRECISION_F32)
+    dy = torch.randn(B, H, W, C, generator=gen).to(DEV)
+    w = (torch.randn(C, 3, 3, C, generator=gen) / np.sqrt(9 * C)).to(DEV)
+    skip = torch.randn(B, H, W, C, generator=gen).to(DEV)
+    dx0 = ops.conv_dgrad(g, dy, w)
+    dx1 = ops.conv_dgrad(g, dy, w, add=skip)
+    assert torch.equal(dx1, dx0 + skip)
+
+
+@pytest.mark.parametrize("case", [("trunk_2048_4x8_f16", 8, 2048, 2048, 4, 8, 1, True, True, True), ("trunk_256_4x8_f16_nores", 8, 256, 256, 4, 8, 1, True, True, False),
+                                  ("ladder_512_1024_s2_f32", 8, 512, 1024, 16, 32, 2, False, False, False),
+                                  ("ladder_512_1024_s2_f16", 8, 512, 1024, 16, 32, 2, False, True, False),
+                                  ("ladder_256_512_s2_f16", 8, 256, 512, 32, 64, 2, False, True, False)], ids=lambda c: c[0])
+def test_instnorm_finishes_the_split_k_convolution(case, monkeypatch):
+    """Round 6: where a forward convolution leaves split-K slabs and the map is small enough for the one-launch InstanceNorm
+    kernel, that kernel sums the slabs itself (+ bias, + the autocast rounding: splitk_epilogue_kernel's arithmetic in its order)
+    instead of reading a tensor an epilogue launch wrote: y, the raw convolution output, mean and rstd are bit for bit what the
+    two launches give (MG_NO_FWD_DEFER=1), also without the raw output (no_grad) and with the float16 copy for the next layer."""
+    from mdctgan_amd import _lib, ops
+    name, B, Ci, Co, H, W, stride, reflect, half, with_res = case
+    gen = torch.Generator().manual_seed(len(name))
+    g = ops.conv_geom(B, H, W, Ci, Co, 3, 3, stride, 1, reflect, _lib.PRECISION_F16 if half else _lib.PRECISION_F32)
+    x = torch.randn(B, H, W, Ci, generator=gen).to(DEV)
+    w = (torch.randn(Co, 3, 3, Ci, generator=gen) / np.sqrt(9 * Ci)).to(DEV)
+    b = torch.randn(Co, generator=gen).to(DEV)
+    res = torch.randn(B, g.OH, g.OW, Co, generator=gen).to(DEV) if with_res else None
+
+    def run(need_raw, want16):
+        y16 = torch.empty(B * g.OH * g.OW * Co, dtype=torch.float16, device=DEV) if want16 else None
+        y, y_raw, mean, rstd = ops.conv_fwd_instnorm(g, x, w, b, ACT_RELU_, res, 1e-5, y16=y16, need_raw=need_raw)
+        return y, y_raw, mean, rstd, y16
+    monkeypatch.setenv("MG_NO_FWD_DEFER", "1")
+    ref = run(True, half)
+    monkeypatch.delenv("MG_NO_FWD_DEFER")
+    got = run(True, half)
+    for a, b_ in zip(ref, got):
+        assert (a is None and b_ is None) or torch.equal(a, b_)
+    lean = run(False, False)
+    assert lean[1] is None and torch.equal(lean[0], ref[0]) and torch.equal(lean[2], ref[2]) and torch.equal(lean[3], ref[3])
+    # (whether a case really leaves slabs is the planner's business: mg_conv_plan_splits says so for the LDS-DMA layers)
