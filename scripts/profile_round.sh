@@ -58,6 +58,6 @@ cd $R
 # (the full-size step parity report is its own call: scripts/r05_step_parity.sh)
 tail -5 $out/${tag}_mdct_bs_ubench.log
 
-# float16 GEMM structure ablation on the dense twin of the 128-channel 64x128 layers (--fp16): which part of
+# float16 GEMM structure ablation on the dense twin of the 128-channel 64x128 layers (HISTORY.md section 3, --fp16): which part of
 # hgemm_kernel's loop sets its time.  Binaries: hipcc ... -DHG_DEBUG_{NO_DMA,NO_LDS,NO_COMPUTE,NO_BARRIER} scripts/ubench/hgemm_bench.hip
 ( cd scripts/ubench; for v in "" _NO_DMA _NO_LDS _NO_COMPUTE _NO_BARRIER; do [ -x ./hgemm_bench$v ] || continue; echo "### hgemm_bench$v"; timeout 120 ./hgemm_bench$v "local128 as" 2>&1 | grep -E "==|splits  1 " | grep -v " rc"; done; echo "### trunk weight gradient"; timeout 120 ./hgemm_bench wgrad 2>&1 | grep -E "==|A-stat|128x128/4x2 " ) > $out/${tag}_hgemm_ablation.log 2>&1

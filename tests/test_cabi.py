@@ -55,7 +55,7 @@ def test_conv_geom_layout_matches_library_and_integration_doc():
 
 
 def test_ladder_weight_gradient_plans_fill_the_resident_slots():
-    """Host-side planner of the LDS-DMA weight gradient (csrc/conv_dma.h): a CU holds 4 / 3 / 2 workgroups
+    """Host-side planner of the LDS-DMA weight gradient (csrc/conv_dma.h, HISTORY.md section 3 "Round 5"): a CU holds 4 / 3 / 2 workgroups
     of the 64x64 / 64x128, 128x64 / 128x128 tiles; for the stride-2 rungs of configs[1] at the bench's batch the plan must fit in
     whole rounds of them with the last round at least three quarters full (the old fixed ladder of split counts left a round of
     one workgroup per CU), take the row-regular gather, and reproduce itself (the workspace query and the launch call it twice)."""
