@@ -232,8 +232,12 @@ inline void h16_launch(const H16Plan& p, bool brc, const HgArgs& a, hipStream_t 
     }
 }
 
+// MG_NO_HGEMM_SA=1: the round-2..5 kernels (im2col matrix + hgemm_kernel) instead of the weight-streaming form (read per call: the
+// bit-identity test flips it)
+inline bool h16_sa_on() { return getenv("MG_NO_HGEMM_SA") == nullptr; }
+// x16_pre (nullable): float16(x) already written by x's producer (MG_TILES_V_FILLED)
 int h16_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act, char* ws,
-            hipStream_t st, const void* w16_pre) {
+            hipStream_t st, const void* w16_pre, const void* x16_pre = nullptr) {
     const long long M = (long long)g->B * g->OH * g->OW;
     const int K = g->KH * g->KW * g->Ci;
     const H16Plan p = h16_plan(M, g->Co, K, false);
@@ -243,15 +247,31 @@ int h16_fwd(const mg_conv_geom* g, const float* x, const float* w, const float* 
     if (w16_pre) w16 = (_Float16*)const_cast<void*>(w16_pre);
     else if (h16_prepare(g, w, w16, st) != MG_OK) return MG_ERR_ARG;
     const Geom gg = to_geom(g);
-    hipLaunchKernelGGL(h16_im2col_kernel, dim3(h16_grid((size_t)M * K / 8)), dim3(256), 0, st, gg, x, xcol);
     HgArgs a{};
-    a.A = xcol; a.B = w16; a.C = y; a.part = p.splits > 1 ? part : nullptr;
-    a.M = (int)M; a.N = g->Co; a.K = K; a.lda = K; a.ldb = K; a.splits = p.splits; a.cps = p.cps;
+    a.B = w16; a.C = y; a.part = p.splits > 1 ? part : nullptr;
+    a.M = (int)M; a.N = g->Co; a.K = K; a.ldb = K; a.splits = p.splits; a.cps = p.cps;
     a.bias = (act == MG_ACT_NONE) ? bias : nullptr; a.round_f16 = 1; a.accumulate = 0; a.b_cpt = 1 << 30; a.b_tap_stride = 0;
+    const bool sa = h16_sa_on() && hgemm_sa_ok(a) && (size_t)g->B * g->H * g->W * g->Ci * 2 < (1ull << 31);
+    if (sa) {
+        // no im2col matrix: the GEMM gathers its A rows from float16(x) [B*H*W][Ci] -- the producer's copy, or one cast pass
+        const void* x16 = x16_pre;
+        if (!x16) {
+            const size_t n8 = (size_t)g->B * g->H * g->W * g->Ci / 8;
+            hipLaunchKernelGGL(h16_cast_kernel, dim3(h16_grid(n8)), dim3(256), 0, st, x, xcol, n8);
+            x16 = xcol;
+        }
+        a.A = x16; a.lda = g->Ci;
+        a.a_cpt = g->Ci / HG_BK; a.gH = g->H; a.gW = g->W; a.gOH = g->OH; a.gOW = g->OW; a.gKW = g->KW; a.gs = g->stride; a.gp = g->pad;
+        a.greflect = g->reflect;
+    } else {
+        hipLaunchKernelGGL(h16_im2col_kernel, dim3(h16_grid((size_t)M * K / 8)), dim3(256), 0, st, gg, x, xcol);
+        a.A = xcol; a.lda = K;
+    }
     const bool fused_epilogue = p.splits == 1 && act == MG_ACT_NONE;
     if (!fused_epilogue) { a.bias = nullptr; a.round_f16 = 0; if (p.splits == 1) { a.part = part; } }
     probe_begin(st);
-    h16_launch(p, false, a, st);
+    if (sa) hgemm_sa_launch<false, true>(a, st);
+    else h16_launch(p, false, a, st);
     probe_end(st);
     if (!fused_epilogue) {
         const size_t n = (size_t)M * g->Co;
@@ -285,7 +305,8 @@ int h16_dgrad(const mg_conv_geom* g, const float* dy, const float* w, float* dx,
     a.M = (int)M; a.N = g->Ci; a.K = K; a.lda = K; a.ldb = KT * g->Ci; a.splits = p.splits; a.cps = p.cps;
     a.bias = nullptr; a.round_f16 = 1; a.accumulate = 0; a.b_cpt = g->Co / HG_BK; a.b_tap_stride = g->Ci;
     probe_begin(st);
-    h16_launch(p, true, a, st);
+    if (h16_sa_on() && hgemm_sa_ok(a)) hgemm_sa_launch<true, false>(a, st);
+    else h16_launch(p, true, a, st);
     probe_end(st);
     if (p.splits > 1) {
         const size_t n = (size_t)M * g->Ci;

@@ -2476,7 +2476,10 @@ int mg_conv_plan_name(int pass, const mg_conv_geom* g, char* out, int out_len) {
         if (pass == 0) deep = h16_deep(px, g->Co, h16_plan(px, g->Co, Kw, false).splits, false);
         else if (pass == 1) deep = h16_deep((long long)g->B * g->H * g->W, g->Ci, h16_plan((long long)g->B * g->H * g->W, g->Ci, g->KH * g->KW * g->Co, true).splits, true);
         else deep = h16_deep(g->Co, Kw, h16_plan(g->Co, Kw, h16_mp(px), false).splits, false);
-        if (pass == 2 && h16_wgrad_as(g)) snprintf(out, out_len, "hgemm_as_kernel<%d, false>", h16_mp(px) / 64);
+        HgArgs probe{};
+        probe.N = pass == 1 ? g->Ci : g->Co; probe.K = pass == 1 ? g->KH * g->KW * g->Co : Kw;
+        if (pass == 2 && h16_wgrad_as(g)) snprintf(out, out_len, "hgemm_as_kernel<%d, false, false>", h16_mp(px) / 64);
+        else if (pass != 2 && h16_sa_on() && hgemm_sa_ok(probe)) snprintf(out, out_len, pass == 1 ? "hgemm_sa_kernel<true, false>" : "hgemm_sa_kernel<false, true>");
         else
         snprintf(out, out_len, pass == 1 ? "hgemm_kernel<128, 128, 4, 2, true, %d>" : "hgemm_kernel<128, 128, 4, 2, false, %d>", deep ? 3 : 2);
     } else if (wino_ok(g) && !kq && 
@@ -2806,7 +2809,8 @@ int mg_conv_fwd_w(const mg_conv_geom* g, const float* x, const float* w, const f
     const float* u = wt ? wt->u : nullptr;
     if (h16_ok(g) && workspace && workspace_bytes >= h16_fwd_ws(g) && aligned16(x) && aligned16(w) && aligned16(y) &&
         aligned16(workspace) && (!bias || aligned16(bias)))
-        return h16_fwd(g, x, w, bias, y, act, (char*)workspace, (hipStream_t)stream, u);
+        return h16_fwd(g, x, w, bias, y, act, (char*)workspace, (hipStream_t)stream, u,
+                       (wt && wt->v && (wt->flags & MG_TILES_V_FILLED)) ? (const void*)wt->v : nullptr);
     if (co1_gemm_ok(g) && workspace && workspace_bytes >= co1_fwd_ws(g) && aligned16(x) && aligned16(w) && aligned16(workspace))
         return co1_fwd(g, x, w, bias, y, act, (char*)workspace, (hipStream_t)stream, u, wt ? wt->v : nullptr);
     if (mg_conv_rowdot_kq(g) && aligned16(x) && aligned16(w)) {

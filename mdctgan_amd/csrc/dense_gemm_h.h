@@ -58,6 +58,10 @@ struct HgArgs {
     // k = tap * Co + co, i.e. k row (tap, co) starts at element (co * ldb + tap * b_tap_stride); ldb = KH*KW*Ci is the
     // distance between consecutive co, b_cpt = Co / 64 the chunks per tap.  A plain [K][N] matrix: ldb = N, b_cpt = 1 << 30.
     int b_cpt, b_tap_stride;
+    // A-gather (hgemm_sa_kernel<.., AG = true>, the forward pass without an im2col matrix): A is the float16 activation
+    // x16 [B*H*W][Ci] (lda = Ci) and row m of the GEMM at chunk c reads pixel src(m, tap = c / a_cpt) -- zero padding is an
+    // out-of-range buffer offset, reflection a reflected index.  K = KH*KW*Ci, a_cpt = Ci / 64.
+    int a_cpt, gH, gW, gOH, gOW, gKW, gs, gp, greflect;
 };
 
 template <int BM, int BN, int WGM, int WGN, bool BRC = false, int NBUF = 2>
@@ -459,4 +463,223 @@ inline void hgemm_as_launch(const void* A, const void* B, void* C, long long M, 
         case 3: hgemm_as_go<3>(a, tiles_m * groups, st, c_half); break;
         default: hgemm_as_go<4>(a, tiles_m * groups, st, c_half); break;
     }
+}
+
+// ---- Loader waves and separate rings for A and B: the weight-STREAMING form (round 6) ----
+// Forward / data gradient of the small-spatial trunk: M = 256 pixels, N = 2048, K = 18432 -- 75 MB of cold float16 weights against
+// an activation matrix that lives in L2.  hgemm_kernel stages A and B through ONE ring of 32 KiB chunks issued by the MFMA waves
+// themselves, so a CU holds 2 chunks = 32 KiB of WEIGHT bytes in flight: 8 MB chip-wide against an HBM latency that needs ~14 MB
+// for 5.5 TB/s (measured 24-27 us per launch = 3 TB/s).  Here (hgemm_as_kernel's scheme, both operands streamed) two loader waves
+// fill a B ring of NBB = 6 buffers -- 5 chunks = 80 KiB of weights in flight per CU -- two more an A ring of NA = 3 (the
+// activations come from L2: two chunks ahead cover that latency), each loader counts only its own DMA's vmcnt, and the eight
+// MFMA waves issue no memory instruction inside the loop.  AG: the A loaders gather the rows from the float16 activation itself
+// (source pixel per row and tap, zero padding = an out-of-range offset): no im2col matrix exists.
+// Same operand values and the same chunk order per accumulator as hgemm_kernel: bit-identical results.
+constexpr int HG_SA_NA = 3, HG_SA_NBB = 6, HG_SA_LW = 2;       // buffers of the A / B rings; loader waves PER ring
+
+template <bool BRC, bool AG>
+__global__ __launch_bounds__(64 * (8 + 2 * HG_SA_LW)) void hgemm_sa_kernel(HgArgs g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NA = HG_SA_NA, NBB = HG_SA_NBB, LW = HG_SA_LW, SZ = 128 * 32;      // 32-bit words per 16 KiB buffer
+    constexpr int PPW = 16 / LW;                            // 1 KiB pieces per loader wave and chunk
+    static_assert((NBB - 2) * PPW <= 63 && (NA - 2) * PPW <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(1024))) float hg_sa_smem[];
+    float* const As0 = hg_sa_smem;
+    float* const Bs0 = hg_sa_smem + NA * SZ;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = g.tiles_m * g.tiles_n;
+    const int L = xcd_remap(blockIdx.x, tiles * g.splits);
+    const int sp = L / tiles, rem = L - sp * tiles;
+    const int tn = rem / g.tiles_m, tm = rem - tn * g.tiles_m;
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int total_chunks = g.K / HG_BK;
+    const int c_begin = sp * g.cps, c_end = min(total_chunks, c_begin + g.cps);
+    const int Q = c_end - c_begin;
+    constexpr unsigned OOB = 0x80000000u;
+
+    if (wave >= 8 + LW) {
+        // ---- A loader waves ----
+        const int lw = wave - 8 - LW;
+        const unsigned long long a = (unsigned long long)g.A;
+        const unsigned a_bytes = AG ? (unsigned)(g.M / (g.gOH * g.gOW)) * (unsigned)(g.gH * g.gW) * (unsigned)g.lda * 2u      // x16 [B*H*W][Ci]
+                                    : (unsigned)g.M * (unsigned)g.lda * 2u;
+        dg_v4i ra;
+        ra[0] = (int)(unsigned)a;
+        ra[1] = (int)((unsigned)(a >> 32) & 0xffffu);
+        ra[2] = (int)a_bytes;
+        ra[3] = 0x00020000;
+        unsigned va[PPW];
+        int gb[PPW], goy[PPW], gox[PPW];
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int row = 8 * (lw * PPW + i) + (lane >> 3), q = (lane & 7) ^ ((row >> 1) & 7);
+            const int m = m0 + row;
+            va[i] = m < g.M ? (unsigned)m * (unsigned)g.lda * 2u + 16u * q : OOB;      // rows past M read zeros (never stored)
+            if (AG) {
+                const int hw = g.gOH * g.gOW, mm = min(m, g.M - 1);
+                gb[i] = mm / hw;
+                const int rm = mm - gb[i] * hw;
+                goy[i] = rm / g.gOW;
+                gox[i] = rm - goy[i] * g.gOW;
+            }
+        }
+        int cur_tap = -1;
+        const unsigned lds0 = (unsigned)(size_t)(dg_lds_ptr)As0 + (unsigned)(lw * PPW) * 1024u;
+        auto issue = [&](int q, int buf) {
+            const int c = c_begin + q;
+            unsigned soff = (unsigned)c * (HG_BK * 2u);
+            if constexpr (AG) {
+                const int tap = c / g.a_cpt, cc = c - tap * g.a_cpt;
+                soff = (unsigned)cc * (HG_BK * 2u);
+                if (tap != cur_tap) {                           // the source pixel of every row of this lane for the new tap
+                    cur_tap = tap;
+                    const int ky = tap / g.gKW, kx = tap - ky * g.gKW;
+#pragma unroll
+                    for (int i = 0; i < PPW; ++i) {
+                        const int row = 8 * (lw * PPW + i) + (lane >> 3), qs = (lane & 7) ^ ((row >> 1) & 7);
+                        int iy = goy[i] * g.gs - g.gp + ky, ix = gox[i] * g.gs - g.gp + kx;
+                        bool ok = m0 + row < g.M;
+                        if (g.greflect) {
+                            iy = iy < 0 ? -iy : (iy >= g.gH ? 2 * (g.gH - 1) - iy : iy);
+                            ix = ix < 0 ? -ix : (ix >= g.gW ? 2 * (g.gW - 1) - ix : ix);
+                        } else {
+                            ok = ok && iy >= 0 && iy < g.gH && ix >= 0 && ix < g.gW;
+                        }
+                        va[i] = ok ? (unsigned)((gb[i] * g.gH + iy) * g.gW + ix) * (unsigned)g.lda * 2u + 16u * qs : OOB;
+                    }
+                }
+            }
+            const unsigned la = lds0 + (unsigned)buf * (unsigned)(SZ * 4);
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) dg_dma16(va[i], ra, la + 1024u * i, soff);
+        };
+#pragma unroll
+        for (int i = 0; i < NA - 1; ++i)
+            if (i < Q) issue(i, i);
+        int nxt = (NA - 1) % NA;
+        for (int q = 0; q < Q; ++q) {
+            if (q + (NA - 1) > Q) dg_wait_vmcnt<0>();
+            else dg_wait_vmcnt<(NA - 2) * PPW>();
+            __builtin_amdgcn_s_barrier();                   // chunk q is in LDS; everybody is done with chunk q - 1
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + (NA - 1) < Q) issue(q + (NA - 1), nxt);
+            nxt = nxt + 1 == NA ? 0 : nxt + 1;
+        }
+        return;
+    }
+    if (wave >= 8) {
+        // ---- B loader waves ----
+        const int lw = wave - 8;
+        const unsigned long long a = (unsigned long long)g.B;
+        dg_v4i rb;
+        rb[0] = (int)(unsigned)a;
+        rb[1] = (int)((unsigned)(a >> 32) & 0xffffu);
+        rb[2] = BRC ? 0x7fffffff : (int)((unsigned)g.N * (unsigned)g.ldb * 2u);
+        rb[3] = 0x00020000;
+        unsigned vb[PPW];
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int piece = lw * PPW + i;
+            if constexpr (BRC) {
+                const int k = piece * 4 + (lane >> 4), c8 = (lane & 15) ^ cd_rc_swz<128>(k);      // a piece = 4 whole k rows of 128 columns
+                vb[i] = ((unsigned)k * (unsigned)g.ldb + (unsigned)min(n0 + 8 * c8, g.N - 8)) * 2u;
+            } else {
+                const int row = 8 * piece + (lane >> 3), q = (lane & 7) ^ ((row >> 1) & 7);
+                vb[i] = (unsigned)min(n0 + row, g.N - 1) * (unsigned)g.ldb * 2u + 16u * q;
+            }
+        }
+        const unsigned lds0 = (unsigned)(size_t)(dg_lds_ptr)Bs0 + (unsigned)(lw * PPW) * 1024u;
+        auto issue = [&](int q, int buf) {
+            const int c = c_begin + q;
+            unsigned soff = (unsigned)c * (HG_BK * 2u);
+            if (BRC) {
+                const int tap = c / g.b_cpt, cc = c - tap * g.b_cpt;
+                soff = ((unsigned)tap * (unsigned)g.b_tap_stride + (unsigned)cc * (unsigned)HG_BK * (unsigned)g.ldb) * 2u;
+            }
+            const unsigned lb = lds0 + (unsigned)buf * (unsigned)(SZ * 4);
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) dg_dma16(vb[i], rb, lb + 1024u * i, soff);
+        };
+#pragma unroll
+        for (int i = 0; i < NBB - 1; ++i)
+            if (i < Q) issue(i, i);
+        int nxt = (NBB - 1) % NBB;
+        for (int q = 0; q < Q; ++q) {
+            if (q + (NBB - 1) > Q) dg_wait_vmcnt<0>();
+            else dg_wait_vmcnt<(NBB - 2) * PPW>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + (NBB - 1) < Q) issue(q + (NBB - 1), nxt);
+            nxt = nxt + 1 == NBB ? 0 : nxt + 1;
+        }
+        return;
+    }
+
+    // ---- MFMA waves: 4 (rows) x 2 (columns), 32 x 64 results each; no memory instruction inside the loop ----
+    const int wm = wave >> 1, wn0 = (wave & 1) * 64;
+    const int r = lane & 31, kh = lane >> 5;
+    f32x16 acc[2] = {f32x16{0}, f32x16{0}};
+    int ca = 0, cb = 0;
+    for (int q = 0; q < Q; ++q) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const float* As = As0 + ca * SZ;
+        const float* Bs = Bs0 + cb * SZ;
+        f16x8 a[2], b[2][2];
+        auto fetch = [&](int s, int buf) {
+            a[buf] = cd_frag_kc(As, 32 * wm + r, s, kh);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                if constexpr (BRC) b[buf][ni] = cd_frag_rc<128>(Bs, wn0 + 32 * ni, s, lane);
+                else b[buf][ni] = cd_frag_kc(Bs, wn0 + 32 * ni + r, s, kh);
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s + 1 < 4) fetch(s + 1, (s + 1) & 1);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[ni] = mfma32x32x16h(a[s & 1], b[s & 1][ni], acc[ni]);
+        }
+        ca = ca + 1 == NA ? 0 : ca + 1;
+        cb = cb + 1 == NBB ? 0 : cb + 1;
+    }
+    float* o = g.part ? g.part + (size_t)sp * ((size_t)g.M * g.N) : g.C;
+    const bool direct = g.part == nullptr;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int col = n0 + wn0 + 32 * ni + (lane & 31);
+        const float bv = (direct && g.bias && col < g.N) ? g.bias[col] : 0.0f;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = m0 + 32 * wm + mfma32_row(rr, lane);
+            if (row < g.M && col < g.N) {
+                float v = acc[ni][rr];
+                if (direct) {
+                    v += bv;
+                    if (g.round_f16) v = round_h(v);
+                    if (g.accumulate) v += o[(size_t)row * g.N + col];
+                }
+                o[(size_t)row * g.N + col] = v;
+            }
+        }
+    }
+#endif
+}
+
+inline bool hgemm_sa_ok(const HgArgs& a) { return a.N % 128 == 0 && a.K % HG_BK == 0; }
+template <bool BRC, bool AG>
+inline void hgemm_sa_launch(const HgArgs& a0, hipStream_t st) {
+    HgArgs a = a0;
+    a.tiles_m = (a.M + 127) / 128;
+    a.tiles_n = a.N / 128;
+    constexpr size_t lds = (size_t)(HG_SA_NA + HG_SA_NBB) * 128 * 32 * 4;
+    static bool once = false;
+    if (!once) {
+        hipFuncSetAttribute((const void*)hgemm_sa_kernel<BRC, AG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        once = true;
+    }
+    const unsigned grid = (unsigned)((long long)a.tiles_m * a.tiles_n * a.splits);
+    mg_launch(hgemm_sa_kernel<BRC, AG>, dim3(grid), dim3(64 * (8 + 2 * HG_SA_LW)), lds, st, a);
 }

@@ -105,7 +105,9 @@ def precast_ok(pass_id: int, g: ConvGeom) -> bool:
     hit = _CASTS.get(key)
     if hit is None:
         name = plan_name(pass_id, g)
-        hit = _CASTS[key] = name.startswith(("conv_fwd_dma_kernel", "conv_dgrad_dma_kernel")[pass_id]) and ", true" in name
+        hit = name.startswith(("conv_fwd_dma_kernel", "conv_dgrad_dma_kernel")[pass_id]) and ", true" in name
+        # ... and (round 6) the forward pass of the weight-streaming layers, whose GEMM gathers its rows from float16(x) itself
+        hit = _CASTS[key] = hit or (pass_id == 0 and name.startswith("hgemm_sa_kernel<false, true>"))
     return hit
 
 

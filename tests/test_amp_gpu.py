@@ -562,3 +562,35 @@ def test_segmented_fp16_optimizer_passes():
     b[3].grad.copy_(g3.to(DEV)); b[3]._mg_fresh = False
     oa.step(); ob.step()
     assert torch.equal(a[3].detach(), b[3].detach()) and torch.equal(oa.flat_m, ob.flat_m) and torch.equal(oa.flat_v, ob.flat_v)
+
+
+@pytest.mark.parametrize("case", [("trunk_256_4x8_reflect", 8, 256, 256, 4, 8, 3, 1, True), ("trunk_2048_4x8_reflect", 8, 2048, 2048, 4, 8, 3, 1, True),
+                                  ("zero_pad_512_4x8", 8, 512, 512, 4, 8, 3, 1, False), ("ragged_rows_3x4x8", 3, 256, 256, 4, 8, 3, 1, True),
+                                  ("bot_1x1_2048_512", 8, 2048, 512, 4, 8, 1, 0, False), ("bot_1x1_512_2048", 8, 512, 2048, 4, 8, 1, 0, False)],
+                         ids=lambda c: c[0])
+def test_weight_streaming_gemm_equals_the_im2col_gemm(case, monkeypatch):
+    """Round 6: forward and data gradient of the weight-streaming --fp16 layers run hgemm_sa_kernel (loader waves, a 6-deep ring for
+    the weights and a 3-deep one for the activations; the forward GATHERS its rows from float16(x), no im2col matrix) -- the same
+    float16 operands in the same chunk order per accumulator as the im2col + hgemm_kernel pair (MG_NO_HGEMM_SA=1): bit for bit, also
+    with float16(x) handed over by the producer (MG_TILES_V_FILLED) and with the skip gradient riding in the epilogue."""
+    from mdctgan_amd import _lib, ops
+    name, B, Ci, Co, H, W, k, pad, reflect = case
+    g = ops.conv_geom(B, H, W, Ci, Co, k, k, 1, pad, reflect, _lib.PRECISION_F16)
+    assert ops.plan_name(0, g).startswith("hgemm_sa_kernel<false, true>") and ops.plan_name(1, g).startswith("hgemm_sa_kernel<true, false>")
+    assert ops.precast_ok(0, g)
+    gen = torch.Generator().manual_seed(len(name))
+    x = torch.randn(B, H, W, Ci, generator=gen).to(DEV)
+    w = (torch.randn(Co, k, k, Ci, generator=gen) / np.sqrt(k * k * Ci)).to(DEV)
+    b = torch.randn(Co, generator=gen).to(DEV)
+    dy = torch.randn(B, g.OH, g.OW, Co, generator=gen).to(DEV)
+    skip = torch.randn(B, H, W, Ci, generator=gen).to(DEV)
+    u = ops.wino_weights(g, w)                                   # the float16 weight copy both passes share
+    x16 = x.half().reshape(-1)
+    got = (ops.conv_fwd(g, x, w, b), ops.conv_fwd(g, x, w, b, u=u, v_out=x16, v_filled=True), ops.conv_dgrad(g, dy, w, u=u),
+           ops.conv_dgrad(g, dy, w, add=skip))
+    monkeypatch.setenv("MG_NO_HGEMM_SA", "1")
+    assert ops.plan_name(0, g).startswith("hgemm_kernel<")
+    ref = (ops.conv_fwd(g, x, w, b), ops.conv_dgrad(g, dy, w, u=u))
+    monkeypatch.delenv("MG_NO_HGEMM_SA")
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[0])
+    assert torch.equal(got[2], ref[1]) and torch.equal(got[3], ref[1] + skip)
