@@ -477,10 +477,14 @@ inline void hgemm_as_launch(const void* A, const void* B, void* C, long long M, 
 // Same operand values and the same chunk order per accumulator as hgemm_kernel: bit-identical results.
 constexpr int HG_SA_NA = 3, HG_SA_NBB = 6, HG_SA_LW = 2;       // buffers of the A / B rings; loader waves PER ring
 
-template <bool BRC, bool AG>
-__global__ __launch_bounds__(64 * (8 + 2 * HG_SA_LW)) void hgemm_sa_kernel(HgArgs g) {
+// WGM x WGN MFMA waves over the 128 x 128 tile: 4 x 2 (32 x 64 results per wave: 12 ds_read_b128 per 8 MFMAs) or 2 x 2 (64 x 64: 16
+// reads per 16 MFMAs -- a third fewer LDS bytes per MFMA, which is what bounds the 8-wave form on this part: 768 LDS cycles against 512
+// MFMA cycles per chunk).
+template <bool BRC, bool AG, int WGM = 4, int WGN = 2>
+__global__ __launch_bounds__(64 * (WGM * WGN + 2 * HG_SA_LW)) void hgemm_sa_kernel(HgArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NA = HG_SA_NA, NBB = HG_SA_NBB, LW = HG_SA_LW, SZ = 128 * 32;      // 32-bit words per 16 KiB buffer
+    constexpr int NMW = WGM * WGN, MB = 128 / WGM / 32, NB = 128 / WGN / 32;
     constexpr int PPW = 16 / LW;                            // 1 KiB pieces per loader wave and chunk
     static_assert((NBB - 2) * PPW <= 63 && (NA - 2) * PPW <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(1024))) float hg_sa_smem[];
@@ -498,9 +502,9 @@ __global__ __launch_bounds__(64 * (8 + 2 * HG_SA_LW)) void hgemm_sa_kernel(HgArg
     const int Q = c_end - c_begin;
     constexpr unsigned OOB = 0x80000000u;
 
-    if (wave >= 8 + LW) {
+    if (wave >= NMW + LW) {
         // ---- A loader waves ----
-        const int lw = wave - 8 - LW;
+        const int lw = wave - NMW - LW;
         const unsigned long long a = (unsigned long long)g.A;
         const unsigned a_bytes = AG ? (unsigned)(g.M / (g.gOH * g.gOW)) * (unsigned)(g.gH * g.gW) * (unsigned)g.lda * 2u      // x16 [B*H*W][Ci]
                                     : (unsigned)g.M * (unsigned)g.lda * 2u;
@@ -568,9 +572,9 @@ __global__ __launch_bounds__(64 * (8 + 2 * HG_SA_LW)) void hgemm_sa_kernel(HgArg
         }
         return;
     }
-    if (wave >= 8) {
+    if (wave >= NMW) {
         // ---- B loader waves ----
-        const int lw = wave - 8;
+        const int lw = wave - NMW;
         const unsigned long long a = (unsigned long long)g.B;
         dg_v4i rb;
         rb[0] = (int)(unsigned)a;
@@ -616,21 +620,26 @@ __global__ __launch_bounds__(64 * (8 + 2 * HG_SA_LW)) void hgemm_sa_kernel(HgArg
         return;
     }
 
-    // ---- MFMA waves: 4 (rows) x 2 (columns), 32 x 64 results each; no memory instruction inside the loop ----
-    const int wm = wave >> 1, wn0 = (wave & 1) * 64;
+    // ---- MFMA waves: WGM (rows) x WGN (columns); no memory instruction inside the loop ----
+    const int wm0 = (wave / WGN) * (128 / WGM), wn0 = (wave % WGN) * (128 / WGN);
     const int r = lane & 31, kh = lane >> 5;
-    f32x16 acc[2] = {f32x16{0}, f32x16{0}};
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = f32x16{0};
     int ca = 0, cb = 0;
     for (int q = 0; q < Q; ++q) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         const float* As = As0 + ca * SZ;
         const float* Bs = Bs0 + cb * SZ;
-        f16x8 a[2], b[2][2];
+        f16x8 a[2][MB], b[2][NB];
         auto fetch = [&](int s, int buf) {
-            a[buf] = cd_frag_kc(As, 32 * wm + r, s, kh);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
+            for (int mi = 0; mi < MB; ++mi) a[buf][mi] = cd_frag_kc(As, wm0 + 32 * mi + r, s, kh);
+#pragma unroll
+            for (int ni = 0; ni < NB; ++ni) {
                 if constexpr (BRC) b[buf][ni] = cd_frag_rc<128>(Bs, wn0 + 32 * ni, s, lane);
                 else b[buf][ni] = cd_frag_kc(Bs, wn0 + 32 * ni + r, s, kh);
             }
@@ -639,8 +648,12 @@ __global__ __launch_bounds__(64 * (8 + 2 * HG_SA_LW)) void hgemm_sa_kernel(HgArg
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if (s + 1 < 4) fetch(s + 1, (s + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[ni] = mfma32x32x16h(a[s & 1], b[s & 1][ni], acc[ni]);
+            for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = mfma32x32x16h(a[s & 1][mi], b[s & 1][ni], acc[mi][ni]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         ca = ca + 1 == NA ? 0 : ca + 1;
         cb = cb + 1 == NBB ? 0 : cb + 1;
@@ -648,28 +661,30 @@ __global__ __launch_bounds__(64 * (8 + 2 * HG_SA_LW)) void hgemm_sa_kernel(HgArg
     float* o = g.part ? g.part + (size_t)sp * ((size_t)g.M * g.N) : g.C;
     const bool direct = g.part == nullptr;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int col = n0 + wn0 + 32 * ni + (lane & 31);
-        const float bv = (direct && g.bias && col < g.N) ? g.bias[col] : 0.0f;
+    for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-            const int row = m0 + 32 * wm + mfma32_row(rr, lane);
-            if (row < g.M && col < g.N) {
-                float v = acc[ni][rr];
-                if (direct) {
-                    v += bv;
-                    if (g.round_f16) v = round_h(v);
-                    if (g.accumulate) v += o[(size_t)row * g.N + col];
+        for (int ni = 0; ni < NB; ++ni) {
+            const int col = n0 + wn0 + 32 * ni + (lane & 31);
+            const float bv = (direct && g.bias && col < g.N) ? g.bias[col] : 0.0f;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int row = m0 + wm0 + 32 * mi + mfma32_row(rr, lane);
+                if (row < g.M && col < g.N) {
+                    float v = acc[mi][ni][rr];
+                    if (direct) {
+                        v += bv;
+                        if (g.round_f16) v = round_h(v);
+                        if (g.accumulate) v += o[(size_t)row * g.N + col];
+                    }
+                    o[(size_t)row * g.N + col] = v;
                 }
-                o[(size_t)row * g.N + col] = v;
             }
         }
-    }
 #endif
 }
 
 inline bool hgemm_sa_ok(const HgArgs& a) { return a.N % 128 == 0 && a.K % HG_BK == 0; }
-template <bool BRC, bool AG>
+template <bool BRC, bool AG, int WGM = 4, int WGN = 2>
 inline void hgemm_sa_launch(const HgArgs& a0, hipStream_t st) {
     HgArgs a = a0;
     a.tiles_m = (a.M + 127) / 128;
@@ -677,9 +692,9 @@ inline void hgemm_sa_launch(const HgArgs& a0, hipStream_t st) {
     constexpr size_t lds = (size_t)(HG_SA_NA + HG_SA_NBB) * 128 * 32 * 4;
     static bool once = false;
     if (!once) {
-        hipFuncSetAttribute((const void*)hgemm_sa_kernel<BRC, AG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)hgemm_sa_kernel<BRC, AG, WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         once = true;
     }
     const unsigned grid = (unsigned)((long long)a.tiles_m * a.tiles_n * a.splits);
-    mg_launch(hgemm_sa_kernel<BRC, AG>, dim3(grid), dim3(64 * (8 + 2 * HG_SA_LW)), lds, st, a);
+    mg_launch(hgemm_sa_kernel<BRC, AG, WGM, WGN>, dim3(grid), dim3(64 * (WGM * WGN + 2 * HG_SA_LW)), lds, st, a);
 }

@@ -66,12 +66,12 @@ __global__ void ref_rc_kernel(const _Float16* A, const _Float16* B, float* out, 
 }
 #define VR(BM, BN, WM, WN) {#BM "x" #BN "/" #WM "x" #WN " rc", BM, BN, hgemm_launch<BM, BN, WM, WN, true>}
 #define VRN(BM, BN, WM, WN, NB) {#BM "x" #BN "/" #WM "x" #WN " rc n" #NB, BM, BN, hgemm_launch<BM, BN, WM, WN, true, NB>}
-const Variant vrc[] = {{"SA ring8 rc", 128, 128, hgemm_sa_launch<true, false>}, VR(128, 64, 2, 2), VR(128, 128, 4, 2), VR(256, 64, 4, 2), VR(256, 128, 4, 2),
+const Variant vrc[] = {{"SA 4x2 rc", 128, 128, hgemm_sa_launch<true, false>}, {"SA 2x2 rc", 128, 128, hgemm_sa_launch<true, false, 2, 2>}, {"SA 2x4 rc", 128, 128, hgemm_sa_launch<true, false, 2, 4>}, VR(128, 64, 2, 2), VR(128, 128, 4, 2), VR(256, 64, 4, 2), VR(256, 128, 4, 2),
                        VRN(128, 64, 2, 2, 3), VRN(128, 64, 2, 2, 4), VRN(128, 128, 4, 2, 3), VRN(128, 128, 4, 2, 4), VRN(256, 64, 4, 2, 3), VRN(256, 64, 4, 2, 4),
                        VRN(256, 128, 4, 2, 3)};
 #define V(BM, BN, WM, WN) {#BM "x" #BN "/" #WM "x" #WN, BM, BN, hgemm_launch<BM, BN, WM, WN>}
 #define VN(BM, BN, WM, WN, NB) {#BM "x" #BN "/" #WM "x" #WN " n" #NB, BM, BN, hgemm_launch<BM, BN, WM, WN, false, NB>}
-const Variant vs[] = {{"SA ring8", 128, 128, hgemm_sa_launch<false, false>}, V(128, 64, 2, 2), V(128, 128, 2, 2), V(128, 128, 4, 2), V(256, 64, 4, 2), V(256, 128, 4, 2), V(256, 256, 4, 2),
+const Variant vs[] = {{"SA 4x2", 128, 128, hgemm_sa_launch<false, false>}, {"SA 2x2", 128, 128, hgemm_sa_launch<false, false, 2, 2>}, {"SA 2x4", 128, 128, hgemm_sa_launch<false, false, 2, 4>}, {"SA 4x1", 128, 128, hgemm_sa_launch<false, false, 4, 1>}, V(128, 64, 2, 2), V(128, 128, 2, 2), V(128, 128, 4, 2), V(256, 64, 4, 2), V(256, 128, 4, 2), V(256, 256, 4, 2),
                       V(256, 128, 2, 2), V(256, 256, 2, 2), V(512, 128, 4, 2), V(256, 128, 4, 1), V(512, 128, 4, 1),
                       VN(128, 64, 2, 2, 3), VN(128, 64, 2, 2, 4), VN(128, 128, 2, 2, 3), VN(128, 128, 2, 2, 4), VN(128, 128, 4, 2, 3), VN(128, 128, 4, 2, 4),
                       VN(256, 64, 4, 2, 3), VN(256, 64, 4, 2, 4), VN(256, 128, 4, 2, 3), VN(256, 256, 4, 2, 3) };

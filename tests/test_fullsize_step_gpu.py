@@ -542,7 +542,8 @@ def test_full_size_step_gradients_mask_pinned(tag, fp16, batch, force_plan, monk
             # a one-element gradient (the 64 -> 1 head's bias) is a signed sum that cancels to ~1e-3 of its terms: no averaging.
             # The bar: rounding (1e-4) -- or, where float32 arithmetic itself is further from float64 on this graph with
             # the decisions shared (the yardstick), 3 x that; --fp16: 1.25 x the reference arithmetic's own error + 2e-2.
-            ok = (err <= 1.25 * e_y + bar) if fp16 else (err <= max(bar * (8.0 if g64.size == 1 else 1.0), 3.0 * e_y))
+            one = 8.0 if g64.size == 1 else 1.0
+            ok = (err <= 1.25 * e_y + bar * one) if fp16 else (err <= max(bar * one, 3.0 * e_y))
             if not ok:
                 bad.append((pre + k, "rel-L2 %.3e" % err, "CPU yardstick on the same decisions %.3e" % e_y))
     import json
