@@ -467,13 +467,16 @@ inline void hgemm_as_launch(const void* A, const void* B, void* C, long long M, 
 
 // ---- Loader waves and separate rings for A and B: the weight-STREAMING form (round 6) ----
 // Forward / data gradient of the small-spatial trunk: M = 256 pixels, N = 2048, K = 18432 -- 75 MB of cold float16 weights against
-// an activation matrix that lives in L2.  hgemm_kernel stages A and B through ONE ring of 32 KiB chunks issued by the MFMA waves
-// themselves, so a CU holds 2 chunks = 32 KiB of WEIGHT bytes in flight: 8 MB chip-wide against an HBM latency that needs ~14 MB
-// for 5.5 TB/s (measured 24-27 us per launch = 3 TB/s).  Here (hgemm_as_kernel's scheme, both operands streamed) two loader waves
-// fill a B ring of NBB = 6 buffers -- 5 chunks = 80 KiB of weights in flight per CU -- two more an A ring of NA = 3 (the
-// activations come from L2: two chunks ahead cover that latency), each loader counts only its own DMA's vmcnt, and the eight
-// MFMA waves issue no memory instruction inside the loop.  AG: the A loaders gather the rows from the float16 activation itself
-// (source pixel per row and tap, zero padding = an out-of-range offset): no im2col matrix exists.
+// an activation matrix that lives in L2.  hgemm_as_kernel's scheme with both operands streamed: two loader waves fill a B ring of
+// NBB = 6 buffers (5 chunks = 80 KiB of weights in flight per CU), two more an A ring of NA = 3, each loader counts only its own
+// DMA's vmcnt, and the MFMA waves issue no memory instruction inside the loop.  AG: the A loaders GATHER the rows from the float16
+// activation itself (source pixel per row and tap; zero padding = an out-of-range offset): no im2col matrix exists -- that launch
+// and its 9x traffic are what this kernel removes from the step.
+// What it does NOT change is the GEMM's own time (scripts/ubench/hgemm_bench, profiles/r06_hgemm_sa_ubench.log: 34.4 vs 34.9 us
+// with the harness's reduce launch included, cold weights): ring depth 3 -> 6, MFMA wave tiles 32x64 / 64x64 / 64x32 / 32x128 and
+// even weights stored as contiguous 16 KiB blocks all land within 3 % -- the shape is bound by neither HBM latency, LDS reads nor
+// DRAM locality but by the matrix pipe at the clock this part holds under dense float16 MFMAs (HISTORY.md section 3 "Round 5":
+// 1.1-1.25 PF = 15.5-17.6 us for these 19.3 GFLOP) plus the fill / drain of 256 single-round workgroups.
 // Same operand values and the same chunk order per accumulator as hgemm_kernel: bit-identical results.
 constexpr int HG_SA_NA = 3, HG_SA_NBB = 6, HG_SA_LW = 2;       // buffers of the A / B rings; loader waves PER ring
 
