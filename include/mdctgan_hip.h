@@ -341,6 +341,11 @@ int mg_instnorm_fwd_h(const float* x, int B, int HW, int C, float eps, int act, 
                       float* mean, float* rstd, void* workspace, size_t workspace_bytes, void* stream, void* y16);
 int mg_instnorm_bwd_h(const float* dy, const float* x, const float* mean, const float* rstd, int B, int HW, int C,
                       int act, float* dx, void* workspace, size_t workspace_bytes, void* stream, void* dx16);
+/* Round 6: the same passes with a SECOND gradient of the tensor (dy2, nullable): the kernels read dy + dy2 (one float32 addition per
+ * element, exactly autograd's accumulation add) -- a discriminator feature map has two consumers, the next layer and the
+ * feature-matching loss (pix2pixHD_model.py:443-451), and the loss's gradient joins the layer's here instead of in an add launch. */
+int mg_instnorm_bwd_add(const float* dy, const float* dy2, const float* x, const float* mean, const float* rstd, int B, int HW, int C,
+                        int act, float* dx, void* workspace, size_t workspace_bytes, void* stream, void* dx16);
 
 /* ------------------------------------------------------------------------------------------
  * K10  bottleneck-transformer block pieces (bottleneck_transformer_pytorch==0.1.4 BottleStack, call sites
@@ -382,6 +387,7 @@ size_t mg_attention_bwd_workspace(int B, int fh, int fw, int heads, int d);
 
 /* K7  elementwise activation backward for conv epilogues: dx = dy * act'(y)  (in place allowed) */
 int mg_act_bwd(const float* dy, const float* y, float* dx, long long n, int act, void* stream);
+int mg_act_bwd_add(const float* dy, const float* dy2, const float* y, float* dx, long long n, int act, void* stream);
 /* out = a + b (residual joins outside a norm), in place allowed */
 int mg_add(const float* a, const float* b, float* out, long long n, void* stream);
 

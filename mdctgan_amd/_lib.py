@@ -110,6 +110,7 @@ SIGNATURES = {
     "mg_instnorm_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _sz, _p]),
     "mg_instnorm_fwd_h": (_i, [_p, _i, _i, _i, _f, _i, _p, _p, _p, _p, _p, _sz, _p, _p]),
     "mg_instnorm_bwd_h": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _sz, _p, _p]),
+    "mg_instnorm_bwd_add": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _sz, _p, _p]),
     "mg_instnorm_workspace": (_sz, [_i, _i, _i]),
     "mg_batchnorm_workspace": (_sz, [_i]),
     "mg_batchnorm_slices": (_i, []),
@@ -121,6 +122,7 @@ SIGNATURES = {
     "mg_attention_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _sz, _p]),
     "mg_attention_bwd_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "mg_act_bwd": (_i, [_p, _p, _p, _ll, _i, _p]),
+    "mg_act_bwd_add": (_i, [_p, _p, _p, _p, _ll, _i, _p]),
     "mg_add": (_i, [_p, _p, _p, _ll, _p]),
     "mg_avgpool3s2_fwd": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "mg_avgpool3s2_bwd": (_i, [_p, _i, _i, _i, _i, _p, _p]),

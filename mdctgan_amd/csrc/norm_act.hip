@@ -47,11 +47,14 @@ NormPlan norm_plan(int B, int HW, int C) {
 // partial per-(b, c) sums over a slice of pixels.  MODE 0: (sum x, sum x^2).
 // MODE 1 (backward): g = dy * act'(xhat); (sum g, sum g * xhat).
 // VEC: 16 lanes x float4 cover the block's 64 channels (256 B per pixel), 16 pixel rows in flight per iteration.
+// dy2 (optional, MODE 1): a second gradient of the same tensor (dy + dy2, one float32 addition -- what autograd's accumulation add
+// computes when the tensor has two consumers: the discriminator features that also feed the feature-matching loss)
 template <int MODE, bool VEC>
 __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, int HW, int C,
-                                                           int rows_per_split, int act, double* __restrict__ part) {
+                                                           int rows_per_split, int act, double* __restrict__ part,
+                                                           const float* __restrict__ dy2 = nullptr) {
     constexpr int V = VEC ? 4 : 1, CL = 64 / V, RG = 256 / CL;
     __shared__ double red[2][RG][64];
     const int cl = threadIdx.x % CL, rg = threadIdx.x / CL;
@@ -74,9 +77,13 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
             if (VEC) {
                 *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + base + (size_t)p * C);
                 if (MODE == 1) *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(dy + base + (size_t)p * C);
+                if (MODE == 1 && dy2) {
+                    const float4 e = *reinterpret_cast<const float4*>(dy2 + base + (size_t)p * C);
+                    gv[0] += e.x; gv[1] += e.y; gv[2] += e.z; gv[3] += e.w;
+                }
             } else {
                 xv[0] = x[base + (size_t)p * C];
-                if (MODE == 1) gv[0] = dy[base + (size_t)p * C];
+                if (MODE == 1) { gv[0] = dy[base + (size_t)p * C]; if (dy2) gv[0] += dy2[base + (size_t)p * C]; }
             }
 #pragma unroll
             for (int j = 0; j < V; ++j) {
@@ -185,7 +192,8 @@ template <bool VEC>
 __global__ void norm_apply_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                       const float* __restrict__ m1, const float* __restrict__ m2, int HW, int C,
-                                      int act, float* __restrict__ dx, size_t total, _Float16* __restrict__ dx16 = nullptr) {
+                                      int act, float* __restrict__ dx, size_t total, _Float16* __restrict__ dx16 = nullptr,
+                                      const float* __restrict__ dy2 = nullptr) {
     constexpr int V = VEC ? 4 : 1;
     const size_t per_b = (size_t)HW * C;
     for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < total;
@@ -196,9 +204,14 @@ __global__ void norm_apply_bwd_kernel(const float* __restrict__ dy, const float*
         if (VEC) {
             *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + i);
             *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(dy + i);
+            if (dy2) {
+                const float4 e = *reinterpret_cast<const float4*>(dy2 + i);
+                gv[0] += e.x; gv[1] += e.y; gv[2] += e.z; gv[3] += e.w;
+            }
         } else {
             xv[0] = x[i];
             gv[0] = dy[i];
+            if (dy2) gv[0] += dy2[i];
         }
 #pragma unroll
         for (int j = 0; j < V; ++j) {
@@ -228,7 +241,8 @@ __global__ __launch_bounds__(256) void norm_apply_rows_kernel(const float* __res
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               const float* __restrict__ m1, const float* __restrict__ m2,
                                                               const float* __restrict__ residual, int HW, int C, int rows_per_split,
-                                                              int act, float* __restrict__ out, _Float16* __restrict__ out16) {
+                                                              int act, float* __restrict__ out, _Float16* __restrict__ out16,
+                                                              const float* __restrict__ dy2 = nullptr) {
     const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int c = blockIdx.x * 64 + 4 * cl, b = blockIdx.y;
     if (c >= C) return;
@@ -255,7 +269,11 @@ __global__ __launch_bounds__(256) void norm_apply_rows_kernel(const float* __res
                 o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
             }
         } else {
-            const float4 g = *reinterpret_cast<const float4*>(dy + i);
+            float4 g = *reinterpret_cast<const float4*>(dy + i);
+            if (dy2) {
+                const float4 e = *reinterpret_cast<const float4*>(dy2 + i);
+                g.x += e.x; g.y += e.y; g.z += e.z; g.w += e.w;
+            }
             const float xh0 = (v.x - mu.x) * rs.x, xh1 = (v.y - mu.y) * rs.y, xh2 = (v.z - mu.z) * rs.z, xh3 = (v.w - mu.w) * rs.w;
             const float g0 = g.x * act_grad_pre(xh0, act), g1 = g.y * act_grad_pre(xh1, act);
             const float g2 = g.z * act_grad_pre(xh2, act), g3 = g.w * act_grad_pre(xh3, act);
@@ -401,7 +419,8 @@ template <int NP>
 __global__ __launch_bounds__(256) void norm_slab_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, int HW, int C, int act,
-                                                            float* __restrict__ dx, _Float16* __restrict__ dx16 = nullptr) {
+                                                            float* __restrict__ dx, _Float16* __restrict__ dx16 = nullptr,
+                                                            const float* __restrict__ dy2 = nullptr) {
     __shared__ double red[2][32][32];
     const int cq = threadIdx.x & 7, pl = threadIdx.x >> 3;
     const int b = blockIdx.y, c0 = blockIdx.x * 32 + 4 * cq;
@@ -418,6 +437,10 @@ __global__ __launch_bounds__(256) void norm_slab_bwd_kernel(const float* __restr
             float xv[4], gv[4];
             *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + base + (size_t)p * C);
             *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(dy + base + (size_t)p * C);
+            if (dy2) {
+                const float4 e = *reinterpret_cast<const float4*>(dy2 + base + (size_t)p * C);
+                gv[0] += e.x; gv[1] += e.y; gv[2] += e.z; gv[3] += e.w;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 xh[i][j] = (xv[j] - mu[j]) * rs[j];
@@ -458,9 +481,9 @@ inline int slab_np(int HW, int C) {     // 0: not eligible
 }
 
 __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
-                               size_t n, int act) {
+                               size_t n, int act, const float* __restrict__ dy2 = nullptr) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        dx[i] = dy[i] * act_grad_post(y[i], act);
+        dx[i] = (dy2 ? dy[i] + dy2[i] : dy[i]) * act_grad_post(y[i], act);
 }
 // nn.Sigmoid (the PatchGAN output under --no_lsgan, networks.py:676-677): y = 1 / (1 + exp(-x)); backward dx = dy y (1 - y)
 __global__ void sigmoid_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
@@ -1023,14 +1046,19 @@ int mg_instnorm_bwd(const float* dy, const float* x, const float* mean, const fl
 }
 int mg_instnorm_bwd_h(const float* dy, const float* x, const float* mean, const float* rstd, int B, int HW, int C,
                       int act, float* dx, void* workspace, size_t workspace_bytes, void* stream, void* dx16v) {
+    return mg_instnorm_bwd_add(dy, nullptr, x, mean, rstd, B, HW, C, act, dx, workspace, workspace_bytes, stream, dx16v);
+}
+int mg_instnorm_bwd_add(const float* dy, const float* dy2, const float* x, const float* mean, const float* rstd, int B, int HW, int C,
+                        int act, float* dx, void* workspace, size_t workspace_bytes, void* stream, void* dx16v) {
     _Float16* dx16 = (_Float16*)dx16v;
+    if (dy2 && !al16(dy2)) return MG_ERR_ARG;
     if (dx16 && ((reinterpret_cast<uintptr_t>(dx16) & 7) != 0 || C % 4 != 0)) return MG_ERR_ARG;
     if (!dy || !x || !mean || !rstd || !dx || !workspace || B <= 0 || HW <= 0 || C <= 0) return MG_ERR_ARG;
     if (workspace_bytes < mg_instnorm_workspace(B, HW, C)) return MG_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (const int np = slab_np(HW, C); np && al16(x) && al16(dy) && al16(dx) && al16(mean) && al16(rstd)) {
         const dim3 grid(C / 32, B);
-#define MG_SLAB_BWD(NP_) hipLaunchKernelGGL(norm_slab_bwd_kernel<NP_>, grid, dim3(256), 0, st, dy, x, mean, rstd, HW, C, act, dx, dx16)
+#define MG_SLAB_BWD(NP_) hipLaunchKernelGGL(norm_slab_bwd_kernel<NP_>, grid, dim3(256), 0, st, dy, x, mean, rstd, HW, C, act, dx, dx16, dy2)
         if (np == 4) MG_SLAB_BWD(4); else if (np == 8) MG_SLAB_BWD(8); else if (np == 16) MG_SLAB_BWD(16); else MG_SLAB_BWD(20);
 #undef MG_SLAB_BWD
         MG_CHECK_LAUNCH();
@@ -1042,10 +1070,10 @@ int mg_instnorm_bwd_h(const float* dy, const float* x, const float* mean, const 
     float* m2 = m1 + (size_t)B * C;
     if (C % 4 == 0 && al16(x) && al16(dy))
         hipLaunchKernelGGL((norm_partial_kernel<1, true>), dim3(p.cblocks, B, p.splits), dim3(256), 0, st, x, dy, mean,
-                           rstd, HW, C, p.rows_per_split, act, part);
+                           rstd, HW, C, p.rows_per_split, act, part, dy2);
     else
         hipLaunchKernelGGL((norm_partial_kernel<1, false>), dim3(p.cblocks, B, p.splits), dim3(256), 0, st, x, dy, mean,
-                           rstd, HW, C, p.rows_per_split, act, part);
+                           rstd, HW, C, p.rows_per_split, act, part, dy2);
     hipLaunchKernelGGL(norm_finalize_kernel<1>, dim3((B * C * 8 + 255) / 256), dim3(256), 0, st, part, B, p.splits, C, HW,
                        0.0f, m1, m2);
     const size_t total = (size_t)B * HW * C;
@@ -1054,21 +1082,24 @@ int mg_instnorm_bwd_h(const float* dy, const float* x, const float* mean, const 
         int rps = 0;
         const dim3 grid = norm_rows_grid(B, HW, C, &rps);
         hipLaunchKernelGGL(norm_apply_rows_kernel<true>, grid, dim3(256), 0, st, x, dy, mean, rstd, (const float*)m1,
-                           (const float*)m2, (const float*)nullptr, HW, C, rps, act, dx, dx16);
+                           (const float*)m2, (const float*)nullptr, HW, C, rps, act, dx, dx16, dy2);
     } else if (vec)
         hipLaunchKernelGGL(norm_apply_bwd_kernel<true>, dim3(grid_for(total, 4)), dim3(256), 0, st, dy, x, mean, rstd,
-                           m1, m2, HW, C, act, dx, total, dx16);
+                           m1, m2, HW, C, act, dx, total, dx16, dy2);
     else
         hipLaunchKernelGGL(norm_apply_bwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, dy, x, mean, rstd,
-                           m1, m2, HW, C, act, dx, total, dx16);
+                           m1, m2, HW, C, act, dx, total, dx16, dy2);
     MG_CHECK_LAUNCH();
     return MG_OK;
 }
 
 int mg_act_bwd(const float* dy, const float* y, float* dx, long long n, int act, void* stream) {
+    return mg_act_bwd_add(dy, nullptr, y, dx, n, act, stream);
+}
+int mg_act_bwd_add(const float* dy, const float* dy2, const float* y, float* dx, long long n, int act, void* stream) {
     if (!dy || !y || !dx || n <= 0) return MG_ERR_ARG;
     hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx,
-                       (size_t)n, act);
+                       (size_t)n, act, dy2);
     MG_CHECK_LAUNCH();
     return MG_OK;
 }

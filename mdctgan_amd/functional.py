@@ -379,6 +379,40 @@ def _is_shared(weight_grad):
 
 
 # ------------------------------------------------------------------------------------------------
+# a second gradient for a tensor with two consumers
+# ------------------------------------------------------------------------------------------------
+# A discriminator feature map feeds the next layer AND the feature-matching loss (pix2pixHD_model.py:443-451): autograd would add the
+# two gradients with an elementwise launch per map (8 / 12 per configs[1] / configs[2] step, up to 100 MB each).  The node that
+# PRODUCED the map (conv + LeakyReLU, or InstanceNorm + LeakyReLU) hangs an ExtraGrad on its output; the loss node
+# (_L1HalvesSumFn) parks its gradient there instead of returning it, and the producer's backward -- which runs later in the same
+# pass, reached through the map's other consumer -- reads dy + extra inside its own kernel (mg_instnorm_bwd_add / mg_act_bwd_add:
+# the same float32 addition).  Valid because the producer's backward always runs after the loss's in a pass that contains both
+# (topological order), and the map's other consumer always carries gradient in such a pass (the GAN term behind the last layer).
+class ExtraGrad:
+    __slots__ = ("g",)
+
+    def __init__(self):
+        self.g = None
+
+
+def _hang_extra(ctx, out):
+    ctx.extra = None
+    if any(ctx.needs_input_grad) and os.environ.get("MG_NO_EXTRA_GRAD", "0") != "1":      # (grad mode reads False inside a forward)
+        ctx.extra = out._mg_extra = ExtraGrad()
+    return out
+
+
+def _take_extra(ctx, like):
+    """The parked second gradient of this node's output (None when nobody parked one), as a tensor shaped like `like`."""
+    h = getattr(ctx, "extra", None)
+    if h is None or h.g is None:
+        return None
+    g, h.g = h.g, None
+    assert g.shape == like.shape
+    return g
+
+
+# ------------------------------------------------------------------------------------------------
 # convolution
 # ------------------------------------------------------------------------------------------------
 class _ConvFn(torch.autograd.Function):
@@ -435,7 +469,7 @@ class _ConvFn(torch.autograd.Function):
         ctx.g, ctx.cfg = g, cfg
         ctx.weight, ctx.bias = weight, bias
         ctx.save_for_backward(x, y if act != ACT_NONE else None)
-        return y
+        return _hang_extra(ctx, y) if act in (ACT_RELU, ACT_LRELU02) else y
 
     @staticmethod
     def backward(ctx, gy):
@@ -468,7 +502,10 @@ def _conv_backward(ctx, gy, x, y, add=None):
     # float16(gy) written by gy's producer (an InstanceNorm backward): only for the whole, untouched tensor
     g16 = _h16_of(gy) if (rows is None and act == ACT_NONE) else None
     if act != ACT_NONE:
-        gy = nchw_view(ops.act_bwd(nhwc_view(gy), nhwc_view(y), act))
+        extra = _take_extra(ctx, gy_full)          # the feature-matching loss's gradient of this layer's output (see ExtraGrad)
+        if extra is not None and rows is not None:
+            extra = extra[:rows]
+        gy = nchw_view(ops.act_bwd(nhwc_view(gy), nhwc_view(y), act, dy2=nhwc_view(to_cl(extra)) if extra is not None else None))
     w = weight.detach()
     dx = None
     md = None
@@ -720,13 +757,16 @@ class _InstNormFn(torch.autograd.Function):
         y, mean, rstd = ops.instnorm_fwd(nhwc_view(x), act, nhwc_view(res) if res is not None else None, eps, y16=y16)
         ctx.act, ctx.half = act, amp.current_precision() == _lib.PRECISION_F16
         ctx.save_for_backward(x, mean, rstd)
-        return _attach_h16(nchw_view(y), y16)
+        return _hang_extra(ctx, _attach_h16(nchw_view(y), y16))
 
     @staticmethod
     def backward(ctx, gy):
         x, mean, rstd = ctx.saved_tensors
         gy = to_cl(gy)
         dx = None
+        extra = _take_extra(ctx, gy)               # the feature-matching loss's gradient of this layer's output (see ExtraGrad)
+        if extra is not None:
+            extra = to_cl(extra)
         if ctx.needs_input_grad[0]:
             rows = _live_rows(x)
             if rows is not None:                               # pass "G" over a stacked discriminator batch
@@ -736,14 +776,15 @@ class _InstNormFn(torch.autograd.Function):
                 d16 = (torch.empty(rows * H * W * C, dtype=torch.float16, device=x.device)
                        if _want_h16(rows, H * W, C, ctx.half) else None)
                 ops.instnorm_bwd(nhwc_view(gy[:rows]), nhwc_view(x[:rows]), mean[:rows], rstd[:rows], ctx.act,
-                                 out=nhwc_view(dx[:rows]), dx16=d16)
+                                 out=nhwc_view(dx[:rows]), dx16=d16, dy2=nhwc_view(extra[:rows]) if extra is not None else None)
                 if d16 is not None:
                     dx._mg_h16_rows = (d16, dx.data_ptr(), dx._version, rows)
                     H16_STATS["made"] += 1
             else:
                 B, C, H, W = x.shape
                 d16 = torch.empty(x.numel(), dtype=torch.float16, device=x.device) if _want_h16(B, H * W, C, ctx.half) else None
-                dx = _attach_h16(nchw_view(ops.instnorm_bwd(nhwc_view(gy), nhwc_view(x), mean, rstd, ctx.act, dx16=d16)), d16)
+                dx = _attach_h16(nchw_view(ops.instnorm_bwd(nhwc_view(gy), nhwc_view(x), mean, rstd, ctx.act, dx16=d16,
+                                                            dy2=nhwc_view(extra) if extra is not None else None)), d16)
         dres = gy if ctx.needs_input_grad[1] else None
         return dx, dres, None, None
 
@@ -1116,6 +1157,7 @@ def _cl(t):
 class _L1HalvesSumFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, scale, *ts):
+        ctx.holders = [getattr(t, "_mg_extra", None) for t in ts]      # where the producers take a second gradient (ExtraGrad)
         ts = [_cl(t) for t in ts]
         if TAP is not None:
             TAP.append(("l1_sign", [torch.sign(t[:t.shape[0] // 2].detach() - t[t.shape[0] // 2:].detach()) for t in ts]))
@@ -1137,6 +1179,13 @@ class _L1HalvesSumFn(torch.autograd.Function):
             rows.append((t[:B], t[B:], g, (t.numel() - t[:B].numel()) if _BackwardPass.kind != "G" else 0))
             grads.append(g)
         ops.loss_multi_bwd(ops.LOSS_L1, rows, 0.0, ctx.scale, go)
+        if _BackwardPass.kind == "G":
+            # optimize_parameters' generator pass: every map's producer runs later in this pass (reached through the next layer) and
+            # adds the parked gradient inside its own kernel -- no accumulation launch
+            for i, h in enumerate(ctx.holders):
+                if h is not None:
+                    assert h.g is None, "an ExtraGrad was parked twice without being taken"
+                    h.g, grads[i] = grads[i], None
         return (None, *grads)
 
 

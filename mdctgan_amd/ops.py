@@ -299,20 +299,21 @@ def instnorm_fwd(x, act=ACT_NONE, residual=None, eps=1e-5, y16=None):
     return y, mean, rstd
 
 
-def instnorm_bwd(dy, x, mean, rstd, act=ACT_NONE, out=None, dx16=None):
+def instnorm_bwd(dy, x, mean, rstd, act=ACT_NONE, out=None, dx16=None, dy2=None):
+    """dy2 (optional): a second gradient of the same tensor, added inside the kernels (mg_instnorm_bwd_add)."""
     lib = _lib.load()
     B, H, W, Cc = x.shape
     dx = torch.empty_like(x) if out is None else out
     ws = _ws(lib.mg_instnorm_workspace(B, H * W, Cc), x.device)
-    _lib.check(lib.mg_instnorm_bwd_h(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), B, H * W, Cc, act,
-                                     _lib.ptr(dx), _lib.ptr(ws), ws.numel(), _lib.stream(), _lib.ptr(dx16)), "mg_instnorm_bwd")
+    _lib.check(lib.mg_instnorm_bwd_add(_lib.ptr(dy), _lib.ptr(dy2), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), B, H * W, Cc, act,
+                                       _lib.ptr(dx), _lib.ptr(ws), ws.numel(), _lib.stream(), _lib.ptr(dx16)), "mg_instnorm_bwd")
     return dx
 
 
-def act_bwd(dy, y, act, out=None):
+def act_bwd(dy, y, act, out=None, dy2=None):
     lib = _lib.load()
     out = torch.empty_like(dy) if out is None else out
-    _lib.check(lib.mg_act_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(out), dy.numel(), act, _lib.stream()), "mg_act_bwd")
+    _lib.check(lib.mg_act_bwd_add(_lib.ptr(dy), _lib.ptr(dy2), _lib.ptr(y), _lib.ptr(out), dy.numel(), act, _lib.stream()), "mg_act_bwd")
     return out
 
 

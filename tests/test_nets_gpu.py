@@ -918,3 +918,54 @@ def test_generate_with_stitching_k2_equals_decode_then_stitch(gen_overlap, monke
     got = generate(model, segs, batch_size=2, gen_overlap=gen_overlap)
     assert got.shape == want.shape and got.shape[-1] >= wave.numel()
     assert torch.equal(got, want), (gen_overlap, (got - want).abs().max().item())
+
+
+@pytest.mark.parametrize("fp16,num_D", [(False, 2), (True, 3)], ids=["f32_numD2", "fp16_numD3"])
+def test_feature_loss_gradient_joins_inside_the_layer_kernels(golden, monkeypatch, fp16, num_D):
+    """Round 6 (functional.ExtraGrad): the feature-matching loss's gradient of a discriminator feature map is no longer added to the
+    next layer's data gradient by an autograd accumulation launch -- the loss parks it and the map's producer (conv + LeakyReLU /
+    InstanceNorm + LeakyReLU) reads dy + extra inside its own backward kernel (mg_act_bwd_add / mg_instnorm_bwd_add).  The same
+    float32 addition: three iterations leave every parameter and both Adam moments bit for bit where MG_NO_EXTRA_GRAD=1 leaves
+    them, and the parked gradients are really taken (no holder is left full)."""
+    g = golden("g6_step_global")
+    lr, hr = torch.from_numpy(g["lr"]).to(DEV), torch.from_numpy(g["hr"]).to(DEV)
+
+    def run(off):
+        if off:
+            monkeypatch.setenv("MG_NO_EXTRA_GRAD", "1")
+        else:
+            monkeypatch.delenv("MG_NO_EXTRA_GRAD", raising=False)
+        from mdctgan_amd import functional as Fh
+        from mdctgan_amd import options
+        from mdctgan_amd.pix2pixHD_model import create_model
+        opt = options.make_opt(*options.SPECTRAL_FLAGS, "--lr_sampling_rate", "12000", "--netG", "global", "--ngf", "8",
+                               "--n_blocks_global", "2", "--n_blocks_attn_g", "0", "--num_D", str(num_D), "--ndf", "8", "--batchSize", "2",
+                               "--bins", "32", "--segment_length", "7936", "--gpu_ids", "0", *(["--fp16"] if fp16 else []))
+        m = create_model(opt)
+        onets.fill_deterministic(m.netG)
+        onets.fill_deterministic(m.netD)
+        if fp16:
+            m.scaler.state[0] = 64.0
+        parked = []
+        real = Fh._take_extra
+
+        def spy(ctx, like):
+            got = real(ctx, like)
+            if got is not None:
+                parked.append(tuple(got.shape))
+            return got
+        monkeypatch.setattr(Fh, "_take_extra", spy)
+        for _ in range(3):
+            ld = m.optimize_parameters(lr, hr)
+        torch.cuda.synchronize()
+        monkeypatch.setattr(Fh, "_take_extra", real)
+        return m, {k: v.item() for k, v in ld.items()}, parked
+    a, la, pa = run(False)
+    b, lb, pb = run(True)
+    assert len(pa) == 3 * 4 * num_D and pb == [], (len(pa), len(pb))      # four feature maps per scale, every iteration
+    assert la == lb
+    for net in ("netG", "netD"):
+        for (k, x), (_, y) in zip(getattr(a, net).state_dict().items(), getattr(b, net).state_dict().items()):
+            assert torch.equal(x, y), (net, k)
+    for oa, ob in ((a.optimizer_G, b.optimizer_G), (a.optimizer_D, b.optimizer_D)):
+        assert torch.equal(oa.flat_m, ob.flat_m) and torch.equal(oa.flat_v, ob.flat_v)
