@@ -132,8 +132,8 @@ AMP_SCALE = 1024.0
 
 @pytest.mark.parametrize("tag,fp16,feat,batch,n_steps",
                          [("configs1", False, True, None, 3), ("configs2", False, True, None, 3), ("configs2", True, True, None, 3),
-                          ("configs2", True, False, None, 1), ("configs1", False, True, 8, 1)],
-                         ids=["configs1_f32_batch2", "configs2_f32_batch1", "configs2_fp16_batch1_3steps", "configs2_fp16_noFeat_batch1",
+                          ("configs2", False, False, None, 1), ("configs1", False, True, 8, 1)],
+                         ids=["configs1_f32_batch2", "configs2_f32_batch1", "configs2_fp16_batch1_3steps", "configs2_f32_noFeat_batch1",
                               "configs1_f32_batch8"])
 def test_full_size_step_gradients(tag, fp16, feat, batch, n_steps, monkeypatch):
     """n_steps = 3: the oracle also takes three Adam steps (float32: iterations 2, 3 run the fused weight-gradient + Adam + transform
