@@ -36,8 +36,8 @@ def test_mdct4_golden(mods, golden):
     Xc = X.cpu().numpy().astype(np.float64)
     for b in range(2):
         assert np.abs(Xc[b] - g["X"][b]).max() <= 2e-6 * np.abs(g["X"][b]).max()
-    # without frames the table-stationary kernel runs (csrc/mdct_bs.h): same float32 window products and fold, another
-    # (still exact-f32) k order in the MFMA chain -> the same 2e-6 bar, not the same bits
+    # without frames the factored-transform kernel runs (csrc/mdct_ct.h; returned frames take the generic dense-table kernel of
+    # csrc/mdct.hip): same float32 window products and fold, the DCT-IV as two short stage sums -> the same 2e-6 bar, not the same bits
     X2, fr2 = mdct(torch.from_numpy(g["x"]).to(DEV))
     assert fr2.numel() == 1
     for b in range(2):
@@ -90,7 +90,8 @@ def test_round_trip_full_size(mods):
     from mdctgan_amd.mdct import IMDCT4
     im64 = IMDCT4(512, 256, 512, imdct.window, device=DEV, dtype=torch.float64)
     y64, _ = im64(X)
-    # (the float64 store is the round-1 kernel's, the float32 one the table-stationary kernel's: another k order, same bar)
+    # (the float64 store is the generic dense-table kernel's (csrc/mdct.hip), the float32 one the factored kernel's (csrc/mdct_ct.h):
+    # other summation orders, same bar)
     assert y64.dtype == torch.float64 and (y64.float() - y).abs().max().item() <= 2e-6 * y.abs().max().item()
 
 
