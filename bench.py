@@ -594,12 +594,26 @@ def main():
     # untimed warm-up: at least 6 eager iterations -- the caching allocator and the per-stream workspaces only reach
     # their steady state after a few steps (measured: 27.7 ms/step when timing starts after 2, 19.8 ms after 5)
     nw = max(args.warmup, 6 if not use_graph else 2)
+    amp_settle = 0
+    if args.mode == "train" and getattr(model, "scaler", None) is not None:
+        # --fp16: GradScaler starts at 65536 and halves the scale on every iteration whose float16 gradients overflow -- skipping that
+        # iteration's optimiser steps (train.py:183-199).  A skipped step does less work than a real one, so none may sit in the timed
+        # region: step (untimed) until the scale has stood still for three iterations, and check again after the timed region.
+        still, last = 0, model.scaler.get_scale()
+        while still < 3 and amp_settle < 64:
+            eager_step()
+            amp_settle += 1
+            now = model.scaler.get_scale()
+            still, last = (still + 1, last) if now == last else (0, now)
+        if still < 3:
+            raise RuntimeError("the GradScaler's loss scale did not settle in 64 iterations")
     for i in range(nw):
         if i == nw - 1 and not args.no_roofline:
             ops.PROFILER = timer_all
         eager_step()
         ops.PROFILER = None
     torch.cuda.synchronize()
+    amp_scale0 = model.scaler.get_scale() if (args.mode == "train" and getattr(model, "scaler", None) is not None) else None
     dominant = None
     symbols = None
 
@@ -643,6 +657,9 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ops.PROFILER = None
+    if amp_scale0 is not None and model.scaler.get_scale() != amp_scale0:
+        raise RuntimeError("the loss scale moved inside the timed region (%r -> %r): a skipped optimiser step would have been timed"
+                           % (amp_scale0, model.scaler.get_scale()))
     if use_graph and timer is not None:
         # graph replays cannot be bracketed per kernel: time the same launches of the dominant kernel with HIP
         # events over K eager iterations of the same step, immediately after the timed region
@@ -793,6 +810,8 @@ def main():
                "config": {"workload": workload,
                           "global_batch": batch * world, "segment_length": T_SEG,
                           "parallelism": "dp%d" % world, "launch": "hipGraph replay" if use_graph else "eager",
+                          **({"amp": {"loss_scale": amp_scale0, "settle_iterations": amp_settle, "skipped_steps_in_timed_region": 0}}
+                             if amp_scale0 is not None else {}),
                           **({"ranks": dist_ranks, "backend": "rccl" if args.backend == "nccl" else args.backend,
                               "ddp_mode": {k: r.mode for k, r in (getattr(model, "reducers", None) or {}).items()}} if use_ddp else {}),
                           "steps_counted": ("one G+D optimisation step per GPU; value = steps of per-GPU batch 8 completed "
