@@ -429,10 +429,15 @@ class Pix2PixHDModel(BaseModel):
         with amp.autocast(self.fp16):
             losses, _ = self._forward(lr_audio, hr_audio, infer=False, share_d_pass=True)
         loss_dict = dict(zip(self.loss_names, losses))
-        loss_D = (loss_dict["D_fake"] + loss_dict["D_real"]) * 0.5
-        loss_G = loss_dict["G_GAN"] + loss_dict.get("G_GAN_Feat", 0)
+        # train.py:170-171, 183, 194: loss_D = (D_fake + D_real) * 0.5, loss_G = G_GAN + G_GAN_Feat, scaler.scale(loss).  The constant
+        # factors (0.5, the loss scale S) ride in the gradient each backward pass starts from -- d loss_D / d(D_fake + D_real) =
+        # 0.5 S either way, bit for bit -- instead of in elementwise launches on one-element tensors (3 multiplies forward, 2 backward,
+        # 2 ones_like fills per iteration)
+        loss_D = loss_dict["D_fake"] + loss_dict["D_real"]
+        loss_G = loss_dict["G_GAN"] + loss_dict["G_GAN_Feat"] if "G_GAN_Feat" in loss_dict else loss_dict["G_GAN"]
         red = getattr(self, "reducers", None)      # data-parallel gradient reducers (mdctgan_amd.ddp.attach)
         sc = self.scaler                           # train.py:183-199: one GradScaler, updated once per iteration
+        seed_G, seed_D = self._backward_seeds(sc, loss_D.device)
         if red:
             red["G"].active, red["D"].active = True, False
         rows = self._shared_rows      # > 0: both losses hang off one discriminator forward (see _forward)
@@ -440,22 +445,20 @@ class Pix2PixHDModel(BaseModel):
         d_kw = dict(inputs=[p for p in self.netD.parameters() if p.requires_grad]) if rows else {}
         self.optimizer_G.zero_grad()
         with Fh.backward_pass("G" if rows else None, rows), Fh.fused_adam_scope(self.optimizer_G if sc is None and not red else None):
+            loss_G.backward(gradient=seed_G, **g_kw)
             if sc is not None:
-                sc.scale(loss_G).backward(**g_kw)
                 sc.step(self.optimizer_G)
             else:
-                loss_G.backward(**g_kw)
                 self.optimizer_G.step()
         if red:
             red["G"].active, red["D"].active = False, True
         self.optimizer_D.zero_grad()
         with Fh.backward_pass("D" if rows else None, rows):
+            loss_D.backward(gradient=seed_D, **d_kw)
             if sc is not None:
-                sc.scale(loss_D).backward(**d_kw)
                 sc.step(self.optimizer_D)
                 sc.update()
             else:
-                loss_D.backward(**d_kw)
                 self.optimizer_D.step()
         if red and getattr(self, "ddp_check_steps", 0) > 0 and not torch.cuda.is_current_stream_capturing():
             # the first data-parallel steps: every rank's parameter arenas must equal rank 0's bit for bit (ddp.check_replicas)
@@ -467,6 +470,18 @@ class Pix2PixHDModel(BaseModel):
         # detached: the caller only prints / logs these; handing out the graph would keep one generator's worth of
         # saved activations alive until the next iteration overwrites the dict
         return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss_dict.items()}
+
+    def _backward_seeds(self, sc, dev):
+        """(d loss_G, d loss_D) the two backward passes start from: (1, 0.5), times the GradScaler's loss scale under --fp16 (read from
+        its device state when the loss-gradient kernels run, so a captured step follows the scale)."""
+        cache = self.__dict__.setdefault("_seed_cache", {})
+        if dev not in cache:
+            cache[dev] = (torch.ones((), device=dev), torch.full((), 0.5, device=dev))
+        one, half = cache[dev]
+        if sc is None or not sc.enabled:
+            return one, half
+        s = sc.state[0]
+        return s, s * 0.5
 
     def _finish_pending(self):
         """Sharded data parallelism (ddp "sharded" mode): the all-gather of the last update may still be in flight."""
