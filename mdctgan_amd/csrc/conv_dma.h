@@ -732,7 +732,7 @@ CdPlan conv_dma_plan(long long M, int N, int chunks, bool wgrad, int ck, int tap
             const int sp_max = f_sp ? f_sp : (chunks / 2 < 64 ? (chunks / 2 < 1 ? 1 : chunks / 2) : 64);
             for (int sp = f_sp ? f_sp : 1; sp <= sp_max && sp <= chunks; ++sp) {
                 const long long wg = w * sp;
-                if (wg > (1 << 16)) break;
+                if (sp > 1 && wg > (1 << 16)) break;      // (an unsplit tiling is always a candidate, however large the GEMM)
                 const int cps = (chunks + sp - 1) / sp;
                 long long left = (wg + 255) / 256;
                 double cycles = 0.0;
@@ -767,7 +767,7 @@ CdPlan conv_dma_plan(long long M, int N, int chunks, bool wgrad, int ck, int tap
             const int sp_max = f_sp ? f_sp : (chunks / 2 < 32 ? (chunks / 2 < 1 ? 1 : chunks / 2) : 32);
             for (int sp = f_sp ? f_sp : 1; sp <= sp_max && sp <= chunks; ++sp) {
                 const long long wg = w * sp;
-                if (wg > (1 << 16)) break;
+                if (sp > 1 && wg > (1 << 16)) break;      // (an unsplit tiling is always a candidate, however large the GEMM)
                 const int cps = (chunks + sp - 1) / sp;
                 long long left = (wg + 255) / 256;
                 double cycles = 0.0;

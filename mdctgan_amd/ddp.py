@@ -33,8 +33,15 @@ class ArenaReducer:
     parameter's gradient during one backward (1 for G; 2 for D: the fake and the real pass)."""
 
     def __init__(self, flat_g, slices, writes_per_step=1, bucket_bytes=128 << 20, group=None, tail_bytes=None,
-                 mode=None):
+                 mode=None, g16_of=None):
         self.flat_g, self.group = flat_g, group
+        # g16_of (round 6, "allreduce" mode under --fp16): callable param -> its float16 gradient arena view or None (FusedAdam
+        # GRAD_F16: the weight-gradient kernel stores float16, the reference's own dtype for an autocast layer's gradient).  Those
+        # ranges go over the links as they are -- 2 bytes per element with no cast pass (configs[3]: 92 % of the generator's 736 M
+        # parameters are the trunk weights stored that way: 2.94 -> 1.59 GB per step and rank) -- and are SUMMED in float16: a sum that
+        # leaves the float16 range becomes inf on every rank alike, the GradScaler's check on the reduced arena skips the step
+        # everywhere and halves the scale, i.e. the loss scale settles up to log2(world) notches lower than on one GPU.
+        self.g16_of = g16_of
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # "allreduce": one RCCL all-reduce per bucket (RCCL picks its own rings over the 7 xGMI links);
         # "rs_ag": reduce-scatter + all-gather per bucket -- the two halves of the same collective issued separately,
@@ -68,6 +75,8 @@ class ArenaReducer:
         self.force = dist.is_initialized()       # a 1-rank group still goes through RCCL (used to test the code path)
         self.buckets = []            # [lo, hi, n_params]
         self.param_bucket = {}
+        self._members = []           # per bucket: [(param, offset, padded_numel)]
+        self._piece_cache = {}
         # Backward fills the arena from its end, so the bucket that holds the FIRST parameters is the last one to
         # launch and the only one whose all-reduce cannot hide behind remaining backward work: keep it small
         # (tail_bytes, default a quarter of a bucket) and never let a large late-arena tensor ride in it.
@@ -81,6 +90,9 @@ class ArenaReducer:
                 self.buckets.append([lo, off, count])
                 self._bucket_writes.append(writes)
                 lo, count, writes = off, 0, 0
+            if len(self._members) == len(self.buckets):
+                self._members.append([])
+            self._members[-1].append((p, off, n))
             self.param_bucket[id(p)] = len(self.buckets)
             count += 1
             writes += int(getattr(p, "_mg_writes", 1)) * writes_per_step
@@ -113,9 +125,42 @@ class ArenaReducer:
         q = 8 * self.world
         return lo + (hi - lo) // q * q
 
+    def _pieces(self, i):
+        """Bucket i as the tensors that travel: maximal runs of float32-stored gradients (views of flat_g) and of float16-stored ones
+        (views of the optimiser's float16 gradient arena, same element offsets).  None: the whole bucket is float32."""
+        if self.g16_of is None:
+            return None
+        halves = tuple(self.g16_of(p) is not None for p, _, _ in self._members[i])
+        if not any(halves):
+            return None
+        hit = self._piece_cache.get(i)
+        if hit is not None and hit[0] == halves:
+            return hit[1]
+        out, run = [], None          # run = [lo, hi, is_half, arena]
+        for (p, off, n), h in zip(self._members[i], halves):
+            arena = None
+            if h:
+                v = self.g16_of(p)
+                arena = v._base if v._base is not None else v
+            if run is not None and run[2] == h and run[1] == off and (not h or run[3] is arena):
+                run[1] = off + n
+            else:
+                if run is not None:
+                    out.append(run)
+                run = [off, off + n, h, arena]
+        out.append(run)
+        pieces = [(a[3] if a[2] else self.flat_g)[a[0]:a[1]] for a in out]
+        self._piece_cache[i] = (halves, pieces)
+        return pieces
+
     def _launch(self, i):
         lo, hi, _ = self.buckets[i]
         if not (self.world > 1 or self.force) or not dist.is_initialized():     # (a reducer that outlived its group)
+            return
+        pieces = self._pieces(i)
+        if pieces is not None:
+            for t in pieces:
+                self.works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             return
         if self.wire is not None:
             w16 = self.wire[lo:hi]
@@ -264,15 +309,20 @@ def attach_optimizer(opt, writes_per_step=1, bucket_bytes=128 << 20, group=None)
     kernel.  Returns the reducer (also used by Pix2PixHDModel.update_fixed_params when it replaces optimizer_G)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     slices = opt.arena_slices()
-    if hasattr(opt, "disable_g16"):
-        opt.disable_g16()      # the reducer reads the float32 gradient arena: no float16-stored gradients under data parallelism
     broadcast_arena(opt.flat_p, 0, group)
     opt.resync_shadow()        # --fp16: the float16 shadow was cast from the PRE-broadcast weights (ADVICE r2, medium)
     n_params = sum(n for _, _, n in slices)
     mode = default_mode(world, n_params)
+    # float16-stored gradients (FusedAdam GRAD_F16) travel as they are in "allreduce" mode; the shard arithmetic of the other
+    # modes and the explicit 16-bit wire copy read the float32 arena alone.  MDCTGAN_DDP_NATIVE_G16=0: float32 arena, float32 wire.
+    native16 = (mode == "allreduce" and not os.environ.get("MDCTGAN_DDP_GRAD_DTYPE", "")
+                and os.environ.get("MDCTGAN_DDP_NATIVE_G16", "1") != "0")
+    if hasattr(opt, "disable_g16") and not native16:
+        opt.disable_g16()
     if world > 1 and (not dist.is_initialized() or dist.get_rank(group) == 0):
         print("[mdctgan_amd.ddp] %d ranks, %.1f M parameters: gradient reduction mode %r" % (world, n_params / 1e6, mode), file=sys.stderr, flush=True)
-    red = ArenaReducer(opt.flat_g, slices, writes_per_step, bucket_bytes, group, mode=mode)
+    red = ArenaReducer(opt.flat_g, slices, writes_per_step, bucket_bytes, group, mode=mode,
+                       g16_of=(lambda p: getattr(p, "_mg_g16", None)) if native16 and hasattr(opt, "disable_g16") else None)
     red.bucket_bytes = bucket_bytes
     opt.grad_scale = 1.0 / world
     opt.pre_step_hook = red.finish

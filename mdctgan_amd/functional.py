@@ -148,6 +148,9 @@ def _tag_g16(g, weight, bias, weight_grad):
     if (g.precision == _lib.PRECISION_F16 and weight_grad is True and weight.requires_grad
             and not hasattr(weight, "_mg_g16_ok")):
         weight._mg_g16_ok = bool(ops.wgrad_h16_ok(g))
+        opt = getattr(weight, "_mg_opt", None)
+        if weight._mg_g16_ok and opt is not None:
+            opt.adopt_g16(weight)         # the arenas were laid out before this first forward pass (ddp.attach)
 
 
 def mark_fresh(params):

@@ -55,6 +55,8 @@ class FusedAdam(torch.optim.Optimizer):
         self.flat_g16 = None
         self._modes = None
         self._seg_cache = {}
+        self._g16_allowed = os.environ.get("MG_NO_G16", "0") != "1"
+        self._index = {}
 
     # -- arena ---------------------------------------------------------------------------------
     def _build(self):
@@ -74,6 +76,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
         self.offsets, self.total = offs, total
+        self._index = {id(p): i for i, p in enumerate(ps)}
         # device-resident clock {step, lr, step_size, sqrt(bias_correction2)}: keeps the step hipGraph-replayable
         # {step, lr, lr / (1 - b1^step), sqrt(1 - b2^step), 1 - b1^(step+1), sqrt(1 - b2^(step+1))}: the last two are the NEXT step's
         # bias-correction terms, read by the kernels that update weights during backward (functional.fused_adam_scope)
@@ -104,7 +107,7 @@ class FusedAdam(torch.optim.Optimizer):
                     # (the Adam kernel writes both through raw pointers, which does not move it)
                     p._mg_h, p._mg_flat, p._mg_h_version = self.flat_h[off:off + n], self.flat_p[off:off + n], p._version
                 self._modes = []
-                store16 = os.environ.get("MG_NO_G16", "0") != "1"
+                store16 = self._g16_allowed
                 for p in ps:
                     if getattr(p, "_mg_grad_f32", False):
                         self._modes.append(_lib.GRAD_F32)
@@ -119,8 +122,26 @@ class FusedAdam(torch.optim.Optimizer):
                         p._mg_g16 = self.flat_g16[off:off + p.numel()] if mode == _lib.GRAD_F16 else None
         self._built = True
 
+    @torch.no_grad()
+    def adopt_g16(self, p):
+        """A weight learned AFTER the arenas were laid out that its gradient kernel can store float16 (functional._tag_g16 at the
+        first forward pass; ddp.attach builds the arenas before any forward pass has run): move it to GRAD_F16."""
+        i = self._index.get(id(p))
+        if (i is None or not self._g16_allowed or self._modes is None or self._modes[i] != _lib.GRAD_AUTOCAST
+                or not getattr(p, "_mg_fresh", True)):
+            return
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("a gradient's storage format changed inside a graph capture: run one eager step first")
+        if self.flat_g16 is None:
+            self.flat_g16 = torch.zeros(self.total, dtype=torch.float16, device=self.flat_p.device)
+        off = self.offsets[i]
+        p._mg_g16 = self.flat_g16[off:off + p.numel()]
+        self._modes[i] = _lib.GRAD_F16
+        self._seg_cache = {}
+
     def disable_g16(self):
-        """Gradients back into the float32 arena (a data-parallel reducer reads flat_g: ddp.attach_optimizer calls this)."""
+        """Gradients back into the float32 arena (a reducer mode that reads flat_g alone: ddp.attach_optimizer calls this)."""
+        self._g16_allowed = False
         if self.flat_g16 is None:
             return
         for i, p in enumerate(self._params):

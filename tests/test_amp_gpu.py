@@ -72,16 +72,19 @@ def close_f16(got, want, ulps=1.5, floor=2.0 ** -11):
 
 
 @pytest.mark.parametrize("case", [("row_pieces_OW128", 2, 64, 8, 256, 128, 3), ("one_row_OW64_4x4", 1, 128, 8, 128, 64, 4),
-                                  ("two_rows_OW32", 2, 64, 32, 64, 128, 3), ("whole_image_OW8", 4, 64, 16, 16, 64, 3)],
+                                  ("two_rows_OW32", 2, 64, 32, 64, 128, 3), ("whole_image_OW8", 4, 64, 16, 16, 64, 3),
+                                  ("stride1_4x4_pad2_OW64", 2, 64, 15, 63, 64, 4, 1, 2), ("stride1_3x3_OW64", 2, 64, 5, 64, 64, 3, 1, 1),
+                                  ("stride1_1x1_OW128", 1, 128, 4, 128, 64, 1, 1, 0)],
                          ids=lambda c: c[0])
 def test_f16_wgrad_row_regular_gather_is_the_general_gather(case, monkeypatch):
     """The float16 instances of the LDS-DMA weight gradient (64-pixel chunks) with the row-regular gather (csrc/conv_dma.h,
     RR = true) against the per-lane coordinate walk (MG_NO_WGRAD_RR=1): the same bits; accuracy is test_conv_f16_precision's
     (its cdh_down3x3_s2 case takes the row-regular kernel)."""
     from mdctgan_amd import _lib, ops
-    name, B, Ci, H, W, Co, k = case
-    g = ops.conv_geom(B, H, W, Ci, Co, k, k, 2, 1, False, _lib.PRECISION_F16)
-    assert "conv_wgrad_dma_kernel" in ops.plan_name(2, g) and ", true" in ops.plan_name(2, g)
+    name, B, Ci, H, W, Co, k = case[:7]
+    stride, pad = case[7:] if len(case) > 7 else (2, 1)           # the discriminator's last layers are 4x4 stride 1 pad 2
+    g = ops.conv_geom(B, H, W, Ci, Co, k, k, stride, pad, False, _lib.PRECISION_F16)
+    assert "conv_wgrad_dma_kernel" in ops.plan_name(2, g) and ops.plan_name(2, g).endswith(", true>")
     assert (B * g.OH * g.OW) % 64 == 0 and (g.OW % 64 == 0 or (64 % g.OW == 0 and (g.OH * g.OW) % 64 == 0))
     gen = torch.Generator().manual_seed(len(name))
     x = torch.randn(B, H, W, Ci, generator=gen).to(DEV)
@@ -95,7 +98,7 @@ def test_f16_wgrad_row_regular_gather_is_the_general_gather(case, monkeypatch):
         out.append(dw)
     assert torch.equal(out[0], out[1])
     ref = torch.zeros(Co, Ci, k, k, dtype=torch.float64, requires_grad=True)
-    F.conv2d(h(x.cpu().permute(0, 3, 1, 2)), ref, None, stride=2, padding=1).backward(h(gy.cpu().permute(0, 3, 1, 2)))
+    F.conv2d(h(x.cpu().permute(0, 3, 1, 2)), ref, None, stride=stride, padding=pad).backward(h(gy.cpu().permute(0, 3, 1, 2)))
     want = nhwc(ref.grad)
     assert (out[0].double().cpu() - want).abs().max().item() <= 3e-5 * want.abs().max().item()
 

@@ -81,6 +81,12 @@ def test_ladder_weight_gradient_plans_fill_the_resident_slots():
     # a geometry the LDS-DMA kernels do not take reports 0 splits
     g = ops.conv_geom(2, 32, 64, 2, 16, 7, 7, 1, 3, True, 0)
     assert _lib.load().mg_conv_plan_splits(0, g) == 0
+    # a float16 forward GEMM so large that EVERY tile shape needs more than 65536 workgroups (6.3 M pixels x 256 channels: 98304
+    # tiles of 128 x 128) is still costed unsplit -- the workgroup cap bounds split plans only -- and takes the tile it takes one
+    # batch size below the cap, not the uncosted 64 x 64 default
+    big, below = (ops.conv_geom(B, 256, 512, 64, 256, 3, 3, 1, 1, False, _lib.PRECISION_F16) for B in (48, 32))
+    assert ops.plan_name(0, big) == ops.plan_name(0, below) == "conv_fwd_dma_kernel<128, 128, true, 2>"
+    assert _lib.load().mg_conv_plan_splits(0, big) == 1
 
 
 def test_host_tensors_are_refused():

@@ -140,6 +140,9 @@ RR_CASES = [
     ("one_row_OW32", 2, 64, 16, 64, 64, 3, 2, 1, True),
     ("two_rows_OW16", 3, 128, 16, 32, 64, 3, 2, 1, True),
     ("whole_image_OW8", 2, 64, 8, 16, 64, 3, 2, 1, True),
+    ("stride1_3x3_odd_height_OW64", 2, 64, 5, 64, 64, 3, 1, 1, True),        # (an odd height keeps the layer off the Winograd path)
+    ("stride1_3x3_OW32", 2, 64, 7, 32, 128, 3, 1, 1, True),
+    ("stride1_1x1_OW64", 2, 64, 8, 64, 64, 1, 1, 0, True),
     ("odd_width_general_path", 2, 64, 17, 33, 64, 3, 2, 1, False),
     ("pixels_not_a_multiple_of_32", 1, 64, 6, 10, 64, 3, 2, 1, False),
 ]

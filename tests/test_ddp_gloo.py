@@ -428,3 +428,89 @@ def test_f16_wire_needs_a_gradscaler(monkeypatch):
     monkeypatch.setenv("MDCTGAN_DDP_GRAD_DTYPE", "f16")
     with pytest.raises(ValueError, match="needs --fp16"):
         ddp.attach(_M())
+
+
+def _worker_native16(rank, world, port, out_dir):
+    """Float16-STORED gradients (FusedAdam GRAD_F16) travel as float16 pieces of their own arena, the others as float32 pieces of
+    flat_g, bucket by bucket."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from mdctgan_amd import ddp
+    from mdctgan_amd import functional as Fh
+    from oracle import nets as onets
+    torch.manual_seed(7)
+    netD = onets.init_weights(onets.MultiscaleDRef(3, ndf=4, n_layers=3, num_D=2))
+    params = list(netD.parameters())
+    flat_g, gslices = _arena(params)
+    flat_g16 = torch.zeros(flat_g.numel(), dtype=torch.float16)
+    half = {id(p) for p in params if p.dim() == 4 and p.numel() >= 256}       # "the weights whose kernel stores float16"
+    assert 0 < len(half) < len(params)
+    views = {id(p): flat_g16[o:o + p.numel()] for p, o, n in gslices if id(p) in half}
+    red = ddp.ArenaReducer(flat_g, gslices, writes_per_step=1, bucket_bytes=4096, mode="allreduce", g16_of=lambda p: views.get(id(p)))
+    kinds = set()
+    for i in range(len(red.buckets)):
+        pieces = red._pieces(i)
+        kinds.update(t.dtype for t in (pieces or [flat_g]))
+        if pieces is not None:
+            lo, hi, _ = red.buckets[i]
+            assert sum(t.numel() for t in pieces) == hi - lo
+    assert kinds == {torch.float16, torch.float32}
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2 * world, 3, 32, 64, generator=g)
+    mine = x[rank * 2:(rank + 1) * 2]
+    scale = 1024.0
+
+    def fill(poison=False):
+        netD.zero_grad()
+        (scale * _loss(netD, mine)).backward()
+        flat_g.fill_(float("nan"))                      # a float16-stored gradient must never be read from the float32 arena
+        for p, o, n in reversed(gslices):
+            if id(p) in half:
+                views[id(p)].copy_(p.grad.reshape(-1))
+            else:
+                flat_g[o:o + n].zero_()
+                flat_g[o:o + p.numel()].copy_(p.grad.reshape(-1))
+            Fh._notify(p)
+        red.finish()
+
+    fill()
+    netD.zero_grad()
+    _loss(netD, x).backward()
+    gmax = max(float(p.grad.abs().max()) for p in params)
+    for p, o, n in gslices:
+        want = p.grad.reshape(-1)
+        if id(p) in half:
+            got = views[id(p)].float() / world / scale
+            tol = 2e-6 * gmax + (4 * 2.0 ** -10 + 2e-5) * float(want.abs().max())
+        else:
+            got = flat_g[o:o + p.numel()] / world / scale
+            tol = 2e-6 * gmax + 2e-5 * float(want.abs().max())
+        assert float((got - want).abs().max()) <= tol, (rank, o, id(p) in half)
+    # float16 sums that leave the range are inf on every rank: the GradScaler's check of the reduced arena then skips the step
+    first_half = next(p for p, o, n in gslices if id(p) in half)
+    netD.zero_grad()
+    (scale * _loss(netD, mine)).backward()
+    for p, o, n in reversed(gslices):
+        if id(p) in half:
+            views[id(p)].copy_(p.grad.reshape(-1))
+            if p is first_half:
+                views[id(p)][0] = 40000.0               # finite on each rank; 2 x 40000 > 65504
+        else:
+            flat_g[o:o + p.numel()].copy_(p.grad.reshape(-1))
+        Fh._notify(p)
+    red.finish()
+    assert bool(torch.isinf(views[id(first_half)][0]))
+    red.close()
+    np.save(os.path.join(out_dir, "ok%d.npy" % rank), np.ones(1))
+    dist.destroy_process_group()
+
+
+def test_float16_stored_gradients_travel_as_float16(tmp_path):
+    """VERDICT r5 item 2, last clause: under --fp16 the trunk weight gradients are float16 tensors in their own arena (as in the
+    reference, train.py:161-164) and go over the links as they are -- no cast pass, half the bytes -- while biases / BatchNorm /
+    position-embedding gradients stay float32; the mean still equals the single-process gradient to float16 rounding, and a sum
+    that overflows float16 is inf on every rank."""
+    port = _free_port()
+    mp.spawn(_worker_native16, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d.npy" % r)) for r in range(2))

@@ -387,6 +387,74 @@ def test_two_rank_capture_fallback_equals_eager_steps(tmp_path):
     assert torch.equal(a0["pG"], e0["pG"]) and torch.equal(a0["pD"], e0["pD"]) and a0["losses"] == e0["losses"]
 
 
+def _wide_trunk_model(batch):
+    """--fp16 generator whose residual trunk (128 channels on a 16 x 8 map) runs the float16 GEMM path: its weight gradients are
+    STORED as float16 (FusedAdam GRAD_F16)."""
+    from mdctgan_amd import options
+    from mdctgan_amd.pix2pixHD_model import create_model
+    opt = options.make_opt(*options.SPECTRAL_FLAGS, "--lr_sampling_rate", "12000", "--netG", "global", "--ngf", "16",
+                           "--n_downsample_global", "3", "--n_blocks_global", "2", "--n_blocks_attn_g", "0", "--num_D", "2",
+                           "--ndf", "8", "--batchSize", str(batch), "--bins", "64", "--segment_length", "8128", "--gpu_ids", "0",
+                           "--fp16")
+    m = create_model(opt)
+    onets.fill_deterministic(m.netG)
+    onets.fill_deterministic(m.netD)
+    return m
+
+
+def _wide_trunk_batch():
+    g = torch.Generator().manual_seed(11)
+    return 0.05 * torch.randn(2, 8128, generator=g), 0.05 * torch.randn(2, 8128, generator=g)
+
+
+def _native16_worker(rank, world, port, out_dir, native):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["MDCTGAN_DDP_NATIVE_G16"] = "1" if native else "0"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mdctgan_amd import _lib, ddp
+    from mdctgan_amd import functional as Fh
+    lr, hr = _wide_trunk_batch()
+    m = _wide_trunk_model(1)
+    ddp.attach(m)                                   # the arenas are laid out here, before any forward pass
+    m.scaler.state[0] = 16.0
+    ld = m.optimize_parameters(lr[rank:rank + 1].cuda(), hr[rank:rank + 1].cuda())
+    torch.cuda.synchronize()
+    opt = m.optimizer_G
+    n16 = sum(1 for k in opt._modes if k == _lib.GRAD_F16)
+    dtypes = sorted({str(t.dtype) for i in range(len(m.reducers["G"].buckets)) for t in (m.reducers["G"]._pieces(i) or [opt.flat_g[:1]])})
+    grads = torch.cat([Fh.grad_of(p).reshape(-1).float().cpu() for p in opt._params])
+    torch.save({"g": grads, "n16": n16, "dtypes": dtypes, "pG": opt.flat_p.cpu(), "pD": m.optimizer_D.flat_p.cpu(),
+                "scale": float(m.scaler.get_scale()), "losses": {k: v.item() for k, v in ld.items()}},
+               os.path.join(out_dir, "n%d_%d.pt" % (int(native), rank)))
+    dist.destroy_process_group()
+
+
+def test_float16_stored_gradients_on_the_wire(tmp_path):
+    """--fp16 data parallelism, 2 ranks on one GPU: the trunk weights adopt the float16 gradient arena at their first forward pass
+    (the arenas exist since attach()), those ranges are all-reduced AS float16 and the rest as float32; against the float32 arena +
+    float32 wire (MDCTGAN_DDP_NATIVE_G16=0) the reduced gradients differ by float16 rounding of each rank's addend only, the ranks
+    stay in lockstep, and the first Adam step lands on the same parameters wherever the gradient's sign is beyond that rounding."""
+    import torch.multiprocessing as mp
+    for native in (True, False):
+        mp.spawn(_native16_worker, args=(2, _free_port(), str(tmp_path), native), nprocs=2, join=True)
+    n0, n1, f0 = (torch.load(os.path.join(str(tmp_path), n)) for n in ("n1_0.pt", "n1_1.pt", "n0_0.pt"))
+    assert n0["n16"] >= 4 and f0["n16"] == 0, (n0["n16"], f0["n16"])
+    assert n0["dtypes"] == ["torch.float16", "torch.float32"] and f0["dtypes"] == ["torch.float32"]
+    assert torch.equal(n0["pG"], n1["pG"]) and torch.equal(n0["pD"], n1["pD"]) and torch.equal(n0["g"], n1["g"])
+    assert n0["scale"] == f0["scale"] == 16.0                       # no overflow, no skipped step on either wire
+    gn, gf = n0["g"], f0["g"]
+    assert torch.isfinite(gn).all() and float(gf.abs().max()) > 0
+    # each rank's float16-stored addend carries half a float16 ulp of its own magnitude; the float32 arena rounds once, at Adam
+    err = float((gn - gf).abs().max())
+    assert err <= 2.0 ** -9 * float(gf.abs().max()), (err, float(gf.abs().max()))
+    assert float((gn - gf).norm() / gf.norm()) <= 1e-3
+    d = (n0["pG"] - f0["pG"]).abs()
+    assert float(d.max()) <= 2 * 2e-4 + 1e-6 and float((d > 2e-6).float().mean()) <= 0.02
+    for k in n0["losses"]:
+        assert n0["losses"][k] == f0["losses"][k], k                 # the forward pass does not depend on the wire
+
+
 def _run_bench(*argv, env=None, timeout=900):
     """bench.py as the driver starts it (a subprocess of the repo root); returns the parsed JSON line (the last line)."""
     import json
