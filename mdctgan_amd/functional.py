@@ -524,6 +524,8 @@ def _conv_backward(ctx, gy, x, y, add=None):
                 _, md = ops.wino_tile_buffers(g, gy.device, want_v=False)
             if rows is not None:
                 assert add is None
+                if u is not None and ops.wino_weights_bytes(g) != ops.wino_weights_bytes(ctx.g):
+                    u = None          # the weight image was made for the stacked batch's plan; half the rows take another path
                 dx = torch.empty_like(x_full)
                 g16r = None
                 if rec16 is not None and act == ACT_NONE and ops.precast_ok(1, g):

@@ -434,7 +434,9 @@ def test_float16_stored_gradients_on_the_wire(tmp_path):
     """--fp16 data parallelism, 2 ranks on one GPU: the trunk weights adopt the float16 gradient arena at their first forward pass
     (the arenas exist since attach()), those ranges are all-reduced AS float16 and the rest as float32; against the float32 arena +
     float32 wire (MDCTGAN_DDP_NATIVE_G16=0) the reduced gradients differ by float16 rounding of each rank's addend only, the ranks
-    stay in lockstep, and the first Adam step lands on the same parameters wherever the gradient's sign is beyond that rounding."""
+    stay in lockstep, and the first Adam step lands on the same parameters wherever the gradient's sign is beyond that rounding.
+    (Also the regression test of a shared discriminator layer whose plan differs between the stacked batch of 2 rows and the
+    generator pass's 1 live row: the weight image of the former must not be handed to the latter -- MG_ERR_ARG before the fix.)"""
     import torch.multiprocessing as mp
     for native in (True, False):
         mp.spawn(_native16_worker, args=(2, _free_port(), str(tmp_path), native), nprocs=2, join=True)
