@@ -486,6 +486,18 @@ def self_launch(n):
         raise SystemExit(rc)
 
 
+def _wire_bytes(r):
+    """Payload one rank hands to the gradient collectives per step (ddp.ArenaReducer): float32 buckets, an explicit 16-bit copy, or
+    float32 + float16 pieces where the gradients are stored as float16."""
+    if r.wire is not None:
+        return int(r.flat_g.numel() * r.wire.element_size())
+    total = 0
+    for i, (lo, hi, _) in enumerate(r.buckets):
+        pieces = r._pieces(i)
+        total += sum(t.numel() * t.element_size() for t in pieces) if pieces is not None else (hi - lo) * 4
+    return int(total)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -813,7 +825,9 @@ def main():
                           **({"amp": {"loss_scale": amp_scale0, "settle_iterations": amp_settle, "skipped_steps_in_timed_region": 0}}
                              if amp_scale0 is not None else {}),
                           **({"ranks": dist_ranks, "backend": "rccl" if args.backend == "nccl" else args.backend,
-                              "ddp_mode": {k: r.mode for k, r in (getattr(model, "reducers", None) or {}).items()}} if use_ddp else {}),
+                              "ddp_mode": {k: r.mode for k, r in (getattr(model, "reducers", None) or {}).items()},
+                              "ddp_wire_bytes_per_step": {k: _wire_bytes(r) for k, r in (getattr(model, "reducers", None) or {}).items()}}
+                             if use_ddp else {}),
                           "steps_counted": ("one G+D optimisation step per GPU; value = steps of per-GPU batch 8 completed "
                                             "per second summed over GPUs (weak scaling)") if args.mode == "train" else
                                            "one step = %d segments through inference + stitching per GPU" % batch},
