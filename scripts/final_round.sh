@@ -15,5 +15,5 @@ for a, n in zip(d.get("also", []), names):
     print(n, a.get("value"), a.get("ms_per_step"), (a.get("roofline") or {}).get("frac"), (a.get("roofline") or {}).get("traffic"))
 PY
 bash scripts/pmc_round.sh $tag > $out/pmc_round.log 2>&1
-python -m pytest tests -m gpu -q 2>&1 | tail -12 > $out/${tag}_pytest.log
+python -m pytest tests -m gpu -q --durations=30 2>&1 | grep -v -i "rccl\|^HIP version\|^ROCm version\|^Hostname\|^Librar" | tail -60 > $out/${tag}_pytest.log
 cat $out/${tag}_pytest.log | tail -4
