@@ -115,12 +115,24 @@ class FusedAdam(torch.optim.Optimizer):
                         self._modes.append(_lib.GRAD_F16)
                     else:
                         self._modes.append(_lib.GRAD_AUTOCAST)
+                for i, p in enumerate(ps):
+                    if i and self._rides_f16(i):
+                        self._modes[i] = _lib.GRAD_F16
                 if _lib.GRAD_F16 in self._modes:
                     # same element index as the float32 arenas; only the GRAD_F16 parameters' slices are ever touched
                     self.flat_g16 = torch.zeros(total, dtype=torch.float16, device=dev)
                     for p, off, mode in zip(ps, offs, self._modes):
                         p._mg_g16 = self.flat_g16[off:off + p.numel()] if mode == _lib.GRAD_F16 else None
         self._built = True
+
+    def _rides_f16(self, i):
+        """A bias whose gradient is identically zero (it feeds an InstanceNorm: functional.mark_bias_feeds_norm -- nobody ever writes
+        it) right behind a weight whose gradient is stored as float16 is carried in the float16 arena too: its slot there stays
+        zero, the optimiser's segments and a data-parallel reducer's float16 pieces then run across whole blocks of the trunk
+        instead of being cut at every 2048-element bias (36 -> 1 pieces on configs[2]'s trunk)."""
+        p = self._params[i]
+        return (self._modes[i] == _lib.GRAD_AUTOCAST and self._modes[i - 1] == _lib.GRAD_F16 and p.dim() == 1
+                and getattr(p, "_mg_zero_grad", False) and not Fh.COMPUTE_DEAD_BIAS_GRADS and getattr(p, "_mg_fresh", True))
 
     @torch.no_grad()
     def adopt_g16(self, p):
@@ -137,6 +149,10 @@ class FusedAdam(torch.optim.Optimizer):
         off = self.offsets[i]
         p._mg_g16 = self.flat_g16[off:off + p.numel()]
         self._modes[i] = _lib.GRAD_F16
+        if i + 1 < len(self._params) and self._rides_f16(i + 1):
+            q, off = self._params[i + 1], self.offsets[i + 1]
+            q._mg_g16 = self.flat_g16[off:off + q.numel()]
+            self._modes[i + 1] = _lib.GRAD_F16
         self._seg_cache = {}
 
     def disable_g16(self):
