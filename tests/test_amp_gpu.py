@@ -567,6 +567,65 @@ def test_segmented_fp16_optimizer_passes():
     assert torch.equal(a[3].detach(), b[3].detach()) and torch.equal(oa.flat_m, ob.flat_m) and torch.equal(oa.flat_v, ob.flat_v)
 
 
+def test_dead_biases_ride_in_the_float16_arena():
+    """A bias whose gradient is identically zero (it feeds an InstanceNorm) behind a weight with float16-stored gradient is carried
+    in the float16 arena as well -- whether the arenas are laid out after the first forward pass (the tags are known) or before it
+    (ddp.attach: FusedAdam.adopt_g16 moves weight AND bias) -- so segments / data-parallel pieces are not cut at every bias; other
+    biases stay float32.  The update equals the float32-storage optimiser's bit for bit (the bias and its moments never move)."""
+    from mdctgan_amd import _lib
+    from mdctgan_amd import functional as Fh
+    from mdctgan_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    shapes = [(128, 3, 3, 64), (128,), (128, 3, 3, 128), (128,), (64, 3, 3, 128), (64,)]
+
+    def params(tag_before):
+        ps = [torch.nn.Parameter(torch.randn(*sh, device=DEV)) for sh in shapes]
+        for i in (1, 3, 5):
+            Fh.mark_bias_feeds_norm(ps[i]) if i != 5 else None          # the last bias feeds no norm
+        if tag_before:
+            ps[0]._mg_g16_ok = ps[2]._mg_g16_ok = True
+        return ps
+    want = [_lib.GRAD_F16, _lib.GRAD_F16, _lib.GRAD_F16, _lib.GRAD_F16, _lib.GRAD_AUTOCAST, _lib.GRAD_AUTOCAST]
+    early = params(True)
+    o1 = FusedAdam(early, lr=1e-2, betas=(0.5, 0.999), half_shadow=True)
+    o1.zero_grad()
+    assert o1._modes == want
+    late = params(False)
+    o2 = FusedAdam(late, lr=1e-2, betas=(0.5, 0.999), half_shadow=True)
+    o2.zero_grad()                                                   # arenas first (ddp.attach) ...
+    assert o2._modes == [_lib.GRAD_AUTOCAST] * 6 and o2.flat_g16 is None
+    for i in (0, 2):                                                 # ... the tags arrive with the first forward pass
+        late[i]._mg_g16_ok = True
+        o2.adopt_g16(late[i])
+    assert o2._modes == want and all((late[i]._mg_g16 is not None) == (want[i] == _lib.GRAD_F16) for i in range(6))
+    plain = params(False)
+    o3 = FusedAdam(plain, lr=1e-2, betas=(0.5, 0.999), half_shadow=True)
+    o3.zero_grad()
+    with torch.no_grad():
+        for ps in (late, plain):
+            for p, q in zip(ps, early):
+                p.copy_(q)
+        for o in (o2, o3):
+            o.resync_shadow()
+    gen = torch.Generator().manual_seed(4)
+    for it in range(3):
+        grads = [torch.randn(*sh, generator=gen) for sh in shapes]
+        for opt, ps in ((o1, early), (o2, late), (o3, plain)):
+            opt.zero_grad()
+            for i, (p, g_) in enumerate(zip(ps, grads)):
+                if i in (1, 3):
+                    Fh._zero_grad_bias(p)                            # what the convolution's backward does for a dead bias
+                elif getattr(p, "_mg_g16", None) is not None:
+                    p._mg_g16.copy_(g_.reshape(-1).half().to(DEV)); p._mg_fresh = False
+                else:
+                    p.grad.copy_(g_.to(DEV)); p._mg_fresh = False
+            opt.step()
+        for a, b, c in zip(early, late, plain):
+            assert torch.equal(a.detach(), b.detach()) and torch.equal(a.detach(), c.detach()), it
+        assert torch.equal(o1.flat_m, o3.flat_m) and torch.equal(o1.flat_v, o3.flat_v) and torch.equal(o2.flat_v, o3.flat_v)
+    assert float(o1.flat_m[o1.offsets[1]:o1.offsets[2]].abs().max()) == 0.0       # the dead bias: zero moments, never moved
+
+
 @pytest.mark.parametrize("case", [("trunk_256_4x8_reflect", 8, 256, 256, 4, 8, 3, 1, True), ("trunk_2048_4x8_reflect", 8, 2048, 2048, 4, 8, 3, 1, True),
                                   ("zero_pad_512_4x8", 8, 512, 512, 4, 8, 3, 1, False), ("ragged_rows_3x4x8", 3, 256, 256, 4, 8, 3, 1, True),
                                   ("bot_1x1_2048_512", 8, 2048, 512, 4, 8, 1, 0, False), ("bot_1x1_512_2048", 8, 512, 2048, 4, 8, 1, 0, False)],
