@@ -2379,10 +2379,10 @@ int smallc_fwd(const mg_conv_geom* g, const float* x, const float* w, const floa
     const SmallcWgradPlan p = smallc_wgrad_plan(g);     // the same staged rows
     const Geom gg = to_geom(g);
     const int rows = g->B * g->OH, cblocks = (g->Co + 63) / 64;
-    int rpw = 1;                                        // rows per workgroup: one workgroup per CU (260 VGPRs: one fits)
-    while ((long long)((rows + rpw - 1) / rpw) * cblocks > 256 && rpw < 8) ++rpw;
+    int rpw = 1;       // rows per workgroup (the weights' LDS image is paid once per workgroup): ~4 resident workgroups per CU (81 VGPRs, 40 KB)
+    while ((long long)((rows + rpw - 1) / rpw) * cblocks > 1024 && rpw < 8) ++rpw;
     const dim3 grid((unsigned)((rows + rpw - 1) / rpw), (unsigned)cblocks);
-    const size_t lds = p.lds + (size_t)64 * g->KH * g->KW * g->Ci * sizeof(float);
+    const size_t lds = p.lds + (size_t)64 * ((g->KH * g->KW * g->Ci) | 1) * sizeof(float);
     switch (smallc_fwd_kind(g)) {
     case 1: hipLaunchKernelGGL((conv_smallc_fwd_kernel<7, 7, 2, 1>), grid, dim3(256), lds, st, gg, x, w, bias, y, act, p.rowlen, rpw, (int)prec_h(g)); break;
     case 2: hipLaunchKernelGGL((conv_smallc_fwd_kernel<4, 4, 3, 2>), grid, dim3(256), lds, st, gg, x, w, bias, y, act, p.rowlen, rpw, (int)prec_h(g)); break;

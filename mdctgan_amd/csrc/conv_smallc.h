@@ -155,17 +155,22 @@ __global__ __launch_bounds__(KH * 64) void conv_smallc_wgrad_kernel(Geom g, cons
 // are staged once into LDS with the padding materialised (as in the weight gradient above), so the A fragment of
 // v_mfma_f32_32x32x2_f32 -- lane (pixel r, k parity h) needs patch(r)[2j + h] -- is ONE ds_read_b32 at
 // ky(k) * rowlen + ox * S * CI + kxci(k), consecutive pixels -> consecutive banks; the B fragments (w[co][2j + h], K / 2 per
-// 32-channel block) come through LDS once and live in registers for all the rows a workgroup does (rows_per_wg consecutive
-// ones, so that their cost is spread).  A wave takes 32-pixel blocks of the row, 64 output channels each.
+// 32-channel block) sit in LDS for all the rows a workgroup does (rows_per_wg consecutive ones, so that staging them is spread)
+// and are read beside the A fragment.  A wave takes 32-pixel blocks of the row, 64 output channels each.
+// The B fragments are read from LDS inside the loop (round 6).  Holding them in 2 x K/2 registers (rounds 4-5) needed ~260 VGPRs:
+// ONE workgroup -- one wave per SIMD -- fitted a CU, and the matrix pipe idled through every staging barrier and store burst
+// (0.37 of the f32 peak at the inference batch).  From LDS (row pitch K | 1: conflict-free) a wave needs 81, four workgroups are
+// resident and cover each other's gaps: 460 -> 358 us at batch 64, 65 -> 51 us at batch 8; the same MFMA sequence on the same
+// operands, so the same bits.
 template <int KH, int KW, int CI, int S>
-__global__ __launch_bounds__(256) void conv_smallc_fwd_kernel(Geom g, const float* __restrict__ x,
-                                                              const float* __restrict__ w, const float* __restrict__ bias,
-                                                              float* __restrict__ y, int act, int rowlen, int rows_per_wg,
-                                                              int hp) {
-    constexpr int KWC = KW * CI, K = KH * KWC, KP = K / 2;
-    static_assert(K % 2 == 0, "k pairs");
+__global__ __launch_bounds__(256, 3) void conv_smallc_fwd_kernel(Geom g, const float* __restrict__ x,
+                                                                 const float* __restrict__ w, const float* __restrict__ bias,
+                                                                 float* __restrict__ y, int act, int rowlen, int rows_per_wg,
+                                                                 int hp) {
+    constexpr int KWC = KW * CI, K = KH * KWC, KS = K | 1, KWC2 = KWC / 2;
+    static_assert(K % 2 == 0 && KWC % 2 == 0, "k pairs never straddle a filter row");
     extern __shared__ __attribute__((aligned(16))) float xs_smallc[];
-    float* wl = xs_smallc + KH * rowlen;            // [64][K] weights of this channel block
+    float* wl = xs_smallc + KH * rowlen;            // [64][KS] weights of this channel block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int co0 = blockIdx.y * 64;
@@ -180,24 +185,16 @@ __global__ __launch_bounds__(256) void conv_smallc_fwd_kernel(Geom g, const floa
             if (e < W2) {
                 float2 v = wsrc[e];
                 if (hp) { v.x = round_h(v.x); v.y = round_h(v.y); }
-                reinterpret_cast<float2*>(wl)[e] = v;
+                const int co = (2 * e) / K, k = 2 * e - co * K;
+                wl[co * KS + k] = v.x;
+                wl[co * KS + k + 1] = v.y;
             }
         }
     }
-    // LDS offset of k = 2 j + h for this lane's k parity
-    int koff[KP];
-#pragma unroll
-    for (int j = 0; j < KP; ++j) {
-        const int k = 2 * j + h, ky = k / KWC;
-        koff[j] = ky * rowlen + (k - ky * KWC);
-    }
     __syncthreads();
-    // B fragments: w[co0 + 32 nb + r][2 j + h], in registers for every row this workgroup does
-    float bw[2][KP];
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int j = 0; j < KP; ++j) bw[nb][j] = wl[(32 * nb + r) * K + 2 * j + h];
+    // B fragments of this lane: w[co0 + 32 nb + r][2 j + h]
+    const float* wb0 = wl + r * KS + h;
+    const float* wb1 = wl + (32 + r) * KS + h;
     const float bv0 = (bias && co0 + r < g.Co) ? bias[co0 + r] : 0.0f;
     const float bv1 = (bias && co0 + 32 + r < g.Co) ? bias[co0 + 32 + r] : 0.0f;
     const int nblk = (g.OW + 31) / 32;
@@ -242,11 +239,31 @@ __global__ __launch_bounds__(256) void conv_smallc_fwd_kernel(Geom g, const floa
             const int ox = min(32 * mb + r, g.OW - 1);
             const float* ap = xs_smallc + ox * (S * CI);
             f32x16 acc0 = f32x16{0}, acc1 = f32x16{0};
+            {
+                // A fragment: lane (pixel r, k parity h) needs patch(r)[2 j + h] = filter row j / (KWC / 2), position 2 (j % (KWC / 2)) + h.
+                // One filter row (KWC / 2 k pairs) per trip: its A and B values are in flight together and the next row's are not
+                // hoisted above this row's MFMAs (fully unrolled, the compiler loads all 3 K / 2 values first and spills).
+                const float* arow = ap + h;
+                const float* b0 = wb0;
+                const float* b1 = wb1;
+#pragma unroll 1
+                for (int ky = 0; ky < KH; ++ky) {
+                    float av[KWC2], bv[2][KWC2];
 #pragma unroll
-            for (int j = 0; j < KP; ++j) {
-                const float a = ap[koff[j]];
-                acc0 = mfma32x32x2(a, bw[0][j], acc0);
-                acc1 = mfma32x32x2(a, bw[1][j], acc1);
+                    for (int jj = 0; jj < KWC2; ++jj) {
+                        av[jj] = arow[2 * jj];
+                        bv[0][jj] = b0[2 * jj];
+                        bv[1][jj] = b1[2 * jj];
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < KWC2; ++jj) {
+                        acc0 = mfma32x32x2(av[jj], bv[0][jj], acc0);
+                        acc1 = mfma32x32x2(av[jj], bv[1][jj], acc1);
+                    }
+                    arow += rowlen;
+                    b0 += KWC;
+                    b1 += KWC;
+                }
             }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
