@@ -1137,8 +1137,19 @@ __global__ void colsum_partial_kernel(const float* __restrict__ a, long long M, 
     const long long m_begin = (long long)blockIdx.y * rows_per_split;
     const long long m_end = min(M, m_begin + rows_per_split);
     float s = 0.0f;
-    if (c < C)
-        for (long long m = m_begin + rg; m < m_end; m += 4) s += a[m * C + c];
+    if (c < C) {
+        // eight rows per trip: their loads are in flight together (one 4-byte load per thread and trip is pure latency); the
+        // additions keep the row order -- the same bits
+        long long m = m_begin + rg;
+        for (; m + 28 < m_end; m += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = a[(m + 4 * u) * C + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; m < m_end; m += 4) s += a[m * C + c];
+    }
     red[rg][threadIdx.x & 63] = s;
     __syncthreads();
     if (rg == 0 && c < C) {
