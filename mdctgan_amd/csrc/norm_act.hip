@@ -272,25 +272,16 @@ __global__ __launch_bounds__(256) void norm_apply_rows_kernel(const float* __res
     }
     const int p0 = blockIdx.z * rows_per_split, p1 = min(HW, p0 + rows_per_split);
     const size_t base = (size_t)b * HW * C + c;
-    for (int p = p0 + rg; p < p1; p += 16) {
-        const size_t i = base + (size_t)p * C;
-        const float4 v = *reinterpret_cast<const float4*>(x + i);
+    auto one = [&](size_t i, const float4 v, float4 g, const float4 r) {
         float4 o;
         if (!BWD) {
             o.x = act_fwd((v.x - mu.x) * rs.x, act);
             o.y = act_fwd((v.y - mu.y) * rs.y, act);
             o.z = act_fwd((v.z - mu.z) * rs.z, act);
             o.w = act_fwd((v.w - mu.w) * rs.w, act);
-            if (residual) {
-                const float4 r = *reinterpret_cast<const float4*>(residual + i);
-                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-            }
+            if (residual) { o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
         } else {
-            float4 g = *reinterpret_cast<const float4*>(dy + i);
-            if (dy2) {
-                const float4 e = *reinterpret_cast<const float4*>(dy2 + i);
-                g.x += e.x; g.y += e.y; g.z += e.z; g.w += e.w;
-            }
+            if (dy2) { g.x += r.x; g.y += r.y; g.z += r.z; g.w += r.w; }
             const float xh0 = (v.x - mu.x) * rs.x, xh1 = (v.y - mu.y) * rs.y, xh2 = (v.z - mu.z) * rs.z, xh3 = (v.w - mu.w) * rs.w;
             const float g0 = g.x * act_grad_pre(xh0, act), g1 = g.y * act_grad_pre(xh1, act);
             const float g2 = g.z * act_grad_pre(xh2, act), g3 = g.w * act_grad_pre(xh3, act);
@@ -301,6 +292,29 @@ __global__ __launch_bounds__(256) void norm_apply_rows_kernel(const float* __res
         }
         *reinterpret_cast<float4*>(out + i) = o;
         if (out16) *reinterpret_cast<h16x4*>(out16 + i) = h16x4{(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
+    };
+    // r: the residual (forward) / the second gradient dy2 (backward)
+    const float* third = BWD ? dy2 : residual;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // four pixel rows per trip: their loads are in flight together (elementwise: the same bits as a row per trip)
+    constexpr int U = 4;
+    int p = p0 + rg;
+    for (; p + (U - 1) * 16 < p1; p += U * 16) {
+        float4 v[U], g[U], r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i = base + (size_t)(p + 16 * u) * C;
+            v[u] = *reinterpret_cast<const float4*>(x + i);
+            g[u] = BWD ? *reinterpret_cast<const float4*>(dy + i) : z4;
+            r[u] = third ? *reinterpret_cast<const float4*>(third + i) : z4;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) one(base + (size_t)(p + 16 * u) * C, v[u], g[u], r[u]);
+    }
+    for (; p < p1; p += 16) {
+        const size_t i = base + (size_t)p * C;
+        one(i, *reinterpret_cast<const float4*>(x + i), BWD ? *reinterpret_cast<const float4*>(dy + i) : z4,
+            third ? *reinterpret_cast<const float4*>(third + i) : z4);
     }
 }
 // row splits so that the launch has ~4096 workgroups (16 rows per pass and block: at least 16 rows per split)
