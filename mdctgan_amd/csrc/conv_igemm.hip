@@ -1098,7 +1098,15 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, int S, size
     const size_t n4 = n / 4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 s = zero4();
-        for (int z = 0; z < S; ++z) add4(s, ld4(part + (size_t)z * n + 4 * i));
+        int z = 0;
+        for (; z + 3 < S; z += 4) {          // four slabs per trip in flight; added in slab order (the same bits)
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = ld4(part + (size_t)(z + u) * n + 4 * i);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) add4(s, v[u]);
+        }
+        for (; z < S; ++z) add4(s, ld4(part + (size_t)z * n + 4 * i));
         if (accumulate) add4(s, ld4(out + 4 * i));
         *reinterpret_cast<float4*>(out + 4 * i) = s;
     }
@@ -1119,7 +1127,15 @@ __global__ void splitk_epilogue_kernel(const float* __restrict__ part, int S, si
     const size_t n4 = n / 4;   // launcher guarantees N % 4 == 0
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 s = zero4();
-        for (int z = 0; z < S; ++z) add4(s, ld4(part + (size_t)z * n + 4 * i));
+        int z = 0;
+        for (; z + 3 < S; z += 4) {          // four slabs per trip in flight; added in slab order (the same bits)
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = ld4(part + (size_t)(z + u) * n + 4 * i);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) add4(s, v[u]);
+        }
+        for (; z < S; ++z) add4(s, ld4(part + (size_t)z * n + 4 * i));
         if (bias) add4(s, ld4(bias + (4 * i) % N));
         s.x = apply_act(s.x, act); s.y = apply_act(s.y, act); s.z = apply_act(s.z, act); s.w = apply_act(s.w, act);
         if (round_f16) { s.x = round_h(s.x); s.y = round_h(s.y); s.z = round_h(s.z); s.w = round_h(s.w); }
