@@ -175,7 +175,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         vv[j * ld + dd] = base[(size_t)j * 3 * HD + 2 * HD + h * d + dd];
     }
     __syncthreads();
-    for (int i = wave; i < n; i += 4) {              // query i handled by one wave
+    // gridDim.y workgroups share a (sample, head): each stages K / V for itself and takes every gridDim.y-th group of four queries
+    for (int i = 4 * blockIdx.y + wave; i < n; i += 4 * gridDim.y) {              // query i handled by one wave
         for (int dd = lane; dd < d; dd += 64) qs[wave * d + dd] = base[(size_t)i * 3 * HD + h * d + dd] * scale;
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void attn_bwd_a_kernel(const float* __restrict
         vv[j * ld + dd] = base[(size_t)j * 3 * HD + 2 * HD + h * d + dd];
     }
     __syncthreads();
-    for (int i = wave; i < n; i += 4) {              // row i of dS
+    for (int i = 4 * blockIdx.y + wave; i < n; i += 4 * gridDim.y) {              // row i of dS
         float dp[2], pv[2], dot = 0.0f;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void attn_bwd_a_kernel(const float* __restrict
         }
     }
     // dV[j][dd] = sum_i P[i][j] dO[i][dd]
-    for (int idx = threadIdx.x; idx < n * d; idx += 256) {
+    for (int idx = 256 * blockIdx.y + threadIdx.x; idx < n * d; idx += 256 * gridDim.y) {
         const int j = idx / d, dd = idx % d;
         float a = 0.0f;
         for (int i = 0; i < n; ++i) a = fmaf(Pb[(size_t)i * n + j], dos[i * ld + dd], a);
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256) void attn_bwd_b_kernel(const float* __restrict
         qq[j * ld + dd] = base[(size_t)j * 3 * HD + h * d + dd] * scale;
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < n * d; idx += 256) {
+    for (int idx = 256 * blockIdx.y + threadIdx.x; idx < n * d; idx += 256 * gridDim.y) {
         const int i = idx / d, dd = idx % d;
         float aq = 0.0f, ak = 0.0f;
         for (int j = 0; j < n; ++j) {
@@ -383,6 +384,14 @@ int mg_batchnorm_bwd(const float* dy, const float* x, const float* y, int R, int
     return MG_OK;
 }
 
+// Workgroups per (sample, head): the kernels are a few microseconds of serial VALU work per query / output element, and B x heads
+// (64 at the bench's batch) workgroups leave three quarters of the chip idle -- split the queries / outputs over up to n / 4 groups
+// until ~256 workgroups exist.  Every output element is computed by the same instructions as before: the same bits.
+static unsigned attn_groups(int BH, int n) {
+    int g = (256 + BH - 1) / BH;
+    if (g > n / 4) g = n / 4;
+    return (unsigned)(g < 1 ? 1 : g);
+}
 static size_t attn_lds(int n, int d, bool fwd) {
     return ((size_t)2 * n * (d + 1) + (fwd ? 4 * n + 4 * d : 0)) * sizeof(float);
 }
@@ -398,7 +407,7 @@ int mg_attention_fwd(const float* qkv, const float* emb_h, const float* emb_w, i
         hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         granted = lds;
     }
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, qkv, emb_h, emb_w, n, fw,
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * heads, attn_groups(B * heads, n)), dim3(256), lds, (hipStream_t)stream, qkv, emb_h, emb_w, n, fw,
                        heads, d, 1.0f / sqrtf((float)d), out, P);
     MG_CHECK_LAUNCH();
     return MG_OK;
@@ -426,8 +435,8 @@ int mg_attention_bwd(const float* qkv, const float* emb_h, const float* emb_w, c
         hipFuncSetAttribute((const void*)attn_bwd_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         granted = lds;
     }
-    hipLaunchKernelGGL(attn_bwd_a_kernel, dim3(B * heads), dim3(256), lds, st, qkv, dout, P, n, heads, d, dqkv, dS);
-    hipLaunchKernelGGL(attn_bwd_b_kernel, dim3(B * heads), dim3(256), lds, st, qkv, emb_h, emb_w, (const float*)dS, n, fw,
+    hipLaunchKernelGGL(attn_bwd_a_kernel, dim3(B * heads, attn_groups(B * heads, n)), dim3(256), lds, st, qkv, dout, P, n, heads, d, dqkv, dS);
+    hipLaunchKernelGGL(attn_bwd_b_kernel, dim3(B * heads, attn_groups(B * heads, n)), dim3(256), lds, st, qkv, emb_h, emb_w, (const float*)dS, n, fw,
                        heads, d, 1.0f / sqrtf((float)d), dqkv, dE);
     if (demb_h && demb_w)
         hipLaunchKernelGGL(posemb_grad_kernel, dim3(fh + fw), dim3(1024), 0, st, (const float*)dE, B * heads, fh, fw, d, demb_h,
